@@ -1,0 +1,116 @@
+/*
+ * coattn.h -- C-ABI of the MI355X (gfx950) Hierarchical Parallel Co-Attention path.
+ *
+ * Drop-in boundary.  The reference exposes no FFI: its boundary is the
+ * Python nn.Module surface
+ *     ParallelCoAttention.forward(x_img[B,N,d], 3 x x_ques[B,T,d]) -> (3 x v[B,d], 3 x q[B,d])
+ *     (/root/reference/model.py:356-397, constructed model.py:167, called model.py:182)
+ * with backward = autograd of model.py:372-392 (triggered at main.py:219-220).  This library
+ * is what a ctypes binding behind that surface calls: coattn_forward replaces the forward
+ * loop (model.py:372-395), coattn_backward replaces its autograd graph.  See INTEGRATION.md
+ * for the reference-side stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (torch tensor.data_ptr()) unless marked "host";
+ *   - the caller owns every buffer, including `saved` and `ws` (sizes: coattn_workspace_bytes);
+ *   - calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream), re-entrant and thread-agnostic (backward runs on the autograd thread);
+ *   - return 0 on success, < 0 on error (never throws); coattn_last_error() returns the
+ *     calling thread's last message;
+ *   - math is fp32 (dtype = COATTN_F32), row-vector convention Linear(x) = x W^T + b.
+ *
+ * Layouts
+ *   V      : [B, d, N]  channel-major image features = the physical buffer behind the
+ *            reference's permuted view x_img[B,N,d] (model.py:215-217): strides (d*N, 1, N).
+ *   Q[l]   : [B, T, d]  contiguous, l = 0..L-1 (word, phrase, sentence; model.py:298).
+ *   W_v,W_q: [d, d] (nn.Linear.weight, out x in); b_v,b_q: [d]; w_v,w_q: [d]; c_v,c_q: [1]
+ *            (model.py:350-354).  W_b (model.py:347) is dead in the reference and not passed.
+ *   v_out,q_out,gv,gq : [L, B, d].
+ */
+#ifndef COATTN_H
+#define COATTN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COATTN_F32 0
+
+/* impl selector (flags & 3): 0 = auto (fused kernels when the shape allows, else general),
+ * 1 = general-shape kernels (MFMA GEMM composition), 2 = fused kernels (error if unsupported). */
+#define COATTN_IMPL_AUTO 0
+#define COATTN_IMPL_GENERAL 1
+#define COATTN_IMPL_FUSED 2
+
+typedef struct coattn_params {
+  const void* W_v; const void* b_v;   /* model.py:350 */
+  const void* W_q; const void* b_q;   /* model.py:351 */
+  const void* w_v; const void* c_v;   /* model.py:353 */
+  const void* w_q; const void* c_q;   /* model.py:354 */
+} coattn_params;
+
+typedef struct coattn_param_grads {
+  void* dW_v; void* db_v; void* dW_q; void* db_q;
+  void* dw_v; void* dc_v; void* dw_q; void* dc_q;
+} coattn_param_grads;
+
+/* library version: major*10000 + minor*100 + patch */
+int coattn_version(void);
+
+/* last error message of the calling thread ("" if none) */
+const char* coattn_last_error(void);
+
+/* 1 if a fused-kernel configuration exists for this shape, else 0 */
+int coattn_fused_supported(int B, int N, int T, int d, int L, int dtype);
+
+/* Buffer sizes in bytes.  saved: forward -> backward state (P_v, P_q, C, a_v, a_q, H_q);
+ * ws_fwd / ws_bwd: scratch, contents undefined after the call. */
+int coattn_workspace_bytes(int B, int N, int T, int d, int L, int dtype, int flags,
+                           size_t* saved, size_t* ws_fwd, size_t* ws_bwd);
+
+/* Forward of model.py:372-395 for all L levels.
+ *   Q      : host array of L device pointers.
+ *   saved  : NULL for inference (nothing kept), else a buffer of `saved` bytes.
+ *   v_out,q_out : [L,B,d]. */
+int coattn_forward(const void* V, const void* const* Q, const coattn_params* p,
+                   void* v_out, void* q_out, void* saved, void* ws,
+                   int B, int N, int T, int d, int L, int dtype, int flags, void* stream);
+
+/* Backward (autograd of model.py:372-392).
+ *   gv,gq : [L,B,d] upstream gradients of v_out,q_out.
+ *   dV    : [B,d,N] (overwritten), or NULL when the image features need no gradient (frozen
+ *           encoder, model.py:239-241);  dQ : host array of L device pointers [B,T,d] (overwritten).
+ *   pg    : parameter gradients; accumulate = 0 overwrites, 1 adds into them (grads of the
+ *           three levels are always summed: one weight set is shared, model.py:167, :372). */
+int coattn_backward(const void* V, const void* const* Q, const coattn_params* p,
+                    const void* saved, const void* gv, const void* gq,
+                    void* dV, void* const* dQ, const coattn_param_grads* pg, int accumulate,
+                    void* ws, int B, int N, int T, int d, int L, int dtype, int flags, void* stream);
+
+/* ---- building blocks (exported for the per-kernel parity tests) ------------------------ */
+
+/* Strided, batched fp32 GEMM on the f32 MFMA:
+ *   C[z](m,n) = act( sum_{i<inner} sum_k A[z,i](m,k) * B[z,i](k,n) + bias_n[n] + bias_m[m]
+ *                    + beta * Cin[z](m,n) )
+ * Row m of A / C / Cin lives at (m / mdiv) * sdiv + (m % mdiv) * sm (mdiv = 0: plain m * sm).
+ * ksplit > 0: batch index z selects the k range [z*ksplit, min(K,(z+1)*ksplit)) instead. */
+typedef struct coattn_gemm_desc {
+  const void* A; const void* B; const void* Cin; void* C;
+  const void* bias_n; const void* bias_m;
+  int M, N, K, batch, inner, inner_total, ksplit, act; /* act: 0 none, 1 tanh */
+  float beta;
+  int64_t a_sm, a_sk, a_sz, a_si, a_mdiv, a_sdiv;
+  int64_t b_sk, b_sn, b_sz, b_si;
+  int64_t c_sm, c_sn, c_sz, c_mdiv, c_sdiv;
+  int64_t cin_sm, cin_sn, cin_sz, cin_mdiv, cin_sdiv;
+} coattn_gemm_desc;
+
+int coattn_gemm_f32(const coattn_gemm_desc* g, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COATTN_H */

@@ -1,0 +1,78 @@
+"""GPU-side test helper: run the C-ABI forward/backward directly (ctypes) on CUDA tensors and
+return every output plus the saved forward state, parsed with the layout of csrc/api.hip."""
+import ctypes as C
+
+import torch
+
+import vqa_amd
+from vqa_amd import _lib
+
+IMPL = {"general": _lib.IMPL_GENERAL, "fused": _lib.IMPL_FUSED, "auto": _lib.IMPL_AUTO}
+
+
+def _al64(n):
+    return (n + 63) & ~63
+
+
+def saved_views(saved, B, N, T, d, L):
+    o = 0
+    out = {}
+    for name, shape in (("P_v", (B, N, d)), ("P_q", (L, B, T, d)), ("C", (L, B, T, N)), ("a_v", (L, B, N)),
+                        ("a_q", (L, B, T)), ("H_q", (L, B, T, d))):
+        n = 1
+        for s in shape:
+            n *= s
+        out[name] = saved[o:o + n].view(*shape)
+        o += _al64(n)
+    return out
+
+
+def run_hip(V, Qs, P, gv=None, gq=None, impl="general", need_dv=True, accumulate=0, grads_init=None):
+    """V [B,d,N], Qs list of [B,T,d], P dict of reference-named params (CPU or CUDA tensors).
+    Returns dict with v,q and saved state; with gv/gq also all gradients."""
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    V = V.to(dev).contiguous()
+    Qs = [q.to(dev).contiguous() for q in Qs]
+    names = ("W_v.weight", "W_v.bias", "W_q.weight", "W_q.bias", "w_v.weight", "w_v.bias", "w_q.weight", "w_q.bias")
+    ps = [P[k].to(dev).contiguous() for k in names]
+    B, d, N = V.shape
+    T = Qs[0].shape[1]
+    L = len(Qs)
+    flag = IMPL[impl]
+    sb, fb, bb = _lib.workspace_bytes(B, N, T, d, L, flag)
+    v = torch.full((L, B, d), float("nan"), device=dev)
+    q = torch.full((L, B, d), float("nan"), device=dev)
+    saved = torch.full((sb // 4,), float("nan"), device=dev)
+    ws = torch.full((fb // 4,), float("nan"), device=dev)
+    qptr = (C.c_void_p * L)(*[t.data_ptr() for t in Qs])
+    p = _lib.Params(*[t.data_ptr() for t in ps])
+    stream = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.coattn_forward(V.data_ptr(), qptr, C.byref(p), v.data_ptr(), q.data_ptr(), saved.data_ptr(),
+                                  ws.data_ptr(), B, N, T, d, L, _lib.F32, flag, C.c_void_p(stream)), "coattn_forward")
+    torch.cuda.synchronize()
+    out = {"v": v, "q": q}
+    out.update(saved_views(saved, B, N, T, d, L))
+    if gv is None:
+        return out
+    gv = gv.to(dev).contiguous()
+    gq = gq.to(dev).contiguous()
+    ws2 = torch.full((bb // 4,), float("nan"), device=dev)
+    dV = torch.full_like(V, float("nan")) if need_dv else None
+    dQs = [torch.full_like(t, float("nan")) for t in Qs]
+    if grads_init is None:
+        grads = [torch.full_like(t, float("nan")) for t in ps]
+    else:
+        grads = [g.to(dev).clone() for g in grads_init]
+    pg = _lib.ParamGrads(*[t.data_ptr() for t in grads])
+    dqptr = (C.c_void_p * L)(*[t.data_ptr() for t in dQs])
+    _lib.check(lib.coattn_backward(V.data_ptr(), qptr, C.byref(p), saved.data_ptr(), gv.data_ptr(), gq.data_ptr(),
+                                   dV.data_ptr() if need_dv else None, dqptr, C.byref(pg), accumulate,
+                                   ws2.data_ptr(), B, N, T, d, L, _lib.F32, flag, C.c_void_p(stream)),
+               "coattn_backward")
+    torch.cuda.synchronize()
+    out["dV_phys"] = dV
+    out["dQ"] = torch.stack(dQs)
+    for k, g in zip(names, grads):
+        out["d" + k] = g
+    return out

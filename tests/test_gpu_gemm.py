@@ -1,0 +1,85 @@
+"""GPU: the strided/batched MFMA GEMM building block (coattn_gemm_f32) against torch fp64."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _gemm(desc_kw, stream=None):
+    from vqa_amd import _lib
+    lib = _lib.load()
+    g = _lib.GemmDesc()
+    for k, v in desc_kw.items():
+        setattr(g, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    _lib.check(lib.coattn_gemm_f32(C.byref(g), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gemm")
+    torch.cuda.synchronize()
+
+
+def _rel(x, ref):
+    return ((x.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-9)).item()
+
+
+@pytest.mark.parametrize("M,N,K", [(26, 196, 512), (196, 512, 26), (130, 200, 70), (300, 96, 33), (5, 37, 96)])
+def test_gemm_plain_rowmajor(M, N, K):
+    torch.manual_seed(1)
+    A = torch.randn(M, K, device="cuda"); B = torch.randn(K, N, device="cuda")
+    Cm = torch.full((M, N), float("nan"), device="cuda")
+    _gemm(dict(A=A, B=B, C=Cm, M=M, N=N, K=K, batch=1, a_sm=K, a_sk=1, b_sk=N, b_sn=1, c_sm=N, c_sn=1))
+    assert _rel(Cm, A.double() @ B.double()) < 2e-6
+
+
+def test_gemm_transposed_operands_bias_beta_tanh():
+    torch.manual_seed(2)
+    M, N, K, Z = 70, 150, 45, 3
+    At = torch.randn(Z, K, M, device="cuda") * 0.2      # A(m,k) = At[z][k][m]
+    Bt = torch.randn(Z, N, K, device="cuda") * 0.2      # B(k,n) = Bt[z][n][k]
+    bn = torch.randn(N, device="cuda"); bm = torch.randn(M, device="cuda")
+    Cin = torch.randn(Z, M, N, device="cuda")
+    Cm = torch.full((Z, M, N), float("nan"), device="cuda")
+    _gemm(dict(A=At, B=Bt, Cin=Cin, C=Cm, bias_n=bn, bias_m=bm, M=M, N=N, K=K, batch=Z, act=1, beta=0.5,
+               a_sm=1, a_sk=M, a_sz=K * M, b_sk=1, b_sn=K, b_sz=N * K,
+               c_sm=N, c_sn=1, c_sz=M * N, cin_sm=N, cin_sn=1, cin_sz=M * N))
+    ref = torch.tanh(At.double().transpose(1, 2) @ Bt.double().transpose(1, 2) + bn.double() + bm.double()[:, None]
+                     + 0.5 * Cin.double())
+    assert (Cm.double() - ref).abs().max().item() < 2e-6
+
+
+def test_gemm_row_split_and_transposed_output():
+    """A rows addressed as (m / N) * d*N + (m % N): the channel-major V of model.py:215-217."""
+    torch.manual_seed(3)
+    B_, d, N = 3, 96, 37
+    V = torch.randn(B_, d, N, device="cuda"); W = torch.randn(d, d, device="cuda") / 10
+    bias = torch.randn(d, device="cuda")
+    Pv = torch.full((B_ * N, d), float("nan"), device="cuda")
+    _gemm(dict(A=V, B=W, C=Pv, bias_n=bias, M=B_ * N, N=d, K=d, batch=1, a_sm=1, a_sk=N, a_mdiv=N, a_sdiv=d * N,
+               b_sk=1, b_sn=d, c_sm=d, c_sn=1))
+    ref = V.double().permute(0, 2, 1).reshape(B_ * N, d) @ W.double().T + bias.double()
+    assert _rel(Pv, ref) < 2e-6
+    # output rows split the same way (writes a [B,d,N] buffer from a [B*N, d] product)
+    out = torch.full((B_, d, N), float("nan"), device="cuda")
+    _gemm(dict(A=Pv, B=W, C=out, M=B_ * N, N=d, K=d, batch=1, a_sm=d, a_sk=1, b_sk=d, b_sn=1,
+               c_sm=1, c_sn=N, c_mdiv=N, c_sdiv=d * N))
+    ref2 = (Pv.double() @ W.double()).reshape(B_, N, d).permute(0, 2, 1)
+    assert _rel(out, ref2) < 2e-6
+
+
+def test_gemm_inner_groups_and_ksplit():
+    torch.manual_seed(4)
+    B_, N, d = 7, 37, 64
+    dP = torch.randn(B_, N, d, device="cuda"); V = torch.randn(B_, d, N, device="cuda")
+    G = 3; S = (B_ + G - 1) // G
+    part = torch.full((S, d, d), float("nan"), device="cuda")
+    _gemm(dict(A=dP, B=V, C=part, M=d, N=d, K=N, batch=S, inner=G, inner_total=B_,
+               a_sm=1, a_sk=d, a_si=N * d, a_sz=G * N * d, b_sk=1, b_sn=N, b_si=d * N, b_sz=G * d * N,
+               c_sm=d, c_sn=1, c_sz=d * d))
+    ref = torch.einsum("bnj,bkn->jk", dP.double(), V.double())
+    assert _rel(part.sum(0), ref) < 2e-6
+    K = 200
+    A = torch.randn(K, d, device="cuda"); Bm = torch.randn(K, d, device="cuda")
+    ks = 48; S = (K + ks - 1) // ks
+    part = torch.full((S, d, d), float("nan"), device="cuda")
+    _gemm(dict(A=A, B=Bm, C=part, M=d, N=d, K=K, batch=S, ksplit=ks, a_sm=1, a_sk=d, b_sk=d, b_sn=1,
+               c_sm=d, c_sn=1, c_sz=d * d))
+    assert _rel(part.sum(0), A.double().T @ Bm.double()) < 2e-6

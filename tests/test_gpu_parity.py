@@ -1,0 +1,148 @@
+"""GPU parity (the tests proper): HIP path through the C-ABI vs the golden vectors produced by
+the imported reference (tests/golden, float64 run) and vs the CPU oracle on the same inputs.
+
+Tolerances (fp32, BASELINE.json north_star: 1e-4): forward outputs / attention maps absolute
+1e-4 (observed ~1e-6); gradients 1e-4 relative to the tensor's max magnitude."""
+import pytest
+import torch
+
+from oracle import coattn_oracle as O
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 1e-4
+GRAD_TOL = 1e-4
+
+
+def _impls(name):
+    import vqa_amd
+    c = G.CASES[name]
+    out = ["general"]
+    if vqa_amd._lib.load().coattn_fused_supported(c["B"], c["N"], c["T"], c["d"], 3, 0):
+        out.append("fused")
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(G.CASES))
+def test_forward_backward_vs_reference_golden(name):
+    from tests._hip import run_hip
+    gold = G.load(name)
+    V, Qs, P, gv, gq = G.build_case(name, torch.float32)
+    for impl in _impls(name):
+        r = run_hip(V, Qs, P, gv, gq, impl=impl)
+        for k, t in r.items():
+            assert torch.isfinite(t).all(), (impl, k)
+        fe = G.fwd_errors(r, gold, "64")
+        ge = G.grad_errors(r, gold, "64")
+        print(name, impl, "fwd", {k: "%.1e" % v for k, v in fe.items()}, "grad", {k: "%.1e" % v for k, v in ge.items()})
+        assert max(fe.values()) < FWD_TOL, (impl, fe)
+        assert max(ge.values()) < GRAD_TOL, (impl, ge)
+
+
+@pytest.mark.parametrize("impl", ["general", "fused"])
+def test_module_dropin_autograd(impl, monkeypatch):
+    """nn.Module surface (model.py:337-397): same state_dict keys, list-in/list-out, autograd; W_b dead."""
+    import vqa_amd
+    B, N, T, d = 4, 49, 26, 256
+    if impl == "fused" and not vqa_amd._lib.load().coattn_fused_supported(B, N, T, d, 3, 0):
+        pytest.skip("no fused configuration for this shape")
+    monkeypatch.setenv("COATTN_IMPL", impl)
+    torch.manual_seed(0)
+    ref = O.OracleParallelCoAttention(d, as_executed=True)
+    mod = vqa_amd.ParallelCoAttention(d)
+    assert list(mod.state_dict().keys()) == list(ref.state_dict().keys())
+    mod.load_state_dict(ref.state_dict())
+    mod = mod.cuda()
+    V, Qs = O.make_inputs(B, N, T, d, 9, lens=[26, 20, 5, 1], scale_q=(2.0 / d) ** 0.5)
+    x_img = V.permute(0, 2, 1)                              # the encoder's permuted view
+    x_ref = x_img.clone().requires_grad_(True)
+    Qr = [q.clone().requires_grad_(True) for q in Qs]
+    vs, qs = ref(x_ref, Qr)
+    x_gpu = V.cuda().permute(0, 2, 1).requires_grad_(True)
+    Qg = [q.cuda().requires_grad_(True) for q in Qs]
+    vg, qg = mod(x_gpu, Qg)
+    assert isinstance(vg, list) and len(vg) == 3 and vg[0].shape == (B, d)
+    w = [torch.randn(B, d) for _ in range(6)]
+    (sum((vs[l] * w[l]).sum() + (qs[l] * w[3 + l]).sum() for l in range(3))).backward()
+    (sum((vg[l] * w[l].cuda()).sum() + (qg[l] * w[3 + l].cuda()).sum() for l in range(3))).backward()
+    for l in range(3):
+        assert (vg[l].cpu() - vs[l]).abs().max() < FWD_TOL and (qg[l].cpu() - qs[l]).abs().max() < FWD_TOL
+
+    def rel(a, b):
+        return ((a.cpu() - b).abs().max() / b.abs().max().clamp_min(1e-6)).item()
+
+    assert rel(x_gpu.grad, x_ref.grad) < GRAD_TOL
+    for l in range(3):
+        assert rel(Qg[l].grad, Qr[l].grad) < GRAD_TOL
+    for (k, pg), (_, pr) in zip(mod.named_parameters(), ref.named_parameters()):
+        if k.startswith("W_b"):
+            assert pg.grad is None and pr.grad is None           # dead layer (model.py:347 vs :377)
+        elif k in ("w_v.bias", "w_q.bias"):
+            assert (pg.grad.cpu() - pr.grad).abs().max() < 1e-4  # analytically zero
+        else:
+            assert rel(pg.grad, pr.grad) < GRAD_TOL, k
+
+
+@pytest.mark.parametrize("impl", ["general", "fused"])
+def test_frozen_image_features_and_accumulate(impl):
+    """dV = NULL (frozen encoder, model.py:239-241) leaves the other gradients unchanged, and
+    accumulate=1 adds into the parameter gradients."""
+    import vqa_amd
+    from tests._hip import run_hip
+    name = "g5_d256"
+    c = G.CASES[name]
+    if impl == "fused" and not vqa_amd._lib.load().coattn_fused_supported(c["B"], c["N"], c["T"], c["d"], 3, 0):
+        pytest.skip("no fused configuration for this shape")
+    V, Qs, P, gv, gq = G.build_case(name, torch.float32)
+    a = run_hip(V, Qs, P, gv, gq, impl=impl)
+    b = run_hip(V, Qs, P, gv, gq, impl=impl, need_dv=False)
+    for k in G.GRAD_KEYS:
+        if k != "dV_phys":
+            assert torch.equal(a[k], b[k]), k
+    names = ("W_v.weight", "W_v.bias", "W_q.weight", "W_q.bias", "w_v.weight", "w_v.bias", "w_q.weight", "w_q.bias")
+    init = [torch.ones_like(P[k]) for k in names]
+    cacc = run_hip(V, Qs, P, gv, gq, impl=impl, accumulate=1, grads_init=init)
+    for k in names:
+        assert (cacc["d" + k] - (a["d" + k] + 1.0)).abs().max() < 1e-4 * max(1.0, a["d" + k].abs().max().item()), k
+
+
+@pytest.mark.parametrize("impl", ["general", "fused"])
+def test_full_size_cfg2_properties(impl):
+    """BASELINE config 2 (B=160, N=196, T=26, d=512): oracle on a sample subset + size-independent
+    properties (attention maps are distributions; v inside the range of V; per-sample independence;
+    backward linear in the upstream gradient)."""
+    import vqa_amd
+    from tests._hip import run_hip
+    B, N, T, d = 160, 196, 26, 512
+    if impl == "fused" and not vqa_amd._lib.load().coattn_fused_supported(B, N, T, d, 3, 0):
+        pytest.skip("no fused configuration for this shape")
+    lens = sorted([26] + [3 + (7 * i) % 24 for i in range(B - 1)], reverse=True)
+    P = O.make_params(d, 5)
+    V, Qs = O.make_inputs(B, N, T, d, 77, lens=lens, scale_q=(2.0 / d) ** 0.5)
+    gv = torch.from_numpy(O.hash_normal((3, B, d), 901)).float()
+    gq = torch.from_numpy(O.hash_normal((3, B, d), 902)).float()
+    r = run_hip(V, Qs, P, gv, gq, impl=impl)
+    assert (r["a_v"].sum(-1) - 1).abs().max() < 1e-5 and (r["a_q"].sum(-1) - 1).abs().max() < 1e-5
+    Vd = V.cuda()
+    assert (r["v"] <= Vd.max(2).values[None] + 1e-5).all() and (r["v"] >= Vd.min(2).values[None] - 1e-5).all()
+    # oracle on 3 samples of the batch (forward is per-sample independent)
+    idx = [0, 77, 159]
+    f = O.coattn_forward(V[idx], [q[idx] for q in Qs], P)
+    assert (r["v"][:, idx].cpu() - f["v"]).abs().max() < FWD_TOL
+    assert (r["q"][:, idx].cpu() - f["q"]).abs().max() < FWD_TOL
+    g = O.coattn_backward(V[idx], [q[idx] for q in Qs], P, gv[:, idx], gq[:, idx])
+    scale = g["dV_phys"].abs().max()
+    assert (r["dV_phys"][idx].cpu() - g["dV_phys"]).abs().max() / scale < GRAD_TOL
+    assert (r["dQ"][:, idx].cpu() - g["dQ"]).abs().max() / g["dQ"].abs().max() < GRAD_TOL
+    # linearity: backward(2*g) == 2*backward(g)
+    r2 = run_hip(V, Qs, P, 2 * gv, 2 * gq, impl=impl)
+    for k in ("dV_phys", "dQ", "dW_v.weight", "dW_q.weight", "dw_v.weight"):
+        assert (r2[k] - 2 * r[k]).abs().max() <= 2e-5 * max(1e-3, r[k].abs().max().item()), k
+    # full-batch parameter gradients vs the oracle (CPU, ~10 s)
+    gf = O.coattn_backward(V, Qs, P, gv, gq)
+    for k in O.PARAM_KEYS:
+        if k.endswith("w_v.bias") or k.endswith("w_q.bias"):
+            continue
+        ref = gf["d" + k]
+        assert (r["d" + k].cpu() - ref).abs().max() / ref.abs().max() < 2e-4, k

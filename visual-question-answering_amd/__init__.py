@@ -1,0 +1,12 @@
+"""MI355X-native Hierarchical Parallel Co-Attention path (drop-in for the reference's
+``--model attention`` hot path, /root/reference/model.py:337-397).
+
+Host side is Python on PyTorch-ROCm (device memory, streams, torch.distributed); the compute
+is a C-ABI HIP library (``include/coattn.h``, sources in ``csrc/``) loaded through ctypes.
+There is no CPU fallback: using the co-attention op without the HIP library or on CPU
+tensors raises.
+"""
+from . import _lib  # noqa: F401
+from .coattention import ParallelCoAttention, coattention  # noqa: F401
+
+__all__ = ["ParallelCoAttention", "coattention", "_lib"]

@@ -1,0 +1,88 @@
+"""ctypes binding of ``libcoattn_hip.so`` (C-ABI declared in ``include/coattn.h``)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcoattn_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+# every symbol include/coattn.h declares
+EXPORTS = ("coattn_version", "coattn_last_error", "coattn_fused_supported", "coattn_workspace_bytes",
+           "coattn_forward", "coattn_backward", "coattn_gemm_f32")
+
+F32 = 0
+IMPL_AUTO, IMPL_GENERAL, IMPL_FUSED = 0, 1, 2
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("W_v", "b_v", "W_q", "b_q", "w_v", "c_v", "w_q", "c_q")]
+
+
+class ParamGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("dW_v", "db_v", "dW_q", "db_q", "dw_v", "dc_v", "dw_q", "dc_q")]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in ("A", "B", "Cin", "C", "bias_n", "bias_m")]
+                + [(n, C.c_int) for n in ("M", "N", "K", "batch", "inner", "inner_total", "ksplit", "act")]
+                + [("beta", C.c_float)]
+                + [(n, C.c_int64) for n in ("a_sm", "a_sk", "a_sz", "a_si", "a_mdiv", "a_sdiv",
+                                            "b_sk", "b_sn", "b_sz", "b_si",
+                                            "c_sm", "c_sn", "c_sz", "c_mdiv", "c_sdiv",
+                                            "cin_sm", "cin_sn", "cin_sz", "cin_mdiv", "cin_sdiv")])
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", CSRC, "-j", "4"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout)
+    if r.returncode != 0:
+        raise RuntimeError("building libcoattn_hip.so failed")
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the library (after torch, so that the HIP runtime torch ships is the one bound)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  -- must be imported first: one HIP runtime per process
+
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the co-attention path)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise RuntimeError("libcoattn_hip.so lacks symbol %s" % name)
+    lib.coattn_version.restype = C.c_int
+    lib.coattn_last_error.restype = C.c_char_p
+    lib.coattn_fused_supported.argtypes = [C.c_int] * 6
+    lib.coattn_workspace_bytes.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_size_t)] * 3
+    lib.coattn_forward.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(Params), C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]
+    lib.coattn_backward.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(Params), C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(ParamGrads), C.c_int,
+                                    C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]
+    lib.coattn_gemm_f32.argtypes = [C.POINTER(GemmDesc), C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, load().coattn_last_error().decode()))
+
+
+def workspace_bytes(B, N, T, d, L, flags=0):
+    s, f, b = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    check(load().coattn_workspace_bytes(B, N, T, d, L, F32, flags, C.byref(s), C.byref(f), C.byref(b)),
+          "coattn_workspace_bytes")
+    return s.value, f.value, b.value

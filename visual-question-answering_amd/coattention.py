@@ -1,0 +1,131 @@
+"""``ParallelCoAttention``: drop-in for /root/reference/model.py:337-397 on MI355X.
+
+Same constructor, attribute names (=> identical ``state_dict`` keys ``W_b, W_v, W_q, w_v, w_q``)
+and ``forward(x_img, x_ques_hierarchy)`` signature as the reference class; the computation runs
+in the HIP library through the C-ABI of ``include/coattn.h`` on the caller's current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def _impl_flag() -> int:
+    return {"auto": _lib.IMPL_AUTO, "general": _lib.IMPL_GENERAL, "fused": _lib.IMPL_FUSED}[
+        os.environ.get("COATTN_IMPL", "auto")]
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _physical_v(x_img: torch.Tensor) -> torch.Tensor:
+    """[B,N,d] module input -> channel-major physical buffer [B,d,N] (no copy when x_img is the
+    permuted view the image encoder produces, model.py:215-217)."""
+    v = x_img.permute(0, 2, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+class _CoAttentionFn(torch.autograd.Function):
+    """forward -> coattn_forward, backward -> coattn_backward (autograd of model.py:372-392)."""
+
+    @staticmethod
+    def forward(ctx, x_img, W_v, b_v, W_q, b_q, w_v, c_v, w_q, c_q, impl, *x_ques):
+        if not x_img.is_cuda:
+            raise RuntimeError("ParallelCoAttention (HIP) needs tensors on the GPU; there is no CPU fallback")
+        if x_img.dtype != torch.float32:
+            raise RuntimeError("ParallelCoAttention (HIP) computes in fp32; got %s" % x_img.dtype)
+        lib = _lib.load()
+        L = len(x_ques)
+        B, N, d = x_img.shape
+        T = x_ques[0].shape[1]
+        for q in x_ques:
+            if tuple(q.shape) != (B, T, d):
+                raise RuntimeError("question features must all be [B,T,d] = %s, got %s" % ((B, T, d), tuple(q.shape)))
+        V = _physical_v(x_img)
+        Qs = [q.contiguous() for q in x_ques]
+        params = [t.contiguous() for t in (W_v, b_v, W_q, b_q, w_v, c_v, w_q, c_q)]
+        need_grad = any(ctx.needs_input_grad)
+        sb, fb, _ = _lib.workspace_bytes(B, N, T, d, L, impl)
+        dev = x_img.device
+        out_v = torch.empty((L, B, d), device=dev, dtype=torch.float32)
+        out_q = torch.empty((L, B, d), device=dev, dtype=torch.float32)
+        saved = torch.empty(sb // 4, device=dev, dtype=torch.float32) if need_grad else None
+        ws = torch.empty(fb // 4, device=dev, dtype=torch.float32)
+        qptr = (C.c_void_p * L)(*[q.data_ptr() for q in Qs])
+        p = _lib.Params(*[t.data_ptr() for t in params])
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(lib.coattn_forward(_ptr(V), qptr, C.byref(p), _ptr(out_v), _ptr(out_q), _ptr(saved), _ptr(ws),
+                                          B, N, T, d, L, _lib.F32, impl, C.c_void_p(stream)), "coattn_forward")
+        if need_grad:
+            ctx.save_for_backward(V, saved, *params, *Qs)
+            ctx.dims = (B, N, T, d, L, impl)
+        return out_v, out_q
+
+    @staticmethod
+    def backward(ctx, g_v, g_q):
+        lib = _lib.load()
+        B, N, T, d, L, impl = ctx.dims
+        sv = ctx.saved_tensors
+        V, saved, params, Qs = sv[0], sv[1], sv[2:10], sv[10:]
+        dev = V.device
+        g_v = g_v.contiguous() if g_v is not None else torch.zeros((L, B, d), device=dev)
+        g_q = g_q.contiguous() if g_q is not None else torch.zeros((L, B, d), device=dev)
+        _, _, bb = _lib.workspace_bytes(B, N, T, d, L, impl)
+        ws = torch.empty(bb // 4, device=dev, dtype=torch.float32)
+        need_dv = ctx.needs_input_grad[0]
+        dV = torch.empty_like(V) if need_dv else None
+        dQs = [torch.empty_like(q) for q in Qs]
+        grads = [torch.empty_like(t) for t in params]
+        pg = _lib.ParamGrads(*[t.data_ptr() for t in grads])
+        p = _lib.Params(*[t.data_ptr() for t in params])
+        qptr = (C.c_void_p * L)(*[q.data_ptr() for q in Qs])
+        dqptr = (C.c_void_p * L)(*[q.data_ptr() for q in dQs])
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(lib.coattn_backward(_ptr(V), qptr, C.byref(p), _ptr(saved), _ptr(g_v), _ptr(g_q), _ptr(dV),
+                                           dqptr, C.byref(pg), 0, _ptr(ws), B, N, T, d, L, _lib.F32, impl,
+                                           C.c_void_p(stream)), "coattn_backward")
+        d_img = dV.permute(0, 2, 1) if need_dv else None
+        return (d_img, *grads, None, *dQs)
+
+
+def coattention(x_img: torch.Tensor, x_ques: Sequence[torch.Tensor], W_v, b_v, W_q, b_q, w_v, c_v, w_q, c_q,
+                impl: int | None = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Functional form: returns (v, q), each [L,B,d]."""
+    if impl is None:
+        impl = _impl_flag()
+    return _CoAttentionFn.apply(x_img, W_v, b_v, W_q, b_q, w_v, c_v, w_q, c_q, impl, *x_ques)
+
+
+class ParallelCoAttention(nn.Module):
+    """Parallel co-attention over image and word/phrase/sentence question features.
+
+    Mirrors the reference class (model.py:337-397): ``W_b`` is constructed but never used
+    (model.py:347 vs :377) so it stays in the state_dict and never receives a gradient;
+    W_v/W_q/w_v/w_q are ``nn.Linear`` with biases; one weight set serves all levels; the
+    softmax over question positions is unmasked (model.py:388).
+    """
+
+    def __init__(self, hidden_dim: int):
+        super().__init__()
+        self.hidden_dim = hidden_dim
+        self.W_b = nn.Linear(hidden_dim, hidden_dim)     # dead in the reference's forward
+        self.W_v = nn.Linear(hidden_dim, hidden_dim)
+        self.W_q = nn.Linear(hidden_dim, hidden_dim)
+        self.w_v = nn.Linear(hidden_dim, 1)
+        self.w_q = nn.Linear(hidden_dim, 1)
+
+    def forward(self, x_img: torch.Tensor, x_ques_hierarchy: Sequence[torch.Tensor]) -> Tuple[List, List]:
+        """x_img [B,N,d]; x_ques_hierarchy: list of [B,T,d] -> (list of v_l [B,d], list of q_l [B,d])."""
+        v, q = coattention(x_img, list(x_ques_hierarchy), self.W_v.weight, self.W_v.bias, self.W_q.weight,
+                           self.W_q.bias, self.w_v.weight, self.w_v.bias, self.w_q.weight, self.w_q.bias)
+        n = v.shape[0]
+        return [v[l] for l in range(n)], [q[l] for l in range(n)]

@@ -1,0 +1,385 @@
+// C-ABI of the co-attention path (include/coattn.h): argument checking, workspace planning
+// and kernel orchestration.  No torch types, no allocation, no synchronisation: every call
+// only enqueues kernels on the caller's stream.
+#include "common.h"
+#include "fused.h"
+
+#include <string.h>
+
+// ---------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void coattn_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int coattn_version(void) { return 100; }
+extern "C" const char* coattn_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------------
+// buffer plans (in floats, every region aligned to 64 floats = 256 B)
+// ---------------------------------------------------------------------------------------
+static inline size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
+
+struct SavedPlan {
+  size_t Pv, Pq, C, av, aq, Hq, total;
+};
+static SavedPlan plan_saved(int B, int N, int T, int d, int L) {
+  SavedPlan p;
+  size_t o = 0;
+  p.Pv = o; o += al64((size_t)B * N * d);
+  p.Pq = o; o += al64((size_t)L * B * T * d);
+  p.C = o;  o += al64((size_t)L * B * T * N);
+  p.av = o; o += al64((size_t)L * B * N);
+  p.aq = o; o += al64((size_t)L * B * T);
+  p.Hq = o; o += al64((size_t)L * B * T * d);
+  p.total = o;
+  return p;
+}
+
+static const int kMaxSplits = 32;
+
+struct BwdPlan {
+  size_t Hv, dPv, dZq, dPq, dC, dav, dsv, daq, dsq, part, total;
+};
+static BwdPlan plan_bwd(int B, int N, int T, int d, int L) {
+  BwdPlan p;
+  size_t o = 0;
+  p.Hv = o;  o += al64((size_t)B * N * d);
+  p.dPv = o; o += al64((size_t)B * N * d);
+  p.dZq = o; o += al64((size_t)B * T * d);
+  p.dPq = o; o += al64((size_t)L * B * T * d);
+  p.dC = o;  o += al64((size_t)L * B * T * N);
+  p.dav = o; o += al64((size_t)L * B * N);
+  p.dsv = o; o += al64((size_t)L * B * N);
+  p.daq = o; o += al64((size_t)L * B * T);
+  p.dsq = o; o += al64((size_t)L * B * T);
+  size_t part = (size_t)kMaxSplits * d * d;
+  size_t cs = (size_t)260 * d;
+  p.part = o; o += al64(part > cs ? part : cs);
+  p.total = o;
+  return p;
+}
+
+static int check_shape(int B, int N, int T, int d, int L, int dtype) {
+  CA_CHECK_ARG(dtype == COATTN_F32, "unsupported dtype %d (only COATTN_F32)", dtype);
+  CA_CHECK_ARG(B > 0 && B <= 65535, "bad batch size B=%d", B);
+  CA_CHECK_ARG(N > 0 && N <= 4096 && T > 0 && T <= 4096, "bad N=%d / T=%d", N, T);
+  CA_CHECK_ARG(d > 0 && d <= 8192, "bad hidden size d=%d", d);
+  CA_CHECK_ARG(L > 0 && L <= 8, "bad number of levels L=%d", L);
+  return 0;
+}
+
+extern "C" int coattn_fused_supported(int B, int N, int T, int d, int L, int dtype) {
+  if (dtype != COATTN_F32) return 0;
+  return fused_supported(B, N, T, d, L);
+}
+
+extern "C" int coattn_workspace_bytes(int B, int N, int T, int d, int L, int dtype, int flags, size_t* saved,
+                                      size_t* ws_fwd, size_t* ws_bwd) {
+  (void)flags;
+  CA_TRY(check_shape(B, N, T, d, L, dtype));
+  const SavedPlan sp = plan_saved(B, N, T, d, L);
+  const BwdPlan bp = plan_bwd(B, N, T, d, L);
+  if (saved) *saved = sp.total * sizeof(float);
+  if (ws_fwd) *ws_fwd = (sp.total + al64((size_t)B * N * d)) * sizeof(float);
+  if (ws_bwd) *ws_bwd = bp.total * sizeof(float);
+  return 0;
+}
+
+extern "C" int coattn_gemm_f32(const coattn_gemm_desc* g, void* stream) {
+  CA_CHECK_ARG(g != nullptr, "gemm: null descriptor");
+  return launch_gemm_f32(*g, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------
+// general-shape implementation: MFMA GEMM composition
+// ---------------------------------------------------------------------------------------
+namespace {
+
+struct Ctx {
+  int B, N, T, d, L;
+  hipStream_t s;
+};
+
+// P_v = V W_v^T + b_v   (model.py:380/384, evaluated once per sample)
+int proj_v(const Ctx& c, const float* V, const float* Wv, const float* bv, float* Pv) {
+  coattn_gemm_desc g = {};
+  g.A = V; g.B = Wv; g.C = Pv; g.bias_n = bv;
+  g.M = c.B * c.N; g.N = c.d; g.K = c.d; g.batch = 1;
+  g.a_sm = 1; g.a_sk = c.N; g.a_mdiv = c.N; g.a_sdiv = (int64_t)c.d * c.N;
+  g.b_sk = 1; g.b_sn = c.d;
+  g.c_sm = c.d; g.c_sn = 1;
+  return launch_gemm_f32(g, c.s);
+}
+// P_q = Q W_q^T + b_q   (model.py:381/383)
+int proj_q(const Ctx& c, const float* Q, const float* Wq, const float* bq, float* Pq) {
+  coattn_gemm_desc g = {};
+  g.A = Q; g.B = Wq; g.C = Pq; g.bias_n = bq;
+  g.M = c.B * c.T; g.N = c.d; g.K = c.d; g.batch = 1;
+  g.a_sm = c.d; g.a_sk = 1;
+  g.b_sk = 1; g.b_sn = c.d;
+  g.c_sm = c.d; g.c_sn = 1;
+  return launch_gemm_f32(g, c.s);
+}
+// C = tanh(Q V)   (model.py:377)
+int affinity(const Ctx& c, const float* Q, const float* V, float* C) {
+  coattn_gemm_desc g = {};
+  g.A = Q; g.a_sz = (int64_t)c.T * c.d; g.a_sm = c.d; g.a_sk = 1;
+  g.B = V; g.b_sz = (int64_t)c.d * c.N; g.b_sk = c.N; g.b_sn = 1;
+  g.C = C; g.c_sz = (int64_t)c.T * c.N; g.c_sm = c.N; g.c_sn = 1;
+  g.M = c.T; g.N = c.N; g.K = c.d; g.batch = c.B; g.act = 1;
+  return launch_gemm_f32(g, c.s);
+}
+// out = act(X + C^T Y): X,out [B,N,d], Y [B,T,d]   (H_v, model.py:380-381; dP_v in backward)
+int ct_times(const Ctx& c, const float* C, const float* Y, const float* X, float* out, int act) {
+  coattn_gemm_desc g = {};
+  g.A = C; g.a_sz = (int64_t)c.T * c.N; g.a_sm = 1; g.a_sk = c.N;
+  g.B = Y; g.b_sz = (int64_t)c.T * c.d; g.b_sk = c.d; g.b_sn = 1;
+  g.Cin = X; g.cin_sz = (int64_t)c.N * c.d; g.cin_sm = c.d; g.cin_sn = 1; g.beta = 1.f;
+  g.C = out; g.c_sz = (int64_t)c.N * c.d; g.c_sm = c.d; g.c_sn = 1;
+  g.M = c.N; g.N = c.d; g.K = c.T; g.batch = c.B; g.act = act;
+  return launch_gemm_f32(g, c.s);
+}
+// out = act(X + C Y): X,out [B,T,d], Y [B,N,d]   (H_q, model.py:383-384; dP_q in backward)
+int c_times(const Ctx& c, const float* C, const float* Y, const float* X, float* out, int act) {
+  coattn_gemm_desc g = {};
+  g.A = C; g.a_sz = (int64_t)c.T * c.N; g.a_sm = c.N; g.a_sk = 1;
+  g.B = Y; g.b_sz = (int64_t)c.N * c.d; g.b_sk = c.d; g.b_sn = 1;
+  g.Cin = X; g.cin_sz = (int64_t)c.T * c.d; g.cin_sm = c.d; g.cin_sn = 1; g.beta = 1.f;
+  g.C = out; g.c_sz = (int64_t)c.T * c.d; g.c_sm = c.d; g.c_sn = 1;
+  g.M = c.T; g.N = c.d; g.K = c.N; g.batch = c.B; g.act = act;
+  return launch_gemm_f32(g, c.s);
+}
+
+int forward_general(const Ctx& c, const float* V, const float* const* Q, const coattn_params* p, float* v_out,
+                    float* q_out, float* sv, float* Hv) {
+  const SavedPlan sp = plan_saved(c.B, c.N, c.T, c.d, c.L);
+  float* Pv = sv + sp.Pv;
+  const size_t BTd = (size_t)c.B * c.T * c.d, BTN = (size_t)c.B * c.T * c.N;
+  CA_TRY(proj_v(c, V, (const float*)p->W_v, (const float*)p->b_v, Pv));
+  for (int l = 0; l < c.L; ++l)
+    CA_TRY(proj_q(c, Q[l], (const float*)p->W_q, (const float*)p->b_q, sv + sp.Pq + l * BTd));
+  for (int l = 0; l < c.L; ++l) {
+    float* Pq = sv + sp.Pq + l * BTd;
+    float* C = sv + sp.C + l * BTN;
+    float* Hq = sv + sp.Hq + l * BTd;
+    float* av = sv + sp.av + (size_t)l * c.B * c.N;
+    float* aq = sv + sp.aq + (size_t)l * c.B * c.T;
+    CA_TRY(affinity(c, Q[l], V, C));
+    CA_TRY(ct_times(c, C, Pq, Pv, Hv, 1));
+    CA_TRY(c_times(c, C, Pv, Pq, Hq, 1));
+    CA_TRY(launch_score_softmax(Hv, (const float*)p->w_v, (const float*)p->c_v, av, c.B, c.N, c.d, c.s));
+    CA_TRY(launch_score_softmax(Hq, (const float*)p->w_q, (const float*)p->c_q, aq, c.B, c.T, c.d, c.s));
+    // v = sum_n a_v[n] V[:,n]   (model.py:391);  q = sum_t a_q[t] Q[t,:]   (model.py:392)
+    CA_TRY(launch_gemv(V, av, v_out + (size_t)l * c.B * c.d, c.B, c.d, c.N, (int64_t)c.d * c.N, c.N, 1, c.N, c.d, c.s));
+    CA_TRY(launch_gemv(Q[l], aq, q_out + (size_t)l * c.B * c.d, c.B, c.d, c.T, (int64_t)c.T * c.d, 1, c.d, c.T, c.d, c.s));
+  }
+  return 0;
+}
+
+int backward_general(const Ctx& c, const float* V, const float* const* Q, const coattn_params* p, const float* sv,
+                     const float* gv, const float* gq, float* dV, float* const* dQ, const coattn_param_grads* pg,
+                     int accumulate, float* ws) {
+  const SavedPlan sp = plan_saved(c.B, c.N, c.T, c.d, c.L);
+  const BwdPlan bp = plan_bwd(c.B, c.N, c.T, c.d, c.L);
+  const int B = c.B, N = c.N, T = c.T, d = c.d, L = c.L;
+  const size_t BTd = (size_t)B * T * d, BTN = (size_t)B * T * N, BNd = (size_t)B * N * d, Bd = (size_t)B * d;
+  const float* Pv = sv + sp.Pv;
+  const float* wv = (const float*)p->w_v;
+  const float* wq = (const float*)p->w_q;
+  float* Hv = ws + bp.Hv;
+  float* dPv = ws + bp.dPv;
+  float* dZq = ws + bp.dZq;
+  float* dC = ws + bp.dC;
+  float* dav = ws + bp.dav;
+  float* dsv = ws + bp.dsv;
+  float* daq = ws + bp.daq;
+  float* dsq = ws + bp.dsq;
+  float* part = ws + bp.part;
+  int nch = 0;
+  for (int l = 0; l < L; ++l) {
+    const float* Pq = sv + sp.Pq + l * BTd;
+    const float* C = sv + sp.C + l * BTN;
+    const float* Hq = sv + sp.Hq + l * BTd;
+    const float* av = sv + sp.av + (size_t)l * B * N;
+    const float* aq = sv + sp.aq + (size_t)l * B * T;
+    float* dPq = ws + bp.dPq + l * BTd;
+    const int acc_l = (accumulate || l > 0) ? 1 : 0;
+    // recompute H_v = tanh(P_v + C^T P_q)
+    CA_TRY(ct_times(c, C, Pq, Pv, Hv, 1));
+    // softmax backward of a_v, a_q
+    CA_TRY(launch_gemv(V, gv + l * Bd, dav, B, N, d, (int64_t)d * N, 1, N, d, N, c.s));
+    CA_TRY(launch_softmax_bwd(av, dav, dsv, B, N, c.s));
+    CA_TRY(launch_gemv(Q[l], gq + l * Bd, daq, B, T, d, (int64_t)T * d, d, 1, d, T, c.s));
+    CA_TRY(launch_softmax_bwd(aq, daq, dsq, B, T, c.s));
+    // dw_v += ds_v^T H_v ; dc_v += sum ds_v ; same for q
+    const int rpc_v = (B * N + 255) / 256 > 32 ? (B * N + 255) / 256 : 32;
+    CA_TRY(launch_colsum_partial(dsv, Hv, part, B * N, d, rpc_v, &nch, c.s));
+    CA_TRY(launch_reduce_partials(part, (float*)pg->dw_v, nch, d, acc_l, c.s));
+    CA_TRY(launch_sum_all(dsv, (float*)pg->dc_v, (int64_t)B * N, acc_l, c.s));
+    const int rpc_q = (B * T + 255) / 256 > 32 ? (B * T + 255) / 256 : 32;
+    CA_TRY(launch_colsum_partial(dsq, Hq, part, B * T, d, rpc_q, &nch, c.s));
+    CA_TRY(launch_reduce_partials(part, (float*)pg->dw_q, nch, d, acc_l, c.s));
+    CA_TRY(launch_sum_all(dsq, (float*)pg->dc_q, (int64_t)B * T, acc_l, c.s));
+    // dZ_v (in place over H_v), dZ_q
+    CA_TRY(launch_dz(dsv, wv, Hv, Hv, (int64_t)B * N, d, c.s));
+    CA_TRY(launch_dz(dsq, wq, Hq, dZq, (int64_t)B * T, d, c.s));
+    // dP_q = dZ_q + C dZ_v
+    CA_TRY(c_times(c, C, Hv, dZq, dPq, 0));
+    // dC = P_q dZ_v^T + dZ_q P_v^T ; dA = dC (1 - C^2)
+    {
+      coattn_gemm_desc g = {};
+      g.A = Pq; g.a_sz = (int64_t)T * d; g.a_sm = d; g.a_sk = 1;
+      g.B = Hv; g.b_sz = (int64_t)N * d; g.b_sk = 1; g.b_sn = d;
+      g.C = dC; g.c_sz = (int64_t)T * N; g.c_sm = N; g.c_sn = 1;
+      g.M = T; g.N = N; g.K = d; g.batch = B;
+      CA_TRY(launch_gemm_f32(g, c.s));
+      g.A = dZq; g.B = Pv; g.Cin = dC; g.cin_sz = g.c_sz; g.cin_sm = N; g.cin_sn = 1; g.beta = 1.f;
+      CA_TRY(launch_gemm_f32(g, c.s));
+    }
+    CA_TRY(launch_dtanh(dC, C, dC, (int64_t)BTN, c.s));
+    // dP_v(level) = dZ_v + C^T dZ_q   (in place), accumulate over levels
+    CA_TRY(ct_times(c, C, dZq, Hv, Hv, 0));
+    CA_TRY(launch_add_inplace(dPv, Hv, (int64_t)BNd, l > 0 ? 1 : 0, c.s));
+    // dQ_l = a_q (x) gq + dA V^T   (+ dP_q W_q below)
+    CA_TRY(launch_rank1(aq, gq + l * Bd, dQ[l], B, T, d, (int64_t)T * d, d, 1, 0, c.s));
+    {
+      coattn_gemm_desc g = {};
+      g.A = dC; g.a_sz = (int64_t)T * N; g.a_sm = N; g.a_sk = 1;
+      g.B = V; g.b_sz = (int64_t)d * N; g.b_sk = 1; g.b_sn = N;
+      g.Cin = dQ[l]; g.cin_sz = (int64_t)T * d; g.cin_sm = d; g.cin_sn = 1; g.beta = 1.f;
+      g.C = dQ[l]; g.c_sz = (int64_t)T * d; g.c_sm = d; g.c_sn = 1;
+      g.M = T; g.N = d; g.K = N; g.batch = B;
+      CA_TRY(launch_gemm_f32(g, c.s));
+    }
+    // dV (+)= a_v (x) gv + Q^T dA
+    if (dV) CA_TRY(launch_rank1(av, gv + l * Bd, dV, B, N, d, (int64_t)d * N, 1, N, l > 0 ? 1 : 0, c.s));
+    if (dV) {
+      coattn_gemm_desc g = {};
+      g.A = Q[l]; g.a_sz = (int64_t)T * d; g.a_sm = 1; g.a_sk = d;
+      g.B = dC; g.b_sz = (int64_t)T * N; g.b_sk = N; g.b_sn = 1;
+      g.Cin = dV; g.cin_sz = (int64_t)d * N; g.cin_sm = N; g.cin_sn = 1; g.beta = 1.f;
+      g.C = dV; g.c_sz = (int64_t)d * N; g.c_sm = N; g.c_sn = 1;
+      g.M = d; g.N = N; g.K = T; g.batch = B;
+      CA_TRY(launch_gemm_f32(g, c.s));
+    }
+  }
+  // projections backward
+  for (int l = 0; l < L; ++l) {
+    const float* dPq = ws + bp.dPq + l * BTd;
+    coattn_gemm_desc g = {};
+    g.A = dPq; g.a_sm = d; g.a_sk = 1;
+    g.B = p->W_q; g.b_sk = d; g.b_sn = 1;
+    g.Cin = dQ[l]; g.cin_sm = d; g.cin_sn = 1; g.beta = 1.f;
+    g.C = dQ[l]; g.c_sm = d; g.c_sn = 1;
+    g.M = B * T; g.N = d; g.K = d; g.batch = 1;
+    CA_TRY(launch_gemm_f32(g, c.s));
+  }
+  if (dV) {
+    // dV[b][k][n] += sum_j W_v[j][k] dP_v[b][n][j]
+    coattn_gemm_desc g = {};
+    g.A = p->W_v; g.a_sm = 1; g.a_sk = d; g.a_sz = 0;
+    g.B = dPv; g.b_sz = (int64_t)N * d; g.b_sk = 1; g.b_sn = d;
+    g.Cin = dV; g.cin_sz = (int64_t)d * N; g.cin_sm = N; g.cin_sn = 1; g.beta = 1.f;
+    g.C = dV; g.c_sz = (int64_t)d * N; g.c_sm = N; g.c_sn = 1;
+    g.M = d; g.N = N; g.K = d; g.batch = B;
+    CA_TRY(launch_gemm_f32(g, c.s));
+  }
+  {
+    // dW_v[j][k] = sum_b sum_n dP_v[b][n][j] V[b][k][n]  -> split over sample groups
+    const int G = (B + kMaxSplits - 1) / kMaxSplits;
+    const int S = (B + G - 1) / G;
+    coattn_gemm_desc g = {};
+    g.A = dPv; g.a_sm = 1; g.a_sk = d; g.a_si = (int64_t)N * d; g.a_sz = (int64_t)G * N * d;
+    g.B = V; g.b_sk = 1; g.b_sn = N; g.b_si = (int64_t)d * N; g.b_sz = (int64_t)G * d * N;
+    g.C = part; g.c_sz = (int64_t)d * d; g.c_sm = d; g.c_sn = 1;
+    g.M = d; g.N = d; g.K = N; g.batch = S; g.inner = G; g.inner_total = B;
+    CA_TRY(launch_gemm_f32(g, c.s));
+    CA_TRY(launch_reduce_partials(part, (float*)pg->dW_v, S, (int64_t)d * d, accumulate, c.s));
+    const int rpc = (B * N + 255) / 256 > 32 ? (B * N + 255) / 256 : 32;
+    CA_TRY(launch_colsum_partial(nullptr, dPv, part, B * N, d, rpc, &nch, c.s));
+    CA_TRY(launch_reduce_partials(part, (float*)pg->db_v, nch, d, accumulate, c.s));
+  }
+  for (int l = 0; l < L; ++l) {
+    // dW_q[j][k] += sum_m dP_q[m][j] Q_l[m][k],  m over (b,t): split-K
+    const float* dPq = ws + bp.dPq + l * BTd;
+    const int K = B * T;
+    int ks = (K + kMaxSplits - 1) / kMaxSplits;
+    ks = (ks + 15) / 16 * 16;
+    const int S = (K + ks - 1) / ks;
+    coattn_gemm_desc g = {};
+    g.A = dPq; g.a_sm = 1; g.a_sk = d;
+    g.B = Q[l]; g.b_sk = d; g.b_sn = 1;
+    g.C = part; g.c_sz = (int64_t)d * d; g.c_sm = d; g.c_sn = 1;
+    g.M = d; g.N = d; g.K = K; g.batch = S; g.ksplit = ks;
+    CA_TRY(launch_gemm_f32(g, c.s));
+    CA_TRY(launch_reduce_partials(part, (float*)pg->dW_q, S, (int64_t)d * d, (accumulate || l > 0) ? 1 : 0, c.s));
+  }
+  {
+    const int R = L * B * T;
+    const int rpc = (R + 255) / 256 > 32 ? (R + 255) / 256 : 32;
+    CA_TRY(launch_colsum_partial(nullptr, ws + bp.dPq, part, R, d, rpc, &nch, c.s));
+    CA_TRY(launch_reduce_partials(part, (float*)pg->db_q, nch, d, accumulate, c.s));
+  }
+  return 0;
+}
+
+int pick_impl(int flags, int B, int N, int T, int d, int L, int* fused) {
+  const int sel = flags & 3;
+  const int ok = fused_supported(B, N, T, d, L);
+  if (sel == COATTN_IMPL_FUSED) {
+    CA_CHECK_ARG(ok, "fused kernels do not support B=%d N=%d T=%d d=%d L=%d", B, N, T, d, L);
+    *fused = 1;
+  } else if (sel == COATTN_IMPL_GENERAL) {
+    *fused = 0;
+  } else {
+    *fused = ok;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int coattn_forward(const void* V, const void* const* Q, const coattn_params* p, void* v_out, void* q_out,
+                              void* saved, void* ws, int B, int N, int T, int d, int L, int dtype, int flags,
+                              void* stream) {
+  CA_TRY(check_shape(B, N, T, d, L, dtype));
+  CA_CHECK_ARG(V && Q && p && v_out && q_out && ws, "forward: null argument");
+  for (int l = 0; l < L; ++l) CA_CHECK_ARG(Q[l] != nullptr, "forward: Q[%d] is null", l);
+  CA_CHECK_ARG(p->W_v && p->b_v && p->W_q && p->b_q && p->w_v && p->c_v && p->w_q && p->c_q,
+               "forward: null parameter pointer");
+  int fused = 0;
+  CA_TRY(pick_impl(flags, B, N, T, d, L, &fused));
+  const SavedPlan sp = plan_saved(B, N, T, d, L);
+  float* sv = saved ? (float*)saved : (float*)ws;      // inference: state lives in the workspace
+  float* tail = (float*)ws + sp.total;
+  Ctx c{B, N, T, d, L, (hipStream_t)stream};
+  if (fused)
+    return fused_forward(B, N, T, d, L, (const float*)V, (const float* const*)Q, p, (float*)v_out, (float*)q_out, sv,
+                         tail, c.s);
+  return forward_general(c, (const float*)V, (const float* const*)Q, p, (float*)v_out, (float*)q_out, sv, tail);
+}
+
+extern "C" int coattn_backward(const void* V, const void* const* Q, const coattn_params* p, const void* saved,
+                               const void* gv, const void* gq, void* dV, void* const* dQ,
+                               const coattn_param_grads* pg, int accumulate, void* ws, int B, int N, int T, int d,
+                               int L, int dtype, int flags, void* stream) {
+  CA_TRY(check_shape(B, N, T, d, L, dtype));
+  CA_CHECK_ARG(V && Q && p && saved && gv && gq && dQ && pg && ws, "backward: null argument");  // dV may be NULL
+  for (int l = 0; l < L; ++l) CA_CHECK_ARG(Q[l] && dQ[l], "backward: Q[%d]/dQ[%d] is null", l, l);
+  CA_CHECK_ARG(pg->dW_v && pg->db_v && pg->dW_q && pg->db_q && pg->dw_v && pg->dc_v && pg->dw_q && pg->dc_q,
+               "backward: null parameter-gradient pointer");
+  int fused = 0;
+  CA_TRY(pick_impl(flags, B, N, T, d, L, &fused));
+  Ctx c{B, N, T, d, L, (hipStream_t)stream};
+  if (fused)
+    return fused_backward(B, N, T, d, L, (const float*)V, (const float* const*)Q, p, (const float*)saved,
+                          (const float*)gv, (const float*)gq, (float*)dV, (float* const*)dQ, pg, accumulate,
+                          (float*)ws, c.s);
+  return backward_general(c, (const float*)V, (const float* const*)Q, p, (const float*)saved, (const float*)gv,
+                          (const float*)gq, (float*)dV, (float* const*)dQ, pg, accumulate, (float*)ws);
+}

@@ -1,0 +1,90 @@
+// Shared device/host helpers for the gfx950 co-attention kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/coattn.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- error plumbing (thread-local message, negative return codes) -----------------------
+void coattn_set_error(const char* fmt, ...);
+
+#define CA_CHECK_ARG(cond, ...)                 \
+  do {                                          \
+    if (!(cond)) {                              \
+      coattn_set_error(__VA_ARGS__);            \
+      return -1;                                \
+    }                                           \
+  } while (0)
+
+#define CA_CHECK_LAUNCH(what)                                                        \
+  do {                                                                               \
+    hipError_t e_ = hipGetLastError();                                               \
+    if (e_ != hipSuccess) {                                                          \
+      coattn_set_error("%s: launch failed: %s", what, hipGetErrorString(e_));        \
+      return -3;                                                                     \
+    }                                                                                \
+  } while (0)
+
+#define CA_TRY(expr)            \
+  do {                          \
+    int rc_ = (expr);           \
+    if (rc_ != 0) return rc_;   \
+  } while (0)
+
+// ---- wave64 reductions ------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// tanh with ~2e-7 absolute error: 1 v_exp + 1 v_rcp.  (1-e)/(1+e), e = exp(-2|x|).
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float ax = fabsf(x);
+  const float e = __expf(-2.0f * ax);
+  const float t = __fdividef(1.0f - e, 1.0f + e);
+  return copysignf(t, x);
+}
+
+// ---- generic GEMM (gemm.hip) ------------------------------------------------------------
+int launch_gemm_f32(const coattn_gemm_desc& g, hipStream_t s);
+
+// ---- small general-shape kernels (small_kernels.hip) ------------------------------------
+// y[z][i] = sum_k X[z*x_sz + i*x_si + k*x_sk] * u[z*u_sz + k]      (i < I, k < K)
+int launch_gemv(const float* X, const float* u, float* y, int Z, int I, int K,
+                int64_t x_sz, int64_t x_si, int64_t x_sk, int64_t u_sz, int64_t y_sz, hipStream_t s);
+// a[z][r] = softmax_r( H[z][r][:] . w + c[0] ),  H rows contiguous (length d)
+int launch_score_softmax(const float* H, const float* w, const float* c, float* a,
+                         int Z, int R, int d, hipStream_t s);
+// ds[z][r] = a[z][r] * (da[z][r] - sum_r a*da)
+int launch_softmax_bwd(const float* a, const float* da, float* ds, int Z, int R, hipStream_t s);
+// part[chunk][j] = sum_{r in chunk} s[r] * X[r][j]   (s may be NULL -> 1); X: [R][d] contiguous
+// returns number of chunks through *nchunks; part must hold nchunks*d floats
+int launch_colsum_partial(const float* s, const float* X, float* part, int R, int d, int rows_per_chunk,
+                          int* nchunks, hipStream_t s_);
+// out[j] (+)= sum_c part[c][j]   (n = elements per partial)
+int launch_reduce_partials(const float* part, float* out, int nparts, int64_t n, int accumulate, hipStream_t s);
+// total (+)= sum of x[0..n)   (single block)
+int launch_sum_all(const float* x, float* out, int64_t n, int accumulate, hipStream_t s);
+// H[z][r][j] = ds[z][r] * w[j] * (1 - H^2)      (in place or out of place)
+int launch_dz(const float* ds, const float* w, const float* H, float* out, int64_t rows, int d, hipStream_t s);
+// dA = dC * (1 - C^2)
+int launch_dtanh(const float* dC, const float* C, float* out, int64_t n, hipStream_t s);
+// y (+)= x
+int launch_add_inplace(float* y, const float* x, int64_t n, int accumulate, hipStream_t s);
+// out[z][i][j] (+)= a[z][i] * g[z][j] with strides (o_sz, o_si, o_sj)
+int launch_rank1(const float* a, const float* g, float* out, int Z, int I, int J,
+                 int64_t o_sz, int64_t o_si, int64_t o_sj, int accumulate, hipStream_t s);
+
+// ---- fused kernels (coattn_fused.hip) ---------------------------------------------------
+int fused_supported(int B, int N, int T, int d, int L);

@@ -1,0 +1,250 @@
+// General-shape (any N, T, d) kernels around the MFMA GEMM: attention scores + row softmax
+// (model.py:387-388), attended-feature reductions (model.py:391-392) and the element-wise
+// pieces of the hand-derived backward.  All HBM-bound; lanes run along
+// the contiguous axis, reductions are wave64 shuffles, results are deterministic (no atomics).
+#include "common.h"
+
+namespace {
+
+// ---- batched GEMV ------------------------------------------------------------------------
+// path A (x_sk == 1): one wave per output i, lanes over k, shuffle reduce.
+__global__ __launch_bounds__(256) void gemv_kcontig(const float* X, const float* u, float* y, int I, int K,
+                                                    long x_sz, long x_si, long u_sz, long y_sz) {
+  const int z = blockIdx.y, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= I) return;
+  const float* xr = X + z * x_sz + i * x_si;
+  const float* uz = u + z * u_sz;
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) acc = fmaf(xr[k], uz[k], acc);
+  acc = wave_sum(acc);
+  if (lane == 0) y[z * y_sz + i] = acc;
+}
+// path B (x_si == 1): one thread per output i, loop over k (coalesced across threads).
+__global__ __launch_bounds__(256) void gemv_icontig(const float* X, const float* u, float* y, int I, int K,
+                                                    long x_sz, long x_sk, long u_sz, long y_sz) {
+  const int z = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= I) return;
+  const float* xz = X + z * x_sz + i;
+  const float* uz = u + z * u_sz;
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) acc = fmaf(xz[(long)k * x_sk], uz[k], acc);
+  y[z * y_sz + i] = acc;
+}
+// fallback: arbitrary strides
+__global__ __launch_bounds__(256) void gemv_generic(const float* X, const float* u, float* y, int I, int K,
+                                                    long x_sz, long x_si, long x_sk, long u_sz, long y_sz) {
+  const int z = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= I) return;
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) acc = fmaf(X[z * x_sz + i * x_si + k * x_sk], u[z * u_sz + k], acc);
+  y[z * y_sz + i] = acc;
+}
+
+// ---- scores + softmax over the R rows of one batch item -----------------------------------
+// one workgroup per z; wave w handles rows w, w+4, ...; scores kept in LDS (R <= 4096).
+__global__ __launch_bounds__(256) void score_softmax_kernel(const float* H, const float* w, const float* c,
+                                                            float* a, int R, int d) {
+  extern __shared__ __attribute__((aligned(16))) float sc[];
+  __shared__ float red[8];
+  const int z = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* Hz = H + (long)z * R * d;
+  const float c0 = c[0];
+  for (int r = wave; r < R; r += 4) {
+    const float* hr = Hz + (long)r * d;
+    float acc = 0.f;
+    for (int k = lane; k < d; k += 64) acc = fmaf(hr[k], w[k], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) sc[r] = acc + c0;
+  }
+  __syncthreads();
+  float m = -INFINITY;
+  for (int r = threadIdx.x; r < R; r += 256) m = fmaxf(m, sc[r]);
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float s = 0.f;
+  for (int r = threadIdx.x; r < R; r += 256) {
+    const float e = expf(sc[r] - m);
+    sc[r] = e;
+    s += e;
+  }
+  s = wave_sum(s);
+  if (lane == 0) red[4 + wave] = s;
+  __syncthreads();
+  s = (red[4] + red[5]) + (red[6] + red[7]);
+  const float inv = 1.0f / s;
+  for (int r = threadIdx.x; r < R; r += 256) a[(long)z * R + r] = sc[r] * inv;
+}
+
+// ds = a * (da - <a,da>), one wave per z
+__global__ __launch_bounds__(64) void softmax_bwd_kernel(const float* a, const float* da, float* ds, int R) {
+  const int z = blockIdx.x, lane = threadIdx.x;
+  const float* az = a + (long)z * R;
+  const float* dz = da + (long)z * R;
+  float dot = 0.f;
+  for (int r = lane; r < R; r += 64) dot = fmaf(az[r], dz[r], dot);
+  dot = wave_sum(dot);
+  for (int r = lane; r < R; r += 64) ds[(long)z * R + r] = az[r] * (dz[r] - dot);
+}
+
+// part[chunk][j] = sum_{r in chunk} s[r] * X[r][j]
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* s, const float* X, float* part,
+                                                             int R, int d, int rpc) {
+  const int chunk = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= d) return;
+  const int r0 = chunk * rpc, r1 = min(R, r0 + rpc);
+  float acc = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const float sv = s ? s[r] : 1.0f;
+    acc = fmaf(sv, X[(long)r * d + j], acc);
+  }
+  part[(long)chunk * d + j] = acc;
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* part, float* out, int nparts, long n,
+                                                              int accumulate) {
+  const long j = (long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  float acc = 0.f;
+  for (int c = 0; c < nparts; ++c) acc += part[(long)c * n + j];
+  out[j] = accumulate ? out[j] + acc : acc;
+}
+
+__global__ __launch_bounds__(256) void sum_all_kernel(const float* x, float* out, long n, int accumulate) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (long i = threadIdx.x; i < n; i += 256) acc += x[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = (red[0] + red[1]) + (red[2] + red[3]);
+    out[0] = accumulate ? out[0] + t : t;
+  }
+}
+
+__global__ __launch_bounds__(256) void dz_kernel(const float* ds, const float* w, const float* H, float* out,
+                                                 long rows, int d) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * d) return;
+  const long r = idx / d;
+  const int j = (int)(idx - r * d);
+  const float h = H[idx];
+  out[idx] = ds[r] * w[j] * (1.0f - h * h);
+}
+
+__global__ __launch_bounds__(256) void dtanh_kernel(const float* dC, const float* C, float* out, long n) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  const float c = C[idx];
+  out[idx] = dC[idx] * (1.0f - c * c);
+}
+
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* y, const float* x, long n, int accumulate) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  y[idx] = accumulate ? y[idx] + x[idx] : x[idx];
+}
+
+// out[z][i][j] (+)= a[z][i] * g[z][j]; threads run along whichever of i/j has stride 1
+__global__ __launch_bounds__(256) void rank1_kernel(const float* a, const float* g, float* out, int I, int J,
+                                                    long o_sz, long o_si, long o_sj, int accumulate, int ifast) {
+  const int z = blockIdx.y;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)I * J) return;
+  int i, j;
+  if (ifast) { i = (int)(idx % I); j = (int)(idx / I); } else { j = (int)(idx % J); i = (int)(idx / J); }
+  const float v = a[(long)z * I + i] * g[(long)z * J + j];
+  float* o = out + z * o_sz + i * o_si + j * o_sj;
+  *o = accumulate ? *o + v : v;
+}
+
+}  // namespace
+
+int launch_gemv(const float* X, const float* u, float* y, int Z, int I, int K, int64_t x_sz, int64_t x_si,
+                int64_t x_sk, int64_t u_sz, int64_t y_sz, hipStream_t s) {
+  CA_CHECK_ARG(Z > 0 && I > 0 && K > 0 && Z <= 65535, "gemv: bad shape");
+  if (x_sk == 1) {
+    hipLaunchKernelGGL(gemv_kcontig, dim3((I + 3) / 4, Z), dim3(256), 0, s, X, u, y, I, K, (long)x_sz, (long)x_si,
+                       (long)u_sz, (long)y_sz);
+  } else if (x_si == 1) {
+    hipLaunchKernelGGL(gemv_icontig, dim3((I + 255) / 256, Z), dim3(256), 0, s, X, u, y, I, K, (long)x_sz,
+                       (long)x_sk, (long)u_sz, (long)y_sz);
+  } else {
+    hipLaunchKernelGGL(gemv_generic, dim3((I + 255) / 256, Z), dim3(256), 0, s, X, u, y, I, K, (long)x_sz,
+                       (long)x_si, (long)x_sk, (long)u_sz, (long)y_sz);
+  }
+  CA_CHECK_LAUNCH("gemv");
+  return 0;
+}
+
+int launch_score_softmax(const float* H, const float* w, const float* c, float* a, int Z, int R, int d,
+                         hipStream_t s) {
+  CA_CHECK_ARG(Z > 0 && R > 0 && R <= 4096 && d > 0, "score_softmax: bad shape Z=%d R=%d d=%d", Z, R, d);
+  hipLaunchKernelGGL(score_softmax_kernel, dim3(Z), dim3(256), (size_t)R * sizeof(float), s, H, w, c, a, R, d);
+  CA_CHECK_LAUNCH("score_softmax");
+  return 0;
+}
+
+int launch_softmax_bwd(const float* a, const float* da, float* ds, int Z, int R, hipStream_t s) {
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3(Z), dim3(64), 0, s, a, da, ds, R);
+  CA_CHECK_LAUNCH("softmax_bwd");
+  return 0;
+}
+
+int launch_colsum_partial(const float* sv, const float* X, float* part, int R, int d, int rpc, int* nchunks,
+                          hipStream_t s) {
+  const int nc = (R + rpc - 1) / rpc;
+  CA_CHECK_ARG(nc <= 65535, "colsum: too many chunks");
+  *nchunks = nc;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((d + 255) / 256, nc), dim3(256), 0, s, sv, X, part, R, d, rpc);
+  CA_CHECK_LAUNCH("colsum_partial");
+  return 0;
+}
+
+int launch_reduce_partials(const float* part, float* out, int nparts, int64_t n, int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, out, nparts,
+                     (long)n, accumulate);
+  CA_CHECK_LAUNCH("reduce_partials");
+  return 0;
+}
+
+int launch_sum_all(const float* x, float* out, int64_t n, int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(256), 0, s, x, out, (long)n, accumulate);
+  CA_CHECK_LAUNCH("sum_all");
+  return 0;
+}
+
+int launch_dz(const float* ds, const float* w, const float* H, float* out, int64_t rows, int d, hipStream_t s) {
+  const long n = rows * d;
+  hipLaunchKernelGGL(dz_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ds, w, H, out, (long)rows, d);
+  CA_CHECK_LAUNCH("dz");
+  return 0;
+}
+
+int launch_dtanh(const float* dC, const float* C, float* out, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(dtanh_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dC, C, out, (long)n);
+  CA_CHECK_LAUNCH("dtanh");
+  return 0;
+}
+
+int launch_add_inplace(float* y, const float* x, int64_t n, int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, x, (long)n,
+                     accumulate);
+  CA_CHECK_LAUNCH("add_inplace");
+  return 0;
+}
+
+int launch_rank1(const float* a, const float* g, float* out, int Z, int I, int J, int64_t o_sz, int64_t o_si,
+                 int64_t o_sj, int accumulate, hipStream_t s) {
+  const long n = (long)I * J;
+  hipLaunchKernelGGL(rank1_kernel, dim3((unsigned)((n + 255) / 256), Z), dim3(256), 0, s, a, g, out, I, J,
+                     (long)o_sz, (long)o_si, (long)o_sj, accumulate, o_si == 1 ? 1 : 0);
+  CA_CHECK_LAUNCH("rank1");
+  return 0;
+}

@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X co-attention path: QA-pairs/sec of the `--model attention` train step.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1], per GPU): HierarchicalCoAttentionNet, K=1000 answers (1001
+logits), batch 160, synthetic 224x224 images (-> 7x7x512 grid, N=49), 26-token questions, fp32;
+one step = forward + CrossEntropy + backward + Adam (+ RCCL gradient all-reduce when N > 1), all
+inputs resident in HBM before the timed region.  Rank 0 prints ONE JSON line; besides the
+contract fields it carries
+  roofline      the fused affinity+softmax+reduce forward kernel, timed live with HIP events on
+                the launch stream at the headline kernel shape (B=160, N=196, T=26, d=512):
+                algorithmic bytes 913,408 B per (pair, level) / avg launch time,
+                against 8 TB/s HBM
+  cpu_baseline  the CPU oracle port (oracle/net_oracle.py) of the same train step, timed on the
+                host cores on a bounded sample (rank 0, N=1 only)
+  hot_path      isolated co-attention (+MLP+CE) fwd+bwd rates on device-resident features, N=196
+                and N=49, and the per-call forward / backward times of the HIP path.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_BYTES_PER_PAIR_LEVEL = lambda N, T, d: 4 * (T * d + d * N + N * d + T * d + 2 * d)   # Q + V + P_v + P_q + v,q
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=160, help="per-GPU batch (BASELINE config 2: 160)")
+    ap.add_argument("--image-size", type=int, default=224)
+    ap.add_argument("--num-cls", type=int, default=1000)
+    ap.add_argument("--vocab", type=int, default=10000)
+    ap.add_argument("--seq-len", type=int, default=26)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the roofline / hot_path legs")
+    ap.add_argument("--cpu-batch", type=int, default=32)
+    return ap.parse_args()
+
+
+def device_batch(T, args, rank, device, batch=None, image_size=None):
+    b = T.synthetic_batch(batch or args.batch, (image_size or args.image_size,) * 2, args.seq_len, args.vocab,
+                          args.num_cls + 1, seed=1234 + rank)
+    image, question, label, lens = T.sort_batch(b["image"], b["question"], b["label"], b["ques_len"])
+    return image.to(device), question.to(device), lens, label.to(device)
+
+
+def timed_steps(trainer, batch, steps, warmup, sync):
+    for _ in range(warmup):
+        trainer.step(*batch)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        trainer.step(*batch)
+    sync()
+    return time.perf_counter() - t0
+
+
+def hot_path_leg(device, N, B=160, T=26, d=512, K=1000, iters=20):
+    """Isolated hot path (co-attention + MLPClassifier + CE, fwd+bwd) on resident features."""
+    import vqa_amd
+    from vqa_amd.modules import MLPClassifier
+    from oracle import coattn_oracle as O
+    torch.manual_seed(0)
+    co = vqa_amd.ParallelCoAttention(d).to(device)
+    mlp = MLPClassifier(d, 1024, K + 1).to(device)
+    lens = sorted([26] + [3 + (7 * i) % 24 for i in range(B - 1)], reverse=True)
+    V, Qs = O.make_inputs(B, N, T, d, 1234, lens=lens)
+    x_img = V.to(device).permute(0, 2, 1)
+    Qs = [q.to(device).requires_grad_(True) for q in Qs]
+    label = (torch.arange(B, device=device) * 7) % (K + 1)
+    crit = torch.nn.CrossEntropyLoss()
+    params = [p for p in list(co.parameters()) + list(mlp.parameters())]
+
+    def step():
+        for p in params:
+            p.grad = None
+        loss = crit(mlp(*co(x_img, Qs)), label)
+        loss.backward()
+
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    # forward / backward of the HIP op alone, HIP events on the launch stream
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    fwd = bwd = 0.0
+    for _ in range(iters):
+        e[0].record()
+        v, q = vqa_amd.coattention(x_img, Qs, co.W_v.weight, co.W_v.bias, co.W_q.weight, co.W_q.bias, co.w_v.weight,
+                                   co.w_v.bias, co.w_q.weight, co.w_q.bias)
+        e[1].record()
+        torch.autograd.backward([v, q], [torch.ones_like(v), torch.ones_like(q)])
+        e[2].record()
+        torch.cuda.synchronize()
+        fwd += e[0].elapsed_time(e[1]); bwd += e[1].elapsed_time(e[2])
+    return {"N": N, "pairs_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3),
+            "coattn_fwd_ms": round(fwd / iters, 4), "coattn_bwd_ms": round(bwd / iters, 4)}
+
+
+def roofline_leg(device, B=160, N=196, T=26, d=512, L=3, iters=50):
+    """Average launch duration of the affinity+softmax+reduce forward kernel(s), HIP events on the
+    launch stream (= torch's current stream, which the C-ABI call is given)."""
+    import ctypes as C
+    import vqa_amd
+    from vqa_amd import _lib
+    from oracle import coattn_oracle as O
+    lib = _lib.load()
+    fused = bool(lib.coattn_fused_supported(B, N, T, d, L, _lib.F32))
+    P = O.make_params(d, 5)
+    V, Qs = O.make_inputs(B, N, T, d, 77, lens=[T] * B)
+    V = V.to(device); Qs = [q.to(device) for q in Qs]
+    names = ("W_v.weight", "W_v.bias", "W_q.weight", "W_q.bias", "w_v.weight", "w_v.bias", "w_q.weight", "w_q.bias")
+    ps = [P[k].to(device).contiguous() for k in names]
+    sb, fb, _ = _lib.workspace_bytes(B, N, T, d, L)
+    saved = torch.empty(sb // 4, device=device); ws = torch.empty(fb // 4, device=device)
+    v = torch.empty(L, B, d, device=device); q = torch.empty(L, B, d, device=device)
+    qptr = (C.c_void_p * L)(*[t.data_ptr() for t in Qs])
+    p = _lib.Params(*[t.data_ptr() for t in ps])
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    args = (V.data_ptr(), qptr, C.byref(p), v.data_ptr(), q.data_ptr(), saved.data_ptr(), ws.data_ptr(),
+            B, N, T, d, L, _lib.F32, 0, stream)
+    _lib.check(lib.coattn_forward(*args), "coattn_forward")          # fills P_v / P_q in `saved`
+    for _ in range(5):
+        _lib.check(lib.coattn_attention_forward(*args), "coattn_attention_forward")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        lib.coattn_attention_forward(*args)
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / iters
+    alg = B * L * ALG_BYTES_PER_PAIR_LEVEL(N, T, d)
+    ach = alg / t / 1e9
+    return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel": "coattn_attention_fwd (affinity+tanh, H_v/H_q, scores, row-softmax, attended reductions)"
+                      + (" [fused]" if fused else " [general-shape kernel sequence]"),
+            "shape": {"B": B, "N": N, "T": T, "d": d, "L": L}, "avg_launch_us": round(t * 1e6, 2),
+            "algorithmic_bytes": alg}
+
+
+def cpu_baseline_leg(args):
+    """The oracle port of the same train step on the host cores; bounded sample."""
+    from oracle import net_oracle as NO
+    from vqa_amd import train as T
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    qp = dict(vocab_size=args.vocab, word_emb_dim=512, hidden_dim=512)
+    net = NO.OracleHierarchicalCoAttentionNet(qp, dict(is_trainable=False, weights_path=None), K=args.num_cls + 1)
+    b = T.synthetic_batch(args.cpu_batch, (args.image_size,) * 2, args.seq_len, args.vocab, args.num_cls + 1, seed=1234)
+    image, question, label, lens = T.sort_batch(b["image"], b["question"], b["label"], b["ques_len"])
+    batch = (image, question, lens, label)
+    NO.train_steps(net, [batch], lr=1e-4)                              # warm-up
+    t0 = time.perf_counter()
+    n = 2
+    NO.train_steps(net, [batch] * n, lr=1e-4)
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(args.cpu_batch / dt, 2), "unit": "QA-pairs/s", "cores": cores, "kind": "port",
+            "sample": "oracle port of the same train step (reference op sequence incl. its 6x W_v(V) "
+                      "re-evaluation), batch %d, %dx%d images, 1 warm-up + %d timed steps, torch CPU fp32, %d threads"
+                      % (args.cpu_batch, args.image_size, args.image_size, n, cores)}
+
+
+def main():
+    args = parse()
+    import vqa_amd
+    from vqa_amd import dist as vdist
+    from vqa_amd import train as T
+    rank, world, local = vdist.init_from_env()
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    torch.manual_seed(0)
+    model = T.build_model("attention", args.vocab, args.num_cls).to(device)
+    trainer = T.Trainer(model, 1e-4, device)
+    batch = device_batch(T, args, rank, device)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    dt = timed_steps(trainer, batch, args.steps, args.warmup, sync)
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    out = None
+    if rank == 0:
+        value = world * args.batch * args.steps / dt
+        n_grid = (args.image_size // 32) ** 2
+        out = {
+            "metric": "QA-pairs/sec (train step, attention model, K=1000)", "value": round(value, 2),
+            "unit": "QA-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "attention model train step (fwd + CE + bwd + Adam%s), K=%d (+1 UNKNOWN), "
+                                   "batch %d/GPU, %dx%d synthetic images -> %d-location x 512 grid, %d-token questions, "
+                                   "vocab %d, fp32, frozen random-init VGG11-bn"
+                                   % (" + RCCL grad all-reduce" if world > 1 else "", args.num_cls, args.batch,
+                                      args.image_size, args.image_size, n_grid, args.seq_len, args.vocab),
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world,
+                       "coattn_impl": "fused" if vqa_amd._lib.load().coattn_fused_supported(
+                           args.batch, n_grid, args.seq_len, 512, 3, 0) else "general"},
+        }
+    if world > 1:
+        if rank == 0 and trainer.reducer is not None:
+            out["allreduce_payload_mb"] = round(trainer.reducer.payload_bytes() / 1e6, 2)
+        vdist.shutdown()
+    elif not args.no_extras:
+        del trainer, model, batch
+        torch.cuda.empty_cache()
+        out["roofline"] = roofline_leg(device)
+        out["hot_path"] = [hot_path_leg(device, 196), hot_path_leg(device, 49)]
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_leg(args)
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

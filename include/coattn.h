@@ -79,6 +79,14 @@ int coattn_forward(const void* V, const void* const* Q, const coattn_params* p,
                    void* v_out, void* q_out, void* saved, void* ws,
                    int B, int N, int T, int d, int L, int dtype, int flags, void* stream);
 
+/* Second half of coattn_forward only: everything after the projections P_v, P_q (affinity +
+ * tanh model.py:377, H_v/H_q :380-384, scores + row softmax :387-388, attended reductions
+ * :391-392), reading P_v / P_q from a `saved` buffer that a previous coattn_forward on the same
+ * inputs filled.  Exists so that tests and bench.py can time / check this kernel in isolation. */
+int coattn_attention_forward(const void* V, const void* const* Q, const coattn_params* p,
+                             void* v_out, void* q_out, void* saved, void* ws,
+                             int B, int N, int T, int d, int L, int dtype, int flags, void* stream);
+
 /* Backward (autograd of model.py:372-392).
  *   gv,gq : [L,B,d] upstream gradients of v_out,q_out.
  *   dV    : [B,d,N] (overwritten), or NULL when the image features need no gradient (frozen

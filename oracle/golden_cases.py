@@ -49,3 +49,49 @@ def build_case(name: str, dtype=torch.float32):
 
 
 GRAD_KEYS = ("dV_phys", "dQ") + tuple("d" + k for k in O.PARAM_KEYS)
+
+
+# ---- network-level cases (G7 logits, G8 train-step trajectory, G9 baseline net) -----------
+NET_CASE = dict(vocab=40, hidden=512, K=10, B=3, T=8, image=64, lens=[8, 5, 2], seed=301, lr=1e-4, steps=3)
+BASE_CASE = dict(vocab=30, emb=300, hidden=1024, K=2, B=2, T=6, lens=[6, 3], seed=401)
+
+
+def closed_form_state(module, seed: int):
+    """Closed-form values for every entry of ``module.state_dict()`` (in its own order):
+    weights U(+-sqrt(3/fan_in)), biases U(+-0.05), BatchNorm affine ~1 / running stats at their
+    defaults, embeddings ~N(0,1) with row 0 = 0 (padding_idx).  Returns a dict of tensors."""
+    import numpy as np
+
+    out = {}
+    for i, (name, t) in enumerate(module.state_dict().items()):
+        s = seed * 1000 + i
+        if name.endswith("num_batches_tracked"):
+            v = torch.zeros_like(t)
+        elif name.endswith("running_mean"):
+            v = torch.zeros_like(t)
+        elif name.endswith("running_var"):
+            v = torch.ones_like(t)
+        elif "word_embedding" in name and t.dim() == 2:
+            v = torch.from_numpy(O.hash_normal(tuple(t.shape), s)).to(t.dtype)
+            v[0] = 0
+        elif t.dim() == 1:
+            base = 1.0 if (name.endswith("weight")) else 0.0          # BatchNorm gamma ~ 1
+            v = torch.from_numpy(base + O.hash_unit(tuple(t.shape), s, 0.05)).to(t.dtype)
+        else:
+            fan_in = int(np.prod(t.shape[1:]))
+            v = torch.from_numpy(O.hash_unit(tuple(t.shape), s, math.sqrt(3.0 / fan_in))).to(t.dtype)
+        out[name] = v
+    return out
+
+
+def net_case_batch(c=None):
+    """(image, question, ques_len, label) of the network-level case, sorted by length (desc)."""
+    c = c or NET_CASE
+    B, T = c["B"], c["T"]
+    image = torch.from_numpy(O.hash_normal((B, 3, c["image"], c["image"]), c["seed"] + 1)).float()
+    tok = (O.hash_uniform(B * T, c["seed"] + 2) * (c["vocab"] - 2)).astype("int64").reshape(B, T) + 2
+    question = torch.from_numpy(tok)
+    lens = torch.tensor(c["lens"], dtype=torch.int64)
+    question = question * (torch.arange(T)[None, :] < lens[:, None])
+    label = torch.from_numpy((O.hash_uniform(B, c["seed"] + 3) * (c["K"] + 1)).astype("int64"))
+    return image, question, lens, label

@@ -1,0 +1,104 @@
+"""CPU, 2 processes over gloo: the data-parallel gradient reducer.  Averaged gradients of two
+half-batches equal the single-process full-batch gradients on the co-attention + MLP subgraph
+(features fixed), the dead W_b is discovered and skipped, and training steps stay in lockstep."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _build(d, K):
+    from oracle.coattn_oracle import OracleMLPClassifier, OracleParallelCoAttention
+
+    class Sub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.co_attention = OracleParallelCoAttention(d, as_executed=False)
+            self.mlp_classify = OracleMLPClassifier(d, 2 * d, K)
+
+        def forward(self, x_img, qs):
+            return self.mlp_classify(*self.co_attention(x_img, qs))
+    torch.manual_seed(0)
+    return Sub()
+
+
+def _data(B, N, T, d, K):
+    from oracle import coattn_oracle as O
+    V, Qs = O.make_inputs(B, N, T, d, 55, lens=[T] * B, scale_q=0.2)
+    label = torch.arange(B) % K
+    return V.permute(0, 2, 1), Qs, label
+
+
+def _worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from vqa_amd import dist as vdist
+    vdist.init_from_env("gloo")
+    B, N, T, d, K = 8, 9, 5, 32, 7
+    model = _build(d, K)
+    x, Qs, label = _data(B, N, T, d, K)
+    sl = slice(rank * B // world, (rank + 1) * B // world)
+    red = vdist.GradReducer(model, bucket_mb=0.01)            # tiny buckets: several collectives
+    opt = torch.optim.Adam(model.parameters(), 1e-3)
+    crit = torch.nn.CrossEntropyLoss()
+    grads_step = []
+    for step in range(3):
+        loss = crit(model(x[sl], [qq[sl] for qq in Qs]), label[sl])
+        opt.zero_grad()
+        red.prepare()
+        loss.backward()
+        red.finish()
+        grads_step.append({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+        opt.step()
+    # plain numpy through the queue (tensor fd-sharing dies with the worker)
+    q.put((rank, red.unused, len(red.buckets), {n: g.numpy() for n, g in grads_step[0].items()},
+           {n: p.detach().numpy().copy() for n, p in model.named_parameters()}))
+    vdist.shutdown()
+
+
+@pytest.mark.timeout(300)
+def test_grad_reducer_world2_equals_full_batch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, unused0, nb0, g0, w0), (_, unused1, nb1, g1, w1) = res
+    g0, g1, w0, w1 = [{n: torch.from_numpy(v) for n, v in dct.items()} for dct in (g0, g1, w0, w1)]
+    assert unused0 == unused1 == ["co_attention.W_b.weight", "co_attention.W_b.bias"]
+    assert nb0 == nb1 and nb0 > 1
+    # single-process full batch reference
+    B, N, T, d, K = 8, 9, 5, 32, 7
+    model = _build(d, K)
+    x, Qs, label = _data(B, N, T, d, K)
+    opt = torch.optim.Adam(model.parameters(), 1e-3)
+    crit = torch.nn.CrossEntropyLoss()
+    first = None
+    for step in range(3):
+        loss = crit(model(x, Qs), label)
+        opt.zero_grad(); loss.backward()
+        if first is None:
+            first = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        opt.step()
+    for n, g in first.items():
+        assert torch.allclose(g0[n], g, atol=1e-6, rtol=1e-5) and torch.equal(g0[n], g1[n]), n
+    for n, p in model.named_parameters():
+        assert torch.equal(w0[n], w1[n]), n                                   # ranks in lockstep
+        if n.endswith("w_v.bias") or n.endswith("w_q.bias"):
+            continue     # analytically zero gradient: Adam turns its rounding noise into +-lr steps
+        assert torch.allclose(w0[n], p.detach(), atol=1e-5), n                # == big-batch training

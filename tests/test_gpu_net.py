@@ -1,0 +1,38 @@
+"""GPU: the whole `--model attention` network with the HIP co-attention op against the
+reference goldens G7 (logits) and G8 (3 Adam steps: loss trajectory), main.py:178-222.
+Tolerance is looser than the op-level 1e-4 because the stock MIOpen convolutions / BatchNorm of
+the frozen VGG feed the path here (observed ~1e-4 on logits)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.golden_cases import NET_CASE, closed_form_state, net_case_batch
+from tests._golden import GOLDEN_DIR
+
+pytestmark = pytest.mark.gpu
+
+
+def test_attention_net_logits_and_train_steps_vs_reference():
+    from vqa_amd import train as T
+    from vqa_amd.modules import HierarchicalCoAttentionNet
+    c = NET_CASE
+    gold = np.load(os.path.join(GOLDEN_DIR, "net_cases.npz"))
+    qp = dict(vocab_size=c["vocab"], word_emb_dim=c["hidden"], hidden_dim=c["hidden"])
+    net = HierarchicalCoAttentionNet(qp, dict(is_trainable=False, weights_path=None), K=c["K"] + 1)
+    sd = closed_form_state(net, c["seed"])
+    net.load_state_dict(sd)
+    net = net.cuda()
+    image, question, lens, label = net_case_batch()
+    batch = (image.cuda(), question.cuda(), lens, label.cuda())
+    logits = net(*batch[:3])
+    err = np.abs(logits.detach().cpu().numpy() - gold["g7_logits"]).max()
+    print("G7 logits err", err)
+    assert err < 2e-3
+    net.load_state_dict(sd)
+    tr = T.Trainer(net, c["lr"], torch.device("cuda:0"))
+    losses = [float(tr.step(*batch)) for _ in range(c["steps"])]
+    print("G8 losses", losses, gold["g8_losses"])
+    assert np.abs(np.array(losses) - gold["g8_losses"]).max() < 5e-3
+    assert torch.equal(net.co_attention.W_b.weight.cpu(), sd["co_attention.W_b.weight"])   # never updated

@@ -11,7 +11,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 # every symbol include/coattn.h declares
 EXPORTS = ("coattn_version", "coattn_last_error", "coattn_fused_supported", "coattn_workspace_bytes",
-           "coattn_forward", "coattn_backward", "coattn_gemm_f32")
+           "coattn_forward", "coattn_attention_forward", "coattn_backward", "coattn_gemm_f32")
 
 F32 = 0
 IMPL_AUTO, IMPL_GENERAL, IMPL_FUSED = 0, 1, 2
@@ -68,6 +68,7 @@ def load() -> C.CDLL:
     lib.coattn_workspace_bytes.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_size_t)] * 3
     lib.coattn_forward.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(Params), C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]
+    lib.coattn_attention_forward.argtypes = lib.coattn_forward.argtypes
     lib.coattn_backward.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(Params), C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(ParamGrads), C.c_int,
                                     C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]

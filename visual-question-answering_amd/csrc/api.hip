@@ -155,14 +155,21 @@ int c_times(const Ctx& c, const float* C, const float* Y, const float* X, float*
   return launch_gemm_f32(g, c.s);
 }
 
-int forward_general(const Ctx& c, const float* V, const float* const* Q, const coattn_params* p, float* v_out,
-                    float* q_out, float* sv, float* Hv) {
+int general_projections(const Ctx& c, const float* V, const float* const* Q, const coattn_params* p, float* sv) {
+  const SavedPlan sp = plan_saved(c.B, c.N, c.T, c.d, c.L);
+  const size_t BTd = (size_t)c.B * c.T * c.d;
+  CA_TRY(proj_v(c, V, (const float*)p->W_v, (const float*)p->b_v, sv + sp.Pv));
+  for (int l = 0; l < c.L; ++l)
+    CA_TRY(proj_q(c, Q[l], (const float*)p->W_q, (const float*)p->b_q, sv + sp.Pq + l * BTd));
+  return 0;
+}
+
+// everything after the projections: affinity, H_v / H_q, scores, softmax, attended reductions
+int general_attention(const Ctx& c, const float* V, const float* const* Q, const coattn_params* p, float* v_out,
+                      float* q_out, float* sv, float* Hv) {
   const SavedPlan sp = plan_saved(c.B, c.N, c.T, c.d, c.L);
   float* Pv = sv + sp.Pv;
   const size_t BTd = (size_t)c.B * c.T * c.d, BTN = (size_t)c.B * c.T * c.N;
-  CA_TRY(proj_v(c, V, (const float*)p->W_v, (const float*)p->b_v, Pv));
-  for (int l = 0; l < c.L; ++l)
-    CA_TRY(proj_q(c, Q[l], (const float*)p->W_q, (const float*)p->b_q, sv + sp.Pq + l * BTd));
   for (int l = 0; l < c.L; ++l) {
     float* Pq = sv + sp.Pq + l * BTd;
     float* C = sv + sp.C + l * BTN;
@@ -344,9 +351,9 @@ int pick_impl(int flags, int B, int N, int T, int d, int L, int* fused) {
 
 }  // namespace
 
-extern "C" int coattn_forward(const void* V, const void* const* Q, const coattn_params* p, void* v_out, void* q_out,
-                              void* saved, void* ws, int B, int N, int T, int d, int L, int dtype, int flags,
-                              void* stream) {
+static int forward_impl(const void* V, const void* const* Q, const coattn_params* p, void* v_out, void* q_out,
+                        void* saved, void* ws, int B, int N, int T, int d, int L, int dtype, int flags, void* stream,
+                        bool do_proj, bool do_attn) {
   CA_TRY(check_shape(B, N, T, d, L, dtype));
   CA_CHECK_ARG(V && Q && p && v_out && q_out && ws, "forward: null argument");
   for (int l = 0; l < L; ++l) CA_CHECK_ARG(Q[l] != nullptr, "forward: Q[%d] is null", l);
@@ -358,10 +365,25 @@ extern "C" int coattn_forward(const void* V, const void* const* Q, const coattn_
   float* sv = saved ? (float*)saved : (float*)ws;      // inference: state lives in the workspace
   float* tail = (float*)ws + sp.total;
   Ctx c{B, N, T, d, L, (hipStream_t)stream};
+  if (do_proj) CA_TRY(general_projections(c, (const float*)V, (const float* const*)Q, p, sv));
+  if (!do_attn) return 0;
   if (fused)
-    return fused_forward(B, N, T, d, L, (const float*)V, (const float* const*)Q, p, (float*)v_out, (float*)q_out, sv,
-                         tail, c.s);
-  return forward_general(c, (const float*)V, (const float* const*)Q, p, (float*)v_out, (float*)q_out, sv, tail);
+    return fused_attention_forward(B, N, T, d, L, (const float*)V, (const float* const*)Q, p, (float*)v_out,
+                                   (float*)q_out, sv, tail, c.s);
+  return general_attention(c, (const float*)V, (const float* const*)Q, p, (float*)v_out, (float*)q_out, sv, tail);
+}
+
+extern "C" int coattn_forward(const void* V, const void* const* Q, const coattn_params* p, void* v_out, void* q_out,
+                              void* saved, void* ws, int B, int N, int T, int d, int L, int dtype, int flags,
+                              void* stream) {
+  return forward_impl(V, Q, p, v_out, q_out, saved, ws, B, N, T, d, L, dtype, flags, stream, true, true);
+}
+
+extern "C" int coattn_attention_forward(const void* V, const void* const* Q, const coattn_params* p, void* v_out,
+                                        void* q_out, void* saved, void* ws, int B, int N, int T, int d, int L,
+                                        int dtype, int flags, void* stream) {
+  CA_CHECK_ARG(saved != nullptr, "attention_forward: needs the saved buffer of a previous coattn_forward");
+  return forward_impl(V, Q, p, v_out, q_out, saved, ws, B, N, T, d, L, dtype, flags, stream, false, true);
 }
 
 extern "C" int coattn_backward(const void* V, const void* const* Q, const coattn_params* p, const void* saved,

@@ -2,8 +2,8 @@
 #include "fused.h"
 
 int fused_supported(int, int, int, int, int) { return 0; }
-int fused_forward(int, int, int, int, int, const float*, const float* const*, const coattn_params*, float*, float*,
-                  float*, float*, hipStream_t) {
+int fused_attention_forward(int, int, int, int, int, const float*, const float* const*, const coattn_params*, float*,
+                            float*, float*, float*, hipStream_t) {
   coattn_set_error("fused forward not built");
   return -2;
 }

@@ -1,0 +1,151 @@
+"""Data-parallel training support: one process per GPU, gradients averaged with bucketed
+all-reduce (RCCL over xGMI through ``torch.distributed`` backend "nccl"; "gloo" on CPU).
+
+The reference has no multi-GPU path (commented TODO, main.py:71, :102-106); the co-attention
+model shards naturally by QA pair, so the only exchange step is the gradient mean
+(SURVEY.md section 8e).  ``GradReducer`` differs from stock DDP where this model needs it:
+
+* ``co_attention.W_b`` is constructed but never used (model.py:347 vs :377), so it never gets a
+  gradient; stock DDP (find_unused_parameters=False) fails on step 2.  The reducer learns the
+  set of parameters that actually receive gradients on the first step and buckets only those.
+* buffers (frozen-VGG BatchNorm statistics, model.py:239-241) are never broadcast.
+* buckets are filled in reverse registration order (~ backward order) and each all-reduce is
+  launched asynchronously as soon as its bucket is complete, overlapping with the rest of
+  backward; xGMI is point-to-point, so buckets are kept large (default 16 MB: the ~49 MB
+  gradient of the attention model goes out in 3-4 collectives).
+"""
+from __future__ import annotations
+
+import os
+from typing import List
+
+import torch
+import torch.distributed as dist
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def init_from_env(backend: str | None = None):
+    """Join the process group described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).
+    Returns (rank, world, local_rank); a no-op for single-process runs."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rk = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rk, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rk, world_size=world)
+    return rk, world, local
+
+
+def shutdown():
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+class _Bucket:
+    def __init__(self, params: List[torch.nn.Parameter]):
+        self.params = params
+        n = sum(p.numel() for p in params)
+        self.flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
+        self.views, o = [], 0
+        for p in params:
+            self.views.append(self.flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+        self.pending = len(params)
+        self.work = None
+
+
+class GradReducer:
+    """Averages ``.grad`` of a module's parameters across ranks.
+
+    Usage per step:  ``prepare()`` -> ``loss.backward()`` -> ``finish()`` -> ``optimizer.step()``.
+    """
+
+    def __init__(self, module: torch.nn.Module, bucket_mb: float = 16.0, group=None):
+        self.module = module
+        self.group = group
+        self.bucket_bytes = int(bucket_mb * (1 << 20))
+        self.world = dist.get_world_size(group)
+        self.buckets: List[_Bucket] | None = None      # built after the first backward
+        self._where = {}
+        self._hooks = []
+        self.unused: List[str] = []
+
+    # -- bucket construction (after the first backward: only parameters that got a gradient) ----
+    def _build(self):
+        named = [(n, p) for n, p in self.module.named_parameters() if p.requires_grad]
+        self.unused = [n for n, p in named if p.grad is None]
+        live = [p for _, p in named if p.grad is not None][::-1]      # ~ order gradients become ready
+        # every rank must agree on the layout
+        sig = torch.tensor([len(live), sum(p.numel() for p in live)], dtype=torch.int64, device=live[0].device)
+        lo, hi = sig.clone(), sig.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        if not (torch.equal(lo, sig) and torch.equal(hi, sig)):
+            raise RuntimeError("ranks disagree on which parameters receive gradients")
+        self.buckets, cur, size = [], [], 0
+        for p in live:
+            nbytes = p.numel() * p.element_size()
+            if cur and (size + nbytes > self.bucket_bytes or p.dtype != cur[0].dtype):
+                self.buckets.append(_Bucket(cur))
+                cur, size = [], 0
+            cur.append(p)
+            size += nbytes
+        if cur:
+            self.buckets.append(_Bucket(cur))
+        for bi, b in enumerate(self.buckets):
+            for pi, p in enumerate(b.params):
+                self._where[p] = (bi, pi)
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def _on_grad(self, p):
+        bi, pi = self._where[p]
+        b = self.buckets[bi]
+        b.views[pi].copy_(p.grad)
+        b.pending -= 1
+        if b.pending == 0:
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    # -- per step -----------------------------------------------------------------------------
+    def prepare(self):
+        if self.buckets is not None:
+            for b in self.buckets:
+                b.pending, b.work = len(b.params), None
+
+    def finish(self):
+        if self.buckets is None:
+            # first step: no overlap; discover the live parameter set, reduce synchronously
+            self._build()
+            for b in self.buckets:
+                for v, p in zip(b.views, b.params):
+                    v.copy_(p.grad)
+                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        for b in self.buckets:
+            if b.work is None:                          # a parameter of this bucket got no gradient this step
+                for v, p in zip(b.views, b.params):
+                    v.copy_(p.grad) if p.grad is not None else v.zero_()
+                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        for b in self.buckets:
+            b.work.wait()
+            b.flat.div_(self.world)
+            for v, p in zip(b.views, b.params):
+                if p.grad is None:
+                    p.grad = v.clone()
+                else:
+                    p.grad.copy_(v)
+
+    def payload_bytes(self) -> int:
+        return sum(b.flat.numel() * b.flat.element_size() for b in (self.buckets or []))

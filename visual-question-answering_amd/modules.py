@@ -1,0 +1,212 @@
+"""Callers and feeders of the co-attention path, on stock PyTorch-ROCm.
+
+Everything here is ordinary ``torch.nn`` (MIOpen convolutions / LSTM, hipBLASLt GEMMs): the
+image and question encoders stay stock by design (BASELINE.json north_star); only
+``co_attention`` is the hand-written HIP path.  Class names, constructor arguments, submodule
+attribute names (= ``state_dict`` keys) and ``forward`` signatures follow the reference so that
+its checkpoints load and its training loop drives these modules unchanged:
+
+  HierarchicalCoAttentionNet   model.py:157-187      VQABaselineNet            model.py:10-38
+  ImageCoAttentionEncoder      model.py:190-243      ImageBaselineEncoder      model.py:41-105
+  QuestionCoAttentionEncoder   model.py:246-298      QuestionBaselineEncoder   model.py:108-151
+  PhraseConvPool               model.py:301-334      MLPClassifier             model.py:400-434
+
+torchvision is not installed here, so the VGG11-bn topology (cfg "A" + BatchNorm) is spelled
+out; a torchvision ``vgg11_bn`` state_dict file loads into it through ``weights_path``.
+"""
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
+
+from .coattention import ParallelCoAttention
+
+_VGG11_CFG = (64, "M", 128, "M", 256, 256, "M", 512, 512, "M", 512, 512, "M")
+
+
+def vgg11_bn_features() -> nn.Sequential:
+    """conv3x3-BN-ReLU stacks with five 2x2 max-pools: 448x448 -> 14x14x512, 224x224 -> 7x7x512."""
+    mods, c_in = [], 3
+    for item in _VGG11_CFG:
+        if item == "M":
+            mods.append(nn.MaxPool2d(2, 2))
+            continue
+        mods.extend((nn.Conv2d(c_in, item, 3, padding=1), nn.BatchNorm2d(item), nn.ReLU(inplace=True)))
+        c_in = item
+    return nn.Sequential(*mods)
+
+
+def _vgg11_bn_classifier_head() -> list:
+    """torchvision's classifier minus the final FC-1000 (model.py:93)."""
+    return [nn.Linear(512 * 7 * 7, 4096), nn.ReLU(True), nn.Dropout(), nn.Linear(4096, 4096), nn.ReLU(True),
+            nn.Dropout()]
+
+
+def _load_vgg_weights(features: nn.Module, classifier: nn.Module | None, weights_path):
+    """Load a torchvision vgg11_bn state_dict file if one is given and present (model.py:232-233).
+    Without a file the reference would download pretrained weights; there is no network here, so
+    the encoder keeps its random init."""
+    if not weights_path or not os.path.isfile(str(weights_path)):
+        return False
+    sd = torch.load(weights_path, map_location="cpu")
+    features.load_state_dict({k[len("features."):]: v for k, v in sd.items() if k.startswith("features.")})
+    if classifier is not None:
+        cls = {k[len("classifier."):]: v for k, v in sd.items() if k.startswith("classifier.")}
+        classifier.load_state_dict({k: v for k, v in cls.items() if not k.startswith("6.")}, strict=False)
+    return True
+
+
+class ImageCoAttentionEncoder(nn.Module):
+    """VGG11-bn ``features`` -> spatial grid [B, N, 512] (a permuted view of [B, 512, N])."""
+
+    def __init__(self, is_trainable, weights_path):
+        super().__init__()
+        self.is_trainable = is_trainable
+        self.weights_path = weights_path
+        self.vgg11_encoder = vgg11_bn_features()
+        _load_vgg_weights(self.vgg11_encoder, None, weights_path)
+        self.flatten = nn.Flatten(start_dim=2, end_dim=3)
+        if not is_trainable:                      # frozen; BatchNorm stays in train mode (model.py:239-241)
+            for prm in self.vgg11_encoder.parameters():
+                prm.requires_grad = False
+
+    def forward(self, x_img):
+        grid = self.flatten(self.vgg11_encoder(x_img))      # [B, 512, N]
+        return grid.permute(0, 2, 1)                         # [B, N, 512] view, strides (512N, 1, N)
+
+
+class PhraseConvPool(nn.Module):
+    """1/2/3-gram Conv1d + tanh, then a max over 3 CONSECUTIVE channels of the concatenated
+    [uni|bi|tri] vector -- the reference's reshape (model.py:324-332) groups channels 3e..3e+2,
+    not the three n-gram responses of one channel; reproduced as is."""
+
+    def __init__(self, emb_dim):
+        super().__init__()
+        self.conv_unigram = nn.Sequential(nn.ConstantPad1d((0, 0), 0), nn.Conv1d(emb_dim, emb_dim, 1, 1), nn.Tanh())
+        self.conv_bigram = nn.Sequential(nn.ConstantPad1d((1, 0), 0), nn.Conv1d(emb_dim, emb_dim, 2, 1), nn.Tanh())
+        self.conv_trigram = nn.Sequential(nn.ConstantPad1d((1, 1), 0), nn.Conv1d(emb_dim, emb_dim, 3, 1), nn.Tanh())
+        self.max_pool = nn.MaxPool2d(kernel_size=(1, 3))
+
+    def forward(self, x_question):
+        B, T, E = x_question.shape
+        x = x_question.permute(0, 2, 1)                                          # [B, E, T]
+        grams = torch.cat([self.conv_unigram(x), self.conv_bigram(x), self.conv_trigram(x)], dim=1)
+        grams = grams.permute(0, 2, 1).reshape(B, T, E, 3)                       # groups of 3 consecutive channels
+        return self.max_pool(grams).squeeze(dim=3)                               # [B, T, E]
+
+
+class QuestionCoAttentionEncoder(nn.Module):
+    """word (embedding) / phrase (n-gram conv + pool) / sentence (LSTM) features, each [B,T,hidden];
+    rows past a question's length are exact zeros at all three levels (padding_idx=0, packed LSTM)."""
+
+    def __init__(self, vocab_size, word_emb_dim, hidden_dim):
+        super().__init__()
+        self.vocab_size, self.embedding_dim, self.hidden_dim = vocab_size, word_emb_dim, hidden_dim
+        self.word_embedding = nn.Embedding(vocab_size, word_emb_dim, padding_idx=0)
+        self.phrase_conv_pool = PhraseConvPool(word_emb_dim)
+        self.sentence_lstm = nn.LSTM(word_emb_dim, hidden_dim)
+
+    def forward(self, x, x_lens):
+        T = x.shape[1]
+        lens = x_lens.cpu() if torch.is_tensor(x_lens) else x_lens    # pack_padded_sequence wants CPU lengths
+        words = self.word_embedding(x)
+        phrases = pack_padded_sequence(self.phrase_conv_pool(words), lens, batch_first=True)
+        sentence, _ = self.sentence_lstm(phrases)
+        phrases = pad_packed_sequence(phrases, batch_first=True, total_length=T)[0]
+        sentence = pad_packed_sequence(sentence, batch_first=True, total_length=T)[0]
+        return words, phrases, sentence
+
+
+class MLPClassifier(nn.Module):
+    """Recursive word -> phrase -> sentence answer head (model.py:414-434)."""
+
+    def __init__(self, hidden_dim, mlp_dim, K):
+        super().__init__()
+        self.W_w = nn.Linear(hidden_dim, hidden_dim)
+        self.W_p = nn.Linear(2 * hidden_dim, hidden_dim)
+        self.W_s = nn.Linear(2 * hidden_dim, mlp_dim)
+        self.W_h = nn.Linear(mlp_dim, K)
+
+    def forward(self, x_img_feats, x_ques_feats):
+        (q_w, q_p, q_s), (v_w, v_p, v_s) = x_ques_feats, x_img_feats
+        h_w = torch.tanh(self.W_w(q_w + v_w))
+        h_p = torch.tanh(self.W_p(torch.cat([q_p + v_p, h_w], dim=1)))
+        h_s = torch.tanh(self.W_s(torch.cat([q_s + v_s, h_p], dim=1)))
+        return self.W_h(h_s)
+
+
+class HierarchicalCoAttentionNet(nn.Module):
+    """question encoder -> image encoder -> parallel co-attention (HIP) -> MLP logits [B, K]."""
+
+    def __init__(self, ques_enc_params, img_enc_params, K, mlp_dim=1024):
+        super().__init__()
+        self.hidden_dim = ques_enc_params["hidden_dim"]
+        self.image_encoder = ImageCoAttentionEncoder(**img_enc_params)
+        self.question_encoder = QuestionCoAttentionEncoder(**ques_enc_params)
+        self.co_attention = ParallelCoAttention(self.hidden_dim)
+        self.mlp_classify = MLPClassifier(self.hidden_dim, mlp_dim, K)
+
+    def forward(self, x_img, x_ques, x_ques_lens):
+        x_ques_features = list(self.question_encoder(x_ques, x_ques_lens))
+        x_img_features = self.image_encoder(x_img)
+        x_img_attn, x_ques_attn = self.co_attention(x_img_features, x_ques_features)
+        return self.mlp_classify(x_img_attn, x_ques_attn)
+
+
+# ---- baseline model (BASELINE config 1: CPU plumbing, no custom kernels) ------------------
+class ImageBaselineEncoder(nn.Module):
+    """VGG11-bn up to fc7 (4096), L2-normalised, -> 1024 tanh."""
+
+    def __init__(self, is_trainable, weights_path):
+        super().__init__()
+        self.is_trainable, self.weights_path = is_trainable, weights_path
+        features = vgg11_bn_features()
+        head = nn.Sequential(*_vgg11_bn_classifier_head())
+        _load_vgg_weights(features, head, weights_path)
+        self.vgg11_encoder = nn.Sequential(OrderedDict([
+            ("conv_layers", features), ("avgpool", nn.AdaptiveAvgPool2d((7, 7))),
+            ("fc_layers", nn.Sequential(nn.Flatten(), *list(head)))]))
+        self.embedding_layer = nn.Sequential(nn.Linear(4096, 1024), nn.Tanh())
+        if not is_trainable:
+            for prm in self.vgg11_encoder.parameters():
+                prm.requires_grad = False
+
+    def forward(self, x_img):
+        return self.embedding_layer(F.normalize(self.vgg11_encoder(x_img), dim=1, p=2))
+
+
+class QuestionBaselineEncoder(nn.Module):
+    """Embedding + tanh -> GRU (last non-pad state via packing) -> 1024 tanh."""
+
+    def __init__(self, vocab_size, word_emb_dim, hidden_dim):
+        super().__init__()
+        self.hidden_dim, self.vocab_size, self.word_emb_dim = hidden_dim, vocab_size, word_emb_dim
+        self.word_embedding = nn.Sequential(nn.Embedding(vocab_size, word_emb_dim), nn.Tanh())
+        self.gru = nn.GRU(word_emb_dim, hidden_dim)
+        self.embedding_layer = nn.Sequential(nn.Linear(hidden_dim, 1024), nn.Tanh())
+
+    def forward(self, x, seq_lengths):
+        lens = seq_lengths.cpu() if torch.is_tensor(seq_lengths) else seq_lengths
+        packed = pack_padded_sequence(self.word_embedding(x), lens, batch_first=True)
+        _, hidden = self.gru(packed)
+        return self.embedding_layer(torch.squeeze(hidden, dim=0))
+
+
+class VQABaselineNet(nn.Module):
+    """Element-wise product of image and question embeddings -> MLP -> logits."""
+
+    def __init__(self, ques_enc_params, img_enc_params, K):
+        super().__init__()
+        self.image_encoder = ImageBaselineEncoder(**img_enc_params)
+        self.question_encoder = QuestionBaselineEncoder(**ques_enc_params)
+        self.mlp = nn.Sequential(nn.Linear(1024, 1000), nn.Dropout(0.5), nn.Tanh())
+        self.fc_final = nn.Linear(1000, K)
+
+    def forward(self, x_img, x_ques, x_ques_len):
+        joint = self.image_encoder(x_img) * self.question_encoder(x_ques, x_ques_len)
+        return self.fc_final(self.mlp(joint))

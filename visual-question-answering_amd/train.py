@@ -1,0 +1,178 @@
+"""Training loop of the reference (``main.py``) restated for MI355X: same ``--model attention``
+registry, same step order (sort batch by length -> H2D -> forward -> CrossEntropyLoss ->
+zero_grad -> backward -> Adam step; main.py:193-222), plus what the reference lacks: synthetic
+data (no dataset / network here) and data-parallel training, one process per GPU, with RCCL
+gradient all-reduce (``vqa_amd.dist``).  apex AMP (main.py:185) is CUDA-only; ``--opt_lvl 0``
+(fp32) is the parity mode, levels >= 1 map to ``torch.autocast(bfloat16)`` around the stock
+encoders while the co-attention path keeps computing in fp32.
+
+Run:  python -m torch.distributed.run --nproc-per-node N -m vqa_amd.train --synthetic ...
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import time
+from typing import Dict
+
+import torch
+import torch.nn as nn
+
+from . import dist as vdist
+from .modules import HierarchicalCoAttentionNet, VQABaselineNet
+
+PATH_VGG_WEIGHTS = None      # the reference hard-codes a local .pth (utils.py:15); none ships here
+
+
+def str2bool(v):
+    return str(v).lower() in ("yes", "true", "t", "1")
+
+
+def int_min_two(k):
+    k = int(k)
+    if k < 2:
+        raise argparse.ArgumentTypeError("must be >= 2")
+    return k
+
+
+def setup_model_configs(model_name: str, vocab_size: int, vgg_train: bool = False, vgg_wts_path=None) -> dict:
+    """--model -> class, image size and encoder parameters (main.py:388-418).  The 'attention'
+    entry's ``mlp_dim`` key is carried but never forwarded by the reference (main.py:164), so the
+    model's own default (1024, model.py:160) applies; both are 1024."""
+    img = dict(is_trainable=vgg_train, weights_path=vgg_wts_path or PATH_VGG_WEIGHTS)
+    registry = {
+        "baseline": dict(model=VQABaselineNet, image_size=(224, 224), image_params=img,
+                         question_params=dict(vocab_size=vocab_size, word_emb_dim=300, hidden_dim=1024)),
+        "attention": dict(model=HierarchicalCoAttentionNet, image_size=(448, 448), image_params=img,
+                          question_params=dict(vocab_size=vocab_size, word_emb_dim=512, hidden_dim=512),
+                          mlp_dim=1024),
+    }
+    return registry[model_name]      # 'bert' is accepted by the reference's argparse but has no entry: KeyError
+
+
+def build_model(model_name: str, vocab_size: int, num_cls: int, **kw) -> nn.Module:
+    """K + 1 output classes: index 0 is UNKNOWN (main.py:155)."""
+    cfg = setup_model_configs(model_name, vocab_size, **kw)
+    return cfg["model"](cfg["question_params"], cfg["image_params"], K=num_cls + 1)
+
+
+def sort_batch(images, questions, answers, ques_seq_lens):
+    """Descending by question length, as packing requires (utils.py:33-45)."""
+    ques_seq_lens, order = ques_seq_lens.sort(dim=0, descending=True)
+    return images[order], questions[order], answers[order], ques_seq_lens
+
+
+def synthetic_batch(batch_size: int, image_size, max_seq_len: int, vocab_size: int, num_classes: int,
+                    seed: int) -> Dict[str, torch.Tensor]:
+    """One batch shaped like VQADataset's output (dataloader.py:72): images N(0,1), token ids
+    U{2..vocab-1} zero-padded to max_seq_len, lengths U{3..max} with at least one full-length
+    question, labels U{0..num_classes-1}.  CPU tensors; lengths are NOT sorted (sort_batch does)."""
+    g = torch.Generator().manual_seed(seed)
+    H, W = image_size
+    image = torch.randn(batch_size, 3, H, W, generator=g)
+    lens = torch.randint(min(3, max_seq_len), max_seq_len + 1, (batch_size,), generator=g)
+    lens[int(torch.randint(0, batch_size, (1,), generator=g))] = max_seq_len
+    question = torch.randint(2, vocab_size, (batch_size, max_seq_len), generator=g)
+    question = question * (torch.arange(max_seq_len)[None, :] < lens[:, None])
+    label = torch.randint(0, num_classes, (batch_size,), generator=g)
+    return {"image": image, "question": question, "ques_len": lens, "label": label}
+
+
+class Trainer:
+    """Owns model, Adam (lr, PyTorch defaults: main.py:180), loss and the gradient reducer."""
+
+    def __init__(self, model: nn.Module, lr: float = 1e-4, device=None, opt_lvl: int = 0,
+                 bucket_mb: float = 16.0):
+        self.device = device or next(model.parameters()).device
+        self.model = model
+        self.criterion = nn.CrossEntropyLoss()
+        self.optimizer = torch.optim.Adam(model.parameters(), lr)
+        self.opt_lvl = opt_lvl
+        self.reducer = vdist.GradReducer(model, bucket_mb=bucket_mb) if vdist.world_size() > 1 else None
+
+    def step(self, image, question, ques_len, label) -> torch.Tensor:
+        """One optimisation step on device-resident, length-sorted tensors; returns the loss."""
+        if self.opt_lvl > 0 and self.device.type == "cuda":
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                logits = self.model(image, question, ques_len)
+        else:
+            logits = self.model(image, question, ques_len)
+        loss = self.criterion(logits.float(), label)
+        self.optimizer.zero_grad()
+        if self.reducer is not None:
+            self.reducer.prepare()
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.optimizer.step()
+        return loss
+
+    @torch.no_grad()
+    def validate(self, batches) -> Dict[str, float]:
+        """Accuracy / mean CE under eval() (main.py:290-351, without its n_iters+1 / n_iters slip)."""
+        self.model.eval()
+        n_ok = n = 0
+        loss = 0.0
+        for image, question, ques_len, label in batches:
+            logits = self.model(image, question, ques_len)
+            loss += float(self.criterion(logits.float(), label))
+            n_ok += int((logits.argmax(1) == label).sum())
+            n += label.numel()
+        self.model.train()
+        return {"accuracy": 100.0 * n_ok / max(n, 1), "loss": loss / max(len(batches), 1)}
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="Visual Question Answering (MI355X co-attention path)")
+    ap.add_argument("--mode", default="train", choices=["train", "test"])
+    ap.add_argument("--model", default="attention", choices=["baseline", "attention", "bert"])
+    ap.add_argument("--num_cls", "-K", type=int_min_two, default=1000)
+    ap.add_argument("--batch_size", "-bs", type=int, default=8)
+    ap.add_argument("--num_steps", type=int, default=20)
+    ap.add_argument("--learning_rate", "-lr", type=float, default=1e-4)
+    ap.add_argument("--log_interval", type=int, default=10)
+    ap.add_argument("--vgg_wts_path", type=str, default=None)
+    ap.add_argument("--vgg_train", type=str2bool, default="false")
+    ap.add_argument("--opt_lvl", type=int, default=0, choices=[0, 1, 2, 3])
+    ap.add_argument("--synthetic", type=str2bool, default="true", help="synthetic data (the only source here)")
+    ap.add_argument("--vocab_size", type=int, default=10000)
+    ap.add_argument("--max_seq_length", type=int, default=26)
+    ap.add_argument("--image_size", type=int, default=0, help="override the model's image size (0 = registry)")
+    ap.add_argument("--model_ckpt", type=str, default=None)
+    ap.add_argument("--save_path", type=str, default=None)
+    args = ap.parse_args(argv)
+    if args.mode == "test":
+        raise NotImplementedError("TODO: test mode")          # as the reference, main.py:286-287
+    if not args.synthetic:
+        raise SystemExit("only --synthetic true is available: the VQA dataset is not present in this environment")
+
+    rank, world, local = vdist.init_from_env()
+    device = torch.device("cuda", local) if torch.cuda.is_available() else torch.device("cpu")
+    if device.type == "cuda":
+        torch.cuda.set_device(device)
+    torch.manual_seed(0)                                        # identical weights on every rank
+    cfg = setup_model_configs(args.model, args.vocab_size, args.vgg_train, args.vgg_wts_path)
+    model = build_model(args.model, args.vocab_size, args.num_cls, vgg_train=args.vgg_train,
+                        vgg_wts_path=args.vgg_wts_path)
+    if args.model_ckpt:
+        model.load_state_dict(torch.load(args.model_ckpt, map_location="cpu"))
+    model.to(device)
+    trainer = Trainer(model, args.learning_rate, device, args.opt_lvl)
+    size = (args.image_size, args.image_size) if args.image_size else cfg["image_size"]
+    t0 = time.time()
+    for step in range(args.num_steps):
+        b = synthetic_batch(args.batch_size, size, args.max_seq_length, args.vocab_size, args.num_cls + 1,
+                            seed=1234 + rank + 1000 * step)
+        image, question, label, ques_len = sort_batch(b["image"], b["question"], b["label"], b["ques_len"])
+        loss = trainer.step(image.to(device), question.to(device), ques_len, label.to(device))
+        if (step + 1) % args.log_interval == 0 and rank == 0:
+            print(json.dumps({"step": step + 1, "loss": round(float(loss), 5),
+                              "pairs_per_s": round(world * args.batch_size * (step + 1) / (time.time() - t0), 2)}))
+    if args.save_path and rank == 0:
+        torch.save(model.state_dict(), args.save_path)
+    vdist.shutdown()
+
+
+if __name__ == "__main__":
+    main()

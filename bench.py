@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--seq-len", type=int, default=26)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline / hot_path legs")
+    ap.add_argument("--only", type=str, default="", help="developer switch: run only 'roofline' or 'hot' legs")
     ap.add_argument("--cpu-batch", type=int, default=32)
     return ap.parse_args()
 
@@ -156,11 +157,23 @@ def roofline_leg(device, B=160, N=196, T=26, d=512, L=3, iters=50):
             "algorithmic_bytes": alg}
 
 
+def host_cores() -> int:
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline_leg(args):
     """The oracle port of the same train step on the host cores; bounded sample."""
     from oracle import net_oracle as NO
     from vqa_amd import train as T
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     qp = dict(vocab_size=args.vocab, word_emb_dim=512, hidden_dim=512)
@@ -184,6 +197,11 @@ def main():
     import vqa_amd
     from vqa_amd import dist as vdist
     from vqa_amd import train as T
+    if args.only:
+        dev = torch.device("cuda", 0)
+        res = roofline_leg(dev) if args.only == "roofline" else [hot_path_leg(dev, 196), hot_path_leg(dev, 49)]
+        print(json.dumps(res))
+        return
     rank, world, local = vdist.init_from_env()
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     device = torch.device("cuda", local)

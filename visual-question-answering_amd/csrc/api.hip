@@ -398,7 +398,7 @@ extern "C" int coattn_backward(const void* V, const void* const* Q, const coattn
   int fused = 0;
   CA_TRY(pick_impl(flags, B, N, T, d, L, &fused));
   Ctx c{B, N, T, d, L, (hipStream_t)stream};
-  if (fused)
+  if (fused && fused_backward_supported(B, N, T, d, L))
     return fused_backward(B, N, T, d, L, (const float*)V, (const float* const*)Q, p, (const float*)saved,
                           (const float*)gv, (const float*)gq, (float*)dV, (float* const*)dQ, pg, accumulate,
                           (float*)ws, c.s);

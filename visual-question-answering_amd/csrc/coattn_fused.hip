@@ -1,12 +1,440 @@
-// Fused co-attention kernels -- placeholder until the fused path lands.
+// Fused co-attention kernels for gfx950 (fp32, exact-f32 MFMA 16x16x4).
+//
+// Forward ("affinity + softmax + reduce", model.py:377-392 after the projections):
+//   coattn_attn_fwd_kernel : one workgroup per (sample b, level l); NW = d/128 waves.
+//     phase 1  A = Q V^T, K (=d) split over the waves: each wave streams its 128 channel rows
+//              of V [d][N] straight from HBM into MFMA B operands (every V element is used by
+//              exactly one wave, so no LDS staging) and its 128-column slice of Q as A operands;
+//              partial [T x N] tiles are summed through LDS in a fixed tree order, C = tanh(A)
+//              lands in LDS (and in `saved` for backward).
+//     phase 2  loop over 16-row tiles of P_v [N][d] (read once): the tile is the B operand of
+//              H_q += C . P_v (contraction over N) and then the accumulator of
+//              H_v = tanh(P_v + C^T P_q) (contraction over T); the wave owns a 128-wide slice of
+//              d, keeps its P_q slice in registers, and folds H_v into score partials
+//              s_v[n] += H_v[n][:] . w_v without ever writing H_v.
+//     phase 3  cross-wave score reduction, un-masked row softmax over N and over T
+//              (model.py:387-388) by wave shuffles, q = a_q^T Q, H_q saved for backward.
+//   attend_v_kernel        : v_l = a_{v,l}^T V for all levels with ONE more pass over V.
+//
+// Register/LDS budget at d=512 (NW=4, 256 threads): <= 256 VGPRs and < 80 KB LDS per workgroup,
+// so two workgroups share a CU (480 workgroups for B=160, L=3 on 256 CUs); block ids are mapped
+// so that the L levels of one sample run on the same XCD (shared L2 for V and P_v).
 #include "fused.h"
 
-int fused_supported(int, int, int, int, int) { return 0; }
-int fused_attention_forward(int, int, int, int, int, const float*, const float* const*, const coattn_params*, float*,
-                            float*, float*, float*, hipStream_t) {
-  coattn_set_error("fused forward not built");
-  return -2;
+namespace {
+
+constexpr int kTS = 7;       // k-steps of 4 over T: T <= 28
+constexpr int kTRows = 28;   // rows of C kept in LDS
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+
+struct FwdArgs {
+  const float* V;        // [B][d][N]
+  const float* Q[8];     // L x [B][T][d]
+  const float* Pv;       // [B][N][d]
+  const float* Pq;       // [L][B][T][d]
+  const float* wv; const float* cv; const float* wq; const float* cq;
+  float* C;              // [L][B][T][N]
+  float* av;             // [L][B][N]
+  float* aq;             // [L][B][T]
+  float* Hq;             // [L][B][T][d]
+  float* q_out;          // [L][B][d]
+  int B, N, T, d, L;
+};
+
+// XCD-aware block -> (b, l): blocks i and i+8 share an XCD (round-robin dispatch), so give the
+// L levels of one sample consecutive slots on one XCD.  Speed only; any mapping is correct.
+__device__ __forceinline__ bool block_to_pair(int bid, int B, int L, int& b, int& l) {
+  const int x = bid & 7, slot = bid >> 3;
+  b = (slot / L) * 8 + x;
+  l = slot % L;
+  return b < B;
+}
+
+template <int NT, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdArgs a) {
+  constexpr int NPAD = 16 * NT;
+  constexpr int LD = NPAD + 4;                       // row stride of the LDS [t][n] images
+  constexpr int NSLOT = (NW / 2 > 2) ? NW / 2 : 2;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* slots = lds;                                // NSLOT x kTRows x LD   (phase 1 reduction)
+  float* Cbuf = lds + NSLOT * kTRows * LD;           // kTRows x LD
+  float* svpart = slots;                             // NW x NPAD             (aliases, phase 2+)
+  float* sqpart = slots + NW * NPAD;                 // NW x 32
+  float* aqs = sqpart + NW * 32;                     // 32
+
+  int b, l;
+  if (!block_to_pair(blockIdx.x, a.B, a.L, b, l)) return;
+  const int N = a.N, T = a.T, d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int j = lane & 15, q4 = lane >> 4;           // MFMA column / k-quad (also C/D row quad)
+  const float* Qp = a.Q[l] + (size_t)b * T * d;
+  const float* Vp = a.V + (size_t)b * d * N;
+  const float* Pvp = a.Pv + (size_t)b * N * d;
+  const float* Pqp = a.Pq + ((size_t)l * a.B + b) * T * d;
+  const size_t pair = (size_t)l * a.B + b;
+
+  // ------------------------------------------------------------------ phase 1: A = Q V^T
+  {
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[tt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ks = w * 128;
+    float vb[2][NT];
+    f32x4 qa[2][2];
+    // A operand (Q): lane (row t = 16tt + j, quad q4) holds Q[t][k0 + 4*q4 + s], s = 0..3
+    // B operand (V): lane (col n = 16tile + j, quad q4) holds V[k0 + 4*q4 + s][n]
+    auto load_q = [&](int kb, f32x4(&dst)[2]) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = 16 * tt + j;
+        dst[tt] = (t < T) ? *reinterpret_cast<const f32x4*>(Qp + (size_t)t * d + ks + 16 * kb + 4 * q4)
+                          : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    auto load_v = [&](int u, float(&dst)[NT]) {
+      const int krow = ks + 16 * (u >> 2) + 4 * q4 + (u & 3);
+      const float* vr = Vp + (size_t)krow * N;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int n = 16 * t + j;
+        dst[t] = (n < N) ? vr[n] : 0.f;
+      }
+    };
+    load_q(0, qa[0]);
+    load_v(0, vb[0]);
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {                   // 32 k-steps of 4 = this wave's 128 channels
+      if (u + 1 < 32) {
+        load_v(u + 1, vb[(u + 1) & 1]);
+        if (((u + 1) & 3) == 0) load_q((u + 1) >> 2, qa[((u + 1) >> 2) & 1]);
+      }
+      const int s = u & 3, qb = (u >> 2) & 1;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        acc[0][t] = mfma16(qa[qb][0][s], vb[u & 1][t], acc[0][t]);
+        acc[1][t] = mfma16(qa[qb][1][s], vb[u & 1][t], acc[1][t]);
+      }
+    }
+    // cross-wave sum in a fixed tree order through LDS; C/D layout: col = j, row = 4*q4 + r
+    auto put = [&](float* slot) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * tt + 4 * q4 + r;
+            if (row < kTRows) slot[row * LD + 16 * t + j] = acc[tt][t][r];
+          }
+    };
+    auto add = [&](const float* slot) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * tt + 4 * q4 + r;
+            if (row < kTRows) acc[tt][t][r] += slot[row * LD + 16 * t + j];
+          }
+    };
+#pragma unroll
+    for (int stride = 1; stride < NW / 2; stride <<= 1) {
+      const int m = 2 * stride - 1;
+      if (stride > 1) __syncthreads();
+      if ((w & m) == stride) put(slots + (w / (2 * stride)) * kTRows * LD);
+      __syncthreads();
+      if ((w & m) == 0) add(slots + (w / (2 * stride)) * kTRows * LD);
+    }
+    if (NW > 2) __syncthreads();
+    if (w == NW / 2) put(slots);
+    if (w == 0) put(slots + kTRows * LD);
+    __syncthreads();
+    // C = tanh(sum) by all threads; rows >= T are tanh(0) = 0 (their Q rows were masked)
+    float* Cg = a.C + pair * (size_t)T * N;
+    for (int e = tid; e < kTRows * NPAD; e += NW * 64) {
+      const int row = e / NPAD, col = e - row * NPAD;
+      const float c = tanh_fast(slots[row * LD + col] + slots[kTRows * LD + row * LD + col]);
+      Cbuf[row * LD + col] = c;
+      if (row < T && col < N) Cg[(size_t)row * N + col] = c;
+    }
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ phase 2: H_v scores, H_q
+  const int dsl = w * 128;
+  float pq[kTS][8];                                  // B operand P_q[t = 4s + q4][dsl + 16c + j]
+#pragma unroll
+  for (int s = 0; s < kTS; ++s) {
+    const int t = 4 * s + q4;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) pq[s][c] = (t < T) ? Pqp[(size_t)t * d + dsl + 16 * c + j] : 0.f;
+  }
+  float wvr[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) wvr[c] = a.wv[dsl + 16 * c + j];
+  f32x4 accq[2][8];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) accq[tt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int ntiles = (N + 15) >> 4;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int nb = 16 * tile;
+    // P_v tile in C/D layout: pv[c][r] = P_v[nb + 4*q4 + r][dsl + 16c + j]  (0 beyond N)
+    f32x4 pv[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = nb + 4 * q4 + r;
+      const float* pr = Pvp + (size_t)n * d + dsl + j;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) pv[c][r] = (n < N) ? pr[16 * c] : 0.f;
+    }
+    // H_q[t][d] += sum_n C[t][n] P_v[n][d]: A = C (rows t), k-step s <-> n = nb + 4*q4 + s
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int t = min(16 * tt + j, kTRows - 1);
+      const f32x4 ca = *reinterpret_cast<const f32x4*>(&Cbuf[t * LD + nb + 4 * q4]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) accq[tt][c] = mfma16(ca[s], pv[c][s], accq[tt][c]);
+    }
+    // H_v[n][d] = P_v[n][d] + sum_t C[t][n] P_q[t][d]: A = C^T (rows n), accumulate into pv
+#pragma unroll
+    for (int s = 0; s < kTS; ++s) {
+      const float ct = Cbuf[(4 * s + q4) * LD + nb + j];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) pv[c] = mfma16(ct, pq[s][c], pv[c]);
+    }
+    // scores: s_v[n] += tanh(H_v[n][d]) w_v[d] over this wave's 128 d's
+    float sv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sv[r] = fmaf(tanh_fast(pv[c][r]), wvr[c], sv[r]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) sv[r] += __shfl_xor(sv[r], o, 64);
+    }
+    if (j == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) svpart[w * NPAD + nb + 4 * q4 + r] = sv[r];
+    }
+  }
+
+  // ------------------------------------------------------------------ phase 3
+  // H_q epilogue: hq = tanh(P_q + acc); saved for backward; s_q partials
+  {
+    float* Hqg = a.Hq + pair * (size_t)T * d;
+    float sq[2][4];
+    float wqr[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) wqr[c] = a.wq[dsl + 16 * c + j];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sq[tt][r] = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = 16 * tt + 4 * q4 + r;
+        if (t < T) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            const int dd = dsl + 16 * c + j;
+            const float h = tanh_fast(accq[tt][c][r] + Pqp[(size_t)t * d + dd]);
+            Hqg[(size_t)t * d + dd] = h;
+            sq[tt][r] = fmaf(h, wqr[c], sq[tt][r]);
+          }
+        }
+      }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) sq[tt][r] += __shfl_xor(sq[tt][r], o, 64);
+        if (j == 0) sqpart[w * 32 + 16 * tt + 4 * q4 + r] = sq[tt][r];
+      }
+  }
+  __syncthreads();
+  if (w == 0) {
+    // a_v = softmax_n(s_v + c_v): N <= 16*NT <= 256 -> <= 4 values per lane
+    constexpr int PER = (NPAD + 63) / 64;
+    float sc[PER];
+    float m = -INFINITY;
+    const float cv = a.cv[0];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int n = lane + 64 * k;
+      float s = -INFINITY;
+      if (n < N) {
+        s = cv;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) s += svpart[ww * NPAD + n];
+      }
+      sc[k] = s;
+      m = fmaxf(m, s);
+    }
+    m = wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      sc[k] = (lane + 64 * k < N) ? expf(sc[k] - m) : 0.f;
+      sum += sc[k];
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    float* avg = a.av + pair * (size_t)N;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int n = lane + 64 * k;
+      if (n < N) avg[n] = sc[k] * inv;
+    }
+    // a_q = softmax_t(s_q + c_q), un-masked over all T positions (model.py:388)
+    float s = -INFINITY;
+    if (lane < T) {
+      s = a.cq[0];
+#pragma unroll
+      for (int ww = 0; ww < NW; ++ww) s += sqpart[ww * 32 + lane];
+    }
+    const float mq = wave_max(s);
+    const float e = (lane < T) ? expf(s - mq) : 0.f;
+    const float se = wave_sum(e);
+    const float aqv = e / se;
+    if (lane < T) {
+      aqs[lane] = aqv;
+      a.aq[pair * (size_t)T + lane] = aqv;
+    }
+  }
+  __syncthreads();
+  // q = sum_t a_q[t] Q[t][:]   (model.py:392)
+  for (int dd = tid; dd < d; dd += NW * 64) {
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) acc = fmaf(aqs[t], Qp[(size_t)t * d + dd], acc);
+    a.q_out[pair * (size_t)d + dd] = acc;
+  }
+}
+
+// v_l[b][k] = sum_n a_v[l][b][n] V[b][k][n]   (model.py:391), all L levels in one pass over V.
+// grid (d/64, B); 256 threads: 16 lanes per channel row, 16 rows per sweep.
+template <int NT>
+__global__ __launch_bounds__(256) void attend_v_kernel(const float* V, const float* av, float* v_out, int B, int N,
+                                                       int d, int L) {
+  const int b = blockIdx.y, k0 = blockIdx.x * 64;
+  const int tid = threadIdx.x, j = tid & 15, rsub = tid >> 4;      // rsub 0..15
+  float aw[3][NT];
+#pragma unroll
+  for (int l = 0; l < 3; ++l)
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+      const int n = j + 16 * m;
+      aw[l][m] = (n < N && l < L) ? av[((size_t)l * B + b) * N + n] : 0.f;
+    }
+  const float* Vb = V + (size_t)b * d * N;
+  for (int it = 0; it < 4; ++it) {
+    const int k = k0 + 16 * it + rsub;
+    const float* vr = Vb + (size_t)k * N;
+    float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+      const int n = j + 16 * m;
+      const float x = (n < N) ? vr[n] : 0.f;
+#pragma unroll
+      for (int l = 0; l < 3; ++l) acc[l] = fmaf(x, aw[l][m], acc[l]);
+    }
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) acc[l] += __shfl_xor(acc[l], o, 64);
+      if (j == 0 && l < L) v_out[((size_t)l * B + b) * d + k] = acc[l];
+    }
+  }
+}
+
+struct SavedOff {
+  size_t Pv, Pq, C, av, aq, Hq;
+};
+inline size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
+inline SavedOff saved_off(int B, int N, int T, int d, int L) {   // must match plan_saved() in api.hip
+  SavedOff p;
+  size_t o = 0;
+  p.Pv = o; o += al64((size_t)B * N * d);
+  p.Pq = o; o += al64((size_t)L * B * T * d);
+  p.C = o;  o += al64((size_t)L * B * T * N);
+  p.av = o; o += al64((size_t)L * B * N);
+  p.aq = o; o += al64((size_t)L * B * T);
+  p.Hq = o;
+  return p;
+}
+
+template <int NT, int NW>
+int launch_fwd(const FwdArgs& a, hipStream_t s) {
+  constexpr int LD = 16 * NT + 4;
+  constexpr int NSLOT = (NW / 2 > 2) ? NW / 2 : 2;
+  const size_t lds = (size_t)(NSLOT + 1) * kTRows * LD * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(coattn_attn_fwd_kernel<NT, NW>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const int groups = (a.B + 7) / 8;
+  dim3 grid(groups * a.L * 8), block(NW * 64);
+  hipLaunchKernelGGL((coattn_attn_fwd_kernel<NT, NW>), grid, block, lds, s, a);
+  CA_CHECK_LAUNCH("coattn_attn_fwd");
+  return 0;
+}
+
+}  // namespace
+
+int fused_supported(int B, int N, int T, int d, int L) {
+  (void)B;
+  if (!(d == 256 || d == 512)) return 0;
+  if (T > kTRows || N > 208 || L > 3) return 0;
+  return 1;
+}
+
+int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, const float* const* Q,
+                            const coattn_params* p, float* v_out, float* q_out, float* saved, float* ws,
+                            hipStream_t s) {
+  (void)ws;
+  CA_CHECK_ARG(fused_supported(B, N, T, d, L), "fused forward: unsupported shape");
+  const SavedOff so = saved_off(B, N, T, d, L);
+  FwdArgs a;
+  a.V = V;
+  for (int l = 0; l < 8; ++l) a.Q[l] = l < L ? Q[l] : nullptr;
+  a.Pv = saved + so.Pv; a.Pq = saved + so.Pq;
+  a.wv = (const float*)p->w_v; a.cv = (const float*)p->c_v; a.wq = (const float*)p->w_q; a.cq = (const float*)p->c_q;
+  a.C = saved + so.C; a.av = saved + so.av; a.aq = saved + so.aq; a.Hq = saved + so.Hq;
+  a.q_out = q_out;
+  a.B = B; a.N = N; a.T = T; a.d = d; a.L = L;
+  const bool small_n = N <= 64;
+  if (d == 512) {
+    CA_TRY(small_n ? (launch_fwd<4, 4>(a, s)) : (launch_fwd<13, 4>(a, s)));
+  } else {
+    CA_TRY(small_n ? (launch_fwd<4, 2>(a, s)) : (launch_fwd<13, 2>(a, s)));
+  }
+  dim3 grid(d / 64, B);
+  if (small_n)
+    hipLaunchKernelGGL(attend_v_kernel<4>, grid, dim3(256), 0, s, V, a.av, v_out, B, N, d, L);
+  else
+    hipLaunchKernelGGL(attend_v_kernel<13>, grid, dim3(256), 0, s, V, a.av, v_out, B, N, d, L);
+  CA_CHECK_LAUNCH("attend_v");
+  return 0;
+}
+
+int fused_backward_supported(int, int, int, int, int) { return 0; }
+
 int fused_backward(int, int, int, int, int, const float*, const float* const*, const coattn_params*, const float*,
                    const float*, const float*, float*, float* const*, const coattn_param_grads*, int, float*,
                    hipStream_t) {

@@ -24,21 +24,8 @@ extern "C" const char* coattn_last_error(void) { return g_err; }
 // ---------------------------------------------------------------------------------------
 static inline size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
 
-struct SavedPlan {
-  size_t Pv, Pq, C, av, aq, Hq, total;
-};
-static SavedPlan plan_saved(int B, int N, int T, int d, int L) {
-  SavedPlan p;
-  size_t o = 0;
-  p.Pv = o; o += al64((size_t)B * N * d);
-  p.Pq = o; o += al64((size_t)L * B * T * d);
-  p.C = o;  o += al64((size_t)L * B * T * N);
-  p.av = o; o += al64((size_t)L * B * N);
-  p.aq = o; o += al64((size_t)L * B * T);
-  p.Hq = o; o += al64((size_t)L * B * T * d);
-  p.total = o;
-  return p;
-}
+typedef SavedOff SavedPlan;
+static SavedPlan plan_saved(int B, int N, int T, int d, int L) { return saved_off(B, N, T, d, L); }
 
 static const int kMaxSplits = 32;
 
@@ -86,7 +73,12 @@ extern "C" int coattn_workspace_bytes(int B, int N, int T, int d, int L, int dty
   const BwdPlan bp = plan_bwd(B, N, T, d, L);
   if (saved) *saved = sp.total * sizeof(float);
   if (ws_fwd) *ws_fwd = (sp.total + al64((size_t)B * N * d)) * sizeof(float);
-  if (ws_bwd) *ws_bwd = bp.total * sizeof(float);
+  size_t bw = bp.total;
+  if (fused_supported(B, N, T, d, L)) {
+    const size_t fb = fused_bwd_ws_floats(B, N, T, d, L);
+    if (fb > bw) bw = fb;
+  }
+  if (ws_bwd) *ws_bwd = bw * sizeof(float);
   return 0;
 }
 

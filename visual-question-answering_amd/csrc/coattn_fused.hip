@@ -23,12 +23,6 @@
 
 namespace {
 
-constexpr int kTS = 7;       // k-steps of 4 over T: T <= 28
-constexpr int kTRows = 28;   // rows of C kept in LDS
-
-__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
 
 struct FwdArgs {
   const float* V;        // [B][d][N]
@@ -44,14 +38,6 @@ struct FwdArgs {
   int B, N, T, d, L;
 };
 
-// XCD-aware block -> (b, l): blocks i and i+8 share an XCD (round-robin dispatch), so give the
-// L levels of one sample consecutive slots on one XCD.  Speed only; any mapping is correct.
-__device__ __forceinline__ bool block_to_pair(int bid, int B, int L, int& b, int& l) {
-  const int x = bid & 7, slot = bid >> 3;
-  b = (slot / L) * 8 + x;
-  l = slot % L;
-  return b < B;
-}
 
 template <int NT, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdArgs a) {
@@ -361,22 +347,6 @@ __global__ __launch_bounds__(256) void attend_v_kernel(const float* V, const flo
   }
 }
 
-struct SavedOff {
-  size_t Pv, Pq, C, av, aq, Hq;
-};
-inline size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
-inline SavedOff saved_off(int B, int N, int T, int d, int L) {   // must match plan_saved() in api.hip
-  SavedOff p;
-  size_t o = 0;
-  p.Pv = o; o += al64((size_t)B * N * d);
-  p.Pq = o; o += al64((size_t)L * B * T * d);
-  p.C = o;  o += al64((size_t)L * B * T * N);
-  p.av = o; o += al64((size_t)L * B * N);
-  p.aq = o; o += al64((size_t)L * B * T);
-  p.Hq = o;
-  return p;
-}
-
 template <int NT, int NW>
 int launch_fwd(const FwdArgs& a, hipStream_t s) {
   constexpr int LD = 16 * NT + 4;
@@ -433,11 +403,3 @@ int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, c
   return 0;
 }
 
-int fused_backward_supported(int, int, int, int, int) { return 0; }
-
-int fused_backward(int, int, int, int, int, const float*, const float* const*, const coattn_params*, const float*,
-                   const float*, const float*, float*, float* const*, const coattn_param_grads*, int, float*,
-                   hipStream_t) {
-  coattn_set_error("fused backward not built");
-  return -2;
-}

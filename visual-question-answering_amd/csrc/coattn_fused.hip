@@ -54,13 +54,17 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
   int b, l;
   if (!block_to_pair(blockIdx.x, a.B, a.L, b, l)) return;
   const int N = a.N, T = a.T, d = a.d;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, q4 = lane >> 4;           // MFMA column / k-quad (also C/D row quad)
   const float* Qp = a.Q[l] + (size_t)b * T * d;
   const float* Vp = a.V + (size_t)b * d * N;
   const float* Pvp = a.Pv + (size_t)b * N * d;
   const float* Pqp = a.Pq + ((size_t)l * a.B + b) * T * d;
   const size_t pair = (size_t)l * a.B + b;
+  // buffer resources over exactly this sample's tensors: rows beyond T / N read as 0
+  const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(Qp, (unsigned)T * d * 4u);
+  const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(Vp, (unsigned)d * N * 4u);
+  const __amdgpu_buffer_rsrc_t rs_pv = make_rsrc(Pvp, (unsigned)N * d * 4u);
 
   // ------------------------------------------------------------------ phase 1: A = Q V^T
   {
@@ -70,40 +74,36 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[tt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ks = w * 128;
-    float vb[2][NT];
+    constexpr int RING = 4;                          // V operand ring: 3 k-steps in flight
+    float vb[RING][NT];
     f32x4 qa[2][2];
     // A operand (Q): lane (row t = 16tt + j, quad q4) holds Q[t][k0 + 4*q4 + s], s = 0..3
     // B operand (V): lane (col n = 16tile + j, quad q4) holds V[k0 + 4*q4 + s][n]
+    const int q_voff0 = (j * d + 4 * q4) * 4, q_voff1 = ((16 + j) * d + 4 * q4) * 4;
+    const int v_voff = (4 * q4 * N + j) * 4;
     auto load_q = [&](int kb, f32x4(&dst)[2]) {
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const int t = 16 * tt + j;
-        dst[tt] = (t < T) ? *reinterpret_cast<const f32x4*>(Qp + (size_t)t * d + ks + 16 * kb + 4 * q4)
-                          : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      dst[0] = buf_load4(rs_q, q_voff0, (ks + 16 * kb) * 4);
+      dst[1] = buf_load4(rs_q, q_voff1, (ks + 16 * kb) * 4);
     };
     auto load_v = [&](int u, float(&dst)[NT]) {
-      const int krow = ks + 16 * (u >> 2) + 4 * q4 + (u & 3);
-      const float* vr = Vp + (size_t)krow * N;
+      const int soff = (ks + 16 * (u >> 2) + (u & 3)) * N * 4;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int n = 16 * t + j;
-        dst[t] = (n < N) ? vr[n] : 0.f;
-      }
+      for (int t = 0; t < NT; ++t) dst[t] = buf_load1(rs_v, v_voff + 64 * t, soff);   // cols >= N: finite junk,
+                                                                                       // zeroed when C is finalised
     };
     load_q(0, qa[0]);
-    load_v(0, vb[0]);
+#pragma unroll
+    for (int u = 0; u < RING - 1; ++u) load_v(u, vb[u]);
 #pragma unroll
     for (int u = 0; u < 32; ++u) {                   // 32 k-steps of 4 = this wave's 128 channels
-      if (u + 1 < 32) {
-        load_v(u + 1, vb[(u + 1) & 1]);
-        if (((u + 1) & 3) == 0) load_q((u + 1) >> 2, qa[((u + 1) >> 2) & 1]);
-      }
+      if (u + RING - 1 < 32) load_v(u + RING - 1, vb[(u + RING - 1) % RING]);
+      if ((u & 3) == 1 && (u >> 2) + 1 < 8) load_q((u >> 2) + 1, qa[((u >> 2) + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);             // keep the prefetch ahead of this step's MFMAs
       const int s = u & 3, qb = (u >> 2) & 1;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        acc[0][t] = mfma16(qa[qb][0][s], vb[u & 1][t], acc[0][t]);
-        acc[1][t] = mfma16(qa[qb][1][s], vb[u & 1][t], acc[1][t]);
+        acc[0][t] = mfma16(qa[qb][0][s], vb[u % RING][t], acc[0][t]);
+        acc[1][t] = mfma16(qa[qb][1][s], vb[u % RING][t], acc[1][t]);
       }
     }
     // cross-wave sum in a fixed tree order through LDS; C/D layout: col = j, row = 4*q4 + r
@@ -141,13 +141,18 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
     if (w == NW / 2) put(slots);
     if (w == 0) put(slots + kTRows * LD);
     __syncthreads();
-    // C = tanh(sum) by all threads; rows >= T are tanh(0) = 0 (their Q rows were masked)
+    // C = tanh(sum) by all threads; rows >= T are tanh(0) = 0 (their Q rows read as 0)
     float* Cg = a.C + pair * (size_t)T * N;
-    for (int e = tid; e < kTRows * NPAD; e += NW * 64) {
-      const int row = e / NPAD, col = e - row * NPAD;
-      const float c = tanh_fast(slots[row * LD + col] + slots[kTRows * LD + row * LD + col]);
-      Cbuf[row * LD + col] = c;
-      if (row < T && col < N) Cg[(size_t)row * N + col] = c;
+    constexpr int RSTEP = NW * 64 / 16;              // rows covered per sweep: 16 lanes per row
+    for (int row = tid >> 4; row < kTRows; row += RSTEP) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int col = 16 * t + (tid & 15);
+        float c = tanh_fast(slots[row * LD + col] + slots[kTRows * LD + row * LD + col]);
+        c = (col < N) ? c : 0.f;                     // padded columns carry junk from phase 1
+        Cbuf[row * LD + col] = c;
+        if (row < T && col < N) Cg[(size_t)row * N + col] = c;
+      }
     }
     __syncthreads();
   }
@@ -171,48 +176,25 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
     for (int c = 0; c < 8; ++c) accq[tt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int ntiles = (N + 15) >> 4;
-  for (int tile = 0; tile < ntiles; ++tile) {
-    const int nb = 16 * tile;
-    // P_v tile in C/D layout: pv[c][r] = P_v[nb + 4*q4 + r][dsl + 16c + j]  (0 beyond N)
-    f32x4 pv[8];
+  {
+    const float dsn0[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 pvA[4], pvB[4];                            // half tiles (4 channel tiles each), double buffered
+    load_pv_half<0>(rs_pv, d, dsl, 0, j, q4, pvA);
+    for (int tile = 0; tile < ntiles; ++tile) {
+      const int nb = 16 * tile;
+      load_pv_half<1>(rs_pv, d, dsl, nb, j, q4, pvB);
+      __builtin_amdgcn_sched_barrier(0);
+      float sv[4] = {0.f, 0.f, 0.f, 0.f};
+      half_unit<false, 0, LD>(pvA, pq, wvr, accq, Cbuf, nb, j, q4, sv, dsn0);
+      load_pv_half<0>(rs_pv, d, dsl, nb + 16, j, q4, pvA);     // next tile (beyond N reads 0)
+      __builtin_amdgcn_sched_barrier(0);
+      half_unit<false, 1, LD>(pvB, pq, wvr, accq, Cbuf, nb, j, q4, sv, dsn0);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = nb + 4 * q4 + r;
-      const float* pr = Pvp + (size_t)n * d + dsl + j;
+      for (int r = 0; r < 4; ++r) sv[r] = row16_sum(sv[r]);
+      if (j == 0) {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) pv[c][r] = (n < N) ? pr[16 * c] : 0.f;
-    }
-    // H_q[t][d] += sum_n C[t][n] P_v[n][d]: A = C (rows t), k-step s <-> n = nb + 4*q4 + s
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      const int t = min(16 * tt + j, kTRows - 1);
-      const f32x4 ca = *reinterpret_cast<const f32x4*>(&Cbuf[t * LD + nb + 4 * q4]);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) accq[tt][c] = mfma16(ca[s], pv[c][s], accq[tt][c]);
-    }
-    // H_v[n][d] = P_v[n][d] + sum_t C[t][n] P_q[t][d]: A = C^T (rows n), accumulate into pv
-#pragma unroll
-    for (int s = 0; s < kTS; ++s) {
-      const float ct = Cbuf[(4 * s + q4) * LD + nb + j];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) pv[c] = mfma16(ct, pq[s][c], pv[c]);
-    }
-    // scores: s_v[n] += tanh(H_v[n][d]) w_v[d] over this wave's 128 d's
-    float sv[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sv[r] = fmaf(tanh_fast(pv[c][r]), wvr[c], sv[r]);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) sv[r] += __shfl_xor(sv[r], o, 64);
-    }
-    if (j == 0) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) svpart[w * NPAD + nb + 4 * q4 + r] = sv[r];
+        for (int r = 0; r < 4; ++r) svpart[w * NPAD + nb + 4 * q4 + r] = sv[r];
+      }
     }
   }
 
@@ -247,8 +229,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) sq[tt][r] += __shfl_xor(sq[tt][r], o, 64);
+        sq[tt][r] = row16_sum(sq[tt][r]);
         if (j == 0) sqpart[w * 32 + 16 * tt + 4 * q4 + r] = sq[tt][r];
       }
   }

@@ -219,11 +219,14 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc_kernel(const BwdArgs a) {
     f32x4 dwv4 = zero4;
     // transposed tiles, C/D layout: col = j <-> n, row = 4*q4 + r <-> channel db + 4*q4 + r
     auto load_pvT = [&](int nt) { return buf_load4(rs_pv, voff, (16 * nt * d + db) * 4); };
-    f32x4 pvT_next = load_pvT(0);
+    f32x4 pvT_q[3];                                    // prefetch ring, two tiles ahead
+    pvT_q[0] = load_pvT(0);
+    if (NT > 1) pvT_q[1] = load_pvT(1);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const f32x4 pvT = pvT_next;
-      if (nt + 1 < NT) pvT_next = load_pvT(nt + 1);     // one tile ahead
+      if (nt + 2 < NT) pvT_q[(nt + 2) % 3] = load_pvT(nt + 2);
+      __builtin_amdgcn_sched_barrier(0);               // pin the prefetch ahead of this tile's math
+      const f32x4 pvT = pvT_q[nt % 3];
       float cB[kTS];                                 // B[k = t][j = n]
 #pragma unroll
       for (int s = 0; s < kTS; ++s) cB[s] = Cbuf[(4 * s + q4) * LD + 16 * nt + j];
@@ -255,10 +258,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc_kernel(const BwdArgs a) {
     }
     // dw_v[db + 4*q4 + r] partial of this (sample, level): sum over the 16 lanes (locations)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) dwv4[r] += __shfl_xor(dwv4[r], o, 64);
-    }
+    for (int r = 0; r < 4; ++r) dwv4[r] = row16_sum(dwv4[r]);
     if (j == 0) *reinterpret_cast<f32x4*>(a.dwv_part + pair * (size_t)d + db + 4 * q4) = dwv4;
   }
 
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dpq_kernel(const BwdArgs a) {
   int b, l;
   if (!block_to_pair(blockIdx.x, a.B, a.L, b, l)) return;
   const int N = a.N, T = a.T, d = a.d;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, q4 = lane >> 4;
   const size_t pair = (size_t)l * a.B + b;
   const float* Pvp = a.Pv + (size_t)b * N * d;
@@ -343,43 +343,22 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dpq_kernel(const BwdArgs a) {
   __syncthreads();
 
   const int ntiles = (N + 15) >> 4;
-  for (int tile = 0; tile < ntiles; ++tile) {
-    const int nb = 16 * tile;
-    f32x4 pv[8];
+  {
+    const __amdgpu_buffer_rsrc_t rs_pv = make_rsrc(Pvp, (unsigned)N * d * 4u);
+    f32x4 pvA[4], pvB[4];
+    float sv[4] = {0.f, 0.f, 0.f, 0.f};
+    load_pv_half<0>(rs_pv, d, dsl, 0, j, q4, pvA);
+    for (int tile = 0; tile < ntiles; ++tile) {
+      const int nb = 16 * tile;
+      load_pv_half<1>(rs_pv, d, dsl, nb, j, q4, pvB);
+      float dsn[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = nb + 4 * q4 + r;
-      const float* pr = Pvp + (size_t)n * d + dsl + j;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) pv[c][r] = (n < N) ? pr[16 * c] : 0.f;
-    }
-    // H_v tile = P_v + C^T P_q
-#pragma unroll
-    for (int s = 0; s < kTS; ++s) {
-      const float ct = Cbuf[(4 * s + q4) * LD + nb + j];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) pv[c] = mfma16(ct, pq[s][c], pv[c]);
-    }
-    // dZ_v tile (in place): ds_v[n] w_v[d] (1 - H_v^2)
-    float dsn[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) dsn[r] = dsvs[nb + 4 * q4 + r];
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float h = tanh_fast(pv[c][r]);
-        pv[c][r] = dsn[r] * wvr[c] * (1.0f - h * h);
-      }
-    // dP_q[t][d] += sum_n C[t][n] dZ_v[n][d]
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      const int t = min(16 * tt + j, kTRows - 1);
-      const f32x4 ca = *reinterpret_cast<const f32x4*>(&Cbuf[t * LD + nb + 4 * q4]);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) accq[tt][c] = mfma16(ca[s], pv[c][s], accq[tt][c]);
+      for (int r = 0; r < 4; ++r) dsn[r] = dsvs[nb + 4 * q4 + r];
+      __builtin_amdgcn_sched_barrier(0);
+      half_unit<true, 0, LD>(pvA, pq, wvr, accq, Cbuf, nb, j, q4, sv, dsn);
+      load_pv_half<0>(rs_pv, d, dsl, nb + 16, j, q4, pvA);
+      __builtin_amdgcn_sched_barrier(0);
+      half_unit<true, 1, LD>(pvB, pq, wvr, accq, Cbuf, nb, j, q4, sv, dsn);
     }
   }
   // dP_q = dZ_q + acc

@@ -48,12 +48,21 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// tanh with ~2e-7 absolute error: 1 v_exp + 1 v_rcp.  (1-e)/(1+e), e = exp(-2|x|).
+// tanh with ~2e-7 absolute error: 1 v_exp + 1 v_rcp.  (1-e)/(1+e), e = exp(-2|x|) in (0,1].
+// (__fdividef lowers to the full IEEE division sequence on gfx950; v_rcp_f32 is 1 ulp.)
+// 5 VALU ops: tanh(x) = 1 - 2 / (1 + exp(2x)); saturates cleanly (exp -> inf gives 1, -> 0 gives -1).
 __device__ __forceinline__ float tanh_fast(float x) {
-  const float ax = fabsf(x);
-  const float e = __expf(-2.0f * ax);
-  const float t = __fdividef(1.0f - e, 1.0f + e);
-  return copysignf(t, x);
+  const float e = __builtin_amdgcn_exp2f(2.8853900817779268f * x);            // exp(2x)
+  return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
+}
+
+// sum over the 16 lanes of a DPP row (lanes sharing lane>>4); result valid in every lane
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
 }
 
 // ---- generic GEMM (gemm.hip) ------------------------------------------------------------

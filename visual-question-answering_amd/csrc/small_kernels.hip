@@ -111,7 +111,15 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* part,
   const long j = (long)blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
   float acc = 0.f;
-  for (int c = 0; c < nparts; ++c) acc += part[(long)c * n + j];
+  int c = 0;
+  for (; c + 8 <= nparts; c += 8) {                  // 8 independent loads in flight, fixed add order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(long)(c + u) * n + j];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  for (; c < nparts; ++c) acc += part[(long)c * n + j];
   out[j] = accumulate ? out[j] + acc : acc;
 }
 

@@ -104,7 +104,11 @@ int coattn_backward(const void* V, const void* const* Q, const coattn_params* p,
  *   C[z](m,n) = act( sum_{i<inner} sum_k A[z,i](m,k) * B[z,i](k,n) + bias_n[n] + bias_m[m]
  *                    + beta * Cin[z](m,n) )
  * Row m of A / C / Cin lives at (m / mdiv) * sdiv + (m % mdiv) * sm (mdiv = 0: plain m * sm).
- * ksplit > 0: batch index z selects the k range [z*ksplit, min(K,(z+1)*ksplit)) instead. */
+ * ksplit > 0: batch index z selects the k range [z*ksplit, min(K,(z+1)*ksplit)) instead.
+ * inner_total > 0: z is a group of `inner` consecutive inner indices ig = z*inner + i < inner_total.
+ * Pointer tables (level-merged launches; NULL entries = unused): a_ptrs/b_ptrs/c_ptrs/cin_ptrs[t]
+ * replace A/B/C/Cin with t = z (ptr_by_inner = 0) or t = ig (ptr_by_inner = 1).
+ * b_imod > 0: the inner stride of B wraps, B[ig] = B + (ig % b_imod) * b_si. */
 typedef struct coattn_gemm_desc {
   const void* A; const void* B; const void* Cin; void* C;
   const void* bias_n; const void* bias_m;
@@ -114,6 +118,8 @@ typedef struct coattn_gemm_desc {
   int64_t b_sk, b_sn, b_sz, b_si;
   int64_t c_sm, c_sn, c_sz, c_mdiv, c_sdiv;
   int64_t cin_sm, cin_sn, cin_sz, cin_mdiv, cin_sdiv;
+  const void* a_ptrs[8]; const void* b_ptrs[8]; void* c_ptrs[8]; const void* cin_ptrs[8];
+  int ptr_by_inner; int b_imod;
 } coattn_gemm_desc;
 
 int coattn_gemm_f32(const coattn_gemm_desc* g, void* stream);

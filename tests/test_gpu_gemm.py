@@ -13,6 +13,7 @@ def _gemm(desc_kw, stream=None):
     g = _lib.GemmDesc()
     for k, v in desc_kw.items():
         setattr(g, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    keep = list(desc_kw.values())  # noqa: F841  (tensors / tables stay alive across the launch)
     _lib.check(lib.coattn_gemm_f32(C.byref(g), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gemm")
     torch.cuda.synchronize()
 
@@ -83,3 +84,56 @@ def test_gemm_inner_groups_and_ksplit():
     _gemm(dict(A=A, B=Bm, C=part, M=d, N=d, K=K, batch=S, ksplit=ks, a_sm=1, a_sk=d, b_sk=d, b_sn=1,
                c_sm=d, c_sn=1, c_sz=d * d))
     assert _rel(part.sum(0), A.double().T @ Bm.double()) < 2e-6
+
+
+@pytest.mark.parametrize("a_m,b_n", [(True, True), (True, False), (False, True), (False, False)])
+def test_gemm_aligned_fast_path_layouts(a_m, b_n):
+    """float4 / BK=32 kernel: all four operand layouts, partial edge tiles, K not a multiple of 32."""
+    torch.manual_seed(5)
+    M, N, K = 260, 200, 100
+    A = torch.randn(K, M, device="cuda") if a_m else torch.randn(M, K, device="cuda")
+    Bm = torch.randn(K, N, device="cuda") if b_n else torch.randn(N, K, device="cuda")
+    bias = torch.randn(N, device="cuda")
+    Cm = torch.full((M, N), float("nan"), device="cuda")
+    kw = dict(A=A, B=Bm, C=Cm, bias_n=bias, M=M, N=N, K=K, batch=1, c_sm=N, c_sn=1)
+    kw.update(dict(a_sm=1, a_sk=M) if a_m else dict(a_sm=K, a_sk=1))
+    kw.update(dict(b_sk=N, b_sn=1) if b_n else dict(b_sk=1, b_sn=K))
+    _gemm(kw)
+    ref = (A.double().T if a_m else A.double()) @ (Bm.double() if b_n else Bm.double().T) + bias.double()
+    assert _rel(Cm, ref) < 2e-6
+
+
+def test_gemm_aligned_row_split_inner_ksplit_and_pointer_tables():
+    torch.manual_seed(6)
+    B_, d, N = 5, 128, 36
+    V = torch.randn(B_, d, N, device="cuda"); W = torch.randn(d, d, device="cuda") / 10
+    Pv = torch.full((B_ * N, d), float("nan"), device="cuda")
+    _gemm(dict(A=V, B=W, C=Pv, M=B_ * N, N=d, K=d, batch=1, a_sm=1, a_sk=N, a_mdiv=N, a_sdiv=d * N,
+               b_sk=1, b_sn=d, c_sm=d, c_sn=1))
+    assert _rel(Pv, V.double().permute(0, 2, 1).reshape(B_ * N, d) @ W.double().T) < 2e-6
+    # weight-gradient form: inner groups over samples
+    dP = torch.randn(B_, N, d, device="cuda")
+    G = 2; S = (B_ + G - 1) // G
+    part = torch.full((S, d, d), float("nan"), device="cuda")
+    _gemm(dict(A=dP, B=V, C=part, M=d, N=d, K=N, batch=S, inner=G, inner_total=B_,
+               a_sm=1, a_sk=d, a_si=N * d, a_sz=G * N * d, b_sk=1, b_sn=N, b_si=d * N, b_sz=G * d * N,
+               c_sm=d, c_sn=1, c_sz=d * d))
+    assert _rel(part.sum(0), torch.einsum("bnj,bkn->jk", dP.double(), V.double())) < 2e-6
+    # level-merged launches: A / C through pointer tables, and B through a table indexed by the inner loop
+    L, M = 3, 132
+    Qs = [torch.randn(M, d, device="cuda") for _ in range(L)]
+    out = torch.full((L, M, d), float("nan"), device="cuda")
+    from vqa_amd import _lib
+    import ctypes as C
+    tab = (C.c_void_p * 8)(*([q.data_ptr() for q in Qs] + [None] * 5))
+    _gemm(dict(a_ptrs=tab, B=W, C=out, M=M, N=d, K=d, batch=L, a_sm=d, a_sk=1, b_sk=1, b_sn=d,
+               c_sm=d, c_sn=1, c_sz=M * d))
+    for l in range(L):
+        assert _rel(out[l], Qs[l].double() @ W.double().T) < 2e-6
+    dPq = torch.randn(L, M, d, device="cuda")
+    ks = 48; S = (M + ks - 1) // ks
+    part = torch.full((S, d, d), float("nan"), device="cuda")
+    _gemm(dict(A=dPq, b_ptrs=tab, ptr_by_inner=1, C=part, M=d, N=d, K=M, batch=S, ksplit=ks, inner=L,
+               a_sm=1, a_sk=d, a_si=M * d, b_sk=d, b_sn=1, c_sm=d, c_sn=1, c_sz=d * d))
+    ref = sum(dPq[l].double().T @ Qs[l].double() for l in range(L))
+    assert _rel(part.sum(0), ref) < 2e-6

@@ -98,8 +98,8 @@ def test_frozen_image_features_and_accumulate(impl):
     a = run_hip(V, Qs, P, gv, gq, impl=impl)
     b = run_hip(V, Qs, P, gv, gq, impl=impl, need_dv=False)
     for k in G.GRAD_KEYS:
-        if k != "dV_phys":
-            assert torch.equal(a[k], b[k]), k
+        if k != "dV_phys":          # same values; summation order over the levels may differ
+            assert (a[k] - b[k]).abs().max() <= 1e-5 * max(1e-3, a[k].abs().max().item()), k
     names = ("W_v.weight", "W_v.bias", "W_q.weight", "W_q.bias", "w_v.weight", "w_v.bias", "w_q.weight", "w_q.bias")
     init = [torch.ones_like(P[k]) for k in names]
     cacc = run_hip(V, Qs, P, gv, gq, impl=impl, accumulate=1, grads_init=init)

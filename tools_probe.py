@@ -1,7 +1,23 @@
-import sys, json, torch
+import sys, time, torch
 sys.path.insert(0, '/root/repo')
-import bench
+import vqa_amd
+from oracle import coattn_oracle as O
 dev = torch.device('cuda', 0)
-for B in (40, 80, 85, 160, 170, 256, 341):
-    r = bench.roofline_leg(dev, B=B)
-    print(B, 3*B, r['avg_launch_us'], r['frac'])
+for N in (196, 49):
+    B, T, d = 160, 26, 512
+    co = vqa_amd.ParallelCoAttention(d).to(dev)
+    V, Qs = O.make_inputs(B, N, T, d, 1234, lens=[26]*B)
+    x = V.to(dev).permute(0, 2, 1)
+    Qs = [q.to(dev).requires_grad_(True) for q in Qs]
+    args = (co.W_v.weight, co.W_v.bias, co.W_q.weight, co.W_q.bias, co.w_v.weight, co.w_v.bias, co.w_q.weight, co.w_q.bias)
+    tf = tb = 0
+    for it in range(25):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        v, q = vqa_amd.coattention(x, Qs, *args)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        g = [torch.ones_like(v), torch.ones_like(q)]
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        torch.autograd.backward([v, q], g)
+        torch.cuda.synchronize(); t5 = time.perf_counter()
+        if it >= 5: tf += t2 - t0; tb += t5 - t3
+    print("N=%d fwd %.3f ms bwd %.3f ms" % (N, tf / 20 * 1e3, tb / 20 * 1e3))

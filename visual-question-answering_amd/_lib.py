@@ -32,7 +32,9 @@ class GemmDesc(C.Structure):
                 + [(n, C.c_int64) for n in ("a_sm", "a_sk", "a_sz", "a_si", "a_mdiv", "a_sdiv",
                                             "b_sk", "b_sn", "b_sz", "b_si",
                                             "c_sm", "c_sn", "c_sz", "c_mdiv", "c_sdiv",
-                                            "cin_sm", "cin_sn", "cin_sz", "cin_mdiv", "cin_sdiv")])
+                                            "cin_sm", "cin_sn", "cin_sz", "cin_mdiv", "cin_sdiv")]
+                + [("a_ptrs", C.c_void_p * 8), ("b_ptrs", C.c_void_p * 8), ("c_ptrs", C.c_void_p * 8),
+                   ("cin_ptrs", C.c_void_p * 8), ("ptr_by_inner", C.c_int), ("b_imod", C.c_int)])
 
 
 def build(verbose: bool = False) -> str:

@@ -151,9 +151,15 @@ int general_projections(const Ctx& c, const float* V, const float* const* Q, con
   const SavedPlan sp = plan_saved(c.B, c.N, c.T, c.d, c.L);
   const size_t BTd = (size_t)c.B * c.T * c.d;
   CA_TRY(proj_v(c, V, (const float*)p->W_v, (const float*)p->b_v, sv + sp.Pv));
-  for (int l = 0; l < c.L; ++l)
-    CA_TRY(proj_q(c, Q[l], (const float*)p->W_q, (const float*)p->b_q, sv + sp.Pq + l * BTd));
-  return 0;
+  // P_q of all levels in one launch: batch z = level, A from the pointer table
+  coattn_gemm_desc g = {};
+  for (int l = 0; l < c.L; ++l) g.a_ptrs[l] = Q[l];
+  g.B = p->W_q; g.C = sv + sp.Pq; g.c_sz = (int64_t)BTd; g.bias_n = p->b_q;
+  g.M = c.B * c.T; g.N = c.d; g.K = c.d; g.batch = c.L;
+  g.a_sm = c.d; g.a_sk = 1;
+  g.b_sk = 1; g.b_sn = c.d;
+  g.c_sm = c.d; g.c_sn = 1;
+  return launch_gemm_f32(g, c.s);
 }
 
 // everything after the projections: affinity, H_v / H_q, scores, softmax, attended reductions

@@ -20,122 +20,140 @@
 
 namespace {
 
+// partial da_v over 64 channel rows: part[b][kc][l][n] = sum_{k in chunk kc} V[b][k][n] gv[l][b][k].
+// grid (d/64, B); thread <-> location n (rows of V are contiguous in n: fully coalesced).
+__global__ __launch_bounds__(256) void bwd_dav_kernel(const float* V, const float* gv, float* part, int B, int N,
+                                                      int d, int L) {
+  const int b = blockIdx.y, kc = blockIdx.x, n = threadIdx.x;
+  __shared__ float g[3][64];
+  if (threadIdx.x < 192) {
+    const int l = threadIdx.x >> 6, k = threadIdx.x & 63;
+    g[l][k] = (l < L) ? gv[((size_t)l * B + b) * d + kc * 64 + k] : 0.f;
+  }
+  __syncthreads();
+  if (n >= N) return;
+  const float* vp = V + ((size_t)b * d + kc * 64) * N + n;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll 16
+  for (int k = 0; k < 64; ++k) {
+    const float x = vp[(size_t)k * N];
+    a0 = fmaf(x, g[0][k], a0);
+    a1 = fmaf(x, g[1][k], a1);
+    a2 = fmaf(x, g[2][k], a2);
+  }
+  float* o = part + (((size_t)b * gridDim.x + kc) * 3) * N + n;
+  o[0] = a0; o[N] = a1; o[2 * (size_t)N] = a2;
+}
+
 struct PreArgs {
-  const float* V; const float* Q[8];
-  const float* gv; const float* gq;      // [L][B][d]
+  const float* dav_part;                 // [B][d/64][3][N] partial da_v (bwd_dav_kernel)
+  const float* Q[8];
+  const float* gq;                       // [L][B][d]
   const float* av; const float* aq;      // saved
   const float* Hq;                       // saved [L][B][T][d]
   const float* wq;
   float* dsv;                            // [L][B][N]
   float* dZq;                            // [L][B][T][d]
-  float* dwq_part;                       // [B][d]
-  float* dcs_part;                       // [B][2]
+  float* dwq_part;                       // [L*B][d]
+  float* dcs_part;                       // [2][L*B]
   int B, N, T, d, L;
 };
 
-template <int NT>
+// One workgroup (256 threads) per (sample, level): softmax backward of a_v (from the da_v
+// partials) and of a_q (da_q = Q gq), dZ_q = ds_q (x) w_q (.) (1 - H_q^2), dw_q / dc partials.
 __global__ __launch_bounds__(256) void bwd_pre_kernel(const PreArgs a) {
-  constexpr int NPAD = 16 * NT;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int d = a.d, N = a.N, T = a.T, L = a.L, B = a.B;
-  float* gvs = lds;                       // 3 x d
-  float* gqs = gvs + 3 * d;               // 3 x d
-  float* red = gqs + 3 * d;               // 16 x 3 x NPAD
-  float* dav = red + 16 * 3 * NPAD;       // 3 x NPAD
-  float* daq = dav + 3 * NPAD;            // 3 x 32
-  float* dsq = daq + 96;                  // 3 x 32
-  float* dcs = dsq + 96;                  // 8
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  for (int e = tid; e < 3 * d; e += 256) {
-    const int l = e / d, k = e - l * d;
-    gvs[e] = (l < L) ? a.gv[((size_t)l * B + b) * d + k] : 0.f;
-    gqs[e] = (l < L) ? a.gq[((size_t)l * B + b) * d + k] : 0.f;
-  }
-  if (tid < 8) dcs[tid] = 0.f;
-  __syncthreads();
-  // ---- da_v[l][n] = sum_k V[k][n] gv[l][k]: 16 lanes per channel row, 16 rows per sweep
-  {
-    const int j = tid & 15, rs = tid >> 4;
-    float acc[3][NT];
-#pragma unroll
-    for (int l = 0; l < 3; ++l)
-#pragma unroll
-      for (int m = 0; m < NT; ++m) acc[l][m] = 0.f;
-    const float* Vb = a.V + (size_t)b * d * N;
-    for (int k = rs; k < d; k += 16) {
-      const float* vr = Vb + (size_t)k * N;
-      const float g0 = gvs[k], g1 = gvs[d + k], g2 = gvs[2 * d + k];
-#pragma unroll
-      for (int m = 0; m < NT; ++m) {
-        const int n = j + 16 * m;
-        const float x = (n < N) ? vr[n] : 0.f;
-        acc[0][m] = fmaf(x, g0, acc[0][m]);
-        acc[1][m] = fmaf(x, g1, acc[1][m]);
-        acc[2][m] = fmaf(x, g2, acc[2][m]);
-      }
-    }
-#pragma unroll
-    for (int l = 0; l < 3; ++l)
-#pragma unroll
-      for (int m = 0; m < NT; ++m) red[(rs * 3 + l) * NPAD + j + 16 * m] = acc[l][m];
-  }
-  __syncthreads();
-  for (int e = tid; e < 3 * NPAD; e += 256) {
-    float s = 0.f;
-#pragma unroll
-    for (int rs = 0; rs < 16; ++rs) s += red[rs * 3 * NPAD + e];
-    dav[e] = s;
-  }
-  // ---- da_q[l][t] = Q_l[t] . gq_l : one wave per (l,t)
-  for (int idx = w; idx < L * T; idx += 4) {
-    const int l = idx / T, t = idx - l * T;
-    const float* qr = a.Q[l] + ((size_t)b * T + t) * d;
-    float acc = 0.f;
-    for (int k = lane; k < d; k += 64) acc = fmaf(qr[k], gqs[l * d + k], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) daq[l * 32 + t] = acc;
-  }
-  __syncthreads();
-  // ---- softmax backward: ds = a (.) (da - <a, da>)
-  if (w < L) {
-    const int l = w;
-    const float* avp = a.av + ((size_t)l * B + b) * N;
+  const int d = a.d, N = a.N, T = a.T, B = a.B;
+  float* daq = lds;                       // 32
+  float* dsq = daq + 32;                  // 32
+  float* dwr = dsq + 32;                  // d   (second row group's dw_q partial)
+  const int pairi = blockIdx.x, l = pairi / B, b = pairi - l * B;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const size_t pair = (size_t)pairi;
+  // ---- image side (wave 0): da_v = sum of the channel-chunk partials; ds_v = a_v (da_v - <a_v, da_v>)
+  float tot_v = 0.f;
+  if (w == 0) {
+    const int nkc = d / 64;
+    const float* pp = a.dav_part + (size_t)b * nkc * 3 * N + (size_t)l * N;
+    const float* avp = a.av + pair * N;
+    float da[4], avv[4];
     float dot = 0.f;
-    for (int n = lane; n < N; n += 64) dot = fmaf(avp[n], dav[l * NPAD + n], dot);
-    dot = wave_sum(dot);
-    float tot = 0.f;
-    for (int n = lane; n < N; n += 64) {
-      const float v = avp[n] * (dav[l * NPAD + n] - dot);
-      a.dsv[((size_t)l * B + b) * N + n] = v;
-      tot += v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int n = lane + 64 * k;
+      float sacc = 0.f;
+      if (n < N)
+        for (int kc = 0; kc < nkc; ++kc) sacc += pp[(size_t)kc * 3 * N + n];
+      da[k] = sacc;
+      avv[k] = (n < N) ? avp[n] : 0.f;
+      dot = fmaf(avv[k], sacc, dot);
     }
-    tot = wave_sum(tot);
-    const float aqv = (lane < T) ? a.aq[((size_t)l * B + b) * T + lane] : 0.f;
-    const float x = (lane < T) ? daq[l * 32 + lane] : 0.f;
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int n = lane + 64 * k;
+      const float v = avv[k] * (da[k] - dot);
+      if (n < N) a.dsv[pair * N + n] = v;
+      tot_v += v;
+    }
+    tot_v = wave_sum(tot_v);
+  }
+  // ---- question side: da_q[t] = Q[t] . gq, one wave per row
+  const float* Qp = a.Q[l] + (size_t)b * T * d;
+  const float* gqp = a.gq + pair * d;
+  for (int t = w; t < T; t += 4) {
+    float acc = 0.f;
+    for (int k = 4 * lane; k < d; k += 256) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(Qp + (size_t)t * d + k);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gqp + k);
+      acc += x[0] * g[0] + x[1] * g[1] + x[2] * g[2] + x[3] * g[3];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) daq[t] = acc;
+  }
+  __syncthreads();
+  if (w == 0) {
+    const float aqv = (lane < T) ? a.aq[pair * T + lane] : 0.f;
+    const float x = (lane < T) ? daq[lane] : 0.f;
     const float dq = wave_sum(aqv * x);
     const float sq = aqv * (x - dq);
-    if (lane < 32) dsq[l * 32 + lane] = (lane < T) ? sq : 0.f;
-    const float totq = wave_sum(sq);
-    if (lane == 0) { dcs[l] = tot; dcs[4 + l] = totq; }
+    if (lane < 32) dsq[lane] = sq;
+    const float tot_q = wave_sum(sq);
+    if (lane == 0) {
+      a.dcs_part[pair] = tot_v;                      // [2][L*B]
+      a.dcs_part[(size_t)a.L * B + pair] = tot_q;
+    }
   }
   __syncthreads();
-  // ---- dZ_q = ds_q (x) w_q (.) (1 - H_q^2); dw_q partial of this sample (summed over levels)
-  for (int dd = tid; dd < d; dd += 256) {
-    const float wqv = a.wq[dd];
-    float dw = 0.f;
-    for (int l = 0; l < L; ++l)
-      for (int t = 0; t < T; ++t) {
-        const size_t o = (((size_t)l * B + b) * T + t) * d + dd;
-        const float h = a.Hq[o];
-        const float s = dsq[l * 32 + t];
-        dw = fmaf(s, h, dw);
-        a.dZq[o] = s * wqv * (1.0f - h * h);
+  // ---- dZ_q rows and the dw_q partial: 128 threads x float4 cover d = 512; two row groups
+  const int grp = tid >> 7, c4 = (tid & 127) * 4;
+  const float* Hp = a.Hq + pair * (size_t)T * d;
+  float* Zp = a.dZq + pair * (size_t)T * d;
+  for (int base = 0; base < d; base += 512) {      // uniform trip count: barriers inside
+    const int c0 = base + c4;
+    const bool act = c0 < d;
+    f32x4 dw = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (act) {
+      const f32x4 wq4 = *reinterpret_cast<const f32x4*>(a.wq + c0);
+      for (int t = grp; t < T; t += 2) {
+        const f32x4 h = *reinterpret_cast<const f32x4*>(Hp + (size_t)t * d + c0);
+        const float sv = dsq[t];
+        f32x4 z;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dw[e] = fmaf(sv, h[e], dw[e]);
+          z[e] = sv * wq4[e] * (1.0f - h[e] * h[e]);
+        }
+        *reinterpret_cast<f32x4*>(Zp + (size_t)t * d + c0) = z;
       }
-    a.dwq_part[(size_t)b * d + dd] = dw;
-  }
-  if (tid == 0) {
-    a.dcs_part[(size_t)b * 2 + 0] = dcs[0] + dcs[1] + dcs[2];
-    a.dcs_part[(size_t)b * 2 + 1] = dcs[4] + dcs[5] + dcs[6];
+      if (grp == 1) *reinterpret_cast<f32x4*>(dwr + c0) = dw;
+    }
+    __syncthreads();
+    if (act && grp == 0) {
+      const f32x4 o = *reinterpret_cast<const f32x4*>(dwr + c0);
+      *reinterpret_cast<f32x4*>(a.dwq_part + pair * (size_t)d + c0) = dw + o;
+    }
+    __syncthreads();
   }
 }
 
@@ -150,6 +168,8 @@ struct BwdArgs {
   float* dPq;             // [L][B][T][d]
   float* dA;              // [L][B][T][N]
   float* dwv_part;        // [L*B][d]
+  float* dbv_part;        // [L*B][d]   sum_n dP_v[n][:]
+  float* dbq_part;        // [L*B][d]   sum_t dP_q[t][:]
   int B, N, T, d, L;
 };
 
@@ -216,7 +236,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc_kernel(const BwdArgs a) {
       dzqA[tt] = (t < T) ? *reinterpret_cast<const f32x4*>(dZqp + (size_t)t * d + db + 4 * q4) : zero4;
     }
     const f32x4 wv4 = *reinterpret_cast<const f32x4*>(a.wv + db + 4 * q4);
-    f32x4 dwv4 = zero4;
+    f32x4 dwv4 = zero4, dbv4 = zero4;
     // transposed tiles, C/D layout: col = j <-> n, row = 4*q4 + r <-> channel db + 4*q4 + r
     auto load_pvT = [&](int nt) { return buf_load4(rs_pv, voff, (16 * nt * d + db) * 4); };
     f32x4 pvT_q[3];                                    // prefetch ring, two tiles ahead
@@ -246,6 +266,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc_kernel(const BwdArgs a) {
 #pragma unroll
       for (int s = 0; s < kTS; ++s) dpv = mfma16(dzqB[s], cB[s], dpv);
       buf_store4(dpv, rs_dpv, voff, (16 * nt * d + db) * 4);
+      dbv4 += dpv;                                   // rows n >= N are exact zeros
       // dC[t][n] += sum_r P_q[t][db+4q4+r] dZ_v[n][..] + dZ_q[t][..] P_v[n][..]
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -258,8 +279,14 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc_kernel(const BwdArgs a) {
     }
     // dw_v[db + 4*q4 + r] partial of this (sample, level): sum over the 16 lanes (locations)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dwv4[r] = row16_sum(dwv4[r]);
-    if (j == 0) *reinterpret_cast<f32x4*>(a.dwv_part + pair * (size_t)d + db + 4 * q4) = dwv4;
+    for (int r = 0; r < 4; ++r) {
+      dwv4[r] = row16_sum(dwv4[r]);
+      dbv4[r] = row16_sum(dbv4[r]);
+    }
+    if (j == 0) {
+      *reinterpret_cast<f32x4*>(a.dwv_part + pair * (size_t)d + db + 4 * q4) = dwv4;
+      *reinterpret_cast<f32x4*>(a.dbv_part + pair * (size_t)d + db + 4 * q4) = dbv4;
+    }
   }
 
   // cross-wave sum of dC in a fixed tree order, then dA = dC (1 - C^2)
@@ -361,8 +388,11 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dpq_kernel(const BwdArgs a) {
       half_unit<true, 1, LD>(pvB, pq, wvr, accq, Cbuf, nb, j, q4, sv, dsn);
     }
   }
-  // dP_q = dZ_q + acc
+  // dP_q = dZ_q + acc ; db_q partial = sum_t dP_q[t][:]
   float* dPqp = a.dPq + pair * (size_t)T * d;
+  float dbq[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) dbq[c] = 0.f;
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -372,10 +402,18 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dpq_kernel(const BwdArgs a) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           const size_t o = (size_t)t * d + dsl + 16 * c + j;
-          dPqp[o] = accq[tt][c][r] + dZqp[o];
+          const float v = accq[tt][c][r] + dZqp[o];
+          dPqp[o] = v;
+          dbq[c] += v;
         }
       }
     }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {                      // sum over the four row quads (lanes j, j+16, j+32, j+48)
+    dbq[c] += __shfl_xor(dbq[c], 16, 64);
+    dbq[c] += __shfl_xor(dbq[c], 32, 64);
+    if (q4 == 0) a.dbq_part[pair * (size_t)d + dsl + 16 * c + j] = dbq[c];
+  }
 }
 
 template <typename K>
@@ -383,12 +421,9 @@ void set_lds(K kern, size_t bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <int NT>
 int launch_pre(const PreArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)(6 * a.d + 16 * 3 * 16 * NT + 3 * 16 * NT + 96 + 96 + 8) * sizeof(float);
-  static bool once = false;
-  if (!once) { set_lds(bwd_pre_kernel<NT>, lds); once = true; }
-  hipLaunchKernelGGL(bwd_pre_kernel<NT>, dim3(a.B), dim3(256), lds, s, a);
+  const size_t lds = (size_t)(64 + a.d) * sizeof(float);
+  hipLaunchKernelGGL(bwd_pre_kernel, dim3(a.L * a.B), dim3(256), lds, s, a);
   CA_CHECK_LAUNCH("bwd_pre");
   return 0;
 }
@@ -429,35 +464,36 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const floa
   const size_t BTd = (size_t)B * T * d, BTN = (size_t)B * T * N, BNd = (size_t)B * N * d, Bd = (size_t)B * d;
   const bool small_n = N <= 64;
   // 1. per-sample pre-pass
+  CA_CHECK_ARG(N <= 256, "fused backward: N > 256");
+  hipLaunchKernelGGL(bwd_dav_kernel, dim3(d / 64, B), dim3(256), 0, s, V, gv, ws + wo.part, B, N, d, L);
+  CA_CHECK_LAUNCH("bwd_dav");
   PreArgs pa;
-  pa.V = V;
+  pa.dav_part = ws + wo.part;
   for (int l = 0; l < 8; ++l) pa.Q[l] = l < L ? Q[l] : nullptr;
-  pa.gv = gv; pa.gq = gq; pa.av = saved + so.av; pa.aq = saved + so.aq; pa.Hq = saved + so.Hq;
+  pa.gq = gq; pa.av = saved + so.av; pa.aq = saved + so.aq; pa.Hq = saved + so.Hq;
   pa.wq = (const float*)p->w_q;
   pa.dsv = ws + wo.dsv; pa.dZq = ws + wo.dZq; pa.dwq_part = ws + wo.dwq_part; pa.dcs_part = ws + wo.dcs_part;
   pa.B = B; pa.N = N; pa.T = T; pa.d = d; pa.L = L;
-  CA_TRY(small_n ? launch_pre<4>(pa, s) : launch_pre<13>(pa, s));
+  CA_TRY(launch_pre(pa, s));
   // 2. the two recompute kernels
   BwdArgs ba;
   ba.Pv = saved + so.Pv; ba.Pq = saved + so.Pq; ba.C = saved + so.C; ba.dsv = ws + wo.dsv; ba.dZq = ws + wo.dZq;
   ba.wv = (const float*)p->w_v;
   ba.dPv = ws + wo.dPv; ba.dPq = ws + wo.dPq; ba.dA = ws + wo.dA; ba.dwv_part = ws + wo.dwv_part;
+  ba.dbv_part = ws + wo.dbv_part; ba.dbq_part = ws + wo.dbq_part;
   ba.B = B; ba.N = N; ba.T = T; ba.d = d; ba.L = L;
   if (d == 512) {
     CA_TRY(small_n ? (launch_main<4, 4>(ba, s)) : (launch_main<13, 4>(ba, s)));
   } else {
     CA_TRY(small_n ? (launch_main<4, 2>(ba, s)) : (launch_main<13, 2>(ba, s)));
   }
-  // 3. small parameter gradients from the partials
-  CA_TRY(launch_reduce_partials(ws + wo.dwv_part, (float*)pg->dw_v, L * B, d, accumulate, s));
-  CA_TRY(launch_reduce_partials(ws + wo.dwq_part, (float*)pg->dw_q, B, d, accumulate, s));
+  // 3. small parameter gradients from the per-(sample, level) partials, one launch
   {
-    // dc_v, dc_q: column sums of dcs_part [B][2]
-    int nch = 0;
-    float* part = ws + wo.part;
-    CA_TRY(launch_colsum_partial(nullptr, ws + wo.dcs_part, part, B, 2, B, &nch, s));
-    CA_TRY(launch_reduce_partials(part, (float*)pg->dc_v, 1, 1, accumulate, s));
-    CA_TRY(launch_reduce_partials(part + 1, (float*)pg->dc_q, 1, 1, accumulate, s));
+    const float* src[4] = {ws + wo.dwv_part, ws + wo.dbv_part, ws + wo.dbq_part, ws + wo.dwq_part};
+    float* dst[4] = {(float*)pg->dw_v, (float*)pg->db_v, (float*)pg->db_q, (float*)pg->dw_q};
+    CA_TRY(launch_reduce_jobs(src, dst, 4, L * B, d, accumulate, s));
+    CA_TRY(launch_sum_all(ws + wo.dcs_part, (float*)pg->dc_v, (int64_t)L * B, accumulate, s));
+    CA_TRY(launch_sum_all(ws + wo.dcs_part + (size_t)L * B, (float*)pg->dc_q, (int64_t)L * B, accumulate, s));
   }
   // 4. dQ_l = a_q (x) gq + dA V^T + dP_q W_q ;  dV = sum_l (a_v (x) gv + Q^T dA) + (sum_l dP_v) W_v
   for (int l = 0; l < L; ++l) {
@@ -474,15 +510,6 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const floa
       g.M = T; g.N = d; g.K = N; g.batch = B;
       CA_TRY(launch_gemm_f32(g, s));
     }
-    {
-      coattn_gemm_desc g = {};
-      g.A = ws + wo.dPq + l * BTd; g.a_sm = d; g.a_sk = 1;
-      g.B = p->W_q; g.b_sk = d; g.b_sn = 1;
-      g.Cin = dQ[l]; g.cin_sm = d; g.cin_sn = 1; g.beta = 1.f;
-      g.C = dQ[l]; g.c_sm = d; g.c_sn = 1;
-      g.M = B * T; g.N = d; g.K = d; g.batch = 1;
-      CA_TRY(launch_gemm_f32(g, s));
-    }
     if (dV) {
       CA_TRY(launch_rank1(av, gv + l * Bd, dV, B, N, d, (int64_t)d * N, 1, N, l > 0 ? 1 : 0, s));
       coattn_gemm_desc g = {};
@@ -494,10 +521,22 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const floa
       CA_TRY(launch_gemm_f32(g, s));
     }
   }
-  // sum dP_v over the levels (in place into level 0)
+  {
+    // dQ_l += dP_q,l W_q for all levels in one launch (batch z = level, C through the pointer table)
+    coattn_gemm_desc g = {};
+    g.A = ws + wo.dPq; g.a_sz = (int64_t)BTd; g.a_sm = d; g.a_sk = 1;
+    g.B = p->W_q; g.b_sk = d; g.b_sn = 1;
+    for (int l = 0; l < L; ++l) { g.c_ptrs[l] = dQ[l]; g.cin_ptrs[l] = dQ[l]; }
+    g.cin_sm = d; g.cin_sn = 1; g.beta = 1.f;
+    g.c_sm = d; g.c_sn = 1;
+    g.M = B * T; g.N = d; g.K = d; g.batch = L;
+    CA_TRY(launch_gemm_f32(g, s));
+  }
+  // sum dP_v over the levels in place into level 0 (two streaming passes)
   float* dPv = ws + wo.dPv;
   for (int l = 1; l < L; ++l) CA_TRY(launch_add_inplace(dPv, dPv + l * BNd, (int64_t)BNd, 1, s));
   if (dV) {
+    // dV[b][k][n] += sum_j W_v[j][k] dP_v[b][n][j]
     coattn_gemm_desc g = {};
     g.A = p->W_v; g.a_sm = 1; g.a_sk = d; g.a_sz = 0;
     g.B = dPv; g.b_sz = (int64_t)N * d; g.b_sk = 1; g.b_sn = d;
@@ -508,8 +547,8 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const floa
   }
   // 5. weight gradients
   float* part = ws + wo.part;
-  int nch = 0;
   {
+    // dW_v[j][k] = sum_{b,n} dP_v[b][n][j] V[b][k][n]: inner index = sample, split into <= 32 groups
     const int G = (B + 31) / 32;
     const int S = (B + G - 1) / G;
     coattn_gemm_desc g = {};
@@ -519,28 +558,22 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const floa
     g.M = d; g.N = d; g.K = N; g.batch = S; g.inner = G; g.inner_total = B;
     CA_TRY(launch_gemm_f32(g, s));
     CA_TRY(launch_reduce_partials(part, (float*)pg->dW_v, S, (int64_t)d * d, accumulate, s));
-    const int rpc = (B * N + 255) / 256 > 32 ? (B * N + 255) / 256 : 32;
-    CA_TRY(launch_colsum_partial(nullptr, dPv, part, B * N, d, rpc, &nch, s));
-    CA_TRY(launch_reduce_partials(part, (float*)pg->db_v, nch, d, accumulate, s));
   }
-  for (int l = 0; l < L; ++l) {
+  {
+    // dW_q[j][k] = sum_l sum_m dP_q,l[m][j] Q_l[m][k]: levels as the inner loop (B from the pointer
+    // table), split-K over the B*T rows
     const int K = B * T;
     int ks = (K + 31) / 32;
     ks = (ks + 15) / 16 * 16;
     const int S = (K + ks - 1) / ks;
     coattn_gemm_desc g = {};
-    g.A = ws + wo.dPq + l * BTd; g.a_sm = 1; g.a_sk = d;
-    g.B = Q[l]; g.b_sk = d; g.b_sn = 1;
+    g.A = ws + wo.dPq; g.a_sm = 1; g.a_sk = d; g.a_si = (int64_t)BTd;
+    for (int l = 0; l < L; ++l) g.b_ptrs[l] = Q[l];
+    g.ptr_by_inner = 1; g.b_sk = d; g.b_sn = 1;
     g.C = part; g.c_sz = (int64_t)d * d; g.c_sm = d; g.c_sn = 1;
-    g.M = d; g.N = d; g.K = K; g.batch = S; g.ksplit = ks;
+    g.M = d; g.N = d; g.K = K; g.batch = S; g.ksplit = ks; g.inner = L;
     CA_TRY(launch_gemm_f32(g, s));
-    CA_TRY(launch_reduce_partials(part, (float*)pg->dW_q, S, (int64_t)d * d, (accumulate || l > 0) ? 1 : 0, s));
-  }
-  {
-    const int R = L * B * T;
-    const int rpc = (R + 255) / 256 > 32 ? (R + 255) / 256 : 32;
-    CA_TRY(launch_colsum_partial(nullptr, ws + wo.dPq, part, R, d, rpc, &nch, s));
-    CA_TRY(launch_reduce_partials(part, (float*)pg->db_q, nch, d, accumulate, s));
+    CA_TRY(launch_reduce_partials(part, (float*)pg->dW_q, S, (int64_t)d * d, accumulate, s));
   }
   return 0;
 }

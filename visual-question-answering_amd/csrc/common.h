@@ -83,6 +83,9 @@ int launch_colsum_partial(const float* s, const float* X, float* part, int R, in
                           int* nchunks, hipStream_t s_);
 // out[j] (+)= sum_c part[c][j]   (n = elements per partial)
 int launch_reduce_partials(const float* part, float* out, int nparts, int64_t n, int accumulate, hipStream_t s);
+// up to 4 reductions dst[i][j] (+)= sum_c src[i][c][j] in one launch
+int launch_reduce_jobs(const float* const* src, float* const* dst, int njobs, int nparts, int64_t n, int accumulate,
+                       hipStream_t s);
 // total (+)= sum of x[0..n)   (single block)
 int launch_sum_all(const float* x, float* out, int64_t n, int accumulate, hipStream_t s);
 // H[z][r][j] = ds[z][r] * w[j] * (1 - H^2)      (in place or out of place)

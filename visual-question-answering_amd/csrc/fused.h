@@ -129,7 +129,7 @@ inline SavedOff saved_off(int B, int N, int T, int d, int L) {   // the one layo
 
 // workspace of the fused backward (floats)
 struct FusedBwdOff {
-  size_t dsv, dZq, dPq, dPv, dA, dwv_part, dwq_part, dcs_part, part, total;
+  size_t dsv, dZq, dPq, dPv, dA, dwv_part, dbv_part, dbq_part, dwq_part, dcs_part, part, total;
 };
 inline FusedBwdOff fused_bwd_off(int B, int N, int T, int d, int L) {
   FusedBwdOff p;
@@ -140,8 +140,10 @@ inline FusedBwdOff fused_bwd_off(int B, int N, int T, int d, int L) {
   p.dPv = o; o += fal64((size_t)L * B * N * d);
   p.dA = o;  o += fal64((size_t)L * B * T * N);
   p.dwv_part = o; o += fal64((size_t)L * B * d);
-  p.dwq_part = o; o += fal64((size_t)B * d);
-  p.dcs_part = o; o += fal64((size_t)B * 2);
+  p.dbv_part = o; o += fal64((size_t)L * B * d);
+  p.dbq_part = o; o += fal64((size_t)L * B * d);
+  p.dwq_part = o; o += fal64((size_t)L * B * d);
+  p.dcs_part = o; o += fal64((size_t)L * B * 2);
   p.part = o; o += fal64((size_t)32 * d * d);
   p.total = o;
   return p;

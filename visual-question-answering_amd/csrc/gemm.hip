@@ -26,6 +26,8 @@ struct GemmK {
   long b_sk, b_sn, b_sz, b_si;
   long c_sm, c_sn, c_sz, c_mdiv, c_sdiv;
   long cin_sm, cin_sn, cin_sz, cin_mdiv, cin_sdiv;
+  const float* a_ptrs[8]; const float* b_ptrs[8]; float* c_ptrs[8]; const float* cin_ptrs[8];
+  int ptr_by_inner, b_imod;
 };
 
 __device__ __forceinline__ long row_off(long m, long sm, long mdiv, long sdiv) {
@@ -97,8 +99,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmK g) {
   // step -> (inner index, k0)
   auto load_step = [&](int step) {
     const int ii = step / ksteps, k0 = kbeg + (step - ii * ksteps) * BK;
-    const float* Ab = g.A + (long)z * g.a_sz + (long)ii * g.a_si + (long)k0 * g.a_sk;
-    const float* Bb = g.B + (long)z * g.b_sz + (long)ii * g.b_si + (long)k0 * g.b_sk;
+    const int ig = g.inner_total > 0 ? z * g.inner + ii : ii;      // global inner index
+    const int pt = g.ptr_by_inner ? ig : z;
+    const float* Ab = (g.a_ptrs[0] ? g.a_ptrs[pt & 7] : g.A + (long)z * g.a_sz + (long)ii * g.a_si)
+                      + (long)k0 * g.a_sk;
+    const float* Bb = (g.b_ptrs[0] ? g.b_ptrs[pt & 7]
+                                   : g.B + (g.b_imod > 0 ? (long)(ig % g.b_imod) * g.b_si
+                                                         : (long)z * g.b_sz + (long)ii * g.b_si))
+                      + (long)k0 * g.b_sk;
     if (k0 + BK <= kend) {
 #pragma unroll
       for (int i = 0; i < EA; ++i) ra[i] = a_ok[i] ? Ab[a_off[i]] : 0.f;
@@ -148,8 +156,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmK g) {
   }
 
   // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  float* Cb = g.C + (long)z * g.c_sz;
-  const float* Cinb = g.Cin ? g.Cin + (long)z * g.cin_sz : nullptr;
+  float* Cb = g.c_ptrs[0] ? g.c_ptrs[z & 7] : g.C + (long)z * g.c_sz;
+  const float* Cinb = g.cin_ptrs[0] ? g.cin_ptrs[z & 7] : (g.Cin ? g.Cin + (long)z * g.cin_sz : nullptr);
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -170,12 +178,171 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmK g) {
     }
 }
 
+
+// ---- aligned fast path: BK = 32, float4 global loads, one LDS buffer + register prefetch --------
+// Operand images: an operand whose fast (contiguous) axis is the tile row/column index (AM / BN)
+// is staged as [k][m] with 16-byte LDS writes; an operand that is contiguous along k is staged
+// as [m][k] with an odd row stride (33), so that both the transposing 4-byte writes and the
+// 32-lane MFMA operand reads are bank-conflict free.
+template <bool AM, bool BN_>
+__global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
+  constexpr int BM = 128, BN = 128, BK = 32;
+  constexpr int LDM = BM + 4;              // [k][m] image row stride
+  constexpr int LDK = BK + 1;              // [m][k] image row stride
+  constexpr int ASZ = AM ? BK * LDM : BM * LDK;
+  constexpr int BSZ = BN_ ? BK * LDM : BN * LDK;
+  __shared__ __attribute__((aligned(16))) float As[ASZ];
+  __shared__ __attribute__((aligned(16))) float Bs[BSZ];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, z = blockIdx.z;
+  int kbeg = 0, kend = g.K;
+  if (g.ksplit > 0) {
+    kbeg = z * g.ksplit;
+    kend = min(g.K, kbeg + g.ksplit);
+  }
+  int ninner = g.inner;
+  if (g.inner_total > 0) ninner = max(0, min(g.inner, g.inner_total - z * g.inner));
+  const int ksteps = (kend - kbeg + BK - 1) / BK;
+  const int nsteps = ninner * max(ksteps, 0);
+
+  // 4 float4 per thread per operand; offsets hoisted (32-bit, element units)
+  int a_off[4], a_lds[4], a_k[4];
+  bool a_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i;                  // float4 index in the 128 x 32 tile
+    int m, k;
+    if (AM) { k = idx >> 5; m = (idx & 31) * 4; } else { m = idx >> 3; k = (idx & 7) * 4; }
+    a_k[i] = k;
+    a_lds[i] = AM ? k * LDM + m : m * LDK + k;
+    a_ok[i] = (m0 + m) < g.M;                      // M % 4 == 0 on this path: whole float4 in or out
+    a_off[i] = a_ok[i] ? (int)(row_off(m0 + m, g.a_sm, g.a_mdiv, g.a_sdiv) + (long)k * g.a_sk) : 0;
+  }
+  int b_off[4], b_lds[4], b_k[4];
+  bool b_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i;
+    int n, k;
+    if (BN_) { k = idx >> 5; n = (idx & 31) * 4; } else { n = idx >> 3; k = (idx & 7) * 4; }
+    b_k[i] = k;
+    b_lds[i] = BN_ ? k * LDM + n : n * LDK + k;
+    b_ok[i] = (n0 + n) < g.N;
+    b_off[i] = b_ok[i] ? (int)((long)k * g.b_sk + (long)(n0 + n) * g.b_sn) : 0;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[4], rb[4];
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto load_step = [&](int step) {
+    const int ii = step / ksteps, k0 = kbeg + (step - ii * ksteps) * BK;
+    const int ig = g.inner_total > 0 ? z * g.inner + ii : ii;
+    const int pt = g.ptr_by_inner ? ig : z;
+    const float* Ab = (g.a_ptrs[0] ? g.a_ptrs[pt & 7] : g.A + (long)z * g.a_sz + (long)ii * g.a_si)
+                      + (long)k0 * g.a_sk;
+    const float* Bb = (g.b_ptrs[0] ? g.b_ptrs[pt & 7]
+                                   : g.B + (g.b_imod > 0 ? (long)(ig % g.b_imod) * g.b_si
+                                                         : (long)z * g.b_sz + (long)ii * g.b_si))
+                      + (long)k0 * g.b_sk;
+    const int klim = kend - k0;                    // K range % 4 == 0 on this path
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      ra[i] = (a_ok[i] && a_k[i] < klim) ? *reinterpret_cast<const f32x4*>(Ab + a_off[i]) : zero4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      rb[i] = (b_ok[i] && b_k[i] < klim) ? *reinterpret_cast<const f32x4*>(Bb + b_off[i]) : zero4;
+  };
+  auto store_step = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (AM) {
+        *reinterpret_cast<f32x4*>(&As[a_lds[i]]) = ra[i];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) As[a_lds[i] + e] = ra[i][e];
+      }
+      if (BN_) {
+        *reinterpret_cast<f32x4*>(&Bs[b_lds[i]]) = rb[i];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Bs[b_lds[i] + e] = rb[i][e];
+      }
+    }
+  };
+
+  if (nsteps > 0) {
+    load_step(0);
+    store_step();
+  }
+  __syncthreads();
+  const int li = lane & 31, lh = lane >> 5;
+  for (int step = 0; step < nsteps; ++step) {
+    if (step + 1 < nsteps) load_step(step + 1);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[2], b[2];
+      const int krow = kk + lh;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = wr * 64 + i * 32 + li;
+        a[i] = AM ? As[krow * LDM + m] : As[m * LDK + krow];
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = wc * 64 + j * 32 + li;
+        b[j] = BN_ ? Bs[krow * LDM + n] : Bs[n * LDK + krow];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (step + 1 < nsteps) {
+      store_step();
+      __syncthreads();
+    }
+  }
+
+  float* Cb = g.c_ptrs[0] ? g.c_ptrs[z & 7] : g.C + (long)z * g.c_sz;
+  const float* Cinb = g.cin_ptrs[0] ? g.cin_ptrs[z & 7] : (g.Cin ? g.Cin + (long)z * g.cin_sz : nullptr);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wc * 64 + j * 32 + li;
+      const float bn = (g.bias_n && col < g.N) ? g.bias_n[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < g.M && col < g.N) {
+          float v = acc[i][j][r] + bn;
+          if (g.bias_m) v += g.bias_m[row];
+          if (Cinb) v += g.beta * Cinb[row_off(row, g.cin_sm, g.cin_mdiv, g.cin_sdiv) + (long)col * g.cin_sn];
+          if (g.act == 1) v = tanhf(v);
+          Cb[row_off(row, g.c_sm, g.c_mdiv, g.c_sdiv) + (long)col * g.c_sn] = v;
+        }
+      }
+    }
+}
+
 }  // namespace
 
 static long span(long n, long s) { return n > 0 ? (n - 1) * (s < 0 ? -s : s) : 0; }
 
 int launch_gemm_f32(const coattn_gemm_desc& d, hipStream_t s) {
-  CA_CHECK_ARG(d.A && d.B && d.C, "gemm: null operand");
+  CA_CHECK_ARG((d.A || d.a_ptrs[0]) && (d.B || d.b_ptrs[0]) && (d.C || d.c_ptrs[0]), "gemm: null operand");
+  CA_CHECK_ARG(!(d.ptr_by_inner && (d.c_ptrs[0] || d.cin_ptrs[0])), "gemm: C tables are indexed by batch only");
   CA_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0 && d.batch > 0, "gemm: bad shape M=%d N=%d K=%d batch=%d", d.M, d.N, d.K, d.batch);
   CA_CHECK_ARG(d.batch <= 65535, "gemm: batch %d exceeds grid.z", d.batch);
   GemmK g;
@@ -187,6 +354,14 @@ int launch_gemm_f32(const coattn_gemm_desc& d, hipStream_t s) {
   g.b_sk = d.b_sk; g.b_sn = d.b_sn; g.b_sz = d.b_sz; g.b_si = d.b_si;
   g.c_sm = d.c_sm; g.c_sn = d.c_sn; g.c_sz = d.c_sz; g.c_mdiv = d.c_mdiv; g.c_sdiv = d.c_sdiv;
   g.cin_sm = d.cin_sm; g.cin_sn = d.cin_sn; g.cin_sz = d.cin_sz; g.cin_mdiv = d.cin_mdiv; g.cin_sdiv = d.cin_sdiv;
+  for (int t = 0; t < 8; ++t) {
+    g.a_ptrs[t] = (const float*)d.a_ptrs[t]; g.b_ptrs[t] = (const float*)d.b_ptrs[t];
+    g.c_ptrs[t] = (float*)d.c_ptrs[t]; g.cin_ptrs[t] = (const float*)d.cin_ptrs[t];
+  }
+  g.ptr_by_inner = d.ptr_by_inner; g.b_imod = d.b_imod;
+  CA_CHECK_ARG(!(d.a_ptrs[0] || d.b_ptrs[0] || d.c_ptrs[0] || d.cin_ptrs[0]) ||
+                   (d.ptr_by_inner ? (d.inner_total > 0 ? d.inner_total : d.inner) : d.batch) <= 8,
+               "gemm: pointer tables hold at most 8 entries");
   // the kernel keeps tile-relative element offsets in 32 bits
   const long a_rows = d.a_mdiv > 0 ? span((d.M + d.a_mdiv - 1) / d.a_mdiv + 1, d.a_sdiv) + span(d.a_mdiv, d.a_sm)
                                    : span(d.M, d.a_sm);
@@ -197,6 +372,28 @@ int launch_gemm_f32(const coattn_gemm_desc& d, hipStream_t s) {
   g.b_nfast = (d.b_sn == 1) ? 1 : 0;
   const bool small_m = d.M <= 64;
   dim3 block(256);
+  // aligned fast path: every float4 the kernel forms must be 16-byte aligned and lie inside one row
+  auto al4 = [](long v) { return (v & 3) == 0; };
+  auto pal = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+  const bool a_m = g.a_mfast != 0, b_n = g.b_nfast != 0;
+  bool vec = !small_m && d.M >= 128 && (d.a_sk == 1 || d.a_sm == 1) && (d.b_sk == 1 || d.b_sn == 1);
+  if (vec) {
+    // A: contiguous axis m (a_m) or k; the other strides / offsets must keep 16-byte alignment
+    vec = vec && (a_m ? (al4(d.M) && al4(d.a_sk) && al4(d.a_mdiv) && al4(d.a_sdiv)) : (al4(d.a_sm) && al4(d.a_sdiv)));
+    vec = vec && (b_n ? (al4(d.N) && al4(d.b_sk)) : al4(d.b_sn));
+    vec = vec && al4(d.K) && al4(d.ksplit) && al4(d.a_sz) && al4(d.a_si) && al4(d.b_sz) && al4(d.b_si);
+    vec = vec && (d.a_ptrs[0] ? true : pal(d.A)) && (d.b_ptrs[0] ? true : pal(d.B));
+    for (int t = 0; t < 8; ++t) vec = vec && pal(d.a_ptrs[t]) && pal(d.b_ptrs[t]);
+  }
+  if (vec) {
+    dim3 grid((d.N + 127) / 128, (d.M + 127) / 128, d.batch);
+    if (a_m && b_n) hipLaunchKernelGGL((gemm_f32_vec_kernel<true, true>), grid, block, 0, s, g);
+    else if (a_m) hipLaunchKernelGGL((gemm_f32_vec_kernel<true, false>), grid, block, 0, s, g);
+    else if (b_n) hipLaunchKernelGGL((gemm_f32_vec_kernel<false, true>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_f32_vec_kernel<false, false>), grid, block, 0, s, g);
+    CA_CHECK_LAUNCH("gemm_f32_vec");
+    return 0;
+  }
   if (small_m) {
     dim3 grid((d.N + 127) / 128, (d.M + 31) / 32, d.batch);
     hipLaunchKernelGGL(gemm_f32_kernel<32>, grid, block, 0, s, g);

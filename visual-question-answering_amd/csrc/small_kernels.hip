@@ -123,6 +123,56 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* part,
   out[j] = accumulate ? out[j] + acc : acc;
 }
 
+// out[j] (+)= sum_c part[c][j], four float columns per thread (n % 4 == 0, 16-byte aligned)
+__global__ __launch_bounds__(256) void reduce_partials4_kernel(const float* part, float* out, int nparts, long n,
+                                                               int accumulate) {
+  const long j = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (j >= n) return;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  int c = 0;
+  for (; c + 8 <= nparts; c += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(part + (long)(c + u) * n + j);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  for (; c < nparts; ++c) acc += *reinterpret_cast<const f32x4*>(part + (long)c * n + j);
+  f32x4* o = reinterpret_cast<f32x4*>(out + j);
+  *o = accumulate ? *o + acc : acc;
+}
+
+// up to 4 independent reductions of [nparts][n] partial buffers in one launch (blockIdx.y = job)
+struct ReduceJobs {
+  const float* src[4];
+  float* dst[4];
+};
+__global__ __launch_bounds__(256) void reduce_jobs_kernel(const ReduceJobs jobs, int nparts, long n, int accumulate) {
+  const float* part = jobs.src[blockIdx.y];
+  float* out = jobs.dst[blockIdx.y];
+  const long j = (long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  float acc = 0.f;
+  int c = 0;
+  for (; c + 8 <= nparts; c += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(long)(c + u) * n + j];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  for (; c < nparts; ++c) acc += part[(long)c * n + j];
+  out[j] = accumulate ? out[j] + acc : acc;
+}
+
+__global__ __launch_bounds__(256) void add4_inplace_kernel(float* y, const float* x, long n4, int accumulate) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n4) return;
+  f32x4* yp = reinterpret_cast<f32x4*>(y) + idx;
+  const f32x4 xv = reinterpret_cast<const f32x4*>(x)[idx];
+  *yp = accumulate ? *yp + xv : xv;
+}
+
 __global__ __launch_bounds__(256) void sum_all_kernel(const float* x, float* out, long n, int accumulate) {
   __shared__ float red[4];
   float acc = 0.f;
@@ -215,7 +265,24 @@ int launch_colsum_partial(const float* sv, const float* X, float* part, int R, i
   return 0;
 }
 
+int launch_reduce_jobs(const float* const* src, float* const* dst, int njobs, int nparts, int64_t n, int accumulate,
+                       hipStream_t s) {
+  CA_CHECK_ARG(njobs >= 1 && njobs <= 4, "reduce_jobs: 1..4 jobs");
+  ReduceJobs jobs;
+  for (int i = 0; i < 4; ++i) { jobs.src[i] = i < njobs ? src[i] : nullptr; jobs.dst[i] = i < njobs ? dst[i] : nullptr; }
+  hipLaunchKernelGGL(reduce_jobs_kernel, dim3((unsigned)((n + 255) / 256), njobs), dim3(256), 0, s, jobs, nparts,
+                     (long)n, accumulate);
+  CA_CHECK_LAUNCH("reduce_jobs");
+  return 0;
+}
+
 int launch_reduce_partials(const float* part, float* out, int nparts, int64_t n, int accumulate, hipStream_t s) {
+  if ((n & 3) == 0 && ((((uintptr_t)part) | ((uintptr_t)out)) & 15) == 0) {
+    hipLaunchKernelGGL(reduce_partials4_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, part, out,
+                       nparts, (long)n, accumulate);
+    CA_CHECK_LAUNCH("reduce_partials4");
+    return 0;
+  }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, out, nparts,
                      (long)n, accumulate);
   CA_CHECK_LAUNCH("reduce_partials");
@@ -242,6 +309,12 @@ int launch_dtanh(const float* dC, const float* C, float* out, int64_t n, hipStre
 }
 
 int launch_add_inplace(float* y, const float* x, int64_t n, int accumulate, hipStream_t s) {
+  if ((n & 3) == 0 && ((((uintptr_t)y) | ((uintptr_t)x)) & 15) == 0) {
+    hipLaunchKernelGGL(add4_inplace_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, y, x, (long)(n / 4),
+                       accumulate);
+    CA_CHECK_LAUNCH("add4_inplace");
+    return 0;
+  }
   hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, x, (long)n,
                      accumulate);
   CA_CHECK_LAUNCH("add_inplace");

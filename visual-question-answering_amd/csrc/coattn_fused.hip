@@ -20,6 +20,7 @@
 // so two workgroups share a CU (480 workgroups for B=160, L=3 on 256 CUs); block ids are mapped
 // so that the L levels of one sample run on the same XCD (shared L2 for V and P_v).
 #include "fused.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -36,6 +37,7 @@ struct FwdArgs {
   float* Hq;             // [L][B][T][d]
   float* q_out;          // [L][B][d]
   int B, N, T, d, L;
+  int dbg;               // developer switch (COATTN_DEBUG): 1 = skip phase-1 k loop, 2 = skip phase-2 tile loop
 };
 
 
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
   constexpr int NSLOT = (NW / 2 > 2) ? NW / 2 : 2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* slots = lds;                                // NSLOT x kTRows x LD   (phase 1 reduction)
-  float* Cbuf = lds + NSLOT * kTRows * LD;           // kTRows x LD
+  float* Cbuf = lds + NSLOT * kSlotRows * LD;           // kTRows x LD
   float* svpart = slots;                             // NW x NPAD             (aliases, phase 2+)
   float* sqpart = slots + NW * NPAD;                 // NW x 32
   float* aqs = sqpart + NW * 32;                     // 32
@@ -65,6 +67,12 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
   const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(Qp, (unsigned)T * d * 4u);
   const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(Vp, (unsigned)d * N * 4u);
   const __amdgpu_buffer_rsrc_t rs_pv = make_rsrc(Pvp, (unsigned)N * d * 4u);
+
+  // phase-2 operands (this wave's 128-channel slice of P_q as MFMA B operands, w_v): loaded at
+  // the end of phase 1 so that they fly under the cross-wave reduction
+  const int dsl = w * 128;
+  float pq[kTS][8];                                  // B operand P_q[t = 4s + q4][dsl + 16c + j]
+  float wvr[8];
 
   // ------------------------------------------------------------------ phase 1: A = Q V^T
   {
@@ -94,6 +102,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
     load_q(0, qa[0]);
 #pragma unroll
     for (int u = 0; u < RING - 1; ++u) load_v(u, vb[u]);
+    if (!(a.dbg & 1))
 #pragma unroll
     for (int u = 0; u < 32; ++u) {                   // 32 k-steps of 4 = this wave's 128 channels
       if (u + RING - 1 < 32) load_v(u + RING - 1, vb[(u + RING - 1) % RING]);
@@ -106,6 +115,15 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
         acc[1][t] = mfma16(qa[qb][1][s], vb[u % RING][t], acc[1][t]);
       }
     }
+    {
+      const __amdgpu_buffer_rsrc_t rs_pq = make_rsrc(Pqp, (unsigned)T * d * 4u);   // rows >= T read 0
+#pragma unroll
+      for (int s = 0; s < kTS; ++s)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) pq[s][c] = buf_load1(rs_pq, ((4 * s + q4) * d + j) * 4 + 64 * c, dsl * 4);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) wvr[c] = a.wv[dsl + 16 * c + j];
+    }
     // cross-wave sum in a fixed tree order through LDS; C/D layout: col = j, row = 4*q4 + r
     auto put = [&](float* slot) {
 #pragma unroll
@@ -114,8 +132,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
         for (int t = 0; t < NT; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int row = 16 * tt + 4 * q4 + r;
-            if (row < kTRows) slot[row * LD + 16 * t + j] = acc[tt][t][r];
+            slot[(16 * tt + 4 * q4 + r) * LD + 16 * t + j] = acc[tt][t][r];
           }
     };
     auto add = [&](const float* slot) {
@@ -125,30 +142,29 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
         for (int t = 0; t < NT; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int row = 16 * tt + 4 * q4 + r;
-            if (row < kTRows) acc[tt][t][r] += slot[row * LD + 16 * t + j];
+            acc[tt][t][r] += slot[(16 * tt + 4 * q4 + r) * LD + 16 * t + j];
           }
     };
 #pragma unroll
     for (int stride = 1; stride < NW / 2; stride <<= 1) {
       const int m = 2 * stride - 1;
       if (stride > 1) __syncthreads();
-      if ((w & m) == stride) put(slots + (w / (2 * stride)) * kTRows * LD);
+      if ((w & m) == stride) put(slots + (w / (2 * stride)) * kSlotRows * LD);
       __syncthreads();
-      if ((w & m) == 0) add(slots + (w / (2 * stride)) * kTRows * LD);
+      if ((w & m) == 0) add(slots + (w / (2 * stride)) * kSlotRows * LD);
     }
     if (NW > 2) __syncthreads();
     if (w == NW / 2) put(slots);
-    if (w == 0) put(slots + kTRows * LD);
+    if (w == 0) put(slots + kSlotRows * LD);
     __syncthreads();
     // C = tanh(sum) by all threads; rows >= T are tanh(0) = 0 (their Q rows read as 0)
     float* Cg = a.C + pair * (size_t)T * N;
     constexpr int RSTEP = NW * 64 / 16;              // rows covered per sweep: 16 lanes per row
-    for (int row = tid >> 4; row < kTRows; row += RSTEP) {
+    for (int row = tid >> 4; row < ((a.dbg & 16) ? 0 : kTRows); row += RSTEP) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int col = 16 * t + (tid & 15);
-        float c = tanh_fast(slots[row * LD + col] + slots[kTRows * LD + row * LD + col]);
+        float c = tanh_fast(slots[row * LD + col] + slots[kSlotRows * LD + row * LD + col]);
         c = (col < N) ? c : 0.f;                     // padded columns carry junk from phase 1
         Cbuf[row * LD + col] = c;
         if (row < T && col < N) Cg[(size_t)row * N + col] = c;
@@ -158,24 +174,13 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
   }
 
   // ------------------------------------------------------------------ phase 2: H_v scores, H_q
-  const int dsl = w * 128;
-  float pq[kTS][8];                                  // B operand P_q[t = 4s + q4][dsl + 16c + j]
-#pragma unroll
-  for (int s = 0; s < kTS; ++s) {
-    const int t = 4 * s + q4;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) pq[s][c] = (t < T) ? Pqp[(size_t)t * d + dsl + 16 * c + j] : 0.f;
-  }
-  float wvr[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) wvr[c] = a.wv[dsl + 16 * c + j];
   f32x4 accq[2][8];
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
     for (int c = 0; c < 8; ++c) accq[tt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int ntiles = (N + 15) >> 4;
+  const int ntiles = (a.dbg & 2) ? 0 : (N + 15) >> 4;
   {
     const float dsn0[4] = {0.f, 0.f, 0.f, 0.f};
     f32x4 pvA[4], pvB[4];                            // half tiles (4 channel tiles each), double buffered
@@ -199,41 +204,40 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
   }
 
   // ------------------------------------------------------------------ phase 3
-  // H_q epilogue: hq = tanh(P_q + acc); saved for backward; s_q partials
-  {
-    float* Hqg = a.Hq + pair * (size_t)T * d;
-    float sq[2][4];
+  // H_q epilogue: hq = tanh(P_q + acc); saved for backward; s_q partials.  Branch-free: rows t >= T
+  // fall outside the per-sample buffers (loads give 0, stores are dropped), all loads issued first.
+  if (!(a.dbg & 4)) {
+    const __amdgpu_buffer_rsrc_t rs_pq = make_rsrc(Pqp, (unsigned)T * d * 4u);
+    const __amdgpu_buffer_rsrc_t rs_hq = make_rsrc(a.Hq + pair * (size_t)T * d, (unsigned)T * d * 4u);
     float wqr[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) wqr[c] = a.wq[dsl + 16 * c + j];
+    float sq[2][4];
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
+    for (int tt = 0; tt < 2; ++tt) {
+      float pqv[4][8];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sq[tt][r] = 0.f;
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
+        for (int c = 0; c < 8; ++c)
+          pqv[r][c] = buf_load1(rs_pq, ((16 * tt + 4 * q4 + r) * d + j) * 4 + 64 * c, dsl * 4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int t = 16 * tt + 4 * q4 + r;
-        if (t < T) {
+        float acc = 0.f;
 #pragma unroll
-          for (int c = 0; c < 8; ++c) {
-            const int dd = dsl + 16 * c + j;
-            const float h = tanh_fast(accq[tt][c][r] + Pqp[(size_t)t * d + dd]);
-            Hqg[(size_t)t * d + dd] = h;
-            sq[tt][r] = fmaf(h, wqr[c], sq[tt][r]);
-          }
+        for (int c = 0; c < 8; ++c) {
+          const float h = tanh_fast(accq[tt][c][r] + pqv[r][c]);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h), rs_hq,
+                                                ((16 * tt + 4 * q4 + r) * d + j) * 4 + 64 * c, dsl * 4, 0);
+          acc = fmaf(h, wqr[c], acc);
         }
-      }
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        sq[tt][r] = row16_sum(sq[tt][r]);
+        sq[tt][r] = row16_sum(acc);
         if (j == 0) sqpart[w * 32 + 16 * tt + 4 * q4 + r] = sq[tt][r];
       }
+    }
   }
   __syncthreads();
+  if (a.dbg & 8) return;
   if (w == 0) {
     // a_v = softmax_n(s_v + c_v): N <= 16*NT <= 256 -> <= 4 values per lane
     constexpr int PER = (NPAD + 63) / 64;
@@ -278,16 +282,18 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
     const float e = (lane < T) ? expf(s - mq) : 0.f;
     const float se = wave_sum(e);
     const float aqv = e / se;
-    if (lane < T) {
-      aqs[lane] = aqv;
-      a.aq[pair * (size_t)T + lane] = aqv;
-    }
+    if (lane < 32) aqs[lane] = aqv;                  // zeros beyond T
+    if (lane < T) a.aq[pair * (size_t)T + lane] = aqv;
   }
   __syncthreads();
-  // q = sum_t a_q[t] Q[t][:]   (model.py:392)
+  // q = sum_t a_q[t] Q[t][:]   (model.py:392): all kTRows row loads in flight at once (rows >= T read 0)
   for (int dd = tid; dd < d; dd += NW * 64) {
+    float x[kTRows];
+#pragma unroll
+    for (int t = 0; t < kTRows; ++t) x[t] = buf_load1(rs_q, (t * d + dd) * 4, 0);
     float acc = 0.f;
-    for (int t = 0; t < T; ++t) acc = fmaf(aqs[t], Qp[(size_t)t * d + dd], acc);
+#pragma unroll
+    for (int t = 0; t < kTRows; ++t) acc = fmaf(aqs[t], x[t], acc);
     a.q_out[pair * (size_t)d + dd] = acc;
   }
 }
@@ -332,7 +338,7 @@ template <int NT, int NW>
 int launch_fwd(const FwdArgs& a, hipStream_t s) {
   constexpr int LD = 16 * NT + 4;
   constexpr int NSLOT = (NW / 2 > 2) ? NW / 2 : 2;
-  const size_t lds = (size_t)(NSLOT + 1) * kTRows * LD * sizeof(float);
+  const size_t lds = (size_t)(NSLOT * kSlotRows + kTRows) * LD * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(coattn_attn_fwd_kernel<NT, NW>),
@@ -369,6 +375,7 @@ int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, c
   a.C = saved + so.C; a.av = saved + so.av; a.aq = saved + so.aq; a.Hq = saved + so.Hq;
   a.q_out = q_out;
   a.B = B; a.N = N; a.T = T; a.d = d; a.L = L;
+  { const char* e = getenv("COATTN_DEBUG"); a.dbg = e ? atoi(e) : 0; }
   const bool small_n = N <= 64;
   if (d == 512) {
     CA_TRY(small_n ? (launch_fwd<4, 4>(a, s)) : (launch_fwd<13, 4>(a, s)));

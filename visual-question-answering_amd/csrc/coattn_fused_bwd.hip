@@ -192,7 +192,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc_kernel(const BwdArgs a) {
   constexpr int NSLOT = (NW / 2 > 2) ? NW / 2 : 2;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* slots = lds;                                // NSLOT x kTRows x LD
-  float* Cbuf = lds + NSLOT * kTRows * LD;           // kTRows x LD
+  float* Cbuf = lds + NSLOT * kSlotRows * LD;           // kTRows x LD
   float* dsvs = Cbuf + kTRows * LD;                  // NPAD
   int b, l;
   if (!block_to_pair(blockIdx.x, a.B, a.L, b, l)) return;
@@ -207,6 +207,8 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc_kernel(const BwdArgs a) {
   // rows n >= N fall outside these buffers: loads give 0, stores are dropped
   const __amdgpu_buffer_rsrc_t rs_pv = make_rsrc(Pvp, (unsigned)N * d * 4u);
   const __amdgpu_buffer_rsrc_t rs_dpv = make_rsrc(dPvp, (unsigned)N * d * 4u);
+  const __amdgpu_buffer_rsrc_t rs_pq = make_rsrc(Pqp, (unsigned)T * d * 4u);
+  const __amdgpu_buffer_rsrc_t rs_dzq = make_rsrc(dZqp, (unsigned)T * d * 4u);
   const int voff = (j * d + 4 * q4) * 4;             // lane's row n = 16nt + j, channels db + 4q4..+3
   stage_c<NPAD, LD, NW * 64>(a, pair, Cbuf, dsvs, tid);
   __syncthreads();
@@ -223,17 +225,15 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc_kernel(const BwdArgs a) {
     // per-channel-tile operands
     float pqB[kTS], dzqB[kTS];                     // A[i = d = db + j][k = t = 4s + q4]
 #pragma unroll
-    for (int s = 0; s < kTS; ++s) {
-      const int t = 4 * s + q4;
-      pqB[s] = (t < T) ? Pqp[(size_t)t * d + db + j] : 0.f;
-      dzqB[s] = (t < T) ? dZqp[(size_t)t * d + db + j] : 0.f;
+    for (int s = 0; s < kTS; ++s) {                // rows t >= T lie outside the buffers: read 0
+      pqB[s] = buf_load1(rs_pq, ((4 * s + q4) * d + j) * 4, db * 4);
+      dzqB[s] = buf_load1(rs_dzq, ((4 * s + q4) * d + j) * 4, db * 4);
     }
     f32x4 pqA[2], dzqA[2];                         // A[i = t = 16tt + j][k = d = db + 4*q4 + r]
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
-      const int t = 16 * tt + j;
-      pqA[tt] = (t < T) ? *reinterpret_cast<const f32x4*>(Pqp + (size_t)t * d + db + 4 * q4) : zero4;
-      dzqA[tt] = (t < T) ? *reinterpret_cast<const f32x4*>(dZqp + (size_t)t * d + db + 4 * q4) : zero4;
+      pqA[tt] = buf_load4(rs_pq, ((16 * tt + j) * d + 4 * q4) * 4, db * 4);
+      dzqA[tt] = buf_load4(rs_dzq, ((16 * tt + j) * d + 4 * q4) * 4, db * 4);
     }
     const f32x4 wv4 = *reinterpret_cast<const f32x4*>(a.wv + db + 4 * q4);
     f32x4 dwv4 = zero4, dbv4 = zero4;
@@ -297,8 +297,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc_kernel(const BwdArgs a) {
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = 16 * tt + 4 * q4 + r;
-          if (row < kTRows) slot[row * LD + 16 * t + j] = acc[tt][t][r];
+          slot[(16 * tt + 4 * q4 + r) * LD + 16 * t + j] = acc[tt][t][r];
         }
   };
   auto add = [&](const float* slot) {
@@ -308,28 +307,27 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc_kernel(const BwdArgs a) {
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = 16 * tt + 4 * q4 + r;
-          if (row < kTRows) acc[tt][t][r] += slot[row * LD + 16 * t + j];
+          acc[tt][t][r] += slot[(16 * tt + 4 * q4 + r) * LD + 16 * t + j];
         }
   };
 #pragma unroll
   for (int stride = 1; stride < NW / 2; stride <<= 1) {
     const int m = 2 * stride - 1;
     if (stride > 1) __syncthreads();
-    if ((w & m) == stride) put(slots + (w / (2 * stride)) * kTRows * LD);
+    if ((w & m) == stride) put(slots + (w / (2 * stride)) * kSlotRows * LD);
     __syncthreads();
-    if ((w & m) == 0) add(slots + (w / (2 * stride)) * kTRows * LD);
+    if ((w & m) == 0) add(slots + (w / (2 * stride)) * kSlotRows * LD);
   }
   if (NW > 2) __syncthreads();
   if (w == NW / 2) put(slots);
-  if (w == 0) put(slots + kTRows * LD);
+  if (w == 0) put(slots + kSlotRows * LD);
   __syncthreads();
   float* dAg = a.dA + pair * (size_t)T * N;
   for (int e = tid; e < T * NPAD; e += NW * 64) {
     const int row = e / NPAD, col = e - row * NPAD;
     if (col < N) {
       const float c = Cbuf[row * LD + col];
-      dAg[(size_t)row * N + col] = (slots[row * LD + col] + slots[kTRows * LD + row * LD + col]) * (1.0f - c * c);
+      dAg[(size_t)row * N + col] = (slots[row * LD + col] + slots[kSlotRows * LD + row * LD + col]) * (1.0f - c * c);
     }
   }
 }
@@ -352,13 +350,13 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dpq_kernel(const BwdArgs a) {
   const float* dZqp = a.dZq + pair * (size_t)T * d;
   stage_c<NPAD, LD, NW * 64>(a, pair, Cbuf, dsvs, tid);
   const int dsl = w * 128;
+  const __amdgpu_buffer_rsrc_t rs_pq = make_rsrc(Pqp, (unsigned)T * d * 4u);       // rows >= T read 0
+  const __amdgpu_buffer_rsrc_t rs_dzq = make_rsrc(dZqp, (unsigned)T * d * 4u);
   float pq[kTS][8];
 #pragma unroll
-  for (int s = 0; s < kTS; ++s) {
-    const int t = 4 * s + q4;
+  for (int s = 0; s < kTS; ++s)
 #pragma unroll
-    for (int c = 0; c < 8; ++c) pq[s][c] = (t < T) ? Pqp[(size_t)t * d + dsl + 16 * c + j] : 0.f;
-  }
+    for (int c = 0; c < 8; ++c) pq[s][c] = buf_load1(rs_pq, ((4 * s + q4) * d + j) * 4 + 64 * c, dsl * 4);
   float wvr[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) wvr[c] = a.wv[dsl + 16 * c + j];
@@ -388,26 +386,30 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dpq_kernel(const BwdArgs a) {
       half_unit<true, 1, LD>(pvB, pq, wvr, accq, Cbuf, nb, j, q4, sv, dsn);
     }
   }
-  // dP_q = dZ_q + acc ; db_q partial = sum_t dP_q[t][:]
-  float* dPqp = a.dPq + pair * (size_t)T * d;
+  // dP_q = dZ_q + acc ; db_q partial = sum_t dP_q[t][:].  Branch-free (rows >= T: loads 0, stores dropped)
+  const __amdgpu_buffer_rsrc_t rs_dpq = make_rsrc(a.dPq + pair * (size_t)T * d, (unsigned)T * d * 4u);
   float dbq[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) dbq[c] = 0.f;
 #pragma unroll
-  for (int tt = 0; tt < 2; ++tt)
+  for (int tt = 0; tt < 2; ++tt) {
+    float zq[4][8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) zq[r][c] = buf_load1(rs_dzq, ((16 * tt + 4 * q4 + r) * d + j) * 4 + 64 * c, dsl * 4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int t = 16 * tt + 4 * q4 + r;
-      if (t < T) {
+      const bool live = (16 * tt + 4 * q4 + r) < T;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const size_t o = (size_t)t * d + dsl + 16 * c + j;
-          const float v = accq[tt][c][r] + dZqp[o];
-          dPqp[o] = v;
-          dbq[c] += v;
-        }
+      for (int c = 0; c < 8; ++c) {
+        const float v = accq[tt][c][r] + zq[r][c];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_dpq,
+                                              ((16 * tt + 4 * q4 + r) * d + j) * 4 + 64 * c, dsl * 4, 0);
+        dbq[c] += live ? v : 0.f;
       }
     }
+  }
 #pragma unroll
   for (int c = 0; c < 8; ++c) {                      // sum over the four row quads (lanes j, j+16, j+32, j+48)
     dbq[c] += __shfl_xor(dbq[c], 16, 64);
@@ -432,7 +434,7 @@ template <int NT, int NW>
 int launch_main(const BwdArgs& a, hipStream_t s) {
   constexpr int LD = 16 * NT + 4;
   constexpr int NSLOT = (NW / 2 > 2) ? NW / 2 : 2;
-  const size_t lds_dc = (size_t)((NSLOT + 1) * kTRows * LD + 16 * NT) * sizeof(float);
+  const size_t lds_dc = (size_t)((NSLOT * kSlotRows + kTRows) * LD + 16 * NT) * sizeof(float);
   const size_t lds_pq = (size_t)(kTRows * LD + 16 * NT) * sizeof(float);
   static bool once = false;
   if (!once) {

@@ -15,6 +15,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const floa
 // ---- shared by the fused forward / backward translation units -------------------------------
 constexpr int kTS = 7;       // k-steps of 4 over T: T <= 28
 constexpr int kTRows = 28;   // rows of C kept in LDS
+constexpr int kSlotRows = 32; // rows of a cross-wave reduction slot (both 16-row MFMA tiles)
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);

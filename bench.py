@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline / hot_path legs")
     ap.add_argument("--only", type=str, default="", help="developer switch: run only 'roofline' or 'hot' legs")
     ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--nchw", dest="channels_last", action="store_false",
+                    help="keep the stock VGG encoder in NCHW (default: channels_last, MIOpen NHWC kernels, ~25 %% "
+                         "faster forward; its first call tunes for up to a minute)")
     return ap.parse_args()
 
 
@@ -99,20 +102,25 @@ def hot_path_leg(device, N, B=160, T=26, d=512, K=1000, iters=20):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
-    # forward / backward of the HIP op alone, HIP events on the launch stream
-    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    # forward / backward of the HIP op alone (C-ABI calls through the autograd function), wall time
+    # around a device synchronisation
+    args = (co.W_v.weight, co.W_v.bias, co.W_q.weight, co.W_q.bias, co.w_v.weight, co.w_v.bias, co.w_q.weight,
+            co.w_q.bias)
     fwd = bwd = 0.0
-    for _ in range(iters):
-        e[0].record()
-        v, q = vqa_amd.coattention(x_img, Qs, co.W_v.weight, co.W_v.bias, co.W_q.weight, co.W_q.bias, co.w_v.weight,
-                                   co.w_v.bias, co.w_q.weight, co.w_q.bias)
-        e[1].record()
-        torch.autograd.backward([v, q], [torch.ones_like(v), torch.ones_like(q)])
-        e[2].record()
-        torch.cuda.synchronize()
-        fwd += e[0].elapsed_time(e[1]); bwd += e[1].elapsed_time(e[2])
+    for it in range(iters + 3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        v, q = vqa_amd.coattention(x_img, Qs, *args)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        g = [torch.ones_like(v), torch.ones_like(q)]
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        torch.autograd.backward([v, q], g)
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        if it >= 3:
+            fwd += t1 - t0; bwd += t3 - t2
+    flop = 3.0 * B * (2 * N * d * d + 3 * 2 * T * d * d + 3 * (3 * 2 * T * N * d + 4 * (N + T) * d))
     return {"N": N, "pairs_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3),
-            "coattn_fwd_ms": round(fwd / iters, 4), "coattn_bwd_ms": round(bwd / iters, 4)}
+            "coattn_fwd_ms": round(fwd / iters * 1e3, 4), "coattn_bwd_ms": round(bwd / iters * 1e3, 4),
+            "coattn_fwd_bwd_tflops": round(flop / ((fwd + bwd) / iters) / 1e12, 2)}
 
 
 def roofline_leg(device, B=160, N=196, T=26, d=512, L=3, iters=50):
@@ -149,8 +157,16 @@ def roofline_leg(device, B=160, N=196, T=26, d=512, L=3, iters=50):
     t = e0.elapsed_time(e1) * 1e-3 / iters
     alg = B * L * ALG_BYTES_PER_PAIR_LEVEL(N, T, d)
     ach = alg / t / 1e9
+    traffic = None                                 # HBM bytes per launch from the committed rocprofv3 PMC passes
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            tr = json.load(fh)
+        if tr.get("shape") == {"B": B, "N": N, "T": T, "d": d, "L": L}:
+            traffic = tr["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
             "kernel": "coattn_attention_fwd (affinity+tanh, H_v/H_q, scores, row-softmax, attended reductions)"
                       + (" [fused]" if fused else " [general-shape kernel sequence]"),
             "shape": {"B": B, "N": N, "T": T, "d": d, "L": L}, "avg_launch_us": round(t * 1e6, 2),
@@ -208,8 +224,12 @@ def main():
     torch.cuda.set_device(device)
     torch.manual_seed(0)
     model = T.build_model("attention", args.vocab, args.num_cls).to(device)
+    if args.channels_last:
+        model.image_encoder.vgg11_encoder.to(memory_format=torch.channels_last)
     trainer = T.Trainer(model, 1e-4, device)
     batch = device_batch(T, args, rank, device)
+    if args.channels_last:
+        batch = (batch[0].contiguous(memory_format=torch.channels_last),) + batch[1:]
 
     def sync():
         torch.cuda.synchronize()
@@ -233,9 +253,10 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "attention model train step (fwd + CE + bwd + Adam%s), K=%d (+1 UNKNOWN), "
                                    "batch %d/GPU, %dx%d synthetic images -> %d-location x 512 grid, %d-token questions, "
-                                   "vocab %d, fp32, frozen random-init VGG11-bn"
+                                   "vocab %d, fp32, frozen random-init VGG11-bn (%s)"
                                    % (" + RCCL grad all-reduce" if world > 1 else "", args.num_cls, args.batch,
-                                      args.image_size, args.image_size, n_grid, args.seq_len, args.vocab),
+                                      args.image_size, args.image_size, n_grid, args.seq_len, args.vocab,
+                                      "channels_last" if args.channels_last else "NCHW"),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                        "coattn_impl": "fused" if vqa_amd._lib.load().coattn_fused_supported(
                            args.batch, n_grid, args.seq_len, 512, 3, 0) else "general"},

@@ -139,6 +139,8 @@ def main(argv=None):
     ap.add_argument("--vocab_size", type=int, default=10000)
     ap.add_argument("--max_seq_length", type=int, default=26)
     ap.add_argument("--image_size", type=int, default=0, help="override the model's image size (0 = registry)")
+    ap.add_argument("--channels_last", type=str2bool, default="true",
+                    help="run the stock image encoder in channels_last (MIOpen NHWC kernels)")
     ap.add_argument("--model_ckpt", type=str, default=None)
     ap.add_argument("--save_path", type=str, default=None)
     args = ap.parse_args(argv)
@@ -158,6 +160,9 @@ def main(argv=None):
     if args.model_ckpt:
         model.load_state_dict(torch.load(args.model_ckpt, map_location="cpu"))
     model.to(device)
+    cl = args.channels_last and device.type == "cuda" and args.model == "attention"
+    if cl:
+        model.image_encoder.vgg11_encoder.to(memory_format=torch.channels_last)
     trainer = Trainer(model, args.learning_rate, device, args.opt_lvl)
     size = (args.image_size, args.image_size) if args.image_size else cfg["image_size"]
     t0 = time.time()
@@ -165,7 +170,10 @@ def main(argv=None):
         b = synthetic_batch(args.batch_size, size, args.max_seq_length, args.vocab_size, args.num_cls + 1,
                             seed=1234 + rank + 1000 * step)
         image, question, label, ques_len = sort_batch(b["image"], b["question"], b["label"], b["ques_len"])
-        loss = trainer.step(image.to(device), question.to(device), ques_len, label.to(device))
+        image = image.to(device)
+        if cl:
+            image = image.contiguous(memory_format=torch.channels_last)
+        loss = trainer.step(image, question.to(device), ques_len, label.to(device))
         if (step + 1) % args.log_interval == 0 and rank == 0:
             print(json.dumps({"step": step + 1, "loss": round(float(loss), 5),
                               "pairs_per_s": round(world * args.batch_size * (step + 1) / (time.time() - t0), 2)}))

@@ -220,7 +220,7 @@ def main():
         return
     rank, world, local = vdist.init_from_env()
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    device = torch.device("cuda", local)
+    device = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(device)
     torch.manual_seed(0)
     model = T.build_model("attention", args.vocab, args.num_cls).to(device)

@@ -20,7 +20,6 @@
 // so two workgroups share a CU (480 workgroups for B=160, L=3 on 256 CUs); block ids are mapped
 // so that the L levels of one sample run on the same XCD (shared L2 for V and P_v).
 #include "fused.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -37,7 +36,6 @@ struct FwdArgs {
   float* Hq;             // [L][B][T][d]
   float* q_out;          // [L][B][d]
   int B, N, T, d, L;
-  int dbg;               // developer switch (COATTN_DEBUG): 1 = skip phase-1 k loop, 2 = skip phase-2 tile loop
 };
 
 
@@ -102,7 +100,6 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
     load_q(0, qa[0]);
 #pragma unroll
     for (int u = 0; u < RING - 1; ++u) load_v(u, vb[u]);
-    if (!(a.dbg & 1))
 #pragma unroll
     for (int u = 0; u < 32; ++u) {                   // 32 k-steps of 4 = this wave's 128 channels
       if (u + RING - 1 < 32) load_v(u + RING - 1, vb[(u + RING - 1) % RING]);
@@ -160,7 +157,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
     // C = tanh(sum) by all threads; rows >= T are tanh(0) = 0 (their Q rows read as 0)
     float* Cg = a.C + pair * (size_t)T * N;
     constexpr int RSTEP = NW * 64 / 16;              // rows covered per sweep: 16 lanes per row
-    for (int row = tid >> 4; row < ((a.dbg & 16) ? 0 : kTRows); row += RSTEP) {
+    for (int row = tid >> 4; row < kTRows; row += RSTEP) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int col = 16 * t + (tid & 15);
@@ -180,7 +177,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
 #pragma unroll
     for (int c = 0; c < 8; ++c) accq[tt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int ntiles = (a.dbg & 2) ? 0 : (N + 15) >> 4;
+  const int ntiles = (N + 15) >> 4;
   {
     const float dsn0[4] = {0.f, 0.f, 0.f, 0.f};
     f32x4 pvA[4], pvB[4];                            // half tiles (4 channel tiles each), double buffered
@@ -206,7 +203,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
   // ------------------------------------------------------------------ phase 3
   // H_q epilogue: hq = tanh(P_q + acc); saved for backward; s_q partials.  Branch-free: rows t >= T
   // fall outside the per-sample buffers (loads give 0, stores are dropped), all loads issued first.
-  if (!(a.dbg & 4)) {
+  {
     const __amdgpu_buffer_rsrc_t rs_pq = make_rsrc(Pqp, (unsigned)T * d * 4u);
     const __amdgpu_buffer_rsrc_t rs_hq = make_rsrc(a.Hq + pair * (size_t)T * d, (unsigned)T * d * 4u);
     float wqr[8];
@@ -237,7 +234,6 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
     }
   }
   __syncthreads();
-  if (a.dbg & 8) return;
   if (w == 0) {
     // a_v = softmax_n(s_v + c_v): N <= 16*NT <= 256 -> <= 4 values per lane
     constexpr int PER = (NPAD + 63) / 64;
@@ -375,7 +371,6 @@ int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, c
   a.C = saved + so.C; a.av = saved + so.av; a.aq = saved + so.aq; a.Hq = saved + so.Hq;
   a.q_out = q_out;
   a.B = B; a.N = N; a.T = T; a.d = d; a.L = L;
-  { const char* e = getenv("COATTN_DEBUG"); a.dbg = e ? atoi(e) : 0; }
   const bool small_n = N <= 64;
   if (d == 512) {
     CA_TRY(small_n ? (launch_fwd<4, 4>(a, s)) : (launch_fwd<13, 4>(a, s)));

@@ -418,6 +418,110 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dpq_kernel(const BwdArgs a) {
   }
 }
 
+// dQ_l[b][t][k] = a_q,l[t] gq_l[k] + sum_n dA_l[t][n] V[b][k][n]   for all levels with one pass over V.
+// grid (d/128, B); a wave owns 32 channels (two 16-wide MFMA column tiles); dA of the three levels is
+// staged zero-padded in LDS and read as MFMA A operands (16 bytes = 4 k-steps per ds_read_b128).
+struct DqArgs {
+  const float* V; const float* dA; const float* aq; const float* gq;
+  float* dQ[8];
+  int B, N, T, d, L;
+};
+
+template <int NT, bool ALIGNED>
+__global__ __launch_bounds__(256, 2) void bwd_dq_kernel(const DqArgs a) {
+  constexpr int NPAD = 16 * NT;
+  constexpr int LD = NPAD + 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* dAs = lds;                                  // 3 x kTRows x LD
+  float* aqs = lds + 3 * kTRows * LD;                // 3 x 32
+  const int b = blockIdx.y, N = a.N, T = a.T, d = a.d, L = a.L, B = a.B;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, q4 = lane >> 4;
+  // stage dA of the three levels, zero padded: one wave per row, lanes along n
+  for (int rr = w; rr < 3 * kTRows; rr += 4) {
+    const int l = rr / kTRows, row = rr - l * kTRows;
+    const bool live = l < L && row < T;
+    const float* src = a.dA + (((size_t)l * B + b) * T + row) * N;
+    float* dst = dAs + (l * kTRows + row) * LD;
+    if (ALIGNED) {
+      for (int c4 = lane; c4 < NPAD / 4; c4 += 64) {
+        const int col = 4 * c4;
+        *reinterpret_cast<f32x4*>(dst + col) =
+            (live && col < N) ? *reinterpret_cast<const f32x4*>(src + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+      for (int col = lane; col < NPAD; col += 64) dst[col] = (live && col < N) ? src[col] : 0.f;
+    }
+  }
+  if (tid < 96) {
+    const int l = tid >> 5, t = tid & 31;
+    aqs[tid] = (l < L && t < T) ? a.aq[((size_t)l * B + b) * T + t] : 0.f;
+  }
+  __syncthreads();
+  const int kb = blockIdx.x * 128 + 32 * w;
+  const float* Vb = a.V + (size_t)b * d * N;
+  const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(Vb, (unsigned)d * N * 4u);
+  f32x4 acc[3][2][2];
+#pragma unroll
+  for (int l = 0; l < 3; ++l)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) acc[l][tt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // B operand: lane (channel kb + 16c + j, quad q4) holds V[k][16g + 4*q4 + s], s = 0..3
+  auto load_v = [&](int g, f32x4(&dst)[2]) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int voff = ((16 * c + j) * N + 4 * q4) * 4;
+      if (ALIGNED) {
+        dst[c] = buf_load4(rs_v, voff, (kb * N + 16 * g) * 4);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dst[c][s] = buf_load1(rs_v, voff + 4 * s, (kb * N + 16 * g) * 4);
+      }
+    }
+  };
+  f32x4 vb[2][2];
+  load_v(0, vb[0]);
+#pragma unroll
+  for (int g = 0; g < NT; ++g) {
+    if (g + 1 < NT) load_v(g + 1, vb[(g + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = min(16 * tt + j, kTRows - 1);
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(&dAs[(l * kTRows + t) * LD + 16 * g + 4 * q4]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) acc[l][tt][c] = mfma16(a4[s], vb[g & 1][c][s], acc[l][tt][c]);
+      }
+  }
+  // epilogue: + a_q (x) gq ; rows t >= T fall outside the per-sample dQ buffer (stores dropped)
+#pragma unroll
+  for (int l = 0; l < 3; ++l) {
+    if (l < L) {
+      const __amdgpu_buffer_rsrc_t rs_dq = make_rsrc(a.dQ[l] + (size_t)b * T * d, (unsigned)T * d * 4u);
+      const float* gqp = a.gq + ((size_t)l * B + b) * d;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float g = gqp[kb + 16 * c + j];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int t = 16 * tt + 4 * q4 + r;
+            const float v = fmaf(aqs[l * 32 + t], g, acc[l][tt][c][r]);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_dq, (t * d + j) * 4 + 64 * c,
+                                                  kb * 4, 0);
+          }
+      }
+    }
+  }
+}
+
 template <typename K>
 void set_lds(K kern, size_t bytes) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -498,21 +602,30 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const floa
     CA_TRY(launch_sum_all(ws + wo.dcs_part + (size_t)L * B, (float*)pg->dc_q, (int64_t)L * B, accumulate, s));
   }
   // 4. dQ_l = a_q (x) gq + dA V^T + dP_q W_q ;  dV = sum_l (a_v (x) gv + Q^T dA) + (sum_l dP_v) W_v
-  for (int l = 0; l < L; ++l) {
-    const float* dA = ws + wo.dA + l * BTN;
-    const float* aq = saved + so.aq + (size_t)l * B * T;
-    const float* av = saved + so.av + (size_t)l * B * N;
-    CA_TRY(launch_rank1(aq, gq + l * Bd, dQ[l], B, T, d, (int64_t)T * d, d, 1, 0, s));
-    {
-      coattn_gemm_desc g = {};
-      g.A = dA; g.a_sz = (int64_t)T * N; g.a_sm = N; g.a_sk = 1;
-      g.B = V; g.b_sz = (int64_t)d * N; g.b_sk = 1; g.b_sn = N;
-      g.Cin = dQ[l]; g.cin_sz = (int64_t)T * d; g.cin_sm = d; g.cin_sn = 1; g.beta = 1.f;
-      g.C = dQ[l]; g.c_sz = (int64_t)T * d; g.c_sm = d; g.c_sn = 1;
-      g.M = T; g.N = d; g.K = N; g.batch = B;
-      CA_TRY(launch_gemm_f32(g, s));
+  {
+    DqArgs da;
+    da.V = V; da.dA = ws + wo.dA; da.aq = saved + so.aq; da.gq = gq;
+    for (int l = 0; l < 8; ++l) da.dQ[l] = l < L ? dQ[l] : nullptr;
+    da.B = B; da.N = N; da.T = T; da.d = d; da.L = L;
+    const bool al = (N % 4) == 0;
+    dim3 grid(d / 128, B), block(256);
+    if (small_n) {
+      const size_t lds = (size_t)(3 * kTRows * (64 + 4) + 96) * sizeof(float);
+      if (al) hipLaunchKernelGGL((bwd_dq_kernel<4, true>), grid, block, lds, s, da);
+      else hipLaunchKernelGGL((bwd_dq_kernel<4, false>), grid, block, lds, s, da);
+    } else {
+      const size_t lds = (size_t)(3 * kTRows * (208 + 4) + 96) * sizeof(float);
+      static bool once = false;
+      if (!once) { set_lds(bwd_dq_kernel<13, true>, lds); set_lds(bwd_dq_kernel<13, false>, lds); once = true; }
+      if (al) hipLaunchKernelGGL((bwd_dq_kernel<13, true>), grid, block, lds, s, da);
+      else hipLaunchKernelGGL((bwd_dq_kernel<13, false>), grid, block, lds, s, da);
     }
-    if (dV) {
+    CA_CHECK_LAUNCH("bwd_dq");
+  }
+  if (dV) {
+    for (int l = 0; l < L; ++l) {
+      const float* dA = ws + wo.dA + l * BTN;
+      const float* av = saved + so.av + (size_t)l * B * N;
       CA_TRY(launch_rank1(av, gv + l * Bd, dV, B, N, d, (int64_t)d * N, 1, N, l > 0 ? 1 : 0, s));
       coattn_gemm_desc g = {};
       g.A = Q[l]; g.a_sz = (int64_t)T * d; g.a_sm = 1; g.a_sk = d;

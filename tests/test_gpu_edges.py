@@ -1,0 +1,91 @@
+"""GPU: edge cases of the drop-in surface -- inference mode, input layouts, autocast, determinism,
+shape limits of the fused kernels (auto dispatch), error behaviour."""
+import pytest
+import torch
+
+from oracle import coattn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _mod(d, seed=3):
+    import vqa_amd
+    m = vqa_amd.ParallelCoAttention(d)
+    m.load_state_dict(O.make_params(d, seed))
+    return m.cuda()
+
+
+def test_inference_equals_training_forward_and_layouts():
+    B, N, T, d = 5, 49, 26, 512
+    m = _mod(d)
+    V, Qs = O.make_inputs(B, N, T, d, 31, lens=[26, 20, 9, 2, 1], scale_q=(2.0 / d) ** 0.5)
+    Vg = V.cuda(); Qg = [q.cuda() for q in Qs]
+    view = Vg.permute(0, 2, 1)                                  # encoder's permuted view (no copy)
+    v_tr, q_tr = m(view.clone().permute(0, 2, 1).contiguous().permute(0, 2, 1).requires_grad_(True), Qg)
+    with torch.no_grad():
+        v_inf, q_inf = m(view, Qg)                              # saved = NULL path
+        v_cl, q_cl = m(view.contiguous(), Qg)                   # [B,N,d]-contiguous (channels_last encoder)
+    for l in range(3):
+        assert torch.equal(v_tr[l], v_inf[l]) and torch.equal(q_tr[l], q_inf[l])
+        assert torch.equal(v_cl[l], v_inf[l]) and torch.equal(q_cl[l], q_inf[l])
+    f = O.coattn_forward(V, Qs, O.make_params(d, 3))
+    assert (torch.stack(v_inf).cpu() - f["v"]).abs().max() < 1e-4
+
+
+def test_autocast_keeps_the_op_in_fp32():
+    B, N, T, d = 3, 49, 26, 256
+    m = _mod(d)
+    V, Qs = O.make_inputs(B, N, T, d, 32, lens=[26, 5, 1], scale_q=(2.0 / d) ** 0.5)
+    x = V.cuda().permute(0, 2, 1)
+    Qg = [q.cuda().requires_grad_(True) for q in Qs]
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        v, q = m(x.bfloat16(), [t.bfloat16() for t in Qg])      # bf16 features from an autocast encoder
+    assert v[0].dtype == torch.float32
+    sum(t.sum() for t in v + q).backward()
+    assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in Qg)
+    f = O.coattn_forward(V.bfloat16().float(), [t.bfloat16().float() for t in Qs], O.make_params(d, 3))
+    assert (torch.stack(v).cpu() - f["v"]).abs().max() < 1e-3
+
+
+def test_bitwise_deterministic():
+    from tests._hip import run_hip
+    from tests import _golden as G
+    V, Qs, P, gv, gq = G.build_case("g5_cfg2_scaled", torch.float32)
+    a = run_hip(V, Qs, P, gv, gq, impl="auto")
+    b = run_hip(V, Qs, P, gv, gq, impl="auto")
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("B,N,T,d", [(1, 1, 1, 32), (2, 208, 28, 512), (2, 209, 26, 512), (2, 196, 29, 512),
+                                     (3, 64, 7, 256), (2, 65, 26, 512), (1, 16, 16, 128)])
+def test_auto_dispatch_shape_limits(B, N, T, d):
+    """Shapes on both sides of the fused kernels' limits (N <= 208, T <= 28, d in {256, 512})."""
+    from tests._hip import run_hip
+    lens = sorted([T] + [max(1, T // 2)] * (B - 1), reverse=True)
+    P = O.make_params(d, 9)
+    V, Qs = O.make_inputs(B, N, T, d, 41, lens=lens, scale_q=(2.0 / d) ** 0.5)
+    gv = torch.from_numpy(O.hash_normal((3, B, d), 5)).float()
+    gq = torch.from_numpy(O.hash_normal((3, B, d), 6)).float()
+    r = run_hip(V, Qs, P, gv, gq, impl="auto")
+    f = O.coattn_forward(V, Qs, P)
+    g = O.coattn_backward(V, Qs, P, gv, gq)
+    assert (r["v"].cpu() - f["v"]).abs().max() < 1e-4 and (r["q"].cpu() - f["q"]).abs().max() < 1e-4
+    for k in ("dV_phys", "dQ", "dW_v.weight", "dW_q.weight", "dw_v.weight", "dw_q.weight", "dW_v.bias", "dW_q.bias"):
+        ref = g[k]
+        assert (r[k].cpu() - ref).abs().max() <= 1e-4 * max(1e-3, ref.abs().max().item()), k
+
+
+def test_errors_are_loud():
+    import vqa_amd
+    from vqa_amd import _lib
+    m = _mod(64)
+    x = torch.zeros(2, 9, 64, device="cuda")
+    with pytest.raises(RuntimeError):
+        m(x, [torch.zeros(2, 5, 64, device="cuda"), torch.zeros(2, 6, 64, device="cuda"), torch.zeros(2, 5, 64, device="cuda")])
+    with pytest.raises(RuntimeError):
+        m(x.double(), [torch.zeros(2, 5, 64, device="cuda", dtype=torch.float64)] * 3)
+    # C-ABI: fused kernels requested for an unsupported shape -> negative return, message set
+    with pytest.raises(RuntimeError, match="fused"):
+        vqa_amd.coattention(x, [torch.zeros(2, 5, 64, device="cuda")] * 3, m.W_v.weight, m.W_v.bias, m.W_q.weight,
+                            m.W_q.bias, m.w_v.weight, m.w_v.bias, m.w_q.weight, m.w_q.bias, impl=_lib.IMPL_FUSED)

@@ -36,10 +36,11 @@ class _CoAttentionFn(torch.autograd.Function):
     """forward -> coattn_forward, backward -> coattn_backward (autograd of model.py:372-392)."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)     # fp32 island under autocast
     def forward(ctx, x_img, W_v, b_v, W_q, b_q, w_v, c_v, w_q, c_q, impl, *x_ques):
         if not x_img.is_cuda:
             raise RuntimeError("ParallelCoAttention (HIP) needs tensors on the GPU; there is no CPU fallback")
-        if x_img.dtype != torch.float32:
+        if x_img.dtype != torch.float32 or any(q.dtype != torch.float32 for q in x_ques):
             raise RuntimeError("ParallelCoAttention (HIP) computes in fp32; got %s" % x_img.dtype)
         lib = _lib.load()
         L = len(x_ques)
@@ -70,6 +71,7 @@ class _CoAttentionFn(torch.autograd.Function):
         return out_v, out_q
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g_v, g_q):
         lib = _lib.load()
         B, N, T, d, L, impl = ctx.dims

@@ -137,3 +137,19 @@ def test_gemm_aligned_row_split_inner_ksplit_and_pointer_tables():
                a_sm=1, a_sk=d, a_si=M * d, b_sk=d, b_sn=1, c_sm=d, c_sn=1, c_sz=d * d))
     ref = sum(dPq[l].double().T @ Qs[l].double() for l in range(L))
     assert _rel(part.sum(0), ref) < 2e-6
+
+
+@pytest.mark.parametrize("a_m", [True, False])
+def test_gemm_large_m(a_m):
+    """Large M (several rounds of workgroups), partial edge tile."""
+    torch.manual_seed(7)
+    M, N, K = 50052, 256, 128
+    A = torch.randn(K, M, device="cuda") if a_m else torch.randn(M, K, device="cuda")
+    W = torch.randn(N, K, device="cuda") / 8
+    bias = torch.randn(N, device="cuda")
+    Cm = torch.full((M, N), float("nan"), device="cuda")
+    kw = dict(A=A, B=W, C=Cm, bias_n=bias, M=M, N=N, K=K, batch=1, b_sk=1, b_sn=K, c_sm=N, c_sn=1)
+    kw.update(dict(a_sm=1, a_sk=M) if a_m else dict(a_sm=K, a_sk=1))
+    _gemm(kw)
+    ref = (A.double().T if a_m else A.double()) @ W.double().T + bias.double()
+    assert _rel(Cm, ref) < 2e-6

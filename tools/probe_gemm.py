@@ -1,0 +1,33 @@
+import sys, os, time, ctypes as C, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import vqa_amd
+from vqa_amd import _lib
+lib = _lib.load()
+dev = torch.device('cuda', 0)
+def run(name, kw, flop, iters=30):
+    g = _lib.GemmDesc()
+    keep = []
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor): keep.append(v); v = v.data_ptr()
+        setattr(g, k, v)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(3): _lib.check(lib.coattn_gemm_f32(C.byref(g), st), name)
+    torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): lib.coattn_gemm_f32(C.byref(g), st)
+    e1.record(); torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / iters * 1e-3
+    print("%-10s %8.1f us  %6.1f TFLOP/s" % (name, t * 1e6, flop / t / 1e12))
+B, N, T, d = 160, 196, 26, 512
+V = torch.randn(B, d, N, device=dev); W = torch.randn(d, d, device=dev); Pv = torch.empty(B * N, d, device=dev)
+run("P_v", dict(A=V, B=W, C=Pv, M=B*N, N=d, K=d, batch=1, a_sm=1, a_sk=N, a_mdiv=N, a_sdiv=d*N, b_sk=1, b_sn=d, c_sm=d, c_sn=1), 2.0*B*N*d*d)
+Q = torch.randn(3 * B * T, d, device=dev); Pq = torch.empty(3 * B * T, d, device=dev)
+run("P_q(x3)", dict(A=Q, B=W, C=Pq, M=3*B*T, N=d, K=d, batch=1, a_sm=d, a_sk=1, b_sk=1, b_sn=d, c_sm=d, c_sn=1), 2.0*3*B*T*d*d)
+run("dQproj", dict(A=Q, B=W, C=Pq, M=3*B*T, N=d, K=d, batch=1, a_sm=d, a_sk=1, b_sk=d, b_sn=1, c_sm=d, c_sn=1), 2.0*3*B*T*d*d)
+G = 5; S = 32
+part = torch.empty(S, d, d, device=dev)
+run("dW_v", dict(A=Pv, B=V, C=part, M=d, N=d, K=N, batch=S, inner=G, inner_total=B, a_sm=1, a_sk=d, a_si=N*d, a_sz=G*N*d,
+                 b_sk=1, b_sn=N, b_si=d*N, b_sz=G*d*N, c_sm=d, c_sn=1, c_sz=d*d), 2.0*B*N*d*d)
+K = 3 * B * T; ks = (K // 32 + 15) // 16 * 16; S2 = (K + ks - 1) // ks
+part2 = torch.empty(S2, d, d, device=dev)
+run("dW_q", dict(A=Pq, B=Q, C=part2, M=d, N=d, K=K, batch=S2, ksplit=ks, a_sm=1, a_sk=d, b_sk=d, b_sn=1, c_sm=d, c_sn=1, c_sz=d*d), 2.0*K*d*d)

@@ -184,9 +184,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmK g) {
 // is staged as [k][m] with 16-byte LDS writes; an operand that is contiguous along k is staged
 // as [m][k] with an odd row stride (33), so that both the transposing 4-byte writes and the
 // 32-lane MFMA operand reads are bank-conflict free.
-template <bool AM, bool BN_>
+template <bool AM, bool BN_, int BM>
 __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
-  constexpr int BM = 128, BN = 128, BK = 32;
+  constexpr int BN = 128, BK = 32;
+  constexpr int TM = BM / 64;              // 32-row MFMA tiles per wave along m (waves are 2 x 2)
+  constexpr int FA = BM * BK / 4 / 256;    // float4 per thread per K-step for A (4 or 6)
   constexpr int LDM = BM + 4;              // [k][m] image row stride
   constexpr int LDK = BK + 1;              // [m][k] image row stride
   constexpr int ASZ = AM ? BK * LDM : BM * LDK;
@@ -207,14 +209,14 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
   const int ksteps = (kend - kbeg + BK - 1) / BK;
   const int nsteps = ninner * max(ksteps, 0);
 
-  // 4 float4 per thread per operand; offsets hoisted (32-bit, element units)
-  int a_off[4], a_lds[4], a_k[4];
-  bool a_ok[4];
+  // FA / 4 float4 per thread per operand; offsets hoisted (32-bit, element units)
+  int a_off[FA], a_lds[FA], a_k[FA];
+  bool a_ok[FA];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = tid + 256 * i;                  // float4 index in the 128 x 32 tile
+  for (int i = 0; i < FA; ++i) {
+    const int idx = tid + 256 * i;                  // float4 index in the BM x 32 tile
     int m, k;
-    if (AM) { k = idx >> 5; m = (idx & 31) * 4; } else { m = idx >> 3; k = (idx & 7) * 4; }
+    if (AM) { k = idx / (BM / 4); m = (idx % (BM / 4)) * 4; } else { m = idx >> 3; k = (idx & 7) * 4; }
     a_k[i] = k;
     a_lds[i] = AM ? k * LDM + m : m * LDK + k;
     a_ok[i] = (m0 + m) < g.M;                      // M % 4 == 0 on this path: whole float4 in or out
@@ -233,15 +235,15 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
     b_off[i] = b_ok[i] ? (int)((long)k * g.b_sk + (long)(n0 + n) * g.b_sn) : 0;
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 ra[4], rb[4];
+  f32x4 ra[FA], rb[4];
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
   auto load_step = [&](int step) {
     const int ii = step / ksteps, k0 = kbeg + (step - ii * ksteps) * BK;
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
                       + (long)k0 * g.b_sk;
     const int klim = kend - k0;                    // K range % 4 == 0 on this path
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FA; ++i)
       ra[i] = (a_ok[i] && a_k[i] < klim) ? *reinterpret_cast<const f32x4*>(Ab + a_off[i]) : zero4;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -263,13 +265,16 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
   };
   auto store_step = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < FA; ++i) {
       if (AM) {
         *reinterpret_cast<f32x4*>(&As[a_lds[i]]) = ra[i];
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) As[a_lds[i] + e] = ra[i][e];
       }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
       if (BN_) {
         *reinterpret_cast<f32x4*>(&Bs[b_lds[i]]) = rb[i];
       } else {
@@ -289,11 +294,11 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
     if (step + 1 < nsteps) load_step(step + 1);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
-      float a[2], b[2];
+      float a[TM], b[2];
       const int krow = kk + lh;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int m = wr * 64 + i * 32 + li;
+      for (int i = 0; i < TM; ++i) {
+        const int m = wr * (TM * 32) + i * 32 + li;
         a[i] = AM ? As[krow * LDM + m] : As[m * LDK + krow];
       }
 #pragma unroll
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
         b[j] = BN_ ? Bs[krow * LDM + n] : Bs[n * LDK + krow];
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
@@ -317,14 +322,14 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
   float* Cb = g.c_ptrs[0] ? g.c_ptrs[z & 7] : g.C + (long)z * g.c_sz;
   const float* Cinb = g.cin_ptrs[0] ? g.cin_ptrs[z & 7] : (g.Cin ? g.Cin + (long)z * g.cin_sz : nullptr);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = n0 + wc * 64 + j * 32 + li;
       const float bn = (g.bias_n && col < g.N) ? g.bias_n[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int row = m0 + wr * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row < g.M && col < g.N) {
           float v = acc[i][j][r] + bn;
           if (g.bias_m) v += g.bias_m[row];
@@ -386,11 +391,13 @@ int launch_gemm_f32(const coattn_gemm_desc& d, hipStream_t s) {
     for (int t = 0; t < 8; ++t) vec = vec && pal(d.a_ptrs[t]) && pal(d.b_ptrs[t]);
   }
   if (vec) {
+    // (192-row tiles were tried to avoid a second, mostly empty round of workgroups for P_v -- 980
+    // vs 768 resident -- and measured slower: 279 vs 235 us; the template parameter stays.)
     dim3 grid((d.N + 127) / 128, (d.M + 127) / 128, d.batch);
-    if (a_m && b_n) hipLaunchKernelGGL((gemm_f32_vec_kernel<true, true>), grid, block, 0, s, g);
-    else if (a_m) hipLaunchKernelGGL((gemm_f32_vec_kernel<true, false>), grid, block, 0, s, g);
-    else if (b_n) hipLaunchKernelGGL((gemm_f32_vec_kernel<false, true>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_f32_vec_kernel<false, false>), grid, block, 0, s, g);
+    if (a_m && b_n) hipLaunchKernelGGL((gemm_f32_vec_kernel<true, true, 128>), grid, block, 0, s, g);
+    else if (a_m) hipLaunchKernelGGL((gemm_f32_vec_kernel<true, false, 128>), grid, block, 0, s, g);
+    else if (b_n) hipLaunchKernelGGL((gemm_f32_vec_kernel<false, true, 128>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_f32_vec_kernel<false, false, 128>), grid, block, 0, s, g);
     CA_CHECK_LAUNCH("gemm_f32_vec");
     return 0;
   }

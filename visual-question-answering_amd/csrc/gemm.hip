@@ -245,17 +245,20 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
 
   f32x4 ra[FA], rb[4];
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto load_step = [&](int step) {
-    const int ii = step / ksteps, k0 = kbeg + (step - ii * ksteps) * BK;
+  // operand base pointers of inner index ii (table lookups happen only here, not per K-step)
+  auto base_a = [&](int ii) -> const float* {
     const int ig = g.inner_total > 0 ? z * g.inner + ii : ii;
     const int pt = g.ptr_by_inner ? ig : z;
-    const float* Ab = (g.a_ptrs[0] ? g.a_ptrs[pt & 7] : g.A + (long)z * g.a_sz + (long)ii * g.a_si)
-                      + (long)k0 * g.a_sk;
-    const float* Bb = (g.b_ptrs[0] ? g.b_ptrs[pt & 7]
-                                   : g.B + (g.b_imod > 0 ? (long)(ig % g.b_imod) * g.b_si
-                                                         : (long)z * g.b_sz + (long)ii * g.b_si))
-                      + (long)k0 * g.b_sk;
-    const int klim = kend - k0;                    // K range % 4 == 0 on this path
+    return (g.a_ptrs[0] ? g.a_ptrs[pt & 7] : g.A + (long)z * g.a_sz + (long)ii * g.a_si) + (long)kbeg * g.a_sk;
+  };
+  auto base_b = [&](int ii) -> const float* {
+    const int ig = g.inner_total > 0 ? z * g.inner + ii : ii;
+    const int pt = g.ptr_by_inner ? ig : z;
+    return (g.b_ptrs[0] ? g.b_ptrs[pt & 7]
+                        : g.B + (g.b_imod > 0 ? (long)(ig % g.b_imod) * g.b_si
+                                              : (long)z * g.b_sz + (long)ii * g.b_si)) + (long)kbeg * g.b_sk;
+  };
+  auto load_regs = [&](const float* Ab, const float* Bb, int klim) {     // K range % 4 == 0 on this path
 #pragma unroll
     for (int i = 0; i < FA; ++i)
       ra[i] = (a_ok[i] && a_k[i] < klim) ? *reinterpret_cast<const f32x4*>(Ab + a_off[i]) : zero4;
@@ -284,34 +287,66 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
     }
   };
 
+  int ii = 0, kidx = 0;
+  const float* Ap = nullptr;
+  const float* Bp = nullptr;
   if (nsteps > 0) {
-    load_step(0);
+    Ap = base_a(0);
+    Bp = base_b(0);
+    load_regs(Ap, Bp, kend - kbeg);
     store_step();
   }
   __syncthreads();
   const int li = lane & 31, lh = lane >> 5;
+  // LDS operand reads of k-pair kk (MFMA 32x32x2: lane holds A[m = li][k = lh], B[k = lh][n = li])
+  auto read_ops = [&](int kk, float(&a)[TM], float(&b)[2]) {
+    const int krow = kk + lh;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = wr * (TM * 32) + i * 32 + li;
+      a[i] = AM ? As[krow * LDM + m] : As[m * LDK + krow];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = wc * 64 + j * 32 + li;
+      b[j] = BN_ ? Bs[krow * LDM + n] : Bs[n * LDK + krow];
+    }
+  };
   for (int step = 0; step < nsteps; ++step) {
-    if (step + 1 < nsteps) load_step(step + 1);
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float a[TM], b[2];
-      const int krow = kk + lh;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int m = wr * (TM * 32) + i * 32 + li;
-        a[i] = AM ? As[krow * LDM + m] : As[m * LDK + krow];
+    if (step + 1 < nsteps) {                         // global loads of the next K-step fly under the MFMAs
+      if (++kidx == ksteps) {
+        kidx = 0; ++ii;
+        Ap = base_a(ii); Bp = base_b(ii);
+      } else {
+        Ap += (long)BK * g.a_sk; Bp += (long)BK * g.b_sk;
       }
+      load_regs(Ap, Bp, kend - kbeg - kidx * BK);
+    }
+    float a0[TM], b0[2], a1[TM], b1[2];              // operand double buffer: reads one k-pair ahead
+    read_ops(0, a0, b0);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = wc * 64 + j * 32 + li;
-        b[j] = BN_ ? Bs[krow * LDM + n] : Bs[n * LDK + krow];
-      }
+    for (int kk = 0; kk < BK; kk += 4) {
+      read_ops(kk + 2, a1, b1);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+      if (kk + 4 < BK) read_ops(kk + 4, a0, b0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
     }
+    // pin the schedule: LDS operand reads run one k-pair ahead of the MFMAs that consume them
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + 2), 0);
+#pragma unroll
+    for (int p = 0; p < BK / 2 - 2; ++p) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, TM + 2, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM, 0);
     __syncthreads();
     if (step + 1 < nsteps) {
       store_step();

@@ -122,6 +122,38 @@ class QuestionCoAttentionEncoder(nn.Module):
         return words, phrases, sentence
 
 
+class QuestionBertCoAttentionEncoder(nn.Module):
+    """BASELINE config 5 (an extension: the reference lists BERT as a TODO, README.md:137-141, and its
+    ``--model bert`` flag has no registry entry): the word level of the hierarchy comes from frozen
+    768-d token embeddings of a BERT-base encoder, projected to ``hidden_dim``; phrase and sentence
+    levels are built on top of it exactly as in QuestionCoAttentionEncoder.  ``bert`` is any module
+    mapping token ids [B,T] to [B,T,bert_dim] (e.g. ``transformers.BertModel(...).embeddings``); it is
+    frozen.  Pad rows are re-zeroed so that the three levels keep the reference's zero-pad invariant."""
+
+    def __init__(self, bert: nn.Module, bert_dim, hidden_dim):
+        super().__init__()
+        self.bert = bert
+        for prm in self.bert.parameters():
+            prm.requires_grad = False
+        self.word_proj = nn.Linear(bert_dim, hidden_dim)
+        self.phrase_conv_pool = PhraseConvPool(hidden_dim)
+        self.sentence_lstm = nn.LSTM(hidden_dim, hidden_dim)
+        self.hidden_dim = hidden_dim
+
+    def forward(self, x, x_lens):
+        T = x.shape[1]
+        lens = x_lens.cpu() if torch.is_tensor(x_lens) else x_lens
+        with torch.no_grad():
+            tok = self.bert(x)
+            tok = tok[0] if isinstance(tok, (tuple, list)) else getattr(tok, "last_hidden_state", tok)
+        words = self.word_proj(tok) * (x != 0).unsqueeze(-1).to(tok.dtype)     # zero the pad rows
+        phrases = pack_padded_sequence(self.phrase_conv_pool(words), lens, batch_first=True)
+        sentence, _ = self.sentence_lstm(phrases)
+        phrases = pad_packed_sequence(phrases, batch_first=True, total_length=T)[0]
+        sentence = pad_packed_sequence(sentence, batch_first=True, total_length=T)[0]
+        return words, phrases, sentence
+
+
 class MLPClassifier(nn.Module):
     """Recursive word -> phrase -> sentence answer head (model.py:414-434)."""
 
@@ -147,7 +179,10 @@ class HierarchicalCoAttentionNet(nn.Module):
         super().__init__()
         self.hidden_dim = ques_enc_params["hidden_dim"]
         self.image_encoder = ImageCoAttentionEncoder(**img_enc_params)
-        self.question_encoder = QuestionCoAttentionEncoder(**ques_enc_params)
+        if "bert" in ques_enc_params:                 # config 5 extension; the reference has only the LSTM path
+            self.question_encoder = QuestionBertCoAttentionEncoder(**ques_enc_params)
+        else:
+            self.question_encoder = QuestionCoAttentionEncoder(**ques_enc_params)
         self.co_attention = ParallelCoAttention(self.hidden_dim)
         self.mlp_classify = MLPClassifier(self.hidden_dim, mlp_dim, K)
 

@@ -51,6 +51,15 @@ def setup_model_configs(model_name: str, vocab_size: int, vgg_train: bool = Fals
     return registry[model_name]      # 'bert' is accepted by the reference's argparse but has no entry: KeyError
 
 
+def bert_question_params(hidden_dim: int = 512, vocab_size: int = 30522, bert_dim: int = 768) -> dict:
+    """Question-encoder parameters for BASELINE config 5: frozen BERT-base token embeddings (random
+    init -- no network for checkpoints) in place of the learned word embedding."""
+    from transformers import BertConfig
+    from transformers.models.bert.modeling_bert import BertEmbeddings
+    cfg = BertConfig(vocab_size=vocab_size, hidden_size=bert_dim)
+    return dict(bert=BertEmbeddings(cfg), bert_dim=bert_dim, hidden_dim=hidden_dim)
+
+
 def build_model(model_name: str, vocab_size: int, num_cls: int, **kw) -> nn.Module:
     """K + 1 output classes: index 0 is UNKNOWN (main.py:155)."""
     cfg = setup_model_configs(model_name, vocab_size, **kw)

@@ -177,27 +177,106 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
 #pragma unroll
     for (int c = 0; c < 8; ++c) accq[tt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Tile loop, software pipelined over quarter tiles (2 channel tiles = 8 VGPRs each, ring of 4):
+  // the MFMAs of quarter u are interleaved with the tanh / score VALU work of quarter u-1, and the
+  // loads of quarter u+2 are issued two steps ahead (rows beyond N read 0 through the buffer rule).
   const int ntiles = (N + 15) >> 4;
   {
-    const float dsn0[4] = {0.f, 0.f, 0.f, 0.f};
-    f32x4 pvA[4], pvB[4];                            // half tiles (4 channel tiles each), double buffered
-    load_pv_half<0>(rs_pv, d, dsl, 0, j, q4, pvA);
-    for (int tile = 0; tile < ntiles; ++tile) {
-      const int nb = 16 * tile;
-      load_pv_half<1>(rs_pv, d, dsl, nb, j, q4, pvB);
-      __builtin_amdgcn_sched_barrier(0);
-      float sv[4] = {0.f, 0.f, 0.f, 0.f};
-      half_unit<false, 0, LD>(pvA, pq, wvr, accq, Cbuf, nb, j, q4, sv, dsn0);
-      load_pv_half<0>(rs_pv, d, dsl, nb + 16, j, q4, pvA);     // next tile (beyond N reads 0)
-      __builtin_amdgcn_sched_barrier(0);
-      half_unit<false, 1, LD>(pvB, pq, wvr, accq, Cbuf, nb, j, q4, sv, dsn0);
+    f32x4 ring[4][2];
+    f32x4 ca[2];
+    float ct[kTS];
+    float sv[4] = {0.f, 0.f, 0.f, 0.f};
+    auto load_q = [&](int tile, int qc, f32x4(&dst)[2]) {        // pv[c][r] = P_v[16 tile + 4 q4 + r][dsl + 16(2qc + c) + j]
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sv[r] = row16_sum(sv[r]);
-      if (j == 0) {
+      for (int r = 0; r < 4; ++r) {
+        const int voff = ((4 * q4 + r) * d + j) * 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) svpart[w * NPAD + nb + 4 * q4 + r] = sv[r];
+        for (int c = 0; c < 2; ++c) dst[c][r] = buf_load1(rs_pv, voff + 64 * (2 * qc + c), (16 * tile * d + dsl) * 4);
       }
+    };
+    auto load_a = [&](int tile) {                                // MFMA A operands of this location tile
+      const int nb = 16 * tile;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = min(16 * tt + j, kTRows - 1);
+        ca[tt] = *reinterpret_cast<const f32x4*>(&Cbuf[t * LD + nb + 4 * q4]);
+      }
+#pragma unroll
+      for (int s = 0; s < kTS; ++s) ct[s] = Cbuf[(4 * s + q4) * LD + nb + j];
+    };
+    // MFMAs of one quarter: accq += C . P_v (B = the tile), then the tile accumulates C^T P_q
+    auto mfma_q = [&](f32x4(&pv)[2], const int qc) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) accq[tt][2 * qc + c] = mfma16(ca[tt][s], pv[c][s], accq[tt][2 * qc + c]);
+#pragma unroll
+      for (int s = 0; s < kTS; ++s)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) pv[c] = mfma16(ct[s], pq[s][2 * qc + c], pv[c]);
+    };
+    auto valu_q = [&](const f32x4(&pv)[2], const int qc) {       // s_v[n] += tanh(H_v[n][d]) w_v[d]
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sv[r] = fmaf(tanh_fast(pv[c][r]), wvr[2 * qc + c], sv[r]);
+    };
+    auto flush_sv = [&](int tile) {                              // 16-lane row sums -> per-wave score partials
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float t = row16_sum(sv[r]);
+        if (j == 0) svpart[w * NPAD + 16 * tile + 4 * q4 + r] = t;
+        sv[r] = 0.f;
+      }
+    };
+    // 30 MFMAs of one quarter interleaved with the ~50 VALU ops of the previous one
+#define COATTN_INTERLEAVE()                                        \
+  _Pragma("unroll") for (int g_ = 0; g_ < 28; ++g_) {              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             \
+    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);             \
+  }                                                                \
+  __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    load_q(0, 0, ring[0]);
+    load_q(0, 1, ring[1]);
+    for (int tile = 0; tile < ntiles; ++tile) {
+      // step 0: quarter 0 of this tile; VALU of quarter 3 of the previous tile
+      load_q(tile, 2, ring[2]);
+      load_a(tile);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_q(ring[0], 0);
+      if (tile > 0) valu_q(ring[3], 3);
+      COATTN_INTERLEAVE();
+      __builtin_amdgcn_sched_barrier(0);
+      if (tile > 0) flush_sv(tile - 1);
+      // step 1
+      load_q(tile, 3, ring[3]);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_q(ring[1], 1);
+      valu_q(ring[0], 0);
+      COATTN_INTERLEAVE();
+      __builtin_amdgcn_sched_barrier(0);
+      // step 2 (next tile's quarter 0 starts loading; beyond N it reads zeros)
+      load_q(tile + 1, 0, ring[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_q(ring[2], 2);
+      valu_q(ring[1], 1);
+      COATTN_INTERLEAVE();
+      __builtin_amdgcn_sched_barrier(0);
+      // step 3
+      load_q(tile + 1, 1, ring[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_q(ring[3], 3);
+      valu_q(ring[2], 2);
+      COATTN_INTERLEAVE();
+      __builtin_amdgcn_sched_barrier(0);
     }
+    if (ntiles > 0) {
+      valu_q(ring[3], 3);
+      flush_sv(ntiles - 1);
+    }
+#undef COATTN_INTERLEAVE
   }
 
   // ------------------------------------------------------------------ phase 3

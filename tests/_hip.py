@@ -36,6 +36,7 @@ def run_hip(V, Qs, P, gv=None, gq=None, impl="general", need_dv=True, accumulate
     Qs = [q.to(dev).contiguous() for q in Qs]
     names = ("W_v.weight", "W_v.bias", "W_q.weight", "W_q.bias", "w_v.weight", "w_v.bias", "w_q.weight", "w_q.bias")
     ps = [P[k].to(dev).contiguous() for k in names]
+    assert gv is None or gv.shape[0] == len(Qs)
     B, d, N = V.shape
     T = Qs[0].shape[1]
     L = len(Qs)

@@ -89,3 +89,36 @@ def test_errors_are_loud():
     with pytest.raises(RuntimeError, match="fused"):
         vqa_amd.coattention(x, [torch.zeros(2, 5, 64, device="cuda")] * 3, m.W_v.weight, m.W_v.bias, m.W_q.weight,
                             m.W_q.bias, m.w_v.weight, m.w_v.bias, m.w_q.weight, m.w_q.bias, impl=_lib.IMPL_FUSED)
+
+
+@pytest.mark.parametrize("L", [1, 2])
+@pytest.mark.parametrize("impl", ["general", "auto"])
+def test_fewer_than_three_levels(L, impl):
+    """The module loops over whatever hierarchy it is given (model.py:372); L = 1, 2 also work."""
+    from tests._hip import run_hip
+    B, N, T, d = 3, 49, 26, 256
+    P = O.make_params(d, 4)
+    V, Qs = O.make_inputs(B, N, T, d, 51, lens=[26, 8, 1], scale_q=(2.0 / d) ** 0.5, L=L)
+    gv = torch.from_numpy(O.hash_normal((L, B, d), 7)).float()
+    gq = torch.from_numpy(O.hash_normal((L, B, d), 8)).float()
+    r = run_hip(V, Qs, P, gv, gq, impl=impl)
+    f = O.coattn_forward(V, Qs, P)
+    g = O.coattn_backward(V, Qs, P, gv, gq)
+    assert (r["v"].cpu() - f["v"]).abs().max() < 1e-4 and (r["q"].cpu() - f["q"]).abs().max() < 1e-4
+    for k in ("dV_phys", "dQ", "dW_v.weight", "dW_q.weight", "dw_v.weight", "dw_q.weight", "dW_v.bias", "dW_q.bias"):
+        assert (r[k].cpu() - g[k]).abs().max() <= 1e-4 * max(1e-3, g[k].abs().max().item()), k
+
+
+def test_trainer_validate_forward_only_path():
+    """compute_validation_metrics (main.py:290-351): eval() + no_grad forward through the HIP op."""
+    from vqa_amd import train as T
+    torch.manual_seed(0)
+    model = T.build_model("attention", 60, 10).cuda()
+    tr = T.Trainer(model, 1e-4, torch.device("cuda:0"))
+    batches = []
+    for i in range(2):
+        b = T.synthetic_batch(4, (64, 64), 26, 60, 11, seed=10 + i)
+        im, qu, la, ln = T.sort_batch(b["image"], b["question"], b["label"], b["ques_len"])
+        batches.append((im.cuda(), qu.cuda(), ln, la.cuda()))
+    m = tr.validate(batches)
+    assert 0.0 <= m["accuracy"] <= 100.0 and m["loss"] > 0 and model.training

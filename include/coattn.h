@@ -44,6 +44,11 @@ extern "C" {
 #define COATTN_IMPL_AUTO 0
 #define COATTN_IMPL_GENERAL 1
 #define COATTN_IMPL_FUSED 2
+/* flags bit 2: run the forward projections P_v, P_q (model.py:380-384) on the bf16 MFMA
+ * (v_mfma_f32_32x32x16_bf16): operands rounded to bf16 while staged, fp32 accumulation, fp32
+ * results -- the reduced-precision mode that the reference reaches through apex AMP O1 (main.py:185).
+ * Everything else stays exact fp32.  Parity then holds to bf16 tolerance (~1e-2), not 1e-4. */
+#define COATTN_FLAG_BF16_PROJ 4
 
 typedef struct coattn_params {
   const void* W_v; const void* b_v;   /* model.py:350 */

@@ -27,7 +27,7 @@ def saved_views(saved, B, N, T, d, L):
     return out
 
 
-def run_hip(V, Qs, P, gv=None, gq=None, impl="general", need_dv=True, accumulate=0, grads_init=None):
+def run_hip(V, Qs, P, gv=None, gq=None, impl="general", need_dv=True, accumulate=0, grads_init=None, bf16_proj=False):
     """V [B,d,N], Qs list of [B,T,d], P dict of reference-named params (CPU or CUDA tensors).
     Returns dict with v,q and saved state; with gv/gq also all gradients."""
     lib = _lib.load()
@@ -40,7 +40,7 @@ def run_hip(V, Qs, P, gv=None, gq=None, impl="general", need_dv=True, accumulate
     B, d, N = V.shape
     T = Qs[0].shape[1]
     L = len(Qs)
-    flag = IMPL[impl]
+    flag = IMPL[impl] | (_lib.FLAG_BF16_PROJ if bf16_proj else 0)
     sb, fb, bb = _lib.workspace_bytes(B, N, T, d, L, flag)
     v = torch.full((L, B, d), float("nan"), device=dev)
     q = torch.full((L, B, d), float("nan"), device=dev)

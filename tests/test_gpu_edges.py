@@ -122,3 +122,23 @@ def test_trainer_validate_forward_only_path():
         batches.append((im.cuda(), qu.cuda(), ln, la.cuda()))
     m = tr.validate(batches)
     assert 0.0 <= m["accuracy"] <= 100.0 and m["loss"] > 0 and model.training
+
+
+@pytest.mark.parametrize("shape", [(2, 49, 26, 2048, "general"), (3, 196, 26, 512, "auto")])
+def test_bf16_mfma_projections(shape):
+    """BASELINE config 4 shape (7x7x2048 features) and the cfg-2 shape with the projections on the bf16
+    MFMA (COATTN_FLAG_BF16_PROJ): bf16-rounded operands, fp32 accumulation -> bf16 tolerance."""
+    from tests._hip import run_hip
+    B, N, T, d, impl = shape
+    P = O.make_params(d, 12)
+    V, Qs = O.make_inputs(B, N, T, d, 61, lens=sorted([26] + [5] * (B - 1), reverse=True), scale_q=(2.0 / d) ** 0.5)
+    gv = torch.from_numpy(O.hash_normal((3, B, d), 3)).float()
+    gq = torch.from_numpy(O.hash_normal((3, B, d), 4)).float()
+    r = run_hip(V, Qs, P, gv, gq, impl=impl, bf16_proj=True)
+    x = run_hip(V, Qs, P, gv, gq, impl=impl, bf16_proj=False)
+    f = O.coattn_forward(V, Qs, P)
+    # the projections themselves: P_v within bf16 rounding of the exact product, and not identical to fp32
+    rel = ((r["P_v"] - x["P_v"]).abs().max() / x["P_v"].abs().max()).item()
+    assert 1e-5 < rel < 2e-2, rel
+    assert (r["v"].cpu() - f["v"]).abs().max() < 3e-2 and (r["q"].cpu() - f["q"]).abs().max() < 3e-2
+    assert all(torch.isfinite(t).all() for t in r.values())

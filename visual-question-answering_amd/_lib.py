@@ -15,6 +15,7 @@ EXPORTS = ("coattn_version", "coattn_last_error", "coattn_fused_supported", "coa
 
 F32 = 0
 IMPL_AUTO, IMPL_GENERAL, IMPL_FUSED = 0, 1, 2
+FLAG_BF16_PROJ = 4
 
 
 class Params(C.Structure):

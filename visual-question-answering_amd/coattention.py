@@ -17,8 +17,11 @@ from . import _lib
 
 
 def _impl_flag() -> int:
-    return {"auto": _lib.IMPL_AUTO, "general": _lib.IMPL_GENERAL, "fused": _lib.IMPL_FUSED}[
+    f = {"auto": _lib.IMPL_AUTO, "general": _lib.IMPL_GENERAL, "fused": _lib.IMPL_FUSED}[
         os.environ.get("COATTN_IMPL", "auto")]
+    if os.environ.get("COATTN_BF16_PROJ", "0") not in ("0", ""):
+        f |= _lib.FLAG_BF16_PROJ
+    return f
 
 
 def _ptr(t):
@@ -124,10 +127,13 @@ class ParallelCoAttention(nn.Module):
         self.W_q = nn.Linear(hidden_dim, hidden_dim)
         self.w_v = nn.Linear(hidden_dim, 1)
         self.w_q = nn.Linear(hidden_dim, 1)
+        # reduced-precision mode (apex O1 analogue, main.py:185): projections on the bf16 MFMA
+        self.bf16_projections = False
 
     def forward(self, x_img: torch.Tensor, x_ques_hierarchy: Sequence[torch.Tensor]) -> Tuple[List, List]:
         """x_img [B,N,d]; x_ques_hierarchy: list of [B,T,d] -> (list of v_l [B,d], list of q_l [B,d])."""
+        impl = _impl_flag() | (_lib.FLAG_BF16_PROJ if self.bf16_projections else 0)
         v, q = coattention(x_img, list(x_ques_hierarchy), self.W_v.weight, self.W_v.bias, self.W_q.weight,
-                           self.W_q.bias, self.w_v.weight, self.w_v.bias, self.w_q.weight, self.w_q.bias)
+                           self.W_q.bias, self.w_v.weight, self.w_v.bias, self.w_q.weight, self.w_q.bias, impl=impl)
         n = v.shape[0]
         return [v[l] for l in range(n)], [q[l] for l in range(n)]

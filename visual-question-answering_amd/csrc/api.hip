@@ -95,7 +95,12 @@ namespace {
 struct Ctx {
   int B, N, T, d, L;
   hipStream_t s;
+  bool bf16_proj = false;     // COATTN_FLAG_BF16_PROJ: forward projections on the bf16 MFMA
 };
+
+int launch_proj(const Ctx& c, const coattn_gemm_desc& g) {
+  return c.bf16_proj ? launch_gemm_bf16in(g, c.s) : launch_gemm_f32(g, c.s);
+}
 
 // P_v = V W_v^T + b_v   (model.py:380/384, evaluated once per sample)
 int proj_v(const Ctx& c, const float* V, const float* Wv, const float* bv, float* Pv) {
@@ -105,7 +110,7 @@ int proj_v(const Ctx& c, const float* V, const float* Wv, const float* bv, float
   g.a_sm = 1; g.a_sk = c.N; g.a_mdiv = c.N; g.a_sdiv = (int64_t)c.d * c.N;
   g.b_sk = 1; g.b_sn = c.d;
   g.c_sm = c.d; g.c_sn = 1;
-  return launch_gemm_f32(g, c.s);
+  return launch_proj(c, g);
 }
 // P_q = Q W_q^T + b_q   (model.py:381/383)
 int proj_q(const Ctx& c, const float* Q, const float* Wq, const float* bq, float* Pq) {
@@ -115,7 +120,7 @@ int proj_q(const Ctx& c, const float* Q, const float* Wq, const float* bq, float
   g.a_sm = c.d; g.a_sk = 1;
   g.b_sk = 1; g.b_sn = c.d;
   g.c_sm = c.d; g.c_sn = 1;
-  return launch_gemm_f32(g, c.s);
+  return launch_proj(c, g);
 }
 // C = tanh(Q V)   (model.py:377)
 int affinity(const Ctx& c, const float* Q, const float* V, float* C) {
@@ -159,7 +164,7 @@ int general_projections(const Ctx& c, const float* V, const float* const* Q, con
   g.a_sm = c.d; g.a_sk = 1;
   g.b_sk = 1; g.b_sn = c.d;
   g.c_sm = c.d; g.c_sn = 1;
-  return launch_gemm_f32(g, c.s);
+  return launch_proj(c, g);
 }
 
 // everything after the projections: affinity, H_v / H_q, scores, softmax, attended reductions
@@ -363,6 +368,7 @@ static int forward_impl(const void* V, const void* const* Q, const coattn_params
   float* sv = saved ? (float*)saved : (float*)ws;      // inference: state lives in the workspace
   float* tail = (float*)ws + sp.total;
   Ctx c{B, N, T, d, L, (hipStream_t)stream};
+  c.bf16_proj = (flags & COATTN_FLAG_BF16_PROJ) != 0;
   if (do_proj) CA_TRY(general_projections(c, (const float*)V, (const float* const*)Q, p, sv));
   if (!do_attn) return 0;
   if (fused)

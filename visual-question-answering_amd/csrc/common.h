@@ -67,6 +67,8 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 // ---- generic GEMM (gemm.hip) ------------------------------------------------------------
 int launch_gemm_f32(const coattn_gemm_desc& g, hipStream_t s);
+// same contract, operands rounded to bf16 for v_mfma_f32_32x32x16_bf16 (falls back to fp32 when unsupported)
+int launch_gemm_bf16in(const coattn_gemm_desc& g, hipStream_t s);
 
 // ---- small general-shape kernels (small_kernels.hip) ------------------------------------
 // y[z][i] = sum_k X[z*x_sz + i*x_si + k*x_sk] * u[z*u_sz + k]      (i < I, k < K)

@@ -376,6 +376,134 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
     }
 }
 
+
+// ---- bf16-MFMA projection GEMM (fp32 in HBM, rounded to bf16 while staging, fp32 accumulate/out) -----
+// C(m,n) = sum_k bf16(A(m,k)) * bf16(B(k,n)) + bias_n[n]; B must be contiguous along k (nn.Linear weight
+// [n][k]); A is contiguous along k (AM = false) or along m (AM = true: channel-major V with the row split).
+// v_mfma_f32_32x32x16_bf16: lane (i = lane&31, h = lane>>5) holds 8 consecutive k of row i -> both
+// operands are staged [row][k] (k contiguous, 80-byte rows) and read with one ds_read_b128 per MFMA.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ short f2bf(float x) {            // round to nearest even (inputs are finite)
+  unsigned u = __builtin_bit_cast(unsigned, x);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (short)(u >> 16);
+}
+
+template <bool AM, bool AVEC>
+__global__ __launch_bounds__(256) void gemm_bf16in_kernel(const GemmK g) {
+  constexpr int BM = 128, BN = 128, BK = 32, LDR = 40;       // row stride in bf16 elements (80 B)
+  __shared__ __attribute__((aligned(16))) short As[BM * LDR];
+  __shared__ __attribute__((aligned(16))) short Bs[BN * LDR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, z = blockIdx.z;
+  const int nsteps = (g.K + BK - 1) / BK;
+  const float* Ab = g.a_ptrs[0] ? g.a_ptrs[z & 7] : g.A + (long)z * g.a_sz;
+  const float* Bb = g.B + (long)z * g.b_sz;
+  int a_off[4], a_m[4], a_k[4];
+  bool a_ok[4];
+  int a_off1[4][4];                                          // per-element offsets when rows are not 16-byte aligned
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i;
+    if (AM) { a_k[i] = idx >> 5; a_m[i] = (idx & 31) * 4; } else { a_m[i] = idx >> 3; a_k[i] = (idx & 7) * 4; }
+    a_ok[i] = (m0 + a_m[i]) < g.M;
+    a_off[i] = a_ok[i] ? (int)(row_off(m0 + a_m[i], g.a_sm, g.a_mdiv, g.a_sdiv) + (long)a_k[i] * g.a_sk) : 0;
+    if (AM && !AVEC) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        a_off1[i][e] = (m0 + a_m[i] + e) < g.M
+                           ? (int)(row_off(m0 + a_m[i] + e, g.a_sm, g.a_mdiv, g.a_sdiv) + (long)a_k[i] * g.a_sk) : -1;
+    }
+  }
+  int b_off[4], b_n[4], b_k[4];
+  bool b_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i;
+    b_n[i] = idx >> 3; b_k[i] = (idx & 7) * 4;
+    b_ok[i] = (n0 + b_n[i]) < g.N;
+    b_off[i] = b_ok[i] ? (int)((long)b_k[i] * g.b_sk + (long)(n0 + b_n[i]) * g.b_sn) : 0;
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  f32x4 ra[4], rb[4];
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto load_regs = [&](int k0) {
+    const int klim = g.K - k0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (AM && !AVEC) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          ra[i][e] = (a_off1[i][e] >= 0 && a_k[i] < klim) ? Ab[(long)k0 * g.a_sk + a_off1[i][e]] : 0.f;
+      } else {
+        ra[i] = (a_ok[i] && a_k[i] < klim) ? *reinterpret_cast<const f32x4*>(Ab + (long)k0 * g.a_sk + a_off[i]) : zero4;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      rb[i] = (b_ok[i] && b_k[i] < klim) ? *reinterpret_cast<const f32x4*>(Bb + (long)k0 * g.b_sk + b_off[i]) : zero4;
+  };
+  auto store_regs = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (AM) {                                              // 4 rows m..m+3 of one k: transposing 2-byte writes
+#pragma unroll
+        for (int e = 0; e < 4; ++e) As[(a_m[i] + e) * LDR + a_k[i]] = f2bf(ra[i][e]);
+      } else {
+        *reinterpret_cast<bf16x4*>(&As[a_m[i] * LDR + a_k[i]]) =
+            bf16x4{f2bf(ra[i][0]), f2bf(ra[i][1]), f2bf(ra[i][2]), f2bf(ra[i][3])};
+      }
+      *reinterpret_cast<bf16x4*>(&Bs[b_n[i] * LDR + b_k[i]]) =
+          bf16x4{f2bf(rb[i][0]), f2bf(rb[i][1]), f2bf(rb[i][2]), f2bf(rb[i][3])};
+    }
+  };
+  if (nsteps > 0) { load_regs(0); store_regs(); }
+  __syncthreads();
+  const int li = lane & 31, lh = lane >> 5;
+  for (int step = 0; step < nsteps; ++step) {
+    if (step + 1 < nsteps) load_regs((step + 1) * BK);
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 16) {
+      bf16x8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8*>(&As[(wr * 64 + i * 32 + li) * LDR + ks + 8 * lh]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(&Bs[(wc * 64 + j * 32 + li) * LDR + ks + 8 * lh]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (step + 1 < nsteps) {
+      store_regs();
+      __syncthreads();
+    }
+  }
+  float* Cb = g.C + (long)z * g.c_sz;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wc * 64 + j * 32 + li;
+      const float bn = (g.bias_n && col < g.N) ? g.bias_n[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < g.M && col < g.N) Cb[row_off(row, g.c_sm, g.c_mdiv, g.c_sdiv) + (long)col * g.c_sn] = acc[i][j][r] + bn;
+      }
+    }
+}
+
 }  // namespace
 
 static long span(long n, long s) { return n > 0 ? (n - 1) * (s < 0 ? -s : s) : 0; }
@@ -444,5 +572,32 @@ int launch_gemm_f32(const coattn_gemm_desc& d, hipStream_t s) {
     hipLaunchKernelGGL(gemm_f32_kernel<128>, grid, block, 0, s, g);
   }
   CA_CHECK_LAUNCH("gemm_f32");
+  return 0;
+}
+
+// Projection GEMM with bf16 MFMA inputs (fp32 storage): the shapes/layouts of P_v and P_q only.
+int launch_gemm_bf16in(const coattn_gemm_desc& d, hipStream_t s) {
+  auto al4 = [](long v) { return (v & 3) == 0; };
+  const bool a_m = (d.a_sm == 1 && d.a_sk != 1);
+  bool tab_ok = true;
+  for (int t = 0; t < 8; ++t) tab_ok = tab_ok && ((((uintptr_t)d.a_ptrs[t]) & 15) == 0);
+  const bool ok = (d.A || d.a_ptrs[0]) && tab_ok && (!d.a_ptrs[0] || d.batch <= 8) && d.B && d.C && !d.Cin && !d.bias_m && d.act == 0 && d.inner <= 1 && d.ksplit == 0 &&
+                  !d.ptr_by_inner && !d.b_ptrs[0] && !d.c_ptrs[0] && d.b_sk == 1 && al4(d.b_sn) && al4(d.K) &&
+                  (a_m ? true : (d.a_sk == 1 && al4(d.a_sm))) &&
+                  al4(d.a_sz) && al4(d.b_sz) && ((((uintptr_t)d.A) | ((uintptr_t)d.B)) & 15) == 0;
+  if (!ok) return launch_gemm_f32(d, s);               // shapes the bf16 kernel does not take: exact fp32 path
+  GemmK g = {};
+  g.A = (const float*)d.A; g.B = (const float*)d.B; g.C = (float*)d.C; g.bias_n = (const float*)d.bias_n;
+  for (int t = 0; t < 8; ++t) g.a_ptrs[t] = (const float*)d.a_ptrs[t];
+  g.M = d.M; g.N = d.N; g.K = d.K;
+  g.a_sm = d.a_sm; g.a_sk = d.a_sk; g.a_sz = d.a_sz; g.a_mdiv = d.a_mdiv; g.a_sdiv = d.a_sdiv;
+  g.b_sk = d.b_sk; g.b_sn = d.b_sn; g.b_sz = d.b_sz;
+  g.c_sm = d.c_sm; g.c_sn = d.c_sn; g.c_sz = d.c_sz; g.c_mdiv = d.c_mdiv; g.c_sdiv = d.c_sdiv;
+  dim3 grid((d.N + 127) / 128, (d.M + 127) / 128, d.batch), block(256);
+  const bool a_vec = al4(d.M) && al4(d.a_sk) && al4(d.a_mdiv) && al4(d.a_sdiv);
+  if (a_m && a_vec) hipLaunchKernelGGL((gemm_bf16in_kernel<true, true>), grid, block, 0, s, g);
+  else if (a_m) hipLaunchKernelGGL((gemm_bf16in_kernel<true, false>), grid, block, 0, s, g);
+  else hipLaunchKernelGGL((gemm_bf16in_kernel<false, true>), grid, block, 0, s, g);
+  CA_CHECK_LAUNCH("gemm_bf16in");
   return 0;
 }

@@ -98,6 +98,8 @@ class Trainer:
         self.criterion = nn.CrossEntropyLoss()
         self.optimizer = torch.optim.Adam(model.parameters(), lr)
         self.opt_lvl = opt_lvl
+        if opt_lvl > 0 and hasattr(model, "co_attention"):      # AMP: projections on the bf16 MFMA as well
+            model.co_attention.bf16_projections = True
         self.reducer = vdist.GradReducer(model, bucket_mb=bucket_mb) if vdist.world_size() > 1 else None
 
     def step(self, image, question, ques_len, label) -> torch.Tensor:

@@ -54,6 +54,17 @@ def parse():
     return ap.parse_args()
 
 
+def synth_features(B, N, T, d, device, seed=1234, L=3):
+    """Device-resident synthetic features of the isolated path: V = relu(N(0,1)) stored
+    channel-major [B,d,N], Q_l ~ N(0,1) [B,T,d] with rows past each (descending) length zeroed."""
+    g = torch.Generator().manual_seed(seed)
+    V = torch.randn(B, d, N, generator=g).clamp_min_(0)
+    lens = torch.tensor(sorted([T] + [3 + (7 * i) % (T - 2) for i in range(B - 1)], reverse=True))
+    mask = (torch.arange(T)[None, :] < lens[:, None]).unsqueeze(-1).float()
+    Qs = [(torch.randn(B, T, d, generator=g) * mask).to(device) for _ in range(L)]
+    return V.to(device), Qs
+
+
 def device_batch(T, args, rank, device, batch=None, image_size=None):
     b = T.synthetic_batch(batch or args.batch, (image_size or args.image_size,) * 2, args.seq_len, args.vocab,
                           args.num_cls + 1, seed=1234 + rank)
@@ -76,14 +87,12 @@ def hot_path_leg(device, N, B=160, T=26, d=512, K=1000, iters=20):
     """Isolated hot path (co-attention + MLPClassifier + CE, fwd+bwd) on resident features."""
     import vqa_amd
     from vqa_amd.modules import MLPClassifier
-    from oracle import coattn_oracle as O
     torch.manual_seed(0)
     co = vqa_amd.ParallelCoAttention(d).to(device)
     mlp = MLPClassifier(d, 1024, K + 1).to(device)
-    lens = sorted([26] + [3 + (7 * i) % 24 for i in range(B - 1)], reverse=True)
-    V, Qs = O.make_inputs(B, N, T, d, 1234, lens=lens)
-    x_img = V.to(device).permute(0, 2, 1)
-    Qs = [q.to(device).requires_grad_(True) for q in Qs]
+    V, Qs = synth_features(B, N, T, d, device)
+    x_img = V.permute(0, 2, 1)
+    Qs = [q.requires_grad_(True) for q in Qs]
     label = (torch.arange(B, device=device) * 7) % (K + 1)
     crit = torch.nn.CrossEntropyLoss()
     params = [p for p in list(co.parameters()) + list(mlp.parameters())]
@@ -129,14 +138,13 @@ def roofline_leg(device, B=160, N=196, T=26, d=512, L=3, iters=50):
     import ctypes as C
     import vqa_amd
     from vqa_amd import _lib
-    from oracle import coattn_oracle as O
     lib = _lib.load()
     fused = bool(lib.coattn_fused_supported(B, N, T, d, L, _lib.F32))
-    P = O.make_params(d, 5)
-    V, Qs = O.make_inputs(B, N, T, d, 77, lens=[T] * B)
-    V = V.to(device); Qs = [q.to(device) for q in Qs]
-    names = ("W_v.weight", "W_v.bias", "W_q.weight", "W_q.bias", "w_v.weight", "w_v.bias", "w_q.weight", "w_q.bias")
-    ps = [P[k].to(device).contiguous() for k in names]
+    torch.manual_seed(0)
+    co = vqa_amd.ParallelCoAttention(d).to(device)
+    V, Qs = synth_features(B, N, T, d, device, seed=77, L=L)
+    ps = [t.detach().contiguous() for t in (co.W_v.weight, co.W_v.bias, co.W_q.weight, co.W_q.bias, co.w_v.weight,
+                                           co.w_v.bias, co.w_q.weight, co.w_q.bias)]
     sb, fb, _ = _lib.workspace_bytes(B, N, T, d, L)
     saved = torch.empty(sb // 4, device=device); ws = torch.empty(fb // 4, device=device)
     v = torch.empty(L, B, d, device=device); q = torch.empty(L, B, d, device=device)

@@ -1,14 +1,13 @@
 import sys, time, torch, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vqa_amd
-from oracle import coattn_oracle as O
 dev = torch.device('cuda', 0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 196
 B, T, d = 160, 26, 512
 co = vqa_amd.ParallelCoAttention(d).to(dev)
-V, Qs = O.make_inputs(B, N, T, d, 1234, lens=[26]*B)
-x = V.to(dev).permute(0, 2, 1)
-Qs = [q.to(dev).requires_grad_(True) for q in Qs]
+torch.manual_seed(1)
+x = torch.randn(B, d, N, device=dev).clamp_min_(0).permute(0, 2, 1)
+Qs = [torch.randn(B, T, d, device=dev).requires_grad_(True) for _ in range(3)]
 args = (co.W_v.weight, co.W_v.bias, co.W_q.weight, co.W_q.bias, co.w_v.weight, co.w_v.bias, co.w_q.weight, co.w_q.bias)
 tf = tb = 0
 for it in range(25):

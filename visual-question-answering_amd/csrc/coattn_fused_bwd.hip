@@ -173,13 +173,25 @@ struct BwdArgs {
   int B, N, T, d, L;
 };
 
-// stage C (zero padded to kTRows x NPAD) and ds_v (zero padded) into LDS
+// stage C (zero padded to kTRows x NPAD) and ds_v (zero padded) into LDS: one wave per row, lanes along n
 template <int NPAD, int LD, int NTHREADS>
 __device__ __forceinline__ void stage_c(const BwdArgs& a, size_t pair, float* Cbuf, float* dsvs, int tid) {
   const float* Cg = a.C + pair * (size_t)a.T * a.N;
-  for (int e = tid; e < kTRows * NPAD; e += NTHREADS) {
-    const int row = e / NPAD, col = e - row * NPAD;
-    Cbuf[row * LD + col] = (row < a.T && col < a.N) ? Cg[(size_t)row * a.N + col] : 0.f;
+  const int lane = tid & 63, w = tid >> 6;
+  const bool al = (a.N & 3) == 0;
+  for (int row = w; row < kTRows; row += NTHREADS / 64) {
+    const bool live = row < a.T;
+    const float* src = Cg + (size_t)row * a.N;
+    float* dst = Cbuf + row * LD;
+    if (al) {
+      for (int c4 = lane; c4 < NPAD / 4; c4 += 64) {
+        const int col = 4 * c4;
+        *reinterpret_cast<f32x4*>(dst + col) =
+            (live && col < a.N) ? *reinterpret_cast<const f32x4*>(src + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+      for (int col = lane; col < NPAD; col += 64) dst[col] = (live && col < a.N) ? src[col] : 0.f;
+    }
   }
   const float* dg = a.dsv + pair * (size_t)a.N;
   for (int e = tid; e < NPAD; e += NTHREADS) dsvs[e] = (e < a.N) ? dg[e] : 0.f;
@@ -250,9 +262,14 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc_kernel(const BwdArgs a) {
       float cB[kTS];                                 // B[k = t][j = n]
 #pragma unroll
       for (int s = 0; s < kTS; ++s) cB[s] = Cbuf[(4 * s + q4) * LD + 16 * nt + j];
-      f32x4 hv = pvT;
+      // two interleaved accumulation chains (even / odd k-steps): a 16x16x4 MFMA can issue every 32 cycles
+      // but a dependent one only after 40
+      f32x4 hv = pvT, hv2 = zero4;
 #pragma unroll
-      for (int s = 0; s < kTS; ++s) hv = mfma16(pqB[s], cB[s], hv);
+      for (int s = 0; s < kTS; ++s) {
+        if (s & 1) hv2 = mfma16(pqB[s], cB[s], hv2); else hv = mfma16(pqB[s], cB[s], hv);
+      }
+      hv += hv2;
       const float dsn = dsvs[16 * nt + j];
       f32x4 dzv;
 #pragma unroll
@@ -262,9 +279,12 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc_kernel(const BwdArgs a) {
         dzv[r] = dsn * wv4[r] * (1.0f - h * h);
       }
       // dP_v^T tile = dZ_v^T + dZ_q^T C
-      f32x4 dpv = dzv;
+      f32x4 dpv = dzv, dpv2 = zero4;
 #pragma unroll
-      for (int s = 0; s < kTS; ++s) dpv = mfma16(dzqB[s], cB[s], dpv);
+      for (int s = 0; s < kTS; ++s) {
+        if (s & 1) dpv2 = mfma16(dzqB[s], cB[s], dpv2); else dpv = mfma16(dzqB[s], cB[s], dpv);
+      }
+      dpv += dpv2;
       buf_store4(dpv, rs_dpv, voff, (16 * nt * d + db) * 4);
       dbv4 += dpv;                                   // rows n >= N are exact zeros
       // dC[t][n] += sum_r P_q[t][db+4q4+r] dZ_v[n][..] + dZ_q[t][..] P_v[n][..]

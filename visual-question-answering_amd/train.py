@@ -88,6 +88,62 @@ def synthetic_batch(batch_size: int, image_size, max_seq_len: int, vocab_size: i
     return {"image": image, "question": question, "ques_len": lens, "label": label}
 
 
+class DevicePrefetcher:
+    """Host -> device hand-off of the next batch on a side stream while the current step computes
+    (main.py:205-208 copies synchronously).  Pinned staging buffers are reused; the consumer stream
+    waits on the copy's event before it touches the tensors.  Lengths stay on the host (packing)."""
+
+    def __init__(self, batches, device, channels_last: bool = False):
+        self.it = iter(batches)
+        self.device = device
+        self.cl = channels_last
+        self.stream = torch.cuda.Stream(device) if device.type == "cuda" else None
+        self.pinned = {}
+        self.next = None
+        self._fetch()
+
+    def _pin(self, name, t):
+        buf = self.pinned.get(name)
+        if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+            buf = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+            self.pinned[name] = buf
+        buf.copy_(t)
+        return buf
+
+    def _fetch(self):
+        try:
+            image, question, ques_len, label = next(self.it)
+        except StopIteration:
+            self.next = None
+            return
+        if self.stream is None:
+            self.next = (image, question, ques_len, label, None)
+            return
+        with torch.cuda.stream(self.stream):
+            im = self._pin("image", image).to(self.device, non_blocking=True)
+            if self.cl:
+                im = im.contiguous(memory_format=torch.channels_last)
+            qu = self._pin("question", question).to(self.device, non_blocking=True)
+            la = self._pin("label", label).to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.next = (im, qu, ques_len, la, ev)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self.next is None:
+            raise StopIteration
+        im, qu, ln, la, ev = self.next
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            for t in (im, qu, la):
+                t.record_stream(torch.cuda.current_stream(self.device))
+        self._fetch()
+        return im, qu, ln, la
+
+
 class Trainer:
     """Owns model, Adam (lr, PyTorch defaults: main.py:180), loss and the gradient reducer."""
 
@@ -176,15 +232,16 @@ def main(argv=None):
         model.image_encoder.vgg11_encoder.to(memory_format=torch.channels_last)
     trainer = Trainer(model, args.learning_rate, device, args.opt_lvl)
     size = (args.image_size, args.image_size) if args.image_size else cfg["image_size"]
+    def host_batches():
+        for step in range(args.num_steps):
+            b = synthetic_batch(args.batch_size, size, args.max_seq_length, args.vocab_size, args.num_cls + 1,
+                                seed=1234 + rank + 1000 * step)
+            image, question, label, ques_len = sort_batch(b["image"], b["question"], b["label"], b["ques_len"])
+            yield image, question, ques_len, label
+
     t0 = time.time()
-    for step in range(args.num_steps):
-        b = synthetic_batch(args.batch_size, size, args.max_seq_length, args.vocab_size, args.num_cls + 1,
-                            seed=1234 + rank + 1000 * step)
-        image, question, label, ques_len = sort_batch(b["image"], b["question"], b["label"], b["ques_len"])
-        image = image.to(device)
-        if cl:
-            image = image.contiguous(memory_format=torch.channels_last)
-        loss = trainer.step(image, question.to(device), ques_len, label.to(device))
+    for step, (image, question, ques_len, label) in enumerate(DevicePrefetcher(host_batches(), device, cl)):
+        loss = trainer.step(image, question, ques_len, label)
         if (step + 1) % args.log_interval == 0 and rank == 0:
             print(json.dumps({"step": step + 1, "loss": round(float(loss), 5),
                               "pairs_per_s": round(world * args.batch_size * (step + 1) / (time.time() - t0), 2)}))

@@ -47,3 +47,43 @@ def test_attention_train_cli_on_gpu(capsys):
             "--vocab_size", "50", "--max_seq_length", "26", "--log_interval", "2", "--learning_rate", "1e-3"])
     recs = [json.loads(l) for l in capsys.readouterr().out.strip().splitlines() if l.startswith("{")]
     assert len(recs) == 3 and all(r["loss"] == r["loss"] for r in recs)
+
+
+def test_config4_resnet_2048_bf16_step():
+    """BASELINE config 4 as a test case: ResNet-152 7x7x2048 grid, hidden 2048, K=3000, bf16 autocast
+    around the stock encoders + bf16-MFMA projections in the co-attention (general-shape kernels at
+    d = 2048); one training step, finite loss, W_b untouched, features are the channel-major view."""
+    from vqa_amd import train as T
+    torch.manual_seed(0)
+    model = T.build_model("attention_resnet", 200, 3000).cuda()
+    assert model.hidden_dim == 2048 and model.mlp_classify.W_h.out_features == 3001
+    tr = T.Trainer(model, 1e-4, torch.device("cuda:0"), opt_lvl=1)
+    assert model.co_attention.bf16_projections
+    b = T.synthetic_batch(4, (224, 224), 26, 200, 3001, seed=5)
+    im, qu, la, ln = T.sort_batch(b["image"], b["question"], b["label"], b["ques_len"])
+    with torch.no_grad():
+        f = model.image_encoder(im.cuda())
+    assert tuple(f.shape) == (4, 49, 2048) and f.stride() == (2048 * 49, 1, 49)
+    wb = model.co_attention.W_b.weight.detach().clone()
+    l0 = float(tr.step(im.cuda(), qu.cuda(), ln, la.cuda()))
+    l1 = float(tr.step(im.cuda(), qu.cuda(), ln, la.cuda()))
+    assert l0 == l0 and l1 == l1 and l0 > 0
+    assert torch.equal(wb, model.co_attention.W_b.weight)
+
+
+def test_config5_bert_word_level_step():
+    """BASELINE config 5 as a test case: frozen BERT-base token embeddings (768-d, random init: no
+    network) -> Linear(768, 512) word level -> phrase / sentence levels -> HIP co-attention; one step."""
+    from vqa_amd import train as T
+    from vqa_amd.modules import HierarchicalCoAttentionNet
+    torch.manual_seed(0)
+    qp = T.bert_question_params(hidden_dim=512, vocab_size=120)
+    net = HierarchicalCoAttentionNet(qp, dict(is_trainable=False, weights_path=None), K=11).cuda()
+    tr = T.Trainer(net, 1e-4, torch.device("cuda:0"))
+    b = T.synthetic_batch(4, (64, 64), 26, 120, 11, seed=6)
+    im, qu, la, ln = T.sort_batch(b["image"], b["question"], b["label"], b["ques_len"])
+    w0 = net.question_encoder.bert.word_embeddings.weight.detach().clone()
+    loss = float(tr.step(im.cuda(), qu.cuda(), ln, la.cuda()))
+    assert loss == loss and loss > 0
+    assert torch.equal(w0, net.question_encoder.bert.word_embeddings.weight)      # frozen
+    assert net.question_encoder.word_proj.weight.grad is not None

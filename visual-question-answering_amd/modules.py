@@ -80,6 +80,58 @@ class ImageCoAttentionEncoder(nn.Module):
         return grid.permute(0, 2, 1)                         # [B, N, 512] view, strides (512N, 1, N)
 
 
+class _Bottleneck(nn.Module):
+    """torchvision's ResNet bottleneck (1x1 -> 3x3 (stride) -> 1x1 x4, BatchNorm, residual)."""
+
+    def __init__(self, c_in, width, stride, downsample):
+        super().__init__()
+        self.conv1 = nn.Conv2d(c_in, width, 1, bias=False); self.bn1 = nn.BatchNorm2d(width)
+        self.conv2 = nn.Conv2d(width, width, 3, stride=stride, padding=1, bias=False); self.bn2 = nn.BatchNorm2d(width)
+        self.conv3 = nn.Conv2d(width, 4 * width, 1, bias=False); self.bn3 = nn.BatchNorm2d(4 * width)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        return self.relu(self.bn3(self.conv3(y)) + idt)
+
+
+def resnet152_features() -> nn.Sequential:
+    """ResNet-152 trunk (stem + layers [3, 8, 36, 3]) up to the 2048-channel stride-32 map:
+    224x224 -> 7x7x2048 (BASELINE config 4).  Stock torch.nn; torchvision-compatible topology."""
+    mods = [nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True),
+            nn.MaxPool2d(3, stride=2, padding=1)]
+    c_in = 64
+    for width, blocks, stride in ((64, 3, 1), (128, 8, 2), (256, 36, 2), (512, 3, 2)):
+        for i in range(blocks):
+            st = stride if i == 0 else 1
+            ds = None
+            if st != 1 or c_in != 4 * width:
+                ds = nn.Sequential(nn.Conv2d(c_in, 4 * width, 1, stride=st, bias=False), nn.BatchNorm2d(4 * width))
+            mods.append(_Bottleneck(c_in, width, st, ds))
+            c_in = 4 * width
+    return nn.Sequential(*mods)
+
+
+class ImageResNetCoAttentionEncoder(nn.Module):
+    """BASELINE config 4 feeder (an extension; the reference only ships the VGG encoder): frozen
+    ResNet-152 trunk -> spatial grid [B, N, 2048] as a permuted view of [B, 2048, N]."""
+
+    def __init__(self, is_trainable=False, weights_path=None):
+        super().__init__()
+        self.is_trainable, self.weights_path = is_trainable, weights_path
+        self.resnet_encoder = resnet152_features()
+        self.flatten = nn.Flatten(start_dim=2, end_dim=3)
+        if not is_trainable:
+            for prm in self.resnet_encoder.parameters():
+                prm.requires_grad = False
+
+    def forward(self, x_img):
+        return self.flatten(self.resnet_encoder(x_img)).permute(0, 2, 1)
+
+
 class PhraseConvPool(nn.Module):
     """1/2/3-gram Conv1d + tanh, then a max over 3 CONSECUTIVE channels of the concatenated
     [uni|bi|tri] vector -- the reference's reshape (model.py:324-332) groups channels 3e..3e+2,
@@ -178,7 +230,11 @@ class HierarchicalCoAttentionNet(nn.Module):
     def __init__(self, ques_enc_params, img_enc_params, K, mlp_dim=1024):
         super().__init__()
         self.hidden_dim = ques_enc_params["hidden_dim"]
-        self.image_encoder = ImageCoAttentionEncoder(**img_enc_params)
+        img_enc_params = dict(img_enc_params)
+        if img_enc_params.pop("arch", "vgg11_bn") == "resnet152":     # config 4 extension (2048-channel grid)
+            self.image_encoder = ImageResNetCoAttentionEncoder(**img_enc_params)
+        else:
+            self.image_encoder = ImageCoAttentionEncoder(**img_enc_params)
         if "bert" in ques_enc_params:                 # config 5 extension; the reference has only the LSTM path
             self.question_encoder = QuestionBertCoAttentionEncoder(**ques_enc_params)
         else:

@@ -47,6 +47,12 @@ def setup_model_configs(model_name: str, vocab_size: int, vgg_train: bool = Fals
         "attention": dict(model=HierarchicalCoAttentionNet, image_size=(448, 448), image_params=img,
                           question_params=dict(vocab_size=vocab_size, word_emb_dim=512, hidden_dim=512),
                           mlp_dim=1024),
+        # BASELINE config 4 (extension): ResNet-152 7x7x2048 grid, hidden size 2048; run with --opt_lvl 1
+        # for bf16 autocast around the stock encoders and the bf16-MFMA projections of the co-attention
+        "attention_resnet": dict(model=HierarchicalCoAttentionNet, image_size=(224, 224),
+                                 image_params=dict(img, arch="resnet152"),
+                                 question_params=dict(vocab_size=vocab_size, word_emb_dim=2048, hidden_dim=2048),
+                                 mlp_dim=1024),
     }
     return registry[model_name]      # 'bert' is accepted by the reference's argparse but has no entry: KeyError
 
@@ -193,7 +199,7 @@ class Trainer:
 def main(argv=None):
     ap = argparse.ArgumentParser(description="Visual Question Answering (MI355X co-attention path)")
     ap.add_argument("--mode", default="train", choices=["train", "test"])
-    ap.add_argument("--model", default="attention", choices=["baseline", "attention", "bert"])
+    ap.add_argument("--model", default="attention", choices=["baseline", "attention", "bert", "attention_resnet"])
     ap.add_argument("--num_cls", "-K", type=int_min_two, default=1000)
     ap.add_argument("--batch_size", "-bs", type=int, default=8)
     ap.add_argument("--num_steps", type=int, default=20)
@@ -227,9 +233,9 @@ def main(argv=None):
     if args.model_ckpt:
         model.load_state_dict(torch.load(args.model_ckpt, map_location="cpu"))
     model.to(device)
-    cl = args.channels_last and device.type == "cuda" and args.model == "attention"
+    cl = args.channels_last and device.type == "cuda" and args.model.startswith("attention")
     if cl:
-        model.image_encoder.vgg11_encoder.to(memory_format=torch.channels_last)
+        model.image_encoder.to(memory_format=torch.channels_last)
     trainer = Trainer(model, args.learning_rate, device, args.opt_lvl)
     size = (args.image_size, args.image_size) if args.image_size else cfg["image_size"]
     def host_batches():

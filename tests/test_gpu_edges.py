@@ -58,9 +58,11 @@ def test_bitwise_deterministic():
 
 
 @pytest.mark.parametrize("B,N,T,d", [(1, 1, 1, 32), (2, 208, 28, 512), (2, 209, 26, 512), (2, 196, 29, 512),
-                                     (3, 64, 7, 256), (2, 65, 26, 512), (1, 16, 16, 128)])
+                                     (3, 64, 7, 256), (2, 65, 26, 512), (1, 16, 16, 128),
+                                     (2, 49, 26, 2048), (2, 196, 26, 1024), (2, 49, 20, 768)])
 def test_auto_dispatch_shape_limits(B, N, T, d):
-    """Shapes on both sides of the fused kernels' limits (N <= 208, T <= 28, d in {256, 512})."""
+    """Shapes on both sides of the fused kernels' limits (N <= 208, T <= 28, d a multiple of 256:
+    several 128-channel slices per wave at d = 768, 1024, 2048)."""
     from tests._hip import run_hip
     lens = sorted([T] + [max(1, T // 2)] * (B - 1), reverse=True)
     P = O.make_params(d, 9)

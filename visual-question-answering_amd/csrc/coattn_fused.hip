@@ -66,11 +66,21 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
   const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(Vp, (unsigned)d * N * 4u);
   const __amdgpu_buffer_rsrc_t rs_pv = make_rsrc(Pvp, (unsigned)N * d * 4u);
 
-  // phase-2 operands (this wave's 128-channel slice of P_q as MFMA B operands, w_v): loaded at
-  // the end of phase 1 so that they fly under the cross-wave reduction
-  const int dsl = w * 128;
+  // A wave owns the 128-channel slices (sl * NW + w), sl = 0 .. d / (128 NW) - 1 (one slice at d = 512).
+  const int nsl = d / (128 * NW);
+  // phase-2 operands (a 128-channel slice of P_q as MFMA B operands, w_v): the first slice is loaded at
+  // the end of phase 1 so that the loads fly under the cross-wave reduction
   float pq[kTS][8];                                  // B operand P_q[t = 4s + q4][dsl + 16c + j]
   float wvr[8];
+  const __amdgpu_buffer_rsrc_t rs_pq = make_rsrc(Pqp, (unsigned)T * d * 4u);     // rows >= T read 0
+  auto load_slice_operands = [&](int dsl) {
+#pragma unroll
+    for (int s = 0; s < kTS; ++s)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) pq[s][c] = buf_load1(rs_pq, ((4 * s + q4) * d + j) * 4 + 64 * c, dsl * 4);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) wvr[c] = a.wv[dsl + 16 * c + j];
+  };
 
   // ------------------------------------------------------------------ phase 1: A = Q V^T
   {
@@ -79,10 +89,10 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[tt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int ks = w * 128;
     constexpr int RING = 4;                          // V operand ring: 3 k-steps in flight
     float vb[RING][NT];
     f32x4 qa[2][2];
+    int ks = w * 128;                                // first channel of the current slice
     // A operand (Q): lane (row t = 16tt + j, quad q4) holds Q[t][k0 + 4*q4 + s], s = 0..3
     // B operand (V): lane (col n = 16tile + j, quad q4) holds V[k0 + 4*q4 + s][n]
     const int q_voff0 = (j * d + 4 * q4) * 4, q_voff1 = ((16 + j) * d + 4 * q4) * 4;
@@ -97,11 +107,13 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
       for (int t = 0; t < NT; ++t) dst[t] = buf_load1(rs_v, v_voff + 64 * t, soff);   // cols >= N: finite junk,
                                                                                        // zeroed when C is finalised
     };
+    for (int sl = 0; sl < nsl; ++sl) {
+    ks = (sl * NW + w) * 128;
     load_q(0, qa[0]);
 #pragma unroll
     for (int u = 0; u < RING - 1; ++u) load_v(u, vb[u]);
 #pragma unroll
-    for (int u = 0; u < 32; ++u) {                   // 32 k-steps of 4 = this wave's 128 channels
+    for (int u = 0; u < 32; ++u) {                   // 32 k-steps of 4 = one 128-channel slice
       if (u + RING - 1 < 32) load_v(u + RING - 1, vb[(u + RING - 1) % RING]);
       if ((u & 3) == 1 && (u >> 2) + 1 < 8) load_q((u >> 2) + 1, qa[((u >> 2) + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);             // keep the prefetch ahead of this step's MFMAs
@@ -112,15 +124,8 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
         acc[1][t] = mfma16(qa[qb][1][s], vb[u % RING][t], acc[1][t]);
       }
     }
-    {
-      const __amdgpu_buffer_rsrc_t rs_pq = make_rsrc(Pqp, (unsigned)T * d * 4u);   // rows >= T read 0
-#pragma unroll
-      for (int s = 0; s < kTS; ++s)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) pq[s][c] = buf_load1(rs_pq, ((4 * s + q4) * d + j) * 4 + 64 * c, dsl * 4);
-#pragma unroll
-      for (int c = 0; c < 8; ++c) wvr[c] = a.wv[dsl + 16 * c + j];
     }
+    load_slice_operands(w * 128);
     // cross-wave sum in a fixed tree order through LDS; C/D layout: col = j, row = 4*q4 + r
     auto put = [&](float* slot) {
 #pragma unroll
@@ -171,6 +176,14 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
   }
 
   // ------------------------------------------------------------------ phase 2: H_v scores, H_q
+  float sqacc[2][4];                                 // s_q partials of this wave, summed over its slices
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sqacc[tt][r] = 0.f;
+  for (int sl = 0; sl < nsl; ++sl) {
+  const int dsl = (sl * NW + w) * 128;
+  if (sl > 0) load_slice_operands(dsl);
   f32x4 accq[2][8];
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt)
@@ -227,7 +240,8 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float t = row16_sum(sv[r]);
-        if (j == 0) svpart[w * NPAD + 16 * tile + 4 * q4 + r] = t;
+        float* dst = &svpart[w * NPAD + 16 * tile + 4 * q4 + r];
+        if (j == 0) *dst = (sl > 0) ? *dst + t : t;             // accumulate over this wave's channel slices
         sv[r] = 0.f;
       }
     };
@@ -283,12 +297,10 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
   // H_q epilogue: hq = tanh(P_q + acc); saved for backward; s_q partials.  Branch-free: rows t >= T
   // fall outside the per-sample buffers (loads give 0, stores are dropped), all loads issued first.
   {
-    const __amdgpu_buffer_rsrc_t rs_pq = make_rsrc(Pqp, (unsigned)T * d * 4u);
     const __amdgpu_buffer_rsrc_t rs_hq = make_rsrc(a.Hq + pair * (size_t)T * d, (unsigned)T * d * 4u);
     float wqr[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) wqr[c] = a.wq[dsl + 16 * c + j];
-    float sq[2][4];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
       float pqv[4][8];
@@ -307,11 +319,16 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
                                                 ((16 * tt + 4 * q4 + r) * d + j) * 4 + 64 * c, dsl * 4, 0);
           acc = fmaf(h, wqr[c], acc);
         }
-        sq[tt][r] = row16_sum(acc);
-        if (j == 0) sqpart[w * 32 + 16 * tt + 4 * q4 + r] = sq[tt][r];
+        sqacc[tt][r] += row16_sum(acc);
       }
     }
   }
+  }   // channel slices
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (j == 0) sqpart[w * 32 + 16 * tt + 4 * q4 + r] = sqacc[tt][r];
   __syncthreads();
   if (w == 0) {
     // a_v = softmax_n(s_v + c_v): N <= 16*NT <= 256 -> <= 4 values per lane
@@ -431,7 +448,7 @@ int launch_fwd(const FwdArgs& a, hipStream_t s) {
 
 int fused_supported(int B, int N, int T, int d, int L) {
   (void)B;
-  if (!(d == 256 || d == 512)) return 0;
+  if (d <= 0 || d % 256 != 0 || d > 4096) return 0;   // NW = 4 waves when d % 512 == 0, else 2; slices of 128 channels
   if (T > kTRows || N > 208 || L > 3) return 0;
   return 1;
 }
@@ -451,7 +468,7 @@ int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, c
   a.q_out = q_out;
   a.B = B; a.N = N; a.T = T; a.d = d; a.L = L;
   const bool small_n = N <= 64;
-  if (d == 512) {
+  if (d % 512 == 0) {
     CA_TRY(small_n ? (launch_fwd<4, 4>(a, s)) : (launch_fwd<13, 4>(a, s)));
   } else {
     CA_TRY(small_n ? (launch_fwd<4, 2>(a, s)) : (launch_fwd<13, 2>(a, s)));

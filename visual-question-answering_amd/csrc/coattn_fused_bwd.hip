@@ -232,8 +232,9 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc_kernel(const BwdArgs a) {
     for (int t = 0; t < NT; ++t) acc[tt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int dt = 0; dt < 8; ++dt) {
-    const int db = w * 128 + 16 * dt;
+  const int nsl = d / (128 * NW);                    // 128-channel slices per wave (1 at d = 512)
+  for (int dt = 0; dt < 8 * nsl; ++dt) {
+    const int db = ((dt >> 3) * NW + w) * 128 + 16 * (dt & 7);
     // per-channel-tile operands
     float pqB[kTS], dzqB[kTS];                     // A[i = d = db + j][k = t = 4s + q4]
 #pragma unroll
@@ -369,9 +370,12 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dpq_kernel(const BwdArgs a) {
   const float* Pqp = a.Pq + pair * (size_t)T * d;
   const float* dZqp = a.dZq + pair * (size_t)T * d;
   stage_c<NPAD, LD, NW * 64>(a, pair, Cbuf, dsvs, tid);
-  const int dsl = w * 128;
+  __syncthreads();
   const __amdgpu_buffer_rsrc_t rs_pq = make_rsrc(Pqp, (unsigned)T * d * 4u);       // rows >= T read 0
   const __amdgpu_buffer_rsrc_t rs_dzq = make_rsrc(dZqp, (unsigned)T * d * 4u);
+  const int nsl = d / (128 * NW);                    // 128-channel slices per wave (1 at d = 512)
+  for (int sl = 0; sl < nsl; ++sl) {
+  const int dsl = (sl * NW + w) * 128;
   float pq[kTS][8];
 #pragma unroll
   for (int s = 0; s < kTS; ++s)
@@ -385,7 +389,6 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dpq_kernel(const BwdArgs a) {
   for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
     for (int c = 0; c < 8; ++c) accq[tt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
 
   const int ntiles = (N + 15) >> 4;
   {
@@ -436,6 +439,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dpq_kernel(const BwdArgs a) {
     dbq[c] += __shfl_xor(dbq[c], 32, 64);
     if (q4 == 0) a.dbq_part[pair * (size_t)d + dsl + 16 * c + j] = dbq[c];
   }
+  }   // channel slices
 }
 
 // dQ_l[b][t][k] = a_q,l[t] gq_l[k] + sum_n dA_l[t][n] V[b][k][n]   for all levels with one pass over V.
@@ -608,7 +612,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const floa
   ba.dPv = ws + wo.dPv; ba.dPq = ws + wo.dPq; ba.dA = ws + wo.dA; ba.dwv_part = ws + wo.dwv_part;
   ba.dbv_part = ws + wo.dbv_part; ba.dbq_part = ws + wo.dbq_part;
   ba.B = B; ba.N = N; ba.T = T; ba.d = d; ba.L = L;
-  if (d == 512) {
+  if (d % 512 == 0) {
     CA_TRY(small_n ? (launch_main<4, 4>(ba, s)) : (launch_main<13, 4>(ba, s)));
   } else {
     CA_TRY(small_n ? (launch_main<4, 2>(ba, s)) : (launch_main<13, 2>(ba, s)));

@@ -671,7 +671,8 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const floa
     g.M = B * T; g.N = d; g.K = d; g.batch = L;
     CA_TRY(launch_gemm_f32(g, s));
   }
-  // sum dP_v over the levels in place into level 0 (two streaming passes)
+  // sum dP_v over the levels in place into level 0 (two streaming passes; folding the sum into the
+  // weight-gradient GEMM's operand loads was measured slower: 302 vs 170 + 50 us)
   float* dPv = ws + wo.dPv;
   for (int l = 1; l < L; ++l) CA_TRY(launch_add_inplace(dPv, dPv + l * BNd, (int64_t)BNd, 1, s));
   if (dV) {

@@ -148,21 +148,30 @@ struct ReduceJobs {
   float* dst[4];
 };
 __global__ __launch_bounds__(256) void reduce_jobs_kernel(const ReduceJobs jobs, int nparts, long n, int accumulate) {
+  // 64 columns per block; the four waves take interleaved parts and are combined in a fixed order
+  __shared__ float red[4][64];
   const float* part = jobs.src[blockIdx.y];
   float* out = jobs.dst[blockIdx.y];
-  const long j = (long)blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const long j = (long)blockIdx.x * 64 + col;
   float acc = 0.f;
-  int c = 0;
-  for (; c + 8 <= nparts; c += 8) {
-    float v[8];
+  if (j < n) {
+    int c = grp;
+    for (; c + 28 < nparts; c += 32) {               // 8 loads in flight per thread
+      float v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = part[(long)(c + u) * n + j];
+      for (int u = 0; u < 8; ++u) v[u] = part[(long)(c + 4 * u) * n + j];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc += v[u];
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; c < nparts; c += 4) acc += part[(long)c * n + j];
   }
-  for (; c < nparts; ++c) acc += part[(long)c * n + j];
-  out[j] = accumulate ? out[j] + acc : acc;
+  red[grp][col] = acc;
+  __syncthreads();
+  if (grp == 0 && j < n) {
+    const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+    out[j] = accumulate ? out[j] + t : t;
+  }
 }
 
 __global__ __launch_bounds__(256) void add4_inplace_kernel(float* y, const float* x, long n4, int accumulate) {
@@ -270,7 +279,7 @@ int launch_reduce_jobs(const float* const* src, float* const* dst, int njobs, in
   CA_CHECK_ARG(njobs >= 1 && njobs <= 4, "reduce_jobs: 1..4 jobs");
   ReduceJobs jobs;
   for (int i = 0; i < 4; ++i) { jobs.src[i] = i < njobs ? src[i] : nullptr; jobs.dst[i] = i < njobs ? dst[i] : nullptr; }
-  hipLaunchKernelGGL(reduce_jobs_kernel, dim3((unsigned)((n + 255) / 256), njobs), dim3(256), 0, s, jobs, nparts,
+  hipLaunchKernelGGL(reduce_jobs_kernel, dim3((unsigned)((n + 63) / 64), njobs), dim3(256), 0, s, jobs, nparts,
                      (long)n, accumulate);
   CA_CHECK_LAUNCH("reduce_jobs");
   return 0;

@@ -274,11 +274,12 @@ def main():
         if rank == 0 and trainer.reducer is not None:
             out["allreduce_payload_mb"] = round(trainer.reducer.payload_bytes() / 1e6, 2)
         vdist.shutdown()
-    elif not args.no_extras:
+    if rank == 0 and not args.no_extras:
         del trainer, model, batch
         torch.cuda.empty_cache()
-        out["roofline"] = roofline_leg(device)
-        out["hot_path"] = [hot_path_leg(device, 196), hot_path_leg(device, 49)]
+        out["roofline"] = roofline_leg(device)                 # per-GPU kernel; the same on every rank
+        if world == 1:
+            out["hot_path"] = [hot_path_leg(device, 196), hot_path_leg(device, 49)]
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg(args)

@@ -278,6 +278,9 @@ def main():
         del trainer, model, batch
         torch.cuda.empty_cache()
         out["roofline"] = roofline_leg(device)                 # per-GPU kernel; the same on every rank
+        # the same kernel at the timed step's own grid (224x224 -> 7x7 = 49 locations)
+        out["roofline_at_step_shape"] = roofline_leg(device, B=args.batch, N=(args.image_size // 32) ** 2,
+                                                     T=args.seq_len)
         if world == 1:
             out["hot_path"] = [hot_path_leg(device, 196), hot_path_leg(device, 49)]
     if rank == 0:

@@ -390,24 +390,110 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dpq_kernel(const BwdArgs a) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) accq[tt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Tile loop over quarter tiles (2 channel tiles, ring of 4 buffers), software pipelined: in step u the
+  // recompute MFMAs of quarter u are interleaved with the tanh / dZ_v VALU work of quarter u-1, whose
+  // dP_q MFMAs follow; loads run two quarters ahead (rows beyond N read 0 through the buffer rule).
   const int ntiles = (N + 15) >> 4;
   {
     const __amdgpu_buffer_rsrc_t rs_pv = make_rsrc(Pvp, (unsigned)N * d * 4u);
-    f32x4 pvA[4], pvB[4];
-    float sv[4] = {0.f, 0.f, 0.f, 0.f};
-    load_pv_half<0>(rs_pv, d, dsl, 0, j, q4, pvA);
-    for (int tile = 0; tile < ntiles; ++tile) {
+    f32x4 ring[4][2];
+    f32x4 ca[2], ca_prev[2];
+    float ct[kTS];
+    float dsn[4], dsn_prev[4];
+    auto load_q = [&](int tile, int qc, f32x4(&dst)[2]) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int voff = ((4 * q4 + r) * d + j) * 4;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) dst[c][r] = buf_load1(rs_pv, voff + 64 * (2 * qc + c), (16 * tile * d + dsl) * 4);
+      }
+    };
+    auto load_a = [&](int tile) {
       const int nb = 16 * tile;
-      load_pv_half<1>(rs_pv, d, dsl, nb, j, q4, pvB);
-      float dsn[4];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = min(16 * tt + j, kTRows - 1);
+        ca[tt] = *reinterpret_cast<const f32x4*>(&Cbuf[t * LD + nb + 4 * q4]);
+      }
+#pragma unroll
+      for (int s = 0; s < kTS; ++s) ct[s] = Cbuf[(4 * s + q4) * LD + nb + j];
 #pragma unroll
       for (int r = 0; r < 4; ++r) dsn[r] = dsvs[nb + 4 * q4 + r];
+    };
+    auto s3_q = [&](f32x4(&pv)[2], const int qc) {            // H_v quarter = P_v + C^T P_q
+#pragma unroll
+      for (int s = 0; s < kTS; ++s)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) pv[c] = mfma16(ct[s], pq[s][2 * qc + c], pv[c]);
+    };
+    auto valu_q = [&](f32x4(&pv)[2], const int qc, const float(&ds)[4]) {     // -> dZ_v = ds_v w_v (1 - H_v^2)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float h = tanh_fast(pv[c][r]);
+          pv[c][r] = ds[r] * wvr[2 * qc + c] * (1.0f - h * h);
+        }
+    };
+    auto aq_q = [&](const f32x4(&pv)[2], const int qc, const f32x4(&cc)[2]) {  // dP_q += C dZ_v
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) accq[tt][2 * qc + c] = mfma16(cc[tt][s], pv[c][s], accq[tt][2 * qc + c]);
+    };
+#define COATTN_INTERLEAVE14()                                      \
+  _Pragma("unroll") for (int g_ = 0; g_ < 14; ++g_) {              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             \
+    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);             \
+  }
+    load_q(0, 0, ring[0]);
+    load_q(0, 1, ring[1]);
+    for (int tile = 0; tile < ntiles; ++tile) {
+      // step 0: recompute quarter 0 of this tile; finish quarter 3 of the previous tile
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) ca_prev[tt] = ca[tt];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dsn_prev[r] = dsn[r];
+      load_q(tile, 2, ring[2]);
+      load_a(tile);
       __builtin_amdgcn_sched_barrier(0);
-      half_unit<true, 0, LD>(pvA, pq, wvr, accq, Cbuf, nb, j, q4, sv, dsn);
-      load_pv_half<0>(rs_pv, d, dsl, nb + 16, j, q4, pvA);
+      s3_q(ring[0], 0);
+      if (tile > 0) valu_q(ring[3], 3, dsn_prev);
+      COATTN_INTERLEAVE14();
       __builtin_amdgcn_sched_barrier(0);
-      half_unit<true, 1, LD>(pvB, pq, wvr, accq, Cbuf, nb, j, q4, sv, dsn);
+      if (tile > 0) aq_q(ring[3], 3, ca_prev);
+      // step 1
+      load_q(tile, 3, ring[3]);
+      __builtin_amdgcn_sched_barrier(0);
+      s3_q(ring[1], 1);
+      valu_q(ring[0], 0, dsn);
+      COATTN_INTERLEAVE14();
+      __builtin_amdgcn_sched_barrier(0);
+      aq_q(ring[0], 0, ca);
+      // step 2
+      load_q(tile + 1, 0, ring[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      s3_q(ring[2], 2);
+      valu_q(ring[1], 1, dsn);
+      COATTN_INTERLEAVE14();
+      __builtin_amdgcn_sched_barrier(0);
+      aq_q(ring[1], 1, ca);
+      // step 3
+      load_q(tile + 1, 1, ring[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      s3_q(ring[3], 3);
+      valu_q(ring[2], 2, dsn);
+      COATTN_INTERLEAVE14();
+      __builtin_amdgcn_sched_barrier(0);
+      aq_q(ring[2], 2, ca);
     }
+    if (ntiles > 0) {
+      valu_q(ring[3], 3, dsn);
+      aq_q(ring[3], 3, ca);
+    }
+#undef COATTN_INTERLEAVE14
   }
   // dP_q = dZ_q + acc ; db_q partial = sum_t dP_q[t][:].  Branch-free (rows >= T: loads 0, stores dropped)
   const __amdgpu_buffer_rsrc_t rs_dpq = make_rsrc(a.dPq + pair * (size_t)T * d, (unsigned)T * d * 4u);

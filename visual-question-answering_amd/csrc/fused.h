@@ -37,70 +37,6 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, int voff, i
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
-// ---- the [n][d]-oriented tile loop shared by the forward (phase 2) and the dP_q backward -------
-// A wave owns 128 channels = 8 channel tiles of 16; a 16-location tile of P_v is processed as two
-// half tiles of 4 channel tiles (16 VGPRs) so that the next half's loads fly under this half's MFMAs.
-// C/D layout of a tile: pv[c][r] = P_v[nb + 4*q4 + r][dsl + 16*(4H + c) + j].
-template <int H>
-__device__ __forceinline__ void load_pv_half(__amdgpu_buffer_rsrc_t rs_pv, int d, int dsl, int nb, int j, int q4,
-                                             f32x4 (&pv)[4]) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int voff = ((4 * q4 + r) * d + j) * 4;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) pv[c][r] = buf_load1(rs_pv, voff + 64 * (4 * H + c), (nb * d + dsl) * 4);
-  }
-}
-
-// forward (BWD = false):  accq += C . P_v ;  pv <- P_v + C^T P_q ;  sv[r] += tanh(pv) . w_v
-// backward (BWD = true):  pv <- P_v + C^T P_q ;  pv <- ds_v w_v (1 - tanh(pv)^2) = dZ_v ;  accq += C . dZ_v
-template <bool BWD, int H, int LD>
-__device__ __forceinline__ void half_unit(f32x4 (&pv)[4], const float (&pq)[kTS][8], const float (&wvr)[8],
-                                          f32x4 (&accq)[2][8], const float* Cbuf, int nb, int j, int q4,
-                                          float (&sv)[4], const float (&dsn)[4]) {
-  f32x4 ca[2];                                       // A = C rows t (contraction over n)
-#pragma unroll
-  for (int tt = 0; tt < 2; ++tt) {
-    const int t = min(16 * tt + j, kTRows - 1);
-    ca[tt] = *reinterpret_cast<const f32x4*>(&Cbuf[t * LD + nb + 4 * q4]);
-  }
-  float ct[kTS];                                     // A = C^T rows n (contraction over t)
-#pragma unroll
-  for (int s = 0; s < kTS; ++s) ct[s] = Cbuf[(4 * s + q4) * LD + nb + j];
-  if (!BWD) {
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) accq[tt][4 * H + c] = mfma16(ca[tt][s], pv[c][s], accq[tt][4 * H + c]);
-  }
-#pragma unroll
-  for (int s = 0; s < kTS; ++s)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) pv[c] = mfma16(ct[s], pq[s][4 * H + c], pv[c]);
-  if (!BWD) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sv[r] = fmaf(tanh_fast(pv[c][r]), wvr[4 * H + c], sv[r]);
-  } else {
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float h = tanh_fast(pv[c][r]);
-        pv[c][r] = dsn[r] * wvr[4 * H + c] * (1.0f - h * h);
-      }
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) accq[tt][4 * H + c] = mfma16(ca[tt][s], pv[c][s], accq[tt][4 * H + c]);
-  }
-}
-
 // XCD-aware block -> (b, l): blocks i and i+8 share an XCD (round-robin dispatch), so give the
 // L levels of one sample consecutive slots on one XCD.  Speed only; any mapping is correct.
 __device__ __forceinline__ bool block_to_pair(int bid, int B, int L, int& b, int& l) {

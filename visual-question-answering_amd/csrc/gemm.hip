@@ -28,7 +28,7 @@ struct GemmK {
   long c_sm, c_sn, c_sz, c_mdiv, c_sdiv;
   long cin_sm, cin_sn, cin_sz, cin_mdiv, cin_sdiv;
   const float* a_ptrs[8]; const float* b_ptrs[8]; float* c_ptrs[8]; const float* cin_ptrs[8];
-  int ptr_by_inner, b_imod;
+  int ptr_by_inner, b_imod, xcd_group;
 };
 
 __device__ __forceinline__ long row_off(long m, long sm, long mdiv, long sdiv) {
@@ -200,7 +200,26 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, z = blockIdx.z;
+  // XCD-aware tile order (speed only): workgroup ids i and i + 8 share an XCD and its L2, so the
+  // n-tiles of one m-tile (they read the same A panel) get ids equal mod 8 when there are many m-tiles.
+  int m0, n0, z;
+  {
+    const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
+    const int id = blockIdx.x, x = id & 7, slot = id >> 3;
+    if (!g.xcd_group) {                              // plain order: few m-tiles, nothing to group
+      const int per = ntm * ntn;
+      z = id / per;
+      const int t = id % per;
+      m0 = (t / ntn) * BM; n0 = (t % ntn) * BN;
+    } else {
+      const int per = ntn * ((ntm + 7) / 8);
+      z = slot / per;
+      const int t = slot % per;
+      const int mt = (t / ntn) * 8 + x;
+      m0 = mt * BM; n0 = (t % ntn) * BN;
+      if (mt >= ntm) return;
+    }
+  }
   int kbeg = 0, kend = g.K;
   if (g.ksplit > 0) {
     kbeg = z * g.ksplit;
@@ -400,7 +419,26 @@ __global__ __launch_bounds__(256) void gemm_bf16in_kernel(const GemmK g) {
   __shared__ __attribute__((aligned(16))) short Bs[BN * LDR];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, z = blockIdx.z;
+  // XCD-aware tile order (speed only): workgroup ids i and i + 8 share an XCD and its L2, so the
+  // n-tiles of one m-tile (they read the same A panel) get ids equal mod 8 when there are many m-tiles.
+  int m0, n0, z;
+  {
+    const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
+    const int id = blockIdx.x, x = id & 7, slot = id >> 3;
+    if (!g.xcd_group) {                              // plain order: few m-tiles, nothing to group
+      const int per = ntm * ntn;
+      z = id / per;
+      const int t = id % per;
+      m0 = (t / ntn) * BM; n0 = (t % ntn) * BN;
+    } else {
+      const int per = ntn * ((ntm + 7) / 8);
+      z = slot / per;
+      const int t = slot % per;
+      const int mt = (t / ntn) * 8 + x;
+      m0 = mt * BM; n0 = (t % ntn) * BN;
+      if (mt >= ntm) return;
+    }
+  }
   const int nsteps = (g.K + BK - 1) / BK;
   const float* Ab = g.a_ptrs[0] ? g.a_ptrs[z & 7] : g.A + (long)z * g.a_sz;
   const float* Bb = g.B + (long)z * g.b_sz;
@@ -563,14 +601,18 @@ int launch_gemm_f32(const coattn_gemm_desc& d, hipStream_t s) {
     const long wg128 = ntn * ((d.M + 127) / 128) * d.batch;
     const char* force = getenv("COATTN_GEMM_BM");
     const bool small_tiles = force ? atoi(force) == 64 : (wg128 > 768 && wg128 < 3 * 768);
+    const int bm = small_tiles ? 64 : 128;
+    const long ntm = (d.M + bm - 1) / bm;
+    g.xcd_group = ntm >= 32 ? 1 : 0;                 // (grouping the tiles of a split index instead measured slower)
+    const long nblk = g.xcd_group ? (long)d.batch * ntn * ((ntm + 7) / 8) * 8 : (long)d.batch * ntn * ntm;
+    CA_CHECK_ARG(nblk < 2147483647L, "gemm: grid too large");
+    dim3 grid((unsigned)nblk);
     if (small_tiles) {
-      dim3 grid((unsigned)ntn, (d.M + 63) / 64, d.batch);
       if (a_m && b_n) hipLaunchKernelGGL((gemm_f32_vec_kernel<true, true, 64>), grid, block, 0, s, g);
       else if (a_m) hipLaunchKernelGGL((gemm_f32_vec_kernel<true, false, 64>), grid, block, 0, s, g);
       else if (b_n) hipLaunchKernelGGL((gemm_f32_vec_kernel<false, true, 64>), grid, block, 0, s, g);
       else hipLaunchKernelGGL((gemm_f32_vec_kernel<false, false, 64>), grid, block, 0, s, g);
     } else {
-      dim3 grid((unsigned)ntn, (d.M + 127) / 128, d.batch);
       if (a_m && b_n) hipLaunchKernelGGL((gemm_f32_vec_kernel<true, true, 128>), grid, block, 0, s, g);
       else if (a_m) hipLaunchKernelGGL((gemm_f32_vec_kernel<true, false, 128>), grid, block, 0, s, g);
       else if (b_n) hipLaunchKernelGGL((gemm_f32_vec_kernel<false, true, 128>), grid, block, 0, s, g);
@@ -608,7 +650,9 @@ int launch_gemm_bf16in(const coattn_gemm_desc& d, hipStream_t s) {
   g.a_sm = d.a_sm; g.a_sk = d.a_sk; g.a_sz = d.a_sz; g.a_mdiv = d.a_mdiv; g.a_sdiv = d.a_sdiv;
   g.b_sk = d.b_sk; g.b_sn = d.b_sn; g.b_sz = d.b_sz;
   g.c_sm = d.c_sm; g.c_sn = d.c_sn; g.c_sz = d.c_sz; g.c_mdiv = d.c_mdiv; g.c_sdiv = d.c_sdiv;
-  dim3 grid((d.N + 127) / 128, (d.M + 127) / 128, d.batch), block(256);
+  const long ntn = (d.N + 127) / 128, ntm = (d.M + 127) / 128;
+  g.xcd_group = ntm >= 32 ? 1 : 0;
+  dim3 grid((unsigned)(g.xcd_group ? (long)d.batch * ntn * ((ntm + 7) / 8) * 8 : (long)d.batch * ntn * ntm)), block(256);
   const bool a_vec = al4(d.M) && al4(d.a_sk) && al4(d.a_mdiv) && al4(d.a_sdiv);
   if (a_m && a_vec) hipLaunchKernelGGL((gemm_bf16in_kernel<true, true>), grid, block, 0, s, g);
   else if (a_m) hipLaunchKernelGGL((gemm_bf16in_kernel<true, false>), grid, block, 0, s, g);

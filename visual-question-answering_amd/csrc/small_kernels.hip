@@ -182,6 +182,14 @@ __global__ __launch_bounds__(256) void add4_inplace_kernel(float* y, const float
   *yp = accumulate ? *yp + xv : xv;
 }
 
+// y += x1 + x2 (fixed order (y + x1) + x2), 16 bytes per thread
+__global__ __launch_bounds__(256) void add3_inplace_kernel(float* y, const float* x1, const float* x2, long n4) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n4) return;
+  f32x4* yp = reinterpret_cast<f32x4*>(y) + idx;
+  *yp = (*yp + reinterpret_cast<const f32x4*>(x1)[idx]) + reinterpret_cast<const f32x4*>(x2)[idx];
+}
+
 __global__ __launch_bounds__(256) void sum_all_kernel(const float* x, float* out, long n, int accumulate) {
   __shared__ float red[4];
   float acc = 0.f;
@@ -328,6 +336,16 @@ int launch_add_inplace(float* y, const float* x, int64_t n, int accumulate, hipS
                      accumulate);
   CA_CHECK_LAUNCH("add_inplace");
   return 0;
+}
+
+int launch_add3_inplace(float* y, const float* x1, const float* x2, int64_t n, hipStream_t s) {
+  if ((n & 3) == 0 && ((((uintptr_t)y) | ((uintptr_t)x1) | ((uintptr_t)x2)) & 15) == 0) {
+    hipLaunchKernelGGL(add3_inplace_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, y, x1, x2, (long)(n / 4));
+    CA_CHECK_LAUNCH("add3_inplace");
+    return 0;
+  }
+  CA_TRY(launch_add_inplace(y, x1, n, 1, s));
+  return launch_add_inplace(y, x2, n, 1, s);
 }
 
 int launch_rank1(const float* a, const float* g, float* out, int Z, int I, int J, int64_t o_sz, int64_t o_si,

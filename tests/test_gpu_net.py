@@ -87,3 +87,57 @@ def test_config5_bert_word_level_step():
     assert loss == loss and loss > 0
     assert torch.equal(w0, net.question_encoder.bert.word_embeddings.weight)      # frozen
     assert net.question_encoder.word_proj.weight.grad is not None
+
+
+def test_encoder_runahead_is_value_preserving():
+    """Trainer's run-ahead of the frozen image encoder (next batch's VGG forward on a second stream while
+    this step's work runs) must not change anything: same losses, parameters and BatchNorm running
+    statistics as the serial schedule over several different batches; and it must switch itself off
+    when the encoder is trainable."""
+    import copy
+    from vqa_amd import train as T
+    from vqa_amd.modules import HierarchicalCoAttentionNet
+    dev = torch.device("cuda:0")
+    qp = dict(vocab_size=60, word_emb_dim=512, hidden_dim=512)
+    torch.manual_seed(3)
+    net0 = HierarchicalCoAttentionNet(qp, dict(is_trainable=False, weights_path=None), K=11)
+    batches = []
+    for s in range(5):
+        b = T.synthetic_batch(6, (96, 96), 26, 60, 11, seed=50 + s)
+        image, question, label, lens = T.sort_batch(b["image"], b["question"], b["label"], b["ques_len"])
+        batches.append((image.to(dev), question.to(dev), lens, label.to(dev)))
+    runs = {}
+    for ahead in (False, True):
+        net = copy.deepcopy(net0).to(dev)
+        tr = T.Trainer(net, 1e-3, dev, encoder_runahead=ahead)
+        assert tr.runahead == ahead
+        losses = []
+        for i, bt in enumerate(batches):
+            nxt = batches[i + 1][0] if i + 1 < len(batches) else None
+            losses.append(float(tr.step(*bt, next_image=nxt).detach()))
+        torch.cuda.synchronize()
+        runs[ahead] = (losses, {k: v.detach().cpu() for k, v in net.state_dict().items()})
+    print("losses", runs[False][0], runs[True][0])
+    # the stock embedding / LSTM backward kernels use atomics: two SERIAL runs already differ by ~1e-7
+    # relative (and MIOpen's convolutions are not bit-reproducible run to run either), so trajectories,
+    # BatchNorm buffers and features are compared to 1e-5; a schedule bug (features consumed before
+    # the encoder stream produced them, buffers updated out of order) would be off by O(1)
+    assert np.allclose(runs[False][0], runs[True][0], rtol=1e-5, atol=0)
+    for k, v in runs[False][1].items():
+        if k.startswith("image_encoder."):
+            assert torch.allclose(v.float(), runs[True][1][k].float(), rtol=1e-5, atol=1e-6), k
+        else:
+            assert torch.allclose(v, runs[True][1][k], atol=5e-3), k        # Adam, lr 1e-3, 5 steps
+    # features handed over from the encoder stream == features computed inline
+    net = copy.deepcopy(net0).to(dev)
+    ref = copy.deepcopy(net)
+    tr = T.Trainer(net, 1e-3, dev)
+    img = batches[0][0]
+    tr._encode_ahead(img)
+    ahead_feats = tr._image_features(img)
+    with torch.no_grad():
+        inline = ref.image_encoder(img)
+    assert ahead_feats.shape == inline.shape and ahead_feats.stride() == inline.stride()
+    assert torch.allclose(ahead_feats, inline, rtol=1e-5, atol=1e-6)
+    net = HierarchicalCoAttentionNet(qp, dict(is_trainable=True, weights_path=None), K=11).to(dev)
+    assert not T.Trainer(net, 1e-3, dev).runahead

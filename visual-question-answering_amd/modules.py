@@ -243,8 +243,12 @@ class HierarchicalCoAttentionNet(nn.Module):
         self.mlp_classify = MLPClassifier(self.hidden_dim, mlp_dim, K)
 
     def forward(self, x_img, x_ques, x_ques_lens):
+        return self.forward_features(self.image_encoder(x_img), x_ques, x_ques_lens)
+
+    def forward_features(self, x_img_features, x_ques, x_ques_lens):
+        """The forward pass from already-encoded image features [B,N,d] (model.py:171-187 minus the
+        image encoder call): lets a frozen encoder run ahead on its own stream (train.Trainer)."""
         x_ques_features = list(self.question_encoder(x_ques, x_ques_lens))
-        x_img_features = self.image_encoder(x_img)
         x_img_attn, x_ques_attn = self.co_attention(x_img_features, x_ques_features)
         return self.mlp_classify(x_img_attn, x_ques_attn)
 

@@ -11,6 +11,7 @@ Run:  python -m torch.distributed.run --nproc-per-node N -m vqa_amd.train --synt
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import time
@@ -106,6 +107,7 @@ class DevicePrefetcher:
         self.stream = torch.cuda.Stream(device) if device.type == "cuda" else None
         self.pinned = {}
         self.next = None
+        self._copied = None
         self._fetch()
 
     def _pin(self, name, t):
@@ -125,6 +127,8 @@ class DevicePrefetcher:
         if self.stream is None:
             self.next = (image, question, ques_len, label, None)
             return
+        if self._copied is not None:
+            self._copied.synchronize()                           # the pinned buffers are free again
         with torch.cuda.stream(self.stream):
             im = self._pin("image", image).to(self.device, non_blocking=True)
             if self.cl:
@@ -133,28 +137,52 @@ class DevicePrefetcher:
             la = self._pin("label", label).to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.stream)
+        self._copied = ev
         self.next = (im, qu, ques_len, la, ev)
 
     def __iter__(self):
         return self
 
-    def __next__(self):
-        if self.next is None:
-            raise StopIteration
+    def _claim(self):
+        """Make the staged batch usable from the current stream (once)."""
         im, qu, ln, la, ev = self.next
         if ev is not None:
             torch.cuda.current_stream(self.device).wait_event(ev)
             for t in (im, qu, la):
                 t.record_stream(torch.cuda.current_stream(self.device))
+            self.next = (im, qu, ln, la, None)
+
+    def peek_image(self):
+        """Image tensor of the batch the next __next__ will return (None at the end); the current
+        stream is made to wait for its copy, so the caller may queue work on it right away."""
+        if self.next is None:
+            return None
+        self._claim()
+        return self.next[0]
+
+    def __next__(self):
+        if self.next is None:
+            raise StopIteration
+        self._claim()
+        im, qu, ln, la, _ = self.next
         self._fetch()
         return im, qu, ln, la
 
 
 class Trainer:
-    """Owns model, Adam (lr, PyTorch defaults: main.py:180), loss and the gradient reducer."""
+    """Owns model, Adam (lr, PyTorch defaults: main.py:180), loss and the gradient reducer.
+
+    Encoder run-ahead: when the image encoder is frozen (the reference default, main.py:67 /
+    model.py:239-241) its output does not depend on the optimiser state, so ``step(...,
+    next_image=...)`` launches the stock encoder for the NEXT batch on a second, high-priority HIP
+    stream before it queues this step's own work.  The long MIOpen convolutions then overlap the
+    many short, latency-bound kernels of the question encoder / co-attention / MLP / backward / Adam
+    (and the RCCL all-reduce) instead of running in series with them.  Values are unchanged: the same
+    modules see the same tensors, BatchNorm running statistics are updated in batch order on that
+    stream."""
 
     def __init__(self, model: nn.Module, lr: float = 1e-4, device=None, opt_lvl: int = 0,
-                 bucket_mb: float = 16.0):
+                 bucket_mb: float = 16.0, encoder_runahead: bool = True):
         self.device = device or next(model.parameters()).device
         self.model = model
         self.criterion = nn.CrossEntropyLoss()
@@ -163,14 +191,53 @@ class Trainer:
         if opt_lvl > 0 and hasattr(model, "co_attention"):      # AMP: projections on the bf16 MFMA as well
             model.co_attention.bf16_projections = True
         self.reducer = vdist.GradReducer(model, bucket_mb=bucket_mb) if vdist.world_size() > 1 else None
+        enc = getattr(model, "image_encoder", None)
+        self.runahead = bool(encoder_runahead and self.device.type == "cuda" and enc is not None
+                             and hasattr(model, "forward_features")
+                             and not any(p.requires_grad for p in enc.parameters()))
+        self.enc_stream = torch.cuda.Stream(self.device, priority=-1) if self.runahead else None
+        self._ahead = None                                       # (image, features, event) of the next batch
 
-    def step(self, image, question, ques_len, label) -> torch.Tensor:
-        """One optimisation step on device-resident, length-sorted tensors; returns the loss."""
+    def _autocast(self):
         if self.opt_lvl > 0 and self.device.type == "cuda":
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                logits = self.model(image, question, ques_len)
+            return torch.autocast("cuda", dtype=torch.bfloat16)
+        return contextlib.nullcontext()
+
+    def _encode_ahead(self, image):
+        """Queue the frozen image encoder for `image` on the encoder stream."""
+        main = torch.cuda.current_stream(self.device)
+        self.enc_stream.wait_stream(main)                        # `image` (and the previous step) is ready
+        with torch.cuda.stream(self.enc_stream), torch.no_grad(), self._autocast():
+            feats = self.model.image_encoder(image)
+            ev = torch.cuda.Event()
+            ev.record(self.enc_stream)
+        image.record_stream(self.enc_stream)
+        self._ahead = (image, feats, ev)
+
+    def _image_features(self, image):
+        if self._ahead is not None and self._ahead[0] is image:
+            _, feats, ev = self._ahead
+            self._ahead = None
+            main = torch.cuda.current_stream(self.device)
+            main.wait_event(ev)
+            feats.record_stream(main)
+            return feats
+        self._ahead = None
+        with torch.no_grad():
+            return self.model.image_encoder(image)
+
+    def step(self, image, question, ques_len, label, next_image=None) -> torch.Tensor:
+        """One optimisation step on device-resident, length-sorted tensors; returns the loss.
+        `next_image`: the following step's image batch (device-resident), if known."""
+        if self.runahead:
+            with self._autocast():
+                feats = self._image_features(image)
+                if next_image is not None:
+                    self._encode_ahead(next_image)
+                logits = self.model.forward_features(feats, question, ques_len)
         else:
-            logits = self.model(image, question, ques_len)
+            with self._autocast():
+                logits = self.model(image, question, ques_len)
         loss = self.criterion(logits.float(), label)
         self.optimizer.zero_grad()
         if self.reducer is not None:
@@ -246,8 +313,9 @@ def main(argv=None):
             yield image, question, ques_len, label
 
     t0 = time.time()
-    for step, (image, question, ques_len, label) in enumerate(DevicePrefetcher(host_batches(), device, cl)):
-        loss = trainer.step(image, question, ques_len, label)
+    batches = DevicePrefetcher(host_batches(), device, cl)
+    for step, (image, question, ques_len, label) in enumerate(batches):
+        loss = trainer.step(image, question, ques_len, label, next_image=batches.peek_image())
         if (step + 1) % args.log_interval == 0 and rank == 0:
             print(json.dumps({"step": step + 1, "loss": round(float(loss), 5),
                               "pairs_per_s": round(world * args.batch_size * (step + 1) / (time.time() - t0), 2)}))

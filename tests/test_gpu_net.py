@@ -133,8 +133,7 @@ def test_encoder_runahead_is_value_preserving():
     ref = copy.deepcopy(net)
     tr = T.Trainer(net, 1e-3, dev)
     img = batches[0][0]
-    tr._encode_ahead(img)
-    ahead_feats = tr._image_features(img)
+    ahead_feats = tr._claim(tr._queue_encoder(img))
     with torch.no_grad():
         inline = ref.image_encoder(img)
     assert ahead_feats.shape == inline.shape and ahead_feats.stride() == inline.stride()

@@ -247,8 +247,11 @@ class HierarchicalCoAttentionNet(nn.Module):
 
     def forward_features(self, x_img_features, x_ques, x_ques_lens):
         """The forward pass from already-encoded image features [B,N,d] (model.py:171-187 minus the
-        image encoder call): lets a frozen encoder run ahead on its own stream (train.Trainer)."""
+        image encoder call): lets a frozen encoder run ahead on its own stream (train.Trainer).
+        `x_img_features` may be a zero-argument callable returning the features."""
         x_ques_features = list(self.question_encoder(x_ques, x_ques_lens))
+        if callable(x_img_features):            # resolved only now: the question side is queued first
+            x_img_features = x_img_features()
         x_img_attn, x_ques_attn = self.co_attention(x_img_features, x_ques_features)
         return self.mlp_classify(x_img_attn, x_ques_attn)
 

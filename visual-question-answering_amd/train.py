@@ -144,21 +144,19 @@ class DevicePrefetcher:
         return self
 
     def _claim(self):
-        """Make the staged batch usable from the current stream (once)."""
+        """Make the staged batch usable from the current stream."""
         im, qu, ln, la, ev = self.next
         if ev is not None:
             torch.cuda.current_stream(self.device).wait_event(ev)
             for t in (im, qu, la):
                 t.record_stream(torch.cuda.current_stream(self.device))
-            self.next = (im, qu, ln, la, None)
 
     def peek_image(self):
-        """Image tensor of the batch the next __next__ will return (None at the end); the current
-        stream is made to wait for its copy, so the caller may queue work on it right away."""
+        """(image, copy-done event) of the batch the next __next__ will return, (None, None) at the
+        end: lets the consumer queue work on that image on another stream behind the event."""
         if self.next is None:
-            return None
-        self._claim()
-        return self.next[0]
+            return None, None
+        return self.next[0], self.next[4]
 
     def __next__(self):
         if self.next is None:
@@ -195,46 +193,58 @@ class Trainer:
         self.runahead = bool(encoder_runahead and self.device.type == "cuda" and enc is not None
                              and hasattr(model, "forward_features")
                              and not any(p.requires_grad for p in enc.parameters()))
-        self.enc_stream = torch.cuda.Stream(self.device, priority=-1) if self.runahead else None
+        self.enc_stream = (torch.cuda.Stream(self.device, priority=int(os.environ.get("VQA_ENC_PRIORITY", "-1")))
+                           if self.runahead else None)
         self._ahead = None                                       # (image, features, event) of the next batch
+        self._resident = None                                    # last image batch consumed on the device
 
     def _autocast(self):
         if self.opt_lvl > 0 and self.device.type == "cuda":
             return torch.autocast("cuda", dtype=torch.bfloat16)
         return contextlib.nullcontext()
 
-    def _encode_ahead(self, image):
-        """Queue the frozen image encoder for `image` on the encoder stream."""
-        main = torch.cuda.current_stream(self.device)
-        self.enc_stream.wait_stream(main)                        # `image` (and the previous step) is ready
+    def _queue_encoder(self, image, ready=None):
+        """Queue the frozen image encoder for `image` on the encoder stream; returns (image, features,
+        done-event).  `ready`: event after which `image` is valid (None: valid once the work queued on
+        the current stream so far is done; nothing to wait for if the batch is the one just consumed).
+        The encoder stream takes no other dependency on the step, so consecutive passes run back to back."""
+        if ready is not None:
+            self.enc_stream.wait_event(ready)
+        elif image is not self._resident:
+            self.enc_stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.enc_stream), torch.no_grad(), self._autocast():
             feats = self.model.image_encoder(image)
             ev = torch.cuda.Event()
             ev.record(self.enc_stream)
         image.record_stream(self.enc_stream)
-        self._ahead = (image, feats, ev)
+        return image, feats, ev
 
-    def _image_features(self, image):
-        if self._ahead is not None and self._ahead[0] is image:
-            _, feats, ev = self._ahead
-            self._ahead = None
-            main = torch.cuda.current_stream(self.device)
-            main.wait_event(ev)
-            feats.record_stream(main)
-            return feats
-        self._ahead = None
-        with torch.no_grad():
-            return self.model.image_encoder(image)
+    def _claim(self, queued):
+        """Hand features queued on the encoder stream to the current stream (which waits for them here)."""
+        _, feats, ev = queued
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(ev)
+        feats.record_stream(main)
+        return feats
 
-    def step(self, image, question, ques_len, label, next_image=None) -> torch.Tensor:
+    def step(self, image, question, ques_len, label, next_image=None, next_ready=None) -> torch.Tensor:
         """One optimisation step on device-resident, length-sorted tensors; returns the loss.
-        `next_image`: the following step's image batch (device-resident), if known."""
+        `next_image`: the following step's image batch (device-resident), if known; `next_ready`: the
+        event that marks its host->device copy complete (DevicePrefetcher.peek_image)."""
         if self.runahead:
             with self._autocast():
-                feats = self._image_features(image)
+                mine, self._ahead = self._ahead, None
+                if mine is not None and mine[0] is not image:
+                    mine = None                                  # queued for some other batch: drop it
+                if mine is None:
+                    with torch.no_grad():
+                        inline = self.model.image_encoder(image)
+                self._resident = image
                 if next_image is not None:
-                    self._encode_ahead(next_image)
-                logits = self.model.forward_features(feats, question, ques_len)
+                    self._ahead = self._queue_encoder(next_image, next_ready)
+                # the question side is queued before the current stream waits for the image features
+                logits = self.model.forward_features((lambda: self._claim(mine)) if mine is not None else inline,
+                                                     question, ques_len)
         else:
             with self._autocast():
                 logits = self.model(image, question, ques_len)
@@ -315,7 +325,8 @@ def main(argv=None):
     t0 = time.time()
     batches = DevicePrefetcher(host_batches(), device, cl)
     for step, (image, question, ques_len, label) in enumerate(batches):
-        loss = trainer.step(image, question, ques_len, label, next_image=batches.peek_image())
+        nxt, ready = batches.peek_image()
+        loss = trainer.step(image, question, ques_len, label, next_image=nxt, next_ready=ready)
         if (step + 1) % args.log_interval == 0 and rank == 0:
             print(json.dumps({"step": step + 1, "loss": round(float(loss), 5),
                               "pairs_per_s": round(world * args.batch_size * (step + 1) / (time.time() - t0), 2)}))

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Copy the summaries produced by tools/refresh_profiles.sh (gpurun_out/refresh/) into profiles/.
+
+usage: tools/collect_profiles.py [round-tag, default r01]
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "refresh")
+DST = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+
+def one(pattern):
+    hits = glob.glob(os.path.join(SRC, pattern), recursive=True)
+    if not hits:
+        raise SystemExit("missing " + pattern)
+    return hits[0]
+
+
+line = [l for l in open(os.path.join(SRC, "bench.json")) if l.startswith("{")][-1]
+json.loads(line)
+open(os.path.join(DST, "%s_bench.json" % tag), "w").write(line)
+for leg, name in (("roofline", "roofline"), ("hot", "hot_path"), ("step", "full_step")):
+    shutil.copy(one("%s/**/*kernel_stats.csv" % leg), os.path.join(DST, "%s_%s_kernel_stats.csv" % (tag, name)))
+shutil.copy(os.path.join(SRC, "pmc_traffic.json"), os.path.join(DST, "pmc_traffic.json"))
+
+# MFMA-busy pass: mean counter value per kernel, and MFMA busy fraction = MFMA_BUSY / (32 * SQ_BUSY)
+vals = {}
+for f in glob.glob(os.path.join(SRC, "pmc_mfma", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        kern = "coattn_attn_fwd_kernel" if "attn_fwd" in k else ("attend_v_kernel" if "attend_v" in k else None)
+        if kern:
+            vals.setdefault(kern, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+if vals:
+    out = {}
+    for kern, cs in vals.items():
+        m = {c: sum(v) / len(v) for c, v in cs.items()}
+        if m.get("SQ_BUSY_CYCLES") and "SQ_VALU_MFMA_BUSY_CYCLES" in m:
+            m["derived_mfma_busy_frac"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (32.0 * m["SQ_BUSY_CYCLES"])
+        out[kern] = m
+    json.dump(out, open(os.path.join(DST, "%s_pmc_mfma.json" % tag), "w"), indent=1)
+print("profiles/ refreshed from", SRC)
+print(line[:400])

@@ -31,3 +31,21 @@ run("dW_v", dict(A=Pv, B=V, C=part, M=d, N=d, K=N, batch=S, inner=G, inner_total
 K = 3 * B * T; ks = (K // 32 + 15) // 16 * 16; S2 = (K + ks - 1) // ks
 part2 = torch.empty(S2, d, d, device=dev)
 run("dW_q", dict(A=Pq, B=Q, C=part2, M=d, N=d, K=K, batch=S2, ksplit=ks, a_sm=1, a_sk=d, b_sk=d, b_sn=1, c_sm=d, c_sn=1, c_sz=d*d), 2.0*K*d*d)
+# practical ceiling: the vendor library's fp32 GEMM on the same shapes (contiguous operands)
+def tref(name, fn, flop, iters=30):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / iters * 1e-3
+    print("%-22s %8.1f us  %6.1f TFLOP/s" % (name, t * 1e6, flop / t / 1e12))
+X = torch.randn(B * N, d, device=dev); out = torch.empty(B * N, d, device=dev)
+tref("torch P_v-shape NT", lambda: torch.mm(X, W.t(), out=out), 2.0*B*N*d*d)
+tref("torch P_v-shape NN", lambda: torch.mm(X, W, out=out), 2.0*B*N*d*d)
+Xt = torch.randn(d, B * N, device=dev); o2 = torch.empty(d, d, device=dev)
+tref("torch dW_v-shape TN", lambda: torch.mm(Xt, X, out=o2), 2.0*B*N*d*d)
+A4 = torch.randn(4096, 4096, device=dev); B4 = torch.randn(4096, 4096, device=dev); o4 = torch.empty(4096, 4096, device=dev)
+tref("torch 4096^3", lambda: torch.mm(A4, B4, out=o4), 2.0*4096**3)
+Vb = torch.randn(B, d, N, device=dev); ob = torch.empty(B, N, d, device=dev)
+tref("torch bmm V^T.W^T (in place layout)", lambda: torch.matmul(Vb.transpose(1, 2), W.t(), out=ob), 2.0*B*N*d*d)

@@ -103,6 +103,35 @@ int coattn_backward(const void* V, const void* const* Q, const coattn_params* p,
                     void* dV, void* const* dQ, const coattn_param_grads* pg, int accumulate,
                     void* ws, int B, int N, int T, int d, int L, int dtype, int flags, void* stream);
 
+/* ---- PhraseConvPool: the question hierarchy's phrase level ----------------
+ * Replaces reference model.py:301-334 (`PhraseConvPool.forward`: 1/2/3-gram Conv1d + Tanh with
+ * ConstantPad1d (0,0) / (1,0) / (1,1), concatenated along channels, then MaxPool2d((1,3)) over
+ * groups of 3 CONSECUTIVE channels) and its autograd.  Weights in torch Conv1d layout
+ * [E_out][E_in][k] (state_dict keys conv_unigram.1.*, conv_bigram.1.*, conv_trigram.1.*). */
+typedef struct coattn_phrase_params {
+  const void* W1; const void* b1;   /* [E,E,1], [E] */
+  const void* W2; const void* b2;   /* [E,E,2], [E] */
+  const void* W3; const void* b3;   /* [E,E,3], [E] */
+} coattn_phrase_params;
+
+typedef struct coattn_phrase_param_grads {
+  void* dW1; void* db1; void* dW2; void* db2; void* dW3; void* db3;
+} coattn_phrase_param_grads;
+
+/* saved: forward -> backward state (argmax index per output element); ws_*: scratch. */
+int coattn_phrase_workspace_bytes(int B, int T, int E, int dtype, size_t* saved, size_t* ws_fwd, size_t* ws_bwd);
+
+/* X [B,T,E] (rows past a question's length are zeros, as the embedding delivers them) -> out [B,T,E].
+ * saved may be NULL for inference. */
+int coattn_phrase_forward(const void* X, const coattn_phrase_params* p, void* out, void* saved, void* ws,
+                          int B, int T, int E, int dtype, void* stream);
+
+/* g_out [B,T,E] -> dX [B,T,E] (overwritten; NULL to skip) and the six parameter gradients
+ * (accumulate = 0 overwrites, 1 adds).  `out` is the forward's output. */
+int coattn_phrase_backward(const void* X, const coattn_phrase_params* p, const void* out, const void* saved,
+                           const void* g_out, void* dX, const coattn_phrase_param_grads* pg, int accumulate,
+                           void* ws, int B, int T, int E, int dtype, void* stream);
+
 /* ---- building blocks (exported for the per-kernel parity tests) ------------------------ */
 
 /* Strided, batched fp32 GEMM on the f32 MFMA:
@@ -113,7 +142,9 @@ int coattn_backward(const void* V, const void* const* Q, const coattn_params* p,
  * inner_total > 0: z is a group of `inner` consecutive inner indices ig = z*inner + i < inner_total.
  * Pointer tables (level-merged launches; NULL entries = unused): a_ptrs/b_ptrs/c_ptrs/cin_ptrs[t]
  * replace A/B/C/Cin with t = z (ptr_by_inner = 0) or t = ig (ptr_by_inner = 1).
- * b_imod > 0: the inner stride of B wraps, B[ig] = B + (ig % b_imod) * b_si. */
+ * b_imod > 0: the inner stride of B wraps, B[ig] = B + (ig % b_imod) * b_si.
+ * kband_n > 0 (multiple of 128, at most 3 bands): columns [j*kband_n, (j+1)*kband_n) contract only
+ * over k in [kband_lo[j], kband_hi[j]) -- block-sparse B operands (n-gram taps of phrase.hip). */
 typedef struct coattn_gemm_desc {
   const void* A; const void* B; const void* Cin; void* C;
   const void* bias_n; const void* bias_m;
@@ -125,6 +156,7 @@ typedef struct coattn_gemm_desc {
   int64_t cin_sm, cin_sn, cin_sz, cin_mdiv, cin_sdiv;
   const void* a_ptrs[8]; const void* b_ptrs[8]; void* c_ptrs[8]; const void* cin_ptrs[8];
   int ptr_by_inner; int b_imod;
+  int kband_n; int kband_lo[3]; int kband_hi[3];
 } coattn_gemm_desc;
 
 int coattn_gemm_f32(const coattn_gemm_desc* g, void* stream);

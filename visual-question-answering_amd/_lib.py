@@ -11,7 +11,8 @@ CSRC = os.path.join(_HERE, "csrc")
 
 # every symbol include/coattn.h declares
 EXPORTS = ("coattn_version", "coattn_last_error", "coattn_fused_supported", "coattn_workspace_bytes",
-           "coattn_forward", "coattn_attention_forward", "coattn_backward", "coattn_gemm_f32")
+           "coattn_forward", "coattn_attention_forward", "coattn_backward", "coattn_gemm_f32",
+           "coattn_phrase_workspace_bytes", "coattn_phrase_forward", "coattn_phrase_backward")
 
 F32 = 0
 IMPL_AUTO, IMPL_GENERAL, IMPL_FUSED = 0, 1, 2
@@ -26,6 +27,14 @@ class ParamGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("dW_v", "db_v", "dW_q", "db_q", "dw_v", "dc_v", "dw_q", "dc_q")]
 
 
+class PhraseParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("W1", "b1", "W2", "b2", "W3", "b3")]
+
+
+class PhraseParamGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("dW1", "db1", "dW2", "db2", "dW3", "db3")]
+
+
 class GemmDesc(C.Structure):
     _fields_ = ([(n, C.c_void_p) for n in ("A", "B", "Cin", "C", "bias_n", "bias_m")]
                 + [(n, C.c_int) for n in ("M", "N", "K", "batch", "inner", "inner_total", "ksplit", "act")]
@@ -35,7 +44,8 @@ class GemmDesc(C.Structure):
                                             "c_sm", "c_sn", "c_sz", "c_mdiv", "c_sdiv",
                                             "cin_sm", "cin_sn", "cin_sz", "cin_mdiv", "cin_sdiv")]
                 + [("a_ptrs", C.c_void_p * 8), ("b_ptrs", C.c_void_p * 8), ("c_ptrs", C.c_void_p * 8),
-                   ("cin_ptrs", C.c_void_p * 8), ("ptr_by_inner", C.c_int), ("b_imod", C.c_int)])
+                   ("cin_ptrs", C.c_void_p * 8), ("ptr_by_inner", C.c_int), ("b_imod", C.c_int),
+                   ("kband_n", C.c_int), ("kband_lo", C.c_int * 3), ("kband_hi", C.c_int * 3)])
 
 
 def build(verbose: bool = False) -> str:
@@ -76,6 +86,12 @@ def load() -> C.CDLL:
                                     C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(ParamGrads), C.c_int,
                                     C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]
     lib.coattn_gemm_f32.argtypes = [C.POINTER(GemmDesc), C.c_void_p]
+    lib.coattn_phrase_workspace_bytes.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_size_t)] * 3
+    lib.coattn_phrase_forward.argtypes = [C.c_void_p, C.POINTER(PhraseParams), C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.coattn_phrase_backward.argtypes = [C.c_void_p, C.POINTER(PhraseParams), C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.POINTER(PhraseParamGrads), C.c_int, C.c_void_p,
+                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     _lib = lib
     return lib
 

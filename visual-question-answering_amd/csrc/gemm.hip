@@ -29,6 +29,7 @@ struct GemmK {
   long cin_sm, cin_sn, cin_sz, cin_mdiv, cin_sdiv;
   const float* a_ptrs[8]; const float* b_ptrs[8]; float* c_ptrs[8]; const float* cin_ptrs[8];
   int ptr_by_inner, b_imod, xcd_group;
+  int kband_n, kband_lo[3], kband_hi[3];
 };
 
 __device__ __forceinline__ long row_off(long m, long sm, long mdiv, long sdiv) {
@@ -56,6 +57,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmK g) {
   if (g.ksplit > 0) {
     kbeg = z * g.ksplit;
     kend = min(g.K, kbeg + g.ksplit);
+  }
+  if (g.kband_n > 0) {                              // columns [j*kband_n, (j+1)*kband_n) contract over a sub-range of k
+    const int band = n0 / g.kband_n;
+    kbeg = max(kbeg, g.kband_lo[band]);
+    kend = min(kend, g.kband_hi[band]);
   }
   int ninner = g.inner;
   if (g.inner_total > 0) ninner = max(0, min(g.inner, g.inner_total - z * g.inner));
@@ -224,6 +230,11 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
   if (g.ksplit > 0) {
     kbeg = z * g.ksplit;
     kend = min(g.K, kbeg + g.ksplit);
+  }
+  if (g.kband_n > 0) {                              // columns [j*kband_n, (j+1)*kband_n) contract over a sub-range of k
+    const int band = n0 / g.kband_n;
+    kbeg = max(kbeg, g.kband_lo[band]);
+    kend = min(kend, g.kband_hi[band]);
   }
   int ninner = g.inner;
   if (g.inner_total > 0) ninner = max(0, min(g.inner, g.inner_total - z * g.inner));
@@ -567,6 +578,15 @@ int launch_gemm_f32(const coattn_gemm_desc& d, hipStream_t s) {
     g.c_ptrs[t] = (float*)d.c_ptrs[t]; g.cin_ptrs[t] = (const float*)d.cin_ptrs[t];
   }
   g.ptr_by_inner = d.ptr_by_inner; g.b_imod = d.b_imod;
+  g.kband_n = d.kband_n;
+  if (d.kband_n > 0) {
+    CA_CHECK_ARG(d.kband_n % 128 == 0 && (d.N + d.kband_n - 1) / d.kband_n <= 3, "gemm: kband_n must be a multiple of 128 with at most 3 bands");
+    for (int t = 0; t < 3; ++t) {
+      CA_CHECK_ARG(d.kband_lo[t] >= 0 && d.kband_hi[t] <= d.K && (d.kband_lo[t] & 3) == 0 && (d.kband_hi[t] & 3) == 0,
+                   "gemm: k bands must lie in [0,K] and be multiples of 4");
+      g.kband_lo[t] = d.kband_lo[t]; g.kband_hi[t] = d.kband_hi[t];
+    }
+  }
   CA_CHECK_ARG(!(d.a_ptrs[0] || d.b_ptrs[0] || d.c_ptrs[0] || d.cin_ptrs[0]) ||
                    (d.ptr_by_inner ? (d.inner_total > 0 ? d.inner_total : d.inner) : d.batch) <= 8,
                "gemm: pointer tables hold at most 8 entries");

@@ -145,6 +145,11 @@ class PhraseConvPool(nn.Module):
         self.max_pool = nn.MaxPool2d(kernel_size=(1, 3))
 
     def forward(self, x_question):
+        if x_question.is_cuda and os.environ.get("VQA_PHRASE_IMPL", "hip") != "stock":
+            # MI355X path (csrc/phrase.hip): same parameters, same values; stock modules below on CPU
+            from .phrase import phrase_conv_pool
+            u, b, t = self.conv_unigram[1], self.conv_bigram[1], self.conv_trigram[1]
+            return phrase_conv_pool(x_question, u.weight, u.bias, b.weight, b.bias, t.weight, t.bias)
         B, T, E = x_question.shape
         x = x_question.permute(0, 2, 1)                                          # [B, E, T]
         grams = torch.cat([self.conv_unigram(x), self.conv_bigram(x), self.conv_trigram(x)], dim=1)

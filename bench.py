@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--no-runahead", dest="runahead", action="store_false",
                     help="run the frozen image encoder in series with the rest of the step (default: one step "
                          "ahead on its own HIP stream)")
+    ap.add_argument("--stock-graph", action="store_true",
+                    help="run the frozen encoder's Sequential as is (default: ReLU/MaxPool swap and conv bias folded "
+                         "into BatchNorm's running mean, modules.run_conv_bn_stack; same stock kernels, same values)")
     ap.add_argument("--nchw", dest="channels_last", action="store_false",
                     help="keep the stock VGG encoder in NCHW (default: channels_last, MIOpen NHWC kernels, ~25 %% "
                          "faster forward; its first call tunes for up to a minute)")
@@ -230,6 +233,8 @@ def cpu_baseline_leg(args):
 
 def main():
     args = parse()
+    if args.stock_graph:
+        os.environ["VQA_ENCODER_REWRITE"] = "0"
     import vqa_amd
     from vqa_amd import dist as vdist
     from vqa_amd import train as T
@@ -278,7 +283,8 @@ def main():
                                    % (" + RCCL grad all-reduce" if world > 1 else "", args.num_cls, args.batch,
                                       args.image_size, args.image_size, n_grid, args.seq_len, args.vocab,
                                       "channels_last" if args.channels_last else "NCHW",
-                                      ", encoder one step ahead on its own stream" if trainer.runahead else ""),
+                                      (", encoder one step ahead on its own stream" if trainer.runahead else "")
+                                      + ("" if args.stock_graph else ", ReLU after MaxPool, conv bias folded into BN running mean")),
                        "untimed_prime_steps": PRIME_STEPS,
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                        "coattn_impl": "fused" if vqa_amd._lib.load().coattn_fused_supported(

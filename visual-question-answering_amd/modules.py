@@ -61,6 +61,45 @@ def _load_vgg_weights(features: nn.Module, classifier: nn.Module | None, weights
     return True
 
 
+def run_conv_bn_stack(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    """Runs a Conv2d / BatchNorm2d / ReLU / MaxPool2d ``Sequential`` (the VGG ``features``) with the
+    same stock kernels but two value-preserving graph rewrites that save whole elementwise passes
+    over the largest activations:
+
+    * ``MaxPool2d(ReLU(x)) == ReLU(MaxPool2d(x))`` exactly (both are monotonic): the ReLU runs on the
+      4x smaller pooled tensor.
+    * A frozen Conv2d bias in front of a BatchNorm2d that normalises with BATCH statistics (train
+      mode -- the reference never calls ``.eval()`` on its frozen VGG, model.py:239-241) cancels in
+      ``(y + b) - mean(y + b)``: the convolution is issued without bias (saves the separate
+      broadcast-add kernel) and ``momentum * b`` is added to ``running_mean`` instead, which is the
+      only place the bias survives (running_var is shift-invariant).  Outputs differ from the plain
+      graph by fp32 rounding only (tests/test_net_cpu.py).
+
+    Anything that does not match these patterns (eval-mode BatchNorm, trainable bias, other modules)
+    is executed as is.  ``VQA_ENCODER_REWRITE=0`` disables both rewrites."""
+    mods = list(seq)
+    if os.environ.get("VQA_ENCODER_REWRITE", "1") == "0":
+        return seq(x)
+    i, n = 0, len(mods)
+    while i < n:
+        m = mods[i]
+        nxt = mods[i + 1] if i + 1 < n else None
+        if (isinstance(m, nn.Conv2d) and m.bias is not None and not m.bias.requires_grad and m.padding_mode == "zeros"
+                and isinstance(nxt, nn.BatchNorm2d) and nxt.training and nxt.momentum is not None):
+            x = nxt(F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups))
+            if nxt.track_running_stats and nxt.running_mean is not None:
+                with torch.no_grad():
+                    nxt.running_mean.add_(m.bias.to(nxt.running_mean.dtype), alpha=nxt.momentum)
+            i += 2
+        elif isinstance(m, nn.ReLU) and isinstance(nxt, nn.MaxPool2d):
+            x = F.relu(nxt(x), inplace=True)
+            i += 2
+        else:
+            x = m(x)
+            i += 1
+    return x
+
+
 class ImageCoAttentionEncoder(nn.Module):
     """VGG11-bn ``features`` -> spatial grid [B, N, 512] (a permuted view of [B, 512, N])."""
 
@@ -76,7 +115,7 @@ class ImageCoAttentionEncoder(nn.Module):
                 prm.requires_grad = False
 
     def forward(self, x_img):
-        grid = self.flatten(self.vgg11_encoder(x_img))      # [B, 512, N]
+        grid = self.flatten(run_conv_bn_stack(self.vgg11_encoder, x_img))      # [B, 512, N]
         return grid.permute(0, 2, 1)                         # [B, N, 512] view, strides (512N, 1, N)
 
 

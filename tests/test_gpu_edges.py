@@ -169,3 +169,41 @@ def test_runs_on_the_callers_stream():
     for l in range(3):
         assert torch.equal(v0[l], v1[l]) and torch.equal(q0[l], q1[l])
         assert torch.equal(g0[l], Qg[l].grad)
+
+
+@pytest.mark.parametrize("N", [49, 196])
+def test_large_batch_is_sample_independent(N):
+    """4x the configured batch (B = 640): every sample's outputs and input gradients are the ones it
+    gets in a batch of 8 (bitwise for the forward: the per-sample reduction order does not depend on
+    the grid), parameter gradients are the sum over samples."""
+    torch.manual_seed(1)
+    B, T, d = 640, 26, 512
+    m = _mod(d)
+    V = torch.randn(B, d, N, device="cuda").clamp_min_(0)
+    lens = [T] + [1 + (5 * i) % T for i in range(B - 1)]
+    mask = (torch.arange(T)[None, :] < torch.tensor(lens)[:, None]).float().unsqueeze(-1).cuda()
+    Qs = [(torch.randn(B, T, d, device="cuda") * (2.0 / d) ** 0.5 * mask) for _ in range(3)]
+    gv = torch.randn(3, B, d, device="cuda"); gq = torch.randn(3, B, d, device="cuda")
+
+    def run(sl):
+        for p in m.parameters():
+            p.grad = None
+        q = [t[sl].clone().requires_grad_(True) for t in Qs]
+        x = V[sl].permute(0, 2, 1).clone().requires_grad_(True)
+        v_o, q_o = m(x, q)
+        loss = sum((v_o[l] * gv[l, sl]).sum() + (q_o[l] * gq[l, sl]).sum() for l in range(3))
+        loss.backward()
+        return (torch.stack(v_o).detach(), torch.stack(q_o).detach(), x.grad, torch.stack([t.grad for t in q]),
+                m.W_v.weight.grad.clone(), m.W_q.weight.grad.clone())
+
+    big = run(slice(0, B))
+    for s0 in (0, 320, 632):
+        small = run(slice(s0, s0 + 8))
+        assert torch.equal(big[0][:, s0:s0 + 8], small[0]) and torch.equal(big[1][:, s0:s0 + 8], small[1])
+        assert (big[2][s0:s0 + 8] - small[2]).abs().max().item() < 1e-5 * max(1.0, small[2].abs().max().item())
+        assert (big[3][:, s0:s0 + 8] - small[3]).abs().max().item() < 1e-5 * max(1.0, small[3].abs().max().item())
+    # parameter gradients: B = 640 equals the sum of its two halves
+    h1 = run(slice(0, 320)); h2 = run(slice(320, 640))
+    for k in (4, 5):
+        ref = h1[k] + h2[k]
+        assert (big[k] - ref).abs().max().item() < 1e-4 * ref.abs().max().item()

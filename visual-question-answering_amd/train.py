@@ -260,7 +260,12 @@ class Trainer:
 
     @torch.no_grad()
     def validate(self, batches) -> Dict[str, float]:
-        """Accuracy / mean CE under eval() (main.py:290-351, without its n_iters+1 / n_iters slip)."""
+        """Accuracy / mean CE under eval() (main.py:290-351, without its n_iters+1 / n_iters slip).
+        With encoder run-ahead, an encoder pass queued for the next training batch is waited for first
+        (its BatchNorm running-statistics update is then already included, i.e. one batch earlier than
+        in the serial schedule); pass next_image=None on the step before validating to avoid that."""
+        if self.enc_stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.enc_stream)
         self.model.eval()
         n_ok = n = 0
         loss = 0.0

@@ -111,13 +111,17 @@ class GradReducer:
                 self._where[p] = (bi, pi)
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
+    def _launch(self, b):
+        """Pack a bucket whose gradients are all there (one multi-tensor copy) and start its all-reduce."""
+        torch._foreach_copy_(b.views, [p.grad if p.grad is not None else torch.zeros_like(p) for p in b.params])
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def _on_grad(self, p):
-        bi, pi = self._where[p]
+        bi, _ = self._where[p]
         b = self.buckets[bi]
-        b.views[pi].copy_(p.grad)
         b.pending -= 1
         if b.pending == 0:
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._launch(b)
 
     # -- per step -----------------------------------------------------------------------------
     def prepare(self):
@@ -130,22 +134,17 @@ class GradReducer:
             # first step: no overlap; discover the live parameter set, reduce synchronously
             self._build()
             for b in self.buckets:
-                for v, p in zip(b.views, b.params):
-                    v.copy_(p.grad)
-                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._launch(b)
         for b in self.buckets:
             if b.work is None:                          # a parameter of this bucket got no gradient this step
-                for v, p in zip(b.views, b.params):
-                    v.copy_(p.grad) if p.grad is not None else v.zero_()
-                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._launch(b)
         for b in self.buckets:
             b.work.wait()
             b.flat.div_(self.world)
             for v, p in zip(b.views, b.params):
                 if p.grad is None:
-                    p.grad = v.clone()
-                else:
-                    p.grad.copy_(v)
+                    p.grad = torch.empty_like(p)
+            torch._foreach_copy_([p.grad for p in b.params], b.views)       # one multi-tensor copy back
 
     def payload_bytes(self) -> int:
         return sum(b.flat.numel() * b.flat.element_size() for b in (self.buckets or []))

@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--no-runahead", dest="runahead", action="store_false",
                     help="run the frozen image encoder in series with the rest of the step (default: one step "
                          "ahead on its own HIP stream)")
+    ap.add_argument("--model", default="attention", choices=["attention", "attention_resnet"],
+                    help="developer switch: attention_resnet + --opt-lvl 1 --num-cls 3000 is BASELINE config 4")
+    ap.add_argument("--opt-lvl", type=int, default=0, help="developer switch: >0 = bf16 autocast (not the headline)")
     ap.add_argument("--stock-graph", action="store_true",
                     help="run the frozen encoder's Sequential as is (default: ReLU/MaxPool swap and conv bias folded "
                          "into BatchNorm's running mean, modules.run_conv_bn_stack; same stock kernels, same values)")
@@ -249,10 +252,10 @@ def main():
     device = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(device)
     torch.manual_seed(0)
-    model = T.build_model("attention", args.vocab, args.num_cls).to(device)
+    model = T.build_model(args.model, args.vocab, args.num_cls).to(device)
     if args.channels_last:
-        model.image_encoder.vgg11_encoder.to(memory_format=torch.channels_last)
-    trainer = T.Trainer(model, 1e-4, device, encoder_runahead=args.runahead)
+        model.image_encoder.to(memory_format=torch.channels_last)
+    trainer = T.Trainer(model, 1e-4, device, opt_lvl=args.opt_lvl, encoder_runahead=args.runahead)
     batch = device_batch(T, args, rank, device)
     if args.channels_last:
         batch = (batch[0].contiguous(memory_format=torch.channels_last),) + batch[1:]
@@ -276,19 +279,22 @@ def main():
             "metric": "QA-pairs/sec (train step, attention model, K=1000)", "value": round(value, 2),
             "unit": "QA-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.opt_lvl == 0 else "bf16", "data": "synthetic",
             "config": {"workload": "attention model train step (fwd + CE + bwd + Adam%s), K=%d (+1 UNKNOWN), "
-                                   "batch %d/GPU, %dx%d synthetic images -> %d-location x 512 grid, %d-token questions, "
-                                   "vocab %d, fp32, frozen random-init VGG11-bn (%s%s)"
+                                   "batch %d/GPU, %dx%d synthetic images -> %d-location x %d grid, %d-token questions, "
+                                   "vocab %d, %s, frozen random-init %s (%s%s)"
                                    % (" + RCCL grad all-reduce" if world > 1 else "", args.num_cls, args.batch,
-                                      args.image_size, args.image_size, n_grid, args.seq_len, args.vocab,
+                                      args.image_size, args.image_size, n_grid, model.co_attention.hidden_dim,
+                                      args.seq_len, args.vocab,
+                                      "fp32" if args.opt_lvl == 0 else "bf16 autocast",
+                                      "VGG11-bn" if args.model == "attention" else "ResNet-152 (hidden 2048)",
                                       "channels_last" if args.channels_last else "NCHW",
                                       (", encoder one step ahead on its own stream" if trainer.runahead else "")
                                       + ("" if args.stock_graph else ", ReLU after MaxPool, conv bias folded into BN running mean")),
                        "untimed_prime_steps": PRIME_STEPS,
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                        "coattn_impl": "fused" if vqa_amd._lib.load().coattn_fused_supported(
-                           args.batch, n_grid, args.seq_len, 512, 3, 0) else "general"},
+                           args.batch, n_grid, args.seq_len, model.co_attention.hidden_dim, 3, 0) else "general"},
         }
     if world > 1:
         if rank == 0 and trainer.reducer is not None:

@@ -44,10 +44,12 @@ extern "C" {
 #define COATTN_IMPL_AUTO 0
 #define COATTN_IMPL_GENERAL 1
 #define COATTN_IMPL_FUSED 2
-/* flags bit 2: run the forward projections P_v, P_q (model.py:380-384) on the bf16 MFMA
+/* flags bit 2: run the projections P_v, P_q (model.py:380-384) and, in the backward, the d x d
+ * contractions that are their gradients (dQ += dP_q W_q, dV += dP_v W_v, dW_v, dW_q) on the bf16 MFMA
  * (v_mfma_f32_32x32x16_bf16): operands rounded to bf16 while staged, fp32 accumulation, fp32
  * results -- the reduced-precision mode that the reference reaches through apex AMP O1 (main.py:185).
- * Everything else stays exact fp32.  Parity then holds to bf16 tolerance (~1e-2), not 1e-4. */
+ * Everything else stays exact fp32.  Parity then holds to bf16 tolerance (~1e-2), not 1e-4.
+ * The same bit selects the bf16 MFMA for the three contractions of coattn_phrase_forward/backward. */
 #define COATTN_FLAG_BF16_PROJ 4
 
 typedef struct coattn_params {
@@ -124,13 +126,13 @@ int coattn_phrase_workspace_bytes(int B, int T, int E, int dtype, size_t* saved,
 /* X [B,T,E] (rows past a question's length are zeros, as the embedding delivers them) -> out [B,T,E].
  * saved may be NULL for inference. */
 int coattn_phrase_forward(const void* X, const coattn_phrase_params* p, void* out, void* saved, void* ws,
-                          int B, int T, int E, int dtype, void* stream);
+                          int B, int T, int E, int dtype, int flags, void* stream);
 
 /* g_out [B,T,E] -> dX [B,T,E] (overwritten; NULL to skip) and the six parameter gradients
  * (accumulate = 0 overwrites, 1 adds).  `out` is the forward's output. */
 int coattn_phrase_backward(const void* X, const coattn_phrase_params* p, const void* out, const void* saved,
                            const void* g_out, void* dX, const coattn_phrase_param_grads* pg, int accumulate,
-                           void* ws, int B, int T, int E, int dtype, void* stream);
+                           void* ws, int B, int T, int E, int dtype, int flags, void* stream);
 
 /* ---- building blocks (exported for the per-kernel parity tests) ------------------------ */
 
@@ -160,6 +162,12 @@ typedef struct coattn_gemm_desc {
 } coattn_gemm_desc;
 
 int coattn_gemm_f32(const coattn_gemm_desc* g, void* stream);
+
+/* Same contract with the operands rounded to bf16 (round to nearest even) while they are staged and
+ * contracted on v_mfma_f32_32x32x16_bf16 (fp32 accumulate / output): the arithmetic of
+ * COATTN_FLAG_BF16_PROJ.  Shapes the bf16 kernels do not take (unaligned strides, M < 128) are computed
+ * in exact fp32 instead. */
+int coattn_gemm_bf16(const coattn_gemm_desc* g, void* stream);
 
 #ifdef __cplusplus
 }

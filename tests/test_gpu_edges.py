@@ -144,6 +144,13 @@ def test_bf16_mfma_projections(shape):
     assert 1e-5 < rel < 2e-2, rel
     assert (r["v"].cpu() - f["v"]).abs().max() < 3e-2 and (r["q"].cpu() - f["q"]).abs().max() < 3e-2
     assert all(torch.isfinite(t).all() for t in r.values())
+    # backward in the same mode: the d x d gradient contractions run on the bf16 MFMA as well -> the
+    # gradients stay within bf16 tolerance of the exact-fp32 run, and differ from it
+    for k in ("dQ", "dW_v.weight", "dW_q.weight", "dV_phys"):
+        scale = x[k].abs().max().item()
+        err = (r[k] - x[k]).abs().max().item() / scale
+        assert err < 5e-2, (k, err)
+    assert (r["dW_q.weight"] - x["dW_q.weight"]).abs().max().item() > 0
 
 
 def test_runs_on_the_callers_stream():

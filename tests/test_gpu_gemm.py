@@ -7,15 +7,22 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _gemm(desc_kw, stream=None):
+def _gemm(desc_kw, stream=None, bf16=False):
     from vqa_amd import _lib
     lib = _lib.load()
     g = _lib.GemmDesc()
     for k, v in desc_kw.items():
         setattr(g, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
     keep = list(desc_kw.values())  # noqa: F841  (tensors / tables stay alive across the launch)
-    _lib.check(lib.coattn_gemm_f32(C.byref(g), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gemm")
+    fn = lib.coattn_gemm_bf16 if bf16 else lib.coattn_gemm_f32
+    _lib.check(fn(C.byref(g), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gemm")
     torch.cuda.synchronize()
+
+
+def _r(x, bf16):
+    """Reference operand: what the kernel multiplies (bf16 mode rounds to nearest even; products of two
+    bf16 values are exact in fp32, so only the accumulation order differs from the float64 reference)."""
+    return x.bfloat16().double() if bf16 else x.double()
 
 
 def _rel(x, ref):
@@ -86,8 +93,9 @@ def test_gemm_inner_groups_and_ksplit():
     assert _rel(part.sum(0), A.double().T @ Bm.double()) < 2e-6
 
 
+@pytest.mark.parametrize("bf16", [False, True])
 @pytest.mark.parametrize("a_m,b_n", [(True, True), (True, False), (False, True), (False, False)])
-def test_gemm_aligned_fast_path_layouts(a_m, b_n):
+def test_gemm_aligned_fast_path_layouts(a_m, b_n, bf16):
     """float4 / BK=32 kernel: all four operand layouts, partial edge tiles, K not a multiple of 32."""
     torch.manual_seed(5)
     M, N, K = 260, 200, 100
@@ -98,27 +106,28 @@ def test_gemm_aligned_fast_path_layouts(a_m, b_n):
     kw = dict(A=A, B=Bm, C=Cm, bias_n=bias, M=M, N=N, K=K, batch=1, c_sm=N, c_sn=1)
     kw.update(dict(a_sm=1, a_sk=M) if a_m else dict(a_sm=K, a_sk=1))
     kw.update(dict(b_sk=N, b_sn=1) if b_n else dict(b_sk=1, b_sn=K))
-    _gemm(kw)
-    ref = (A.double().T if a_m else A.double()) @ (Bm.double() if b_n else Bm.double().T) + bias.double()
+    _gemm(kw, bf16=bf16)
+    ref = (_r(A, bf16).T if a_m else _r(A, bf16)) @ (_r(Bm, bf16) if b_n else _r(Bm, bf16).T) + bias.double()
     assert _rel(Cm, ref) < 2e-6
 
 
-def test_gemm_aligned_row_split_inner_ksplit_and_pointer_tables():
+@pytest.mark.parametrize("bf16", [False, True])
+def test_gemm_aligned_row_split_inner_ksplit_and_pointer_tables(bf16):
     torch.manual_seed(6)
     B_, d, N = 5, 128, 36
     V = torch.randn(B_, d, N, device="cuda"); W = torch.randn(d, d, device="cuda") / 10
     Pv = torch.full((B_ * N, d), float("nan"), device="cuda")
     _gemm(dict(A=V, B=W, C=Pv, M=B_ * N, N=d, K=d, batch=1, a_sm=1, a_sk=N, a_mdiv=N, a_sdiv=d * N,
-               b_sk=1, b_sn=d, c_sm=d, c_sn=1))
-    assert _rel(Pv, V.double().permute(0, 2, 1).reshape(B_ * N, d) @ W.double().T) < 2e-6
+               b_sk=1, b_sn=d, c_sm=d, c_sn=1), bf16=bf16)
+    assert _rel(Pv, _r(V, bf16).permute(0, 2, 1).reshape(B_ * N, d) @ _r(W, bf16).T) < 2e-6
     # weight-gradient form: inner groups over samples
     dP = torch.randn(B_, N, d, device="cuda")
     G = 2; S = (B_ + G - 1) // G
     part = torch.full((S, d, d), float("nan"), device="cuda")
     _gemm(dict(A=dP, B=V, C=part, M=d, N=d, K=N, batch=S, inner=G, inner_total=B_,
                a_sm=1, a_sk=d, a_si=N * d, a_sz=G * N * d, b_sk=1, b_sn=N, b_si=d * N, b_sz=G * d * N,
-               c_sm=d, c_sn=1, c_sz=d * d))
-    assert _rel(part.sum(0), torch.einsum("bnj,bkn->jk", dP.double(), V.double())) < 2e-6
+               c_sm=d, c_sn=1, c_sz=d * d), bf16=bf16)
+    assert _rel(part.sum(0), torch.einsum("bnj,bkn->jk", _r(dP, bf16), _r(V, bf16))) < 2e-6
     # level-merged launches: A / C through pointer tables, and B through a table indexed by the inner loop
     L, M = 3, 132
     Qs = [torch.randn(M, d, device="cuda") for _ in range(L)]
@@ -127,15 +136,15 @@ def test_gemm_aligned_row_split_inner_ksplit_and_pointer_tables():
     import ctypes as C
     tab = (C.c_void_p * 8)(*([q.data_ptr() for q in Qs] + [None] * 5))
     _gemm(dict(a_ptrs=tab, B=W, C=out, M=M, N=d, K=d, batch=L, a_sm=d, a_sk=1, b_sk=1, b_sn=d,
-               c_sm=d, c_sn=1, c_sz=M * d))
+               c_sm=d, c_sn=1, c_sz=M * d), bf16=bf16)
     for l in range(L):
-        assert _rel(out[l], Qs[l].double() @ W.double().T) < 2e-6
+        assert _rel(out[l], _r(Qs[l], bf16) @ _r(W, bf16).T) < 2e-6
     dPq = torch.randn(L, M, d, device="cuda")
     ks = 48; S = (M + ks - 1) // ks
     part = torch.full((S, d, d), float("nan"), device="cuda")
     _gemm(dict(A=dPq, b_ptrs=tab, ptr_by_inner=1, C=part, M=d, N=d, K=M, batch=S, ksplit=ks, inner=L,
-               a_sm=1, a_sk=d, a_si=M * d, b_sk=d, b_sn=1, c_sm=d, c_sn=1, c_sz=d * d))
-    ref = sum(dPq[l].double().T @ Qs[l].double() for l in range(L))
+               a_sm=1, a_sk=d, a_si=M * d, b_sk=d, b_sn=1, c_sm=d, c_sn=1, c_sz=d * d), bf16=bf16)
+    ref = sum(_r(dPq[l], bf16).T @ _r(Qs[l], bf16) for l in range(L))
     assert _rel(part.sum(0), ref) < 2e-6
 
 

@@ -72,3 +72,30 @@ def test_phrase_errors_are_loud():
         phrase_conv_pool(x, W[0], b, W[1], b, W[2], b)
     with pytest.raises(RuntimeError, match="weights"):
         phrase_conv_pool(x.cuda(), W[1].cuda(), b.cuda(), W[1].cuda(), b.cuda(), W[2].cuda(), b.cuda())
+
+
+def test_phrase_bf16_mfma_mode():
+    """bf16=True (what CUDA autocast selects): bf16-rounded operands on the bf16 MFMA, fp32 accumulation
+    -> values and gradients within bf16 tolerance of the float64 oracle, not identical to the fp32 mode."""
+    from vqa_amd.phrase import phrase_conv_pool
+    B, T, E = 6, 26, 256
+    mod, ref, x, g = _case(B, T, E, 21)
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(g.double())
+    mod = mod.cuda()
+    u, b, t = mod.conv_unigram[1], mod.conv_bigram[1], mod.conv_trigram[1]
+    xg = x.cuda().requires_grad_(True)
+    y = phrase_conv_pool(xg, u.weight, u.bias, b.weight, b.bias, t.weight, t.bias, bf16=True)
+    y.backward(g.cuda())
+    y32 = phrase_conv_pool(xg.detach(), u.weight, u.bias, b.weight, b.bias, t.weight, t.bias, bf16=False)
+    assert (y.detach() - y32).abs().max().item() > 0
+    assert (y.detach().cpu().double() - yr.detach()).abs().max().item() < 3e-2
+    def rel(a, r):      # relative L2 error: a reduced-precision max-pool may route single gradients to another channel
+        return ((a.cpu().double() - r).norm() / r.norm()).item()
+    assert rel(xg.grad, xr.grad) < 1e-1
+    for (k, p), (_, pr) in zip(mod.named_parameters(), ref.named_parameters()):
+        assert rel(p.grad, pr.grad) < 1e-1, (k, rel(p.grad, pr.grad))
+    with torch.autocast("cuda", dtype=torch.bfloat16):          # autocast picks the bf16 mode, output stays fp32
+        ya = mod(xg.detach())
+    assert ya.dtype == torch.float32 and torch.equal(ya, y.detach())

@@ -11,7 +11,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 # every symbol include/coattn.h declares
 EXPORTS = ("coattn_version", "coattn_last_error", "coattn_fused_supported", "coattn_workspace_bytes",
-           "coattn_forward", "coattn_attention_forward", "coattn_backward", "coattn_gemm_f32",
+           "coattn_forward", "coattn_attention_forward", "coattn_backward", "coattn_gemm_f32", "coattn_gemm_bf16",
            "coattn_phrase_workspace_bytes", "coattn_phrase_forward", "coattn_phrase_backward")
 
 F32 = 0
@@ -86,12 +86,13 @@ def load() -> C.CDLL:
                                     C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(ParamGrads), C.c_int,
                                     C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]
     lib.coattn_gemm_f32.argtypes = [C.POINTER(GemmDesc), C.c_void_p]
+    lib.coattn_gemm_bf16.argtypes = [C.POINTER(GemmDesc), C.c_void_p]
     lib.coattn_phrase_workspace_bytes.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_size_t)] * 3
     lib.coattn_phrase_forward.argtypes = [C.c_void_p, C.POINTER(PhraseParams), C.c_void_p, C.c_void_p, C.c_void_p,
-                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.coattn_phrase_backward.argtypes = [C.c_void_p, C.POINTER(PhraseParams), C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.POINTER(PhraseParamGrads), C.c_int, C.c_void_p,
-                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     _lib = lib
     return lib
 

@@ -87,6 +87,11 @@ extern "C" int coattn_gemm_f32(const coattn_gemm_desc* g, void* stream) {
   return launch_gemm_f32(*g, (hipStream_t)stream);
 }
 
+extern "C" int coattn_gemm_bf16(const coattn_gemm_desc* g, void* stream) {
+  CA_CHECK_ARG(g != nullptr, "gemm: null descriptor");
+  return launch_gemm_bf16in(*g, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------------------------------
 // general-shape implementation: MFMA GEMM composition
 // ---------------------------------------------------------------------------------------
@@ -95,7 +100,7 @@ namespace {
 struct Ctx {
   int B, N, T, d, L;
   hipStream_t s;
-  bool bf16_proj = false;     // COATTN_FLAG_BF16_PROJ: forward projections on the bf16 MFMA
+  bool bf16_proj = false;     // COATTN_FLAG_BF16_PROJ: the projections and their gradients on the bf16 MFMA
 };
 
 int launch_proj(const Ctx& c, const coattn_gemm_desc& g) {
@@ -287,7 +292,7 @@ int backward_general(const Ctx& c, const float* V, const float* const* Q, const 
     g.Cin = dQ[l]; g.cin_sm = d; g.cin_sn = 1; g.beta = 1.f;
     g.C = dQ[l]; g.c_sm = d; g.c_sn = 1;
     g.M = B * T; g.N = d; g.K = d; g.batch = 1;
-    CA_TRY(launch_gemm_f32(g, c.s));
+    CA_TRY(c.bf16_proj ? launch_gemm_bf16in(g, c.s) : launch_gemm_f32(g, c.s));
   }
   if (dV) {
     // dV[b][k][n] += sum_j W_v[j][k] dP_v[b][n][j]
@@ -297,7 +302,7 @@ int backward_general(const Ctx& c, const float* V, const float* const* Q, const 
     g.Cin = dV; g.cin_sz = (int64_t)d * N; g.cin_sm = N; g.cin_sn = 1; g.beta = 1.f;
     g.C = dV; g.c_sz = (int64_t)d * N; g.c_sm = N; g.c_sn = 1;
     g.M = d; g.N = N; g.K = d; g.batch = B;
-    CA_TRY(launch_gemm_f32(g, c.s));
+    CA_TRY(c.bf16_proj ? launch_gemm_bf16in(g, c.s) : launch_gemm_f32(g, c.s));
   }
   {
     // dW_v[j][k] = sum_b sum_n dP_v[b][n][j] V[b][k][n]  -> split over sample groups
@@ -308,7 +313,7 @@ int backward_general(const Ctx& c, const float* V, const float* const* Q, const 
     g.B = V; g.b_sk = 1; g.b_sn = N; g.b_si = (int64_t)d * N; g.b_sz = (int64_t)G * d * N;
     g.C = part; g.c_sz = (int64_t)d * d; g.c_sm = d; g.c_sn = 1;
     g.M = d; g.N = d; g.K = N; g.batch = S; g.inner = G; g.inner_total = B;
-    CA_TRY(launch_gemm_f32(g, c.s));
+    CA_TRY(c.bf16_proj ? launch_gemm_bf16in(g, c.s) : launch_gemm_f32(g, c.s));
     CA_TRY(launch_reduce_partials(part, (float*)pg->dW_v, S, (int64_t)d * d, accumulate, c.s));
     const int rpc = (B * N + 255) / 256 > 32 ? (B * N + 255) / 256 : 32;
     CA_TRY(launch_colsum_partial(nullptr, dPv, part, B * N, d, rpc, &nch, c.s));
@@ -326,7 +331,7 @@ int backward_general(const Ctx& c, const float* V, const float* const* Q, const 
     g.B = Q[l]; g.b_sk = d; g.b_sn = 1;
     g.C = part; g.c_sz = (int64_t)d * d; g.c_sm = d; g.c_sn = 1;
     g.M = d; g.N = d; g.K = K; g.batch = S; g.ksplit = ks;
-    CA_TRY(launch_gemm_f32(g, c.s));
+    CA_TRY(c.bf16_proj ? launch_gemm_bf16in(g, c.s) : launch_gemm_f32(g, c.s));
     CA_TRY(launch_reduce_partials(part, (float*)pg->dW_q, S, (int64_t)d * d, (accumulate || l > 0) ? 1 : 0, c.s));
   }
   {
@@ -402,10 +407,11 @@ extern "C" int coattn_backward(const void* V, const void* const* Q, const coattn
   int fused = 0;
   CA_TRY(pick_impl(flags, B, N, T, d, L, &fused));
   Ctx c{B, N, T, d, L, (hipStream_t)stream};
+  c.bf16_proj = (flags & COATTN_FLAG_BF16_PROJ) != 0;
   if (fused && fused_backward_supported(B, N, T, d, L))
     return fused_backward(B, N, T, d, L, (const float*)V, (const float* const*)Q, p, (const float*)saved,
                           (const float*)gv, (const float*)gq, (float*)dV, (float* const*)dQ, pg, accumulate,
-                          (float*)ws, c.s);
+                          (float*)ws, c.s, c.bf16_proj ? 1 : 0);
   return backward_general(c, (const float*)V, (const float* const*)Q, p, (const float*)saved, (const float*)gv,
                           (const float*)gq, (float*)dV, (float* const*)dQ, pg, accumulate, (float*)ws);
 }

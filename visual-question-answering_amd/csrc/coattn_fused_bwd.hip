@@ -673,8 +673,10 @@ int fused_backward_supported(int B, int N, int T, int d, int L) { return fused_s
 
 int fused_backward(int B, int N, int T, int d, int L, const float* V, const float* const* Q, const coattn_params* p,
                    const float* saved, const float* gv, const float* gq, float* dV, float* const* dQ,
-                   const coattn_param_grads* pg, int accumulate, float* ws, hipStream_t s) {
+                   const coattn_param_grads* pg, int accumulate, float* ws, hipStream_t s, int bf16_proj) {
   CA_CHECK_ARG(fused_backward_supported(B, N, T, d, L), "fused backward: unsupported shape");
+  // gradients of the two projections (d x d contractions): fp32 MFMA, or bf16 MFMA under COATTN_FLAG_BF16_PROJ
+  auto gemm_proj = [&](const coattn_gemm_desc& g) { return bf16_proj ? launch_gemm_bf16in(g, s) : launch_gemm_f32(g, s); };
   const SavedOff so = saved_off(B, N, T, d, L);
   const FusedBwdOff wo = fused_bwd_off(B, N, T, d, L);
   const size_t BTd = (size_t)B * T * d, BTN = (size_t)B * T * N, BNd = (size_t)B * N * d, Bd = (size_t)B * d;
@@ -755,7 +757,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const floa
     g.cin_sm = d; g.cin_sn = 1; g.beta = 1.f;
     g.c_sm = d; g.c_sn = 1;
     g.M = B * T; g.N = d; g.K = d; g.batch = L;
-    CA_TRY(launch_gemm_f32(g, s));
+    CA_TRY(gemm_proj(g));
   }
   // sum dP_v over the levels in place into level 0 (one streaming pass for L = 3; folding the sum into
   // the weight-gradient GEMM's operand loads was measured slower: 302 vs 170 + 50 us)
@@ -773,7 +775,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const floa
     g.Cin = dV; g.cin_sz = (int64_t)d * N; g.cin_sm = N; g.cin_sn = 1; g.beta = 1.f;
     g.C = dV; g.c_sz = (int64_t)d * N; g.c_sm = N; g.c_sn = 1;
     g.M = d; g.N = N; g.K = d; g.batch = B;
-    CA_TRY(launch_gemm_f32(g, s));
+    CA_TRY(gemm_proj(g));
   }
   // 5. weight gradients
   float* part = ws + wo.part;
@@ -786,7 +788,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const floa
     g.B = V; g.b_sk = 1; g.b_sn = N; g.b_si = (int64_t)d * N; g.b_sz = (int64_t)G * d * N;
     g.C = part; g.c_sz = (int64_t)d * d; g.c_sm = d; g.c_sn = 1;
     g.M = d; g.N = d; g.K = N; g.batch = S; g.inner = G; g.inner_total = B;
-    CA_TRY(launch_gemm_f32(g, s));
+    CA_TRY(gemm_proj(g));
     CA_TRY(launch_reduce_partials(part, (float*)pg->dW_v, S, (int64_t)d * d, accumulate, s));
   }
   {
@@ -802,7 +804,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const floa
     g.ptr_by_inner = 1; g.b_sk = d; g.b_sn = 1;
     g.C = part; g.c_sz = (int64_t)d * d; g.c_sm = d; g.c_sn = 1;
     g.M = d; g.N = d; g.K = K; g.batch = S; g.ksplit = ks; g.inner = L;
-    CA_TRY(launch_gemm_f32(g, s));
+    CA_TRY(gemm_proj(g));
     CA_TRY(launch_reduce_partials(part, (float*)pg->dW_q, S, (int64_t)d * d, accumulate, s));
   }
   return 0;

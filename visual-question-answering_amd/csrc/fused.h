@@ -10,7 +10,7 @@ int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, c
 int fused_backward_supported(int B, int N, int T, int d, int L);
 int fused_backward(int B, int N, int T, int d, int L, const float* V, const float* const* Q, const coattn_params* p,
                    const float* saved, const float* gv, const float* gq, float* dV, float* const* dQ,
-                   const coattn_param_grads* pg, int accumulate, float* ws, hipStream_t s);
+                   const coattn_param_grads* pg, int accumulate, float* ws, hipStream_t s, int bf16_proj);
 
 // ---- shared by the fused forward / backward translation units -------------------------------
 constexpr int kTS = 7;       // k-steps of 4 over T: T <= 28

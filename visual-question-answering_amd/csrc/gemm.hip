@@ -186,12 +186,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmK g) {
 }
 
 
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ short f2bf(float x) {            // round to nearest even (inputs are finite)
+  unsigned u = __builtin_bit_cast(unsigned, x);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (short)(u >> 16);
+}
+
 // ---- aligned fast path: BK = 32, float4 global loads, one LDS buffer + register prefetch --------
 // Operand images: an operand whose fast (contiguous) axis is the tile row/column index (AM / BN)
 // is staged as [k][m] with 16-byte LDS writes; an operand that is contiguous along k is staged
 // as [m][k] with an odd row stride (33), so that both the transposing 4-byte writes and the
 // 32-lane MFMA operand reads are bank-conflict free.
-template <bool AM, bool BN_, int BM>
+// BF = true: same addressing, but the operands are rounded to bf16 while they are staged ([row][k]
+// images, 80-byte rows, one ds_read_b128 per operand) and contracted with v_mfma_f32_32x32x16_bf16
+// (fp32 accumulate / output): the reduced-precision mode of COATTN_FLAG_BF16_PROJ.
+template <bool AM, bool BN_, int BM, bool BF = false>
 __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
   constexpr int BN = 128, BK = 32;
   constexpr int TM = BM / 64;              // 32-row MFMA tiles per wave along m (waves are 2 x 2)
@@ -201,8 +213,13 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
   constexpr int LDK = BK + 1;              // [m][k] / [n][k] image row stride
   constexpr int ASZ = AM ? BK * LDM : BM * LDK;
   constexpr int BSZ = BN_ ? BK * LDN : BN * LDK;
-  __shared__ __attribute__((aligned(16))) float As[ASZ];
-  __shared__ __attribute__((aligned(16))) float Bs[BSZ];
+  constexpr int LDR = 40;                  // bf16 image row stride (elements)
+  constexpr int LDS_BYTES = BF ? (BM + BN) * LDR * 2 : (ASZ + BSZ) * 4;
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  float* const As = reinterpret_cast<float*>(smem);
+  float* const Bs = As + ASZ;
+  short* const Ah = reinterpret_cast<short*>(smem);
+  short* const Bh = Ah + BM * LDR;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -250,7 +267,7 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
     int m, k;
     if (AM) { k = idx / (BM / 4); m = (idx % (BM / 4)) * 4; } else { m = idx >> 3; k = (idx & 7) * 4; }
     a_k[i] = k;
-    a_lds[i] = AM ? k * LDM + m : m * LDK + k;
+    a_lds[i] = BF ? m * LDR + k : (AM ? k * LDM + m : m * LDK + k);
     a_ok[i] = (m0 + m) < g.M;                      // M % 4 == 0 on this path: whole float4 in or out
     a_off[i] = a_ok[i] ? (int)(row_off(m0 + m, g.a_sm, g.a_mdiv, g.a_sdiv) + (long)k * g.a_sk) : 0;
   }
@@ -262,7 +279,7 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
     int n, k;
     if (BN_) { k = idx >> 5; n = (idx & 31) * 4; } else { n = idx >> 3; k = (idx & 7) * 4; }
     b_k[i] = k;
-    b_lds[i] = BN_ ? k * LDN + n : n * LDK + k;
+    b_lds[i] = BF ? n * LDR + k : (BN_ ? k * LDN + n : n * LDK + k);
     b_ok[i] = (n0 + n) < g.N;
     b_off[i] = b_ok[i] ? (int)((long)k * g.b_sk + (long)(n0 + n) * g.b_sn) : 0;
   }
@@ -299,6 +316,27 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
       rb[i] = (b_ok[i] && b_k[i] < klim) ? *reinterpret_cast<const f32x4*>(Bb + b_off[i]) : zero4;
   };
   auto store_step = [&]() {
+    if constexpr (BF) {
+#pragma unroll
+      for (int i = 0; i < FA; ++i) {
+        if (AM) {                                        // 4 rows m..m+3 of one k: transposing 2-byte writes
+#pragma unroll
+          for (int e = 0; e < 4; ++e) Ah[a_lds[i] + e * LDR] = f2bf(ra[i][e]);
+        } else {
+          *reinterpret_cast<bf16x4*>(&Ah[a_lds[i]]) = bf16x4{f2bf(ra[i][0]), f2bf(ra[i][1]), f2bf(ra[i][2]), f2bf(ra[i][3])};
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (BN_) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) Bh[b_lds[i] + e * LDR] = f2bf(rb[i][e]);
+        } else {
+          *reinterpret_cast<bf16x4*>(&Bh[b_lds[i]]) = bf16x4{f2bf(rb[i][0]), f2bf(rb[i][1]), f2bf(rb[i][2]), f2bf(rb[i][3])};
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < FA; ++i) {
       if (AM) {
@@ -354,6 +392,23 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
       }
       load_regs(Ap, Bp, kend - kbeg - kidx * BK);
     }
+    if constexpr (BF) {
+#pragma unroll
+      for (int ks = 0; ks < BK; ks += 16) {
+        bf16x8 ah[TM], bh[2];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          ah[i] = *reinterpret_cast<const bf16x8*>(&Ah[(wr * (TM * 32) + i * 32 + li) * LDR + ks + 8 * lh]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          bh[j] = *reinterpret_cast<const bf16x8*>(&Bh[(wc * 64 + j * 32 + li) * LDR + ks + 8 * lh]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
     float a0[TM], b0[2], a1[TM], b1[2];              // operand double buffer: reads one k-pair ahead
     read_ops(0, a0, b0);
 #pragma unroll
@@ -379,6 +434,7 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
       __builtin_amdgcn_sched_group_barrier(0x100, TM + 2, 0);
     }
     __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM, 0);
+    }
     __syncthreads();
     if (step + 1 < nsteps) {
       store_step();
@@ -414,15 +470,6 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
 // [n][k]); A is contiguous along k (AM = false) or along m (AM = true: channel-major V with the row split).
 // v_mfma_f32_32x32x16_bf16: lane (i = lane&31, h = lane>>5) holds 8 consecutive k of row i -> both
 // operands are staged [row][k] (k contiguous, 80-byte rows) and read with one ds_read_b128 per MFMA.
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef short bf16x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ short f2bf(float x) {            // round to nearest even (inputs are finite)
-  unsigned u = __builtin_bit_cast(unsigned, x);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (short)(u >> 16);
-}
-
 template <bool AM, bool AVEC>
 __global__ __launch_bounds__(256) void gemm_bf16in_kernel(const GemmK g) {
   constexpr int BM = 128, BN = 128, BK = 32, LDR = 40;       // row stride in bf16 elements (80 B)
@@ -559,7 +606,9 @@ __global__ __launch_bounds__(256) void gemm_bf16in_kernel(const GemmK g) {
 
 static long span(long n, long s) { return n > 0 ? (n - 1) * (s < 0 ? -s : s) : 0; }
 
-int launch_gemm_f32(const coattn_gemm_desc& d, hipStream_t s) {
+// bf16: 0 = fp32 MFMA; 1 = bf16-input MFMA on the aligned fast path, return 1 (nothing launched) when
+// the shape is not eligible for it
+static int launch_gemm_impl(const coattn_gemm_desc& d, hipStream_t s, int bf16) {
   CA_CHECK_ARG((d.A || d.a_ptrs[0]) && (d.B || d.b_ptrs[0]) && (d.C || d.c_ptrs[0]), "gemm: null operand");
   CA_CHECK_ARG(!(d.ptr_by_inner && (d.c_ptrs[0] || d.cin_ptrs[0])), "gemm: C tables are indexed by batch only");
   CA_CHECK_ARG(d.M > 0 && d.N > 0 && d.K > 0 && d.batch > 0, "gemm: bad shape M=%d N=%d K=%d batch=%d", d.M, d.N, d.K, d.batch);
@@ -613,6 +662,20 @@ int launch_gemm_f32(const coattn_gemm_desc& d, hipStream_t s) {
     vec = vec && (d.a_ptrs[0] ? true : pal(d.A)) && (d.b_ptrs[0] ? true : pal(d.B));
     for (int t = 0; t < 8; ++t) vec = vec && pal(d.a_ptrs[t]) && pal(d.b_ptrs[t]);
   }
+  if (bf16) {
+    if (!vec) return 1;
+    const long ntn = (d.N + 127) / 128, ntm = (d.M + 127) / 128;
+    g.xcd_group = ntm >= 32 ? 1 : 0;
+    const long nblk = g.xcd_group ? (long)d.batch * ntn * ((ntm + 7) / 8) * 8 : (long)d.batch * ntn * ntm;
+    CA_CHECK_ARG(nblk < 2147483647L, "gemm: grid too large");
+    dim3 grid((unsigned)nblk);
+    if (a_m && b_n) hipLaunchKernelGGL((gemm_f32_vec_kernel<true, true, 128, true>), grid, block, 0, s, g);
+    else if (a_m) hipLaunchKernelGGL((gemm_f32_vec_kernel<true, false, 128, true>), grid, block, 0, s, g);
+    else if (b_n) hipLaunchKernelGGL((gemm_f32_vec_kernel<false, true, 128, true>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_f32_vec_kernel<false, false, 128, true>), grid, block, 0, s, g);
+    CA_CHECK_LAUNCH("gemm_bf16_vec");
+    return 0;
+  }
   if (vec) {
     // Tile height: 128 rows, or 64 rows when 128-row tiles would leave a mostly empty last round of
     // workgroups (P_v at B=160, N=196: 980 tiles for 768 resident -> 1,960 half-size tiles at 5/CU).
@@ -652,8 +715,16 @@ int launch_gemm_f32(const coattn_gemm_desc& d, hipStream_t s) {
   return 0;
 }
 
-// Projection GEMM with bf16 MFMA inputs (fp32 storage): the shapes/layouts of P_v and P_q only.
+int launch_gemm_f32(const coattn_gemm_desc& d, hipStream_t s) { return launch_gemm_impl(d, s, 0); }
+
+// GEMM with bf16 MFMA inputs (fp32 storage, fp32 accumulate / output): every aligned shape through the
+// bf16 mode of the fast-path kernel; the unaligned channel-major projection (P_v at N = 49) through
+// gemm_bf16in_kernel; anything else in exact fp32.
 int launch_gemm_bf16in(const coattn_gemm_desc& d, hipStream_t s) {
+  {
+    const int rc = launch_gemm_impl(d, s, 1);
+    if (rc <= 0) return rc;                              // launched (0) or argument error (< 0)
+  }
   auto al4 = [](long v) { return (v & 3) == 0; };
   const bool a_m = (d.a_sm == 1 && d.a_sk != 1);
   bool tab_ok = true;

@@ -207,10 +207,12 @@ extern "C" int coattn_phrase_workspace_bytes(int B, int T, int E, int dtype, siz
 }
 
 extern "C" int coattn_phrase_forward(const void* X, const coattn_phrase_params* p, void* out, void* saved, void* ws,
-                                     int B, int T, int E, int dtype, void* stream) {
+                                     int B, int T, int E, int dtype, int flags, void* stream) {
   CA_TRY(check_phrase(X, p, B, T, E, dtype));
   CA_CHECK_ARG(out && ws, "phrase_forward: NULL output or workspace");
   hipStream_t s = (hipStream_t)stream;
+  const bool bf16 = (flags & COATTN_FLAG_BF16_PROJ) != 0;
+  auto gemm = [&](const coattn_gemm_desc& g) { return bf16 ? launch_gemm_bf16in(g, s) : launch_gemm_f32(g, s); };
   const PhrasePlan pl = plan_phrase(B, T, E);
   char* w = static_cast<char*>(ws);
   CA_TRY(build_operands((const float*)X, p, w, pl, B, T, E, s));
@@ -224,7 +226,7 @@ extern "C" int coattn_phrase_forward(const void* X, const coattn_phrase_params* 
     g.kband_lo[1] = 0; g.kband_hi[1] = 2 * E;
     g.kband_lo[2] = 0; g.kband_hi[2] = 3 * E;
   }
-  CA_TRY(launch_gemm_f32(g, s));
+  CA_TRY(gemm(g));
   const long n = (long)B * T * E;
   hipLaunchKernelGGL(phrase_pool_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
                      reinterpret_cast<const float*>(w + pl.z), (float*)out, (unsigned char*)saved, n);
@@ -234,9 +236,13 @@ extern "C" int coattn_phrase_forward(const void* X, const coattn_phrase_params* 
 
 extern "C" int coattn_phrase_backward(const void* X, const coattn_phrase_params* p, const void* out, const void* saved,
                                       const void* g_out, void* dX, const coattn_phrase_param_grads* pg, int accumulate,
-                                      void* ws, int B, int T, int E, int dtype, void* stream) {
+                                      void* ws, int B, int T, int E, int dtype, int flags, void* stream) {
   CA_TRY(check_phrase(X, p, B, T, E, dtype));
   CA_CHECK_ARG(out && saved && g_out && pg && ws, "phrase_backward: NULL pointer");
+  const bool bf16 = (flags & COATTN_FLAG_BF16_PROJ) != 0;
+  auto gemm = [&](const coattn_gemm_desc& g) {
+    return bf16 ? launch_gemm_bf16in(g, (hipStream_t)stream) : launch_gemm_f32(g, (hipStream_t)stream);
+  };
   CA_CHECK_ARG(pg->dW1 && pg->db1 && pg->dW2 && pg->db2 && pg->dW3 && pg->db3, "phrase_backward: NULL gradient pointer");
   hipStream_t s = (hipStream_t)stream;
   const PhrasePlan pl = plan_phrase(B, T, E);
@@ -265,7 +271,7 @@ extern "C" int coattn_phrase_backward(const void* X, const coattn_phrase_params*
     g.C = reinterpret_cast<float*>(w + pl.part) + (long)gr * E * 3 * E + lo;
     g.M = E; g.N = hi - lo; g.K = (int)bt; g.batch = pl.nsplit; g.inner = 1; g.ksplit = pl.ksplit;
     g.a_sm = 1; g.a_sk = 3 * E; g.b_sk = 3 * E; g.b_sn = 1; g.c_sm = 3 * E; g.c_sn = 1; g.c_sz = 9L * E * E;
-    CA_TRY(launch_gemm_f32(g, s));
+    CA_TRY(gemm(g));
   }
   const long nt = 6L * E * E;
   hipLaunchKernelGGL(phrase_unpack_dw_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s,
@@ -284,7 +290,7 @@ extern "C" int coattn_phrase_backward(const void* X, const coattn_phrase_params*
       h.kband_lo[1] = 0; h.kband_hi[1] = 3 * E;           // x[t]  : all
       h.kband_lo[2] = 2 * E; h.kband_hi[2] = 3 * E;       // x[t+1]: tri
     }
-    CA_TRY(launch_gemm_f32(h, s));
+    CA_TRY(gemm(h));
     hipLaunchKernelGGL(phrase_col2im_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
                        reinterpret_cast<const float*>(w + pl.xcat), (float*)dX, T, E, n);
     CA_CHECK_LAUNCH("phrase_col2im");

@@ -28,7 +28,7 @@ class _PhraseConvPoolFn(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)     # fp32 island under autocast
-    def forward(ctx, x, W1, b1, W2, b2, W3, b3):
+    def forward(ctx, x, W1, b1, W2, b2, W3, b3, flags):
         if not x.is_cuda:
             raise RuntimeError("phrase_conv_pool (HIP) needs tensors on the GPU")
         if x.dtype != torch.float32:
@@ -47,8 +47,9 @@ class _PhraseConvPoolFn(torch.autograd.Function):
         p = _lib.PhraseParams(*[t.data_ptr() for t in ps])
         stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
         _lib.check(lib.coattn_phrase_forward(_ptr(X), C.byref(p), _ptr(out), _ptr(saved), _ptr(ws), B, T, E, _lib.F32,
-                                             stream), "coattn_phrase_forward")
+                                             flags, stream), "coattn_phrase_forward")
         if need_grad:
+            ctx.flags = flags
             ctx.save_for_backward(X, out, saved, *ps)
         return out
 
@@ -67,11 +68,15 @@ class _PhraseConvPoolFn(torch.autograd.Function):
         pg = _lib.PhraseParamGrads(*[t.data_ptr() for t in grads])
         stream = C.c_void_p(torch.cuda.current_stream(X.device).cuda_stream)
         _lib.check(lib.coattn_phrase_backward(_ptr(X), C.byref(p), _ptr(out), _ptr(saved), _ptr(g), _ptr(dX),
-                                              C.byref(pg), 0, _ptr(ws), B, T, E, _lib.F32, stream),
+                                              C.byref(pg), 0, _ptr(ws), B, T, E, _lib.F32, ctx.flags, stream),
                    "coattn_phrase_backward")
-        return (dX, *grads)
+        return (dX, *grads, None)
 
 
-def phrase_conv_pool(x, W1, b1, W2, b2, W3, b3):
-    """x [B,T,E] -> [B,T,E]; weights in torch Conv1d layout ([E,E,k]) of the unigram / bigram / trigram convs."""
-    return _PhraseConvPoolFn.apply(x, W1, b1, W2, b2, W3, b3)
+def phrase_conv_pool(x, W1, b1, W2, b2, W3, b3, bf16=None):
+    """x [B,T,E] -> [B,T,E]; weights in torch Conv1d layout ([E,E,k]) of the unigram / bigram / trigram convs.
+    bf16: contract on the bf16 MFMA (fp32 storage / accumulation); default: when CUDA autocast is on --
+    the stock Conv1d modules would run in reduced precision there too."""
+    if bf16 is None:
+        bf16 = x.is_cuda and torch.is_autocast_enabled("cuda")
+    return _PhraseConvPoolFn.apply(x, W1, b1, W2, b2, W3, b3, _lib.FLAG_BF16_PROJ if bf16 else 0)

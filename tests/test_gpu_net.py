@@ -47,6 +47,12 @@ def test_attention_train_cli_on_gpu(capsys):
             "--vocab_size", "50", "--max_seq_length", "26", "--log_interval", "2", "--learning_rate", "1e-3"])
     recs = [json.loads(l) for l in capsys.readouterr().out.strip().splitlines() if l.startswith("{")]
     assert len(recs) == 3 and all(r["loss"] == r["loss"] for r in recs)
+    # with periodic validation (eval() forward-only path, main.py:290-351)
+    T.main(["--model", "attention", "--num_cls", "10", "--batch_size", "8", "--num_steps", "4", "--image_size", "64",
+            "--vocab_size", "50", "--log_interval", "4", "--val_interval", "2", "--val_batches", "2"])
+    recs = [json.loads(l) for l in capsys.readouterr().out.strip().splitlines() if l.startswith("{")]
+    vals = [r for r in recs if "val_accuracy" in r]
+    assert len(vals) == 2 and all(0.0 <= r["val_accuracy"] <= 100.0 and r["val_loss"] == r["val_loss"] for r in vals)
 
 
 def test_config4_resnet_2048_bf16_step():

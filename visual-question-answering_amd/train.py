@@ -296,6 +296,10 @@ def main(argv=None):
     ap.add_argument("--image_size", type=int, default=0, help="override the model's image size (0 = registry)")
     ap.add_argument("--channels_last", type=str2bool, default="true",
                     help="run the stock image encoder in channels_last (MIOpen NHWC kernels)")
+    ap.add_argument("--val_interval", type=int, default=0,
+                    help="every this many steps: accuracy / loss under eval() on --val_batches synthetic batches "
+                         "(main.py:242-257, :290-351); 0 = off")
+    ap.add_argument("--val_batches", type=int, default=2)
     ap.add_argument("--model_ckpt", type=str, default=None)
     ap.add_argument("--save_path", type=str, default=None)
     args = ap.parse_args(argv)
@@ -327,14 +331,31 @@ def main(argv=None):
             image, question, label, ques_len = sort_batch(b["image"], b["question"], b["label"], b["ques_len"])
             yield image, question, ques_len, label
 
+    val = []
+    if args.val_interval > 0:
+        for i in range(args.val_batches):
+            b = synthetic_batch(args.batch_size, size, args.max_seq_length, args.vocab_size, args.num_cls + 1,
+                                seed=987654 + rank + 1000 * i)
+            image, question, label, ques_len = sort_batch(b["image"], b["question"], b["label"], b["ques_len"])
+            image = image.to(device)
+            if cl:
+                image = image.contiguous(memory_format=torch.channels_last)
+            val.append((image, question.to(device), ques_len, label.to(device)))
+
     t0 = time.time()
     batches = DevicePrefetcher(host_batches(), device, cl)
     for step, (image, question, ques_len, label) in enumerate(batches):
-        nxt, ready = batches.peek_image()
+        validate_now = bool(val) and (step + 1) % args.val_interval == 0
+        # no encoder run-ahead across a validation: its BatchNorm statistics must be those of this step
+        nxt, ready = (None, None) if validate_now else batches.peek_image()
         loss = trainer.step(image, question, ques_len, label, next_image=nxt, next_ready=ready)
         if (step + 1) % args.log_interval == 0 and rank == 0:
             print(json.dumps({"step": step + 1, "loss": round(float(loss), 5),
                               "pairs_per_s": round(world * args.batch_size * (step + 1) / (time.time() - t0), 2)}))
+        if validate_now:
+            m = trainer.validate(val)
+            if rank == 0:
+                print(json.dumps({"step": step + 1, "val_accuracy": round(m["accuracy"], 3), "val_loss": round(m["loss"], 5)}))
     if args.save_path and rank == 0:
         torch.save(model.state_dict(), args.save_path)
     vdist.shutdown()

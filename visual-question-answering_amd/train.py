@@ -96,60 +96,82 @@ def synthetic_batch(batch_size: int, image_size, max_seq_len: int, vocab_size: i
 
 
 class DevicePrefetcher:
-    """Host -> device hand-off of the next batch on a side stream while the current step computes
-    (main.py:205-208 copies synchronously).  Pinned staging buffers are reused; the consumer stream
-    waits on the copy's event before it touches the tensors.  Lengths stay on the host (packing)."""
+    """Host -> device hand-off of the following batches while the current step computes
+    (main.py:205-208 copies synchronously).  A worker thread pulls batches from the host iterator,
+    stages them in pinned buffers (a ring of two sets, reused once their copy has completed) and queues
+    the copies on a side stream; the consumer stream waits on the copy's event before it touches the
+    tensors.  Lengths stay on the host (packing).  At most `depth` batches are in flight."""
 
-    def __init__(self, batches, device, channels_last: bool = False):
-        self.it = iter(batches)
+    _END = object()
+
+    def __init__(self, batches, device, channels_last: bool = False, depth: int = 2):
         self.device = device
         self.cl = channels_last
-        self.stream = torch.cuda.Stream(device) if device.type == "cuda" else None
-        self.pinned = {}
         self.next = None
-        self._copied = None
-        self._fetch()
+        if device.type != "cuda":
+            self._it = iter(batches)
+            self._q = None
+            self._advance()
+            return
+        import queue
+        import threading
+        self.stream = torch.cuda.Stream(device)
+        self._q = queue.Queue(maxsize=max(1, depth))
+        self._err = None
+        self._thread = threading.Thread(target=self._worker, args=(iter(batches),), daemon=True)
+        self._thread.start()
+        self._advance()
 
-    def _pin(self, name, t):
-        buf = self.pinned.get(name)
-        if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
-            buf = torch.empty(t.shape, dtype=t.dtype).pin_memory()
-            self.pinned[name] = buf
-        buf.copy_(t)
-        return buf
-
-    def _fetch(self):
+    def _worker(self, it):
         try:
-            image, question, ques_len, label = next(self.it)
-        except StopIteration:
+            torch.cuda.set_device(self.device)
+            ring = [{}, {}]                                       # pinned staging buffers + their last copy event
+            for i, (image, question, ques_len, label) in enumerate(it):
+                slot = ring[i & 1]
+                if slot.get("event") is not None:
+                    slot["event"].synchronize()                  # the previous copy out of this set is done
+
+                def pin(name, t):
+                    buf = slot.get(name)
+                    if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+                        buf = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+                        slot[name] = buf
+                    buf.copy_(t)
+                    return buf
+
+                with torch.cuda.stream(self.stream):
+                    im = pin("image", image).to(self.device, non_blocking=True)
+                    if self.cl:
+                        im = im.contiguous(memory_format=torch.channels_last)
+                    qu = pin("question", question).to(self.device, non_blocking=True)
+                    la = pin("label", label).to(self.device, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self.stream)
+                slot["event"] = ev
+                self._q.put((im, qu, ques_len, la, ev))
+        except BaseException as e:                                # surfaced in the consumer thread
+            self._err = e
+        finally:
+            self._q.put(self._END)
+
+    def _advance(self):
+        if self._q is None:
+            try:
+                image, question, ques_len, label = next(self._it)
+                self.next = (image, question, ques_len, label, None)
+            except StopIteration:
+                self.next = None
+            return
+        item = self._q.get()
+        if item is self._END:
             self.next = None
-            return
-        if self.stream is None:
-            self.next = (image, question, ques_len, label, None)
-            return
-        if self._copied is not None:
-            self._copied.synchronize()                           # the pinned buffers are free again
-        with torch.cuda.stream(self.stream):
-            im = self._pin("image", image).to(self.device, non_blocking=True)
-            if self.cl:
-                im = im.contiguous(memory_format=torch.channels_last)
-            qu = self._pin("question", question).to(self.device, non_blocking=True)
-            la = self._pin("label", label).to(self.device, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
-        self._copied = ev
-        self.next = (im, qu, ques_len, la, ev)
+            if self._err is not None:
+                raise self._err
+        else:
+            self.next = item
 
     def __iter__(self):
         return self
-
-    def _claim(self):
-        """Make the staged batch usable from the current stream."""
-        im, qu, ln, la, ev = self.next
-        if ev is not None:
-            torch.cuda.current_stream(self.device).wait_event(ev)
-            for t in (im, qu, la):
-                t.record_stream(torch.cuda.current_stream(self.device))
 
     def peek_image(self):
         """(image, copy-done event) of the batch the next __next__ will return, (None, None) at the
@@ -161,9 +183,13 @@ class DevicePrefetcher:
     def __next__(self):
         if self.next is None:
             raise StopIteration
-        self._claim()
-        im, qu, ln, la, _ = self.next
-        self._fetch()
+        im, qu, ln, la, ev = self.next
+        if ev is not None:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            for t in (im, qu, la):
+                t.record_stream(cur)
+        self._advance()
         return im, qu, ln, la
 
 

@@ -201,14 +201,8 @@ def roofline_leg(device, B=160, N=196, T=26, d=512, L=3, iters=50):
 
 def host_cores() -> int:
     """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = max(1, min(n, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        pass
-    return n
+    from vqa_amd.train import usable_cpus
+    return usable_cpus()
 
 
 def cpu_baseline_leg(args):

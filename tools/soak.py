@@ -8,6 +8,7 @@ from vqa_amd import train as T
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 dev = torch.device("cuda", 0)
+torch.set_num_threads(max(1, min(4, T.usable_cpus())))     # as train.main does
 torch.manual_seed(0)
 model = T.build_model("attention", 10000, 1000).to(dev)
 model.image_encoder.to(memory_format=torch.channels_last)

@@ -200,11 +200,21 @@ __device__ __forceinline__ short f2bf(float x) {            // round to nearest 
 // is staged as [k][m] with 16-byte LDS writes; an operand that is contiguous along k is staged
 // as [m][k] with an odd row stride (33), so that both the transposing 4-byte writes and the
 // 32-lane MFMA operand reads are bank-conflict free.
-// BF = true: same addressing, but the operands are rounded to bf16 while they are staged ([row][k]
+// MODE 1: same addressing, but the operands are rounded to bf16 while they are staged ([row][k]
 // images, 80-byte rows, one ds_read_b128 per operand) and contracted with v_mfma_f32_32x32x16_bf16
 // (fp32 accumulate / output): the reduced-precision mode of COATTN_FLAG_BF16_PROJ.
-template <bool AM, bool BN_, int BM, bool BF = false>
+// MODE 2: fp32-accurate product on the bf16 MFMA: every fp32 operand element is split exactly into
+// three bf16 pieces x = hi + mid + lo (24 significand bits) while it is staged, and the six partial
+// products down to relative order 2^-16 (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid) are accumulated
+// in fp32.  Each bf16*bf16 product is exact in fp32; what is dropped (mid*lo, lo*mid, lo*lo) is below
+// 2^-23 of |x||y|, the size of one fp32 rounding.  The bf16 MFMA has 16x the fp32 MFMA rate, so the
+// six products cost 6/16 of the fp32 MFMA time.
+typedef __bf16 bfv4 __attribute__((ext_vector_type(4)));
+
+template <bool AM, bool BN_, int BM, int MODE = 0>
 __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
+  constexpr bool BF = MODE != 0;
+  constexpr int NIMG = MODE == 2 ? 3 : 1;
   constexpr int BN = 128, BK = 32;
   constexpr int TM = BM / 64;              // 32-row MFMA tiles per wave along m (waves are 2 x 2)
   constexpr int FA = BM * BK / 4 / 256;    // float4 per thread per K-step for A (4 or 6)
@@ -214,12 +224,12 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
   constexpr int ASZ = AM ? BK * LDM : BM * LDK;
   constexpr int BSZ = BN_ ? BK * LDN : BN * LDK;
   constexpr int LDR = 40;                  // bf16 image row stride (elements)
-  constexpr int LDS_BYTES = BF ? (BM + BN) * LDR * 2 : (ASZ + BSZ) * 4;
+  constexpr int LDS_BYTES = BF ? NIMG * (BM + BN) * LDR * 2 : (ASZ + BSZ) * 4;
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   float* const As = reinterpret_cast<float*>(smem);
   float* const Bs = As + ASZ;
-  short* const Ah = reinterpret_cast<short*>(smem);
-  short* const Bh = Ah + BM * LDR;
+  short* const Ah = reinterpret_cast<short*>(smem);          // NIMG images of BM rows
+  short* const Bh = Ah + NIMG * BM * LDR;                    // NIMG images of BN rows
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -265,7 +275,9 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
   for (int i = 0; i < FA; ++i) {
     const int idx = tid + 256 * i;                  // float4 index in the BM x 32 tile
     int m, k;
-    if (AM) { k = idx / (BM / 4); m = (idx % (BM / 4)) * 4; } else { m = idx >> 3; k = (idx & 7) * 4; }
+    if (AM && BF) { m = idx % BM; k = (idx / BM) * 4; }       // bf16 images are [row][k]: lanes run along m
+    else if (AM) { k = idx / (BM / 4); m = (idx % (BM / 4)) * 4; }   // (coalesced dword loads), 4 consecutive k per thread
+    else { m = idx >> 3; k = (idx & 7) * 4; }
     a_k[i] = k;
     a_lds[i] = BF ? m * LDR + k : (AM ? k * LDM + m : m * LDK + k);
     a_ok[i] = (m0 + m) < g.M;                      // M % 4 == 0 on this path: whole float4 in or out
@@ -277,7 +289,9 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
   for (int i = 0; i < 4; ++i) {
     const int idx = tid + 256 * i;
     int n, k;
-    if (BN_) { k = idx >> 5; n = (idx & 31) * 4; } else { n = idx >> 3; k = (idx & 7) * 4; }
+    if (BN_ && BF) { n = idx % BN; k = (idx / BN) * 4; }
+    else if (BN_) { k = idx >> 5; n = (idx & 31) * 4; }
+    else { n = idx >> 3; k = (idx & 7) * 4; }
     b_k[i] = k;
     b_lds[i] = BF ? n * LDR + k : (BN_ ? k * LDN + n : n * LDK + k);
     b_ok[i] = (n0 + n) < g.N;
@@ -309,31 +323,62 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
   };
   auto load_regs = [&](const float* Ab, const float* Bb, int klim) {     // K range % 4 == 0 on this path
 #pragma unroll
-    for (int i = 0; i < FA; ++i)
-      ra[i] = (a_ok[i] && a_k[i] < klim) ? *reinterpret_cast<const f32x4*>(Ab + a_off[i]) : zero4;
+    for (int i = 0; i < FA; ++i) {
+      if constexpr (AM && BF) {                                  // 4 consecutive k of one row: strided dword loads
+        const bool ok = a_ok[i] && a_k[i] < klim;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      rb[i] = (b_ok[i] && b_k[i] < klim) ? *reinterpret_cast<const f32x4*>(Bb + b_off[i]) : zero4;
+        for (int e = 0; e < 4; ++e) ra[i][e] = ok ? Ab[a_off[i] + (long)e * g.a_sk] : 0.f;
+      } else {
+        ra[i] = (a_ok[i] && a_k[i] < klim) ? *reinterpret_cast<const f32x4*>(Ab + a_off[i]) : zero4;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (BN_ && BF) {
+        const bool ok = b_ok[i] && b_k[i] < klim;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rb[i][e] = ok ? Bb[b_off[i] + (long)e * g.b_sk] : 0.f;
+      } else {
+        rb[i] = (b_ok[i] && b_k[i] < klim) ? *reinterpret_cast<const f32x4*>(Bb + b_off[i]) : zero4;
+      }
+    }
   };
   auto store_step = [&]() {
-    if constexpr (BF) {
+    if constexpr (MODE == 2) {
+      // exact 3-way split of each element, one image per piece
+      auto put = [&](short* img, int rows, int off, bool transposed, const f32x4& v) {
+        const bfv4 h = __builtin_convertvector(v, bfv4);
+        const f32x4 r1 = v - __builtin_convertvector(h, f32x4);
+        const bfv4 m = __builtin_convertvector(r1, bfv4);
+        const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);
+        const bfv4 l = __builtin_convertvector(r2, bfv4);
+        const bfv4 pc[3] = {h, m, l};
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          short* dst = img + p * rows * LDR + off;
+          if (transposed) {
+            const bf16x4 sv = __builtin_bit_cast(bf16x4, pc[p]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[e * LDR] = sv[e];
+          } else {
+            *reinterpret_cast<bfv4*>(dst) = pc[p];
+          }
+        }
+      };
+#pragma unroll
+      for (int i = 0; i < FA; ++i) put(Ah, BM, a_lds[i], false, ra[i]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) put(Bh, BN, b_lds[i], false, rb[i]);
+      return;
+    }
+    if constexpr (MODE == 1) {
 #pragma unroll
       for (int i = 0; i < FA; ++i) {
-        if (AM) {                                        // 4 rows m..m+3 of one k: transposing 2-byte writes
-#pragma unroll
-          for (int e = 0; e < 4; ++e) Ah[a_lds[i] + e * LDR] = f2bf(ra[i][e]);
-        } else {
-          *reinterpret_cast<bf16x4*>(&Ah[a_lds[i]]) = bf16x4{f2bf(ra[i][0]), f2bf(ra[i][1]), f2bf(ra[i][2]), f2bf(ra[i][3])};
-        }
+        *reinterpret_cast<bf16x4*>(&Ah[a_lds[i]]) = bf16x4{f2bf(ra[i][0]), f2bf(ra[i][1]), f2bf(ra[i][2]), f2bf(ra[i][3])};
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        if (BN_) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) Bh[b_lds[i] + e * LDR] = f2bf(rb[i][e]);
-        } else {
-          *reinterpret_cast<bf16x4*>(&Bh[b_lds[i]]) = bf16x4{f2bf(rb[i][0]), f2bf(rb[i][1]), f2bf(rb[i][2]), f2bf(rb[i][3])};
-        }
+        *reinterpret_cast<bf16x4*>(&Bh[b_lds[i]]) = bf16x4{f2bf(rb[i][0]), f2bf(rb[i][1]), f2bf(rb[i][2]), f2bf(rb[i][3])};
       }
       return;
     }
@@ -392,7 +437,31 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
       }
       load_regs(Ap, Bp, kend - kbeg - kidx * BK);
     }
-    if constexpr (BF) {
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int ks = 0; ks < BK; ks += 16) {
+        bf16x8 ah[3][TM], bh[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            ah[p][i] = *reinterpret_cast<const bf16x8*>(&Ah[p * BM * LDR + (wr * (TM * 32) + i * 32 + li) * LDR + ks + 8 * lh]);
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            bh[p][j] = *reinterpret_cast<const bf16x8*>(&Bh[p * BN * LDR + (wc * 64 + j * 32 + li) * LDR + ks + 8 * lh]);
+        }
+        // smallest terms first: lo*hi, hi*lo, mid*mid, then mid*hi, hi*mid, then hi*hi
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[PA[t]][i], bh[PB[t]][j], acc[i][j], 0, 0, 0);
+      }
+    } else if constexpr (MODE == 1) {
 #pragma unroll
       for (int ks = 0; ks < BK; ks += 16) {
         bf16x8 ah[TM], bh[2];
@@ -606,8 +675,8 @@ __global__ __launch_bounds__(256) void gemm_bf16in_kernel(const GemmK g) {
 
 static long span(long n, long s) { return n > 0 ? (n - 1) * (s < 0 ? -s : s) : 0; }
 
-// bf16: 0 = fp32 MFMA; 1 = bf16-input MFMA on the aligned fast path, return 1 (nothing launched) when
-// the shape is not eligible for it
+// bf16: 0 = fp32 MFMA; 1 = bf16-input MFMA, 2 = 3-way bf16 split (fp32-accurate) on the aligned fast path:
+// these two return 1 (nothing launched) when the shape is not eligible
 static int launch_gemm_impl(const coattn_gemm_desc& d, hipStream_t s, int bf16) {
   CA_CHECK_ARG((d.A || d.a_ptrs[0]) && (d.B || d.b_ptrs[0]) && (d.C || d.c_ptrs[0]), "gemm: null operand");
   CA_CHECK_ARG(!(d.ptr_by_inner && (d.c_ptrs[0] || d.cin_ptrs[0])), "gemm: C tables are indexed by batch only");
@@ -669,10 +738,18 @@ static int launch_gemm_impl(const coattn_gemm_desc& d, hipStream_t s, int bf16) 
     const long nblk = g.xcd_group ? (long)d.batch * ntn * ((ntm + 7) / 8) * 8 : (long)d.batch * ntn * ntm;
     CA_CHECK_ARG(nblk < 2147483647L, "gemm: grid too large");
     dim3 grid((unsigned)nblk);
-    if (a_m && b_n) hipLaunchKernelGGL((gemm_f32_vec_kernel<true, true, 128, true>), grid, block, 0, s, g);
-    else if (a_m) hipLaunchKernelGGL((gemm_f32_vec_kernel<true, false, 128, true>), grid, block, 0, s, g);
-    else if (b_n) hipLaunchKernelGGL((gemm_f32_vec_kernel<false, true, 128, true>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_f32_vec_kernel<false, false, 128, true>), grid, block, 0, s, g);
+    if (bf16 == 2) {
+      if (a_m && b_n) hipLaunchKernelGGL((gemm_f32_vec_kernel<true, true, 128, 2>), grid, block, 0, s, g);
+      else if (a_m) hipLaunchKernelGGL((gemm_f32_vec_kernel<true, false, 128, 2>), grid, block, 0, s, g);
+      else if (b_n) hipLaunchKernelGGL((gemm_f32_vec_kernel<false, true, 128, 2>), grid, block, 0, s, g);
+      else hipLaunchKernelGGL((gemm_f32_vec_kernel<false, false, 128, 2>), grid, block, 0, s, g);
+      CA_CHECK_LAUNCH("gemm_bf16x3_vec");
+      return 0;
+    }
+    if (a_m && b_n) hipLaunchKernelGGL((gemm_f32_vec_kernel<true, true, 128, 1>), grid, block, 0, s, g);
+    else if (a_m) hipLaunchKernelGGL((gemm_f32_vec_kernel<true, false, 128, 1>), grid, block, 0, s, g);
+    else if (b_n) hipLaunchKernelGGL((gemm_f32_vec_kernel<false, true, 128, 1>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_f32_vec_kernel<false, false, 128, 1>), grid, block, 0, s, g);
     CA_CHECK_LAUNCH("gemm_bf16_vec");
     return 0;
   }
@@ -715,7 +792,20 @@ static int launch_gemm_impl(const coattn_gemm_desc& d, hipStream_t s, int bf16) 
   return 0;
 }
 
-int launch_gemm_f32(const coattn_gemm_desc& d, hipStream_t s) { return launch_gemm_impl(d, s, 0); }
+// fp32 GEMM: the f32 MFMA, or -- where it is measured faster -- the fp32-accurate 3-way bf16 split
+// (MODE 2) on the bf16 MFMA.  COATTN_GEMM_X3: 0 = never, 1 = auto (default), 2 = whenever eligible.
+// Auto takes the split only for operands that are both contiguous along k (P_q, the phrase-level
+// forward: 94 vs 69 TFLOP/s); with a transposing operand its strided dword loads cost more than the
+// shorter MFMA stream saves (P_v 203 vs 182 us, dW_q 117 vs 83 us).
+int launch_gemm_f32(const coattn_gemm_desc& d, hipStream_t s) {
+  static const int x3 = [] { const char* e = getenv("COATTN_GEMM_X3"); return e ? atoi(e) : 1; }();
+  const bool k_contig = d.a_sk == 1 && d.b_sk == 1;
+  if (x3 == 2 || (x3 == 1 && k_contig)) {
+    const int rc = launch_gemm_impl(d, s, 2);            // 0 launched, < 0 error, 1 not eligible
+    if (rc <= 0) return rc;
+  }
+  return launch_gemm_impl(d, s, 0);
+}
 
 // GEMM with bf16 MFMA inputs (fp32 storage, fp32 accumulate / output): every aligned shape through the
 // bf16 mode of the fast-path kernel; the unaligned channel-major projection (P_v at N = 49) through

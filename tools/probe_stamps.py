@@ -1,0 +1,62 @@
+"""Developer probe: where a workgroup of the fused affinity+softmax+reduce forward kernel spends its time.
+
+Needs a DIAGNOSTIC build of the library (never the shipped one):
+    hipcc ... -DCOATTN_STAMPS=1 -c coattn_fused.hip ; link as tools/ab/libcoattn_stamps.so
+    COATTN_LIB_PATH=$PWD/tools/ab/libcoattn_stamps.so python tools/probe_stamps.py
+In that build wave 0 of every workgroup writes the 100 MHz constant clock (s_memrealtime) at its phase
+boundaries into the forward workspace tail, which no other code reads.  Prints per-phase durations
+(mean / min / max over workgroups, microseconds) and the spread of start / end times.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import vqa_amd  # noqa: E402
+from vqa_amd import _lib  # noqa: E402
+from bench import synth_features  # noqa: E402
+
+B, N, T, d, L = (int(os.environ.get(k, v)) for k, v in (("B", 160), ("N", 196), ("T", 26), ("D", 512), ("L", 3)))
+dev = torch.device("cuda", 0)
+lib = _lib.load()
+torch.manual_seed(0)
+co = vqa_amd.ParallelCoAttention(d).to(dev)
+V, Qs = synth_features(B, N, T, d, dev, seed=77, L=L)
+ps = [t.detach().contiguous() for t in (co.W_v.weight, co.W_v.bias, co.W_q.weight, co.W_q.bias, co.w_v.weight,
+                                       co.w_v.bias, co.w_q.weight, co.w_q.bias)]
+sb, fb, _ = _lib.workspace_bytes(B, N, T, d, L)
+saved = torch.empty(sb // 4, device=dev)
+ws = torch.zeros(fb // 4, device=dev)
+v = torch.empty(L, B, d, device=dev)
+q = torch.empty(L, B, d, device=dev)
+qptr = (C.c_void_p * L)(*[t.data_ptr() for t in Qs])
+p = _lib.Params(*[t.data_ptr() for t in ps])
+stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+args = (V.data_ptr(), qptr, C.byref(p), v.data_ptr(), q.data_ptr(), saved.data_ptr(), ws.data_ptr(),
+        B, N, T, d, L, _lib.F32, 0, stream)
+_lib.check(lib.coattn_forward(*args), "coattn_forward")
+for _ in range(5):
+    _lib.check(lib.coattn_attention_forward(*args), "coattn_attention_forward")
+torch.cuda.synchronize()
+nblk = ((B + 7) // 8) * L * 8
+tail = ws[sb // 4:].view(torch.int64)[: nblk * 8].cpu().numpy().reshape(nblk, 8).astype(np.float64)
+live = tail[:, 0] > 0
+if not live.any():
+    sys.exit("no stamps found: this is not a -DCOATTN_STAMPS=1 build")
+st = tail[live] * 0.01                       # 100 MHz ticks -> microseconds
+t0 = st[:, 0].min()
+names = ["phase 1 MFMA loop (A = Q V^T)", "cross-wave sum + C = tanh", "phase 2 tile loop (H_v scores, H_q)",
+         "H_q epilogue", "softmaxes + q"]
+print("workgroups with stamps: %d; kernel span (first start -> last end): %.1f us" % (live.sum(), st[:, 5].max() - t0))
+print("start spread: %.1f us; end spread: %.1f us" % (st[:, 0].max() - t0, st[:, 5].max() - st[:, 5].min()))
+for k, nm in enumerate(names):
+    dt = st[:, k + 1] - st[:, k]
+    print("  %-40s mean %6.1f  min %6.1f  max %6.1f us" % (nm, dt.mean(), dt.min(), dt.max()))
+tot = st[:, 5] - st[:, 0]
+print("  %-40s mean %6.1f  min %6.1f  max %6.1f us" % ("whole workgroup", tot.mean(), tot.min(), tot.max()))
+for k in range(6):
+    print("  boundary %d reached at (rel. to first start): mean %6.1f  min %6.1f  max %6.1f us"
+          % (k, (st[:, k] - t0).mean(), (st[:, k] - t0).min(), (st[:, k] - t0).max()))

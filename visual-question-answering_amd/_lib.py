@@ -6,7 +6,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcoattn_hip.so")
+# COATTN_LIB_PATH: developer override for A/B timing of two builds; the product loads the in-tree library
+LIB_PATH = os.environ.get("COATTN_LIB_PATH") or os.path.join(_HERE, "libcoattn_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 # every symbol include/coattn.h declares

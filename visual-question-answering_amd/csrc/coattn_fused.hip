@@ -21,6 +21,25 @@
 // so that the L levels of one sample run on the same XCD (shared L2 for V and P_v).
 #include "fused.h"
 
+#include <stdlib.h>
+
+#ifndef COATTN_SPLIT_ASM
+#define COATTN_SPLIT_ASM 1
+#endif
+// Diagnostic build only (tools/probe_stamps.py, -DCOATTN_STAMPS=1): wave 0 of every workgroup writes the
+// 100 MHz constant clock at its phase boundaries into the (otherwise unused) forward workspace tail.
+#ifndef COATTN_STAMPS
+#define COATTN_STAMPS 0
+#endif
+#if COATTN_STAMPS
+#define CA_STAMP(k)                                                                                   \
+  do {                                                                                                \
+    if (threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime();  \
+  } while (0)
+#else
+#define CA_STAMP(k)
+#endif
+
 namespace {
 
 
@@ -35,11 +54,63 @@ struct FwdArgs {
   float* aq;             // [L][B][T]
   float* Hq;             // [L][B][T][d]
   float* q_out;          // [L][B][d]
+  unsigned long long* stamps;   // diagnostic builds only
   int B, N, T, d, L;
 };
 
 
-template <int NT, int NW>
+// fp32 -> three bf16 pieces with x = hi + mid + lo exactly (round to nearest even at every step).
+// Pairwise: one v_cvt_pk_bf16_f32 per piece and pair, the rounded halves come back as floats by a
+// shift / a mask (11 VALU ops per pair of elements).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bfv2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{a, b}), bfv2));
+}
+// a - b as ONE v_sub_f32: keeps the compiler from pairing the residual subtractions into v_pk_add_f32,
+// which costs more issue cycles beside MFMAs than two plain subtractions
+__device__ __forceinline__ float sub1(float a, float b) {
+#if COATTN_SPLIT_ASM
+  float r;
+  asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#else
+  return a - b;
+#endif
+}
+__device__ __forceinline__ void split3(const f32x8& v, bf16x8 (&p)[3]) {
+  u32x4v h, m, l;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = v[2 * i], b = v[2 * i + 1];
+    h[i] = cvt_pk_bf16(a, b);
+    const float ra = sub1(a, __builtin_bit_cast(float, h[i] << 16));
+    const float rb = sub1(b, __builtin_bit_cast(float, h[i] & 0xffff0000u));
+    m[i] = cvt_pk_bf16(ra, rb);
+    const float sa = sub1(ra, __builtin_bit_cast(float, m[i] << 16));
+    const float sb = sub1(rb, __builtin_bit_cast(float, m[i] & 0xffff0000u));
+    l[i] = cvt_pk_bf16(sa, sb);
+  }
+  p[0] = __builtin_bit_cast(bf16x8, h);
+  p[1] = __builtin_bit_cast(bf16x8, m);
+  p[2] = __builtin_bit_cast(bf16x8, l);
+}
+// c += a . b over 32 k with fp32 accuracy: the six partial products down to relative order 2^-16
+// (each bf16 x bf16 product is exact in the fp32 accumulator), smallest terms first
+__device__ __forceinline__ f32x4 mfma_x3(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], c, 0, 0, 0);
+  return c;
+}
+
+// X3: phase 1 (A = Q V^T) on the bf16 MFMA with the exact 3-way split of both operands (fp32-accurate,
+// 6/16 of the f32-MFMA time); 0 = v_mfma_f32_16x16x4_f32.
+template <int NT, int NW, int X3>
 __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdArgs a) {
   constexpr int NPAD = 16 * NT;
   constexpr int LD = NPAD + 4;                       // row stride of the LDS [t][n] images
@@ -53,6 +124,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
 
   int b, l;
   if (!block_to_pair(blockIdx.x, a.B, a.L, b, l)) return;
+  CA_STAMP(0);
   const int N = a.N, T = a.T, d = a.d;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, q4 = lane >> 4;           // MFMA column / k-quad (also C/D row quad)
@@ -89,6 +161,56 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[tt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (X3) {
+      // bf16 MFMA 16x16x32: lane (row/col = j, k-group q4) holds 8 consecutive k = channels 8*q4 .. 8*q4+7
+      // of a 32-channel step.  A operand: Q[t = 16tt + j][k]; B operand: V[k][n = 16 tile + j].
+      constexpr int RING = 4;                        // V tiles in flight (8 dwords each)
+      const int q_voff0 = (j * d + 8 * q4) * 4, q_voff1 = ((16 + j) * d + 8 * q4) * 4;
+      const int v_voff = (8 * q4 * N + j) * 4;
+      f32x8 vr[RING];                                // ring over the location tiles of the current step
+      f32x8 vn[RING - 1];                            // first tiles of the next step, loaded ahead
+      f32x8 qr[2];
+      bf16x8 qa[2][3];
+      // g enumerates the 32-channel steps of this wave: 4 per 128-channel slice
+      const int G = 4 * nsl;
+      auto chan0 = [&](int g) { return ((g >> 2) * NW + w) * 128 + 32 * (g & 3); };
+      auto load_q = [&](int k0) {
+        const f32x4 a0 = buf_load4(rs_q, q_voff0, k0 * 4), a1 = buf_load4(rs_q, q_voff0 + 16, k0 * 4);
+        const f32x4 b0 = buf_load4(rs_q, q_voff1, k0 * 4), b1 = buf_load4(rs_q, q_voff1 + 16, k0 * 4);
+        qr[0] = f32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        qr[1] = f32x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      };
+      auto load_v = [&](int k0, int t, f32x8& dst) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)                  // cols >= N: finite junk, zeroed when C is finalised
+          dst[i] = buf_load1(rs_v, v_voff + 64 * t, (k0 + i) * N * 4);
+      };
+      load_q(chan0(0));
+#pragma unroll
+      for (int t = 0; t < RING - 1; ++t) load_v(chan0(0), t, vr[t]);
+#pragma unroll 1
+      for (int g = 0; g < G; ++g) {
+        const int k0 = chan0(g), k1 = chan0(g + 1);
+        const bool more = g + 1 < G;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          if (t + RING - 1 < NT) load_v(k0, t + RING - 1, vr[(t + RING - 1) % RING]);
+          else if (more) load_v(k1, t + RING - 1 - NT, vn[t + RING - 1 - NT]);
+          if (t == 0) {
+            split3(qr[0], qa[0]);
+            split3(qr[1], qa[1]);
+            if (more) load_q(k1);
+          }
+          __builtin_amdgcn_sched_barrier(0);         // keep the prefetch ahead of this step's work
+          bf16x8 vb[3];
+          split3(vr[t % RING], vb);
+          acc[0][t] = mfma_x3(qa[0], vb, acc[0][t]);
+          acc[1][t] = mfma_x3(qa[1], vb, acc[1][t]);
+        }
+#pragma unroll
+        for (int t = 0; t < RING - 1; ++t) vr[t] = vn[t];
+      }
+    } else {
     constexpr int RING = 4;                          // V operand ring: 3 k-steps in flight
     float vb[RING][NT];
     f32x4 qa[2][2];
@@ -125,6 +247,8 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
       }
     }
     }
+    }
+    CA_STAMP(1);
     load_slice_operands(w * 128);
     // cross-wave sum in a fixed tree order through LDS; C/D layout: col = j, row = 4*q4 + r
     auto put = [&](float* slot) {
@@ -173,6 +297,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
       }
     }
     __syncthreads();
+    CA_STAMP(2);
   }
 
   // ------------------------------------------------------------------ phase 2: H_v scores, H_q
@@ -292,6 +417,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
     }
 #undef COATTN_INTERLEAVE
   }
+  CA_STAMP(3);
 
   // ------------------------------------------------------------------ phase 3
   // H_q epilogue: hq = tanh(P_q + acc); saved for backward; s_q partials.  Branch-free: rows t >= T
@@ -324,6 +450,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
     }
   }
   }   // channel slices
+  CA_STAMP(4);
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -388,6 +515,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
     for (int t = 0; t < kTRows; ++t) acc = fmaf(aqs[t], x[t], acc);
     a.q_out[pair * (size_t)d + dd] = acc;
   }
+  CA_STAMP(5);
 }
 
 // v_l[b][k] = sum_n a_v[l][b][n] V[b][k][n]   (model.py:391), all L levels in one pass over V.
@@ -426,20 +554,20 @@ __global__ __launch_bounds__(256) void attend_v_kernel(const float* V, const flo
   }
 }
 
-template <int NT, int NW>
+template <int NT, int NW, int X3>
 int launch_fwd(const FwdArgs& a, hipStream_t s) {
   constexpr int LD = 16 * NT + 4;
   constexpr int NSLOT = (NW / 2 > 2) ? NW / 2 : 2;
   const size_t lds = (size_t)(NSLOT * kSlotRows + kTRows) * LD * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(coattn_attn_fwd_kernel<NT, NW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(coattn_attn_fwd_kernel<NT, NW, X3>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const int groups = (a.B + 7) / 8;
   dim3 grid(groups * a.L * 8), block(NW * 64);
-  hipLaunchKernelGGL((coattn_attn_fwd_kernel<NT, NW>), grid, block, lds, s, a);
+  hipLaunchKernelGGL((coattn_attn_fwd_kernel<NT, NW, X3>), grid, block, lds, s, a);
   CA_CHECK_LAUNCH("coattn_attn_fwd");
   return 0;
 }
@@ -456,7 +584,6 @@ int fused_supported(int B, int N, int T, int d, int L) {
 int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, const float* const* Q,
                             const coattn_params* p, float* v_out, float* q_out, float* saved, float* ws,
                             hipStream_t s) {
-  (void)ws;
   CA_CHECK_ARG(fused_supported(B, N, T, d, L), "fused forward: unsupported shape");
   const SavedOff so = saved_off(B, N, T, d, L);
   FwdArgs a;
@@ -466,12 +593,17 @@ int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, c
   a.wv = (const float*)p->w_v; a.cv = (const float*)p->c_v; a.wq = (const float*)p->w_q; a.cq = (const float*)p->c_q;
   a.C = saved + so.C; a.av = saved + so.av; a.aq = saved + so.aq; a.Hq = saved + so.Hq;
   a.q_out = q_out;
+  a.stamps = COATTN_STAMPS ? reinterpret_cast<unsigned long long*>(ws) : nullptr;
   a.B = B; a.N = N; a.T = T; a.d = d; a.L = L;
   const bool small_n = N <= 64;
+  // COATTN_FWD_X3=0: phase 1 on the f32 MFMA (developer switch for ablations; default: bf16 3-way split)
+  static const int x3 = [] { const char* e = getenv("COATTN_FWD_X3"); return (e && e[0] == '0') ? 0 : 1; }();
   if (d % 512 == 0) {
-    CA_TRY(small_n ? (launch_fwd<4, 4>(a, s)) : (launch_fwd<13, 4>(a, s)));
+    if (x3) CA_TRY(small_n ? (launch_fwd<4, 4, 1>(a, s)) : (launch_fwd<13, 4, 1>(a, s)));
+    else CA_TRY(small_n ? (launch_fwd<4, 4, 0>(a, s)) : (launch_fwd<13, 4, 0>(a, s)));
   } else {
-    CA_TRY(small_n ? (launch_fwd<4, 2>(a, s)) : (launch_fwd<13, 2>(a, s)));
+    if (x3) CA_TRY(small_n ? (launch_fwd<4, 2, 1>(a, s)) : (launch_fwd<13, 2, 1>(a, s)));
+    else CA_TRY(small_n ? (launch_fwd<4, 2, 0>(a, s)) : (launch_fwd<13, 2, 0>(a, s)));
   }
   dim3 grid(d / 64, B);
   if (small_n)

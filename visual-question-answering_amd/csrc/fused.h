@@ -22,6 +22,9 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));      // MFMA 16x16x32 bf16 operand: 8 k-values per lane
+typedef __bf16 bfv8 __attribute__((ext_vector_type(8)));
 
 // buffer resource over [ptr, ptr + bytes): out-of-range loads return 0, stores are dropped
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, unsigned bytes) {

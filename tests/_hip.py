@@ -7,7 +7,9 @@ import torch
 import vqa_amd
 from vqa_amd import _lib
 
-IMPL = {"general": _lib.IMPL_GENERAL, "fused": _lib.IMPL_FUSED, "auto": _lib.IMPL_AUTO}
+IMPL = {"general": _lib.IMPL_GENERAL, "fused": _lib.IMPL_FUSED, "auto": _lib.IMPL_AUTO,
+        # fused kernels with the tile-pipelined forward schedule (csrc/coattn_fused2.hip) where the shape allows it
+        "fused_tiled": _lib.IMPL_FUSED | _lib.FLAG_FWD_TILED}
 
 
 def _al64(n):

@@ -21,6 +21,8 @@ def _impls(name):
     out = ["general"]
     if vqa_amd._lib.load().coattn_fused_supported(c["B"], c["N"], c["T"], c["d"], 3, 0):
         out.append("fused")
+        if c["d"] in (256, 512) and c["T"] <= 26:      # shapes the tile-pipelined forward schedule takes
+            out.append("fused_tiled")
     return out
 
 
@@ -107,7 +109,7 @@ def test_frozen_image_features_and_accumulate(impl):
         assert (cacc["d" + k] - (a["d" + k] + 1.0)).abs().max() < 1e-4 * max(1.0, a["d" + k].abs().max().item()), k
 
 
-@pytest.mark.parametrize("impl", ["general", "fused"])
+@pytest.mark.parametrize("impl", ["general", "fused", "fused_tiled"])
 def test_full_size_cfg2_properties(impl):
     """BASELINE config 2 (B=160, N=196, T=26, d=512): oracle on a sample subset + size-independent
     properties (attention maps are distributions; v inside the range of V; per-sample independence;
@@ -115,7 +117,7 @@ def test_full_size_cfg2_properties(impl):
     import vqa_amd
     from tests._hip import run_hip
     B, N, T, d = 160, 196, 26, 512
-    if impl == "fused" and not vqa_amd._lib.load().coattn_fused_supported(B, N, T, d, 3, 0):
+    if impl != "general" and not vqa_amd._lib.load().coattn_fused_supported(B, N, T, d, 3, 0):
         pytest.skip("no fused configuration for this shape")
     lens = sorted([26] + [3 + (7 * i) % 24 for i in range(B - 1)], reverse=True)
     P = O.make_params(d, 5)

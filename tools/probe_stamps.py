@@ -42,7 +42,7 @@ for _ in range(5):
     _lib.check(lib.coattn_attention_forward(*args), "coattn_attention_forward")
 torch.cuda.synchronize()
 nblk = ((B + 7) // 8) * L * 8
-tail = ws[sb // 4:].view(torch.int64)[: nblk * 8].cpu().numpy().reshape(nblk, 8).astype(np.float64)
+tail = ws[sb // 4:].view(torch.int64)[: nblk * 64].cpu().numpy().reshape(nblk, 64).astype(np.float64)
 live = tail[:, 0] > 0
 if not live.any():
     sys.exit("no stamps found: this is not a -DCOATTN_STAMPS=1 build")
@@ -60,3 +60,17 @@ print("  %-40s mean %6.1f  min %6.1f  max %6.1f us" % ("whole workgroup", tot.me
 for k in range(6):
     print("  boundary %d reached at (rel. to first start): mean %6.1f  min %6.1f  max %6.1f us"
           % (k, (st[:, k] - t0).mean(), (st[:, k] - t0).min(), (st[:, k] - t0).max()))
+
+# per-tile stamps of the tile-pipelined kernel (coattn_fused2.hip): loop top, steps done, barrier passed, C ready
+nt = (N + 15) // 16
+if st.shape[1] >= 8 + 4 * nt and (st[:, 8:8 + 4 * nt] > 0).all():
+    tl = st[:, 8:8 + 4 * nt].reshape(-1, nt, 4)
+    steps = tl[:, :, 1] - tl[:, :, 0]
+    bar = tl[:, :, 2] - tl[:, :, 1]
+    fin = tl[:, :, 3] - tl[:, :, 2]
+    print("per tile (mean over workgroups and tiles): 4 MFMA steps %.2f us, partial write + barrier %.2f us, "
+          "sum/tanh/C store %.2f us" % (steps.mean(), bar.mean(), fin.mean()))
+    lone = (st[:, 5] - st[:, 0]) < np.percentile(st[:, 5] - st[:, 0], 8)
+    print("  workgroups alone on their CU (fastest 8%%): steps %.2f, barrier %.2f, finish %.2f us"
+          % (steps[lone].mean(), bar[lone].mean(), fin[lone].mean()))
+    print("  steps per tile index:", " ".join("%.1f" % x for x in steps.mean(axis=0)))

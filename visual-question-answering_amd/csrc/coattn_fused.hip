@@ -34,7 +34,7 @@
 #if COATTN_STAMPS
 #define CA_STAMP(k)                                                                                   \
   do {                                                                                                \
-    if (threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime();  \
+    if (threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 64 + (k)] = __builtin_amdgcn_s_memrealtime();  \
   } while (0)
 #else
 #define CA_STAMP(k)
@@ -43,20 +43,6 @@
 namespace {
 
 
-struct FwdArgs {
-  const float* V;        // [B][d][N]
-  const float* Q[8];     // L x [B][T][d]
-  const float* Pv;       // [B][N][d]
-  const float* Pq;       // [L][B][T][d]
-  const float* wv; const float* cv; const float* wq; const float* cq;
-  float* C;              // [L][B][T][N]
-  float* av;             // [L][B][N]
-  float* aq;             // [L][B][T]
-  float* Hq;             // [L][B][T][d]
-  float* q_out;          // [L][B][d]
-  unsigned long long* stamps;   // diagnostic builds only
-  int B, N, T, d, L;
-};
 
 
 // fp32 -> three bf16 pieces with x = hi + mid + lo exactly (round to nearest even at every step).
@@ -583,7 +569,7 @@ int fused_supported(int B, int N, int T, int d, int L) {
 
 int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, const float* const* Q,
                             const coattn_params* p, float* v_out, float* q_out, float* saved, float* ws,
-                            hipStream_t s) {
+                            hipStream_t s, int tiled) {
   CA_CHECK_ARG(fused_supported(B, N, T, d, L), "fused forward: unsupported shape");
   const SavedOff so = saved_off(B, N, T, d, L);
   FwdArgs a;
@@ -596,9 +582,15 @@ int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, c
   a.stamps = COATTN_STAMPS ? reinterpret_cast<unsigned long long*>(ws) : nullptr;
   a.B = B; a.N = N; a.T = T; a.d = d; a.L = L;
   const bool small_n = N <= 64;
+  // the tile-pipelined kernel of coattn_fused2.hip: COATTN_FLAG_FWD_TILED, or COATTN_FWD_V2=1 in the environment
+  // (developer switch; measured slower than the phase-ordered kernel)
+  static const int v2env = [] { const char* e = getenv("COATTN_FWD_V2"); return (e && e[0] == '1') ? 1 : 0; }();
+  const int v2 = tiled || v2env;
   // COATTN_FWD_X3=0: phase 1 on the f32 MFMA (developer switch for ablations; default: bf16 3-way split)
   static const int x3 = [] { const char* e = getenv("COATTN_FWD_X3"); return (e && e[0] == '0') ? 0 : 1; }();
-  if (d % 512 == 0) {
+  if (v2 && fused2_supported(B, N, T, d, L)) {
+    CA_TRY(fused2_launch(a, s));
+  } else if (d % 512 == 0) {
     if (x3) CA_TRY(small_n ? (launch_fwd<4, 4, 1>(a, s)) : (launch_fwd<13, 4, 1>(a, s)));
     else CA_TRY(small_n ? (launch_fwd<4, 4, 0>(a, s)) : (launch_fwd<13, 4, 0>(a, s)));
   } else {

@@ -6,7 +6,7 @@ int fused_supported(int B, int N, int T, int d, int L);
 // everything after the projections (P_v, P_q already in `saved`)
 int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, const float* const* Q,
                             const coattn_params* p, float* v_out, float* q_out, float* saved, float* ws,
-                            hipStream_t s);
+                            hipStream_t s, int tiled);
 int fused_backward_supported(int B, int N, int T, int d, int L);
 int fused_backward(int B, int N, int T, int d, int L, const float* V, const float* const* Q, const coattn_params* p,
                    const float* saved, const float* gv, const float* gq, float* dV, float* const* dQ,
@@ -48,6 +48,26 @@ __device__ __forceinline__ bool block_to_pair(int bid, int B, int L, int& b, int
   l = slot % L;
   return b < B;
 }
+
+// arguments of the fused forward kernels (coattn_fused.hip, coattn_fused2.hip)
+struct FwdArgs {
+  const float* V;        // [B][d][N]
+  const float* Q[8];     // L x [B][T][d]
+  const float* Pv;       // [B][N][d]
+  const float* Pq;       // [L][B][T][d]
+  const float* wv; const float* cv; const float* wq; const float* cq;
+  float* C;              // [L][B][T][N]
+  float* av;             // [L][B][N]
+  float* aq;             // [L][B][T]
+  float* Hq;             // [L][B][T][d]
+  float* q_out;          // [L][B][d]
+  unsigned long long* stamps;   // diagnostic builds only
+  int B, N, T, d, L;
+};
+
+// tile-pipelined forward kernel (coattn_fused2.hip): d = 256 or 512, T <= 26, N <= 208
+int fused2_supported(int B, int N, int T, int d, int L);
+int fused2_launch(const FwdArgs& a, hipStream_t s);
 
 inline size_t fal64(size_t n) { return (n + 63) & ~(size_t)63; }
 

@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import dist as vdist
+from .mlp import CrossEntropyLoss
 from .modules import HierarchicalCoAttentionNet, VQABaselineNet
 
 PATH_VGG_WEIGHTS = None      # the reference hard-codes a local .pth (utils.py:15); none ships here
@@ -221,7 +222,7 @@ class Trainer:
                  bucket_mb: float = 16.0, encoder_runahead: bool = True):
         self.device = device or next(model.parameters()).device
         self.model = model
-        self.criterion = nn.CrossEntropyLoss()
+        self.criterion = CrossEntropyLoss()      # nn.CrossEntropyLoss() semantics (main.py:94); fused HIP kernel on CUDA
         self.optimizer = torch.optim.Adam(model.parameters(), lr)
         self.opt_lvl = opt_lvl
         if opt_lvl > 0 and hasattr(model, "co_attention"):      # AMP: projections on the bf16 MFMA as well

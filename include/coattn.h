@@ -157,7 +157,7 @@ typedef struct coattn_mlp_param_grads {
   void* dW_w; void* db_w; void* dW_p; void* db_p; void* dW_s; void* db_s; void* dW_h; void* db_h;
 } coattn_mlp_param_grads;
 
-/* saved: forward -> backward state (h_w, h_p, h_s); ws_fwd is only needed when saved is NULL (inference). */
+/* saved: forward -> backward state (h_w, h_p, h_s), NULL for inference; ws_fwd / ws_bwd: scratch (split-k partials). */
 int coattn_mlp_workspace_bytes(int B, int d, int mlp, int K, int dtype, size_t* saved, size_t* ws_fwd, size_t* ws_bwd);
 
 int coattn_mlp_forward(const void* v, const void* q, const coattn_mlp_params* p, void* logits, void* saved, void* ws,

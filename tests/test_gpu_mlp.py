@@ -34,8 +34,9 @@ def _rel(a, b):
 
 @pytest.mark.parametrize("shape", [(160, 512, 1024, 1001), (5, 64, 96, 7), (32, 128, 256, 3), (3, 20, 12, 5)],
                          ids=lambda s: "B%d_d%d_mlp%d_K%d" % s)
-def test_mlp_and_cross_entropy_vs_oracle(shape):
+def test_mlp_and_cross_entropy_vs_oracle(shape, monkeypatch):
     from vqa_amd.mlp import CrossEntropyLoss
+    monkeypatch.setenv("VQA_MLP_IMPL", "hip")
     B, d, mlp, K = shape
     mod, ref, v, q, labels = _case(B, d, mlp, K, 40 + d)
     vr, qr = v.double().requires_grad_(True), q.double().requires_grad_(True)
@@ -100,9 +101,10 @@ def test_cross_entropy_semantics():
     assert torch.isfinite(cross_entropy(z2, lab))
 
 
-def test_c_abi_errors_and_inference():
+def test_c_abi_errors_and_inference(monkeypatch):
     """Loud argument errors; inference (saved = NULL) equals the training-mode forward."""
     from vqa_amd import _lib
+    monkeypatch.setenv("VQA_MLP_IMPL", "hip")
     lib = _lib.load()
     assert lib.coattn_mlp_forward(None, None, None, None, None, None, 4, 64, 64, 3, _lib.F32, 0, None) < 0
     assert b"null" in lib.coattn_last_error()

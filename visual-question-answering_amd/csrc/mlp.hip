@@ -87,7 +87,52 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
   }
 }
 
+// out[i] = act( sum_s part[s][i] + bias[i % n] )   (fixed summation order; bias may be NULL)
+__global__ __launch_bounds__(256) void mlp_reduce_kernel(const float* __restrict__ part, int nparts, long mn, int n,
+                                                         const float* __restrict__ bias, int act,
+                                                         float* __restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= mn) return;
+  float v = 0.f;
+  for (int s = 0; s < nparts; ++s) v += part[(long)s * mn + i];
+  if (bias) v += bias[i % n];
+  if (act == 1) v = tanhf(v);
+  out[i] = v;
+}
+
 inline size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
+
+// The products of the head have only B (= 160) rows: a 128-row tile grid would be 8 .. 16 workgroups walking
+// the whole contraction.  They are split over k instead (64 .. 256 workgroups), partials summed in a fixed order
+// by mlp_reduce_kernel together with bias and tanh.
+constexpr int kMaxSplit = 16;
+int split_len(int K) {
+  int ks = 64;
+  if ((K + ks - 1) / ks > kMaxSplit) ks = ((K + kMaxSplit - 1) / kMaxSplit + 31) / 32 * 32;
+  return ks;
+}
+size_t part_floats(int B, int d, int mlp, int K) {
+  size_t n = (size_t)(d > mlp ? d : mlp);
+  if ((size_t)K > n) n = (size_t)K;
+  return al64((size_t)kMaxSplit * B * n);
+}
+int skinny_gemm(coattn_gemm_desc g, float* part, const float* bias, int act, float* out, hipStream_t s) {
+  const int ks = split_len(g.K);
+  const int S = (g.K + ks - 1) / ks;
+  if (S == 1) {
+    g.C = out; g.bias_n = bias; g.act = act;
+    return launch_gemm_f32(g, s);
+  }
+  const long mn = (long)g.M * g.N;
+  g.ksplit = ks; g.batch = S;
+  g.C = part; g.c_sz = mn; g.c_sm = g.N; g.c_sn = 1;
+  g.bias_n = nullptr; g.act = 0;
+  CA_TRY(launch_gemm_f32(g, s));
+  hipLaunchKernelGGL(mlp_reduce_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, s, part, S, mn, g.N, bias,
+                     act, out);
+  CA_CHECK_LAUNCH("mlp_reduce");
+  return 0;
+}
 
 struct MlpSaved { size_t hw, hp, hs, total; };
 MlpSaved plan_saved(int B, int d, int mlp) {
@@ -99,13 +144,14 @@ MlpSaved plan_saved(int B, int d, int mlp) {
   p.total = o;
   return p;
 }
-struct MlpBwd { size_t dhs, dhp, dhw, total; };
-MlpBwd plan_bwd(int B, int d, int mlp) {
+struct MlpBwd { size_t dhs, dhp, dhw, part, total; };
+MlpBwd plan_bwd(int B, int d, int mlp, int K) {
   MlpBwd p;
   size_t o = 0;
   p.dhs = o; o += al64((size_t)B * mlp);
   p.dhp = o; o += al64((size_t)B * d);
   p.dhw = o; o += al64((size_t)B * d);
+  p.part = o; o += part_floats(B, d, mlp, K);
   p.total = o;
   return p;
 }
@@ -119,7 +165,7 @@ int check_mlp_shape(int B, int d, int mlp, int K, int dtype) {
 
 // out[B, n_out] = act( sum_pieces X_i[B, d] . W[:, koff_i : koff_i + d]^T + bias ),  W row stride = w_ld
 int layer_forward(const float* const* X, const int* koff, int npieces, const float* W, int w_ld, const float* bias,
-                  float* out, int B, int d, int n_out, int act, hipStream_t s) {
+                  float* out, float* part, int B, int d, int n_out, int act, hipStream_t s) {
   coattn_gemm_desc g = {};
   for (int i = 0; i < npieces; ++i) {
     g.a_ptrs[i] = X[i];
@@ -127,12 +173,11 @@ int layer_forward(const float* const* X, const int* koff, int npieces, const flo
   }
   g.ptr_by_inner = 1;
   g.inner = npieces;
-  g.C = out; g.bias_n = bias; g.act = act;
   g.M = B; g.N = n_out; g.K = d; g.batch = 1;
   g.a_sm = d; g.a_sk = 1;
   g.b_sk = 1; g.b_sn = w_ld;
   g.c_sm = n_out; g.c_sn = 1;
-  return launch_gemm_f32(g, s);
+  return skinny_gemm(g, part, bias, act, out, s);
 }
 
 // dW[:, col0 : col0 + d] (+)= sum_pieces dz^T X_i      dz [B, n_out], X_i [B, d], dW row stride = w_ld
@@ -157,15 +202,15 @@ int layer_dweight(const float* dz, const float* const* X, int npieces, float* dW
 }
 
 // dx[B, n_in] = dz[B, n_out] . W[:, col0 : col0 + n_in]
-int layer_dinput(const float* dz, const float* W, int w_ld, int col0, float* dx, int B, int n_out, int n_in,
-                 hipStream_t s) {
+int layer_dinput(const float* dz, const float* W, int w_ld, int col0, float* dx, float* part, int B, int n_out,
+                 int n_in, hipStream_t s) {
   coattn_gemm_desc g = {};
-  g.A = dz; g.B = W + col0; g.C = dx;
+  g.A = dz; g.B = W + col0;
   g.M = B; g.N = n_in; g.K = n_out; g.batch = 1;
   g.a_sm = n_out; g.a_sk = 1;
   g.b_sk = w_ld; g.b_sn = 1;
   g.c_sm = n_in; g.c_sn = 1;
-  return launch_gemm_f32(g, s);
+  return skinny_gemm(g, part, nullptr, 0, dx, s);
 }
 
 int launch_dz_colsum(const float* dh, const float* h, float* dz, float* db, int R, int n, int accumulate,
@@ -181,8 +226,9 @@ extern "C" int coattn_mlp_workspace_bytes(int B, int d, int mlp, int K, int dtyp
                                           size_t* ws_bwd) {
   CA_TRY(check_mlp_shape(B, d, mlp, K, dtype));
   if (saved) *saved = plan_saved(B, d, mlp).total * sizeof(float);
-  if (ws_fwd) *ws_fwd = plan_saved(B, d, mlp).total * sizeof(float);      // inference: the hidden states live here
-  if (ws_bwd) *ws_bwd = plan_bwd(B, d, mlp).total * sizeof(float);
+  // forward scratch: split-k partials, then (inference, saved == NULL) the hidden states
+  if (ws_fwd) *ws_fwd = (part_floats(B, d, mlp, K) + plan_saved(B, d, mlp).total) * sizeof(float);
+  if (ws_bwd) *ws_bwd = plan_bwd(B, d, mlp, K).total * sizeof(float);
   return 0;
 }
 
@@ -190,12 +236,13 @@ extern "C" int coattn_mlp_forward(const void* v, const void* q, const coattn_mlp
                                   void* ws, int B, int d, int mlp, int K, int dtype, int flags, void* stream) {
   (void)flags;
   CA_TRY(check_mlp_shape(B, d, mlp, K, dtype));
-  CA_CHECK_ARG(v && q && p && logits && (saved || ws), "mlp_forward: null argument");
+  CA_CHECK_ARG(v && q && p && logits && ws, "mlp_forward: null argument");
   CA_CHECK_ARG(p->W_w && p->b_w && p->W_p && p->b_p && p->W_s && p->b_s && p->W_h && p->b_h,
                "mlp_forward: null parameter pointer");
   hipStream_t s = (hipStream_t)stream;
   const MlpSaved sp = plan_saved(B, d, mlp);
-  float* st = saved ? (float*)saved : (float*)ws;
+  float* part = (float*)ws;
+  float* st = saved ? (float*)saved : (float*)ws + part_floats(B, d, mlp, K);
   float* hw = st + sp.hw;
   float* hp = st + sp.hp;
   float* hs = st + sp.hs;
@@ -205,24 +252,24 @@ extern "C" int coattn_mlp_forward(const void* v, const void* q, const coattn_mlp
   const int k0[3] = {0, 0, d};
   {
     const float* X[2] = {Q, V};                                        // word level
-    CA_TRY(layer_forward(X, k0, 2, (const float*)p->W_w, d, (const float*)p->b_w, hw, B, d, d, 1, s));
+    CA_TRY(layer_forward(X, k0, 2, (const float*)p->W_w, d, (const float*)p->b_w, hw, part, B, d, d, 1, s));
   }
   {
     const float* X[3] = {Q + Bd, V + Bd, hw};                          // phrase level
-    CA_TRY(layer_forward(X, k0, 3, (const float*)p->W_p, 2 * d, (const float*)p->b_p, hp, B, d, d, 1, s));
+    CA_TRY(layer_forward(X, k0, 3, (const float*)p->W_p, 2 * d, (const float*)p->b_p, hp, part, B, d, d, 1, s));
   }
   {
     const float* X[3] = {Q + 2 * Bd, V + 2 * Bd, hp};                  // sentence level
-    CA_TRY(layer_forward(X, k0, 3, (const float*)p->W_s, 2 * d, (const float*)p->b_s, hs, B, d, mlp, 1, s));
+    CA_TRY(layer_forward(X, k0, 3, (const float*)p->W_s, 2 * d, (const float*)p->b_s, hs, part, B, d, mlp, 1, s));
   }
   {
     coattn_gemm_desc g = {};
-    g.A = hs; g.B = p->W_h; g.C = logits; g.bias_n = p->b_h;
+    g.A = hs; g.B = p->W_h;
     g.M = B; g.N = K; g.K = mlp; g.batch = 1;
     g.a_sm = mlp; g.a_sk = 1;
     g.b_sk = 1; g.b_sn = mlp;
     g.c_sm = K; g.c_sn = 1;
-    CA_TRY(launch_gemm_f32(g, s));
+    CA_TRY(skinny_gemm(g, part, (const float*)p->b_h, 0, (float*)logits, s));
   }
   return 0;
 }
@@ -238,7 +285,7 @@ extern "C" int coattn_mlp_backward(const void* v, const void* q, const coattn_ml
                "mlp_backward: null parameter-gradient pointer");
   hipStream_t s = (hipStream_t)stream;
   const MlpSaved sp = plan_saved(B, d, mlp);
-  const MlpBwd bp = plan_bwd(B, d, mlp);
+  const MlpBwd bp = plan_bwd(B, d, mlp, K);
   const float* st = (const float*)saved;
   const float* hw = st + sp.hw;
   const float* hp = st + sp.hp;
@@ -247,6 +294,7 @@ extern "C" int coattn_mlp_backward(const void* v, const void* q, const coattn_ml
   float* dhs = w + bp.dhs;
   float* dhp = w + bp.dhp;
   float* dhw = w + bp.dhw;
+  float* part = w + bp.part;
   const float* V = (const float*)v;
   const float* Q = (const float*)q;
   const float* G = (const float*)g_logits;
@@ -257,7 +305,7 @@ extern "C" int coattn_mlp_backward(const void* v, const void* q, const coattn_ml
     const float* X[1] = {hs};
     CA_TRY(layer_dweight(G, X, 1, (float*)pg->dW_h, mlp, 0, B, mlp, K, accumulate, s));
     CA_TRY(launch_dz_colsum(G, nullptr, nullptr, (float*)pg->db_h, B, K, accumulate, s));
-    CA_TRY(layer_dinput(G, (const float*)p->W_h, mlp, 0, dhs, B, K, mlp, s));
+    CA_TRY(layer_dinput(G, (const float*)p->W_h, mlp, 0, dhs, part, B, K, mlp, s));
   }
   // sentence level: h_s = tanh(W_s [x_s | h_p] + b_s)
   {
@@ -266,8 +314,8 @@ extern "C" int coattn_mlp_backward(const void* v, const void* q, const coattn_ml
     CA_TRY(layer_dweight(dhs, X, 2, (float*)pg->dW_s, 2 * d, 0, B, d, mlp, accumulate, s));
     const float* H[1] = {hp};
     CA_TRY(layer_dweight(dhs, H, 1, (float*)pg->dW_s, 2 * d, d, B, d, mlp, accumulate, s));
-    if (gx) CA_TRY(layer_dinput(dhs, (const float*)p->W_s, 2 * d, 0, gx + 2 * Bd, B, mlp, d, s));
-    CA_TRY(layer_dinput(dhs, (const float*)p->W_s, 2 * d, d, dhp, B, mlp, d, s));
+    if (gx) CA_TRY(layer_dinput(dhs, (const float*)p->W_s, 2 * d, 0, gx + 2 * Bd, part, B, mlp, d, s));
+    CA_TRY(layer_dinput(dhs, (const float*)p->W_s, 2 * d, d, dhp, part, B, mlp, d, s));
   }
   // phrase level: h_p = tanh(W_p [x_p | h_w] + b_p)
   {
@@ -276,15 +324,15 @@ extern "C" int coattn_mlp_backward(const void* v, const void* q, const coattn_ml
     CA_TRY(layer_dweight(dhp, X, 2, (float*)pg->dW_p, 2 * d, 0, B, d, d, accumulate, s));
     const float* H[1] = {hw};
     CA_TRY(layer_dweight(dhp, H, 1, (float*)pg->dW_p, 2 * d, d, B, d, d, accumulate, s));
-    if (gx) CA_TRY(layer_dinput(dhp, (const float*)p->W_p, 2 * d, 0, gx + Bd, B, d, d, s));
-    CA_TRY(layer_dinput(dhp, (const float*)p->W_p, 2 * d, d, dhw, B, d, d, s));
+    if (gx) CA_TRY(layer_dinput(dhp, (const float*)p->W_p, 2 * d, 0, gx + Bd, part, B, d, d, s));
+    CA_TRY(layer_dinput(dhp, (const float*)p->W_p, 2 * d, d, dhw, part, B, d, d, s));
   }
   // word level: h_w = tanh(W_w x_w + b_w)
   {
     CA_TRY(launch_dz_colsum(dhw, hw, dhw, (float*)pg->db_w, B, d, accumulate, s));
     const float* X[2] = {Q, V};
     CA_TRY(layer_dweight(dhw, X, 2, (float*)pg->dW_w, d, 0, B, d, d, accumulate, s));
-    if (gx) CA_TRY(layer_dinput(dhw, (const float*)p->W_w, d, 0, gx, B, d, d, s));
+    if (gx) CA_TRY(layer_dinput(dhw, (const float*)p->W_w, d, 0, gx, part, B, d, d, s));
   }
   return 0;
 }

@@ -53,7 +53,7 @@ class _MlpFn(torch.autograd.Function):
         dev = v.device
         logits = torch.empty((B, K), device=dev, dtype=torch.float32)
         saved = torch.empty(sb // 4, device=dev, dtype=torch.float32) if need_grad else None
-        ws = None if need_grad else torch.empty(fb // 4, device=dev, dtype=torch.float32)
+        ws = torch.empty(fb // 4, device=dev, dtype=torch.float32)
         p = _lib.MlpParams(*[t.data_ptr() for t in ps])
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         with torch.cuda.device(dev):

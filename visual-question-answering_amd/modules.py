@@ -261,8 +261,9 @@ class MLPClassifier(nn.Module):
         self.W_h = nn.Linear(mlp_dim, K)
 
     def forward(self, x_img_feats, x_ques_feats):
-        if x_img_feats[0].is_cuda and os.environ.get("VQA_MLP_IMPL", "hip") != "stock":
-            # MI355X path (csrc/mlp.hip): same parameters, same values; stock modules below on CPU
+        if x_img_feats[0].is_cuda and os.environ.get("VQA_MLP_IMPL", "stock") == "hip":
+            # MI355X path (csrc/mlp.hip): same parameters, same values.  Opt-in: at B = 160 its 30
+            # launch-latency-bound kernels take longer on the GPU than the stock modules' 
             from .mlp import as_level_stack, mlp_classify
             return mlp_classify(as_level_stack(x_img_feats), as_level_stack(x_ques_feats), self.W_w.weight,
                                 self.W_w.bias, self.W_p.weight, self.W_p.bias, self.W_s.weight, self.W_s.bias,

@@ -231,13 +231,21 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
   constexpr int LDK = BK + 1;              // [m][k] / [n][k] image row stride
   constexpr int ASZ = AM ? BK * LDM : BM * LDK;
   constexpr int BSZ = BN_ ? BK * LDN : BN * LDK;
-  constexpr int LDR = 40;                  // bf16 image row stride (elements)
-  constexpr int LDS_BYTES = BF ? NIMG * (BM + BN) * LDR * 2 : (ASZ + BSZ) * 4;
+  constexpr int LDR = 40;                  // bf16 [row][k] image row stride (elements)
+  // MODE 2, operand contiguous along its tile index (A along m / B along n): the pieces are staged as [k][m]
+  // bf16 images straight from the coalesced float4 loads (one 8-byte LDS write per piece) and the MFMA
+  // fragments (8 consecutive k of one row) are read with ds_read_b64_tr_b16, the transposing LDS read of
+  // gfx950.  Row stride BM + 32: conflict-free for both the writes and the transposed reads.
+  constexpr bool TRA = MODE == 2 && AM, TRB = MODE == 2 && BN_;
+  constexpr int LDTA = BM + 32, LDTB = BN + 32;
+  constexpr int AIMG = TRA ? BK * LDTA : BM * LDR;            // elements of one A image
+  constexpr int BIMG = TRB ? BK * LDTB : BN * LDR;
+  constexpr int LDS_BYTES = BF ? NIMG * (AIMG + BIMG) * 2 : (ASZ + BSZ) * 4;
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   float* const As = reinterpret_cast<float*>(smem);
   float* const Bs = As + ASZ;
-  short* const Ah = reinterpret_cast<short*>(smem);          // NIMG images of BM rows
-  short* const Bh = Ah + NIMG * BM * LDR;                    // NIMG images of BN rows
+  short* const Ah = reinterpret_cast<short*>(smem);          // NIMG images of A
+  short* const Bh = Ah + NIMG * AIMG;                        // NIMG images of B
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -283,11 +291,11 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
   for (int i = 0; i < FA; ++i) {
     const int idx = tid + 256 * i;                  // float4 index in the BM x 32 tile
     int m, k;
-    if (AM && BF) { m = idx % BM; k = (idx / BM) * 4; }       // bf16 images are [row][k]: lanes run along m
+    if (AM && BF && !TRA) { m = idx % BM; k = (idx / BM) * 4; }   // bf16 [row][k] images: lanes run along m
     else if (AM) { k = idx / (BM / 4); m = (idx % (BM / 4)) * 4; }   // (coalesced dword loads), 4 consecutive k per thread
     else { m = idx >> 3; k = (idx & 7) * 4; }
     a_k[i] = k;
-    a_lds[i] = BF ? m * LDR + k : (AM ? k * LDM + m : m * LDK + k);
+    a_lds[i] = TRA ? k * LDTA + m : (BF ? m * LDR + k : (AM ? k * LDM + m : m * LDK + k));
     a_ok[i] = (m0 + m) < g.M;                      // M % 4 == 0 on this path: whole float4 in or out
     a_off[i] = a_ok[i] ? (int)(row_off(m0 + m, g.a_sm, g.a_mdiv, g.a_sdiv) + (long)k * g.a_sk) : 0;
   }
@@ -297,11 +305,11 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
   for (int i = 0; i < 4; ++i) {
     const int idx = tid + 256 * i;
     int n, k;
-    if (BN_ && BF) { n = idx % BN; k = (idx / BN) * 4; }
+    if (BN_ && BF && !TRB) { n = idx % BN; k = (idx / BN) * 4; }
     else if (BN_) { k = idx >> 5; n = (idx & 31) * 4; }
     else { n = idx >> 3; k = (idx & 7) * 4; }
     b_k[i] = k;
-    b_lds[i] = BF ? n * LDR + k : (BN_ ? k * LDN + n : n * LDK + k);
+    b_lds[i] = TRB ? k * LDTB + n : (BF ? n * LDR + k : (BN_ ? k * LDN + n : n * LDK + k));
     b_ok[i] = (n0 + n) < g.N;
     b_off[i] = b_ok[i] ? (int)((long)k * g.b_sk + (long)(n0 + n) * g.b_sn) : 0;
   }
@@ -332,7 +340,7 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
   auto load_regs = [&](const float* Ab, const float* Bb, int klim) {     // K range % 4 == 0 on this path
 #pragma unroll
     for (int i = 0; i < FA; ++i) {
-      if constexpr (AM && BF) {                                  // 4 consecutive k of one row: strided dword loads
+      if constexpr (AM && BF && !TRA) {                          // 4 consecutive k of one row: strided dword loads
         const bool ok = a_ok[i] && a_k[i] < klim;
 #pragma unroll
         for (int e = 0; e < 4; ++e) ra[i][e] = ok ? Ab[a_off[i] + (long)e * g.a_sk] : 0.f;
@@ -342,7 +350,7 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if constexpr (BN_ && BF) {
+      if constexpr (BN_ && BF && !TRB) {
         const bool ok = b_ok[i] && b_k[i] < klim;
 #pragma unroll
         for (int e = 0; e < 4; ++e) rb[i][e] = ok ? Bb[b_off[i] + (long)e * g.b_sk] : 0.f;
@@ -354,29 +362,21 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
   auto store_step = [&]() {
     if constexpr (MODE == 2) {
       // exact 3-way split of each element, one image per piece
-      auto put = [&](short* img, int rows, int off, bool transposed, const f32x4& v) {
+      // (a float4 holds 4 consecutive k of one row for [row][k] images, 4 consecutive rows of one k for [k][row])
+      auto put = [&](short* img, int piece, int off, const f32x4& v) {
         const bfv4 h = __builtin_convertvector(v, bfv4);
         const f32x4 r1 = v - __builtin_convertvector(h, f32x4);
         const bfv4 m = __builtin_convertvector(r1, bfv4);
         const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);
         const bfv4 l = __builtin_convertvector(r2, bfv4);
-        const bfv4 pc[3] = {h, m, l};
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          short* dst = img + p * rows * LDR + off;
-          if (transposed) {
-            const bf16x4 sv = __builtin_bit_cast(bf16x4, pc[p]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) dst[e * LDR] = sv[e];
-          } else {
-            *reinterpret_cast<bfv4*>(dst) = pc[p];
-          }
-        }
+        *reinterpret_cast<bfv4*>(img + off) = h;
+        *reinterpret_cast<bfv4*>(img + piece + off) = m;
+        *reinterpret_cast<bfv4*>(img + 2 * piece + off) = l;
       };
 #pragma unroll
-      for (int i = 0; i < FA; ++i) put(Ah, BM, a_lds[i], false, ra[i]);
+      for (int i = 0; i < FA; ++i) put(Ah, AIMG, a_lds[i], ra[i]);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) put(Bh, BN, b_lds[i], false, rb[i]);
+      for (int i = 0; i < 4; ++i) put(Bh, BIMG, b_lds[i], rb[i]);
       return;
     }
     if constexpr (MODE == 1) {
@@ -449,14 +449,29 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
 #pragma unroll
       for (int ks = 0; ks < BK; ks += 16) {
         bf16x8 ah[3][TM], bh[3][2];
+        // transposed fragment read of a [k][row] image: each 16-lane group fetches a 4 (k) x 16 (rows) block,
+        // lane 4q+p of the group supplies the address of block row q, columns 4p .. 4p+3, and receives the 4 k
+        // of row (lane & 15); two reads give the 8 consecutive k (8 lh .. 8 lh + 7) of MFMA row li
+        auto read_tr = [&](const short* img, int ld, int row0) -> bf16x8 {
+          const short* ptr = img + (ks + 8 * lh + ((lane & 15) >> 2)) * ld + row0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) bf16x4*)(const_cast<short*>(ptr)));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) bf16x4*)(const_cast<short*>(ptr + 4 * ld)));
+          return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
-          for (int i = 0; i < TM; ++i)
-            ah[p][i] = *reinterpret_cast<const bf16x8*>(&Ah[p * BM * LDR + (wr * (TM * 32) + i * 32 + li) * LDR + ks + 8 * lh]);
+          for (int i = 0; i < TM; ++i) {
+            if constexpr (TRA) ah[p][i] = read_tr(Ah + p * AIMG, LDTA, wr * (TM * 32) + i * 32);
+            else ah[p][i] = *reinterpret_cast<const bf16x8*>(&Ah[p * AIMG + (wr * (TM * 32) + i * 32 + li) * LDR + ks + 8 * lh]);
+          }
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-            bh[p][j] = *reinterpret_cast<const bf16x8*>(&Bh[p * BN * LDR + (wc * 64 + j * 32 + li) * LDR + ks + 8 * lh]);
+          for (int j = 0; j < 2; ++j) {
+            if constexpr (TRB) bh[p][j] = read_tr(Bh + p * BIMG, LDTB, wc * 64 + j * 32);
+            else bh[p][j] = *reinterpret_cast<const bf16x8*>(&Bh[p * BIMG + (wc * 64 + j * 32 + li) * LDR + ks + 8 * lh]);
+          }
         }
         // smallest terms first: lo*hi, hi*lo, mid*mid, then mid*hi, hi*mid, then hi*hi
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
@@ -800,15 +815,14 @@ static int launch_gemm_impl(const coattn_gemm_desc& d, hipStream_t s, int bf16) 
   return 0;
 }
 
-// fp32 GEMM: the f32 MFMA, or -- where it is measured faster -- the fp32-accurate 3-way bf16 split
-// (MODE 2) on the bf16 MFMA.  COATTN_GEMM_X3: 0 = never, 1 = auto (default), 2 = whenever eligible.
-// Auto takes the split only for operands that are both contiguous along k (P_q, the phrase-level
-// forward: 94 vs 69 TFLOP/s); with a transposing operand its strided dword loads cost more than the
-// shorter MFMA stream saves (P_v 203 vs 182 us, dW_q 117 vs 83 us).
+// fp32 GEMM: the fp32-accurate 3-way bf16 split (MODE 2) on the bf16 MFMA for every shape the aligned fast path
+// takes, the f32 MFMA otherwise.  COATTN_GEMM_X3: 0 = never, 1 = auto (default) = whenever eligible.
+// With the [k][row] bf16 images + transposed LDS reads for operands contiguous along their tile index the
+// split is the faster mode on all layouts of the path (P_v 188 -> 128 us, dW_v 172 -> 124, dQ projection
+// 87 -> 60, dW_q 73 -> 57, P_q 87 -> 62); before that it lost on transposing operands (P_v 203 vs 182 us).
 int launch_gemm_f32(const coattn_gemm_desc& d, hipStream_t s) {
   static const int x3 = [] { const char* e = getenv("COATTN_GEMM_X3"); return e ? atoi(e) : 1; }();
-  const bool k_contig = d.a_sk == 1 && d.b_sk == 1;
-  if (x3 == 2 || (x3 == 1 && k_contig)) {
+  if (x3 >= 1) {
     const int rc = launch_gemm_impl(d, s, 2);            // 0 launched, < 0 error, 1 not eligible
     if (rc <= 0) return rc;
   }

@@ -20,7 +20,7 @@ def one(pattern):
     hits = glob.glob(os.path.join(SRC, pattern), recursive=True)
     if not hits:
         raise SystemExit("missing " + pattern)
-    return hits[0]
+    return max(hits, key=os.path.getmtime)      # gpurun merges into gpurun_out/ without removing older runs' files
 
 
 line = [l for l in open(os.path.join(SRC, "bench.json")) if l.startswith("{")][-1]

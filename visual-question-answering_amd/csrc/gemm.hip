@@ -536,22 +536,35 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
 
   float* Cb = g.c_ptrs[0] ? g.c_ptrs[z & 7] : g.C + (long)z * g.c_sz;
   const float* Cinb = g.cin_ptrs[0] ? g.cin_ptrs[z & 7] : (g.Cin ? g.Cin + (long)z * g.cin_sz : nullptr);
+  // per-thread column terms once (2 columns), row terms once per row (16 TM rows): an element costs an add, the
+  // optional terms and its store
+  long ccol[2], cincol[2];
+  float bn[2];
+  bool cok[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wc * 64 + j * 32 + li;
+    cok[j] = col < g.N;
+    bn[j] = (g.bias_n && cok[j]) ? g.bias_n[col] : 0.f;
+    ccol[j] = (long)col * g.c_sn;
+    cincol[j] = (long)col * g.cin_sn;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wc * 64 + j * 32 + li;
-      const float bn = (g.bias_n && col < g.N) ? g.bias_n[col] : 0.f;
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wr * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row >= g.M) continue;
+      float* crow = Cb + row_off(row, g.c_sm, g.c_mdiv, g.c_sdiv);
+      const float* cinrow = Cinb ? Cinb + row_off(row, g.cin_sm, g.cin_mdiv, g.cin_sdiv) : nullptr;
+      const float bm = g.bias_m ? g.bias_m[row] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wr * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < g.M && col < g.N) {
-          float v = acc[i][j][r] + bn;
-          if (g.bias_m) v += g.bias_m[row];
-          if (Cinb) v += g.beta * Cinb[row_off(row, g.cin_sm, g.cin_mdiv, g.cin_sdiv) + (long)col * g.cin_sn];
-          if (g.act == 1) v = tanh_outlined(v);
-          Cb[row_off(row, g.c_sm, g.c_mdiv, g.c_sdiv) + (long)col * g.c_sn] = v;
-        }
+      for (int j = 0; j < 2; ++j) {
+        if (!cok[j]) continue;
+        float v = acc[i][j][r] + bn[j] + bm;
+        if (cinrow) v += g.beta * cinrow[cincol[j]];
+        if (g.act == 1) v = tanh_outlined(v);
+        crow[ccol[j]] = v;
       }
     }
 }

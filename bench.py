@@ -14,6 +14,8 @@ contract fields it carries
                 against 8 TB/s HBM
   cpu_baseline  the CPU oracle port (oracle/net_oracle.py) of the same train step, timed on the
                 host cores on a bounded sample (rank 0, N=1 only)
+  roofline_projection  the MFMA-bound P_v projection GEMM, timed the same way: fp32-equivalent TFLOP/s
+                against the fp32 matrix peak and the issued bf16 flops against the dense bf16 peak
   hot_path      isolated co-attention (+MLP+CE) fwd+bwd rates on device-resident features, N=196
                 and N=49, and the per-call forward / backward times of the HIP path.
 """
@@ -199,6 +201,44 @@ def roofline_leg(device, B=160, N=196, T=26, d=512, L=3, iters=50):
             "algorithmic_bytes": alg}
 
 
+def projection_leg(device, B=160, N=196, d=512, iters=50):
+    """The dominant MFMA-bound kernel of the path: P_v = V W_v^T + b_v (model.py:380/384, once per sample), read in
+    place from the channel-major V.  Algorithmic flops 2 B N d^2 / average launch time (HIP events
+    on the launch stream).  The kernel computes every fp32 product as six bf16 x bf16 partial products of an
+    exact 3-way split on the bf16 MFMA (fp32-accurate), so two fractions are reported: fp32-equivalent flops
+    against the fp32 matrix peak (157.3 TFLOP/s), and the issued bf16 flops (6x) against the dense bf16 peak."""
+    import ctypes as C
+    from vqa_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    V = torch.randn(B, d, N, generator=g).to(device)
+    W = (torch.randn(d, d, generator=g) / d ** 0.5).to(device)
+    bias = torch.zeros(d, device=device)
+    Pv = torch.empty(B * N, d, device=device)
+    gd = _lib.GemmDesc()
+    gd.A, gd.B, gd.C, gd.bias_n = V.data_ptr(), W.data_ptr(), Pv.data_ptr(), bias.data_ptr()
+    gd.M, gd.N, gd.K, gd.batch = B * N, d, d, 1
+    gd.a_sm, gd.a_sk, gd.a_mdiv, gd.a_sdiv = 1, N, N, d * N
+    gd.b_sk, gd.b_sn, gd.c_sm, gd.c_sn = 1, d, d, 1
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(5):
+        _lib.check(lib.coattn_gemm_f32(C.byref(gd), stream), "coattn_gemm_f32")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        lib.coattn_gemm_f32(C.byref(gd), stream)
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / iters
+    flop = 2.0 * B * N * d * d
+    split = os.environ.get("COATTN_GEMM_X3", "1") != "0" and N % 4 == 0
+    ach = flop / t / 1e12
+    return {"bound": "mfma", "achieved": round(ach, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4),
+            "traffic": None, "kernel": "P_v projection GEMM (gemm_f32_vec_kernel%s)" % (", 3-way bf16 split" if split else ""),
+            "shape": {"M": B * N, "N": d, "K": d}, "avg_launch_us": round(t * 1e6, 2), "algorithmic_flops": flop,
+            "bf16_mfma_frac": round(6.0 * ach / 2500.0, 4) if split else None}
+
+
 def host_cores() -> int:
     """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
     from vqa_amd.train import usable_cpus
@@ -237,7 +277,8 @@ def main():
     from vqa_amd import train as T
     if args.only:
         dev = torch.device("cuda", 0)
-        res = roofline_leg(dev) if args.only == "roofline" else [hot_path_leg(dev, 196), hot_path_leg(dev, 49)]
+        res = ({"roofline": roofline_leg(dev), "roofline_projection": projection_leg(dev)} if args.only == "roofline"
+               else [hot_path_leg(dev, 196), hot_path_leg(dev, 49)])
         print(json.dumps(res))
         return
     torch.set_num_threads(max(1, min(4, host_cores())))   # the step is GPU work; do not oversubscribe host cores per rank
@@ -301,6 +342,7 @@ def main():
         # the same kernel at the timed step's own grid (224x224 -> 7x7 = 49 locations)
         out["roofline_at_step_shape"] = roofline_leg(device, B=args.batch, N=(args.image_size // 32) ** 2,
                                                      T=args.seq_len)
+        out["roofline_projection"] = projection_leg(device)
         if world == 1:
             out["hot_path"] = [hot_path_leg(device, 196), hot_path_leg(device, 49)]
     if rank == 0:

@@ -35,7 +35,8 @@ vals = {}
 for f in glob.glob(os.path.join(SRC, "pmc_mfma", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        kern = "coattn_attn_fwd_kernel" if "attn_fwd" in k else ("attend_v_kernel" if "attend_v" in k else None)
+        kern = ("coattn_attn_fwd_kernel" if "attn_fwd" in k else "attend_v_kernel" if "attend_v" in k
+                else "gemm_f32_vec_kernel (P_v projection)" if "gemm_f32_vec" in k else None)
         if kern:
             vals.setdefault(kern, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 if vals:

@@ -218,6 +218,16 @@ __device__ __forceinline__ short f2bf(float x) {            // round to nearest 
 // 2^-23 of |x||y|, the size of one fp32 rounding.  The bf16 MFMA has 16x the fp32 MFMA rate, so the
 // six products cost 6/16 of the fp32 MFMA time.
 typedef __bf16 bfv4 __attribute__((ext_vector_type(4)));
+typedef float f32x2g __attribute__((ext_vector_type(2)));
+typedef __bf16 bfv2g __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {      // one v_cvt_pk_bf16_f32 (round to nearest even)
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2g{a, b}), bfv2g));
+}
+__device__ __forceinline__ float sub1(float a, float b) {                 // one v_sub_f32 (never paired into v_pk_add_f32)
+  float r;
+  asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 
 template <bool AM, bool BN_, int BM, int MODE = 0>
 __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
@@ -364,14 +374,24 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
       // exact 3-way split of each element, one image per piece
       // (a float4 holds 4 consecutive k of one row for [row][k] images, 4 consecutive rows of one k for [k][row])
       auto put = [&](short* img, int piece, int off, const f32x4& v) {
-        const bfv4 h = __builtin_convertvector(v, bfv4);
-        const f32x4 r1 = v - __builtin_convertvector(h, f32x4);
-        const bfv4 m = __builtin_convertvector(r1, bfv4);
-        const f32x4 r2 = r1 - __builtin_convertvector(m, f32x4);
-        const bfv4 l = __builtin_convertvector(r2, bfv4);
-        *reinterpret_cast<bfv4*>(img + off) = h;
-        *reinterpret_cast<bfv4*>(img + piece + off) = m;
-        *reinterpret_cast<bfv4*>(img + 2 * piece + off) = l;
+        // pairwise: one v_cvt_pk_bf16_f32 per piece and pair; the rounded halves come back as floats by a
+        // shift / a mask, the residuals by single v_sub_f32 (11 VALU ops per pair of elements)
+        unsigned h[2], m[2], l[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float a = v[2 * e], b = v[2 * e + 1];
+          h[e] = cvt_pk_bf16(a, b);
+          const float ra_ = sub1(a, __builtin_bit_cast(float, h[e] << 16));
+          const float rb_ = sub1(b, __builtin_bit_cast(float, h[e] & 0xffff0000u));
+          m[e] = cvt_pk_bf16(ra_, rb_);
+          const float sa_ = sub1(ra_, __builtin_bit_cast(float, m[e] << 16));
+          const float sb_ = sub1(rb_, __builtin_bit_cast(float, m[e] & 0xffff0000u));
+          l[e] = cvt_pk_bf16(sa_, sb_);
+        }
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u32x2*>(img + off) = u32x2{h[0], h[1]};
+        *reinterpret_cast<u32x2*>(img + piece + off) = u32x2{m[0], m[1]};
+        *reinterpret_cast<u32x2*>(img + 2 * piece + off) = u32x2{l[0], l[1]};
       };
 #pragma unroll
       for (int i = 0; i < FA; ++i) put(Ah, AIMG, a_lds[i], ra[i]);

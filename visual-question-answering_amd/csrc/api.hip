@@ -16,7 +16,7 @@ void coattn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int coattn_version(void) { return 100; }
+extern "C" int coattn_version(void) { return 200; }   // 0.2.0: + coattn_mlp_*, coattn_ce_*, COATTN_FLAG_FWD_TILED
 extern "C" const char* coattn_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------------------------------

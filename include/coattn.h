@@ -55,6 +55,10 @@ extern "C" {
  * (csrc/coattn_fused2.hip) where the shape allows it (d = 256 or 512, T <= 26, N <= 208), else ignored.  Same
  * values as the default schedule; kept selectable for measurements. */
 #define COATTN_FLAG_FWD_TILED 8
+/* flags bit 4 (forward, fused kernels only): phase 1 of the default schedule split over location columns instead
+ * of channels (no cross-wave reduction) where the shape allows it (d % 512 == 0, 64 < N, N % 4 == 0), else ignored.
+ * Same values, same speed at cfg 2; selectable for measurements. */
+#define COATTN_FLAG_FWD_COLSPLIT 16
 
 typedef struct coattn_params {
   const void* W_v; const void* b_v;   /* model.py:350 */

@@ -378,7 +378,8 @@ static int forward_impl(const void* V, const void* const* Q, const coattn_params
   if (!do_attn) return 0;
   if (fused)
     return fused_attention_forward(B, N, T, d, L, (const float*)V, (const float* const*)Q, p, (float*)v_out,
-                                   (float*)q_out, sv, tail, c.s, (flags & COATTN_FLAG_FWD_TILED) != 0);
+                                   (float*)q_out, sv, tail, c.s,
+                                   ((flags & COATTN_FLAG_FWD_TILED) ? 1 : 0) | ((flags & COATTN_FLAG_FWD_COLSPLIT) ? 2 : 0));
   return general_attention(c, (const float*)V, (const float* const*)Q, p, (float*)v_out, (float*)q_out, sv, tail);
 }
 

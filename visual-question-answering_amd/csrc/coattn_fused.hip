@@ -686,7 +686,7 @@ int fused_supported(int B, int N, int T, int d, int L) {
 
 int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, const float* const* Q,
                             const coattn_params* p, float* v_out, float* q_out, float* saved, float* ws,
-                            hipStream_t s, int tiled) {
+                            hipStream_t s, int sched) {
   CA_CHECK_ARG(fused_supported(B, N, T, d, L), "fused forward: unsupported shape");
   const SavedOff so = saved_off(B, N, T, d, L);
   FwdArgs a;
@@ -702,12 +702,13 @@ int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, c
   // the tile-pipelined kernel of coattn_fused2.hip: COATTN_FLAG_FWD_TILED, or COATTN_FWD_V2=1 in the environment
   // (developer switch; measured slower than the phase-ordered kernel)
   static const int v2env = [] { const char* e = getenv("COATTN_FWD_V2"); return (e && e[0] == '1') ? 1 : 0; }();
-  const int v2 = tiled || v2env;
+  const int v2 = (sched & 1) || v2env;            // sched bit 0: COATTN_FLAG_FWD_TILED, bit 1: COATTN_FLAG_FWD_COLSPLIT
   // COATTN_FWD_X3=0: phase 1 on the f32 MFMA (developer switch for ablations; default: bf16 3-way split)
   // COATTN_FWD_X3: 0 = phase 1 on the f32 MFMA, 1 (default) = bf16 split with the channels split over the waves,
   // 2 = bf16 split with the location columns split over the waves (no cross-wave reduction; 4 waves, N > 64,
   // N % 4 == 0).  1 and 2 measure the same (118 us at cfg 2): 2 trades the 10 us reduction for a longer phase 1.
-  static const int x3 = [] { const char* e = getenv("COATTN_FWD_X3"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }();
+  static const int x3env = [] { const char* e = getenv("COATTN_FWD_X3"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }();
+  const int x3 = (sched & 2) ? 2 : x3env;
   if (v2 && fused2_supported(B, N, T, d, L)) {
     CA_TRY(fused2_launch(a, s));
   } else if (d % 512 == 0) {

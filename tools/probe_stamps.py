@@ -74,3 +74,10 @@ if st.shape[1] >= 8 + 4 * nt and (st[:, 8:8 + 4 * nt] > 0).all():
     print("  workgroups alone on their CU (fastest 8%%): steps %.2f, barrier %.2f, finish %.2f us"
           % (steps[lone].mean(), bar[lone].mean(), fin[lone].mean()))
     print("  steps per tile index:", " ".join("%.1f" % x for x in steps.mean(axis=0)))
+
+# shader-cycle stamps (s_memtime) around the tile loop of coattn_fused.hip: cycles per tile and the clock they imply
+if st.shape[1] > 7 and (tail[live][:, 6] > 0).all() and (tail[live][:, 7] > 0).all():
+    cyc = tail[live][:, 7] - tail[live][:, 6]
+    us = st[:, 3] - st[:, 2]
+    print("tile loop: %.0f shader cycles per workgroup (%.0f per tile) in %.1f us -> %.2f GHz; MFMA issue cycles per wave: %d"
+          % (cyc.mean(), cyc.mean() / nt, us.mean(), (cyc / us).mean() / 1e3, nt * 120 * 32))

@@ -36,8 +36,13 @@
   do {                                                                                                \
     if (threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 64 + (k)] = __builtin_amdgcn_s_memrealtime();  \
   } while (0)
+#define CA_STAMP_CYC(k)                                                                               \
+  do {                                                                                                \
+    if (threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 64 + (k)] = __builtin_amdgcn_s_memtime();      \
+  } while (0)
 #else
 #define CA_STAMP(k)
+#define CA_STAMP_CYC(k)
 #endif
 
 namespace {
@@ -258,6 +263,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
     }
     __syncthreads();
     CA_STAMP(2);
+    CA_STAMP_CYC(6);
   } else {
     f32x4 acc[2][NT];
 #pragma unroll
@@ -401,6 +407,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
     }
     __syncthreads();
     CA_STAMP(2);
+    CA_STAMP_CYC(6);
   }
 
   // ------------------------------------------------------------------ phase 2: H_v scores, H_q
@@ -520,6 +527,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
     }
 #undef COATTN_INTERLEAVE
   }
+  CA_STAMP_CYC(7);                                   // shader cycles around the tile loop (with stamp 6)
   CA_STAMP(3);
 
   // ------------------------------------------------------------------ phase 3

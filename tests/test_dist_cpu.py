@@ -36,7 +36,7 @@ def _data(B, N, T, d, K):
     return V.permute(0, 2, 1), Qs, label
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, exchange="allreduce"):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
@@ -48,7 +48,7 @@ def _worker(rank, world, port, q):
     model = _build(d, K)
     x, Qs, label = _data(B, N, T, d, K)
     sl = slice(rank * B // world, (rank + 1) * B // world)
-    red = vdist.GradReducer(model, bucket_mb=0.01)            # tiny buckets: several collectives
+    red = vdist.GradReducer(model, bucket_mb=0.01, exchange=exchange)   # tiny buckets: several collectives
     opt = torch.optim.Adam(model.parameters(), 1e-3)
     crit = torch.nn.CrossEntropyLoss()
     grads_step = []
@@ -67,11 +67,13 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_grad_reducer_world2_equals_full_batch():
+@pytest.mark.parametrize("exchange", ["allreduce", "direct"])
+def test_grad_reducer_world2_equals_full_batch(exchange):
+    """exchange = "direct": the one-shot all-to-all / local sum / all-gather pattern."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, exchange)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
@@ -102,3 +104,53 @@ def test_grad_reducer_world2_equals_full_batch():
         if n.endswith("w_v.bias") or n.endswith("w_q.bias"):
             continue     # analytically zero gradient: Adam turns its rounding noise into +-lr steps
         assert torch.allclose(w0[n], p.detach(), atol=1e-5), n                # == big-batch training
+
+
+def _worker3(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from vqa_amd import dist as vdist
+    vdist.init_from_env("gloo")
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))     # 40 + 18 = 58 elements: not % 3
+    out = {}
+    for exchange in ("allreduce", "direct"):
+        red = vdist.GradReducer(model, bucket_mb=0.0001, exchange=exchange)
+        for step in range(2):                                                   # step 0 builds, step 1 runs hooked
+            for i, p in enumerate(model.parameters()):
+                p.grad = None
+            red.prepare()
+            x = torch.full((4, 7), float(rank + 1 + step))
+            model(x).square().sum().backward()
+            red.finish()
+        out[exchange] = [p.grad.clone().numpy() for p in model.parameters()]
+        for h in red._hooks:
+            h.remove()
+    q.put((rank, out))
+    vdist.shutdown()
+
+
+@pytest.mark.timeout(300)
+def test_direct_exchange_world3_matches_allreduce():
+    """Three ranks, bucket sizes that are not multiples of the world size (padded shards): the one-shot exchange
+    gives the same averaged gradients as the ring all-reduce, identical on every rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker3, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ref = res[0][1]
+    for a, b in zip(ref["allreduce"], ref["direct"]):
+        assert torch.allclose(torch.from_numpy(a), torch.from_numpy(b), rtol=1e-6, atol=1e-7)
+    for _, out in res[1:]:
+        for k in ("allreduce", "direct"):
+            for a, b in zip(ref[k], out[k]):
+                assert (a == b).all()                                           # ranks hold identical gradients

@@ -13,6 +13,12 @@ model shards naturally by QA pair, so the only exchange step is the gradient mea
   launched asynchronously as soon as its bucket is complete, overlapping with the rest of
   backward; xGMI is point-to-point, so buckets are kept large (default 16 MB: the ~49 MB
   gradient of the attention model goes out in 3-4 collectives).
+* ``exchange="direct"`` (or ``VQA_GRAD_EXCHANGE=direct``) replaces the ring all-reduce by the
+  one-shot pattern that fits a fully connected xGMI node: every rank owns 1/world of a bucket, an all-to-all
+  sends shard j of every rank's bucket straight to rank j (all 7 peer links carry S/8 each at once instead of
+  2 (w-1)/w S circling one ring), the owner sums the w pieces in rank order, and an all-gather returns the reduced
+  shards.  Same values on every rank; opt-in until it has been timed against RCCL's own all-reduce on a
+  multi-GPU node (a one-GPU box cannot).
 """
 from __future__ import annotations
 
@@ -56,10 +62,13 @@ def shutdown():
 
 
 class _Bucket:
-    def __init__(self, params: List[torch.nn.Parameter]):
+    def __init__(self, params: List[torch.nn.Parameter], pad_to: int = 1):
         self.params = params
         n = sum(p.numel() for p in params)
+        self.numel = n
+        n = (n + pad_to - 1) // pad_to * pad_to          # direct exchange: equal shards per rank
         self.flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
+        self.recv = None                                  # direct exchange: the w pieces of this rank's shard
         self.views, o = [], 0
         for p in params:
             self.views.append(self.flat[o:o + p.numel()].view_as(p))
@@ -74,9 +83,12 @@ class GradReducer:
     Usage per step:  ``prepare()`` -> ``loss.backward()`` -> ``finish()`` -> ``optimizer.step()``.
     """
 
-    def __init__(self, module: torch.nn.Module, bucket_mb: float = 16.0, group=None):
+    def __init__(self, module: torch.nn.Module, bucket_mb: float = 16.0, group=None, exchange: str | None = None):
         self.module = module
         self.group = group
+        self.exchange = exchange or os.environ.get("VQA_GRAD_EXCHANGE", "allreduce")
+        if self.exchange not in ("allreduce", "direct"):
+            raise ValueError("exchange must be 'allreduce' or 'direct', got %r" % self.exchange)
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.world = dist.get_world_size(group)
         self.buckets: List[_Bucket] | None = None      # built after the first backward
@@ -97,15 +109,16 @@ class GradReducer:
         if not (torch.equal(lo, sig) and torch.equal(hi, sig)):
             raise RuntimeError("ranks disagree on which parameters receive gradients")
         self.buckets, cur, size = [], [], 0
+        pad = self.world if self.exchange == "direct" else 1
         for p in live:
             nbytes = p.numel() * p.element_size()
             if cur and (size + nbytes > self.bucket_bytes or p.dtype != cur[0].dtype):
-                self.buckets.append(_Bucket(cur))
+                self.buckets.append(_Bucket(cur, pad))
                 cur, size = [], 0
             cur.append(p)
             size += nbytes
         if cur:
-            self.buckets.append(_Bucket(cur))
+            self.buckets.append(_Bucket(cur, pad))
         for bi, b in enumerate(self.buckets):
             for pi, p in enumerate(b.params):
                 self._where[p] = (bi, pi)
@@ -114,7 +127,13 @@ class GradReducer:
     def _launch(self, b):
         """Pack a bucket whose gradients are all there (one multi-tensor copy) and start its all-reduce."""
         torch._foreach_copy_(b.views, [p.grad if p.grad is not None else torch.zeros_like(p) for p in b.params])
-        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if self.exchange == "direct":
+            # stage 1: shard j of this rank's bucket goes straight to rank j (stage 2 in finish())
+            if b.recv is None:
+                b.recv = torch.empty_like(b.flat)
+            b.work = dist.all_to_all_single(b.recv, b.flat, group=self.group, async_op=True)
+        else:
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_grad(self, p):
         bi, _ = self._where[p]
@@ -138,13 +157,27 @@ class GradReducer:
         for b in self.buckets:
             if b.work is None:                          # a parameter of this bucket got no gradient this step
                 self._launch(b)
+        if self.exchange == "direct":
+            # stage 2: sum the w pieces of the own shard in rank order, scale, gather the reduced shards
+            gathers = []
+            for b in self.buckets:
+                b.work.wait()
+                pieces = b.recv.view(self.world, -1)
+                shard = pieces[0].clone()
+                for r in range(1, self.world):
+                    shard.add_(pieces[r])
+                shard.div_(self.world)
+                gathers.append((dist.all_gather_into_tensor(b.flat, shard, group=self.group, async_op=True), shard))
+            for work, _ in gathers:
+                work.wait()
         for b in self.buckets:
-            b.work.wait()
-            b.flat.div_(self.world)
+            if self.exchange != "direct":
+                b.work.wait()
+                b.flat.div_(self.world)
             for v, p in zip(b.views, b.params):
                 if p.grad is None:
                     p.grad = torch.empty_like(p)
             torch._foreach_copy_([p.grad for p in b.params], b.views)       # one multi-tensor copy back
 
     def payload_bytes(self) -> int:
-        return sum(b.flat.numel() * b.flat.element_size() for b in (self.buckets or []))
+        return sum(b.numel * b.flat.element_size() for b in (self.buckets or []))

@@ -47,5 +47,23 @@ if vals:
             m["derived_mfma_busy_frac"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (32.0 * m["SQ_BUSY_CYCLES"])
         out[kern] = m
     json.dump(out, open(os.path.join(DST, "%s_pmc_mfma.json" % tag), "w"), indent=1)
+# the same counters over the whole isolated hot path (bench.py --only hot): one entry per kernel of the HIP library
+hot = {}
+for f in glob.glob(os.path.join(SRC, "pmc_hot", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "anonymous namespace" not in k or "at::native" in k or "softmax_warp" in k:
+            continue                                   # stock PyTorch / MIOpen / rocBLAS kernels are not ours
+        name = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
+        hot.setdefault(name, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+if hot:
+    out = {}
+    for name, cs in sorted(hot.items()):
+        m = {c: sum(v) / len(v) for c, v in cs.items()}
+        m["dispatches"] = len(next(iter(cs.values())))
+        if m.get("SQ_BUSY_CYCLES") and "SQ_VALU_MFMA_BUSY_CYCLES" in m:
+            m["derived_mfma_busy_frac"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (32.0 * m["SQ_BUSY_CYCLES"]), 4)
+        out[name] = m
+    json.dump(out, open(os.path.join(DST, "%s_pmc_hot_path_kernels.json" % tag), "w"), indent=1)
 print("profiles/ refreshed from", SRC)
 print(line[:400])

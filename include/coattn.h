@@ -51,15 +51,6 @@ extern "C" {
  * Everything else stays exact fp32.  Parity then holds to bf16 tolerance (~1e-2), not 1e-4.
  * The same bit selects the bf16 MFMA for the three contractions of coattn_phrase_forward/backward. */
 #define COATTN_FLAG_BF16_PROJ 4
-/* flags bit 3 (forward, fused kernels only): the tile-pipelined schedule of the affinity/softmax/reduce kernel
- * (csrc/coattn_fused2.hip) where the shape allows it (d = 256 or 512, T <= 26, N <= 208), else ignored.  Same
- * values as the default schedule; kept selectable for measurements. */
-#define COATTN_FLAG_FWD_TILED 8
-/* flags bit 4 (forward, fused kernels only): phase 1 of the default schedule split over location columns instead
- * of channels (no cross-wave reduction) where the shape allows it (d % 512 == 0, 64 < N, N % 4 == 0), else ignored.
- * Same values, same speed at cfg 2; selectable for measurements. */
-#define COATTN_FLAG_FWD_COLSPLIT 16
-
 typedef struct coattn_params {
   const void* W_v; const void* b_v;   /* model.py:350 */
   const void* W_q; const void* b_q;   /* model.py:351 */

@@ -7,11 +7,7 @@ import torch
 import vqa_amd
 from vqa_amd import _lib
 
-IMPL = {"general": _lib.IMPL_GENERAL, "fused": _lib.IMPL_FUSED, "auto": _lib.IMPL_AUTO,
-        # fused kernels with the tile-pipelined forward schedule (csrc/coattn_fused2.hip) where the shape allows it
-        "fused_tiled": _lib.IMPL_FUSED | _lib.FLAG_FWD_TILED,
-        # fused kernels with phase 1 of the forward split over location columns (d % 512 == 0, N > 64, N % 4 == 0)
-        "fused_colsplit": _lib.IMPL_FUSED | _lib.FLAG_FWD_COLSPLIT}
+IMPL = {"general": _lib.IMPL_GENERAL, "fused": _lib.IMPL_FUSED, "auto": _lib.IMPL_AUTO}
 
 
 def _al64(n):

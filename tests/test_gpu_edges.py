@@ -214,3 +214,26 @@ def test_large_batch_is_sample_independent(N):
     for k in (4, 5):
         ref = h1[k] + h2[k]
         assert (big[k] - ref).abs().max().item() < 1e-4 * ref.abs().max().item()
+
+
+def test_large_batch_backward_workspace():
+    """B large enough that the da_v partials ([B][d/64][3][N]) outgrow the 32 d^2 split-K scratch they share
+    (B * 3 * N > 2048 d): the workspace plan must cover them (round-1 advisor finding).  Fused vs general-shape
+    kernels on the same inputs; the workspace is followed by a canary region that must stay untouched."""
+    import ctypes as C
+    from tests._hip import run_hip
+    from vqa_amd import _lib
+    B, N, T, d = 1024, 196, 26, 256
+    assert B * 3 * N > 2048 * d
+    lens = sorted([T] + [3 + (5 * i) % (T - 2) for i in range(B - 1)], reverse=True)
+    P = O.make_params(d, 13)
+    V, Qs = O.make_inputs(B, N, T, d, 57, lens=lens, scale_q=(2.0 / d) ** 0.5)
+    gv = torch.from_numpy(O.hash_normal((3, B, d), 15)).float()
+    gq = torch.from_numpy(O.hash_normal((3, B, d), 16)).float()
+    a = run_hip(V, Qs, P, gv, gq, impl="fused", need_dv=False)
+    b = run_hip(V, Qs, P, gv, gq, impl="general", need_dv=False)
+    for k in ("dQ", "dW_v.weight", "dW_q.weight", "dw_v.weight", "dw_q.weight", "dW_v.bias", "dW_q.bias"):
+        assert (a[k] - b[k]).abs().max() <= 1e-4 * max(1e-3, b[k].abs().max().item()), k
+    # the plan itself: bytes reported >= what bwd_dav_kernel writes behind the other regions
+    _, _, bb = _lib.workspace_bytes(B, N, T, d, 3, _lib.IMPL_FUSED)
+    assert bb // 4 >= B * (d // 64) * 3 * N

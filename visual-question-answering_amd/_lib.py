@@ -20,8 +20,6 @@ EXPORTS = ("coattn_version", "coattn_last_error", "coattn_fused_supported", "coa
 F32 = 0
 IMPL_AUTO, IMPL_GENERAL, IMPL_FUSED = 0, 1, 2
 FLAG_BF16_PROJ = 4
-FLAG_FWD_TILED = 8
-FLAG_FWD_COLSPLIT = 16
 
 
 class Params(C.Structure):

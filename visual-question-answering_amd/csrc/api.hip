@@ -16,7 +16,7 @@ void coattn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int coattn_version(void) { return 200; }   // 0.2.0: + coattn_mlp_*, coattn_ce_*, COATTN_FLAG_FWD_TILED
+extern "C" int coattn_version(void) { return 300; }   // 0.3.0: V strides (coattn_forward_strided / _backward_strided)
 extern "C" const char* coattn_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------------------------------
@@ -378,8 +378,7 @@ static int forward_impl(const void* V, const void* const* Q, const coattn_params
   if (!do_attn) return 0;
   if (fused)
     return fused_attention_forward(B, N, T, d, L, (const float*)V, (const float* const*)Q, p, (float*)v_out,
-                                   (float*)q_out, sv, tail, c.s,
-                                   ((flags & COATTN_FLAG_FWD_TILED) ? 1 : 0) | ((flags & COATTN_FLAG_FWD_COLSPLIT) ? 2 : 0));
+                                   (float*)q_out, sv, tail, c.s);
   return general_attention(c, (const float*)V, (const float* const*)Q, p, (float*)v_out, (float*)q_out, sv, tail);
 }
 

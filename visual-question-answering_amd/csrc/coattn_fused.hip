@@ -100,8 +100,7 @@ __device__ __forceinline__ f32x4 mfma_x3(const bf16x8 (&a)[3], const bf16x8 (&b)
 }
 
 // X3: phase 1 (A = Q V^T) on the bf16 MFMA with the exact 3-way split of both operands (fp32-accurate,
-// 6/16 of the f32-MFMA time): 1 = channels split over the waves + cross-wave sum, 2 = location columns split
-// over the waves (no reduction; NW = 4 only); 0 = v_mfma_f32_16x16x4_f32.
+// 6/16 of the f32-MFMA time), channels split over the waves + cross-wave sum; 0 = v_mfma_f32_16x16x4_f32.
 template <int NT, int NW, int X3>
 __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdArgs a) {
   constexpr int NPAD = 16 * NT;
@@ -147,124 +146,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
   };
 
   // ------------------------------------------------------------------ phase 1: A = Q V^T
-  if constexpr (X3 == 2) {
-    // Split over LOCATION COLUMNS (NW = 4): wave w computes A[:, 64w .. 64w+63] over ALL channels on the bf16
-    // MFMA (3-way split), so no cross-wave reduction exists.  V is read with float4 loads along n: lane (j, q4)
-    // gets V[k = 32g + 8 q4 + i][64w + 4j + e], e = 0..3, and element e of the eight rows is the B operand of
-    // "tile" e, whose MFMA column j is location 64w + 4j + e (a column permutation that ends when C is written).
-    // A last group of <= 16 columns (N = 196: locations 192..195) takes dword loads and one plain tile.
-    const int c0 = 64 * w, ncols = N - c0;
-    const int G = d / 32;                            // 32-channel steps
-    const int q_voff0 = (j * d + 8 * q4) * 4, q_voff1 = ((16 + j) * d + 8 * q4) * 4;
-    const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(a.C + pair * (size_t)T * N, (unsigned)T * N * 4u);
-    f32x8 qr[2];
-    bf16x8 qa[2][3];
-    auto load_q = [&](int k0) {
-      const f32x4 a0 = buf_load4(rs_q, q_voff0, k0 * 4), a1 = buf_load4(rs_q, q_voff0 + 16, k0 * 4);
-      const f32x4 b0 = buf_load4(rs_q, q_voff1, k0 * 4), b1 = buf_load4(rs_q, q_voff1 + 16, k0 * 4);
-      qr[0] = f32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-      qr[1] = f32x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-    };
-    constexpr int kDeadOff = 0x7ffffff0;             // beyond every buffer: stores dropped
-    if (ncols > 16) {
-      f32x4 acc[2][4];
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[tt][e] = f32x4{0.f, 0.f, 0.f, 0.f};
-      f32x4 vr[4][8];                                // ring over the 32-channel steps: 3 in flight
-      const int v_voff = (8 * q4 * N + c0 + 4 * j) * 4;
-      auto load_v = [&](int g, f32x4(&dst)[8]) {     // cols >= N: finite junk, zeroed below
-#pragma unroll
-        for (int i = 0; i < 8; ++i) dst[i] = buf_load4(rs_v, v_voff, (32 * g + i) * N * 4);
-      };
-      auto step = [&](int g, f32x4(&vs)[8]) {
-        split3(qr[0], qa[0]);
-        split3(qr[1], qa[1]);
-        if (g + 1 < G) load_q(32 * (g + 1));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const f32x8 x = f32x8{vs[0][e], vs[1][e], vs[2][e], vs[3][e], vs[4][e], vs[5][e], vs[6][e], vs[7][e]};
-          bf16x8 vb[3];
-          split3(x, vb);
-          acc[0][e] = mfma_x3(qa[0], vb, acc[0][e]);
-          acc[1][e] = mfma_x3(qa[1], vb, acc[1][e]);
-        }
-        if (g + 4 < G) load_v(g + 4, vs);            // refill the slot just consumed
-      };
-      load_q(0);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) load_v(g, vr[g]);  // G >= 8
-#pragma unroll 1
-      for (int g = 0; g < G; g += 4) {
-        step(g, vr[0]);
-        step(g + 1, vr[1]);
-        step(g + 2, vr[2]);
-        step(g + 3, vr[3]);
-      }
-      CA_STAMP(1);
-      load_slice_operands(w * 128);
-      // C = tanh(A): C/D layout col = j, row = 4 q4 + r; element e of a lane's four tiles = 4 consecutive locations
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * tt + 4 * q4 + r, col = c0 + 4 * j;
-          f32x4 c4;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) c4[e] = tanh_fast(acc[tt][e][r]) * ((col + e < N) ? 1.f : 0.f);   // padded columns carry junk
-          if (row < kTRows) *reinterpret_cast<f32x4*>(&Cbuf[row * LD + col]) = c4;
-          buf_store4(c4, rs_c, (col < N) ? (row * N + col) * 4 : kDeadOff, 0);      // N % 4 == 0; rows >= T are dropped
-        }
-    } else if (ncols > 0) {
-      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-      float vr[4][8];
-      const int v_voff = (8 * q4 * N + c0 + j) * 4;
-      auto load_v = [&](int g, float(&dst)[8]) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) dst[i] = buf_load1(rs_v, v_voff, (32 * g + i) * N * 4);
-      };
-      auto step = [&](int g, float(&vs)[8]) {
-        split3(qr[0], qa[0]);
-        split3(qr[1], qa[1]);
-        if (g + 1 < G) load_q(32 * (g + 1));
-        const f32x8 x = f32x8{vs[0], vs[1], vs[2], vs[3], vs[4], vs[5], vs[6], vs[7]};
-        bf16x8 vb[3];
-        split3(x, vb);
-        acc[0] = mfma_x3(qa[0], vb, acc[0]);
-        acc[1] = mfma_x3(qa[1], vb, acc[1]);
-        if (g + 4 < G) load_v(g + 4, vs);
-      };
-      load_q(0);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) load_v(g, vr[g]);
-#pragma unroll 1
-      for (int g = 0; g < G; g += 4) {
-        step(g, vr[0]);
-        step(g + 1, vr[1]);
-        step(g + 2, vr[2]);
-        step(g + 3, vr[3]);
-      }
-      CA_STAMP(1);
-      load_slice_operands(w * 128);
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * tt + 4 * q4 + r, col = c0 + j;
-          const float c = tanh_fast(acc[tt][r]) * ((col < N) ? 1.f : 0.f);
-          if (row < kTRows) Cbuf[row * LD + col] = c;
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c), rs_c,
-                                                (col < N) ? (row * N + col) * 4 : kDeadOff, 0, 0);
-        }
-    } else {
-      CA_STAMP(1);
-      load_slice_operands(w * 128);
-    }
-    __syncthreads();
-    CA_STAMP(2);
-    CA_STAMP_CYC(6);
-  } else {
+  {
     f32x4 acc[2][NT];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
@@ -670,12 +552,11 @@ int launch_fwd(const FwdArgs& a, hipStream_t s) {
   constexpr int LD = 16 * NT + 4;
   constexpr int NSLOT = (NW / 2 > 2) ? NW / 2 : 2;
   const size_t lds = (size_t)(NSLOT * kSlotRows + kTRows) * LD * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(coattn_attn_fwd_kernel<NT, NW, X3>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static DeviceOnce once;                            // the attribute is per device
+  CA_TRY(once.run([&] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(coattn_attn_fwd_kernel<NT, NW, X3>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }, "coattn_attn_fwd"));
   const int groups = (a.B + 7) / 8;
   dim3 grid(groups * a.L * 8), block(NW * 64);
   hipLaunchKernelGGL((coattn_attn_fwd_kernel<NT, NW, X3>), grid, block, lds, s, a);
@@ -694,7 +575,7 @@ int fused_supported(int B, int N, int T, int d, int L) {
 
 int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, const float* const* Q,
                             const coattn_params* p, float* v_out, float* q_out, float* saved, float* ws,
-                            hipStream_t s, int sched) {
+                            hipStream_t s) {
   CA_CHECK_ARG(fused_supported(B, N, T, d, L), "fused forward: unsupported shape");
   const SavedOff so = saved_off(B, N, T, d, L);
   FwdArgs a;
@@ -707,21 +588,10 @@ int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, c
   a.stamps = COATTN_STAMPS ? reinterpret_cast<unsigned long long*>(ws) : nullptr;
   a.B = B; a.N = N; a.T = T; a.d = d; a.L = L;
   const bool small_n = N <= 64;
-  // the tile-pipelined kernel of coattn_fused2.hip: COATTN_FLAG_FWD_TILED, or COATTN_FWD_V2=1 in the environment
-  // (developer switch; measured slower than the phase-ordered kernel)
-  static const int v2env = [] { const char* e = getenv("COATTN_FWD_V2"); return (e && e[0] == '1') ? 1 : 0; }();
-  const int v2 = (sched & 1) || v2env;            // sched bit 0: COATTN_FLAG_FWD_TILED, bit 1: COATTN_FLAG_FWD_COLSPLIT
-  // COATTN_FWD_X3=0: phase 1 on the f32 MFMA (developer switch for ablations; default: bf16 3-way split)
-  // COATTN_FWD_X3: 0 = phase 1 on the f32 MFMA, 1 (default) = bf16 split with the channels split over the waves,
-  // 2 = bf16 split with the location columns split over the waves (no cross-wave reduction; 4 waves, N > 64,
-  // N % 4 == 0).  1 and 2 measure the same (118 us at cfg 2): 2 trades the 10 us reduction for a longer phase 1.
-  static const int x3env = [] { const char* e = getenv("COATTN_FWD_X3"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }();
-  const int x3 = (sched & 2) ? 2 : x3env;
-  if (v2 && fused2_supported(B, N, T, d, L)) {
-    CA_TRY(fused2_launch(a, s));
-  } else if (d % 512 == 0) {
-    if (x3 == 2 && !small_n && N % 4 == 0) CA_TRY((launch_fwd<13, 4, 2>(a, s)));
-    else if (x3) CA_TRY(small_n ? (launch_fwd<4, 4, 1>(a, s)) : (launch_fwd<13, 4, 1>(a, s)));
+  // COATTN_FWD_X3=0: phase 1 on the f32 MFMA (developer switch for ablations; default 1: bf16 3-way split)
+  static const int x3 = [] { const char* e = getenv("COATTN_FWD_X3"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (d % 512 == 0) {
+    if (x3) CA_TRY(small_n ? (launch_fwd<4, 4, 1>(a, s)) : (launch_fwd<13, 4, 1>(a, s)));
     else CA_TRY(small_n ? (launch_fwd<4, 4, 0>(a, s)) : (launch_fwd<13, 4, 0>(a, s)));
   } else {
     if (x3) CA_TRY(small_n ? (launch_fwd<4, 2, 1>(a, s)) : (launch_fwd<13, 2, 1>(a, s)));

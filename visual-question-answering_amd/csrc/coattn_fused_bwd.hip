@@ -633,8 +633,8 @@ __global__ __launch_bounds__(256, 2) void bwd_dq_kernel(const DqArgs a) {
 }
 
 template <typename K>
-void set_lds(K kern, size_t bytes) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+hipError_t set_lds(K kern, size_t bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 int launch_pre(const PreArgs& a, hipStream_t s) {
@@ -650,12 +650,11 @@ int launch_main(const BwdArgs& a, hipStream_t s) {
   constexpr int NSLOT = (NW / 2 > 2) ? NW / 2 : 2;
   const size_t lds_dc = (size_t)((NSLOT * kSlotRows + kTRows) * LD + 16 * NT) * sizeof(float);
   const size_t lds_pq = (size_t)(kTRows * LD + 16 * NT) * sizeof(float);
-  static bool once = false;
-  if (!once) {
-    set_lds(bwd_dc_kernel<NT, NW>, lds_dc);
-    set_lds(bwd_dpq_kernel<NT, NW>, lds_pq);
-    once = true;
-  }
+  static DeviceOnce once;                            // the attribute is per device
+  CA_TRY(once.run([&] {
+    const hipError_t e = set_lds(bwd_dc_kernel<NT, NW>, lds_dc);
+    return e != hipSuccess ? e : set_lds(bwd_dpq_kernel<NT, NW>, lds_pq);
+  }, "bwd_dc/bwd_dpq"));
   const int groups = (a.B + 7) / 8;
   dim3 grid(groups * a.L * 8), block(NW * 64);
   hipLaunchKernelGGL((bwd_dc_kernel<NT, NW>), grid, block, lds_dc, s, a);
@@ -727,8 +726,11 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const floa
       else hipLaunchKernelGGL((bwd_dq_kernel<4, false>), grid, block, lds, s, da);
     } else {
       const size_t lds = (size_t)(3 * kTRows * (208 + 4) + 96) * sizeof(float);
-      static bool once = false;
-      if (!once) { set_lds(bwd_dq_kernel<13, true>, lds); set_lds(bwd_dq_kernel<13, false>, lds); once = true; }
+      static DeviceOnce once;
+      CA_TRY(once.run([&] {
+        const hipError_t e = set_lds(bwd_dq_kernel<13, true>, lds);
+        return e != hipSuccess ? e : set_lds(bwd_dq_kernel<13, false>, lds);
+      }, "bwd_dq"));
       if (al) hipLaunchKernelGGL((bwd_dq_kernel<13, true>), grid, block, lds, s, da);
       else hipLaunchKernelGGL((bwd_dq_kernel<13, false>), grid, block, lds, s, da);
     }

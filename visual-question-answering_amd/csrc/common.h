@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <mutex>
 
 #include "../../include/coattn.h"
 
@@ -35,6 +36,31 @@ void coattn_set_error(const char* fmt, ...);
     int rc_ = (expr);           \
     if (rc_ != 0) return rc_;   \
   } while (0)
+
+// One-time, per-device setup (hipFuncSetAttribute is a per-device property): thread-safe, keyed by the calling
+// thread's current device.  run() returns 0, or -3 with the error message set.
+struct DeviceOnce {
+  static constexpr int kMaxDev = 64;
+  std::once_flag flag[kMaxDev];
+  hipError_t err[kMaxDev];
+  template <typename F>
+  int run(F f, const char* what) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) {
+      if (dev < 0 || dev >= kMaxDev) e = f();            // beyond the table: set it every time
+      else {
+        std::call_once(flag[dev], [&] { err[dev] = f(); });
+        e = err[dev];
+      }
+    }
+    if (e != hipSuccess) {
+      coattn_set_error("%s: per-device setup failed: %s", what, hipGetErrorString(e));
+      return -3;
+    }
+    return 0;
+  }
+};
 
 // ---- wave64 reductions ------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

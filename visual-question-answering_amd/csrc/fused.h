@@ -6,7 +6,7 @@ int fused_supported(int B, int N, int T, int d, int L);
 // everything after the projections (P_v, P_q already in `saved`)
 int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, const float* const* Q,
                             const coattn_params* p, float* v_out, float* q_out, float* saved, float* ws,
-                            hipStream_t s, int sched);
+                            hipStream_t s);
 int fused_backward_supported(int B, int N, int T, int d, int L);
 int fused_backward(int B, int N, int T, int d, int L, const float* V, const float* const* Q, const coattn_params* p,
                    const float* saved, const float* gv, const float* gq, float* dV, float* const* dQ,
@@ -49,7 +49,7 @@ __device__ __forceinline__ bool block_to_pair(int bid, int B, int L, int& b, int
   return b < B;
 }
 
-// arguments of the fused forward kernels (coattn_fused.hip, coattn_fused2.hip)
+// arguments of the fused forward kernel (coattn_fused.hip)
 struct FwdArgs {
   const float* V;        // [B][d][N]
   const float* Q[8];     // L x [B][T][d]
@@ -64,10 +64,6 @@ struct FwdArgs {
   unsigned long long* stamps;   // diagnostic builds only
   int B, N, T, d, L;
 };
-
-// tile-pipelined forward kernel (coattn_fused2.hip): d = 256 or 512, T <= 26, N <= 208
-int fused2_supported(int B, int N, int T, int d, int L);
-int fused2_launch(const FwdArgs& a, hipStream_t s);
 
 inline size_t fal64(size_t n) { return (n + 63) & ~(size_t)63; }
 
@@ -104,7 +100,10 @@ inline FusedBwdOff fused_bwd_off(int B, int N, int T, int d, int L) {
   p.dbq_part = o; o += fal64((size_t)L * B * d);
   p.dwq_part = o; o += fal64((size_t)L * B * d);
   p.dcs_part = o; o += fal64((size_t)L * B * 2);
-  p.part = o; o += fal64((size_t)32 * d * d);
+  // shared scratch: split-K partials of the weight-gradient GEMMs (<= 32 x d x d) and, before them, the da_v
+  // partials of bwd_dav_kernel ([B][d/64][3][N]), which outgrow the former at large B
+  const size_t part_gemm = (size_t)32 * d * d, part_dav = (size_t)B * (d / 64) * 3 * N;
+  p.part = o; o += fal64(part_gemm > part_dav ? part_gemm : part_dav);
   p.total = o;
   return p;
 }

@@ -815,8 +815,8 @@ static int launch_gemm_impl(const coattn_gemm_desc& d, hipStream_t s, int bf16) 
     // (192-row tiles were also tried for that case and measured slower: 279 vs 235 us.)
     const long ntn = (d.N + 127) / 128;
     const long wg128 = ntn * ((d.M + 127) / 128) * d.batch;
-    const char* force = getenv("COATTN_GEMM_BM");
-    const bool small_tiles = force ? atoi(force) == 64 : (wg128 > 768 && wg128 < 3 * 768);
+    static const int force_bm = [] { const char* e = getenv("COATTN_GEMM_BM"); return e ? atoi(e) : 0; }();   // developer switch
+    const bool small_tiles = force_bm ? force_bm == 64 : (wg128 > 768 && wg128 < 3 * 768);
     const int bm = small_tiles ? 64 : 128;
     const long ntm = (d.M + bm - 1) / bm;
     g.xcd_group = ntm >= 32 ? 1 : 0;                 // (grouping the tiles of a split index instead measured slower)

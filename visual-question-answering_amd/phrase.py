@@ -46,8 +46,9 @@ class _PhraseConvPoolFn(torch.autograd.Function):
         ws = torch.empty(fb, dtype=torch.uint8, device=x.device)
         p = _lib.PhraseParams(*[t.data_ptr() for t in ps])
         stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        _lib.check(lib.coattn_phrase_forward(_ptr(X), C.byref(p), _ptr(out), _ptr(saved), _ptr(ws), B, T, E, _lib.F32,
-                                             flags, stream), "coattn_phrase_forward")
+        with torch.cuda.device(x.device):
+            _lib.check(lib.coattn_phrase_forward(_ptr(X), C.byref(p), _ptr(out), _ptr(saved), _ptr(ws), B, T, E,
+                                                 _lib.F32, flags, stream), "coattn_phrase_forward")
         if need_grad:
             ctx.flags = flags
             ctx.save_for_backward(X, out, saved, *ps)
@@ -67,9 +68,10 @@ class _PhraseConvPoolFn(torch.autograd.Function):
         p = _lib.PhraseParams(*[t.data_ptr() for t in ps])
         pg = _lib.PhraseParamGrads(*[t.data_ptr() for t in grads])
         stream = C.c_void_p(torch.cuda.current_stream(X.device).cuda_stream)
-        _lib.check(lib.coattn_phrase_backward(_ptr(X), C.byref(p), _ptr(out), _ptr(saved), _ptr(g), _ptr(dX),
-                                              C.byref(pg), 0, _ptr(ws), B, T, E, _lib.F32, ctx.flags, stream),
-                   "coattn_phrase_backward")
+        with torch.cuda.device(X.device):
+            _lib.check(lib.coattn_phrase_backward(_ptr(X), C.byref(p), _ptr(out), _ptr(saved), _ptr(g), _ptr(dX),
+                                                  C.byref(pg), 0, _ptr(ws), B, T, E, _lib.F32, ctx.flags, stream),
+                       "coattn_phrase_backward")
         return (dX, *grads, None)
 
 

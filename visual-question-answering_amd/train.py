@@ -278,6 +278,9 @@ class Trainer:
                 if mine is None:
                     with torch.no_grad():
                         inline = self.model.image_encoder(image)
+                    # the inline pass updated the BatchNorm running statistics on this stream: the pass queued
+                    # below for the next batch must come after it (batch order)
+                    self.enc_stream.wait_stream(torch.cuda.current_stream(self.device))
                 self._resident = image
                 if next_image is not None:
                     self._ahead = self._queue_encoder(next_image, next_ready)

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X co-attention path: QA-pairs/sec of the `--model attention` train step.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+(N > 1: either under torch.distributed.run, one rank per GPU, or from a plain shell -- bench.py then
+starts the N ranks itself)
 
 Workload (BASELINE.json configs[1], per GPU): HierarchicalCoAttentionNet, K=1000 answers (1001
 logits), batch 160, synthetic 224x224 images (-> 7x7x512 grid, N=49), 26-token questions, fp32;
@@ -13,7 +15,8 @@ contract fields it carries
                 algorithmic bytes 913,408 B per (pair, level) / avg launch time,
                 against 8 TB/s HBM
   cpu_baseline  the CPU oracle port (oracle/net_oracle.py) of the same train step, timed on the
-                host cores on a bounded sample (rank 0, N=1 only)
+                host cores on a bounded sample (rank 0, N=1 only); cpu_baseline_hot_path: the oracle
+                port of the isolated hot path (co-attention + MLP + CE fwd+bwd) at N=196 and N=49
   roofline_projection  the MFMA-bound P_v projection GEMM, timed the same way: fp32-equivalent TFLOP/s
                 against the fp32 matrix peak and the issued bf16 flops against the dense bf16 peak
   hot_path      isolated co-attention (+MLP+CE) fwd+bwd rates on device-resident features, N=196
@@ -195,6 +198,8 @@ def roofline_leg(device, B=160, N=196, T=26, d=512, L=3, iters=50):
         pass
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_source": "profiles/pmc_traffic.json (rocprofv3 PMC passes of this kernel at this shape, committed; "
+                              "not measured by this run)" if traffic is not None else None,
             "kernel": "coattn_attention_fwd (affinity+tanh, H_v/H_q, scores, row-softmax, attended reductions)"
                       + (" [fused]" if fused else " [general-shape kernel sequence]"),
             "shape": {"B": B, "N": N, "T": T, "d": d, "L": L}, "avg_launch_us": round(t * 1e6, 2),
@@ -245,8 +250,22 @@ def host_cores() -> int:
     return usable_cpus()
 
 
+def cpu_model_string() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+CPU_WARM, CPU_TIMED = 3, 5          # >= 3 warm-up + >= 5 timed steps on the CPU
+
+
 def cpu_baseline_leg(args):
-    """The oracle port of the same train step on the host cores; bounded sample."""
+    """The oracle port of the same train step on the host cores; bounded sample (BASELINE.md section 3 protocol:
+    3 warm-up + 5 timed steps, median)."""
     from oracle import net_oracle as NO
     from vqa_amd import train as T
     cores = host_cores()
@@ -257,19 +276,89 @@ def cpu_baseline_leg(args):
     b = T.synthetic_batch(args.cpu_batch, (args.image_size,) * 2, args.seq_len, args.vocab, args.num_cls + 1, seed=1234)
     image, question, label, lens = T.sort_batch(b["image"], b["question"], b["label"], b["ques_len"])
     batch = (image, question, lens, label)
-    NO.train_steps(net, [batch], lr=1e-4)                              # warm-up
-    t0 = time.perf_counter()
-    n = 2
-    NO.train_steps(net, [batch] * n, lr=1e-4)
-    dt = (time.perf_counter() - t0) / n
+    NO.train_steps(net, [batch] * CPU_WARM, lr=1e-4)
+    ts = []
+    for _ in range(CPU_TIMED):
+        t0 = time.perf_counter()
+        NO.train_steps(net, [batch], lr=1e-4)
+        ts.append(time.perf_counter() - t0)
+    dt = sorted(ts)[len(ts) // 2]
     return {"value": round(args.cpu_batch / dt, 2), "unit": "QA-pairs/s", "cores": cores, "kind": "port",
+            "cpu": cpu_model_string(),
             "sample": "oracle port of the same train step (reference op sequence incl. its 6x W_v(V) "
-                      "re-evaluation), batch %d, %dx%d images, 1 warm-up + %d timed steps, torch CPU fp32, %d threads"
-                      % (args.cpu_batch, args.image_size, args.image_size, n, cores)}
+                      "re-evaluation), batch %d, %dx%d images, %d warm-up + %d timed steps (median), torch CPU fp32, "
+                      "%d threads" % (args.cpu_batch, args.image_size, args.image_size, CPU_WARM, CPU_TIMED, cores)}
+
+
+def cpu_hot_path_leg(N, B=160, T=26, d=512, K=1000):
+    """The isolated hot path (co-attention + MLPClassifier + CE, forward + backward) of the
+    oracle port on the host cores, on the same synthetic features as `hot_path_leg`."""
+    from oracle import coattn_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    co = O.OracleParallelCoAttention(d, as_executed=True)
+    mlp = O.OracleMLPClassifier(d, 1024, K + 1)
+    V, Qs = synth_features(B, N, T, d, torch.device("cpu"))
+    x_img = V.permute(0, 2, 1)                       # the encoder's permuted view (model.py:215-217)
+    Qs = [q.requires_grad_(True) for q in Qs]
+    label = (torch.arange(B) * 7) % (K + 1)
+    crit = torch.nn.CrossEntropyLoss()
+    params = list(co.parameters()) + list(mlp.parameters())
+
+    def step():
+        for p in params:
+            p.grad = None
+        crit(mlp(*co(x_img, Qs)), label).backward()
+
+    for _ in range(CPU_WARM):
+        step()
+    ts = []
+    for _ in range(CPU_TIMED):
+        t0 = time.perf_counter()
+        step()
+        ts.append(time.perf_counter() - t0)
+    dt = sorted(ts)[len(ts) // 2]
+    return {"N": N, "value": round(B / dt, 1), "unit": "QA-pairs/s", "ms_per_step": round(dt * 1e3, 1), "cores": cores,
+            "kind": "port", "cpu": cpu_model_string(),
+            "sample": "oracle port of co-attention + MLPClassifier + CE, fwd+bwd, B=%d N=%d T=%d d=%d, %d warm-up + %d "
+                      "timed (median), torch CPU fp32, %d threads" % (B, N, T, d, CPU_WARM, CPU_TIMED, cores)}
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` from a plain shell: start the N ranks here (one process per GPU, RANK / WORLD_SIZE /
+    LOCAL_RANK / MASTER_* set before anything touches a GPU -- this parent never does), relay rank 0's JSON line and
+    return non-zero if any rank failed."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()                # does not initialise the GPU
+    if n_dev < args.gpus:
+        print("bench.py: --gpus %d needs %d visible GPUs, found %d" % (args.gpus, args.gpus, n_dev), file=sys.stderr)
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print("bench.py: ranks failed (rank, exit code): %s" % bad, file=sys.stderr)
+        return 1
+    return 0
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:       # not under torch.distributed.run: launch the ranks ourselves
+        sys.exit(self_launch(args))
     if args.stock_graph:
         os.environ["VQA_ENCODER_REWRITE"] = "0"
     import vqa_amd
@@ -283,7 +372,8 @@ def main():
         return
     torch.set_num_threads(max(1, min(4, host_cores())))   # the step is GPU work; do not oversubscribe host cores per rank
     rank, world, local = vdist.init_from_env()
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     device = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(device)
     torch.manual_seed(0)
@@ -348,6 +438,7 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg(args)
+            out["cpu_baseline_hot_path"] = [cpu_hot_path_leg(196), cpu_hot_path_leg(49)]
         print(json.dumps(out))
 
 

@@ -106,8 +106,10 @@ def timed_steps(trainer, batch, steps, warmup, sync):
     return time.perf_counter() - t0
 
 
-def hot_path_leg(device, N, B=160, T=26, d=512, K=1000, iters=20):
-    """Isolated hot path (co-attention + MLPClassifier + CE, fwd+bwd) on resident features."""
+def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20):
+    """Isolated hot path (co-attention + MLPClassifier + CE, fwd+bwd) on resident features.
+    layout: "lm" = x_img contiguous [B,N,d] (what the channels_last encoder of the train step hands over),
+    "cm" = the permuted view of a channel-major [B,d,N] buffer (the reference's NCHW encoder, model.py:215-217)."""
     import vqa_amd
     from vqa_amd.modules import MLPClassifier
     torch.manual_seed(0)
@@ -115,6 +117,8 @@ def hot_path_leg(device, N, B=160, T=26, d=512, K=1000, iters=20):
     mlp = MLPClassifier(d, 1024, K + 1).to(device)
     V, Qs = synth_features(B, N, T, d, device)
     x_img = V.permute(0, 2, 1)
+    if layout == "lm":
+        x_img = x_img.contiguous()
     Qs = [q.requires_grad_(True) for q in Qs]
     label = (torch.arange(B, device=device) * 7) % (K + 1)
     crit = torch.nn.CrossEntropyLoss()
@@ -150,14 +154,15 @@ def hot_path_leg(device, N, B=160, T=26, d=512, K=1000, iters=20):
         if it >= 3:
             fwd += t1 - t0; bwd += t3 - t2
     flop = 3.0 * B * (2 * N * d * d + 3 * 2 * T * d * d + 3 * (3 * 2 * T * N * d + 4 * (N + T) * d))
-    return {"N": N, "pairs_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3),
+    return {"N": N, "layout": layout, "pairs_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3),
             "coattn_fwd_ms": round(fwd / iters * 1e3, 4), "coattn_bwd_ms": round(bwd / iters * 1e3, 4),
             "coattn_fwd_bwd_tflops": round(flop / ((fwd + bwd) / iters) / 1e12, 2)}
 
 
-def roofline_leg(device, B=160, N=196, T=26, d=512, L=3, iters=50):
+def roofline_leg(device, B=160, N=196, T=26, d=512, L=3, iters=50, layout="lm"):
     """Average launch duration of the affinity+softmax+reduce forward kernel(s), HIP events on the
-    launch stream (= torch's current stream, which the C-ABI call is given)."""
+    launch stream (= torch's current stream, which the C-ABI call is given).  layout: physical layout of the
+    image features, "lm" [B,N,d] (channels_last encoder: the train step's default) or "cm" [B,d,N] (NCHW)."""
     import ctypes as C
     import vqa_amd
     from vqa_amd import _lib
@@ -166,6 +171,9 @@ def roofline_leg(device, B=160, N=196, T=26, d=512, L=3, iters=50):
     torch.manual_seed(0)
     co = vqa_amd.ParallelCoAttention(d).to(device)
     V, Qs = synth_features(B, N, T, d, device, seed=77, L=L)
+    vstr = (d * N, 1, N)
+    if layout == "lm":
+        V, vstr = V.permute(0, 2, 1).contiguous(), (N * d, d, 1)
     ps = [t.detach().contiguous() for t in (co.W_v.weight, co.W_v.bias, co.W_q.weight, co.W_q.bias, co.w_v.weight,
                                            co.w_v.bias, co.w_q.weight, co.w_q.bias)]
     sb, fb, _ = _lib.workspace_bytes(B, N, T, d, L)
@@ -174,7 +182,7 @@ def roofline_leg(device, B=160, N=196, T=26, d=512, L=3, iters=50):
     qptr = (C.c_void_p * L)(*[t.data_ptr() for t in Qs])
     p = _lib.Params(*[t.data_ptr() for t in ps])
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    args = (V.data_ptr(), qptr, C.byref(p), v.data_ptr(), q.data_ptr(), saved.data_ptr(), ws.data_ptr(),
+    args = (V.data_ptr(), *vstr, qptr, C.byref(p), v.data_ptr(), q.data_ptr(), saved.data_ptr(), ws.data_ptr(),
             B, N, T, d, L, _lib.F32, 0, stream)
     _lib.check(lib.coattn_forward(*args), "coattn_forward")          # fills P_v / P_q in `saved`
     for _ in range(5):
@@ -192,7 +200,7 @@ def roofline_leg(device, B=160, N=196, T=26, d=512, L=3, iters=50):
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             tr = json.load(fh)
-        if tr.get("shape") == {"B": B, "N": N, "T": T, "d": d, "L": L}:
+        if tr.get("shape") == {"B": B, "N": N, "T": T, "d": d, "L": L} and tr.get("layout", "cm") == layout:
             traffic = tr["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
@@ -202,7 +210,7 @@ def roofline_leg(device, B=160, N=196, T=26, d=512, L=3, iters=50):
                               "not measured by this run)" if traffic is not None else None,
             "kernel": "coattn_attention_fwd (affinity+tanh, H_v/H_q, scores, row-softmax, attended reductions)"
                       + (" [fused]" if fused else " [general-shape kernel sequence]"),
-            "shape": {"B": B, "N": N, "T": T, "d": d, "L": L}, "avg_launch_us": round(t * 1e6, 2),
+            "shape": {"B": B, "N": N, "T": T, "d": d, "L": L}, "v_layout": layout, "avg_launch_us": round(t * 1e6, 2),
             "algorithmic_bytes": alg}
 
 
@@ -366,8 +374,11 @@ def main():
     from vqa_amd import train as T
     if args.only:
         dev = torch.device("cuda", 0)
-        res = ({"roofline": roofline_leg(dev), "roofline_projection": projection_leg(dev)} if args.only == "roofline"
-               else [hot_path_leg(dev, 196), hot_path_leg(dev, 49)])
+        res = ({"roofline": roofline_leg(dev), "roofline_channel_major": roofline_leg(dev, layout="cm"),
+                "roofline_at_step_shape": roofline_leg(dev, N=49),
+                "roofline_at_step_shape_channel_major": roofline_leg(dev, N=49, layout="cm"),
+                "roofline_projection": projection_leg(dev)} if args.only == "roofline"
+               else [hot_path_leg(dev, n, lay) for n in (196, 49) for lay in ("lm", "cm")])
         print(json.dumps(res))
         return
     torch.set_num_threads(max(1, min(4, host_cores())))   # the step is GPU work; do not oversubscribe host cores per rank
@@ -428,13 +439,17 @@ def main():
     if rank == 0 and not args.no_extras:
         del trainer, model, batch
         torch.cuda.empty_cache()
-        out["roofline"] = roofline_leg(device)                 # per-GPU kernel; the same on every rank
+        # per-GPU kernel, the same on every rank; image features location-major [B,N,d], as the channels_last
+        # encoder of the timed step hands them over (no copy in between)
+        out["roofline"] = roofline_leg(device)
+        # the same kernel on the reference's own layout (NCHW encoder -> channel-major [B,d,N] behind a permuted view)
+        out["roofline_channel_major"] = roofline_leg(device, layout="cm")
         # the same kernel at the timed step's own grid (224x224 -> 7x7 = 49 locations)
         out["roofline_at_step_shape"] = roofline_leg(device, B=args.batch, N=(args.image_size // 32) ** 2,
                                                      T=args.seq_len)
         out["roofline_projection"] = projection_leg(device)
         if world == 1:
-            out["hot_path"] = [hot_path_leg(device, 196), hot_path_leg(device, 49)]
+            out["hot_path"] = [hot_path_leg(device, n, lay) for n in (196, 49) for lay in ("lm", "cm")]
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg(args)

@@ -20,8 +20,14 @@
  *   - math is fp32 (dtype = COATTN_F32), row-vector convention Linear(x) = x W^T + b.
  *
  * Layouts
- *   V      : [B, d, N]  channel-major image features = the physical buffer behind the
- *            reference's permuted view x_img[B,N,d] (model.py:215-217): strides (d*N, 1, N).
+ *   V      : the image features x_img[B,N,d] (model.py:215-217), given as a base pointer plus the element
+ *            strides (v_sB, v_sN, v_sD) of that logical view -- no copy is ever made.  Two physical layouts
+ *            run on the fused kernels:
+ *              channel-major  [B][d][N]: (v_sB >= d*N, v_sN = 1, v_sD = N) -- the buffer behind the permuted
+ *                             view the reference's NCHW encoder returns;
+ *              location-major [B][N][d]: (v_sB >= N*d, v_sN = d, v_sD = 1) -- what a channels_last encoder
+ *                             emits (x_img is then contiguous);
+ *            any other strides take the general-shape kernels.  dV is described the same way.
  *   Q[l]   : [B, T, d]  contiguous, l = 0..L-1 (word, phrase, sentence; model.py:298).
  *   W_v,W_q: [d, d] (nn.Linear.weight, out x in); b_v,b_q: [d]; w_v,w_q: [d]; c_v,c_q: [1]
  *            (model.py:350-354).  W_b (model.py:347) is dead in the reference and not passed.
@@ -69,7 +75,7 @@ int coattn_version(void);
 /* last error message of the calling thread ("" if none) */
 const char* coattn_last_error(void);
 
-/* 1 if a fused-kernel configuration exists for this shape, else 0 */
+/* 1 if a fused-kernel configuration exists for this shape (for channel-major or location-major V), else 0 */
 int coattn_fused_supported(int B, int N, int T, int d, int L, int dtype);
 
 /* Buffer sizes in bytes.  saved: forward -> backward state (P_v, P_q, C, a_v, a_q, H_q);
@@ -81,27 +87,29 @@ int coattn_workspace_bytes(int B, int N, int T, int d, int L, int dtype, int fla
  *   Q      : host array of L device pointers.
  *   saved  : NULL for inference (nothing kept), else a buffer of `saved` bytes.
  *   v_out,q_out : [L,B,d]. */
-int coattn_forward(const void* V, const void* const* Q, const coattn_params* p,
-                   void* v_out, void* q_out, void* saved, void* ws,
+int coattn_forward(const void* V, int64_t v_sB, int64_t v_sN, int64_t v_sD, const void* const* Q,
+                   const coattn_params* p, void* v_out, void* q_out, void* saved, void* ws,
                    int B, int N, int T, int d, int L, int dtype, int flags, void* stream);
 
 /* Second half of coattn_forward only: everything after the projections P_v, P_q (affinity +
  * tanh model.py:377, H_v/H_q :380-384, scores + row softmax :387-388, attended reductions
  * :391-392), reading P_v / P_q from a `saved` buffer that a previous coattn_forward on the same
  * inputs filled.  Exists so that tests and bench.py can time / check this kernel in isolation. */
-int coattn_attention_forward(const void* V, const void* const* Q, const coattn_params* p,
-                             void* v_out, void* q_out, void* saved, void* ws,
+int coattn_attention_forward(const void* V, int64_t v_sB, int64_t v_sN, int64_t v_sD, const void* const* Q,
+                             const coattn_params* p, void* v_out, void* q_out, void* saved, void* ws,
                              int B, int N, int T, int d, int L, int dtype, int flags, void* stream);
 
 /* Backward (autograd of model.py:372-392).
  *   gv,gq : [L,B,d] upstream gradients of v_out,q_out.
- *   dV    : [B,d,N] (overwritten), or NULL when the image features need no gradient (frozen
- *           encoder, model.py:239-241);  dQ : host array of L device pointers [B,T,d] (overwritten).
+ *   dV    : gradient of x_img with its own strides (dv_sB, dv_sN, dv_sD) (overwritten), or NULL when the image
+ *           features need no gradient (frozen encoder, model.py:239-241);
+ *   dQ    : host array of L device pointers [B,T,d] (overwritten).
  *   pg    : parameter gradients; accumulate = 0 overwrites, 1 adds into them (grads of the
  *           three levels are always summed: one weight set is shared, model.py:167, :372). */
-int coattn_backward(const void* V, const void* const* Q, const coattn_params* p,
-                    const void* saved, const void* gv, const void* gq,
-                    void* dV, void* const* dQ, const coattn_param_grads* pg, int accumulate,
+int coattn_backward(const void* V, int64_t v_sB, int64_t v_sN, int64_t v_sD, const void* const* Q,
+                    const coattn_params* p, const void* saved, const void* gv, const void* gq,
+                    void* dV, int64_t dv_sB, int64_t dv_sN, int64_t dv_sD, void* const* dQ,
+                    const coattn_param_grads* pg, int accumulate,
                     void* ws, int B, int N, int T, int d, int L, int dtype, int flags, void* stream);
 
 /* ---- PhraseConvPool: the question hierarchy's phrase level ----------------

@@ -27,17 +27,28 @@ def saved_views(saved, B, N, T, d, L):
     return out
 
 
-def run_hip(V, Qs, P, gv=None, gq=None, impl="general", need_dv=True, accumulate=0, grads_init=None, bf16_proj=False):
-    """V [B,d,N], Qs list of [B,T,d], P dict of reference-named params (CPU or CUDA tensors).
-    Returns dict with v,q and saved state; with gv/gq also all gradients."""
+LAYOUTS = ("cm", "lm")      # channel-major [B,d,N] (the reference's NCHW encoder) / location-major [B,N,d] (channels_last)
+
+
+def run_hip(V, Qs, P, gv=None, gq=None, impl="general", need_dv=True, accumulate=0, grads_init=None, bf16_proj=False,
+            layout="cm"):
+    """V [B,d,N] (channel-major values; `layout` selects the PHYSICAL layout handed to the C-ABI: "cm" as is, "lm" a
+    [B,N,d] buffer), Qs list of [B,T,d], P dict of reference-named params (CPU or CUDA tensors).
+    Returns dict with v,q and saved state; with gv/gq also all gradients (dV_phys always as [B,d,N] values)."""
     lib = _lib.load()
     dev = torch.device("cuda:0")
     V = V.to(dev).contiguous()
+    B, d, N = V.shape
+    if layout == "lm":
+        Vbuf = V.permute(0, 2, 1).contiguous()          # [B,N,d]
+        vstr = (N * d, d, 1)
+    else:
+        Vbuf = V
+        vstr = (d * N, 1, N)
     Qs = [q.to(dev).contiguous() for q in Qs]
     names = ("W_v.weight", "W_v.bias", "W_q.weight", "W_q.bias", "w_v.weight", "w_v.bias", "w_q.weight", "w_q.bias")
     ps = [P[k].to(dev).contiguous() for k in names]
     assert gv is None or gv.shape[0] == len(Qs)
-    B, d, N = V.shape
     T = Qs[0].shape[1]
     L = len(Qs)
     flag = IMPL[impl] | (_lib.FLAG_BF16_PROJ if bf16_proj else 0)
@@ -49,7 +60,7 @@ def run_hip(V, Qs, P, gv=None, gq=None, impl="general", need_dv=True, accumulate
     qptr = (C.c_void_p * L)(*[t.data_ptr() for t in Qs])
     p = _lib.Params(*[t.data_ptr() for t in ps])
     stream = torch.cuda.current_stream().cuda_stream
-    _lib.check(lib.coattn_forward(V.data_ptr(), qptr, C.byref(p), v.data_ptr(), q.data_ptr(), saved.data_ptr(),
+    _lib.check(lib.coattn_forward(Vbuf.data_ptr(), *vstr, qptr, C.byref(p), v.data_ptr(), q.data_ptr(), saved.data_ptr(),
                                   ws.data_ptr(), B, N, T, d, L, _lib.F32, flag, C.c_void_p(stream)), "coattn_forward")
     torch.cuda.synchronize()
     out = {"v": v, "q": q}
@@ -59,7 +70,7 @@ def run_hip(V, Qs, P, gv=None, gq=None, impl="general", need_dv=True, accumulate
     gv = gv.to(dev).contiguous()
     gq = gq.to(dev).contiguous()
     ws2 = torch.full((bb // 4,), float("nan"), device=dev)
-    dV = torch.full_like(V, float("nan")) if need_dv else None
+    dV = torch.full_like(Vbuf, float("nan")) if need_dv else None
     dQs = [torch.full_like(t, float("nan")) for t in Qs]
     if grads_init is None:
         grads = [torch.full_like(t, float("nan")) for t in ps]
@@ -67,12 +78,12 @@ def run_hip(V, Qs, P, gv=None, gq=None, impl="general", need_dv=True, accumulate
         grads = [g.to(dev).clone() for g in grads_init]
     pg = _lib.ParamGrads(*[t.data_ptr() for t in grads])
     dqptr = (C.c_void_p * L)(*[t.data_ptr() for t in dQs])
-    _lib.check(lib.coattn_backward(V.data_ptr(), qptr, C.byref(p), saved.data_ptr(), gv.data_ptr(), gq.data_ptr(),
-                                   dV.data_ptr() if need_dv else None, dqptr, C.byref(pg), accumulate,
-                                   ws2.data_ptr(), B, N, T, d, L, _lib.F32, flag, C.c_void_p(stream)),
+    _lib.check(lib.coattn_backward(Vbuf.data_ptr(), *vstr, qptr, C.byref(p), saved.data_ptr(), gv.data_ptr(),
+                                   gq.data_ptr(), dV.data_ptr() if need_dv else None, *vstr, dqptr, C.byref(pg),
+                                   accumulate, ws2.data_ptr(), B, N, T, d, L, _lib.F32, flag, C.c_void_p(stream)),
                "coattn_backward")
     torch.cuda.synchronize()
-    out["dV_phys"] = dV
+    out["dV_phys"] = (dV.permute(0, 2, 1).contiguous() if layout == "lm" else dV) if need_dv else None
     out["dQ"] = torch.stack(dQs)
     for k, g in zip(names, grads):
         out["d" + k] = g

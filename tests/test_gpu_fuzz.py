@@ -43,8 +43,10 @@ def test_random_shape_vs_oracle(shape):
     impls = ["general"]
     if vqa_amd._lib.load().coattn_fused_supported(B, N, T, d, L, 0):
         impls.append("fused")
-    for impl in impls:
-        r = run_hip(V, Qs, P, gv, gq, impl=impl)
+    from tests._hip import LAYOUTS
+    for impl, layout in [(i, lay) for i in impls for lay in LAYOUTS]:
+        r = run_hip(V, Qs, P, gv, gq, impl=impl, layout=layout)
+        impl = impl + "/" + layout
         for k in ("v", "q", "C", "a_v", "a_q"):
             err = (r[k].double().cpu() - f[k]).abs().max().item()
             assert err < FWD_TOL, (impl, k, err)

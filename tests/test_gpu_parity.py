@@ -29,15 +29,18 @@ def test_forward_backward_vs_reference_golden(name):
     from tests._hip import run_hip
     gold = G.load(name)
     V, Qs, P, gv, gq = G.build_case(name, torch.float32)
+    from tests._hip import LAYOUTS
     for impl in _impls(name):
-        r = run_hip(V, Qs, P, gv, gq, impl=impl)
-        for k, t in r.items():
-            assert torch.isfinite(t).all(), (impl, k)
-        fe = G.fwd_errors(r, gold, "64")
-        ge = G.grad_errors(r, gold, "64")
-        print(name, impl, "fwd", {k: "%.1e" % v for k, v in fe.items()}, "grad", {k: "%.1e" % v for k, v in ge.items()})
-        assert max(fe.values()) < FWD_TOL, (impl, fe)
-        assert max(ge.values()) < GRAD_TOL, (impl, ge)
+        for layout in LAYOUTS:      # channel-major [B,d,N] (NCHW encoder) and location-major [B,N,d] (channels_last)
+            r = run_hip(V, Qs, P, gv, gq, impl=impl, layout=layout)
+            for k, t in r.items():
+                assert torch.isfinite(t).all(), (impl, layout, k)
+            fe = G.fwd_errors(r, gold, "64")
+            ge = G.grad_errors(r, gold, "64")
+            print(name, impl, layout, "fwd", {k: "%.1e" % v for k, v in fe.items()},
+                  "grad", {k: "%.1e" % v for k, v in ge.items()})
+            assert max(fe.values()) < FWD_TOL, (impl, layout, fe)
+            assert max(ge.values()) < GRAD_TOL, (impl, layout, ge)
 
 
 @pytest.mark.parametrize("impl", ["general", "fused"])
@@ -107,14 +110,16 @@ def test_frozen_image_features_and_accumulate(impl):
         assert (cacc["d" + k] - (a["d" + k] + 1.0)).abs().max() < 1e-4 * max(1.0, a["d" + k].abs().max().item()), k
 
 
-@pytest.mark.parametrize("impl", ["general", "fused"])
-def test_full_size_cfg2_properties(impl):
-    """BASELINE config 2 (B=160, N=196, T=26, d=512): oracle on a sample subset + size-independent
-    properties (attention maps are distributions; v inside the range of V; per-sample independence;
-    backward linear in the upstream gradient)."""
+@pytest.mark.parametrize("impl,layout,N", [("general", "cm", 196), ("fused", "cm", 196), ("fused", "lm", 196),
+                                           ("general", "lm", 49), ("fused", "cm", 49), ("fused", "lm", 49)])
+def test_full_size_cfg2_properties(impl, layout, N):
+    """BASELINE config 2 (B=160, T=26, d=512) at the reference's own grid (448x448 -> N=196) and at the grid of
+    BASELINE's 224x224 images (N=49), both physical layouts of the image features: oracle on a sample subset +
+    size-independent properties (attention maps are distributions; v inside the range of V; per-sample
+    independence; backward linear in the upstream gradient) + full-batch parameter gradients vs the oracle."""
     import vqa_amd
     from tests._hip import run_hip
-    B, N, T, d = 160, 196, 26, 512
+    B, T, d = 160, 26, 512
     if impl != "general" and not vqa_amd._lib.load().coattn_fused_supported(B, N, T, d, 3, 0):
         pytest.skip("no fused configuration for this shape")
     lens = sorted([26] + [3 + (7 * i) % 24 for i in range(B - 1)], reverse=True)
@@ -122,7 +127,7 @@ def test_full_size_cfg2_properties(impl):
     V, Qs = O.make_inputs(B, N, T, d, 77, lens=lens, scale_q=(2.0 / d) ** 0.5)
     gv = torch.from_numpy(O.hash_normal((3, B, d), 901)).float()
     gq = torch.from_numpy(O.hash_normal((3, B, d), 902)).float()
-    r = run_hip(V, Qs, P, gv, gq, impl=impl)
+    r = run_hip(V, Qs, P, gv, gq, impl=impl, layout=layout)
     assert (r["a_v"].sum(-1) - 1).abs().max() < 1e-5 and (r["a_q"].sum(-1) - 1).abs().max() < 1e-5
     Vd = V.cuda()
     assert (r["v"] <= Vd.max(2).values[None] + 1e-5).all() and (r["v"] >= Vd.min(2).values[None] - 1e-5).all()
@@ -136,7 +141,7 @@ def test_full_size_cfg2_properties(impl):
     assert (r["dV_phys"][idx].cpu() - g["dV_phys"]).abs().max() / scale < GRAD_TOL
     assert (r["dQ"][:, idx].cpu() - g["dQ"]).abs().max() / g["dQ"].abs().max() < GRAD_TOL
     # linearity: backward(2*g) == 2*backward(g)
-    r2 = run_hip(V, Qs, P, 2 * gv, 2 * gq, impl=impl)
+    r2 = run_hip(V, Qs, P, 2 * gv, 2 * gq, impl=impl, layout=layout)
     for k in ("dV_phys", "dQ", "dW_v.weight", "dW_q.weight", "dw_v.weight"):
         assert (r2[k] - 2 * r[k]).abs().max() <= 2e-5 * max(1e-3, r[k].abs().max().item()), k
     # full-batch parameter gradients vs the oracle (CPU, ~10 s)

@@ -35,7 +35,10 @@ q = torch.empty(L, B, d, device=dev)
 qptr = (C.c_void_p * L)(*[t.data_ptr() for t in Qs])
 p = _lib.Params(*[t.data_ptr() for t in ps])
 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-args = (V.data_ptr(), qptr, C.byref(p), v.data_ptr(), q.data_ptr(), saved.data_ptr(), ws.data_ptr(),
+vstr = (d * N, 1, N)
+if os.environ.get("LAYOUT", "lm") == "lm":
+    V, vstr = V.permute(0, 2, 1).contiguous(), (N * d, d, 1)
+args = (V.data_ptr(), *vstr, qptr, C.byref(p), v.data_ptr(), q.data_ptr(), saved.data_ptr(), ws.data_ptr(),
         B, N, T, d, L, _lib.F32, 0, stream)
 _lib.check(lib.coattn_forward(*args), "coattn_forward")
 for _ in range(5):
@@ -49,7 +52,7 @@ if not live.any():
 st = tail[live] * 0.01                       # 100 MHz ticks -> microseconds
 t0 = st[:, 0].min()
 names = ["phase 1 MFMA loop (A = Q V^T)", "cross-wave sum + C = tanh", "phase 2 tile loop (H_v scores, H_q)",
-         "H_q epilogue", "softmaxes + q"]
+         "H_q epilogue / barrier", "softmaxes + q"]
 print("workgroups with stamps: %d; kernel span (first start -> last end): %.1f us" % (live.sum(), st[:, 5].max() - t0))
 print("start spread: %.1f us; end spread: %.1f us" % (st[:, 0].max() - t0, st[:, 5].max() - st[:, 5].min()))
 for k, nm in enumerate(names):
@@ -61,7 +64,7 @@ for k in range(6):
     print("  boundary %d reached at (rel. to first start): mean %6.1f  min %6.1f  max %6.1f us"
           % (k, (st[:, k] - t0).mean(), (st[:, k] - t0).min(), (st[:, k] - t0).max()))
 
-# per-tile stamps of the tile-pipelined kernel (coattn_fused2.hip): loop top, steps done, barrier passed, C ready
+# (the per-tile stamps of the removed tile-pipelined kernel are no longer produced)
 nt = (N + 15) // 16
 if st.shape[1] >= 8 + 4 * nt and (st[:, 8:8 + 4 * nt] > 0).all():
     tl = st[:, 8:8 + 4 * nt].reshape(-1, nt, 4)
@@ -81,3 +84,11 @@ if st.shape[1] > 7 and (tail[live][:, 6] > 0).all() and (tail[live][:, 7] > 0).a
     us = st[:, 3] - st[:, 2]
     print("tile loop: %.0f shader cycles per workgroup (%.0f per tile) in %.1f us -> %.2f GHz; MFMA issue cycles per wave: %d"
           % (cyc.mean(), cyc.mean() / nt, us.mean(), (cyc / us).mean() / 1e3, nt * 120 * 32))
+
+# per-pass stamps of coattn_fwd32.hip: pass start, tile loop done, epilogue done (two passes per 128-channel slice)
+npass = 2 * max(1, d // (128 * (4 if d % 512 == 0 else 2)))
+if st.shape[1] >= 8 + 3 * npass and (st[:, 8:8 + 3 * npass] > 0).all():
+    ps = st[:, 8:8 + 3 * npass].reshape(-1, npass, 3)
+    print("per pass (mean over workgroups): " + "; ".join(
+        "pass %d: tile loop %.1f us, epilogue %.1f us" % (i, (ps[:, i, 1] - ps[:, i, 0]).mean(), (ps[:, i, 2] - ps[:, i, 1]).mean())
+        for i in range(npass)))

@@ -90,11 +90,12 @@ def load() -> C.CDLL:
     lib.coattn_last_error.restype = C.c_char_p
     lib.coattn_fused_supported.argtypes = [C.c_int] * 6
     lib.coattn_workspace_bytes.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_size_t)] * 3
-    lib.coattn_forward.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(Params), C.c_void_p, C.c_void_p,
-                                   C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]
+    lib.coattn_forward.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(Params),
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]
     lib.coattn_attention_forward.argtypes = lib.coattn_forward.argtypes
-    lib.coattn_backward.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(Params), C.c_void_p, C.c_void_p,
-                                    C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(ParamGrads), C.c_int,
+    lib.coattn_backward.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(Params),
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                    C.POINTER(C.c_void_p), C.POINTER(ParamGrads), C.c_int,
                                     C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]
     lib.coattn_gemm_f32.argtypes = [C.POINTER(GemmDesc), C.c_void_p]
     lib.coattn_gemm_bf16.argtypes = [C.POINTER(GemmDesc), C.c_void_p]

@@ -28,11 +28,24 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-def _physical_v(x_img: torch.Tensor) -> torch.Tensor:
-    """[B,N,d] module input -> channel-major physical buffer [B,d,N] (no copy when x_img is the
-    permuted view the image encoder produces, model.py:215-217)."""
-    v = x_img.permute(0, 2, 1)
-    return v if v.is_contiguous() else v.contiguous()
+def _native_layout(x_img: torch.Tensor) -> torch.Tensor:
+    """The module input x_img[B,N,d] as the kernels take it: by pointer + element strides, no copy, when it is
+    channel-major (the permuted view of an NCHW encoder, model.py:215-217: strides (d N, 1, N)) or location-major
+    (a channels_last encoder: contiguous [B,N,d]); anything else is made contiguous once."""
+    B, N, d = x_img.shape
+    sB, sN, sD = x_img.stride()
+    if B == 1:
+        sB = max(sB, N * d)                 # the stride of a size-1 dimension is arbitrary
+    ext = (N - 1) * sN + (d - 1) * sD
+    if ((sD == 1 and sN == d) or (sN == 1 and sD == N)) and sB > ext and x_img.data_ptr() % 16 == 0:
+        return x_img
+    return x_img.contiguous()
+
+
+def _strides(x: torch.Tensor):
+    B, N, d = x.shape
+    sB, sN, sD = x.stride()
+    return (max(sB, N * d) if B == 1 else sB), sN, sD
 
 
 class _CoAttentionFn(torch.autograd.Function):
@@ -52,7 +65,7 @@ class _CoAttentionFn(torch.autograd.Function):
         for q in x_ques:
             if tuple(q.shape) != (B, T, d):
                 raise RuntimeError("question features must all be [B,T,d] = %s, got %s" % ((B, T, d), tuple(q.shape)))
-        V = _physical_v(x_img)
+        V = _native_layout(x_img)
         Qs = [q.contiguous() for q in x_ques]
         params = [t.contiguous() for t in (W_v, b_v, W_q, b_q, w_v, c_v, w_q, c_q)]
         need_grad = any(ctx.needs_input_grad)
@@ -66,8 +79,9 @@ class _CoAttentionFn(torch.autograd.Function):
         p = _lib.Params(*[t.data_ptr() for t in params])
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
-            _lib.check(lib.coattn_forward(_ptr(V), qptr, C.byref(p), _ptr(out_v), _ptr(out_q), _ptr(saved), _ptr(ws),
-                                          B, N, T, d, L, _lib.F32, impl, C.c_void_p(stream)), "coattn_forward")
+            _lib.check(lib.coattn_forward(_ptr(V), *_strides(V), qptr, C.byref(p), _ptr(out_v), _ptr(out_q), _ptr(saved),
+                                          _ptr(ws), B, N, T, d, L, _lib.F32, impl, C.c_void_p(stream)),
+                       "coattn_forward")
         if need_grad:
             ctx.save_for_backward(V, saved, *params, *Qs)
             ctx.dims = (B, N, T, d, L, impl)
@@ -86,7 +100,10 @@ class _CoAttentionFn(torch.autograd.Function):
         _, _, bb = _lib.workspace_bytes(B, N, T, d, L, impl)
         ws = torch.empty(bb // 4, device=dev, dtype=torch.float32)
         need_dv = ctx.needs_input_grad[0]
-        dV = torch.empty_like(V) if need_dv else None
+        dV = None
+        if need_dv:                         # gradient of x_img[B,N,d] in the layout of x_img itself
+            dV = (torch.empty((B, N, d), device=dev) if V.stride(2) == 1
+                  else torch.empty((B, d, N), device=dev).permute(0, 2, 1))
         dQs = [torch.empty_like(q) for q in Qs]
         grads = [torch.empty_like(t) for t in params]
         pg = _lib.ParamGrads(*[t.data_ptr() for t in grads])
@@ -95,11 +112,11 @@ class _CoAttentionFn(torch.autograd.Function):
         dqptr = (C.c_void_p * L)(*[q.data_ptr() for q in dQs])
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
-            _lib.check(lib.coattn_backward(_ptr(V), qptr, C.byref(p), _ptr(saved), _ptr(g_v), _ptr(g_q), _ptr(dV),
-                                           dqptr, C.byref(pg), 0, _ptr(ws), B, N, T, d, L, _lib.F32, impl,
-                                           C.c_void_p(stream)), "coattn_backward")
-        d_img = dV.permute(0, 2, 1) if need_dv else None
-        return (d_img, *grads, None, *dQs)
+            _lib.check(lib.coattn_backward(_ptr(V), *_strides(V), qptr, C.byref(p), _ptr(saved), _ptr(g_v), _ptr(g_q),
+                                           _ptr(dV), *(_strides(dV) if need_dv else (0, 0, 0)), dqptr, C.byref(pg), 0,
+                                           _ptr(ws), B, N, T, d, L, _lib.F32, impl, C.c_void_p(stream)),
+                       "coattn_backward")
+        return (dV, *grads, None, *dQs)
 
 
 def coattention(x_img: torch.Tensor, x_ques: Sequence[torch.Tensor], W_v, b_v, W_q, b_q, w_v, c_v, w_q, c_q,

@@ -100,6 +100,7 @@ namespace {
 struct Ctx {
   int B, N, T, d, L;
   hipStream_t s;
+  VLayout vl;                 // element strides of x_img[B,N,d]
   bool bf16_proj = false;     // COATTN_FLAG_BF16_PROJ: the projections and their gradients on the bf16 MFMA
 };
 
@@ -112,7 +113,8 @@ int proj_v(const Ctx& c, const float* V, const float* Wv, const float* bv, float
   coattn_gemm_desc g = {};
   g.A = V; g.B = Wv; g.C = Pv; g.bias_n = bv;
   g.M = c.B * c.N; g.N = c.d; g.K = c.d; g.batch = 1;
-  g.a_sm = 1; g.a_sk = c.N; g.a_mdiv = c.N; g.a_sdiv = (int64_t)c.d * c.N;
+  g.a_sm = c.vl.sN; g.a_sk = c.vl.sD;            // row m = (b, n): split rows unless the samples abut
+  if (c.vl.sB != (int64_t)c.N * c.vl.sN) { g.a_mdiv = c.N; g.a_sdiv = c.vl.sB; }
   g.b_sk = 1; g.b_sn = c.d;
   g.c_sm = c.d; g.c_sn = 1;
   return launch_proj(c, g);
@@ -131,7 +133,7 @@ int proj_q(const Ctx& c, const float* Q, const float* Wq, const float* bq, float
 int affinity(const Ctx& c, const float* Q, const float* V, float* C) {
   coattn_gemm_desc g = {};
   g.A = Q; g.a_sz = (int64_t)c.T * c.d; g.a_sm = c.d; g.a_sk = 1;
-  g.B = V; g.b_sz = (int64_t)c.d * c.N; g.b_sk = c.N; g.b_sn = 1;
+  g.B = V; g.b_sz = c.vl.sB; g.b_sk = c.vl.sD; g.b_sn = c.vl.sN;
   g.C = C; g.c_sz = (int64_t)c.T * c.N; g.c_sm = c.N; g.c_sn = 1;
   g.M = c.T; g.N = c.N; g.K = c.d; g.batch = c.B; g.act = 1;
   return launch_gemm_f32(g, c.s);
@@ -190,15 +192,15 @@ int general_attention(const Ctx& c, const float* V, const float* const* Q, const
     CA_TRY(launch_score_softmax(Hv, (const float*)p->w_v, (const float*)p->c_v, av, c.B, c.N, c.d, c.s));
     CA_TRY(launch_score_softmax(Hq, (const float*)p->w_q, (const float*)p->c_q, aq, c.B, c.T, c.d, c.s));
     // v = sum_n a_v[n] V[:,n]   (model.py:391);  q = sum_t a_q[t] Q[t,:]   (model.py:392)
-    CA_TRY(launch_gemv(V, av, v_out + (size_t)l * c.B * c.d, c.B, c.d, c.N, (int64_t)c.d * c.N, c.N, 1, c.N, c.d, c.s));
+    CA_TRY(launch_gemv(V, av, v_out + (size_t)l * c.B * c.d, c.B, c.d, c.N, c.vl.sB, c.vl.sD, c.vl.sN, c.N, c.d, c.s));
     CA_TRY(launch_gemv(Q[l], aq, q_out + (size_t)l * c.B * c.d, c.B, c.d, c.T, (int64_t)c.T * c.d, 1, c.d, c.T, c.d, c.s));
   }
   return 0;
 }
 
 int backward_general(const Ctx& c, const float* V, const float* const* Q, const coattn_params* p, const float* sv,
-                     const float* gv, const float* gq, float* dV, float* const* dQ, const coattn_param_grads* pg,
-                     int accumulate, float* ws) {
+                     const float* gv, const float* gq, float* dV, const VLayout& dvl, float* const* dQ,
+                     const coattn_param_grads* pg, int accumulate, float* ws) {
   const SavedPlan sp = plan_saved(c.B, c.N, c.T, c.d, c.L);
   const BwdPlan bp = plan_bwd(c.B, c.N, c.T, c.d, c.L);
   const int B = c.B, N = c.N, T = c.T, d = c.d, L = c.L;
@@ -227,7 +229,7 @@ int backward_general(const Ctx& c, const float* V, const float* const* Q, const 
     // recompute H_v = tanh(P_v + C^T P_q)
     CA_TRY(ct_times(c, C, Pq, Pv, Hv, 1));
     // softmax backward of a_v, a_q
-    CA_TRY(launch_gemv(V, gv + l * Bd, dav, B, N, d, (int64_t)d * N, 1, N, d, N, c.s));
+    CA_TRY(launch_gemv(V, gv + l * Bd, dav, B, N, d, c.vl.sB, c.vl.sN, c.vl.sD, d, N, c.s));
     CA_TRY(launch_softmax_bwd(av, dav, dsv, B, N, c.s));
     CA_TRY(launch_gemv(Q[l], gq + l * Bd, daq, B, T, d, (int64_t)T * d, d, 1, d, T, c.s));
     CA_TRY(launch_softmax_bwd(aq, daq, dsq, B, T, c.s));
@@ -265,20 +267,20 @@ int backward_general(const Ctx& c, const float* V, const float* const* Q, const 
     {
       coattn_gemm_desc g = {};
       g.A = dC; g.a_sz = (int64_t)T * N; g.a_sm = N; g.a_sk = 1;
-      g.B = V; g.b_sz = (int64_t)d * N; g.b_sk = 1; g.b_sn = N;
+      g.B = V; g.b_sz = c.vl.sB; g.b_sk = c.vl.sN; g.b_sn = c.vl.sD;
       g.Cin = dQ[l]; g.cin_sz = (int64_t)T * d; g.cin_sm = d; g.cin_sn = 1; g.beta = 1.f;
       g.C = dQ[l]; g.c_sz = (int64_t)T * d; g.c_sm = d; g.c_sn = 1;
       g.M = T; g.N = d; g.K = N; g.batch = B;
       CA_TRY(launch_gemm_f32(g, c.s));
     }
     // dV (+)= a_v (x) gv + Q^T dA
-    if (dV) CA_TRY(launch_rank1(av, gv + l * Bd, dV, B, N, d, (int64_t)d * N, 1, N, l > 0 ? 1 : 0, c.s));
+    if (dV) CA_TRY(launch_rank1(av, gv + l * Bd, dV, B, N, d, dvl.sB, dvl.sN, dvl.sD, l > 0 ? 1 : 0, c.s));
     if (dV) {
       coattn_gemm_desc g = {};
       g.A = Q[l]; g.a_sz = (int64_t)T * d; g.a_sm = 1; g.a_sk = d;
       g.B = dC; g.b_sz = (int64_t)T * N; g.b_sk = N; g.b_sn = 1;
-      g.Cin = dV; g.cin_sz = (int64_t)d * N; g.cin_sm = N; g.cin_sn = 1; g.beta = 1.f;
-      g.C = dV; g.c_sz = (int64_t)d * N; g.c_sm = N; g.c_sn = 1;
+      g.Cin = dV; g.cin_sz = dvl.sB; g.cin_sm = dvl.sD; g.cin_sn = dvl.sN; g.beta = 1.f;
+      g.C = dV; g.c_sz = dvl.sB; g.c_sm = dvl.sD; g.c_sn = dvl.sN;
       g.M = d; g.N = N; g.K = T; g.batch = B;
       CA_TRY(launch_gemm_f32(g, c.s));
     }
@@ -299,8 +301,8 @@ int backward_general(const Ctx& c, const float* V, const float* const* Q, const 
     coattn_gemm_desc g = {};
     g.A = p->W_v; g.a_sm = 1; g.a_sk = d; g.a_sz = 0;
     g.B = dPv; g.b_sz = (int64_t)N * d; g.b_sk = 1; g.b_sn = d;
-    g.Cin = dV; g.cin_sz = (int64_t)d * N; g.cin_sm = N; g.cin_sn = 1; g.beta = 1.f;
-    g.C = dV; g.c_sz = (int64_t)d * N; g.c_sm = N; g.c_sn = 1;
+    g.Cin = dV; g.cin_sz = dvl.sB; g.cin_sm = dvl.sD; g.cin_sn = dvl.sN; g.beta = 1.f;
+    g.C = dV; g.c_sz = dvl.sB; g.c_sm = dvl.sD; g.c_sn = dvl.sN;
     g.M = d; g.N = N; g.K = d; g.batch = B;
     CA_TRY(c.bf16_proj ? launch_gemm_bf16in(g, c.s) : launch_gemm_f32(g, c.s));
   }
@@ -310,7 +312,7 @@ int backward_general(const Ctx& c, const float* V, const float* const* Q, const 
     const int S = (B + G - 1) / G;
     coattn_gemm_desc g = {};
     g.A = dPv; g.a_sm = 1; g.a_sk = d; g.a_si = (int64_t)N * d; g.a_sz = (int64_t)G * N * d;
-    g.B = V; g.b_sk = 1; g.b_sn = N; g.b_si = (int64_t)d * N; g.b_sz = (int64_t)G * d * N;
+    g.B = V; g.b_sk = c.vl.sN; g.b_sn = c.vl.sD; g.b_si = c.vl.sB; g.b_sz = (int64_t)G * c.vl.sB;
     g.C = part; g.c_sz = (int64_t)d * d; g.c_sm = d; g.c_sn = 1;
     g.M = d; g.N = d; g.K = N; g.batch = S; g.inner = G; g.inner_total = B;
     CA_TRY(c.bf16_proj ? launch_gemm_bf16in(g, c.s) : launch_gemm_f32(g, c.s));
@@ -343,11 +345,12 @@ int backward_general(const Ctx& c, const float* V, const float* const* Q, const 
   return 0;
 }
 
-int pick_impl(int flags, int B, int N, int T, int d, int L, int* fused) {
+int pick_impl(int flags, int B, int N, int T, int d, int L, const VLayout& vl, int* fused) {
   const int sel = flags & 3;
-  const int ok = fused_supported(B, N, T, d, L);
+  const int ok = fused_supported(B, N, T, d, L) && fused_layout_ok(vl, N, d);
   if (sel == COATTN_IMPL_FUSED) {
-    CA_CHECK_ARG(ok, "fused kernels do not support B=%d N=%d T=%d d=%d L=%d", B, N, T, d, L);
+    CA_CHECK_ARG(ok, "fused kernels do not support B=%d N=%d T=%d d=%d L=%d with V strides (%ld, %ld, %ld)", B, N, T, d, L,
+                 vl.sB, vl.sN, vl.sD);
     *fused = 1;
   } else if (sel == COATTN_IMPL_GENERAL) {
     *fused = 0;
@@ -359,59 +362,76 @@ int pick_impl(int flags, int B, int N, int T, int d, int L, int* fused) {
 
 }  // namespace
 
-static int forward_impl(const void* V, const void* const* Q, const coattn_params* p, void* v_out, void* q_out,
-                        void* saved, void* ws, int B, int N, int T, int d, int L, int dtype, int flags, void* stream,
-                        bool do_proj, bool do_attn) {
+static int check_vlayout(const VLayout& v, int B, int N, int d, const char* what) {
+  (void)B;
+  CA_CHECK_ARG(v.sN > 0 && v.sD > 0 && v.sB > 0, "%s: strides must be positive (sB=%ld sN=%ld sD=%ld)", what, v.sB, v.sN, v.sD);
+  // the extent of one sample must not reach into the next one
+  CA_CHECK_ARG((long)(N - 1) * v.sN + (long)(d - 1) * v.sD < v.sB, "%s: sample stride %ld is smaller than a sample's extent", what, v.sB);
+  return 0;
+}
+
+static int forward_impl(const void* V, const VLayout& vl, const void* const* Q, const coattn_params* p, void* v_out,
+                        void* q_out, void* saved, void* ws, int B, int N, int T, int d, int L, int dtype, int flags,
+                        void* stream, bool do_proj, bool do_attn) {
   CA_TRY(check_shape(B, N, T, d, L, dtype));
   CA_CHECK_ARG(V && Q && p && v_out && q_out && ws, "forward: null argument");
+  CA_TRY(check_vlayout(vl, B, N, d, "forward: V"));
   for (int l = 0; l < L; ++l) CA_CHECK_ARG(Q[l] != nullptr, "forward: Q[%d] is null", l);
   CA_CHECK_ARG(p->W_v && p->b_v && p->W_q && p->b_q && p->w_v && p->c_v && p->w_q && p->c_q,
                "forward: null parameter pointer");
   int fused = 0;
-  CA_TRY(pick_impl(flags, B, N, T, d, L, &fused));
+  CA_TRY(pick_impl(flags, B, N, T, d, L, vl, &fused));
   const SavedPlan sp = plan_saved(B, N, T, d, L);
   float* sv = saved ? (float*)saved : (float*)ws;      // inference: state lives in the workspace
   float* tail = (float*)ws + sp.total;
-  Ctx c{B, N, T, d, L, (hipStream_t)stream};
+  Ctx c{B, N, T, d, L, (hipStream_t)stream, vl};
   c.bf16_proj = (flags & COATTN_FLAG_BF16_PROJ) != 0;
   if (do_proj) CA_TRY(general_projections(c, (const float*)V, (const float* const*)Q, p, sv));
   if (!do_attn) return 0;
   if (fused)
-    return fused_attention_forward(B, N, T, d, L, (const float*)V, (const float* const*)Q, p, (float*)v_out,
+    return fused_attention_forward(B, N, T, d, L, (const float*)V, vl, (const float* const*)Q, p, (float*)v_out,
                                    (float*)q_out, sv, tail, c.s);
   return general_attention(c, (const float*)V, (const float* const*)Q, p, (float*)v_out, (float*)q_out, sv, tail);
 }
 
-extern "C" int coattn_forward(const void* V, const void* const* Q, const coattn_params* p, void* v_out, void* q_out,
-                              void* saved, void* ws, int B, int N, int T, int d, int L, int dtype, int flags,
-                              void* stream) {
-  return forward_impl(V, Q, p, v_out, q_out, saved, ws, B, N, T, d, L, dtype, flags, stream, true, true);
+extern "C" int coattn_forward(const void* V, int64_t v_sB, int64_t v_sN, int64_t v_sD, const void* const* Q,
+                              const coattn_params* p, void* v_out, void* q_out, void* saved, void* ws, int B, int N,
+                              int T, int d, int L, int dtype, int flags, void* stream) {
+  return forward_impl(V, VLayout{(long)v_sB, (long)v_sN, (long)v_sD}, Q, p, v_out, q_out, saved, ws, B, N, T, d, L,
+                      dtype, flags, stream, true, true);
 }
 
-extern "C" int coattn_attention_forward(const void* V, const void* const* Q, const coattn_params* p, void* v_out,
-                                        void* q_out, void* saved, void* ws, int B, int N, int T, int d, int L,
-                                        int dtype, int flags, void* stream) {
+extern "C" int coattn_attention_forward(const void* V, int64_t v_sB, int64_t v_sN, int64_t v_sD, const void* const* Q,
+                                        const coattn_params* p, void* v_out, void* q_out, void* saved, void* ws,
+                                        int B, int N, int T, int d, int L, int dtype, int flags, void* stream) {
   CA_CHECK_ARG(saved != nullptr, "attention_forward: needs the saved buffer of a previous coattn_forward");
-  return forward_impl(V, Q, p, v_out, q_out, saved, ws, B, N, T, d, L, dtype, flags, stream, false, true);
+  return forward_impl(V, VLayout{(long)v_sB, (long)v_sN, (long)v_sD}, Q, p, v_out, q_out, saved, ws, B, N, T, d, L,
+                      dtype, flags, stream, false, true);
 }
 
-extern "C" int coattn_backward(const void* V, const void* const* Q, const coattn_params* p, const void* saved,
-                               const void* gv, const void* gq, void* dV, void* const* dQ,
+extern "C" int coattn_backward(const void* V, int64_t v_sB, int64_t v_sN, int64_t v_sD, const void* const* Q,
+                               const coattn_params* p, const void* saved, const void* gv, const void* gq, void* dV,
+                               int64_t dv_sB, int64_t dv_sN, int64_t dv_sD, void* const* dQ,
                                const coattn_param_grads* pg, int accumulate, void* ws, int B, int N, int T, int d,
                                int L, int dtype, int flags, void* stream) {
   CA_TRY(check_shape(B, N, T, d, L, dtype));
   CA_CHECK_ARG(V && Q && p && saved && gv && gq && dQ && pg && ws, "backward: null argument");  // dV may be NULL
+  const VLayout vl{(long)v_sB, (long)v_sN, (long)v_sD};
+  VLayout dvl{(long)dv_sB, (long)dv_sN, (long)dv_sD};
+  CA_TRY(check_vlayout(vl, B, N, d, "backward: V"));
+  if (dV) CA_TRY(check_vlayout(dvl, B, N, d, "backward: dV"));
+  else dvl = vl;
   for (int l = 0; l < L; ++l) CA_CHECK_ARG(Q[l] && dQ[l], "backward: Q[%d]/dQ[%d] is null", l, l);
   CA_CHECK_ARG(pg->dW_v && pg->db_v && pg->dW_q && pg->db_q && pg->dw_v && pg->dc_v && pg->dw_q && pg->dc_q,
                "backward: null parameter-gradient pointer");
   int fused = 0;
-  CA_TRY(pick_impl(flags, B, N, T, d, L, &fused));
-  Ctx c{B, N, T, d, L, (hipStream_t)stream};
+  CA_TRY(pick_impl(flags, B, N, T, d, L, vl, &fused));
+  Ctx c{B, N, T, d, L, (hipStream_t)stream, vl};
   c.bf16_proj = (flags & COATTN_FLAG_BF16_PROJ) != 0;
   if (fused && fused_backward_supported(B, N, T, d, L))
-    return fused_backward(B, N, T, d, L, (const float*)V, (const float* const*)Q, p, (const float*)saved,
-                          (const float*)gv, (const float*)gq, (float*)dV, (float* const*)dQ, pg, accumulate,
+    return fused_backward(B, N, T, d, L, (const float*)V, vl, (const float* const*)Q, p, (const float*)saved,
+                          (const float*)gv, (const float*)gq, (float*)dV, dvl, (float* const*)dQ, pg, accumulate,
                           (float*)ws, c.s, c.bf16_proj ? 1 : 0);
   return backward_general(c, (const float*)V, (const float* const*)Q, p, (const float*)saved, (const float*)gv,
-                          (const float*)gq, (float*)dV, (float* const*)dQ, pg, accumulate, (float*)ws);
+                          (const float*)gq, (float*)dV, dvl, (float* const*)dQ, pg, accumulate, (float*)ws);
 }

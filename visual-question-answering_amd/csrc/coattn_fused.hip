@@ -23,70 +23,11 @@
 
 #include <stdlib.h>
 
-#ifndef COATTN_SPLIT_ASM
-#define COATTN_SPLIT_ASM 1
-#endif
-// Diagnostic build only (tools/probe_stamps.py, -DCOATTN_STAMPS=1): wave 0 of every workgroup writes the
-// 100 MHz constant clock at its phase boundaries into the (otherwise unused) forward workspace tail.
-#ifndef COATTN_STAMPS
-#define COATTN_STAMPS 0
-#endif
-#if COATTN_STAMPS
-#define CA_STAMP(k)                                                                                   \
-  do {                                                                                                \
-    if (threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 64 + (k)] = __builtin_amdgcn_s_memrealtime();  \
-  } while (0)
-#define CA_STAMP_CYC(k)                                                                               \
-  do {                                                                                                \
-    if (threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 64 + (k)] = __builtin_amdgcn_s_memtime();      \
-  } while (0)
-#else
-#define CA_STAMP(k)
-#define CA_STAMP_CYC(k)
-#endif
-
 namespace {
 
 
 
 
-// fp32 -> three bf16 pieces with x = hi + mid + lo exactly (round to nearest even at every step).
-// Pairwise: one v_cvt_pk_bf16_f32 per piece and pair, the rounded halves come back as floats by a
-// shift / a mask (11 VALU ops per pair of elements).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bfv2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
-  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{a, b}), bfv2));
-}
-// a - b as ONE v_sub_f32: keeps the compiler from pairing the residual subtractions into v_pk_add_f32,
-// which costs more issue cycles beside MFMAs than two plain subtractions
-__device__ __forceinline__ float sub1(float a, float b) {
-#if COATTN_SPLIT_ASM
-  float r;
-  asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-#else
-  return a - b;
-#endif
-}
-__device__ __forceinline__ void split3(const f32x8& v, bf16x8 (&p)[3]) {
-  u32x4v h, m, l;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float a = v[2 * i], b = v[2 * i + 1];
-    h[i] = cvt_pk_bf16(a, b);
-    const float ra = sub1(a, __builtin_bit_cast(float, h[i] << 16));
-    const float rb = sub1(b, __builtin_bit_cast(float, h[i] & 0xffff0000u));
-    m[i] = cvt_pk_bf16(ra, rb);
-    const float sa = sub1(ra, __builtin_bit_cast(float, m[i] << 16));
-    const float sb = sub1(rb, __builtin_bit_cast(float, m[i] & 0xffff0000u));
-    l[i] = cvt_pk_bf16(sa, sb);
-  }
-  p[0] = __builtin_bit_cast(bf16x8, h);
-  p[1] = __builtin_bit_cast(bf16x8, m);
-  p[2] = __builtin_bit_cast(bf16x8, l);
-}
 // c += a . b over 32 k with fp32 accuracy: the six partial products down to relative order 2^-16
 // (each bf16 x bf16 product is exact in the fp32 accumulator), smallest terms first
 __device__ __forceinline__ f32x4 mfma_x3(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 c) {
@@ -120,7 +61,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, q4 = lane >> 4;           // MFMA column / k-quad (also C/D row quad)
   const float* Qp = a.Q[l] + (size_t)b * T * d;
-  const float* Vp = a.V + (size_t)b * d * N;
+  const float* Vp = a.V + (size_t)b * a.v_sB;
   const float* Pvp = a.Pv + (size_t)b * N * d;
   const float* Pqp = a.Pq + ((size_t)l * a.B + b) * T * d;
   const size_t pair = (size_t)l * a.B + b;
@@ -514,8 +455,8 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_attn_fwd_kernel(const FwdAr
 // v_l[b][k] = sum_n a_v[l][b][n] V[b][k][n]   (model.py:391), all L levels in one pass over V.
 // grid (d/64, B); 256 threads: 16 lanes per channel row, 16 rows per sweep.
 template <int NT>
-__global__ __launch_bounds__(256) void attend_v_kernel(const float* V, const float* av, float* v_out, int B, int N,
-                                                       int d, int L) {
+__global__ __launch_bounds__(256) void attend_v_kernel(const float* V, long v_sB, const float* av, float* v_out, int B,
+                                                       int N, int d, int L) {
   const int b = blockIdx.y, k0 = blockIdx.x * 64;
   const int tid = threadIdx.x, j = tid & 15, rsub = tid >> 4;      // rsub 0..15
   float aw[3][NT];
@@ -526,7 +467,7 @@ __global__ __launch_bounds__(256) void attend_v_kernel(const float* V, const flo
       const int n = j + 16 * m;
       aw[l][m] = (n < N && l < L) ? av[((size_t)l * B + b) * N + n] : 0.f;
     }
-  const float* Vb = V + (size_t)b * d * N;
+  const float* Vb = V + (size_t)b * v_sB;
   for (int it = 0; it < 4; ++it) {
     const int k = k0 + 16 * it + rsub;
     const float* vr = Vb + (size_t)k * N;
@@ -573,13 +514,15 @@ int fused_supported(int B, int N, int T, int d, int L) {
   return 1;
 }
 
-int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, const float* const* Q,
-                            const coattn_params* p, float* v_out, float* q_out, float* saved, float* ws,
-                            hipStream_t s) {
+int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, const VLayout& vl,
+                            const float* const* Q, const coattn_params* p, float* v_out, float* q_out, float* saved,
+                            float* ws, hipStream_t s) {
   CA_CHECK_ARG(fused_supported(B, N, T, d, L), "fused forward: unsupported shape");
+  const bool lm = v_is_lm(vl, N, d);
+  CA_CHECK_ARG(lm || v_is_cm(vl, N, d), "fused forward: image features must be channel-major [B,d,N] or location-major [B,N,d]");
   const SavedOff so = saved_off(B, N, T, d, L);
   FwdArgs a;
-  a.V = V;
+  a.V = V; a.v_sB = vl.sB; a.lm = lm ? 1 : 0;
   for (int l = 0; l < 8; ++l) a.Q[l] = l < L ? Q[l] : nullptr;
   a.Pv = saved + so.Pv; a.Pq = saved + so.Pq;
   a.wv = (const float*)p->w_v; a.cv = (const float*)p->c_v; a.wq = (const float*)p->w_q; a.cq = (const float*)p->c_q;
@@ -588,21 +531,27 @@ int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, c
   a.stamps = COATTN_STAMPS ? reinterpret_cast<unsigned long long*>(ws) : nullptr;
   a.B = B; a.N = N; a.T = T; a.d = d; a.L = L;
   const bool small_n = N <= 64;
-  // COATTN_FWD_X3=0: phase 1 on the f32 MFMA (developer switch for ablations; default 1: bf16 3-way split)
+  // COATTN_FWD_K (developer switch): 32 = the bf16-split kernel on the 32x32x16 MFMA (coattn_fwd32.hip) for both
+  // layouts, 16 = the 16x16 kernel of this file (channel-major only).  Default: 32 for location-major features,
+  // 16 for channel-major ones.
+  static const int kenv = [] { const char* e = getenv("COATTN_FWD_K"); return e ? atoi(e) : 0; }();
+  // COATTN_FWD_X3=0: phase 1 of the 16x16 kernel on the f32 MFMA (developer switch for ablations; default 1: bf16 split)
   static const int x3 = [] { const char* e = getenv("COATTN_FWD_X3"); return (e && e[0] == '0') ? 0 : 1; }();
-  if (d % 512 == 0) {
+  if (lm || kenv == 32) {
+    CA_TRY(fused32_forward(a, s));
+  } else if (d % 512 == 0) {
     if (x3) CA_TRY(small_n ? (launch_fwd<4, 4, 1>(a, s)) : (launch_fwd<13, 4, 1>(a, s)));
     else CA_TRY(small_n ? (launch_fwd<4, 4, 0>(a, s)) : (launch_fwd<13, 4, 0>(a, s)));
   } else {
     if (x3) CA_TRY(small_n ? (launch_fwd<4, 2, 1>(a, s)) : (launch_fwd<13, 2, 1>(a, s)));
     else CA_TRY(small_n ? (launch_fwd<4, 2, 0>(a, s)) : (launch_fwd<13, 2, 0>(a, s)));
   }
+  if (lm) return launch_attend_v_lm(V, vl.sB, a.av, v_out, B, N, d, L, s);
   dim3 grid(d / 64, B);
   if (small_n)
-    hipLaunchKernelGGL(attend_v_kernel<4>, grid, dim3(256), 0, s, V, a.av, v_out, B, N, d, L);
+    hipLaunchKernelGGL(attend_v_kernel<4>, grid, dim3(256), 0, s, V, vl.sB, a.av, v_out, B, N, d, L);
   else
-    hipLaunchKernelGGL(attend_v_kernel<13>, grid, dim3(256), 0, s, V, a.av, v_out, B, N, d, L);
+    hipLaunchKernelGGL(attend_v_kernel<13>, grid, dim3(256), 0, s, V, vl.sB, a.av, v_out, B, N, d, L);
   CA_CHECK_LAUNCH("attend_v");
   return 0;
 }
-

@@ -22,8 +22,8 @@ namespace {
 
 // partial da_v over 64 channel rows: part[b][kc][l][n] = sum_{k in chunk kc} V[b][k][n] gv[l][b][k].
 // grid (d/64, B); thread <-> location n (rows of V are contiguous in n: fully coalesced).
-__global__ __launch_bounds__(256) void bwd_dav_kernel(const float* V, const float* gv, float* part, int B, int N,
-                                                      int d, int L) {
+__global__ __launch_bounds__(256) void bwd_dav_kernel(const float* V, long v_sB, const float* gv, float* part, int B,
+                                                      int N, int d, int L) {
   const int b = blockIdx.y, kc = blockIdx.x, n = threadIdx.x;
   __shared__ float g[3][64];
   if (threadIdx.x < 192) {
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void bwd_dav_kernel(const float* V, const floa
   }
   __syncthreads();
   if (n >= N) return;
-  const float* vp = V + ((size_t)b * d + kc * 64) * N + n;
+  const float* vp = V + (size_t)b * v_sB + (size_t)kc * 64 * N + n;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll 16
   for (int k = 0; k < 64; ++k) {
@@ -45,8 +45,39 @@ __global__ __launch_bounds__(256) void bwd_dav_kernel(const float* V, const floa
   o[0] = a0; o[N] = a1; o[2 * (size_t)N] = a2;
 }
 
+// location-major V [N][d]: da_v[l][n] = V[n][:] . gv[l][:], whole rows -> part[b][0][l][n] (one "chunk").
+// grid (ceil(N / 16), B); a wave takes 4 rows, lanes along the channels (float4), three wave sums per row.
+__global__ __launch_bounds__(256) void bwd_dav_lm_kernel(const float* V, long v_sB, const float* gv, float* part, int B,
+                                                         int N, int d, int L) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float* Vb = V + (size_t)b * v_sB;
+  for (int i = 0; i < 4; ++i) {
+    const int n = blockIdx.x * 16 + 4 * w + i;
+    if (n >= N) break;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int k = 4 * lane; k < d; k += 256) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(Vb + (size_t)n * d + k);
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gv + ((size_t)0 * B + b) * d + k);
+      const f32x4 g1 = L > 1 ? *reinterpret_cast<const f32x4*>(gv + ((size_t)1 * B + b) * d + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 g2 = L > 2 ? *reinterpret_cast<const f32x4*>(gv + ((size_t)2 * B + b) * d + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a0 = fmaf(x[e], g0[e], a0);
+        a1 = fmaf(x[e], g1[e], a1);
+        a2 = fmaf(x[e], g2[e], a2);
+      }
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
+    if (lane == 0) {
+      float* o = part + (size_t)b * 3 * N + n;
+      o[0] = a0; o[N] = a1; o[2 * (size_t)N] = a2;
+    }
+  }
+}
+
 struct PreArgs {
-  const float* dav_part;                 // [B][d/64][3][N] partial da_v (bwd_dav_kernel)
+  const float* dav_part;                 // [B][nkc][3][N] partial da_v (bwd_dav_kernel: nkc = d/64; _lm: nkc = 1)
+  int nkc;
   const float* Q[8];
   const float* gq;                       // [L][B][d]
   const float* av; const float* aq;      // saved
@@ -73,7 +104,7 @@ __global__ __launch_bounds__(256) void bwd_pre_kernel(const PreArgs a) {
   // ---- image side (wave 0): da_v = sum of the channel-chunk partials; ds_v = a_v (da_v - <a_v, da_v>)
   float tot_v = 0.f;
   if (w == 0) {
-    const int nkc = d / 64;
+    const int nkc = a.nkc;
     const float* pp = a.dav_part + (size_t)b * nkc * 3 * N + (size_t)l * N;
     const float* avp = a.av + pair * N;
     float da[4], avv[4];
@@ -532,12 +563,13 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dpq_kernel(const BwdArgs a) {
 // grid (d/128, B); a wave owns 32 channels (two 16-wide MFMA column tiles); dA of the three levels is
 // staged zero-padded in LDS and read as MFMA A operands (16 bytes = 4 k-steps per ds_read_b128).
 struct DqArgs {
-  const float* V; const float* dA; const float* aq; const float* gq;
+  const float* V; long v_sB; const float* dA; const float* aq; const float* gq;
   float* dQ[8];
   int B, N, T, d, L;
 };
 
-template <int NT, bool ALIGNED>
+// LM: V location-major [N][d] (dword loads, 64 contiguous bytes per 16 lanes); else channel-major [d][N].
+template <int NT, bool ALIGNED, bool LM = false>
 __global__ __launch_bounds__(256, 2) void bwd_dq_kernel(const DqArgs a) {
   constexpr int NPAD = 16 * NT;
   constexpr int LD = NPAD + 4;
@@ -569,7 +601,7 @@ __global__ __launch_bounds__(256, 2) void bwd_dq_kernel(const DqArgs a) {
   }
   __syncthreads();
   const int kb = blockIdx.x * 128 + 32 * w;
-  const float* Vb = a.V + (size_t)b * d * N;
+  const float* Vb = a.V + (size_t)b * a.v_sB;
   const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(Vb, (unsigned)d * N * 4u);
   f32x4 acc[3][2][2];
 #pragma unroll
@@ -582,6 +614,11 @@ __global__ __launch_bounds__(256, 2) void bwd_dq_kernel(const DqArgs a) {
   auto load_v = [&](int g, f32x4(&dst)[2]) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
+      if constexpr (LM) {                            // rows n >= N lie beyond the buffer: read 0
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dst[c][s] = buf_load1(rs_v, ((4 * q4 + s) * d + 16 * c + j) * 4, (16 * g * d + kb) * 4);
+        continue;
+      }
       const int voff = ((16 * c + j) * N + 4 * q4) * 4;
       if (ALIGNED) {
         dst[c] = buf_load4(rs_v, voff, (kb * N + 16 * g) * 4);
@@ -670,10 +707,13 @@ size_t fused_bwd_ws_floats(int B, int N, int T, int d, int L) { return fused_bwd
 
 int fused_backward_supported(int B, int N, int T, int d, int L) { return fused_supported(B, N, T, d, L); }
 
-int fused_backward(int B, int N, int T, int d, int L, const float* V, const float* const* Q, const coattn_params* p,
-                   const float* saved, const float* gv, const float* gq, float* dV, float* const* dQ,
-                   const coattn_param_grads* pg, int accumulate, float* ws, hipStream_t s, int bf16_proj) {
+int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLayout& vl, const float* const* Q,
+                   const coattn_params* p, const float* saved, const float* gv, const float* gq, float* dV,
+                   const VLayout& dvl, float* const* dQ, const coattn_param_grads* pg, int accumulate, float* ws,
+                   hipStream_t s, int bf16_proj) {
   CA_CHECK_ARG(fused_backward_supported(B, N, T, d, L), "fused backward: unsupported shape");
+  const bool lm = v_is_lm(vl, N, d);
+  CA_CHECK_ARG(lm || v_is_cm(vl, N, d), "fused backward: image features must be channel-major [B,d,N] or location-major [B,N,d]");
   // gradients of the two projections (d x d contractions): fp32 MFMA, or bf16 MFMA under COATTN_FLAG_BF16_PROJ
   auto gemm_proj = [&](const coattn_gemm_desc& g) { return bf16_proj ? launch_gemm_bf16in(g, s) : launch_gemm_f32(g, s); };
   const SavedOff so = saved_off(B, N, T, d, L);
@@ -682,10 +722,12 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const floa
   const bool small_n = N <= 64;
   // 1. per-sample pre-pass
   CA_CHECK_ARG(N <= 256, "fused backward: N > 256");
-  hipLaunchKernelGGL(bwd_dav_kernel, dim3(d / 64, B), dim3(256), 0, s, V, gv, ws + wo.part, B, N, d, L);
+  if (lm) hipLaunchKernelGGL(bwd_dav_lm_kernel, dim3((N + 15) / 16, B), dim3(256), 0, s, V, vl.sB, gv, ws + wo.part, B, N, d, L);
+  else hipLaunchKernelGGL(bwd_dav_kernel, dim3(d / 64, B), dim3(256), 0, s, V, vl.sB, gv, ws + wo.part, B, N, d, L);
   CA_CHECK_LAUNCH("bwd_dav");
   PreArgs pa;
   pa.dav_part = ws + wo.part;
+  pa.nkc = lm ? 1 : d / 64;
   for (int l = 0; l < 8; ++l) pa.Q[l] = l < L ? Q[l] : nullptr;
   pa.gq = gq; pa.av = saved + so.av; pa.aq = saved + so.aq; pa.Hq = saved + so.Hq;
   pa.wq = (const float*)p->w_q;
@@ -715,23 +757,30 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const floa
   // 4. dQ_l = a_q (x) gq + dA V^T + dP_q W_q ;  dV = sum_l (a_v (x) gv + Q^T dA) + (sum_l dP_v) W_v
   {
     DqArgs da;
-    da.V = V; da.dA = ws + wo.dA; da.aq = saved + so.aq; da.gq = gq;
+    da.V = V; da.v_sB = vl.sB; da.dA = ws + wo.dA; da.aq = saved + so.aq; da.gq = gq;
     for (int l = 0; l < 8; ++l) da.dQ[l] = l < L ? dQ[l] : nullptr;
     da.B = B; da.N = N; da.T = T; da.d = d; da.L = L;
     const bool al = (N % 4) == 0;
     dim3 grid(d / 128, B), block(256);
     if (small_n) {
       const size_t lds = (size_t)(3 * kTRows * (64 + 4) + 96) * sizeof(float);
-      if (al) hipLaunchKernelGGL((bwd_dq_kernel<4, true>), grid, block, lds, s, da);
+      if (lm && al) hipLaunchKernelGGL((bwd_dq_kernel<4, true, true>), grid, block, lds, s, da);
+      else if (lm) hipLaunchKernelGGL((bwd_dq_kernel<4, false, true>), grid, block, lds, s, da);
+      else if (al) hipLaunchKernelGGL((bwd_dq_kernel<4, true>), grid, block, lds, s, da);
       else hipLaunchKernelGGL((bwd_dq_kernel<4, false>), grid, block, lds, s, da);
     } else {
       const size_t lds = (size_t)(3 * kTRows * (208 + 4) + 96) * sizeof(float);
       static DeviceOnce once;
       CA_TRY(once.run([&] {
-        const hipError_t e = set_lds(bwd_dq_kernel<13, true>, lds);
-        return e != hipSuccess ? e : set_lds(bwd_dq_kernel<13, false>, lds);
+        hipError_t e = set_lds(bwd_dq_kernel<13, true>, lds);
+        if (e == hipSuccess) e = set_lds(bwd_dq_kernel<13, false>, lds);
+        if (e == hipSuccess) e = set_lds(bwd_dq_kernel<13, true, true>, lds);
+        if (e == hipSuccess) e = set_lds(bwd_dq_kernel<13, false, true>, lds);
+        return e;
       }, "bwd_dq"));
-      if (al) hipLaunchKernelGGL((bwd_dq_kernel<13, true>), grid, block, lds, s, da);
+      if (lm && al) hipLaunchKernelGGL((bwd_dq_kernel<13, true, true>), grid, block, lds, s, da);
+      else if (lm) hipLaunchKernelGGL((bwd_dq_kernel<13, false, true>), grid, block, lds, s, da);
+      else if (al) hipLaunchKernelGGL((bwd_dq_kernel<13, true>), grid, block, lds, s, da);
       else hipLaunchKernelGGL((bwd_dq_kernel<13, false>), grid, block, lds, s, da);
     }
     CA_CHECK_LAUNCH("bwd_dq");
@@ -740,12 +789,12 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const floa
     for (int l = 0; l < L; ++l) {
       const float* dA = ws + wo.dA + l * BTN;
       const float* av = saved + so.av + (size_t)l * B * N;
-      CA_TRY(launch_rank1(av, gv + l * Bd, dV, B, N, d, (int64_t)d * N, 1, N, l > 0 ? 1 : 0, s));
+      CA_TRY(launch_rank1(av, gv + l * Bd, dV, B, N, d, dvl.sB, dvl.sN, dvl.sD, l > 0 ? 1 : 0, s));
       coattn_gemm_desc g = {};
       g.A = Q[l]; g.a_sz = (int64_t)T * d; g.a_sm = 1; g.a_sk = d;
       g.B = dA; g.b_sz = (int64_t)T * N; g.b_sk = N; g.b_sn = 1;
-      g.Cin = dV; g.cin_sz = (int64_t)d * N; g.cin_sm = N; g.cin_sn = 1; g.beta = 1.f;
-      g.C = dV; g.c_sz = (int64_t)d * N; g.c_sm = N; g.c_sn = 1;
+      g.Cin = dV; g.cin_sz = dvl.sB; g.cin_sm = dvl.sD; g.cin_sn = dvl.sN; g.beta = 1.f;
+      g.C = dV; g.c_sz = dvl.sB; g.c_sm = dvl.sD; g.c_sn = dvl.sN;
       g.M = d; g.N = N; g.K = T; g.batch = B;
       CA_TRY(launch_gemm_f32(g, s));
     }
@@ -774,22 +823,35 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const floa
     coattn_gemm_desc g = {};
     g.A = p->W_v; g.a_sm = 1; g.a_sk = d; g.a_sz = 0;
     g.B = dPv; g.b_sz = (int64_t)N * d; g.b_sk = 1; g.b_sn = d;
-    g.Cin = dV; g.cin_sz = (int64_t)d * N; g.cin_sm = N; g.cin_sn = 1; g.beta = 1.f;
-    g.C = dV; g.c_sz = (int64_t)d * N; g.c_sm = N; g.c_sn = 1;
+    g.Cin = dV; g.cin_sz = dvl.sB; g.cin_sm = dvl.sD; g.cin_sn = dvl.sN; g.beta = 1.f;
+    g.C = dV; g.c_sz = dvl.sB; g.c_sm = dvl.sD; g.c_sn = dvl.sN;
     g.M = d; g.N = N; g.K = d; g.batch = B;
     CA_TRY(gemm_proj(g));
   }
   // 5. weight gradients
   float* part = ws + wo.part;
   {
-    // dW_v[j][k] = sum_{b,n} dP_v[b][n][j] V[b][k][n]: inner index = sample, split into <= 32 groups
-    const int G = (B + 31) / 32;
-    const int S = (B + G - 1) / G;
+    // dW_v[j][k] = sum_{b,n} dP_v[b][n][j] V[b][k][n]
     coattn_gemm_desc g = {};
-    g.A = dPv; g.a_sm = 1; g.a_sk = d; g.a_si = (int64_t)N * d; g.a_sz = (int64_t)G * N * d;
-    g.B = V; g.b_sk = 1; g.b_sn = N; g.b_si = (int64_t)d * N; g.b_sz = (int64_t)G * d * N;
+    int S;
+    if (lm && vl.sB == (long)N * d) {
+      // location-major, samples abutting: one flat contraction over m = (b, n), split-K over the B*N rows
+      const int K = B * N;
+      int ks = (K + 31) / 32;
+      ks = (ks + 15) / 16 * 16;
+      S = (K + ks - 1) / ks;
+      g.A = dPv; g.a_sm = 1; g.a_sk = d;
+      g.B = V; g.b_sk = d; g.b_sn = 1;
+      g.M = d; g.N = d; g.K = K; g.batch = S; g.ksplit = ks;
+    } else {
+      // inner index = sample, split into <= 32 groups
+      const int G = (B + 31) / 32;
+      S = (B + G - 1) / G;
+      g.A = dPv; g.a_sm = 1; g.a_sk = d; g.a_si = (int64_t)N * d; g.a_sz = (int64_t)G * N * d;
+      g.B = V; g.b_sk = vl.sN; g.b_sn = vl.sD; g.b_si = vl.sB; g.b_sz = (int64_t)G * vl.sB;
+      g.M = d; g.N = d; g.K = N; g.batch = S; g.inner = G; g.inner_total = B;
+    }
     g.C = part; g.c_sz = (int64_t)d * d; g.c_sm = d; g.c_sn = 1;
-    g.M = d; g.N = d; g.K = N; g.batch = S; g.inner = G; g.inner_total = B;
     CA_TRY(gemm_proj(g));
     CA_TRY(launch_reduce_partials(part, (float*)pg->dW_v, S, (int64_t)d * d, accumulate, s));
   }

@@ -1,0 +1,701 @@
+// Fused co-attention forward for gfx950, every contraction on the bf16 MFMA 32x32x16 with the exact 3-way
+// split (fp32-accurate: x = hi + mid + lo in bf16 pieces, six partial products, fp32 accumulation).
+//
+// "affinity + softmax + reduce" (model.py:377-392 after the projections), one workgroup per (sample b, level l),
+// NW = d/128 waves (4 at d = 512), two workgroups per CU:
+//   phase 1  A = Q V^T, K (= d) split over the waves: a wave streams its 128-channel slices of V straight from HBM
+//            into MFMA B operands (location-major V [N][d]: two 16-byte loads per lane and 16-channel step;
+//            channel-major V [d][N]: eight dword loads) and its slice of Q as A operands; the [32 x N] partial
+//            tiles are summed across waves through LDS in a fixed tree order; C = tanh(A) goes to `saved` and, split
+//            once into its three bf16 pieces, into ONE LDS image [piece][n][t] (64-byte rows, 16-byte chunks
+//            XOR-swizzled by (n >> 2) & 3) that serves both orientations conflict-free: row reads (ds_read_b128)
+//            give C^T as the A operand of H_v, transposing reads (ds_read_b64_tr_b16) give C as the A operand of H_q.
+//   phase 2  two passes per 128-channel slice (64 channels each), loop over 32-location tiles of P_v [N][d] (read
+//            once): the raw tile is split and is the B operand of H_q += C . P_v (contraction over n: the
+//            accumulator layout of a 32x32 tile IS the B-operand layout of the next MFMA), then the same registers
+//            accumulate H_v = P_v + C^T P_q (contraction over t, one 32-deep step); tanh, and
+//            s_v[n] += H_v[n][:] . w_v without ever writing H_v.
+//   phase 3  score reduction over waves / passes in a fixed order, un-masked row softmax over N and over T
+//            (model.py:387-388) by wave shuffles, H_q saved, q = a_q^T Q.
+//   attend_v_lm_kernel : v_l = a_{v,l}^T V for all levels with one more pass over a location-major V.
+#include "fused.h"
+
+#include <stdlib.h>
+
+// Phase 1: number of 32-location tiles per k-step that run on the bf16 MFMA with the 3-way split (the others take the
+// f32 MFMA).  -1: the default share (6 of 7); tuning builds override it.
+#ifndef COATTN_P1_NB
+#define COATTN_P1_NB -1
+#endif
+#ifndef COATTN_P1_RING
+#define COATTN_P1_RING 4
+#endif
+
+namespace {
+
+__device__ __forceinline__ bf16x4 lds_tr16(const short* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(const_cast<short*>(p)));
+}
+
+// wait until at most n of this wave's vector-memory operations (loads, stores, LDS-DMA: one in-order counter) are
+// still outstanding; hand-placed for the LDS-DMA ring, whose data dependences the compiler does not see.  n is a
+// constant after unrolling: one s_waitcnt remains.
+__device__ __forceinline__ void vmcnt_wait(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+    case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+    case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
+    case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
+    case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
+    case 27: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
+    case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+    case 29: asm volatile("s_waitcnt vmcnt(29)" ::: "memory"); break;
+    case 30: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
+    case 31: asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); break;
+    case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+    case 33: asm volatile("s_waitcnt vmcnt(33)" ::: "memory"); break;
+    case 34: asm volatile("s_waitcnt vmcnt(34)" ::: "memory"); break;
+    case 35: asm volatile("s_waitcnt vmcnt(35)" ::: "memory"); break;
+    case 36: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+    case 37: asm volatile("s_waitcnt vmcnt(37)" ::: "memory"); break;
+    case 38: asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); break;
+    case 39: asm volatile("s_waitcnt vmcnt(39)" ::: "memory"); break;
+    case 40: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+    case 41: asm volatile("s_waitcnt vmcnt(41)" ::: "memory"); break;
+    case 42: asm volatile("s_waitcnt vmcnt(42)" ::: "memory"); break;
+    case 43: asm volatile("s_waitcnt vmcnt(43)" ::: "memory"); break;
+    case 44: asm volatile("s_waitcnt vmcnt(44)" ::: "memory"); break;
+    case 45: asm volatile("s_waitcnt vmcnt(45)" ::: "memory"); break;
+    case 46: asm volatile("s_waitcnt vmcnt(46)" ::: "memory"); break;
+    case 47: asm volatile("s_waitcnt vmcnt(47)" ::: "memory"); break;
+    case 48: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+    case 49: asm volatile("s_waitcnt vmcnt(49)" ::: "memory"); break;
+    case 50: asm volatile("s_waitcnt vmcnt(50)" ::: "memory"); break;
+    case 51: asm volatile("s_waitcnt vmcnt(51)" ::: "memory"); break;
+    case 52: asm volatile("s_waitcnt vmcnt(52)" ::: "memory"); break;
+    case 53: asm volatile("s_waitcnt vmcnt(53)" ::: "memory"); break;
+    case 54: asm volatile("s_waitcnt vmcnt(54)" ::: "memory"); break;
+    case 55: asm volatile("s_waitcnt vmcnt(55)" ::: "memory"); break;
+    case 56: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
+    case 57: asm volatile("s_waitcnt vmcnt(57)" ::: "memory"); break;
+    case 58: asm volatile("s_waitcnt vmcnt(58)" ::: "memory"); break;
+    case 59: asm volatile("s_waitcnt vmcnt(59)" ::: "memory"); break;
+    case 60: asm volatile("s_waitcnt vmcnt(60)" ::: "memory"); break;
+    case 61: asm volatile("s_waitcnt vmcnt(61)" ::: "memory"); break;
+    case 62: asm volatile("s_waitcnt vmcnt(62)" ::: "memory"); break;
+    case 63: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+// C/D row of accumulator register g in lane half h (32x32 MFMA)
+__device__ __forceinline__ constexpr int crow(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
+
+template <int NT, int NW, bool LM>
+__global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs a) {
+  constexpr int NPAD = 32 * NT;
+  constexpr int SLD = NPAD + 4;                      // row stride of the f32 reduction slots [t][n]
+  constexpr int SLOT_FLOATS = 32 * SLD;
+  constexpr int PIECE = NPAD * 32;                   // bf16 elements of one piece of the C image [n][t = 32]
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* slot0 = reinterpret_cast<float*>(smem);
+  short* Cimg = reinterpret_cast<short*>(smem + SLOT_FLOATS * 4);
+  float* slot1 = reinterpret_cast<float*>(Cimg);     // aliases the image until the image is written
+  float* svpart = slot0;                             // [NW * 4][NPAD]   (aliases slot0 from phase 2 on)
+  float* sqpart = slot0 + NW * 4 * NPAD;             // [NW * 2][32]
+  float* aqs = sqpart + NW * 2 * 32;                 // 32
+  static_assert(NW * 4 * NPAD + NW * 2 * 32 + 32 <= SLOT_FLOATS, "phase-2 scratch must fit the slot");
+  static_assert(SLOT_FLOATS * 4 <= 3 * PIECE * 2, "slot 1 must fit inside the image region");
+
+  int b, l;
+  if (!block_to_pair(blockIdx.x, a.B, a.L, b, l)) return;
+  CA_STAMP(0);
+  const int N = a.N, T = a.T, d = a.d;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // The lane id is re-derived (v_mbcnt) at every phase: kept from kernel entry, the values computed from it would
+  // live across the fully unrolled phase 1 and be spilled (a kernel with scratch pays for it at every launch).
+  auto lane_id = [] { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); };
+  int lane = lane_id();
+  int tid = w * 64 + lane;
+  int r = lane & 31, h = lane >> 5;                  // MFMA row / column index, lane half
+  const float* Qp = a.Q[l] + (size_t)b * T * d;
+  const float* Vp = a.V + (size_t)b * a.v_sB;
+  const float* Pvp = a.Pv + (size_t)b * N * d;
+  const size_t pair = (size_t)l * a.B + b;
+  const float* Pqp = a.Pq + pair * (size_t)T * d;
+  // buffer resources over exactly this sample's tensors: rows beyond T / N read as 0, stores there are dropped
+  const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(Qp, (unsigned)T * d * 4u);
+  const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(Vp, (unsigned)d * N * 4u);
+  const __amdgpu_buffer_rsrc_t rs_pv = make_rsrc(Pvp, (unsigned)N * d * 4u);
+  const __amdgpu_buffer_rsrc_t rs_pq = make_rsrc(Pqp, (unsigned)T * d * 4u);
+  const int nsl = d / (128 * NW);                    // 128-channel slices per wave (1 at d = 512)
+
+  // B operands of H_v (P_q, contraction index t): lane (channel c0 + 32 ct + r, half h) holds
+  // P_q[t = 16 ks + 8 h + i][channel], i = 0..7; raw loads first, split when needed
+  // (one lane-dependent offset, recomputed at every call, and scalar row offsets: kept as 16 hoisted vector offsets
+  // they would live -- spilled -- across the unit pipeline)
+  auto load_pq_raw = [&](int c0, f32x8 (&raw)[2][2]) {
+    int base = (8 * h * d + r) * 4;
+    asm volatile("" : "+v"(base));
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          raw[ct][ks][i] = buf_load1(rs_pq, base + 128 * ct, (c0 + (16 * ks + i) * d) * 4);
+  };
+
+  // ------------------------------------------------------------------ phase 1: A = Q V^T
+  f32x8 pq_raw[2][2];
+  {
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[nt][g] = 0.f;
+    // Operand stream.  Element i of a lane's fragment <-> channel k0 + 4 h + (i & 3) + 8 (i >> 2): the same order
+    // for A and B, chosen so that the two 16-byte loads of a location-major row are contiguous across the lane halves.
+    // The stream is latency-bound (a wave alone needs ~8 KB in flight to cover HBM latency at its share of the
+    // bandwidth, twice that under load), and registers cannot hold that: the fragments go HBM -> LDS by LDS-DMA
+    // (buffer_load ... lds, no VGPR destination) into a per-wave ring of R slots of 2 KB -- the LDS is idle until the
+    // cross-wave reduction -- and are read back (ds_read_b128 x 2 per lane, lane-linear, conflict-free) one unit
+    // before their MFMAs.  Units of a k-step (16 channels): the Q fragment, then the NT location tiles.
+    // The first NB tiles of a k-step run on the bf16 MFMA with the exact 3-way split (6 MFMAs of 32 cycles + 44 VALU
+    // per unit), the others on the f32 MFMA straight from the registers (8 MFMAs of 64 cycles, no VALU; lane (., h)
+    // of a 32x32x2 MFMA supplies k = h: element i pairs channels (k0 + (i&3) + 8(i>>2), the same + 4)).
+    constexpr int NB = COATTN_P1_NB >= 0 ? (COATTN_P1_NB < NT ? COATTN_P1_NB : NT) : NT;
+    constexpr int UPK = NT + 1;                      // units per k-step
+    constexpr int KU = (UPK >= 6) ? 1 : 2;           // k-steps per loop body
+    constexpr int R = UPK * KU;                      // ring slots = units per loop body: static slot indices
+    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};   // smallest piece products first
+    char* ringb = smem + w * (R * 2048);
+    const int q_voff = (r * d + 4 * h) * 4;
+    const int v_voff = LM ? (r * d + 4 * h) * 4 : (4 * h * N + r) * 4;
+    const int G = 8 * nsl;                           // 16-channel steps of this wave
+    auto chan0 = [&](int g) { return ((g >> 3) * NW + w) * 128 + 16 * (g & 7); };
+    // DMA of unit (k-step g, position j) into its slot; beyond the last k-step the addresses fall outside the sample or
+    // on its next rows: harmless, the data is never used
+    auto dma_unit = [&](int g, const int j, const int slot) {
+      typedef __attribute__((address_space(3))) void* lds_ptr;
+      char* dst = ringb + slot * 2048;
+      const int k0 = chan0(g);
+      if (j == 0) {                                  // Q fragment
+        // (the +32 bytes of the second piece go into the scalar offset: an instruction offset would also move the
+        // LDS address)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_ptr)dst, 16, q_voff, k0 * 4, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_ptr)(dst + 1024), 16, q_voff, k0 * 4 + 32, 0, 0);
+      } else if constexpr (LM) {
+        const int so = (32 * (j - 1) * d + k0) * 4;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_ptr)dst, 16, v_voff, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_ptr)(dst + 1024), 16, v_voff, so + 32, 0, 0);
+      } else {
+        // channel-major: eight dword pieces (element i of the fragment = row k0 + 4h + (i&3) + 8(i>>2) of V [d][N])
+        const int so = (k0 * N + 32 * (j - 1)) * 4;  // columns >= N: finite junk, zeroed when C is finalised
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_ptr)(dst + 256 * i), 4, v_voff,
+                                                   so + ((i & 3) + 8 * (i >> 2)) * N * 4, 0, 0);
+      }
+    };
+    constexpr int DPU = LM ? 2 : 8;                  // DMA instructions of a V unit (a Q unit: 2)
+    auto read_unit = [&](const int j, const int slot) -> f32x8 {
+      const char* src = ringb + slot * 2048;
+      if (LM || j == 0) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(src + lane * 16);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(src + 1024 + lane * 16);
+        return f32x8{x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+      }
+      f32x8 x;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = *reinterpret_cast<const float*>(src + 256 * i + lane * 4);
+      return x;
+    };
+    // DMAs still allowed in flight when unit p of the body is read back: those of the R - 2 units issued after it
+    // (unit p+1 .. p+R-2; position 0 of a k-step is a Q unit)
+    auto pending_after = [&](const int p) {
+      int n = 0;
+      for (int q = p + 1; q <= p + R - 2; ++q) n += (q % UPK == 0) ? 2 : DPU;
+      return n;
+    };
+    f32x8 qraw, cur, nxt;
+    bf16x8 qa[3];
+    u32x4 vh, vm, vl;                                // split pieces of the current bf16 unit's V fragment
+    auto split_pair_v = [&](const f32x8& x, const int pr) {
+      unsigned hh, mm, ll;
+      split3_pair(x[2 * pr], x[2 * pr + 1], hh, mm, ll);
+      vh[pr] = hh; vm[pr] = mm; vl[pr] = ll;
+    };
+    // prologue: units 0 .. R-2 in flight, unit 0 (the first Q fragment) read back
+#pragma unroll
+    for (int p = 0; p < R - 1; ++p) dma_unit(p / UPK, p % UPK, p);
+    vmcnt_wait(pending_after(0));                    // unit 0 has landed; units 1 .. R-2 may fly
+    nxt = read_unit(0, 0);
+#pragma unroll 1
+    for (int g0 = 0; g0 < G; g0 += KU) {
+#pragma unroll
+      for (int p = 0; p < R; ++p) {                  // unit p of the body: k-step g0 + p / UPK, position p % UPK
+        const int j = p % UPK, pn = (p + 1) % R, jn = (p + 1) % UPK;
+        cur = nxt;
+        // refill the slot of the previous unit (its read-back has completed), then read back the next unit
+        dma_unit(g0 + (p + R - 1) / UPK, (p + R - 1) % UPK, (p + R - 1) % R);
+        vmcnt_wait(pending_after(pn));
+        nxt = read_unit(jn, pn);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool next_bf = jn >= 1 && (jn - 1) < NB;    // the next unit is a V tile on the bf16 path: split it here
+        if (j == 0) {                                // Q fragment of this k-step: split it, and the first tile's fragment
+          qraw = cur;
+          if (NB > 0) split3(qraw, qa);
+          if (next_bf) {
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr) split_pair_v(nxt, pr);
+          }
+        } else if (j - 1 < NB) {
+          const bf16x8 b3[3] = {__builtin_bit_cast(bf16x8, vh), __builtin_bit_cast(bf16x8, vm), __builtin_bit_cast(bf16x8, vl)};
+          u32x4 nh, nm, nl;
+#pragma unroll
+          for (int m = 0; m < 6; ++m) {
+            acc[j - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[PA[m]], b3[PB[m]], acc[j - 1], 0, 0, 0);
+            if (next_bf && m < 4) {
+              unsigned hh, mm, ll;
+              split3_pair(nxt[2 * m], nxt[2 * m + 1], hh, mm, ll);
+              nh[m] = hh; nm[m] = mm; nl[m] = ll;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (next_bf) { vh = nh; vm = nm; vl = nl; }
+        } else {
+#pragma unroll
+          for (int m = 0; m < 8; ++m) {
+            acc[j - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qraw[m], cur[m], acc[j - 1], 0, 0, 0);
+            if (next_bf && m < 4) split_pair_v(nxt, m);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    }
+    vmcnt_wait(0);                                   // the rings' memory becomes the reduction slots:
+    __syncthreads();                                 // every wave is done with its ring
+    CA_STAMP(1);
+    // cross-wave sum in a fixed tree order through LDS; C/D layout: col = r (location), row = crow(g, h) (token)
+    auto put = [&](float* slot) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) slot[crow(g, h) * SLD + 32 * nt + r] = acc[nt][g];
+    };
+    auto add = [&](const float* slot) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[nt][g] += slot[crow(g, h) * SLD + 32 * nt + r];
+    };
+    if constexpr (NW == 4) {
+      if (w == 1) put(slot0);
+      if (w == 3) put(slot1);
+      __syncthreads();
+      if (w == 0) add(slot0);
+      if (w == 2) add(slot1);
+      __syncthreads();
+      if (w == 2) put(slot0);
+      __syncthreads();
+      if (w == 0) { add(slot0); put(slot0); }        // ((w0 + w1) + (w2 + w3))
+      __syncthreads();
+    } else {
+      if (w == 1) put(slot0);
+      __syncthreads();
+      if (w == 0) { add(slot0); put(slot0); }
+      __syncthreads();
+    }
+  }
+  lane = lane_id(); tid = w * 64 + lane; r = lane & 31; h = lane >> 5;
+  load_pq_raw(w * 128, pq_raw);                      // the first pass' P_q operands fly under the tanh / split pass
+  bf16x8 pqB[2][2][3];
+  // C = tanh(sum) by all threads: a thread takes a token pair (2 tp, 2 tp + 1) of one location; rows >= T are
+  // tanh(0) = 0 (their Q rows read as 0).  The three bf16 pieces go to the image [piece][n][t] (4-byte writes).
+  {
+    float* Cg = a.C + pair * (size_t)T * N;
+    for (int e = tid; e < 16 * NPAD; e += NW * 64) {
+      const int tp = e / NPAD, n = e - tp * NPAD;
+      float c0 = tanh_fast(slot0[(2 * tp) * SLD + n]);
+      float c1 = tanh_fast(slot0[(2 * tp + 1) * SLD + n]);
+      const bool in = n < N;
+      c0 = in ? c0 : 0.f;                            // padded columns of a channel-major V carry junk
+      c1 = in ? c1 : 0.f;
+      if (in && 2 * tp < T) Cg[(size_t)(2 * tp) * N + n] = c0;
+      if (in && 2 * tp + 1 < T) Cg[(size_t)(2 * tp + 1) * N + n] = c1;
+      unsigned hh, mm, ll;
+      split3_pair(c0, c1, hh, mm, ll);
+      const int off = n * 32 + 8 * ((tp >> 2) ^ ((n >> 2) & 3)) + 2 * (tp & 3);
+      *reinterpret_cast<unsigned*>(Cimg + off) = hh;
+      *reinterpret_cast<unsigned*>(Cimg + PIECE + off) = mm;
+      *reinterpret_cast<unsigned*>(Cimg + 2 * PIECE + off) = ll;
+    }
+  }
+  __syncthreads();
+  CA_STAMP(2);
+
+  // ------------------------------------------------------------------ phase 2: H_v scores, H_q
+  const int ntiles = (N + 31) >> 5;
+  // lane constants of the transposing reads (A operand of H_q): lane 4 q + p of a 16-lane group supplies the address
+  // of image row n1 + q, tokens 16 g1 + 4 p .. + 3; the rows' swizzle key is ((n1 + q) >> 2) & 3 = h (first read,
+  // n1 = 32 nt + 16 s + 4 h) and h + 2 (second read, n1 + 8)
+  const int tq = (lane & 15) >> 2, tp_ = lane & 3, g1 = (lane >> 4) & 1;
+  const int tr_off0 = (4 * h + tq) * 32 + 8 * ((2 * g1 + (tp_ >> 1)) ^ h) + 4 * (tp_ & 1);
+  const int tr_off1 = (4 * h + 8 + tq) * 32 + 8 * ((2 * g1 + (tp_ >> 1)) ^ (h + 2)) + 4 * (tp_ & 1);
+  const int rk = (r >> 2) & 3;                       // swizzle key of this lane's own image row (row reads)
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) split3(pq_raw[ct][ks], pqB[ct][ks]);
+  {
+#pragma unroll 1
+    for (int pi = 0; pi < 2 * nsl; ++pi) {           // passes: 64 channels each, two per 128-channel slice
+      const int sl = pi >> 1, ps = pi & 1;
+      const int c0 = (sl * NW + w) * 128 + 64 * ps;
+      const float wvr[2] = {a.wv[c0 + r], a.wv[c0 + 32 + r]};
+      f32x16 accq[2];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) accq[ct][g] = 0.f;
+      // Unit pipeline over u = 2 nt + ct (a 32-location x 32-channel fragment of P_v, 16 VGPRs): while the MFMAs of
+      // unit u run (H_q += C . P_v with the raw fragment as B operand, then H_v = P_v + C^T P_q accumulated onto
+      // it), the VALU finishes unit u-1 (tanh, scores) and splits the operands of the following MFMAs; loads run
+      // two units ahead.  Ring of four fragments: u+2 in flight, u+1 landed, u in the MFMAs, u-1 in the VALU.
+      f32x16 ring[4];
+      float svp[16];                                 // score partials of the current tile's first channel half
+      bf16x8 pb0[3];                                 // split B operand of the next unit's first k-step
+      const int U = 2 * ntiles;
+      // pv[g] = P_v[32 nt + crow(g, h)][c0 + 32 ct + r]: 128 contiguous bytes per half wave and load
+      auto load_unit = [&](int u, f32x16& dst) {     // beyond the last tile: zeros through the buffer rule, no traffic
+#pragma unroll
+        for (int g = 0; g < 16; ++g)
+          dst[g] = buf_load1(rs_pv, (crow(g, h) * d + r) * 4, (32 * (u >> 1) * d + c0 + 32 * (u & 1)) * 4);
+      };
+      auto split_half = [&](const f32x16& pv, const int s2, bf16x8 (&pb)[3]) {
+        const f32x8 x = f32x8{pv[8 * s2], pv[8 * s2 + 1], pv[8 * s2 + 2], pv[8 * s2 + 3],
+                              pv[8 * s2 + 4], pv[8 * s2 + 5], pv[8 * s2 + 6], pv[8 * s2 + 7]};
+        split3(x, pb);
+      };
+      auto read_cq = [&](const short* img, const int s2, bf16x8 (&cq)[3]) {     // A = C (tokens x locations)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const bf16x4 lo = lds_tr16(img + p * PIECE + 16 * s2 * 32 + tr_off0);
+          const bf16x4 hi = lds_tr16(img + p * PIECE + 16 * s2 * 32 + tr_off1);
+          cq[p] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+      };
+      auto read_ca = [&](const short* img, const int ks, bf16x8 (&ca)[3]) {      // A = C^T (locations x tokens)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          ca[p] = *reinterpret_cast<const bf16x8*>(img + p * PIECE + r * 32 + 8 * ((2 * ks + h) ^ rk));
+      };
+      auto store_scores = [&](int u, float mine) {   // u: the finished unit (second channel half of tile u >> 1)
+        if (u >= 0) {
+          float* dst = &svpart[((w * 2 + ps) * 2 + g1) * NPAD + 32 * (u >> 1) + crow(lane & 15, h)];
+          if (sl > 0) mine += *dst;                  // accumulate over this wave's channel slices
+          *dst = mine;
+        }
+      };
+      // One unit = 24 MFMAs of unit u (fragment `cur`), each followed by one chunk of the VALU work that does not
+      // depend on it: the split of the unit's second k-step, tanh / scores of unit u-1 (`prev`), the split of the
+      // first k-step of unit u+1 (`next`), the 16-lane row sums.  The compiler's scheduler clusters MFMAs and VALU
+      // work when left alone (a lone wave then pays both in series), so every (MFMA, chunk) pair is fenced.
+      // Piece products of the exact split, smallest first: a0 b2, a2 b0, a1 b1, a0 b1, a1 b0, a0 b0.
+      auto unit = [&](int u, const int ct, f32x16& cur, const f32x16& prev, const f32x16& next) {
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+        const short* img = Cimg + 32 * (u >> 1) * 32;
+        bf16x8 cq0[3], cq1[3], ca0[3], ca1[3];       // A operands, read one MFMA group ahead of their use
+        u32x4 h1, m1, l1, h0, m0, l0;                // pieces of pb1 (this unit, k-step 1) / the next unit's pb0
+        float tcur = 0.f, mine = 0.f;
+        read_cq(img, 0, cq0);
+#pragma unroll
+        for (int m = 0; m < 24; ++m) {
+          // ---- the MFMA
+          const int grp = m / 6, i = m % 6;
+          if (grp == 0) accq[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cq0[PA[i]], pb0[PB[i]], accq[ct], 0, 0, 0);
+          if (grp == 1) {
+            const bf16x8 b = PB[i] == 0 ? __builtin_bit_cast(bf16x8, h1) : PB[i] == 1 ? __builtin_bit_cast(bf16x8, m1)
+                                                                                      : __builtin_bit_cast(bf16x8, l1);
+            accq[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cq1[PA[i]], b, accq[ct], 0, 0, 0);
+          }
+          if (grp == 2) cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca0[PA[i]], pqB[ct][0][PB[i]], cur, 0, 0, 0);
+          if (grp == 3) cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca1[PA[i]], pqB[ct][1][PB[i]], cur, 0, 0, 0);
+          // ---- the next group's A operands
+          if (m == 1) read_cq(img, 1, cq1);
+          if (m == 7) read_ca(img, 0, ca0);
+          if (m == 13) read_ca(img, 1, ca1);
+          // ---- its VALU chunk
+          if (m < 4) {                               // split pair m of this unit's second k-step (registers 8 .. 15)
+            unsigned hh, mm, ll;
+            split3_pair(cur[8 + 2 * m], cur[8 + 2 * m + 1], hh, mm, ll);
+            h1[m] = hh; m1[m] = mm; l1[m] = ll;
+          }
+          if (m >= 4 && m < 20) {                    // register g = m - 4 of unit u-1: tanh and its score term
+            const int g = m - 4;
+            if (ct == 1) {
+              svp[g] = tanh_fast(prev[g]) * wvr[0];                              // u-1 was a first channel half
+              asm volatile("" : "+v"(svp[g]));       // computed HERE (machine sinking would move it to its use)
+            } else {                                                             // second half: add the first, and
+              if (g > 0) {                                                       // row-sum the previous register's term
+                const float t = row16_sum(tcur);
+                mine = ((lane & 15) == g - 1) ? t : mine;
+              }
+              tcur = fmaf(tanh_fast(prev[g]), wvr[1], svp[g]);
+            }
+          }
+          if (m >= 20) {                             // split pair m - 20 of the next unit's first k-step
+            if (m == 20 && ct == 0) {
+              const float t = row16_sum(tcur);
+              mine = ((lane & 15) == 15) ? t : mine;
+            }
+            unsigned hh, mm, ll;
+            split3_pair(next[2 * (m - 20)], next[2 * (m - 20) + 1], hh, mm, ll);
+            h0[m - 20] = hh; m0[m - 20] = mm; l0[m - 20] = ll;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        pb0[0] = __builtin_bit_cast(bf16x8, h0);
+        pb0[1] = __builtin_bit_cast(bf16x8, m0);
+        pb0[2] = __builtin_bit_cast(bf16x8, l0);
+        if (ct == 0) store_scores(u - 1, mine);
+      };
+      // scores of the last unit (a second channel half), outside the pipeline
+      auto finish_last = [&](const f32x16& pv) -> float {
+        float mine = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const float t = row16_sum(fmaf(tanh_fast(pv[g]), wvr[1], svp[g]));
+          mine = ((lane & 15) == g) ? t : mine;
+        }
+        return mine;
+      };
+      CA_STAMP(8 + 3 * pi);
+      load_unit(0, ring[0]);
+      load_unit(1, ring[1]);
+      split_half(ring[0], 0, pb0);
+#pragma unroll
+      for (int g = 0; g < 16; ++g) { svp[g] = 0.f; ring[3][g] = 0.f; }
+#pragma unroll 1
+      for (int u0 = 0; u0 < U; u0 += 4) {            // U is even: units come in (ct = 0, ct = 1) pairs
+        load_unit(u0 + 2, ring[2]);
+        __builtin_amdgcn_sched_barrier(0);
+        unit(u0, 0, ring[0], ring[3], ring[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_unit(u0 + 3, ring[3]);
+        __builtin_amdgcn_sched_barrier(0);
+        unit(u0 + 1, 1, ring[1], ring[0], ring[2]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (u0 + 2 < U) {
+          load_unit(u0 + 4, ring[0]);
+          __builtin_amdgcn_sched_barrier(0);
+          unit(u0 + 2, 0, ring[2], ring[1], ring[3]);
+          __builtin_amdgcn_sched_barrier(0);
+          load_unit(u0 + 5, ring[1]);
+          __builtin_amdgcn_sched_barrier(0);
+          unit(u0 + 3, 1, ring[3], ring[2], ring[0]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // the last unit's scores
+      store_scores(U - 1, (U & 2) ? finish_last(ring[1]) : finish_last(ring[3]));
+      CA_STAMP(9 + 3 * pi);
+      // the next pass' P_q operands fly under the epilogue (beyond the last pass: channel offsets >= d, the
+      // values are never used)
+      load_pq_raw((((pi + 1) >> 1) * NW + w) * 128 + 64 * ((pi + 1) & 1), pq_raw);
+      // H_q epilogue: hq = tanh(P_q + acc); saved for backward; s_q partials.  Branch-free: rows t >= T fall
+      // outside the per-sample buffers (loads give 0, stores are dropped)
+      {
+        const __amdgpu_buffer_rsrc_t rs_hq = make_rsrc(a.Hq + pair * (size_t)T * d, (unsigned)T * d * 4u);
+        // the row offsets are recomputed here in every pass: hoisted out of the pass loop they would be 16 registers
+        // that live (spilled) across the unit pipeline
+        int hrow = (4 * h * d + r) * 4;
+        asm volatile("" : "+v"(hrow));
+        auto eoff = [&](const int g, const int ct) { return hrow + (((g & 3) + 8 * (g >> 2)) * d + 32 * ct) * 4; };
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const float wq = a.wq[c0 + 32 * ct + r];
+          float pqv[16];
+#pragma unroll
+          for (int g = 0; g < 16; ++g) pqv[g] = buf_load1(rs_pq, eoff(g, ct), c0 * 4);
+          float mine = 0.f;                          // lane (j, .) of a 16-lane row keeps the sum of register g = j
+#pragma unroll
+          for (int g = 0; g < 16; ++g) {
+            const float hq = tanh_fast(accq[ct][g] + pqv[g]);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hq), rs_hq, eoff(g, ct), c0 * 4, 0);
+            // s_q partial of token crow(g, h) over this lane row's 16 channels
+            const float t = row16_sum(hq * wq);
+            mine = ((lane & 15) == g) ? t : mine;
+          }
+          float* dst = &sqpart[(w * 2 + g1) * 32 + crow(lane & 15, h)];
+          if (pi > 0 || ct > 0) mine += *dst;        // summed into the wave's slot in a fixed order
+          *dst = mine;
+        }
+      }
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) split3(pq_raw[ct][ks], pqB[ct][ks]);
+      CA_STAMP(10 + 3 * pi);
+    }
+  }
+
+  // ------------------------------------------------------------------ phase 3
+  lane = lane_id(); tid = w * 64 + lane;
+  CA_STAMP(3);
+  __syncthreads();
+  CA_STAMP(4);
+  if (w == 0) {
+    // a_v = softmax_n(s_v + c_v): N <= 32 NT <= 256 -> <= 4 values per lane
+    constexpr int PER = (NPAD + 63) / 64;
+    float sc[PER];
+    float m = -INFINITY;
+    const float cv = a.cv[0];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int n = lane + 64 * k;
+      float s = -INFINITY;
+      if (n < N) {
+        s = cv;
+#pragma unroll
+        for (int p = 0; p < NW * 4; ++p) s += svpart[p * NPAD + n];
+      }
+      sc[k] = s;
+      m = fmaxf(m, s);
+    }
+    m = wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      sc[k] = (lane + 64 * k < N) ? expf(sc[k] - m) : 0.f;
+      sum += sc[k];
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    float* avg = a.av + pair * (size_t)N;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int n = lane + 64 * k;
+      if (n < N) avg[n] = sc[k] * inv;
+    }
+    // a_q = softmax_t(s_q + c_q), un-masked over all T positions (model.py:388)
+    float s = -INFINITY;
+    if (lane < T) {
+      s = a.cq[0];
+#pragma unroll
+      for (int p = 0; p < NW * 2; ++p) s += sqpart[p * 32 + lane];
+    }
+    const float mq = wave_max(s);
+    const float e = (lane < T) ? expf(s - mq) : 0.f;
+    const float se = wave_sum(e);
+    const float aqv = e / se;
+    if (lane < 32) aqs[lane] = aqv;                  // zeros beyond T
+    if (lane < T) a.aq[pair * (size_t)T + lane] = aqv;
+  }
+  __syncthreads();
+  // q = sum_t a_q[t] Q[t][:]   (model.py:392): all kTRows row loads in flight at once (rows >= T read 0)
+  for (int dd = tid; dd < d; dd += NW * 64) {
+    float x[kTRows];
+#pragma unroll
+    for (int t = 0; t < kTRows; ++t) x[t] = buf_load1(rs_q, (t * d + dd) * 4, 0);
+    float acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < kTRows; ++t) acc = fmaf(aqs[t], x[t], acc);
+    a.q_out[pair * (size_t)d + dd] = acc;
+  }
+  CA_STAMP(5);
+}
+
+// v_l[b][ch] = sum_n a_v[l][b][n] V[b][n][ch]   (model.py:391), location-major V, all L levels in one pass.
+// grid (d / 128, B); 256 threads = 32 float4 lanes (128 channels) x 8 location phases, fixed-order sum over the phases.
+__global__ __launch_bounds__(256) void attend_v_lm_kernel(const float* V, long v_sB, const float* av, float* v_out,
+                                                          int B, int N, int d, int L) {
+  __shared__ float aw[3][256];
+  __shared__ f32x4 part[3][8][32];
+  const int b = blockIdx.y, c0 = blockIdx.x * 128;
+  const int tid = threadIdx.x, cl = tid & 31, ph = tid >> 5;
+  for (int i = tid; i < 3 * 256; i += 256) {
+    const int l = i >> 8, n = i & 255;
+    aw[l][n] = (l < L && n < N) ? av[((size_t)l * B + b) * N + n] : 0.f;
+  }
+  __syncthreads();
+  const float* vp = V + (size_t)b * v_sB + c0 + 4 * cl;
+  f32x4 acc[3];
+#pragma unroll
+  for (int l = 0; l < 3; ++l) acc[l] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 7
+  for (int n = ph; n < N; n += 8) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(vp + (size_t)n * d);
+#pragma unroll
+    for (int l = 0; l < 3; ++l) acc[l] += x * aw[l][n];
+  }
+#pragma unroll
+  for (int l = 0; l < 3; ++l) part[l][ph][cl] = acc[l];
+  __syncthreads();
+  if (tid < 96) {
+    const int l = tid >> 5, c = tid & 31;
+    f32x4 s = part[l][0][c];
+#pragma unroll
+    for (int p = 1; p < 8; ++p) s += part[l][p][c];
+    if (l < L) *reinterpret_cast<f32x4*>(v_out + ((size_t)l * B + b) * d + c0 + 4 * c) = s;
+  }
+}
+
+template <int NT, int NW, bool LM>
+int launch_fwd32(const FwdArgs& a, hipStream_t s) {
+  constexpr int NPAD = 32 * NT;
+  constexpr int RING_SLOTS = (NT + 1) * ((NT + 1 >= 6) ? 1 : 2);
+  const size_t lds_p2 = (size_t)32 * (NPAD + 4) * 4 + (size_t)3 * NPAD * 32 * 2, lds_p1 = (size_t)NW * RING_SLOTS * 2048;
+  const size_t lds = lds_p2 > lds_p1 ? lds_p2 : lds_p1;
+  static DeviceOnce once;                            // the attribute is per device
+  CA_TRY(once.run([&] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(coattn_fwd32_kernel<NT, NW, LM>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }, "coattn_fwd32"));
+  const int groups = (a.B + 7) / 8;
+  dim3 grid(groups * a.L * 8), block(NW * 64);
+  hipLaunchKernelGGL((coattn_fwd32_kernel<NT, NW, LM>), grid, block, lds, s, a);
+  CA_CHECK_LAUNCH("coattn_fwd32");
+  return 0;
+}
+
+template <bool LM>
+int dispatch_fwd32(const FwdArgs& a, hipStream_t s) {
+  const bool small_n = a.N <= 64;
+  if (a.d % 512 == 0) return small_n ? launch_fwd32<2, 4, LM>(a, s) : launch_fwd32<7, 4, LM>(a, s);
+  return small_n ? launch_fwd32<2, 2, LM>(a, s) : launch_fwd32<7, 2, LM>(a, s);
+}
+
+}  // namespace
+
+int fused32_forward(const FwdArgs& a, hipStream_t s) { return a.lm ? dispatch_fwd32<true>(a, s) : dispatch_fwd32<false>(a, s); }
+
+int launch_attend_v_lm(const float* V, long v_sB, const float* av, float* v_out, int B, int N, int d, int L, hipStream_t s) {
+  CA_CHECK_ARG(N <= 256 && L <= 3 && d % 128 == 0, "attend_v (location-major): unsupported shape");
+  hipLaunchKernelGGL(attend_v_lm_kernel, dim3(d / 128, B), dim3(256), 0, s, V, v_sB, av, v_out, B, N, d, L);
+  CA_CHECK_LAUNCH("attend_v_lm");
+  return 0;
+}

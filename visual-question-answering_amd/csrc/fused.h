@@ -2,15 +2,47 @@
 #pragma once
 #include "common.h"
 
+// Element strides of the logical image-feature view x_img[B,N,d] (model.py:215-217).  The fused kernels take two
+// physical layouts: channel-major [B][d][N] (sN = 1, sD = N: what the reference's NCHW encoder leaves behind its
+// permuted view) and location-major [B][N][d] (sD = 1, sN = d: a channels_last encoder); the general-shape
+// kernels take any strides.
+struct VLayout {
+  long sB, sN, sD;
+};
+inline bool v_is_lm(const VLayout& v, int N, int d) { (void)N; return v.sD == 1 && v.sN == d; }
+inline bool v_is_cm(const VLayout& v, int N, int d) { (void)d; return v.sN == 1 && v.sD == N; }
+
 int fused_supported(int B, int N, int T, int d, int L);
+inline bool fused_layout_ok(const VLayout& v, int N, int d) { return v_is_lm(v, N, d) || v_is_cm(v, N, d); }
 // everything after the projections (P_v, P_q already in `saved`)
-int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, const float* const* Q,
-                            const coattn_params* p, float* v_out, float* q_out, float* saved, float* ws,
-                            hipStream_t s);
+int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, const VLayout& vl,
+                            const float* const* Q, const coattn_params* p, float* v_out, float* q_out, float* saved,
+                            float* ws, hipStream_t s);
 int fused_backward_supported(int B, int N, int T, int d, int L);
-int fused_backward(int B, int N, int T, int d, int L, const float* V, const float* const* Q, const coattn_params* p,
-                   const float* saved, const float* gv, const float* gq, float* dV, float* const* dQ,
-                   const coattn_param_grads* pg, int accumulate, float* ws, hipStream_t s, int bf16_proj);
+int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLayout& vl, const float* const* Q,
+                   const coattn_params* p, const float* saved, const float* gv, const float* gq, float* dV,
+                   const VLayout& dvl, float* const* dQ, const coattn_param_grads* pg, int accumulate, float* ws,
+                   hipStream_t s, int bf16_proj);
+
+// Diagnostic build only (tools/probe_stamps.py, -DCOATTN_STAMPS=1): wave 0 of every workgroup writes the
+// 100 MHz constant clock at its phase boundaries into the (otherwise unused) forward workspace tail.
+#ifndef COATTN_STAMPS
+#define COATTN_STAMPS 0
+#endif
+#if COATTN_STAMPS
+#define CA_STAMP(k)                                                                                   \
+  do {                                                                                                \
+    if (threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 64 + (k)] = __builtin_amdgcn_s_memrealtime();  \
+  } while (0)
+#define CA_STAMP_CYC(k)                                                                               \
+  do {                                                                                                \
+    if (threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 64 + (k)] = __builtin_amdgcn_s_memtime();      \
+  } while (0)
+#else
+#define CA_STAMP(k)
+#define CA_STAMP_CYC(k)
+#endif
+
 
 // ---- shared by the fused forward / backward translation units -------------------------------
 constexpr int kTS = 7;       // k-steps of 4 over T: T <= 28
@@ -23,8 +55,53 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
-typedef short bf16x8 __attribute__((ext_vector_type(8)));      // MFMA 16x16x32 bf16 operand: 8 k-values per lane
+typedef short bf16x8 __attribute__((ext_vector_type(8)));      // bf16 MFMA operand: 8 k-values per lane
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bfv8 __attribute__((ext_vector_type(8)));
+
+// ---- fp32-accurate products on the bf16 MFMA: exact 3-way split x = hi + mid + lo ----------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bfv2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {      // one v_cvt_pk_bf16_f32 (round to nearest even)
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{a, b}), bfv2));
+}
+// a - b.  The residual subtractions must stay single v_sub_f32 (paired into v_pk_add_f32 they cost more issue
+// cycles beside MFMAs than two plain subtractions): the kernels are compiled with -fno-slp-vectorize; an inline-asm
+// v_sub_f32 would do the same but costs a wait state after every statement.
+__device__ __forceinline__ float sub1(float a, float b) { return a - b; }
+// one pair of fp32 values -> the three packed bf16 pairs (11 VALU ops)
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+  h = cvt_pk_bf16(a, b);
+  const float ra = sub1(a, __builtin_bit_cast(float, h << 16));
+  const float rb = sub1(b, __builtin_bit_cast(float, h & 0xffff0000u));
+  m = cvt_pk_bf16(ra, rb);
+  const float sa = sub1(ra, __builtin_bit_cast(float, m << 16));
+  const float sb = sub1(rb, __builtin_bit_cast(float, m & 0xffff0000u));
+  l = cvt_pk_bf16(sa, sb);
+}
+__device__ __forceinline__ void split3(const f32x8& v, bf16x8 (&p)[3]) {
+  u32x4 h, m, l;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned hh, mm, ll;
+    split3_pair(v[2 * i], v[2 * i + 1], hh, mm, ll);
+    h[i] = hh; m[i] = mm; l[i] = ll;
+  }
+  p[0] = __builtin_bit_cast(bf16x8, h);
+  p[1] = __builtin_bit_cast(bf16x8, m);
+  p[2] = __builtin_bit_cast(bf16x8, l);
+}
+// c += a . b over 16 k (32x32x16) with fp32 accuracy: the six partial products down to relative order 2^-16
+// (each bf16 x bf16 product is exact in the fp32 accumulator), smallest terms first
+__device__ __forceinline__ f32x16 mfma32_x3(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+  return c;
+}
 
 // buffer resource over [ptr, ptr + bytes): out-of-range loads return 0, stores are dropped
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, unsigned bytes) {
@@ -51,7 +128,9 @@ __device__ __forceinline__ bool block_to_pair(int bid, int B, int L, int& b, int
 
 // arguments of the fused forward kernel (coattn_fused.hip)
 struct FwdArgs {
-  const float* V;        // [B][d][N]
+  const float* V;        // [B][d][N] (lm = 0) or [B][N][d] (lm = 1), sample stride v_sB
+  long v_sB;
+  int lm;
   const float* Q[8];     // L x [B][T][d]
   const float* Pv;       // [B][N][d]
   const float* Pq;       // [L][B][T][d]
@@ -64,6 +143,10 @@ struct FwdArgs {
   unsigned long long* stamps;   // diagnostic builds only
   int B, N, T, d, L;
 };
+
+// bf16-split forward kernel on the 32x32x16 MFMA (coattn_fwd32.hip)
+int fused32_forward(const FwdArgs& a, hipStream_t s);
+int launch_attend_v_lm(const float* V, long v_sB, const float* av, float* v_out, int B, int N, int d, int L, hipStream_t s);
 
 inline size_t fal64(size_t n) { return (n + 63) & ~(size_t)63; }
 

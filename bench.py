@@ -20,7 +20,8 @@ contract fields it carries
   roofline_projection  the MFMA-bound P_v projection GEMM, timed the same way: fp32-equivalent TFLOP/s
                 against the fp32 matrix peak and the issued bf16 flops against the dense bf16 peak
   hot_path      isolated co-attention (+MLP+CE) fwd+bwd rates on device-resident features, N=196
-                and N=49, and the per-call forward / backward times of the HIP path.
+                and N=49, both feature layouts; the HIP op's fwd+bwd device time (pipelined calls) and the
+                wall time of single synchronised calls.
 """
 from __future__ import annotations
 
@@ -138,25 +139,44 @@ def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
-    # forward / backward of the HIP op alone (C-ABI calls through the autograd function), wall time
-    # around a device synchronisation
+    # forward + backward of the HIP op alone (C-ABI calls through the autograd function):
+    #  (a) device time of a pipelined run (HIP events around `iters` back-to-back fwd+bwd calls: what the train
+    #      loop sees, the host runs ahead of the GPU);
+    #  (b) wall time of a single forward / backward call between two device synchronisations (adds the launch
+    #      latency and the host side of one call).
     args = (co.W_v.weight, co.W_v.bias, co.W_q.weight, co.W_q.bias, co.w_v.weight, co.w_v.bias, co.w_q.weight,
             co.w_q.bias)
+    gv = torch.ones(3, B, d, device=device)
+    gq = torch.ones(3, B, d, device=device)
+
+    def fb():
+        v, q = vqa_amd.coattention(x_img, Qs, *args)
+        torch.autograd.backward([v, q], [gv, gq])
+
+    for _ in range(3):
+        fb()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fb()
+    e1.record()
+    torch.cuda.synchronize()
+    t_dev = e0.elapsed_time(e1) * 1e-3 / iters
     fwd = bwd = 0.0
     for it in range(iters + 3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         v, q = vqa_amd.coattention(x_img, Qs, *args)
         torch.cuda.synchronize(); t1 = time.perf_counter()
-        g = [torch.ones_like(v), torch.ones_like(q)]
-        torch.cuda.synchronize(); t2 = time.perf_counter()
-        torch.autograd.backward([v, q], g)
+        torch.autograd.backward([v, q], [gv, gq])
         torch.cuda.synchronize(); t3 = time.perf_counter()
         if it >= 3:
-            fwd += t1 - t0; bwd += t3 - t2
+            fwd += t1 - t0; bwd += t3 - t1
     flop = 3.0 * B * (2 * N * d * d + 3 * 2 * T * d * d + 3 * (3 * 2 * T * N * d + 4 * (N + T) * d))
     return {"N": N, "layout": layout, "pairs_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3),
-            "coattn_fwd_ms": round(fwd / iters * 1e3, 4), "coattn_bwd_ms": round(bwd / iters * 1e3, 4),
-            "coattn_fwd_bwd_tflops": round(flop / ((fwd + bwd) / iters) / 1e12, 2)}
+            "coattn_fwd_bwd_ms": round(t_dev * 1e3, 4), "coattn_fwd_bwd_tflops": round(flop / t_dev / 1e12, 2),
+            "coattn_fwd_wall_ms": round(fwd / iters * 1e3, 4), "coattn_bwd_wall_ms": round(bwd / iters * 1e3, 4),
+            "coattn_fwd_bwd_wall_tflops": round(flop / ((fwd + bwd) / iters) / 1e12, 2)}
 
 
 def roofline_leg(device, B=160, N=196, T=26, d=512, L=3, iters=50, layout="lm"):

@@ -95,3 +95,25 @@ def net_case_batch(c=None):
     question = question * (torch.arange(T)[None, :] < lens[:, None])
     label = torch.from_numpy((O.hash_uniform(B, c["seed"] + 3) * (c["K"] + 1)).astype("int64"))
     return image, question, lens, label
+
+
+# ---- network-level cases with INJECTED image features (SURVEY 8c G7 "stub VGG features injected") ---------
+# The HIP path is then compared inside the network at the op-level tolerance (1e-4): nothing stock and
+# batch-statistics dependent (MIOpen convolutions, 3-sample BatchNorm) sits in front of it.
+#   NETF_CASE: cfg-2 like (hidden 512, 7x7 grid).   NETF4_CASE: BASELINE config 4 (ResNet-152-like 7x7x2048
+#   features, hidden 2048, K=3000 -> 3001 logits), fp32 reference values; the bf16 mode is checked against
+#   them at a stated bf16 tolerance.
+NETF_CASE = dict(vocab=40, hidden=512, K=10, B=3, T=26, N=49, lens=[26, 11, 3], seed=501, lr=1e-4, steps=3)
+NETF4_CASE = dict(vocab=30, hidden=2048, K=3000, B=2, T=26, N=49, lens=[26, 9], seed=601, lr=1e-4, steps=2)
+
+
+def netf_inputs(c):
+    """(features [B,N,d] as the permuted view of a channel-major [B,d,N] buffer -- the reference's layout,
+    model.py:215-217 --, question, ques_len, label), closed form."""
+    B, T, N, d = c["B"], c["T"], c["N"], c["hidden"]
+    feats = torch.from_numpy(O.hash_normal((B, d, N), c["seed"] + 1)).float().clamp_min(0).permute(0, 2, 1)
+    tok = (O.hash_uniform(B * T, c["seed"] + 2) * (c["vocab"] - 2)).astype("int64").reshape(B, T) + 2
+    lens = torch.tensor(c["lens"], dtype=torch.int64)
+    question = torch.from_numpy(tok) * (torch.arange(T)[None, :] < lens[:, None])
+    label = torch.from_numpy((O.hash_uniform(B, c["seed"] + 3) * (c["K"] + 1)).astype("int64"))
+    return feats, question, lens, label

@@ -122,8 +122,32 @@ def check(rc: int, what: str) -> None:
         raise RuntimeError("%s failed (%d): %s" % (what, rc, load().coattn_last_error().decode()))
 
 
+_ws_cache = {}
+
+
 def workspace_bytes(B, N, T, d, L, flags=0):
+    """(saved, ws_fwd, ws_bwd) in bytes; cached per shape (the plan is a pure function of the shape)."""
+    key = (B, N, T, d, L, flags)
+    hit = _ws_cache.get(key)
+    if hit is not None:
+        return hit
     s, f, b = C.c_size_t(), C.c_size_t(), C.c_size_t()
     check(load().coattn_workspace_bytes(B, N, T, d, L, F32, flags, C.byref(s), C.byref(f), C.byref(b)),
           "coattn_workspace_bytes")
-    return s.value, f.value, b.value
+    _ws_cache[key] = (s.value, f.value, b.value)
+    return _ws_cache[key]
+
+
+_scratch = {}
+
+
+def scratch(nbytes: int, device, stream_ptr: int):
+    """Scratch workspace (contents undefined after a call) kept per (device, stream): calls on one stream run in
+    order, so they can share it; grown on demand, never shrunk."""
+    import torch
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream_ptr)
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
+        _scratch[key] = buf
+    return buf

@@ -74,10 +74,10 @@ class _CoAttentionFn(torch.autograd.Function):
         out_v = torch.empty((L, B, d), device=dev, dtype=torch.float32)
         out_q = torch.empty((L, B, d), device=dev, dtype=torch.float32)
         saved = torch.empty(sb // 4, device=dev, dtype=torch.float32) if need_grad else None
-        ws = torch.empty(fb // 4, device=dev, dtype=torch.float32)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        ws = _lib.scratch(fb, dev, stream)            # per-stream scratch, reused from call to call
         qptr = (C.c_void_p * L)(*[q.data_ptr() for q in Qs])
         p = _lib.Params(*[t.data_ptr() for t in params])
-        stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
             _lib.check(lib.coattn_forward(_ptr(V), *_strides(V), qptr, C.byref(p), _ptr(out_v), _ptr(out_q), _ptr(saved),
                                           _ptr(ws), B, N, T, d, L, _lib.F32, impl, C.c_void_p(stream)),
@@ -98,7 +98,8 @@ class _CoAttentionFn(torch.autograd.Function):
         g_v = g_v.contiguous() if g_v is not None else torch.zeros((L, B, d), device=dev)
         g_q = g_q.contiguous() if g_q is not None else torch.zeros((L, B, d), device=dev)
         _, _, bb = _lib.workspace_bytes(B, N, T, d, L, impl)
-        ws = torch.empty(bb // 4, device=dev, dtype=torch.float32)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        ws = _lib.scratch(bb, dev, stream)
         need_dv = ctx.needs_input_grad[0]
         dV = None
         if need_dv:                         # gradient of x_img[B,N,d] in the layout of x_img itself
@@ -110,7 +111,6 @@ class _CoAttentionFn(torch.autograd.Function):
         p = _lib.Params(*[t.data_ptr() for t in params])
         qptr = (C.c_void_p * L)(*[q.data_ptr() for q in Qs])
         dqptr = (C.c_void_p * L)(*[q.data_ptr() for q in dQs])
-        stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
             _lib.check(lib.coattn_backward(_ptr(V), *_strides(V), qptr, C.byref(p), _ptr(saved), _ptr(g_v), _ptr(g_q),
                                            _ptr(dV), *(_strides(dV) if need_dv else (0, 0, 0)), dqptr, C.byref(pg), 0,

@@ -235,6 +235,14 @@ class QuestionBertCoAttentionEncoder(nn.Module):
         self.phrase_conv_pool = PhraseConvPool(hidden_dim)
         self.sentence_lstm = nn.LSTM(hidden_dim, hidden_dim)
         self.hidden_dim = hidden_dim
+        self.bert.eval()
+
+    def train(self, mode: bool = True):
+        """The frozen token-embedding module stays in eval mode (its dropout would make the "frozen embeddings"
+        of BASELINE config 5 random)."""
+        super().train(mode)
+        self.bert.eval()
+        return self
 
     def forward(self, x, x_lens):
         T = x.shape[1]

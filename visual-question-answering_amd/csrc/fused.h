@@ -110,8 +110,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* ptr, uns
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+// 16-byte buffer store.  The scalar offset is folded into the vector offset ON PURPOSE: a buffer store of more than
+// 64 bits reads its data registers late, and hipcc (ROCm 7.2) pads the following overwrite of those registers only
+// when the store has NO scalar-offset register -- with one, a VALU write scheduled right behind the store corrupted
+// the stored data on gfx950 (dP_v of the fused backward: wrong by O(1) in the elements the next v_pk_add reused).
 __device__ __forceinline__ void buf_store4(f32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff + soff, 0, 0);
 }
 __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));

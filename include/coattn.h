@@ -141,37 +141,10 @@ int coattn_phrase_backward(const void* X, const coattn_phrase_params* p, const v
                            const void* g_out, void* dX, const coattn_phrase_param_grads* pg, int accumulate,
                            void* ws, int B, int T, int E, int dtype, int flags, void* stream);
 
-/* ---- MLPClassifier + cross entropy: the consumer of the path -----------------
- * coattn_mlp_forward/backward replace reference model.py:400-434 (`MLPClassifier.forward`: h_w = tanh(W_w(q_w+v_w)),
- * h_p = tanh(W_p[q_p+v_p | h_w]), h_s = tanh(W_s[q_s+v_s | h_p]), logits = W_h h_s) and its autograd;
- * coattn_ce_forward replaces `nn.CrossEntropyLoss()(logits, label)` of the train step (main.py:94, :214; mean over
- * the batch) together with its gradient.  Weights in nn.Linear layout (out x in): W_w [d,d], W_p [d,2d], W_s [mlp,2d],
- * W_h [K,mlp] (state_dict keys mlp_classify.W_w/W_p/W_s/W_h .weight/.bias, model.py:409-412).
- *   v, q   : [3, B, d], the buffers coattn_forward writes (level order word, phrase, sentence);
- *   logits : [B, K]. */
-typedef struct coattn_mlp_params {
-  const void* W_w; const void* b_w;   /* model.py:409 */
-  const void* W_p; const void* b_p;   /* model.py:410 */
-  const void* W_s; const void* b_s;   /* model.py:411 */
-  const void* W_h; const void* b_h;   /* model.py:412 */
-} coattn_mlp_params;
-
-typedef struct coattn_mlp_param_grads {
-  void* dW_w; void* db_w; void* dW_p; void* db_p; void* dW_s; void* db_s; void* dW_h; void* db_h;
-} coattn_mlp_param_grads;
-
-/* saved: forward -> backward state (h_w, h_p, h_s), NULL for inference; ws_fwd / ws_bwd: scratch (split-k partials). */
-int coattn_mlp_workspace_bytes(int B, int d, int mlp, int K, int dtype, size_t* saved, size_t* ws_fwd, size_t* ws_bwd);
-
-int coattn_mlp_forward(const void* v, const void* q, const coattn_mlp_params* p, void* logits, void* saved, void* ws,
-                       int B, int d, int mlp, int K, int dtype, int flags, void* stream);
-
-/* g_logits [B,K] -> g_vq [3,B,d] (overwritten; NULL to skip): the gradient with respect to v AND to q (they enter
- * through q_l + v_l, model.py:427-429), and the eight parameter gradients (accumulate = 0 overwrites, 1 adds). */
-int coattn_mlp_backward(const void* v, const void* q, const coattn_mlp_params* p, const void* saved,
-                        const void* g_logits, void* g_vq, const coattn_mlp_param_grads* pg, int accumulate, void* ws,
-                        int B, int d, int mlp, int K, int dtype, int flags, void* stream);
-
+/* ---- cross entropy of the train step ------------------------------------------------
+ * coattn_ce_forward replaces `nn.CrossEntropyLoss()(logits, label)` (main.py:94, :214; mean over the batch)
+ * together with its gradient.  The MLPClassifier that produces the logits (model.py:400-434) stays on the stock
+ * PyTorch-ROCm modules. */
 /* Mean cross entropy over B rows of [B,K] logits with int64 labels in [0,K) (a label outside makes the loss NaN):
  * loss[0] = mean_i (logsumexp(z_i) - z_i[label_i]);  dlogits [B,K] = (softmax(z) - onehot) / B, or NULL to skip.
  * ws: coattn_ce_workspace_bytes. */

@@ -33,7 +33,7 @@ def _net(c):
 
 def _steps(net, feats, question, lens, label, c, autocast=False):
     """main.py:211-222 from the features on: logits, then `steps` Adam steps; returns (logits, losses)."""
-    from vqa_amd.mlp import CrossEntropyLoss
+    from vqa_amd.loss import CrossEntropyLoss
     import contextlib
     ctx = (lambda: torch.autocast("cuda", dtype=torch.bfloat16)) if autocast else contextlib.nullcontext
     with torch.no_grad(), ctx():

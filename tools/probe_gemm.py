@@ -31,6 +31,13 @@ run("dW_v", dict(A=Pv, B=V, C=part, M=d, N=d, K=N, batch=S, inner=G, inner_total
 K = 3 * B * T; ks = (K // 32 + 15) // 16 * 16; S2 = (K + ks - 1) // ks
 part2 = torch.empty(S2, d, d, device=dev)
 run("dW_q", dict(A=Pq, B=Q, C=part2, M=d, N=d, K=K, batch=S2, ksplit=ks, a_sm=1, a_sk=d, b_sk=d, b_sn=1, c_sm=d, c_sn=1, c_sz=d*d), 2.0*K*d*d)
+# the same products on location-major features (channels_last encoder): plain row-major P_v, flat split-K dW_v
+Vl = torch.randn(B * N, d, device=dev)
+run("P_v lm", dict(A=Vl, B=W, C=Pv, M=B*N, N=d, K=d, batch=1, a_sm=d, a_sk=1, b_sk=1, b_sn=d, c_sm=d, c_sn=1), 2.0*B*N*d*d)
+Kv = B * N; ksv = ((Kv + 31) // 32 + 15) // 16 * 16; Sv = (Kv + ksv - 1) // ksv
+partv = torch.empty(Sv, d, d, device=dev)
+run("dW_v lm", dict(A=Pv, B=Vl, C=partv, M=d, N=d, K=Kv, batch=Sv, ksplit=ksv, a_sm=1, a_sk=d, b_sk=d, b_sn=1, c_sm=d, c_sn=1, c_sz=d*d), 2.0*Kv*d*d)
+if os.environ.get("SKIP_TORCH"): sys.exit(0)
 # practical ceiling: the vendor library's fp32 GEMM on the same shapes (contiguous operands)
 def tref(name, fn, flop, iters=30):
     for _ in range(3): fn()

@@ -8,6 +8,6 @@ tensors raises.
 """
 from . import _lib  # noqa: F401
 from .coattention import ParallelCoAttention, coattention  # noqa: F401
-from .mlp import CrossEntropyLoss, cross_entropy, mlp_classify  # noqa: F401
+from .loss import CrossEntropyLoss, cross_entropy  # noqa: F401
 
-__all__ = ["ParallelCoAttention", "coattention", "mlp_classify", "cross_entropy", "CrossEntropyLoss", "_lib"]
+__all__ = ["ParallelCoAttention", "coattention", "cross_entropy", "CrossEntropyLoss", "_lib"]

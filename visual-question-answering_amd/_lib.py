@@ -14,7 +14,6 @@ CSRC = os.path.join(_HERE, "csrc")
 EXPORTS = ("coattn_version", "coattn_last_error", "coattn_fused_supported", "coattn_workspace_bytes",
            "coattn_forward", "coattn_attention_forward", "coattn_backward", "coattn_gemm_f32", "coattn_gemm_bf16",
            "coattn_phrase_workspace_bytes", "coattn_phrase_forward", "coattn_phrase_backward",
-           "coattn_mlp_workspace_bytes", "coattn_mlp_forward", "coattn_mlp_backward",
            "coattn_ce_workspace_bytes", "coattn_ce_forward")
 
 F32 = 0
@@ -36,14 +35,6 @@ class PhraseParams(C.Structure):
 
 class PhraseParamGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("dW1", "db1", "dW2", "db2", "dW3", "db3")]
-
-
-class MlpParams(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("W_w", "b_w", "W_p", "b_p", "W_s", "b_s", "W_h", "b_h")]
-
-
-class MlpParamGrads(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("dW_w", "db_w", "dW_p", "db_p", "dW_s", "db_s", "dW_h", "db_h")]
 
 
 class GemmDesc(C.Structure):
@@ -105,12 +96,6 @@ def load() -> C.CDLL:
     lib.coattn_phrase_backward.argtypes = [C.c_void_p, C.POINTER(PhraseParams), C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.POINTER(PhraseParamGrads), C.c_int, C.c_void_p,
                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
-    lib.coattn_mlp_workspace_bytes.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_size_t)] * 3
-    lib.coattn_mlp_forward.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(MlpParams), C.c_void_p, C.c_void_p,
-                                       C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
-    lib.coattn_mlp_backward.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(MlpParams), C.c_void_p, C.c_void_p,
-                                        C.c_void_p, C.POINTER(MlpParamGrads), C.c_int, C.c_void_p] + [C.c_int] * 6 + [
-                                            C.c_void_p]
     lib.coattn_ce_workspace_bytes.argtypes = [C.c_int] * 3 + [C.POINTER(C.c_size_t)]
     lib.coattn_ce_forward.argtypes = [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p]
     _lib = lib

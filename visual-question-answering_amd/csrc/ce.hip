@@ -1,0 +1,73 @@
+// Cross entropy of the train step on gfx950 (reference main.py:94 / :214: nn.CrossEntropyLoss() on the logits of
+// MLPClassifier, mean over the batch) together with its gradient: one workgroup per row -- log-sum-exp, loss and
+// d logits = (softmax - onehot) / B in one pass -- and a fixed-order sum of the row losses.  Deterministic: no
+// atomics.  (SURVEY.md section 8f-1.  The MLPClassifier itself stays on the stock PyTorch-ROCm modules: a
+// composition of this library's GEMM for its four B-row products was built and measured in round 1 -- 30 launches,
+// 0.53 ms against ~0.2 ms for the stock head -- and was removed again in round 2; see DESIGN.md.)
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float block_max(float v, float* sh) {
+  v = wave_max(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float r = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  __syncthreads();
+  return r;
+}
+
+// row_loss[i] = (logsumexp(z_i) - z_i[label_i]) * inv_b ; dlogits = (softmax(z_i) - onehot(label_i)) * inv_b.
+// A label outside [0, K) makes the row's loss NaN (nn.CrossEntropyLoss raises there).
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                                                      float* __restrict__ row_loss, float* __restrict__ dlogits, int K,
+                                                      float inv_b) {
+  __shared__ float sh[4];
+  const int i = blockIdx.x;
+  const float* z = logits + (long)i * K;
+  float m = -INFINITY;
+  for (int k = threadIdx.x; k < K; k += 256) m = fmaxf(m, z[k]);
+  m = block_max(m, sh);
+  float s = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) s += expf(z[k] - m);
+  s = block_sum(s, sh);
+  const long long lab = labels[i];
+  const bool ok = lab >= 0 && lab < K;
+  if (threadIdx.x == 0) row_loss[i] = ok ? (logf(s) + m - z[lab]) * inv_b : NAN;
+  if (dlogits) {
+    const float inv = inv_b / s;
+    for (int k = threadIdx.x; k < K; k += 256)
+      dlogits[(long)i * K + k] = expf(z[k] - m) * inv - ((ok && k == lab) ? inv_b : 0.f);
+  }
+}
+
+inline size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
+
+}  // namespace
+
+extern "C" int coattn_ce_workspace_bytes(int B, int K, int dtype, size_t* ws) {
+  CA_CHECK_ARG(dtype == COATTN_F32, "unsupported dtype %d (only COATTN_F32)", dtype);
+  CA_CHECK_ARG(B > 0 && K > 0, "bad B=%d / K=%d", B, K);
+  if (ws) *ws = al64((size_t)B) * sizeof(float);
+  return 0;
+}
+
+extern "C" int coattn_ce_forward(const void* logits, const void* labels, void* loss, void* dlogits, void* ws, int B,
+                                 int K, int dtype, void* stream) {
+  CA_CHECK_ARG(dtype == COATTN_F32, "unsupported dtype %d (only COATTN_F32)", dtype);
+  CA_CHECK_ARG(B > 0 && B <= (1 << 24) && K > 0, "bad B=%d / K=%d", B, K);
+  CA_CHECK_ARG(logits && labels && loss && ws, "ce_forward: null argument");                   // dlogits may be NULL
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(ce_rows_kernel, dim3(B), dim3(256), 0, s, (const float*)logits, (const long long*)labels,
+                     (float*)ws, (float*)dlogits, K, 1.0f / (float)B);
+  CA_CHECK_LAUNCH("ce_rows");
+  return launch_sum_all((const float*)ws, (float*)loss, B, 0, s);
+}

@@ -259,7 +259,7 @@ class QuestionBertCoAttentionEncoder(nn.Module):
 
 
 class MLPClassifier(nn.Module):
-    """Recursive word -> phrase -> sentence answer head (model.py:414-434)."""
+    """Recursive word -> phrase -> sentence answer head (model.py:414-434); stock PyTorch-ROCm (hipBLASLt) modules."""
 
     def __init__(self, hidden_dim, mlp_dim, K):
         super().__init__()
@@ -269,13 +269,6 @@ class MLPClassifier(nn.Module):
         self.W_h = nn.Linear(mlp_dim, K)
 
     def forward(self, x_img_feats, x_ques_feats):
-        if x_img_feats[0].is_cuda and os.environ.get("VQA_MLP_IMPL", "stock") == "hip":
-            # MI355X path (csrc/mlp.hip): same parameters, same values.  Opt-in: at B = 160 its 30
-            # launch-latency-bound kernels take longer on the GPU than the stock modules' 
-            from .mlp import as_level_stack, mlp_classify
-            return mlp_classify(as_level_stack(x_img_feats), as_level_stack(x_ques_feats), self.W_w.weight,
-                                self.W_w.bias, self.W_p.weight, self.W_p.bias, self.W_s.weight, self.W_s.bias,
-                                self.W_h.weight, self.W_h.bias)
         (q_w, q_p, q_s), (v_w, v_p, v_s) = x_ques_feats, x_img_feats
         h_w = torch.tanh(self.W_w(q_w + v_w))
         h_p = torch.tanh(self.W_p(torch.cat([q_p + v_p, h_w], dim=1)))

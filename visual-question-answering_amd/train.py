@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import dist as vdist
-from .mlp import CrossEntropyLoss
+from .loss import CrossEntropyLoss
 from .modules import HierarchicalCoAttentionNet, VQABaselineNet
 
 PATH_VGG_WEIGHTS = None      # the reference hard-codes a local .pth (utils.py:15); none ships here

@@ -64,6 +64,10 @@ for k in range(6):
     print("  boundary %d reached at (rel. to first start): mean %6.1f  min %6.1f  max %6.1f us"
           % (k, (st[:, k] - t0).mean(), (st[:, k] - t0).min(), (st[:, k] - t0).max()))
 
+if st.shape[1] > 6 and (tail[live][:, 6] > 0).all():
+    print("  of the cross-wave sum + tanh span: tree %.1f us, tanh / split / image %.1f us"
+          % ((st[:, 6] - st[:, 1]).mean(), (st[:, 2] - st[:, 6]).mean()))
+
 # (the per-tile stamps of the removed tile-pipelined kernel are no longer produced)
 nt = (N + 15) // 16
 if st.shape[1] >= 8 + 4 * nt and (st[:, 8:8 + 4 * nt] > 0).all():
@@ -79,7 +83,7 @@ if st.shape[1] >= 8 + 4 * nt and (st[:, 8:8 + 4 * nt] > 0).all():
     print("  steps per tile index:", " ".join("%.1f" % x for x in steps.mean(axis=0)))
 
 # shader-cycle stamps (s_memtime) around the tile loop of coattn_fused.hip: cycles per tile and the clock they imply
-if st.shape[1] > 7 and (tail[live][:, 6] > 0).all() and (tail[live][:, 7] > 0).all():
+if st.shape[1] > 7 and (tail[live][:, 7] > 0).all() and (tail[live][:, 6] > 0).all() and False:
     cyc = tail[live][:, 7] - tail[live][:, 6]
     us = st[:, 3] - st[:, 2]
     print("tile loop: %.0f shader cycles per workgroup (%.0f per tile) in %.1f us -> %.2f GHz; MFMA issue cycles per wave: %d"

@@ -24,6 +24,12 @@
 
 // Phase 1: number of 32-location tiles per k-step that run on the bf16 MFMA with the 3-way split (the others take the
 // f32 MFMA).  -1: the default share (6 of 7); tuning builds override it.
+#ifndef COATTN_P1_NODMA
+#define COATTN_P1_NODMA 0      // developer switches of the phase-1 experiments (wrong results when set)
+#endif
+#ifndef COATTN_P1_NOMATH
+#define COATTN_P1_NOMATH 0
+#endif
 #ifndef COATTN_P1_NB
 #define COATTN_P1_NB -1
 #endif
@@ -159,146 +165,249 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
   const __amdgpu_buffer_rsrc_t rs_pq = make_rsrc(Pqp, (unsigned)T * d * 4u);
   const int nsl = d / (128 * NW);                    // 128-channel slices per wave (1 at d = 512)
 
-  // B operands of H_v (P_q, contraction index t): lane (channel c0 + 32 ct + r, half h) holds
-  // P_q[t = 16 ks + 8 h + i][channel], i = 0..7; raw loads first, split when needed
-  // (one lane-dependent offset, recomputed at every call, and scalar row offsets: kept as 16 hoisted vector offsets
-  // they would live -- spilled -- across the unit pipeline)
-  auto load_pq_raw = [&](int c0, f32x8 (&raw)[2][2]) {
-    int base = (8 * h * d + r) * 4;
+  // P_q of a pass (64 channels from c0), as two accumulator-shaped fragments: register g of lane (r, h) of fragment ct
+  // holds P_q[t = crow(g, h)][c0 + 32 ct + r] -- the initial value of the H_q accumulators.  (One lane-dependent
+  // offset, recomputed at every call, and scalar row offsets: 16 hoisted vector offsets would live -- spilled --
+  // across the unit pipeline.)
+  auto load_pq_frag = [&](int c0, f32x16 (&f)[2]) {
+    int base = (4 * h * d + r) * 4;
     asm volatile("" : "+v"(base));
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-          raw[ct][ks][i] = buf_load1(rs_pq, base + 128 * ct, (c0 + (16 * ks + i) * d) * 4);
+      for (int g = 0; g < 16; ++g)
+        f[ct][g] = buf_load1(rs_pq, base + 128 * ct, (c0 + ((g & 3) + 8 * (g >> 2)) * d) * 4);
   };
 
   // ------------------------------------------------------------------ phase 1: A = Q V^T
-  f32x8 pq_raw[2][2];
+  f32x16 pqf[2];
   {
     f32x16 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[nt][g] = 0.f;
-    // Operand stream.  Element i of a lane's fragment <-> channel k0 + 4 h + (i & 3) + 8 (i >> 2): the same order
-    // for A and B, chosen so that the two 16-byte loads of a location-major row are contiguous across the lane halves.
-    // The stream is latency-bound (a wave alone needs ~8 KB in flight to cover HBM latency at its share of the
-    // bandwidth, twice that under load), and registers cannot hold that: the fragments go HBM -> LDS by LDS-DMA
-    // (buffer_load ... lds, no VGPR destination) into a per-wave ring of R slots of 2 KB -- the LDS is idle until the
-    // cross-wave reduction -- and are read back (ds_read_b128 x 2 per lane, lane-linear, conflict-free) one unit
-    // before their MFMAs.  Units of a k-step (16 channels): the Q fragment, then the NT location tiles.
-    // The first NB tiles of a k-step run on the bf16 MFMA with the exact 3-way split (6 MFMAs of 32 cycles + 44 VALU
-    // per unit), the others on the f32 MFMA straight from the registers (8 MFMAs of 64 cycles, no VALU; lane (., h)
-    // of a 32x32x2 MFMA supplies k = h: element i pairs channels (k0 + (i&3) + 8(i>>2), the same + 4)).
-    constexpr int NB = COATTN_P1_NB >= 0 ? (COATTN_P1_NB < NT ? COATTN_P1_NB : NT) : NT;
-    constexpr int UPK = NT + 1;                      // units per k-step
-    constexpr int KU = (UPK >= 6) ? 1 : 2;           // k-steps per loop body
-    constexpr int R = UPK * KU;                      // ring slots = units per loop body: static slot indices
     constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};   // smallest piece products first
-    char* ringb = smem + w * (R * 2048);
-    const int q_voff = (r * d + 4 * h) * 4;
-    const int v_voff = LM ? (r * d + 4 * h) * 4 : (4 * h * N + r) * 4;
-    const int G = 8 * nsl;                           // 16-channel steps of this wave
-    auto chan0 = [&](int g) { return ((g >> 3) * NW + w) * 128 + 16 * (g & 7); };
-    // DMA of unit (k-step g, position j) into its slot; beyond the last k-step the addresses fall outside the sample or
-    // on its next rows: harmless, the data is never used
-    auto dma_unit = [&](int g, const int j, const int slot) {
-      typedef __attribute__((address_space(3))) void* lds_ptr;
-      char* dst = ringb + slot * 2048;
-      const int k0 = chan0(g);
-      if (j == 0) {                                  // Q fragment
-        // (the +32 bytes of the second piece go into the scalar offset: an instruction offset would also move the
-        // LDS address)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_ptr)dst, 16, q_voff, k0 * 4, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_ptr)(dst + 1024), 16, q_voff, k0 * 4 + 32, 0, 0);
-      } else if constexpr (LM) {
-        const int so = (32 * (j - 1) * d + k0) * 4;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_ptr)dst, 16, v_voff, so, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_ptr)(dst + 1024), 16, v_voff, so + 32, 0, 0);
-      } else {
-        // channel-major: eight dword pieces (element i of the fragment = row k0 + 4h + (i&3) + 8(i>>2) of V [d][N])
-        const int so = (k0 * N + 32 * (j - 1)) * 4;  // columns >= N: finite junk, zeroed when C is finalised
+    if constexpr (LM) {
+      // Location-major operand stream, whole cache lines.  Element i of a lane's fragment <-> channel
+      // k0 + 4 h + (i & 3) + 8 (i >> 2), the same order for A and B.  A unit is 32 rows (tokens of Q, or the locations
+      // of one tile of V) x 32 channels = 32 x 128 B: four LDS-DMA instructions (buffer_load_dwordx4 ... lds) of 8 rows
+      // x 128 B each -- every instruction touches 8 whole lines (a lane per 16 bytes of a line); a fragment-shaped
+      // access (a lane per row) touches 32 lines for the same kilobyte and the stream ran at half the rate.
+      // The DMA writes LDS lane-linear, so the bank swizzle is applied on the global side: 16-byte position pos of
+      // row n holds channel chunk pos ^ (n & 7).  Read-back: 4 x ds_read_b128 per lane (chunks h, 2+h, 4+h, 6+h of
+      // the lane's row: the fragments of the unit's two 16-channel k-steps), 8 consecutive lanes = 8 rows at 8
+      // distinct positions.  Per-wave ring of 4 slots of 4 KB (the LDS is idle until the cross-wave reduction): one
+      // unit in the registers, one being read back, three in flight (12 KB per wave, counted vmcnt).
+      constexpr int UPK = NT + 1;                    // units per 32-channel step: the Q unit, then the NT tiles
+      constexpr int BODY = (UPK % 4 == 0) ? UPK : (UPK % 2 == 0) ? 2 * UPK : 4 * UPK;   // static slot indices
+      constexpr int KU = BODY / UPK;
+      char* ringb = smem + w * (4 * 4096);
+      const int dvoff = ((lane >> 3) * d) * 4 + (((lane & 7) ^ (lane >> 3)) << 4);
+      const int G = 4 * nsl;                         // 32-channel steps of this wave (a multiple of KU)
+      auto chan0 = [&](int g) { return ((g >> 2) * NW + w) * 128 + 32 * (g & 3); };
+      // beyond the last step the addresses fall outside the sample or on its next rows: harmless, never used
+      auto dma_unit = [&](int g, const int j, const int slot) {
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        if (COATTN_P1_NODMA) return;                 // developer switch: the compute side alone (stale LDS data)
+        char* dst = ringb + slot * 4096;
+        const int so = ((j == 0 ? 0 : 32 * (j - 1) * d) + chan0(g)) * 4;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_ptr)(dst + 256 * i), 4, v_voff,
-                                                   so + ((i & 3) + 8 * (i >> 2)) * N * 4, 0, 0);
-      }
-    };
-    constexpr int DPU = LM ? 2 : 8;                  // DMA instructions of a V unit (a Q unit: 2)
-    auto read_unit = [&](const int j, const int slot) -> f32x8 {
-      const char* src = ringb + slot * 2048;
-      if (LM || j == 0) {
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(src + lane * 16);
-        const f32x4 x1 = *reinterpret_cast<const f32x4*>(src + 1024 + lane * 16);
-        return f32x8{x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-      }
-      f32x8 x;
+        for (int i = 0; i < 4; ++i) {
+          if (j == 0)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_ptr)(dst + 1024 * i), 16, dvoff, so + 8 * i * d * 4, 0, 0);
+          else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_ptr)(dst + 1024 * i), 16, dvoff, so + 8 * i * d * 4, 0, 0);
+        }
+      };
+      const int rd_off = r * 128, rd_key = r & 7;
+      auto read_unit = [&](const int slot) -> f32x16 {
+        const char* src = ringb + slot * 4096 + rd_off;
+        f32x16 x;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) x[i] = *reinterpret_cast<const float*>(src + 256 * i + lane * 4);
-      return x;
-    };
-    // DMAs still allowed in flight when unit p of the body is read back: those of the R - 2 units issued after it
-    // (unit p+1 .. p+R-2; position 0 of a k-step is a Q unit)
-    auto pending_after = [&](const int p) {
-      int n = 0;
-      for (int q = p + 1; q <= p + R - 2; ++q) n += (q % UPK == 0) ? 2 : DPU;
-      return n;
-    };
-    f32x8 qraw, cur, nxt;
-    bf16x8 qa[3];
-    u32x4 vh, vm, vl;                                // split pieces of the current bf16 unit's V fragment
-    auto split_pair_v = [&](const f32x8& x, const int pr) {
-      unsigned hh, mm, ll;
-      split3_pair(x[2 * pr], x[2 * pr + 1], hh, mm, ll);
-      vh[pr] = hh; vm[pr] = mm; vl[pr] = ll;
-    };
-    // prologue: units 0 .. R-2 in flight, unit 0 (the first Q fragment) read back
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(src + (((2 * c + h) ^ rd_key) << 4));
+          x[4 * c] = v[0]; x[4 * c + 1] = v[1]; x[4 * c + 2] = v[2]; x[4 * c + 3] = v[3];
+        }
+        return x;
+      };
+      f32x16 nxt;
+      bf16x8 qa[2][3];
+      u32x4 vh[2], vm[2], vl[2];                     // split pieces of the current V unit (two k-steps)
 #pragma unroll
-    for (int p = 0; p < R - 1; ++p) dma_unit(p / UPK, p % UPK, p);
-    vmcnt_wait(pending_after(0));                    // unit 0 has landed; units 1 .. R-2 may fly
-    nxt = read_unit(0, 0);
+      for (int p = 0; p < 4; ++p) dma_unit(p / UPK, p % UPK, p);
+      vmcnt_wait(12);                                // unit 0 (the first Q unit) has landed; units 1 .. 3 may fly
+      nxt = read_unit(0);
 #pragma unroll 1
-    for (int g0 = 0; g0 < G; g0 += KU) {
+      for (int g0 = 0; g0 < G; g0 += KU) {
 #pragma unroll
-      for (int p = 0; p < R; ++p) {                  // unit p of the body: k-step g0 + p / UPK, position p % UPK
-        const int j = p % UPK, pn = (p + 1) % R, jn = (p + 1) % UPK;
-        cur = nxt;
-        // refill the slot of the previous unit (its read-back has completed), then read back the next unit
-        dma_unit(g0 + (p + R - 1) / UPK, (p + R - 1) % UPK, (p + R - 1) % R);
-        vmcnt_wait(pending_after(pn));
-        nxt = read_unit(jn, pn);
-        __builtin_amdgcn_sched_barrier(0);
-        const bool next_bf = jn >= 1 && (jn - 1) < NB;    // the next unit is a V tile on the bf16 path: split it here
-        if (j == 0) {                                // Q fragment of this k-step: split it, and the first tile's fragment
-          qraw = cur;
-          if (NB > 0) split3(qraw, qa);
-          if (next_bf) {
-#pragma unroll
-            for (int pr = 0; pr < 4; ++pr) split_pair_v(nxt, pr);
+        for (int p = 0; p < BODY; ++p) {             // unit p of the body: step g0 + p / UPK, position p % UPK
+          const int j = p % UPK, jn = (p + 1) % UPK;
+          const f32x16 cur = nxt;
+          // the read-back of unit p is complete: refill its slot with unit p + 4, then read back unit p + 1
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          dma_unit(g0 + (p + 4) / UPK, (p + 4) % UPK, p % 4);
+          vmcnt_wait(12);                            // units p + 2 .. p + 4 may fly
+          nxt = read_unit((p + 1) % 4);
+          __builtin_amdgcn_sched_barrier(0);
+          if (COATTN_P1_NOMATH) {                    // developer switch: the operand stream alone
+            acc[0][p % 16] += nxt[0] + nxt[15];
+            continue;
           }
-        } else if (j - 1 < NB) {
-          const bf16x8 b3[3] = {__builtin_bit_cast(bf16x8, vh), __builtin_bit_cast(bf16x8, vm), __builtin_bit_cast(bf16x8, vl)};
-          u32x4 nh, nm, nl;
+          if (j == 0) {                              // Q unit: split it, and the first tile's fragment
+            split3(f32x8{cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6], cur[7]}, qa[0]);
+            split3(f32x8{cur[8], cur[9], cur[10], cur[11], cur[12], cur[13], cur[14], cur[15]}, qa[1]);
 #pragma unroll
-          for (int m = 0; m < 6; ++m) {
-            acc[j - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[PA[m]], b3[PB[m]], acc[j - 1], 0, 0, 0);
-            if (next_bf && m < 4) {
+            for (int m = 0; m < 8; ++m) {
               unsigned hh, mm, ll;
               split3_pair(nxt[2 * m], nxt[2 * m + 1], hh, mm, ll);
-              nh[m] = hh; nm[m] = mm; nl[m] = ll;
+              vh[m >> 2][m & 3] = hh; vm[m >> 2][m & 3] = mm; vl[m >> 2][m & 3] = ll;
             }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          if (next_bf) { vh = nh; vm = nm; vl = nl; }
-        } else {
+          } else {
+            const bf16x8 b3[2][3] = {{__builtin_bit_cast(bf16x8, vh[0]), __builtin_bit_cast(bf16x8, vm[0]), __builtin_bit_cast(bf16x8, vl[0])},
+                                     {__builtin_bit_cast(bf16x8, vh[1]), __builtin_bit_cast(bf16x8, vm[1]), __builtin_bit_cast(bf16x8, vl[1])}};
+            u32x4 nh[2], nm[2], nl[2];
 #pragma unroll
-          for (int m = 0; m < 8; ++m) {
-            acc[j - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qraw[m], cur[m], acc[j - 1], 0, 0, 0);
-            if (next_bf && m < 4) split_pair_v(nxt, m);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int m = 0; m < 12; ++m) {
+              const int ks = m / 6, i = m % 6;
+              acc[j - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks][PA[i]], b3[ks][PB[i]], acc[j - 1], 0, 0, 0);
+              if (jn != 0 && m >= 2 && m < 10) {     // the next unit is a V tile: split it under these MFMAs
+                const int pr = m - 2;
+                unsigned hh, mm, ll;
+                split3_pair(nxt[2 * pr], nxt[2 * pr + 1], hh, mm, ll);
+                nh[pr >> 2][pr & 3] = hh; nm[pr >> 2][pr & 3] = mm; nl[pr >> 2][pr & 3] = ll;
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            if (jn != 0) {
+#pragma unroll
+              for (int ks = 0; ks < 2; ++ks) { vh[ks] = nh[ks]; vm[ks] = nm[ks]; vl[ks] = nl[ks]; }
+            }
+          }
+        }
+      }
+    } else {
+      // Operand stream.  Element i of a lane's fragment <-> channel k0 + 4 h + (i & 3) + 8 (i >> 2): the same order
+      // for A and B, chosen so that the two 16-byte loads of a location-major row are contiguous across the lane halves.
+      // The stream is latency-bound (a wave alone needs ~8 KB in flight to cover HBM latency at its share of the
+      // bandwidth, twice that under load), and registers cannot hold that: the fragments go HBM -> LDS by LDS-DMA
+      // (buffer_load ... lds, no VGPR destination) into a per-wave ring of R slots of 2 KB -- the LDS is idle until the
+      // cross-wave reduction -- and are read back (ds_read_b128 x 2 per lane, lane-linear, conflict-free) one unit
+      // before their MFMAs.  Units of a k-step (16 channels): the Q fragment, then the NT location tiles.
+      // The first NB tiles of a k-step run on the bf16 MFMA with the exact 3-way split (6 MFMAs of 32 cycles + 44 VALU
+      // per unit), the others on the f32 MFMA straight from the registers (8 MFMAs of 64 cycles, no VALU; lane (., h)
+      // of a 32x32x2 MFMA supplies k = h: element i pairs channels (k0 + (i&3) + 8(i>>2), the same + 4)).
+      constexpr int NB = COATTN_P1_NB >= 0 ? (COATTN_P1_NB < NT ? COATTN_P1_NB : NT) : NT;
+      constexpr int UPK = NT + 1;                      // units per k-step
+      constexpr int KU = (UPK >= 6) ? 1 : 2;           // k-steps per loop body
+      constexpr int R = UPK * KU;                      // ring slots = units per loop body: static slot indices
+      char* ringb = smem + w * (R * 2048);
+      const int q_voff = (r * d + 4 * h) * 4;
+      const int v_voff = LM ? (r * d + 4 * h) * 4 : (4 * h * N + r) * 4;
+      const int G = 8 * nsl;                           // 16-channel steps of this wave
+      auto chan0 = [&](int g) { return ((g >> 3) * NW + w) * 128 + 16 * (g & 7); };
+      // DMA of unit (k-step g, position j) into its slot; beyond the last k-step the addresses fall outside the sample or
+      // on its next rows: harmless, the data is never used
+      auto dma_unit = [&](int g, const int j, const int slot) {
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        char* dst = ringb + slot * 2048;
+        const int k0 = chan0(g);
+        if (COATTN_P1_NODMA) return;                   // developer switch: the compute side alone (stale LDS data)
+        if (j == 0) {                                  // Q fragment
+          // (the +32 bytes of the second piece go into the scalar offset: an instruction offset would also move the
+          // LDS address)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_ptr)dst, 16, q_voff, k0 * 4, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_ptr)(dst + 1024), 16, q_voff, k0 * 4 + 32, 0, 0);
+        } else if constexpr (LM) {
+          const int so = (32 * (j - 1) * d + k0) * 4;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_ptr)dst, 16, v_voff, so, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_ptr)(dst + 1024), 16, v_voff, so + 32, 0, 0);
+        } else {
+          // channel-major: eight dword pieces (element i of the fragment = row k0 + 4h + (i&3) + 8(i>>2) of V [d][N])
+          const int so = (k0 * N + 32 * (j - 1)) * 4;  // columns >= N: finite junk, zeroed when C is finalised
+  #pragma unroll
+          for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_ptr)(dst + 256 * i), 4, v_voff,
+                                                     so + ((i & 3) + 8 * (i >> 2)) * N * 4, 0, 0);
+        }
+      };
+      constexpr int DPU = LM ? 2 : 8;                  // DMA instructions of a V unit (a Q unit: 2)
+      auto read_unit = [&](const int j, const int slot) -> f32x8 {
+        const char* src = ringb + slot * 2048;
+        if (LM || j == 0) {
+          const f32x4 x0 = *reinterpret_cast<const f32x4*>(src + lane * 16);
+          const f32x4 x1 = *reinterpret_cast<const f32x4*>(src + 1024 + lane * 16);
+          return f32x8{x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        }
+        f32x8 x;
+  #pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = *reinterpret_cast<const float*>(src + 256 * i + lane * 4);
+        return x;
+      };
+      // DMAs still allowed in flight when unit p of the body is read back: those of the R - 2 units issued after it
+      // (unit p+1 .. p+R-2; position 0 of a k-step is a Q unit)
+      auto pending_after = [&](const int p) {
+        int n = 0;
+        for (int q = p + 1; q <= p + R - 2; ++q) n += (q % UPK == 0) ? 2 : DPU;
+        return n;
+      };
+      f32x8 qraw, cur, nxt;
+      bf16x8 qa[3];
+      u32x4 vh, vm, vl;                                // split pieces of the current bf16 unit's V fragment
+      auto split_pair_v = [&](const f32x8& x, const int pr) {
+        unsigned hh, mm, ll;
+        split3_pair(x[2 * pr], x[2 * pr + 1], hh, mm, ll);
+        vh[pr] = hh; vm[pr] = mm; vl[pr] = ll;
+      };
+      // prologue: units 0 .. R-2 in flight, unit 0 (the first Q fragment) read back
+  #pragma unroll
+      for (int p = 0; p < R - 1; ++p) dma_unit(p / UPK, p % UPK, p);
+      vmcnt_wait(pending_after(0));                    // unit 0 has landed; units 1 .. R-2 may fly
+      nxt = read_unit(0, 0);
+  #pragma unroll 1
+      for (int g0 = 0; g0 < G; g0 += KU) {
+  #pragma unroll
+        for (int p = 0; p < R; ++p) {                  // unit p of the body: k-step g0 + p / UPK, position p % UPK
+          const int j = p % UPK, pn = (p + 1) % R, jn = (p + 1) % UPK;
+          cur = nxt;
+          // refill the slot of the previous unit (its read-back has completed), then read back the next unit
+          dma_unit(g0 + (p + R - 1) / UPK, (p + R - 1) % UPK, (p + R - 1) % R);
+          vmcnt_wait(pending_after(pn));
+          nxt = read_unit(jn, pn);
+          __builtin_amdgcn_sched_barrier(0);
+          if (COATTN_P1_NOMATH) {                      // developer switch: the operand stream alone
+            acc[0][p % 16] += nxt[0] + nxt[7];
+            continue;
+          }
+          const bool next_bf = jn >= 1 && (jn - 1) < NB;    // the next unit is a V tile on the bf16 path: split it here
+          if (j == 0) {                                // Q fragment of this k-step: split it, and the first tile's fragment
+            qraw = cur;
+            if (NB > 0) split3(qraw, qa);
+            if (next_bf) {
+  #pragma unroll
+              for (int pr = 0; pr < 4; ++pr) split_pair_v(nxt, pr);
+            }
+          } else if (j - 1 < NB) {
+            const bf16x8 b3[3] = {__builtin_bit_cast(bf16x8, vh), __builtin_bit_cast(bf16x8, vm), __builtin_bit_cast(bf16x8, vl)};
+            u32x4 nh, nm, nl;
+  #pragma unroll
+            for (int m = 0; m < 6; ++m) {
+              acc[j - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[PA[m]], b3[PB[m]], acc[j - 1], 0, 0, 0);
+              if (next_bf && m < 4) {
+                unsigned hh, mm, ll;
+                split3_pair(nxt[2 * m], nxt[2 * m + 1], hh, mm, ll);
+                nh[m] = hh; nm[m] = mm; nl[m] = ll;
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            if (next_bf) { vh = nh; vm = nm; vl = nl; }
+          } else {
+  #pragma unroll
+            for (int m = 0; m < 8; ++m) {
+              acc[j - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qraw[m], cur[m], acc[j - 1], 0, 0, 0);
+              if (next_bf && m < 4) split_pair_v(nxt, m);
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
         }
       }
@@ -338,16 +447,27 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
     }
   }
   lane = lane_id(); tid = w * 64 + lane; r = lane & 31; h = lane >> 5;
-  load_pq_raw(w * 128, pq_raw);                      // the first pass' P_q operands fly under the tanh / split pass
+  load_pq_frag(w * 128, pqf);                        // the first pass' P_q fragments fly under the tanh / split pass
   bf16x8 pqB[2][2][3];
   // C = tanh(sum) by all threads: a thread takes a token pair (2 tp, 2 tp + 1) of one location; rows >= T are
   // tanh(0) = 0 (their Q rows read as 0).  The three bf16 pieces go to the image [piece][n][t] (4-byte writes).
+  CA_STAMP(6);
   {
     float* Cg = a.C + pair * (size_t)T * N;
-    for (int e = tid; e < 16 * NPAD; e += NW * 64) {
-      const int tp = e / NPAD, n = e - tp * NPAD;
-      float c0 = tanh_fast(slot0[(2 * tp) * SLD + n]);
-      float c1 = tanh_fast(slot0[(2 * tp + 1) * SLD + n]);
+    constexpr int PER = 16 * NPAD / (NW * 64);       // token pairs x locations per thread (exact: NPAD = 32 NT)
+    static_assert(16 * NPAD % (NW * 64) == 0, "the tanh pass covers the slot in whole sweeps");
+    float s0[PER], s1[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {                  // all the slot reads first: one LDS latency, not PER of them
+      const int e = tid + k * NW * 64, tp = e / NPAD, n = e - tp * NPAD;
+      s0[k] = slot0[(2 * tp) * SLD + n];
+      s1[k] = slot0[(2 * tp + 1) * SLD + n];
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int e = tid + k * NW * 64, tp = e / NPAD, n = e - tp * NPAD;
+      float c0 = tanh_fast(s0[k]);
+      float c1 = tanh_fast(s1[k]);
       const bool in = n < N;
       c0 = in ? c0 : 0.f;                            // padded columns of a channel-major V carry junk
       c1 = in ? c1 : 0.f;
@@ -361,7 +481,11 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
       *reinterpret_cast<unsigned*>(Cimg + 2 * PIECE + off) = ll;
     }
   }
-  __syncthreads();
+  // the image is complete once every wave's LDS writes have landed: a barrier on the LDS counter alone (a
+  // __syncthreads() would also drain the C stores and the P_q loads still in flight)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
   CA_STAMP(2);
 
   // ------------------------------------------------------------------ phase 2: H_v scores, H_q
@@ -373,21 +497,42 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
   const int tr_off0 = (4 * h + tq) * 32 + 8 * ((2 * g1 + (tp_ >> 1)) ^ h) + 4 * (tp_ & 1);
   const int tr_off1 = (4 * h + 8 + tq) * 32 + 8 * ((2 * g1 + (tp_ >> 1)) ^ (h + 2)) + 4 * (tp_ & 1);
   const int rk = (r >> 2) & 3;                       // swizzle key of this lane's own image row (row reads)
+  // A pass' P_q fragments (accumulator-shaped) become (a) the initial value of the H_q accumulators: H_q = P_q + C P_v,
+  // and (b) the split B operands of H_v = P_v + C^T P_q, whose k index runs t = 16 ks + 8 h + i in lane half h: the
+  // accumulator rows of a half are t = 16 ks + 4 h + {0..3, 8..11}, so registers 8 ks + k of the upper lane half
+  // trade places with registers 8 ks + 4 + k of the lower half (v_permlane32_swap).
+  f32x16 accq[2];
+  auto take_pq = [&](f32x16& f0, f32x16& f1) {
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < 2; ++ct) {
+      f32x16& f = ct ? f1 : f0;
+      accq[ct] = f;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) split3(pq_raw[ct][ks], pqB[ct][ks]);
+      for (int ks = 0; ks < 2; ++ks) {
+        f32x8 x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          // (inline asm, not __builtin_amdgcn_permlane32_swap: with both inputs live after the swap hipcc (ROCm 7.2)
+          // copied ONE of them into both operands -- wrong B operands, caught by the parity tests; the no-ops cover
+          // the VALU-write -> permlane-swap wait state the compiler would have inserted)
+          float lo = f[8 * ks + k], hi = f[8 * ks + 4 + k];
+          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+          x[k] = lo;
+          x[4 + k] = hi;
+        }
+        split3(x, pqB[ct][ks]);
+      }
+    }
+  };
+  take_pq(pqf[0], pqf[1]);
   {
 #pragma unroll 1
     for (int pi = 0; pi < 2 * nsl; ++pi) {           // passes: 64 channels each, two per 128-channel slice
       const int sl = pi >> 1, ps = pi & 1;
       const int c0 = (sl * NW + w) * 128 + 64 * ps;
       const float wvr[2] = {a.wv[c0 + r], a.wv[c0 + 32 + r]};
-      f32x16 accq[2];
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int g = 0; g < 16; ++g) accq[ct][g] = 0.f;
+      // the next pass' channels (beyond the last pass: offsets >= d, the values are never used)
+      const int c0n = ((((pi + 1) >> 1) * NW + w) * 128 + 64 * ((pi + 1) & 1));
       // Unit pipeline over u = 2 nt + ct (a 32-location x 32-channel fragment of P_v, 16 VGPRs): while the MFMAs of
       // unit u run (H_q += C . P_v with the raw fragment as B operand, then H_v = P_v + C^T P_q accumulated onto
       // it), the VALU finishes unit u-1 (tanh, scores) and splits the operands of the following MFMAs; loads run
@@ -397,10 +542,14 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
       bf16x8 pb0[3];                                 // split B operand of the next unit's first k-step
       const int U = 2 * ntiles;
       // pv[g] = P_v[32 nt + crow(g, h)][c0 + 32 ct + r]: 128 contiguous bytes per half wave and load
-      auto load_unit = [&](int u, f32x16& dst) {     // beyond the last tile: zeros through the buffer rule, no traffic
+      // The two units past the last tile are the next pass' P_q fragments (same lane pattern: rows crow(g, h) of
+      // P_q, channels c0n + 32 (u - U) + r): they fly under the last units and the epilogue.
+      auto load_unit = [&](int u, f32x16& dst) {
+        const bool tail = u >= U;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(tail ? Pqp : Pvp, (unsigned)(tail ? T : N) * d * 4u);
+        const int so = tail ? (c0n + 32 * (u - U)) * 4 : (32 * (u >> 1) * d + c0 + 32 * (u & 1)) * 4;
 #pragma unroll
-        for (int g = 0; g < 16; ++g)
-          dst[g] = buf_load1(rs_pv, (crow(g, h) * d + r) * 4, (32 * (u >> 1) * d + c0 + 32 * (u & 1)) * 4);
+        for (int g = 0; g < 16; ++g) dst[g] = buf_load1(rs, (crow(g, h) * d + r) * 4, so);
       };
       auto split_half = [&](const f32x16& pv, const int s2, bf16x8 (&pb)[3]) {
         const f32x8 x = f32x8{pv[8 * s2], pv[8 * s2 + 1], pv[8 * s2 + 2], pv[8 * s2 + 3],
@@ -530,10 +679,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
       // the last unit's scores
       store_scores(U - 1, (U & 2) ? finish_last(ring[1]) : finish_last(ring[3]));
       CA_STAMP(9 + 3 * pi);
-      // the next pass' P_q operands fly under the epilogue (beyond the last pass: channel offsets >= d, the
-      // values are never used)
-      load_pq_raw((((pi + 1) >> 1) * NW + w) * 128 + 64 * ((pi + 1) & 1), pq_raw);
-      // H_q epilogue: hq = tanh(P_q + acc); saved for backward; s_q partials.  Branch-free: rows t >= T fall
+      // H_q epilogue: hq = tanh(acc) (the accumulators started from P_q); saved for backward; s_q partials.  Branch-free: rows t >= T fall
       // outside the per-sample buffers (loads give 0, stores are dropped)
       {
         const __amdgpu_buffer_rsrc_t rs_hq = make_rsrc(a.Hq + pair * (size_t)T * d, (unsigned)T * d * 4u);
@@ -545,13 +691,10 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
           const float wq = a.wq[c0 + 32 * ct + r];
-          float pqv[16];
-#pragma unroll
-          for (int g = 0; g < 16; ++g) pqv[g] = buf_load1(rs_pq, eoff(g, ct), c0 * 4);
           float mine = 0.f;                          // lane (j, .) of a 16-lane row keeps the sum of register g = j
 #pragma unroll
           for (int g = 0; g < 16; ++g) {
-            const float hq = tanh_fast(accq[ct][g] + pqv[g]);
+            const float hq = tanh_fast(accq[ct][g]);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hq), rs_hq, eoff(g, ct), c0 * 4, 0);
             // s_q partial of token crow(g, h) over this lane row's 16 channels
             const float t = row16_sum(hq * wq);
@@ -562,10 +705,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
           *dst = mine;
         }
       }
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) split3(pq_raw[ct][ks], pqB[ct][ks]);
+      if (U & 2) take_pq(ring[2], ring[3]); else take_pq(ring[0], ring[1]);
       CA_STAMP(10 + 3 * pi);
     }
   }
@@ -675,7 +815,7 @@ template <int NT, int NW, bool LM>
 int launch_fwd32(const FwdArgs& a, hipStream_t s) {
   constexpr int NPAD = 32 * NT;
   constexpr int RING_SLOTS = (NT + 1) * ((NT + 1 >= 6) ? 1 : 2);
-  const size_t lds_p2 = (size_t)32 * (NPAD + 4) * 4 + (size_t)3 * NPAD * 32 * 2, lds_p1 = (size_t)NW * RING_SLOTS * 2048;
+  const size_t lds_p2 = (size_t)32 * (NPAD + 4) * 4 + (size_t)3 * NPAD * 32 * 2, lds_p1 = LM ? (size_t)NW * 4 * 4096 : (size_t)NW * RING_SLOTS * 2048;
   const size_t lds = lds_p2 > lds_p1 ? lds_p2 : lds_p1;
   static DeviceOnce once;                            // the attribute is per device
   CA_TRY(once.run([&] {

@@ -116,14 +116,22 @@ __device__ __forceinline__ void vmcnt_wait(int n) {
   }
 }
 
+// Workgroup barrier on the LDS counter alone: the LDS traffic of every wave has landed, global loads and stores stay
+// in flight (a __syncthreads() drains them too).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // C/D row of accumulator register g in lane half h (32x32 MFMA)
 __device__ __forceinline__ constexpr int crow(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
 
 template <int NT, int NW, bool LM>
 __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs a) {
   constexpr int NPAD = 32 * NT;
-  constexpr int SLD = NPAD + 4;                      // row stride of the f32 reduction slots [t][n]
-  constexpr int SLOT_FLOATS = 32 * SLD;
+  constexpr int SLD = 36;                            // row stride of the f32 reduction slots [n][t = 32]: 16-byte accesses
+  constexpr int SLOT_FLOATS = NPAD * SLD;            //   of 8 consecutive rows cover the 32 banks once
   constexpr int PIECE = NPAD * 32;                   // bf16 elements of one piece of the C image [n][t = 32]
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* slot0 = reinterpret_cast<float*>(smem);
@@ -415,29 +423,33 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
     vmcnt_wait(0);                                   // the rings' memory becomes the reduction slots:
     __syncthreads();                                 // every wave is done with its ring
     CA_STAMP(1);
-    // cross-wave sum in a fixed tree order through LDS; C/D layout: col = r (location), row = crow(g, h) (token)
+    // cross-wave sum in a fixed order through LDS.  C/D layout: col = r (location), rows crow(g, h) (tokens): registers
+    // 4 gg .. 4 gg + 3 are four consecutive tokens of one location -> one 16-byte access of the slot [n][t].
     auto put = [&](float* slot) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int g = 0; g < 16; ++g) slot[crow(g, h) * SLD + 32 * nt + r] = acc[nt][g];
+        for (int gg = 0; gg < 4; ++gg)
+          *reinterpret_cast<f32x4*>(&slot[(32 * nt + r) * SLD + 8 * gg + 4 * h]) =
+              f32x4{acc[nt][4 * gg], acc[nt][4 * gg + 1], acc[nt][4 * gg + 2], acc[nt][4 * gg + 3]};
     };
     auto add = [&](const float* slot) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int g = 0; g < 16; ++g) acc[nt][g] += slot[crow(g, h) * SLD + 32 * nt + r];
+        for (int gg = 0; gg < 4; ++gg) {
+          const f32x4 x = *reinterpret_cast<const f32x4*>(&slot[(32 * nt + r) * SLD + 8 * gg + 4 * h]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[nt][4 * gg + i] += x[i];
+        }
     };
+    // (w0 + w1) -> slot 0, (w2 + w3) -> slot 1; the image pass adds the two
     if constexpr (NW == 4) {
       if (w == 1) put(slot0);
       if (w == 3) put(slot1);
       __syncthreads();
-      if (w == 0) add(slot0);
-      if (w == 2) add(slot1);
-      __syncthreads();
-      if (w == 2) put(slot0);
-      __syncthreads();
-      if (w == 0) { add(slot0); put(slot0); }        // ((w0 + w1) + (w2 + w3))
+      if (w == 0) { add(slot0); put(slot0); }
+      if (w == 2) { add(slot1); put(slot1); }
       __syncthreads();
     } else {
       if (w == 1) put(slot0);
@@ -449,43 +461,45 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
   lane = lane_id(); tid = w * 64 + lane; r = lane & 31; h = lane >> 5;
   load_pq_frag(w * 128, pqf);                        // the first pass' P_q fragments fly under the tanh / split pass
   bf16x8 pqB[2][2][3];
-  // C = tanh(sum) by all threads: a thread takes a token pair (2 tp, 2 tp + 1) of one location; rows >= T are
-  // tanh(0) = 0 (their Q rows read as 0).  The three bf16 pieces go to the image [piece][n][t] (4-byte writes).
   CA_STAMP(6);
+  // C = tanh(sum) by all threads: a thread takes four consecutive tokens 4 tq .. 4 tq + 3 of one location (one 16-byte
+  // slot read per partial sum); rows >= T are tanh(0) = 0 (their Q rows read as 0).  The three bf16 pieces go to the
+  // image [piece][n][t] (8-byte writes).  All the slot reads come first: slot 1 lies inside the image region.
   {
     float* Cg = a.C + pair * (size_t)T * N;
-    constexpr int PER = 16 * NPAD / (NW * 64);       // token pairs x locations per thread (exact: NPAD = 32 NT)
-    static_assert(16 * NPAD % (NW * 64) == 0, "the tanh pass covers the slot in whole sweeps");
-    float s0[PER], s1[PER];
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {                  // all the slot reads first: one LDS latency, not PER of them
-      const int e = tid + k * NW * 64, tp = e / NPAD, n = e - tp * NPAD;
-      s0[k] = slot0[(2 * tp) * SLD + n];
-      s1[k] = slot0[(2 * tp + 1) * SLD + n];
-    }
+    constexpr int PER = 8 * NPAD / (NW * 64);        // (location, token quad) items per thread (exact: NPAD = 32 NT)
+    static_assert(8 * NPAD % (NW * 64) == 0, "the image pass covers the slot in whole sweeps");
+    f32x4 sum[PER];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-      const int e = tid + k * NW * 64, tp = e / NPAD, n = e - tp * NPAD;
-      float c0 = tanh_fast(s0[k]);
-      float c1 = tanh_fast(s1[k]);
-      const bool in = n < N;
-      c0 = in ? c0 : 0.f;                            // padded columns of a channel-major V carry junk
-      c1 = in ? c1 : 0.f;
-      if (in && 2 * tp < T) Cg[(size_t)(2 * tp) * N + n] = c0;
-      if (in && 2 * tp + 1 < T) Cg[(size_t)(2 * tp + 1) * N + n] = c1;
-      unsigned hh, mm, ll;
-      split3_pair(c0, c1, hh, mm, ll);
-      const int off = n * 32 + 8 * ((tp >> 2) ^ ((n >> 2) & 3)) + 2 * (tp & 3);
-      *reinterpret_cast<unsigned*>(Cimg + off) = hh;
-      *reinterpret_cast<unsigned*>(Cimg + PIECE + off) = mm;
-      *reinterpret_cast<unsigned*>(Cimg + 2 * PIECE + off) = ll;
+      const int e = tid + k * NW * 64, tq = e / NPAD, n = e - tq * NPAD;
+      sum[k] = *reinterpret_cast<const f32x4*>(&slot0[n * SLD + 4 * tq]);
+      if constexpr (NW == 4) sum[k] += *reinterpret_cast<const f32x4*>(&slot1[n * SLD + 4 * tq]);
+    }
+    if constexpr (NW == 4) lds_barrier();            // every read of slot 1 is done: the image may overwrite it
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int e = tid + k * NW * 64, tq = e / NPAD, n = e - tq * NPAD;
+      const bool in = n < N;                         // padded columns of a channel-major V carry junk
+      float c[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        c[i] = in ? tanh_fast(sum[k][i]) : 0.f;
+        if (in && 4 * tq + i < T) Cg[(size_t)(4 * tq + i) * N + n] = c[i];
+      }
+      unsigned hh[2], mm[2], ll[2];
+      split3_pair(c[0], c[1], hh[0], mm[0], ll[0]);
+      split3_pair(c[2], c[3], hh[1], mm[1], ll[1]);
+      const int off = n * 32 + 8 * ((tq >> 1) ^ ((n >> 2) & 3)) + 4 * (tq & 1);
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      *reinterpret_cast<u32x2*>(Cimg + off) = u32x2{hh[0], hh[1]};
+      *reinterpret_cast<u32x2*>(Cimg + PIECE + off) = u32x2{mm[0], mm[1]};
+      *reinterpret_cast<u32x2*>(Cimg + 2 * PIECE + off) = u32x2{ll[0], ll[1]};
     }
   }
   // the image is complete once every wave's LDS writes have landed: a barrier on the LDS counter alone (a
   // __syncthreads() would also drain the C stores and the P_q loads still in flight)
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
+  lds_barrier();
   CA_STAMP(2);
 
   // ------------------------------------------------------------------ phase 2: H_v scores, H_q
@@ -530,7 +544,10 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
     for (int pi = 0; pi < 2 * nsl; ++pi) {           // passes: 64 channels each, two per 128-channel slice
       const int sl = pi >> 1, ps = pi & 1;
       const int c0 = (sl * NW + w) * 128 + 64 * ps;
-      const float wvr[2] = {a.wv[c0 + r], a.wv[c0 + 32 + r]};
+      // Scores without the tanh's last step: tanh(x) = 1 - 2 / (1 + e^{2x}), so sum_k w_k tanh(x_k) = sum_k w_k +
+      // sum_k (-2 w_k) / (1 + e^{2 x_k}); the first sum is the same for every location and the softmax over the
+      // locations is invariant to it -- it is dropped, and one VALU operation per element with it.
+      const float wvr[2] = {-2.0f * a.wv[c0 + r], -2.0f * a.wv[c0 + 32 + r]};
       // the next pass' channels (beyond the last pass: offsets >= d, the values are never used)
       const int c0n = ((((pi + 1) >> 1) * NW + w) * 128 + 64 * ((pi + 1) & 1));
       // Unit pipeline over u = 2 nt + ct (a 32-location x 32-channel fragment of P_v, 16 VGPRs): while the MFMAs of
@@ -586,7 +603,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
         const short* img = Cimg + 32 * (u >> 1) * 32;
         bf16x8 cq0[3], cq1[3], ca0[3], ca1[3];       // A operands, read one MFMA group ahead of their use
         u32x4 h1, m1, l1, h0, m0, l0;                // pieces of pb1 (this unit, k-step 1) / the next unit's pb0
-        float tcur = 0.f, mine = 0.f;
+        float mine = 0.f, y[8], z[4], w2[2];
         read_cq(img, 0, cq0);
 #pragma unroll
         for (int m = 0; m < 24; ++m) {
@@ -610,24 +627,20 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
             split3_pair(cur[8 + 2 * m], cur[8 + 2 * m + 1], hh, mm, ll);
             h1[m] = hh; m1[m] = mm; l1[m] = ll;
           }
-          if (m >= 4 && m < 20) {                    // register g = m - 4 of unit u-1: tanh and its score term
+          if (m >= 4 && m < 20) {                    // register g = m - 4 of unit u-1: its score term
             const int g = m - 4;
-            if (ct == 1) {
-              svp[g] = tanh_fast(prev[g]) * wvr[0];                              // u-1 was a first channel half
-              asm volatile("" : "+v"(svp[g]));       // computed HERE (machine sinking would move it to its use)
-            } else {                                                             // second half: add the first, and
-              if (g > 0) {                                                       // row-sum the previous register's term
-                const float t = row16_sum(tcur);
-                mine = ((lane & 15) == g - 1) ? t : mine;
-              }
-              tcur = fmaf(tanh_fast(prev[g]), wvr[1], svp[g]);
-            }
+            if (ct == 1) svp[g] = sig2_fast(prev[g]) * wvr[0];                    // u-1 was a first channel half
+            else svp[g] = fmaf(sig2_fast(prev[g]), wvr[1], svp[g]);              // second half: add the first
+            asm volatile("" : "+v"(svp[g]));         // computed HERE (machine sinking would move it to its use)
+          }
+          if (ct == 0) {                             // the tile's 16 score registers: transposing sum over the row
+            if (m >= 13 && m <= 20) y[m - 13] = bfly_a(svp[m - 13], svp[m - 5]);
+            if (m == 20) z[0] = bfly_b(y[0], y[4]);
+            if (m == 21) { z[1] = bfly_b(y[1], y[5]); z[2] = bfly_b(y[2], y[6]); }
+            if (m == 22) { z[3] = bfly_b(y[3], y[7]); w2[0] = bfly_c(z[0], z[2], lane); }
+            if (m == 23) { w2[1] = bfly_c(z[1], z[3], lane); mine = bfly_d(w2[0], w2[1], lane); }
           }
           if (m >= 20) {                             // split pair m - 20 of the next unit's first k-step
-            if (m == 20 && ct == 0) {
-              const float t = row16_sum(tcur);
-              mine = ((lane & 15) == 15) ? t : mine;
-            }
             unsigned hh, mm, ll;
             split3_pair(next[2 * (m - 20)], next[2 * (m - 20) + 1], hh, mm, ll);
             h0[m - 20] = hh; m0[m - 20] = mm; l0[m - 20] = ll;
@@ -641,13 +654,10 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
       };
       // scores of the last unit (a second channel half), outside the pipeline
       auto finish_last = [&](const f32x16& pv) -> float {
-        float mine = 0.f;
+        float x[16];
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          const float t = row16_sum(fmaf(tanh_fast(pv[g]), wvr[1], svp[g]));
-          mine = ((lane & 15) == g) ? t : mine;
-        }
-        return mine;
+        for (int g = 0; g < 16; ++g) x[g] = fmaf(sig2_fast(pv[g]), wvr[1], svp[g]);
+        return row16_sum16(x, lane);
       };
       CA_STAMP(8 + 3 * pi);
       load_unit(0, ring[0]);
@@ -688,22 +698,22 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
         int hrow = (4 * h * d + r) * 4;
         asm volatile("" : "+v"(hrow));
         auto eoff = [&](const int g, const int ct) { return hrow + (((g & 3) + 8 * (g >> 2)) * d + 32 * ct) * 4; };
+        float part[16];                              // s_q terms of token crow(g, h) over this lane's two channels
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
           const float wq = a.wq[c0 + 32 * ct + r];
-          float mine = 0.f;                          // lane (j, .) of a 16-lane row keeps the sum of register g = j
 #pragma unroll
           for (int g = 0; g < 16; ++g) {
             const float hq = tanh_fast(accq[ct][g]);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hq), rs_hq, eoff(g, ct), c0 * 4, 0);
-            // s_q partial of token crow(g, h) over this lane row's 16 channels
-            const float t = row16_sum(hq * wq);
-            mine = ((lane & 15) == g) ? t : mine;
+            part[g] = ct ? fmaf(hq, wq, part[g]) : hq * wq;
           }
-          float* dst = &sqpart[(w * 2 + g1) * 32 + crow(lane & 15, h)];
-          if (pi > 0 || ct > 0) mine += *dst;        // summed into the wave's slot in a fixed order
-          *dst = mine;
         }
+        // lane (j, .) of a 16-lane row keeps the sum of register g = j over the row's 16 channels
+        float mine = row16_sum16(part, lane);
+        float* dst = &sqpart[(w * 2 + g1) * 32 + crow(lane & 15, h)];
+        if (pi > 0) mine += *dst;                    // summed into the wave's slot in a fixed order
+        *dst = mine;
       }
       if (U & 2) take_pq(ring[2], ring[3]); else take_pq(ring[0], ring[1]);
       CA_STAMP(10 + 3 * pi);
@@ -815,7 +825,7 @@ template <int NT, int NW, bool LM>
 int launch_fwd32(const FwdArgs& a, hipStream_t s) {
   constexpr int NPAD = 32 * NT;
   constexpr int RING_SLOTS = (NT + 1) * ((NT + 1 >= 6) ? 1 : 2);
-  const size_t lds_p2 = (size_t)32 * (NPAD + 4) * 4 + (size_t)3 * NPAD * 32 * 2, lds_p1 = LM ? (size_t)NW * 4 * 4096 : (size_t)NW * RING_SLOTS * 2048;
+  const size_t lds_p2 = (size_t)NPAD * 36 * 4 + (size_t)3 * NPAD * 32 * 2, lds_p1 = LM ? (size_t)NW * 4 * 4096 : (size_t)NW * RING_SLOTS * 2048;
   const size_t lds = lds_p2 > lds_p1 ? lds_p2 : lds_p1;
   static DeviceOnce once;                            // the attribute is per device
   CA_TRY(once.run([&] {

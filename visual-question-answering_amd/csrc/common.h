@@ -82,6 +82,11 @@ __device__ __forceinline__ float tanh_fast(float x) {
   return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
 }
 
+// 1 / (1 + exp(2x)): tanh(x) = 1 - 2 sig2(x)
+__device__ __forceinline__ float sig2_fast(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+
 // sum over the 16 lanes of a DPP row (lanes sharing lane>>4); result valid in every lane
 __device__ __forceinline__ float row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
@@ -89,6 +94,40 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
   return v;
+}
+
+// Transposing sum of 16 registers over a DPP row: lane j of every 16-lane row ends with sum_i x[j][lane i].
+// A butterfly whose halving steps also halve the register set (45 VALU operations; 16 separate row16_sum chains are 64
+// plus the selects): steps A / B pair registers (g, g + 8) / (g, g + 4) and exchange across lane distance 8 / 4 -- the
+// bank mask of a DPP move picks which half of the lanes takes the partner's value --, steps C / D finish inside a quad.
+template <int CTRL, int BANK>
+__device__ __forceinline__ float dpp_mov(float old, float src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                                               CTRL, 0xF, BANK, false));
+}
+// lanes 0-7 of a row: lo[i] + lo[i + 8]; lanes 8-15: hi[i] + hi[i - 8]      (row_ror:8)
+__device__ __forceinline__ float bfly_a(float lo, float hi) { return dpp_mov<0x128, 0x3>(hi, lo) + dpp_mov<0x128, 0xC>(lo, hi); }
+// lanes with bit 2 clear: lo[i] + lo[i + 4] (row_shl:4); set: hi[i] + hi[i - 4] (row_shr:4)
+__device__ __forceinline__ float bfly_b(float lo, float hi) { return dpp_mov<0x104, 0x5>(hi, lo) + dpp_mov<0x114, 0xA>(lo, hi); }
+// lanes with bit 1 clear: lo[i] + lo[i ^ 2]; set: hi[i] + hi[i ^ 2]         (quad_perm [2,3,0,1])
+__device__ __forceinline__ float bfly_c(float lo, float hi, int lane) {
+  const float a = lo + dpp_mov<0x4E, 0xF>(0.f, lo), b = hi + dpp_mov<0x4E, 0xF>(0.f, hi);
+  return (lane & 2) ? b : a;
+}
+// lanes with bit 0 clear: lo[i] + lo[i ^ 1]; set: hi[i] + hi[i ^ 1]         (quad_perm [1,0,3,2])
+__device__ __forceinline__ float bfly_d(float lo, float hi, int lane) {
+  const float a = lo + dpp_mov<0xB1, 0xF>(0.f, lo), b = hi + dpp_mov<0xB1, 0xF>(0.f, hi);
+  return (lane & 1) ? b : a;
+}
+__device__ __forceinline__ float row16_sum16(const float (&x)[16], int lane) {
+  float y[8], z[4], w[2];
+#pragma unroll
+  for (int g = 0; g < 8; ++g) y[g] = bfly_a(x[g], x[g + 8]);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) z[g] = bfly_b(y[g], y[g + 4]);
+#pragma unroll
+  for (int g = 0; g < 2; ++g) w[g] = bfly_c(z[g], z[g + 2], lane);
+  return bfly_d(w[0], w[1], lane);
 }
 
 // ---- generic GEMM (gemm.hip) ------------------------------------------------------------

@@ -466,7 +466,9 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
   // slot read per partial sum); rows >= T are tanh(0) = 0 (their Q rows read as 0).  The three bf16 pieces go to the
   // image [piece][n][t] (8-byte writes).  All the slot reads come first: slot 1 lies inside the image region.
   {
-    float* Cg = a.C + pair * (size_t)T * N;
+    // C of this (sample, level) as a buffer: rows t >= T fall outside it (stores dropped), and a lane of a padded
+    // column n >= N is sent outside it through its offset -- no branches around the stores
+    const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(a.C + pair * (size_t)T * N, (unsigned)T * N * 4u);
     constexpr int PER = 8 * NPAD / (NW * 64);        // (location, token quad) items per thread (exact: NPAD = 32 NT)
     static_assert(8 * NPAD % (NW * 64) == 0, "the image pass covers the slot in whole sweeps");
     f32x4 sum[PER];
@@ -481,11 +483,13 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
     for (int k = 0; k < PER; ++k) {
       const int e = tid + k * NW * 64, tq = e / NPAD, n = e - tq * NPAD;
       const bool in = n < N;                         // padded columns of a channel-major V carry junk
+      const int cvoff = in ? (4 * tq * N + n) * 4 : 0x40000000;
       float c[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        c[i] = in ? tanh_fast(sum[k][i]) : 0.f;
-        if (in && 4 * tq + i < T) Cg[(size_t)(4 * tq + i) * N + n] = c[i];
+        const float th = tanh_fast(sum[k][i]);
+        c[i] = in ? th : 0.f;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, th), rs_c, cvoff, i * N * 4, 0);
       }
       unsigned hh[2], mm[2], ll[2];
       split3_pair(c[0], c[1], hh[0], mm[0], ll[0]);
@@ -497,8 +501,6 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
       *reinterpret_cast<u32x2*>(Cimg + 2 * PIECE + off) = u32x2{ll[0], ll[1]};
     }
   }
-  // the image is complete once every wave's LDS writes have landed: a barrier on the LDS counter alone (a
-  // __syncthreads() would also drain the C stores and the P_q loads still in flight)
   lds_barrier();
   CA_STAMP(2);
 
@@ -723,7 +725,16 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
   // ------------------------------------------------------------------ phase 3
   lane = lane_id(); tid = w * 64 + lane;
   CA_STAMP(3);
-  __syncthreads();
+  // q = sum_t a_q[t] Q[t][:]   (model.py:392): the Q rows of the thread's first channels are requested before the
+  // softmaxes, whose latency they hide (all kTRows row loads in flight at once; rows >= T read 0)
+  constexpr int QPRE = 2;                            // channel sweeps prefetched (d = 512 with four waves: all of them)
+  float xq[QPRE][kTRows];
+#pragma unroll
+  for (int i = 0; i < QPRE; ++i)
+#pragma unroll
+    for (int t = 0; t < kTRows; ++t)
+      xq[i][t] = buf_load1(rs_q, (t * d + tid + i * NW * 64) * 4, 0);   // sweeps past d: rows past T or junk, unused
+  lds_barrier();                                     // every wave's score partials are in LDS
   CA_STAMP(4);
   if (w == 0) {
     // a_v = softmax_n(s_v + c_v): N <= 32 NT <= 256 -> <= 4 values per lane
@@ -758,7 +769,9 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
       const int n = lane + 64 * k;
       if (n < N) avg[n] = sc[k] * inv;
     }
-    // a_q = softmax_t(s_q + c_q), un-masked over all T positions (model.py:388)
+  }
+  if (w == 1) {
+    // a_q = softmax_t(s_q + c_q), un-masked over all T positions (model.py:388), by the second wave
     float s = -INFINITY;
     if (lane < T) {
       s = a.cq[0];
@@ -772,15 +785,25 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
     if (lane < 32) aqs[lane] = aqv;                  // zeros beyond T
     if (lane < T) a.aq[pair * (size_t)T + lane] = aqv;
   }
-  __syncthreads();
-  // q = sum_t a_q[t] Q[t][:]   (model.py:392): all kTRows row loads in flight at once (rows >= T read 0)
-  for (int dd = tid; dd < d; dd += NW * 64) {
+  lds_barrier();
+  float aqr[kTRows];
+#pragma unroll
+  for (int t = 0; t < kTRows; ++t) aqr[t] = aqs[t];
+#pragma unroll
+  for (int i = 0; i < QPRE; ++i) {
+    const int dd = tid + i * NW * 64;
+    float acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < kTRows; ++t) acc = fmaf(aqr[t], xq[i][t], acc);
+    if (dd < d) a.q_out[pair * (size_t)d + dd] = acc;
+  }
+  for (int dd = tid + QPRE * NW * 64; dd < d; dd += NW * 64) {
     float x[kTRows];
 #pragma unroll
     for (int t = 0; t < kTRows; ++t) x[t] = buf_load1(rs_q, (t * d + dd) * 4, 0);
     float acc = 0.f;
 #pragma unroll
-    for (int t = 0; t < kTRows; ++t) acc = fmaf(aqs[t], x[t], acc);
+    for (int t = 0; t < kTRows; ++t) acc = fmaf(aqr[t], x[t], acc);
     a.q_out[pair * (size_t)d + dd] = acc;
   }
   CA_STAMP(5);

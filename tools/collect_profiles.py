@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Copy the summaries produced by tools/refresh_profiles.sh (gpurun_out/refresh/) into profiles/.
 
-usage: tools/collect_profiles.py [round-tag, default r01]
+usage: tools/collect_profiles.py [round-tag, default r02]
 """
 import csv
 import glob
@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "refresh")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
 def one(pattern):
@@ -26,7 +26,7 @@ def one(pattern):
 line = [l for l in open(os.path.join(SRC, "bench.json")) if l.startswith("{")][-1]
 json.loads(line)
 open(os.path.join(DST, "%s_bench.json" % tag), "w").write(line)
-for leg, name in (("roofline", "roofline"), ("hot", "hot_path"), ("step", "full_step")):
+for leg, name in (("roofline", "roofline"), ("hot", "hot_path"), ("step", "full_step"), ("bench_stats", "bench")):
     shutil.copy(one("%s/**/*kernel_stats.csv" % leg), os.path.join(DST, "%s_%s_kernel_stats.csv" % (tag, name)))
 shutil.copy(os.path.join(SRC, "pmc_traffic.json"), os.path.join(DST, "pmc_traffic.json"))
 
@@ -35,8 +35,7 @@ vals = {}
 for f in glob.glob(os.path.join(SRC, "pmc_mfma", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        kern = ("coattn_attn_fwd_kernel" if "attn_fwd" in k else "attend_v_kernel" if "attend_v" in k
-                else "gemm_f32_vec_kernel (P_v projection)" if "gemm_f32_vec" in k else None)
+        kern = ("coattn_fwd32_kernel" if "coattn_fwd32" in k else "attend_v_lm_kernel" if "attend_v" in k else None)
         if kern:
             vals.setdefault(kern, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 if vals:
@@ -45,6 +44,8 @@ if vals:
         m = {c: sum(v) / len(v) for c, v in cs.items()}
         if m.get("SQ_BUSY_CYCLES") and "SQ_VALU_MFMA_BUSY_CYCLES" in m:
             m["derived_mfma_busy_frac"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (32.0 * m["SQ_BUSY_CYCLES"])
+        if m.get("SQ_WAVE_CYCLES") and "SQ_ACTIVE_INST_VALU" in m:      # share of a wave's life with a VALU/MFMA instruction issuing
+            m["derived_valu_active_per_wave"] = m["SQ_ACTIVE_INST_VALU"] / m["SQ_WAVE_CYCLES"]
         out[kern] = m
     json.dump(out, open(os.path.join(DST, "%s_pmc_mfma.json" % tag), "w"), indent=1)
 # the same counters over the whole isolated hot path (bench.py --only hot): one entry per kernel of the HIP library

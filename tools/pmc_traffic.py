@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected in SEPARATE runs of
-`bench.py --only roofline`) into profiles/pmc_traffic.json: HBM bytes per launch of the
-affinity+softmax+reduce forward (coattn_attn_fwd_kernel + attend_v_kernel).
+`tools/probe_fwd_one.py`: the headline shape and layout only) into profiles/pmc_traffic.json: HBM bytes per launch
+of the affinity+softmax+reduce forward (coattn_fwd32_kernel + attend_v_lm_kernel / attend_v_kernel).
 
 gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE is in KiB and reports 1/2 of the
-bytes of a coalesced streaming read -> doubled; the factor is calibrated on attend_v_kernel,
+bytes of a coalesced streaming read -> doubled; the factor is calibrated on the attend_v kernel,
 whose read volume is known exactly (one pass over V + a_v); WRITE_SIZE (KiB) is exact.
 
-usage: tools/pmc_traffic.py <dir with *counter_collection.csv> [...]  B N T d L
+usage: tools/pmc_traffic.py <dir with *counter_collection.csv> [...]  B N T d L layout
 """
 import csv
 import glob
@@ -15,14 +15,14 @@ import json
 import os
 import sys
 
-dirs, dims = sys.argv[1:-5], [int(x) for x in sys.argv[-5:]]
+dirs, dims, layout = sys.argv[1:-6], [int(x) for x in sys.argv[-6:-1]], sys.argv[-1]
 B, N, T, d, L = dims
 vals = {}
 for dd in dirs:
     for f in glob.glob(os.path.join(dd, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            kern = "fwd" if "attn_fwd" in k else ("attend_v" if "attend_v" in k else None)
+            kern = "fwd" if "coattn_fwd32" in k else ("attend_v" if "attend_v" in k else None)
             if kern:
                 vals.setdefault((kern, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
 mean = {k: sum(v) / len(v) for k, v in vals.items()}
@@ -30,13 +30,13 @@ known_attend_read = 4.0 * (B * d * N + L * B * N)              # V once + a_v
 calib = known_attend_read / (mean[("attend_v", "FETCH_SIZE")] * 1024.0)
 fetch = (mean[("fwd", "FETCH_SIZE")] + mean[("attend_v", "FETCH_SIZE")]) * 1024.0 * 2.0
 write = (mean[("fwd", "WRITE_SIZE")] + mean[("attend_v", "WRITE_SIZE")]) * 1024.0
-out = {"shape": {"B": B, "N": N, "T": T, "d": d, "L": L},
+out = {"shape": {"B": B, "N": N, "T": T, "d": d, "L": L}, "layout": layout,
        "hbm_bytes_per_launch": int(fetch + write),
        "fetch_bytes_corrected_x2": int(fetch), "write_bytes": int(write),
        "fetch_calibration_factor_on_attend_v": round(calib, 3),
        "raw_kib": {"%s.%s" % k: round(v, 1) for k, v in mean.items()},
        "note": "FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950 halves coalesced-read bytes); calibration on "
-               "attend_v_kernel's exactly known read volume; counters from separate --pmc passes"}
+               "the attend_v kernel's exactly known read volume; counters from separate --pmc passes"}
 with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json"), "w") as fh:
     json.dump(out, fh, indent=1)
 print(json.dumps(out))

@@ -7,7 +7,6 @@
 //   (the location-major twin is attend_v_lm_kernel in coattn_fwd32.hip).
 #include "fused.h"
 
-#include <stdlib.h>
 
 namespace {
 
@@ -72,9 +71,6 @@ int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, c
   a.q_out = q_out;
   a.stamps = COATTN_STAMPS ? reinterpret_cast<unsigned long long*>(ws) : nullptr;
   a.B = B; a.N = N; a.T = T; a.d = d; a.L = L;
-  // COATTN_FWD_STAGGER_US (developer switch): delay of the second workgroup of every CU, see coattn_fwd32.hip
-  static const int stag = [] { const char* e = getenv("COATTN_FWD_STAGGER_US"); return e ? atoi(e) : 0; }();
-  a.stagger_ticks = stag * 100;
   CA_TRY(fused32_forward(a, s));
   if (lm) return launch_attend_v_lm(V, vl.sB, a.av, v_out, B, N, d, L, s);
   dim3 grid(d / 64, B);

@@ -145,13 +145,6 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
 
   int b, l;
   if (!block_to_pair(blockIdx.x, a.B, a.L, b, l)) return;
-  // Stagger: workgroups are dealt one per CU first, so those past the 256th share a CU with an earlier one.
-  // Started together the two stream V at the same time (memory path saturated, VALU idle) and later split P_v at
-  // the same time (VALU saturated); delayed by about one phase, one streams while the other computes.  Speed only.
-  if (a.stagger_ticks > 0 && blockIdx.x >= 256) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)a.stagger_ticks) __builtin_amdgcn_s_sleep(32);
-  }
   CA_STAMP(0);
   const int N = a.N, T = a.T, d = a.d;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

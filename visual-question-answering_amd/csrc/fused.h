@@ -146,7 +146,6 @@ struct FwdArgs {
   float* q_out;          // [L][B][d]
   unsigned long long* stamps;   // diagnostic builds only
   int B, N, T, d, L;
-  int stagger_ticks;     // delay (100 MHz ticks) of the workgroups past the first one of every CU; 0 = none
 };
 
 // bf16-split forward kernel on the 32x32x16 MFMA (coattn_fwd32.hip)

@@ -803,27 +803,51 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
 }
 
 // v_l[b][ch] = sum_n a_v[l][b][n] V[b][n][ch]   (model.py:391), location-major V, all L levels in one pass.
-// grid (d / 128, B); 256 threads = 32 float4 lanes (128 channels) x 8 location phases, fixed-order sum over the phases.
+// grid (d / 128, B); 256 threads = 32 float4 lanes (128 channels: whole 512-byte row segments) x 8 location phases,
+// fixed-order sum over the phases.  A thread's rows (<= 32 at N <= 256) come in four batches of 8 with two batches in
+// flight; the first is requested before the attention weights are staged, so their latencies overlap.  Rows >= N lie
+// outside the sample's buffer and read 0.
 __global__ __launch_bounds__(256) void attend_v_lm_kernel(const float* V, long v_sB, const float* av, float* v_out,
                                                           int B, int N, int d, int L) {
   __shared__ float aw[3][256];
   __shared__ f32x4 part[3][8][32];
   const int b = blockIdx.y, c0 = blockIdx.x * 128;
   const int tid = threadIdx.x, cl = tid & 31, ph = tid >> 5;
+  const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(V + (size_t)b * v_sB, (unsigned)N * d * 4u);
+  const int voff = (ph * d + c0 + 4 * cl) * 4;
+  const int rstep = 8 * d * 4;                         // a thread's consecutive rows are 8 apart
+  f32x4 x0[8], x1[8];
+  auto load8 = [&](const int batch, f32x4 (&x)[8]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = buf_load4(rs_v, voff, (8 * batch + k) * rstep);
+  };
+  load8(0, x0);
   for (int i = tid; i < 3 * 256; i += 256) {
     const int l = i >> 8, n = i & 255;
     aw[l][n] = (l < L && n < N) ? av[((size_t)l * B + b) * N + n] : 0.f;
   }
   __syncthreads();
-  const float* vp = V + (size_t)b * v_sB + c0 + 4 * cl;
   f32x4 acc[3];
 #pragma unroll
   for (int l = 0; l < 3; ++l) acc[l] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 7
-  for (int n = ph; n < N; n += 8) {
-    const f32x4 x = *reinterpret_cast<const f32x4*>(vp + (size_t)n * d);
+  auto fma8 = [&](const int batch, const f32x4 (&x)[8]) {
 #pragma unroll
-    for (int l = 0; l < 3; ++l) acc[l] += x * aw[l][n];
+    for (int k = 0; k < 8; ++k) {
+      const int n = (ph + 8 * (8 * batch + k)) & 255;  // n < 256 always (ph + 8 * 31 = 255 at most)
+#pragma unroll
+      for (int l = 0; l < 3; ++l) acc[l] += x[k] * aw[l][n];
+    }
+  };
+  load8(1, x1);
+  fma8(0, x0);
+  if (N > 128) {                                       // uniform: rows 128.. exist only then
+    load8(2, x0);
+    fma8(1, x1);
+    load8(3, x1);
+    fma8(2, x0);
+    fma8(3, x1);
+  } else {
+    fma8(1, x1);
   }
 #pragma unroll
   for (int l = 0; l < 3; ++l) part[l][ph][cl] = acc[l];

@@ -288,23 +288,20 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
         }
       }
     } else {
-      // Operand stream.  Element i of a lane's fragment <-> channel k0 + 4 h + (i & 3) + 8 (i >> 2): the same order
-      // for A and B, chosen so that the two 16-byte loads of a location-major row are contiguous across the lane halves.
-      // The stream is latency-bound (a wave alone needs ~8 KB in flight to cover HBM latency at its share of the
-      // bandwidth, twice that under load), and registers cannot hold that: the fragments go HBM -> LDS by LDS-DMA
-      // (buffer_load ... lds, no VGPR destination) into a per-wave ring of R slots of 2 KB -- the LDS is idle until the
-      // cross-wave reduction -- and are read back (ds_read_b128 x 2 per lane, lane-linear, conflict-free) one unit
-      // before their MFMAs.  Units of a k-step (16 channels): the Q fragment, then the NT location tiles.
-      // The first NB tiles of a k-step run on the bf16 MFMA with the exact 3-way split (6 MFMAs of 32 cycles + 44 VALU
-      // per unit), the others on the f32 MFMA straight from the registers (8 MFMAs of 64 cycles, no VALU; lane (., h)
-      // of a 32x32x2 MFMA supplies k = h: element i pairs channels (k0 + (i&3) + 8(i>>2), the same + 4)).
+      // Channel-major operand stream.  Element i of a lane's fragment <-> channel k0 + 4 h + (i & 3) + 8 (i >> 2), the
+      // same order for A and B.  The fragments go HBM -> LDS by LDS-DMA (buffer_load ... lds, no VGPR destination) into
+      // a per-wave ring of R slots of 2 KB -- the LDS is idle until the cross-wave reduction -- and are read back one
+      // unit before their MFMAs.  Units of a k-step (16 channels): the Q fragment, then the NT location tiles.
+      // The first NB tiles of a k-step run on the bf16 MFMA with the exact 3-way split, the others (none by default) on
+      // the f32 MFMA straight from the registers (lane (., h) of a 32x32x2 MFMA supplies k = h: element i pairs
+      // channels (k0 + (i&3) + 8(i>>2), the same + 4)).
       constexpr int NB = COATTN_P1_NB >= 0 ? (COATTN_P1_NB < NT ? COATTN_P1_NB : NT) : NT;
       constexpr int UPK = NT + 1;                      // units per k-step
       constexpr int KU = (UPK >= 6) ? 1 : 2;           // k-steps per loop body
       constexpr int R = UPK * KU;                      // ring slots = units per loop body: static slot indices
       char* ringb = smem + w * (R * 2048);
       const int q_voff = (r * d + 4 * h) * 4;
-      const int v_voff = LM ? (r * d + 4 * h) * 4 : (4 * h * N + r) * 4;
+      const int v_voff = ((lane >> 3) * N + (lane & 7) * 4) * 4;
       const int G = 8 * nsl;                           // 16-channel steps of this wave
       auto chan0 = [&](int g) { return ((g >> 3) * NW + w) * 128 + 16 * (g & 7); };
       // DMA of unit (k-step g, position j) into its slot; beyond the last k-step the addresses fall outside the sample or
@@ -319,30 +316,26 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
           // LDS address)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_ptr)dst, 16, q_voff, k0 * 4, 0, 0);
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (lds_ptr)(dst + 1024), 16, q_voff, k0 * 4 + 32, 0, 0);
-        } else if constexpr (LM) {
-          const int so = (32 * (j - 1) * d + k0) * 4;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_ptr)dst, 16, v_voff, so, 0, 0);
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_ptr)(dst + 1024), 16, v_voff, so + 32, 0, 0);
         } else {
-          // channel-major: eight dword pieces (element i of the fragment = row k0 + 4h + (i&3) + 8(i>>2) of V [d][N])
+          // channel-major V [d][N]: a unit is 16 channel rows x 32 locations (128 B per row), fetched by two 16-byte
+          // DMAs of 8 rows each (a lane per 16 bytes of a row segment) into a row-major image [16][32]
           const int so = (k0 * N + 32 * (j - 1)) * 4;  // columns >= N: finite junk, zeroed when C is finalised
-  #pragma unroll
-          for (int i = 0; i < 8; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_ptr)(dst + 256 * i), 4, v_voff,
-                                                     so + ((i & 3) + 8 * (i >> 2)) * N * 4, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_ptr)dst, 16, v_voff, so, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_ptr)(dst + 1024), 16, v_voff, so + 8 * N * 4, 0, 0);
         }
       };
-      constexpr int DPU = LM ? 2 : 8;                  // DMA instructions of a V unit (a Q unit: 2)
+      constexpr int DPU = 2;                           // DMA instructions of a unit
       auto read_unit = [&](const int j, const int slot) -> f32x8 {
         const char* src = ringb + slot * 2048;
-        if (LM || j == 0) {
+        if (j == 0) {
           const f32x4 x0 = *reinterpret_cast<const f32x4*>(src + lane * 16);
           const f32x4 x1 = *reinterpret_cast<const f32x4*>(src + 1024 + lane * 16);
           return f32x8{x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
         }
-        f32x8 x;
+        f32x8 x;                                       // element i <-> channel row 4h + (i&3) + 8(i>>2), location r
   #pragma unroll
-        for (int i = 0; i < 8; ++i) x[i] = *reinterpret_cast<const float*>(src + 256 * i + lane * 4);
+        for (int i = 0; i < 8; ++i)
+          x[i] = *reinterpret_cast<const float*>(src + (4 * h + (i & 3) + 8 * (i >> 2)) * 128 + r * 4);
         return x;
       };
       // DMAs still allowed in flight when unit p of the body is read back: those of the R - 2 units issued after it

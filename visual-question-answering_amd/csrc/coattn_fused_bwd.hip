@@ -1,5 +1,5 @@
 // Fused backward of the parallel co-attention (hand-derived; SURVEY.md section 8, checked
-// against autograd of the reference by the oracle).  fp32, exact-f32 MFMA 16x16x4.
+// against autograd of the reference by the oracle).  fp32; the kernels of this file use the exact-f32 MFMA 16x16x4.
 //
 // H_v [N,d] is never stored: both big kernels recompute it from P_v, P_q and C (saved).
 //
@@ -11,12 +11,13 @@
 //                   dw_v partials, and dC += P_q dZ_v^T + dZ_q P_v^T with the dZ_v^T / P_v^T
 //                   accumulator registers reused directly as MFMA B operands (contraction over d);
 //                   cross-wave tree sum through LDS, dA = dC (.) (1 - C^2).
-//   bwd_dpq_kernel  (per sample x level, orientation [n][d], same loop as forward phase 2):
-//                   H_v tile -> dZ_v tile, which is the B operand of dP_q += C dZ_v
-//                   (contraction over N).
+//   bwd_dpq32_kernel (coattn_bwd32.hip; per sample x level, orientation [n][d], the loop of forward phase 2, on
+//                   the bf16 MFMA with the exact 3-way split): H_v tile -> dZ_v tile, which is the B operand of
+//                   dP_q += C dZ_v (contraction over N).
 //   then MFMA GEMMs: dQ = a_q (x) gq + dA V^T + dP_q W_q;  dV = sum_l (a_v (x) gv + Q^T dA) +
 //   (sum_l dP_v) W_v (skipped when the image features need no gradient);  dW_v, dW_q, biases.
 #include "fused.h"
+
 
 namespace {
 
@@ -188,21 +189,6 @@ __global__ __launch_bounds__(256) void bwd_pre_kernel(const PreArgs a) {
   }
 }
 
-struct BwdArgs {
-  const float* Pv;        // [B][N][d]
-  const float* Pq;        // [L][B][T][d]
-  const float* C;         // [L][B][T][N]
-  const float* dsv;       // [L][B][N]
-  const float* dZq;       // [L][B][T][d]
-  const float* wv;
-  float* dPv;             // [L][B][N][d]
-  float* dPq;             // [L][B][T][d]
-  float* dA;              // [L][B][T][N]
-  float* dwv_part;        // [L*B][d]
-  float* dbv_part;        // [L*B][d]   sum_n dP_v[n][:]
-  float* dbq_part;        // [L*B][d]   sum_t dP_q[t][:]
-  int B, N, T, d, L;
-};
 
 // stage C (zero padded to kTRows x NPAD) and ds_v (zero padded) into LDS: one wave per row, lanes along n
 template <int NPAD, int LD, int NTHREADS>
@@ -384,181 +370,6 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc_kernel(const BwdArgs a) {
   }
 }
 
-template <int NT, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void bwd_dpq_kernel(const BwdArgs a) {
-  constexpr int NPAD = 16 * NT;
-  constexpr int LD = NPAD + 4;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Cbuf = lds;                                 // kTRows x LD
-  float* dsvs = Cbuf + kTRows * LD;                  // NPAD
-  int b, l;
-  if (!block_to_pair(blockIdx.x, a.B, a.L, b, l)) return;
-  const int N = a.N, T = a.T, d = a.d;
-  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 15, q4 = lane >> 4;
-  const size_t pair = (size_t)l * a.B + b;
-  const float* Pvp = a.Pv + (size_t)b * N * d;
-  const float* Pqp = a.Pq + pair * (size_t)T * d;
-  const float* dZqp = a.dZq + pair * (size_t)T * d;
-  stage_c<NPAD, LD, NW * 64>(a, pair, Cbuf, dsvs, tid);
-  __syncthreads();
-  const __amdgpu_buffer_rsrc_t rs_pq = make_rsrc(Pqp, (unsigned)T * d * 4u);       // rows >= T read 0
-  const __amdgpu_buffer_rsrc_t rs_dzq = make_rsrc(dZqp, (unsigned)T * d * 4u);
-  const int nsl = d / (128 * NW);                    // 128-channel slices per wave (1 at d = 512)
-  for (int sl = 0; sl < nsl; ++sl) {
-  const int dsl = (sl * NW + w) * 128;
-  float pq[kTS][8];
-#pragma unroll
-  for (int s = 0; s < kTS; ++s)
-#pragma unroll
-    for (int c = 0; c < 8; ++c) pq[s][c] = buf_load1(rs_pq, ((4 * s + q4) * d + j) * 4 + 64 * c, dsl * 4);
-  float wvr[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) wvr[c] = a.wv[dsl + 16 * c + j];
-  f32x4 accq[2][8];
-#pragma unroll
-  for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-    for (int c = 0; c < 8; ++c) accq[tt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // Tile loop over quarter tiles (2 channel tiles, ring of 4 buffers), software pipelined: in step u the
-  // recompute MFMAs of quarter u are interleaved with the tanh / dZ_v VALU work of quarter u-1, whose
-  // dP_q MFMAs follow; loads run two quarters ahead (rows beyond N read 0 through the buffer rule).
-  const int ntiles = (N + 15) >> 4;
-  {
-    const __amdgpu_buffer_rsrc_t rs_pv = make_rsrc(Pvp, (unsigned)N * d * 4u);
-    f32x4 ring[4][2];
-    f32x4 ca[2], ca_prev[2];
-    float ct[kTS];
-    float dsn[4], dsn_prev[4];
-    auto load_q = [&](int tile, int qc, f32x4(&dst)[2]) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int voff = ((4 * q4 + r) * d + j) * 4;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) dst[c][r] = buf_load1(rs_pv, voff + 64 * (2 * qc + c), (16 * tile * d + dsl) * 4);
-      }
-    };
-    auto load_a = [&](int tile) {
-      const int nb = 16 * tile;
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const int t = min(16 * tt + j, kTRows - 1);
-        ca[tt] = *reinterpret_cast<const f32x4*>(&Cbuf[t * LD + nb + 4 * q4]);
-      }
-#pragma unroll
-      for (int s = 0; s < kTS; ++s) ct[s] = Cbuf[(4 * s + q4) * LD + nb + j];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dsn[r] = dsvs[nb + 4 * q4 + r];
-    };
-    auto s3_q = [&](f32x4(&pv)[2], const int qc) {            // H_v quarter = P_v + C^T P_q
-#pragma unroll
-      for (int s = 0; s < kTS; ++s)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) pv[c] = mfma16(ct[s], pq[s][2 * qc + c], pv[c]);
-    };
-    auto valu_q = [&](f32x4(&pv)[2], const int qc, const float(&ds)[4]) {     // -> dZ_v = ds_v w_v (1 - H_v^2)
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float h = tanh_fast(pv[c][r]);
-          pv[c][r] = ds[r] * wvr[2 * qc + c] * (1.0f - h * h);
-        }
-    };
-    auto aq_q = [&](const f32x4(&pv)[2], const int qc, const f32x4(&cc)[2]) {  // dP_q += C dZ_v
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int c = 0; c < 2; ++c) accq[tt][2 * qc + c] = mfma16(cc[tt][s], pv[c][s], accq[tt][2 * qc + c]);
-    };
-#define COATTN_INTERLEAVE14()                                      \
-  _Pragma("unroll") for (int g_ = 0; g_ < 14; ++g_) {              \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             \
-    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);             \
-  }
-    load_q(0, 0, ring[0]);
-    load_q(0, 1, ring[1]);
-    for (int tile = 0; tile < ntiles; ++tile) {
-      // step 0: recompute quarter 0 of this tile; finish quarter 3 of the previous tile
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) ca_prev[tt] = ca[tt];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dsn_prev[r] = dsn[r];
-      load_q(tile, 2, ring[2]);
-      load_a(tile);
-      __builtin_amdgcn_sched_barrier(0);
-      s3_q(ring[0], 0);
-      if (tile > 0) valu_q(ring[3], 3, dsn_prev);
-      COATTN_INTERLEAVE14();
-      __builtin_amdgcn_sched_barrier(0);
-      if (tile > 0) aq_q(ring[3], 3, ca_prev);
-      // step 1
-      load_q(tile, 3, ring[3]);
-      __builtin_amdgcn_sched_barrier(0);
-      s3_q(ring[1], 1);
-      valu_q(ring[0], 0, dsn);
-      COATTN_INTERLEAVE14();
-      __builtin_amdgcn_sched_barrier(0);
-      aq_q(ring[0], 0, ca);
-      // step 2
-      load_q(tile + 1, 0, ring[0]);
-      __builtin_amdgcn_sched_barrier(0);
-      s3_q(ring[2], 2);
-      valu_q(ring[1], 1, dsn);
-      COATTN_INTERLEAVE14();
-      __builtin_amdgcn_sched_barrier(0);
-      aq_q(ring[1], 1, ca);
-      // step 3
-      load_q(tile + 1, 1, ring[1]);
-      __builtin_amdgcn_sched_barrier(0);
-      s3_q(ring[3], 3);
-      valu_q(ring[2], 2, dsn);
-      COATTN_INTERLEAVE14();
-      __builtin_amdgcn_sched_barrier(0);
-      aq_q(ring[2], 2, ca);
-    }
-    if (ntiles > 0) {
-      valu_q(ring[3], 3, dsn);
-      aq_q(ring[3], 3, ca);
-    }
-#undef COATTN_INTERLEAVE14
-  }
-  // dP_q = dZ_q + acc ; db_q partial = sum_t dP_q[t][:].  Branch-free (rows >= T: loads 0, stores dropped)
-  const __amdgpu_buffer_rsrc_t rs_dpq = make_rsrc(a.dPq + pair * (size_t)T * d, (unsigned)T * d * 4u);
-  float dbq[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) dbq[c] = 0.f;
-#pragma unroll
-  for (int tt = 0; tt < 2; ++tt) {
-    float zq[4][8];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int c = 0; c < 8; ++c) zq[r][c] = buf_load1(rs_dzq, ((16 * tt + 4 * q4 + r) * d + j) * 4 + 64 * c, dsl * 4);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool live = (16 * tt + 4 * q4 + r) < T;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const float v = accq[tt][c][r] + zq[r][c];
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_dpq,
-                                              ((16 * tt + 4 * q4 + r) * d + j) * 4 + 64 * c, dsl * 4, 0);
-        dbq[c] += live ? v : 0.f;
-      }
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {                      // sum over the four row quads (lanes j, j+16, j+32, j+48)
-    dbq[c] += __shfl_xor(dbq[c], 16, 64);
-    dbq[c] += __shfl_xor(dbq[c], 32, 64);
-    if (q4 == 0) a.dbq_part[pair * (size_t)d + dsl + 16 * c + j] = dbq[c];
-  }
-  }   // channel slices
-}
-
 // dQ_l[b][t][k] = a_q,l[t] gq_l[k] + sum_n dA_l[t][n] V[b][k][n]   for all levels with one pass over V.
 // grid (d/128, B); a wave owns 32 channels (two 16-wide MFMA column tiles); dA of the three levels is
 // staged zero-padded in LDS and read as MFMA A operands (16 bytes = 4 k-steps per ds_read_b128).
@@ -686,18 +497,13 @@ int launch_main(const BwdArgs& a, hipStream_t s) {
   constexpr int LD = 16 * NT + 4;
   constexpr int NSLOT = (NW / 2 > 2) ? NW / 2 : 2;
   const size_t lds_dc = (size_t)((NSLOT * kSlotRows + kTRows) * LD + 16 * NT) * sizeof(float);
-  const size_t lds_pq = (size_t)(kTRows * LD + 16 * NT) * sizeof(float);
   static DeviceOnce once;                            // the attribute is per device
-  CA_TRY(once.run([&] {
-    const hipError_t e = set_lds(bwd_dc_kernel<NT, NW>, lds_dc);
-    return e != hipSuccess ? e : set_lds(bwd_dpq_kernel<NT, NW>, lds_pq);
-  }, "bwd_dc/bwd_dpq"));
+  CA_TRY(once.run([&] { return set_lds(bwd_dc_kernel<NT, NW>, lds_dc); }, "bwd_dc"));
   const int groups = (a.B + 7) / 8;
   dim3 grid(groups * a.L * 8), block(NW * 64);
   hipLaunchKernelGGL((bwd_dc_kernel<NT, NW>), grid, block, lds_dc, s, a);
   CA_CHECK_LAUNCH("bwd_dc");
-  hipLaunchKernelGGL((bwd_dpq_kernel<NT, NW>), grid, block, lds_pq, s, a);
-  CA_CHECK_LAUNCH("bwd_dpq");
+  return launch_bwd_dpq32(a, s);                     // dP_q, db_q (coattn_bwd32.hip)
   return 0;
 }
 

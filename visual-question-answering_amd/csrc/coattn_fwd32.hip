@@ -39,9 +39,6 @@
 
 namespace {
 
-__device__ __forceinline__ bf16x4 lds_tr16(const short* p) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(const_cast<short*>(p)));
-}
 
 // wait until at most n of this wave's vector-memory operations (loads, stores, LDS-DMA: one in-order counter) are
 // still outstanding; hand-placed for the LDS-DMA ring, whose data dependences the compiler does not see.  n is a
@@ -116,16 +113,6 @@ __device__ __forceinline__ void vmcnt_wait(int n) {
   }
 }
 
-// Workgroup barrier on the LDS counter alone: the LDS traffic of every wave has landed, global loads and stores stay
-// in flight (a __syncthreads() drains them too).
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
-
-// C/D row of accumulator register g in lane half h (32x32 MFMA)
-__device__ __forceinline__ constexpr int crow(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
 
 template <int NT, int NW, bool LM>
 __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs a) {

@@ -130,6 +130,22 @@ __device__ __forceinline__ bool block_to_pair(int bid, int B, int L, int& b, int
   return b < B;
 }
 
+// gfx950 transposing LDS read: each 16-lane group fetches a 4 x 16 block of 16-bit elements transposed
+__device__ __forceinline__ bf16x4 lds_tr16(const short* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(const_cast<short*>(p)));
+}
+
+// Workgroup barrier on the LDS counter alone: the LDS traffic of every wave has landed, global loads and stores stay
+// in flight (a __syncthreads() drains them too).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// C/D row of accumulator register g in lane half h (32x32 MFMA)
+__device__ __forceinline__ constexpr int crow(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
+
 // arguments of the fused forward kernel (coattn_fused.hip)
 struct FwdArgs {
   const float* V;        // [B][d][N] (lm = 0) or [B][N][d] (lm = 1), sample stride v_sB
@@ -147,6 +163,26 @@ struct FwdArgs {
   unsigned long long* stamps;   // diagnostic builds only
   int B, N, T, d, L;
 };
+
+// arguments of the two big fused backward kernels (coattn_fused_bwd.hip, coattn_bwd32.hip)
+struct BwdArgs {
+  const float* Pv;        // [B][N][d]
+  const float* Pq;        // [L][B][T][d]
+  const float* C;         // [L][B][T][N]
+  const float* dsv;       // [L][B][N]
+  const float* dZq;       // [L][B][T][d]
+  const float* wv;
+  float* dPv;             // [L][B][N][d]
+  float* dPq;             // [L][B][T][d]
+  float* dA;              // [L][B][T][N]
+  float* dwv_part;        // [L*B][d]
+  float* dbv_part;        // [L*B][d]   sum_n dP_v[n][:]
+  float* dbq_part;        // [L*B][d]   sum_t dP_q[t][:]
+  int B, N, T, d, L;
+};
+
+// dP_q on the bf16 MFMA 32x32x16 with the exact 3-way split (coattn_bwd32.hip); same shapes as the fused forward
+int launch_bwd_dpq32(const BwdArgs& a, hipStream_t s);
 
 // bf16-split forward kernel on the 32x32x16 MFMA (coattn_fwd32.hip)
 int fused32_forward(const FwdArgs& a, hipStream_t s);

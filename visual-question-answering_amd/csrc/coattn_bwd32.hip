@@ -1,22 +1,26 @@
-// Fused backward, question side: dP_q = dZ_q + C dZ_v   (autograd of model.py:380-388; SURVEY.md section 8 "Backward").
+// Fused backward in the orientation [locations][channels]: dP_q = dZ_q + C dZ_v, dP_v = dZ_v + C^T dZ_q, dw_v, db_v, db_q
+// (autograd of model.py:380-388; SURVEY.md section 8 "Backward").
 //
-// bwd_dpq32_kernel<NT,NW>: one workgroup per (sample, level), NW waves owning 128-channel slices, on the bf16 MFMA
+// bwd_nat32_kernel<NT,NW>: one workgroup per (sample, level), NW waves owning 128-channel slices, on the bf16 MFMA
 // 32x32x16 with the exact 3-way split (fused.h) -- the backward twin of the forward kernel's phase 2
 // (coattn_fwd32.hip), whose operand layouts it shares:
 //   * C (saved) is split once into the LDS image [piece][n][32 t]; row reads give C^T fragments (A operand of
-//     H_v = P_v + C^T P_q), transposing reads give C fragments (A operand of dP_q += C dZ_v);
+//     H_v = P_v + C^T P_q and of dP_v = dZ_v + C^T dZ_q), transposing reads give C fragments (A operand of
+//     dP_q += C dZ_v);
 //   * unit pipeline over 32-location x 32-channel fragments of P_v (accumulator-shaped, 128 contiguous bytes per half
 //     wave and load, two units ahead): the fragment is the accumulator of the recomputed H_v tile; tanh and
 //     dZ_v = ds_v w_v (1 - H_v^2) = 4 ds_v w_v r (1 - r), r = 1 / (1 + e^{2 H}), happen in place; split, the dZ_v
-//     fragment is the B operand of dP_q += C dZ_v (contraction over the fragment's row index = locations);
-//   * the dP_q accumulators start from dZ_q; db_q partials are in-lane sums over the accumulator rows.
+//     fragment is the B operand of dP_q += C dZ_v (contraction over the fragment's row index = locations), and then
+//     the accumulator of dP_v, stored as it lies (whole 128-byte row segments);
+//   * the dP_q accumulators start from dZ_q; dw_v, db_v, db_q partials are in-lane sums over the accumulator rows.
 // H_v is never stored.  Rows t >= T / n >= N fall outside the per-sample buffer descriptors (loads 0, stores dropped).
+// (dC, which contracts over the channels, needs the transposed orientation: bwd_dc_kernel, coattn_fused_bwd.hip.)
 #include "fused.h"
 
 namespace {
 
 template <int NT, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void bwd_dpq32_kernel(const BwdArgs a) {
+__global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) {
   constexpr int NPAD = 32 * NT;
   constexpr int PIECE = NPAD * 32;                   // bf16 elements of one piece of the C image [n][t = 32]
   constexpr int NTHR = NW * 64;
@@ -38,19 +42,24 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dpq32_kernel(const BwdArgs a) 
   const int nsl = d / (128 * NW);                    // 128-channel slices per wave (1 at d = 512)
   constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};   // smallest piece products first
 
-  // B operands of H_v (P_q, k index t = 16 ks + 8 h + i in lane half h), raw; split when needed
-  auto load_pq_nat = [&](int c0, f32x8 (&raw)[2][2]) {
-    int base = (8 * h * d + r) * 4;
-    asm volatile("" : "+v"(base));
+  const __amdgpu_buffer_rsrc_t rs_dpv = make_rsrc(a.dPv + pair * (size_t)N * d, (unsigned)N * d * 4u);
+  // B operands of a pass (32 channels c0 .. c0 + 31, lane r <-> channel c0 + r): P_q in the k order of the C^T rows
+  // (t = 16 ks + 8 h + i), raw; dZ_q accumulator-shaped (rows crow(g, h)), which is also the start of the dP_q
+  // accumulators -- its B-operand order comes from one v_permlane32_swap per register pair (coattn_fwd32.hip).
+  auto load_pass = [&](int c0, f32x8 (&praw)[2], f32x16& zf) {
+    int bn = (8 * h * d + r) * 4, bc = (4 * h * d + r) * 4;
+    asm volatile("" : "+v"(bn));
+    asm volatile("" : "+v"(bc));
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+      for (int i = 0; i < 8; ++i) praw[ks][i] = buf_load1(rs_pq, bn, (c0 + (16 * ks + i) * d) * 4);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) raw[ct][ks][i] = buf_load1(rs_pq, base + 128 * ct, (c0 + (16 * ks + i) * d) * 4);
+    for (int g = 0; g < 16; ++g) zf[g] = buf_load1(rs_dzq, bc, (c0 + ((g & 3) + 8 * (g >> 2)) * d) * 4);
   };
-  f32x8 pq_raw[2][2];
-  load_pq_nat(w * 128, pq_raw);                      // the first pass' operands fly under the image build
+  f32x8 pq_raw[2];
+  f32x16 zq_frag;
+  load_pass(w * 128, pq_raw, zq_frag);               // the first pass' operands fly under the image build
 
   // ---- the image of C (three bf16 pieces, [piece][n][t], 64-byte rows with XOR-swizzled 16-byte chunks) and ds_v
   {
@@ -78,7 +87,6 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dpq32_kernel(const BwdArgs a) 
   lds_barrier();
 
   const int ntiles = (N + 31) >> 5;
-  const int U = 2 * ntiles;
   // lane constants of the image reads (see coattn_fwd32.hip)
   const int tq = (lane & 15) >> 2, tp_ = lane & 3, g1 = (lane >> 4) & 1;
   const int tr_off0 = (4 * h + tq) * 32 + 8 * ((2 * g1 + (tp_ >> 1)) ^ h) + 4 * (tp_ & 1);
@@ -99,52 +107,53 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dpq32_kernel(const BwdArgs a) 
   };
 
 #pragma unroll 1
-  for (int pi = 0; pi < 2 * nsl; ++pi) {             // passes: 64 channels each, two per 128-channel slice
-    const int c0 = ((pi >> 1) * NW + w) * 128 + 64 * (pi & 1);
-    const int c0n = (((pi + 1) >> 1) * NW + w) * 128 + 64 * ((pi + 1) & 1);
-    const float wv4[2] = {4.0f * a.wv[c0 + r], 4.0f * a.wv[c0 + 32 + r]};
-    bf16x8 pqB[2][2][3];
+  for (int pi = 0; pi < 4 * nsl; ++pi) {             // passes: 32 channels each, four per 128-channel slice
+    const int c0 = ((pi >> 2) * NW + w) * 128 + 32 * (pi & 3);
+    const int c0n = (((pi + 1) >> 2) * NW + w) * 128 + 32 * ((pi + 1) & 3);
+    const float wv4 = 4.0f * a.wv[c0 + r];
+    bf16x8 pqB[2][3], zqB[2][3];
+    f32x16 accq = zq_frag;                           // dP_q = dZ_q + C dZ_v
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int ks = 0; ks < 2; ++ks) {
+      split3(pq_raw[ks], pqB[ks]);
+      f32x8 x;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) split3(pq_raw[ct][ks], pqB[ct][ks]);
-    // the dP_q accumulators start from dZ_q: register g of lane (r, h) <-> dZ_q[t = crow(g, h)][c0 + 32 ct + r]
-    f32x16 accq[2];
-    {
-      int base = (4 * h * d + r) * 4;
-      asm volatile("" : "+v"(base));
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int g = 0; g < 16; ++g)
-          accq[ct][g] = buf_load1(rs_dzq, base + 128 * ct, (c0 + ((g & 3) + 8 * (g >> 2)) * d) * 4);
+      for (int k = 0; k < 4; ++k) {
+        float lo = zq_frag[8 * ks + k], hi = zq_frag[8 * ks + 4 + k];
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+        x[k] = lo;
+        x[4 + k] = hi;
+      }
+      split3(x, zqB[ks]);
     }
+    float dwacc = 0.f, dbacc = 0.f;                  // this lane's column sums over its rows: dw_v, db_v
     f32x16 ring[4];
     u32x4 Ph[2], Pm[2], Pl[2];                       // split dZ_v of the previous unit (two k-steps of 16 locations)
-    // pv[g] = P_v[32 nt + crow(g, h)][c0 + 32 ct + r]; past the last tile: zeros through the buffer rule, no traffic
+    // pv[g] = P_v[32 nt + crow(g, h)][c0 + r]; past the last tile: zeros through the buffer rule, no traffic
     auto load_unit = [&](int u, f32x16& dst) {
 #pragma unroll
-      for (int g = 0; g < 16; ++g)
-        dst[g] = buf_load1(rs_pv, (crow(g, h) * d + r) * 4, (32 * (u >> 1) * d + c0 + 32 * (u & 1)) * 4);
+      for (int g = 0; g < 16; ++g) dst[g] = buf_load1(rs_pv, (crow(g, h) * d + r) * 4, (32 * u * d + c0) * 4);
     };
-    // One step = unit u.  First half: the 12 MFMAs of H_v(u) = P_v + C^T P_q on the fragment `cur`, each followed by a
-    // share of the split of dZ_v(u-1) (`dzp`).  Second half: the 12 MFMAs of dP_q += C dZ_v(u-1), each followed by a
-    // share of tanh / dZ_v of unit u, in place in `cur`.
-    auto step = [&](const int u, const int ct, f32x16& cur, const f32x16& dzp) {
-      const short* img = Cimg + 32 * (u >> 1) * 32;
-      const short* imgp = Cimg + 32 * ((u > 0 ? u - 1 : 0) >> 1) * 32;
+    // One step = unit u (location tile u of this pass' channels).
+    //  [a] the 12 MFMAs of H_v(u) = P_v + C^T P_q on the fragment `cur`; beside them the split of dZ_v(u-1) (`dzp`);
+    //  [b] the 12 MFMAs of dP_q += C dZ_v(u-1);
+    //  [c] the 12 MFMAs of dP_v(u-1) = dZ_v(u-1) + C^T dZ_q on `dzp` (already split), then its stores and db_v terms;
+    //      beside [b] and [c]: tanh / dZ_v of unit u in place in `cur`, and its dw_v terms.
+    auto step = [&](const int u, f32x16& cur, f32x16& dzp) {
+      const short* img = Cimg + 32 * u * 32;
+      const short* imgp = Cimg + 32 * (u > 0 ? u - 1 : 0) * 32;
       bf16x8 ca0[3], ca1[3], cq0[3], cq1[3];
       f32x4 dsn[4];
       read_ca(img, 0, ca0);
 #pragma unroll
       for (int m = 0; m < 12; ++m) {
         const int ks = m / 6, i = m % 6;
-        cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks ? ca1[PA[i]] : ca0[PA[i]], pqB[ct][ks][PB[i]], cur, 0, 0, 0);
+        cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks ? ca1[PA[i]] : ca0[PA[i]], pqB[ks][PB[i]], cur, 0, 0, 0);
         if (m == 1) read_ca(img, 1, ca1);           // operands are read one MFMA group ahead of their use
         if (m == 8) read_cq(imgp, 0, cq0);
         if (m == 11) {
 #pragma unroll
-          for (int gg = 0; gg < 4; ++gg) dsn[gg] = *reinterpret_cast<const f32x4*>(&dsvs[32 * (u >> 1) + 8 * gg + 4 * h]);
+          for (int gg = 0; gg < 4; ++gg) dsn[gg] = *reinterpret_cast<const f32x4*>(&dsvs[32 * u + 8 * gg + 4 * h]);
         }
         if (m < 8) {                                 // split pair m of dZ_v(u-1)
           unsigned hh, mm, ll;
@@ -153,24 +162,40 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dpq32_kernel(const BwdArgs a) 
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      const int ctp = ct ^ 1;                        // unit u-1's channel half
+      auto dz_reg = [&](const int g) {
+        const float rr = sig2_fast(cur[g]);
+        const float ds = dsn[g >> 2][g & 3];
+        dwacc = fmaf(ds, fmaf(-2.0f, rr, 1.0f), dwacc);               // ds_v[n] H_v[n][k]
+        cur[g] = fmaf(-rr, rr, rr) * ds * wv4;                        // r (1 - r) = (1 - tanh^2) / 4
+      };
 #pragma unroll
       for (int m = 0; m < 12; ++m) {
         const int ks = m / 6, i = m % 6;
         const bf16x8 bp = PB[i] == 0 ? __builtin_bit_cast(bf16x8, Ph[ks]) : PB[i] == 1 ? __builtin_bit_cast(bf16x8, Pm[ks])
                                                                                         : __builtin_bit_cast(bf16x8, Pl[ks]);
-        accq[ctp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks ? cq1[PA[i]] : cq0[PA[i]], bp, accq[ctp], 0, 0, 0);
+        accq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks ? cq1[PA[i]] : cq0[PA[i]], bp, accq, 0, 0, 0);
         if (m == 1) read_cq(imgp, 1, cq1);
-        // dZ_v of unit u in place: two registers beside each of the first four MFMAs, one beside each of the others
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int g = m < 4 ? 2 * m + q : m + 4;
-          if (q == 1 && m >= 4) continue;
-          const float rr = sig2_fast(cur[g]);
-          const float t = fmaf(-rr, rr, rr);         // r (1 - r) = (1 - tanh^2) / 4
-          cur[g] = t * dsn[g >> 2][g & 3] * wv4[ct];
-        }
+        if (m == 9) read_ca(imgp, 0, ca0);
+        if (m == 11) read_ca(imgp, 1, ca1);
+        if (m >= 4) dz_reg(m - 4);                   // dZ_v of unit u in place, registers 0 .. 7 (8 .. 15 follow in [c])
         __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int m = 0; m < 12; ++m) {
+        const int ks = m / 6, i = m % 6;
+        dzp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks ? ca1[PA[i]] : ca0[PA[i]], zqB[ks][PB[i]], dzp, 0, 0, 0);
+        if (m < 8) dz_reg(8 + m);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // dP_v(u-1) out (u = 0: zeros into rows that do not exist -- the offset lies outside the buffer)
+      const int so = u > 0 ? (32 * (u - 1) * d + c0) * 4 : 0x40000000;
+      const float live = u > 0 ? 1.f : 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        float v = dzp[g];
+        asm volatile("" : "+v"(v));                  // (opaque scalar: see the epilogue)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_dpv, (crow(g, h) * d + r) * 4, so, 0);
+        dbacc = fmaf(live, v, dbacc);
       }
     };
     load_unit(0, ring[0]);
@@ -178,78 +203,105 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dpq32_kernel(const BwdArgs a) 
 #pragma unroll
     for (int g = 0; g < 16; ++g) ring[3][g] = 0.f;   // "dZ_v of unit -1"
 #pragma unroll 1
-    for (int u0 = 0; u0 < U; u0 += 4) {              // U is even: units come in (ct = 0, ct = 1) pairs
+    for (int u0 = 0; u0 < ntiles; u0 += 4) {
       load_unit(u0 + 2, ring[2]);
       __builtin_amdgcn_sched_barrier(0);
-      step(u0, 0, ring[0], ring[3]);
+      step(u0, ring[0], ring[3]);
       __builtin_amdgcn_sched_barrier(0);
-      load_unit(u0 + 3, ring[3]);
-      __builtin_amdgcn_sched_barrier(0);
-      step(u0 + 1, 1, ring[1], ring[0]);
-      __builtin_amdgcn_sched_barrier(0);
-      if (u0 + 2 < U) {
+      if (u0 + 1 < ntiles) {
+        load_unit(u0 + 3, ring[3]);
+        __builtin_amdgcn_sched_barrier(0);
+        step(u0 + 1, ring[1], ring[0]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (u0 + 2 < ntiles) {
         load_unit(u0 + 4, ring[0]);
         __builtin_amdgcn_sched_barrier(0);
-        step(u0 + 2, 0, ring[2], ring[1]);
+        step(u0 + 2, ring[2], ring[1]);
         __builtin_amdgcn_sched_barrier(0);
+      }
+      if (u0 + 3 < ntiles) {
         load_unit(u0 + 5, ring[1]);
         __builtin_amdgcn_sched_barrier(0);
-        step(u0 + 3, 1, ring[3], ring[2]);
+        step(u0 + 3, ring[3], ring[2]);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // the last unit's dZ_v (a second channel half, tile ntiles - 1): split and accumulate
-    {
-      const f32x16& dz = (U & 2) ? ring[1] : ring[3];
-      const short* imgp = Cimg + 32 * (ntiles - 1) * 32;
-      bf16x8 cq0[3], cq1[3], b0[3], b1[3];
+    // the next pass' operands fly under the tail and the epilogue (beyond the last pass: channel offsets >= d,
+    // the values are never used)
+    load_pass(c0n, pq_raw, zq_frag);
+    // the last unit's dZ_v: split, dP_q and dP_v contributions, dP_v out
+    auto finish = [&](f32x16& dz) {
+      const int lu = ntiles - 1;
+      const short* imgp = Cimg + 32 * lu * 32;
+      bf16x8 cq0[3], cq1[3], ca0[3], ca1[3], b0[3], b1[3];
       read_cq(imgp, 0, cq0);
       read_cq(imgp, 1, cq1);
+      read_ca(imgp, 0, ca0);
+      read_ca(imgp, 1, ca1);
       split3(f32x8{dz[0], dz[1], dz[2], dz[3], dz[4], dz[5], dz[6], dz[7]}, b0);
       split3(f32x8{dz[8], dz[9], dz[10], dz[11], dz[12], dz[13], dz[14], dz[15]}, b1);
-      accq[1] = mfma32_x3(cq0, b0, accq[1]);
-      accq[1] = mfma32_x3(cq1, b1, accq[1]);
+      accq = mfma32_x3(cq0, b0, accq);
+      accq = mfma32_x3(cq1, b1, accq);
+      dz = mfma32_x3(ca0, zqB[0], dz);
+      dz = mfma32_x3(ca1, zqB[1], dz);
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        float v = dz[g];
+        asm volatile("" : "+v"(v));
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_dpv, (crow(g, h) * d + r) * 4,
+                                              (32 * lu * d + c0) * 4, 0);
+        dbacc += v;
+      }
+    };
+    switch ((ntiles - 1) & 3) {                      // uniform: the ring slot of the last unit
+      case 0: finish(ring[0]); break;
+      case 1: finish(ring[1]); break;
+      case 2: finish(ring[2]); break;
+      default: finish(ring[3]); break;
     }
-    // the next pass' P_q operands fly under the epilogue (beyond the last pass: channel offsets >= d, never used)
-    load_pq_nat(c0n, pq_raw);
-    // epilogue: dP_q out; db_q partial = sum_t dP_q[t][:] (rows t >= T are exact zeros)
+    // epilogue: dP_q out; db_q = sum_t dP_q[t][:] (rows t >= T are exact zeros), dw_v, db_v partials of this
+    // (sample, level): in-lane sums over the accumulator rows, then the two lane halves
     {
       int hrow = (4 * h * d + r) * 4;
       asm volatile("" : "+v"(hrow));
+      float s = 0.f;
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        float s = 0.f;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          // (through an opaque scalar: given bit_cast(accq[ct][g]) directly, hipcc (ROCm 7.2) stored element 0 sixteen
-          // times -- caught by the parity tests)
-          float v = accq[ct][g];
-          asm volatile("" : "+v"(v));
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_dpq,
-                                                hrow + (((g & 3) + 8 * (g >> 2)) * d + 32 * ct) * 4, c0 * 4, 0);
-          s += v;
-        }
-        s += __shfl_xor(s, 32, 64);
-        if (h == 0) a.dbq_part[pair * (size_t)d + c0 + 32 * ct + r] = s;
+      for (int g = 0; g < 16; ++g) {
+        // (through an opaque scalar: given bit_cast(accq[g]) directly, hipcc (ROCm 7.2) stored element 0 sixteen
+        // times -- caught by the parity tests)
+        float v = accq[g];
+        asm volatile("" : "+v"(v));
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_dpq,
+                                              hrow + ((g & 3) + 8 * (g >> 2)) * d * 4, c0 * 4, 0);
+        s += v;
+      }
+      s += __shfl_xor(s, 32, 64);
+      dwacc += __shfl_xor(dwacc, 32, 64);
+      dbacc += __shfl_xor(dbacc, 32, 64);
+      if (h == 0) {
+        a.dbq_part[pair * (size_t)d + c0 + r] = s;
+        a.dwv_part[pair * (size_t)d + c0 + r] = dwacc;
+        a.dbv_part[pair * (size_t)d + c0 + r] = dbacc;
       }
     }
   }
 }
 
 template <int NT, int NW>
-int launch_dpq32(const BwdArgs& a, hipStream_t s) {
+int launch_nat32(const BwdArgs& a, hipStream_t s) {
   constexpr int NPAD = 32 * NT;
   const size_t lds = (size_t)3 * NPAD * 32 * 2 + (size_t)NPAD * 4;
   const int groups = (a.B + 7) / 8;
-  hipLaunchKernelGGL((bwd_dpq32_kernel<NT, NW>), dim3(groups * a.L * 8), dim3(NW * 64), lds, s, a);
-  CA_CHECK_LAUNCH("bwd_dpq32");
+  hipLaunchKernelGGL((bwd_nat32_kernel<NT, NW>), dim3(groups * a.L * 8), dim3(NW * 64), lds, s, a);
+  CA_CHECK_LAUNCH("bwd_nat32");
   return 0;
 }
 
 }  // namespace
 
-int launch_bwd_dpq32(const BwdArgs& a, hipStream_t s) {
+int launch_bwd_nat32(const BwdArgs& a, hipStream_t s) {
   const bool small_n = a.N <= 64;
-  if (a.d % 512 == 0) return small_n ? launch_dpq32<2, 4>(a, s) : launch_dpq32<7, 4>(a, s);
-  return small_n ? launch_dpq32<2, 2>(a, s) : launch_dpq32<7, 2>(a, s);
+  if (a.d % 512 == 0) return small_n ? launch_nat32<2, 4>(a, s) : launch_nat32<7, 4>(a, s);
+  return small_n ? launch_nat32<2, 2>(a, s) : launch_nat32<7, 2>(a, s);
 }

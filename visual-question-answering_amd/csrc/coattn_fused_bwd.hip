@@ -7,13 +7,13 @@
 //                   ds_v; da_q = Q gq -> ds_q; dZ_q = ds_q (x) w_q (.) (1 - H_q^2); dw_q / dc partials.
 //   bwd_dc_kernel   (per sample x level; the wave owns 128 channels, outer loop over 16-channel
 //                   tiles, inner over 16-location tiles, orientation [d][n]):
-//                   H_v^T tile = P_v^T + P_q^T C -> dZ_v^T -> dP_v^T = dZ_v^T + dZ_q^T C (stored),
-//                   dw_v partials, and dC += P_q dZ_v^T + dZ_q P_v^T with the dZ_v^T / P_v^T
-//                   accumulator registers reused directly as MFMA B operands (contraction over d);
-//                   cross-wave tree sum through LDS, dA = dC (.) (1 - C^2).
-//   bwd_dpq32_kernel (coattn_bwd32.hip; per sample x level, orientation [n][d], the loop of forward phase 2, on
+//                   H_v^T tile = P_v^T + P_q^T C -> dZ_v^T, and dC += P_q dZ_v^T + dZ_q P_v^T with the
+//                   dZ_v^T / P_v^T accumulator registers reused directly as MFMA B operands (contraction
+//                   over d); cross-wave tree sum through LDS, dA = dC (.) (1 - C^2).
+//   bwd_nat32_kernel (coattn_bwd32.hip; per sample x level, orientation [n][d], the loop of forward phase 2, on
 //                   the bf16 MFMA with the exact 3-way split): H_v tile -> dZ_v tile, which is the B operand of
-//                   dP_q += C dZ_v (contraction over N).
+//                   dP_q += C dZ_v (contraction over N) and then the accumulator of dP_v = dZ_v + C^T dZ_q
+//                   (stored as it lies); dw_v, db_v, db_q partials.
 //   then MFMA GEMMs: dQ = a_q (x) gq + dA V^T + dP_q W_q;  dV = sum_l (a_v (x) gv + Q^T dA) +
 //   (sum_l dP_v) W_v (skipped when the image features need no gradient);  dW_v, dW_q, biases.
 #include "fused.h"
@@ -232,10 +232,8 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc_kernel(const BwdArgs a) {
   const float* Pvp = a.Pv + (size_t)b * N * d;
   const float* Pqp = a.Pq + pair * (size_t)T * d;
   const float* dZqp = a.dZq + pair * (size_t)T * d;
-  float* dPvp = a.dPv + pair * (size_t)N * d;
   // rows n >= N fall outside these buffers: loads give 0, stores are dropped
   const __amdgpu_buffer_rsrc_t rs_pv = make_rsrc(Pvp, (unsigned)N * d * 4u);
-  const __amdgpu_buffer_rsrc_t rs_dpv = make_rsrc(dPvp, (unsigned)N * d * 4u);
   const __amdgpu_buffer_rsrc_t rs_pq = make_rsrc(Pqp, (unsigned)T * d * 4u);
   const __amdgpu_buffer_rsrc_t rs_dzq = make_rsrc(dZqp, (unsigned)T * d * 4u);
   const int voff = (j * d + 4 * q4) * 4;             // lane's row n = 16nt + j, channels db + 4q4..+3
@@ -253,12 +251,10 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc_kernel(const BwdArgs a) {
   for (int dt = 0; dt < 8 * nsl; ++dt) {
     const int db = ((dt >> 3) * NW + w) * 128 + 16 * (dt & 7);
     // per-channel-tile operands
-    float pqB[kTS], dzqB[kTS];                     // A[i = d = db + j][k = t = 4s + q4]
+    float pqB[kTS];                                // A[i = d = db + j][k = t = 4s + q4]
 #pragma unroll
-    for (int s = 0; s < kTS; ++s) {                // rows t >= T lie outside the buffers: read 0
+    for (int s = 0; s < kTS; ++s)                  // rows t >= T lie outside the buffers: read 0
       pqB[s] = buf_load1(rs_pq, ((4 * s + q4) * d + j) * 4, db * 4);
-      dzqB[s] = buf_load1(rs_dzq, ((4 * s + q4) * d + j) * 4, db * 4);
-    }
     f32x4 pqA[2], dzqA[2];                         // A[i = t = 16tt + j][k = d = db + 4*q4 + r]
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
@@ -266,7 +262,6 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc_kernel(const BwdArgs a) {
       dzqA[tt] = buf_load4(rs_dzq, ((16 * tt + j) * d + 4 * q4) * 4, db * 4);
     }
     const f32x4 wv4 = *reinterpret_cast<const f32x4*>(a.wv + db + 4 * q4);
-    f32x4 dwv4 = zero4, dbv4 = zero4;
     // transposed tiles, C/D layout: col = j <-> n, row = 4*q4 + r <-> channel db + 4*q4 + r
     auto load_pvT = [&](int nt) { return buf_load4(rs_pv, voff, (16 * nt * d + db) * 4); };
     f32x4 pvT_q[3];                                    // prefetch ring, two tiles ahead
@@ -293,18 +288,8 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc_kernel(const BwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float h = tanh_fast(hv[r]);
-        dwv4[r] = fmaf(dsn, h, dwv4[r]);
         dzv[r] = dsn * wv4[r] * (1.0f - h * h);
       }
-      // dP_v^T tile = dZ_v^T + dZ_q^T C
-      f32x4 dpv = dzv, dpv2 = zero4;
-#pragma unroll
-      for (int s = 0; s < kTS; ++s) {
-        if (s & 1) dpv2 = mfma16(dzqB[s], cB[s], dpv2); else dpv = mfma16(dzqB[s], cB[s], dpv);
-      }
-      dpv += dpv2;
-      buf_store4(dpv, rs_dpv, voff, (16 * nt * d + db) * 4);
-      dbv4 += dpv;                                   // rows n >= N are exact zeros
       // dC[t][n] += sum_r P_q[t][db+4q4+r] dZ_v[n][..] + dZ_q[t][..] P_v[n][..]
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -314,16 +299,6 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc_kernel(const BwdArgs a) {
         acc[1][nt] = mfma16(dzqA[1][r], pvT[r], acc[1][nt]);
       }
       __builtin_amdgcn_sched_barrier(0);               // keep live ranges per tile (no cross-tile hoisting)
-    }
-    // dw_v[db + 4*q4 + r] partial of this (sample, level): sum over the 16 lanes (locations)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      dwv4[r] = row16_sum(dwv4[r]);
-      dbv4[r] = row16_sum(dbv4[r]);
-    }
-    if (j == 0) {
-      *reinterpret_cast<f32x4*>(a.dwv_part + pair * (size_t)d + db + 4 * q4) = dwv4;
-      *reinterpret_cast<f32x4*>(a.dbv_part + pair * (size_t)d + db + 4 * q4) = dbv4;
     }
   }
 
@@ -503,7 +478,7 @@ int launch_main(const BwdArgs& a, hipStream_t s) {
   dim3 grid(groups * a.L * 8), block(NW * 64);
   hipLaunchKernelGGL((bwd_dc_kernel<NT, NW>), grid, block, lds_dc, s, a);
   CA_CHECK_LAUNCH("bwd_dc");
-  return launch_bwd_dpq32(a, s);                     // dP_q, db_q (coattn_bwd32.hip)
+  return launch_bwd_nat32(a, s);                     // dP_q, dP_v, dw_v, db_v, db_q (coattn_bwd32.hip)
   return 0;
 }
 

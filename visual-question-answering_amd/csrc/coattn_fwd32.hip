@@ -149,7 +149,6 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
   // buffer resources over exactly this sample's tensors: rows beyond T / N read as 0, stores there are dropped
   const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(Qp, (unsigned)T * d * 4u);
   const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(Vp, (unsigned)d * N * 4u);
-  const __amdgpu_buffer_rsrc_t rs_pv = make_rsrc(Pvp, (unsigned)N * d * 4u);
   const __amdgpu_buffer_rsrc_t rs_pq = make_rsrc(Pqp, (unsigned)T * d * 4u);
   const int nsl = d / (128 * NW);                    // 128-channel slices per wave (1 at d = 512)
 

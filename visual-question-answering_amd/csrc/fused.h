@@ -182,7 +182,7 @@ struct BwdArgs {
 };
 
 // dP_q on the bf16 MFMA 32x32x16 with the exact 3-way split (coattn_bwd32.hip); same shapes as the fused forward
-int launch_bwd_dpq32(const BwdArgs& a, hipStream_t s);
+int launch_bwd_nat32(const BwdArgs& a, hipStream_t s);
 
 // bf16-split forward kernel on the 32x32x16 MFMA (coattn_fwd32.hip)
 int fused32_forward(const FwdArgs& a, hipStream_t s);

@@ -34,11 +34,12 @@ def test_inference_equals_training_forward_and_layouts():
     assert (torch.stack(v_cl).cpu() - f["v"]).abs().max() < 1e-4
 
 
-@pytest.mark.parametrize("layout", ["lm", "cm", "strided"])
+@pytest.mark.parametrize("layout", ["lm", "cm", "cm49", "strided"])
 def test_module_takes_the_features_where_they_lie(layout):
     """No copy between encoder and kernels for the two native layouts (the same storage is read; the gradient comes
-    back in the layout of x_img), a copy only for anything else; values and gradients equal the oracle's."""
-    B, N, T, d = 4, 49, 26, 512
+    back in the layout of x_img), a copy only for anything else -- that includes channel-major rows that are not
+    16-byte multiples (N = 49); values and gradients equal the oracle's."""
+    B, N, T, d = 4, (52 if layout == "cm" else 49), 26, 512
     m = _mod(d)
     V, Qs = O.make_inputs(B, N, T, d, 33, lens=[26, 17, 4, 1], scale_q=(2.0 / d) ** 0.5)
     P = O.make_params(d, 3)
@@ -46,7 +47,7 @@ def test_module_takes_the_features_where_they_lie(layout):
     gq = torch.from_numpy(O.hash_normal((3, B, d), 12)).float()
     if layout == "lm":
         x = V.cuda().permute(0, 2, 1).contiguous()                    # [B,N,d] contiguous
-    elif layout == "cm":
+    elif layout in ("cm", "cm49"):
         x = V.cuda().permute(0, 2, 1)                                 # permuted view of [B,d,N]
     else:
         x = torch.zeros(B, N, 2 * d, device="cuda")[:, :, ::2]        # neither: stride 2 along d
@@ -55,7 +56,7 @@ def test_module_takes_the_features_where_they_lie(layout):
     import sys
     import vqa_amd  # noqa: F401
     native = sys.modules["vqa_amd.coattention"]._native_layout(x)
-    assert (native.data_ptr() == x.data_ptr()) == (layout != "strided")
+    assert (native.data_ptr() == x.data_ptr()) == (layout in ("lm", "cm"))
     Qg = [q.cuda().requires_grad_(True) for q in Qs]
     v, q = m(x, Qg)
     (sum((v[l] * gv[l].cuda()).sum() + (q[l] * gq[l].cuda()).sum() for l in range(3))).backward()
@@ -63,7 +64,7 @@ def test_module_takes_the_features_where_they_lie(layout):
     g = O.coattn_backward(V, Qs, P, gv, gq)
     assert (torch.stack(v).cpu() - f["v"]).abs().max() < 1e-4 and (torch.stack(q).cpu() - f["q"]).abs().max() < 1e-4
     assert x.grad.shape == x.shape
-    if layout != "strided":
+    if layout in ("lm", "cm"):
         assert x.grad.stride() == x.stride()
     ref = g["dV_phys"].permute(0, 2, 1)
     assert (x.grad.cpu() - ref).abs().max() <= 1e-4 * ref.abs().max()

@@ -30,14 +30,18 @@ def _ptr(t):
 
 def _native_layout(x_img: torch.Tensor) -> torch.Tensor:
     """The module input x_img[B,N,d] as the kernels take it: by pointer + element strides, no copy, when it is
-    channel-major (the permuted view of an NCHW encoder, model.py:215-217: strides (d N, 1, N)) or location-major
-    (a channels_last encoder: contiguous [B,N,d]); anything else is made contiguous once."""
+    location-major (a channels_last encoder: contiguous [B,N,d]) or channel-major (the permuted view of an NCHW
+    encoder, model.py:215-217: strides (d N, 1, N)) with rows that are 16-byte multiples (N % 4 == 0: N = 196);
+    anything else is made contiguous -- location-major -- once.  That includes channel-major features at N = 49: their
+    196-byte rows push the projection GEMMs onto dword loads (2 x 80 us per step), a 16 MB re-layout costs 8 us."""
     B, N, d = x_img.shape
     sB, sN, sD = x_img.stride()
     if B == 1:
         sB = max(sB, N * d)                 # the stride of a size-1 dimension is arbitrary
     ext = (N - 1) * sN + (d - 1) * sD
-    if ((sD == 1 and sN == d) or (sN == 1 and sD == N)) and sB > ext and x_img.data_ptr() % 16 == 0:
+    lm = sD == 1 and sN == d
+    cm = sN == 1 and sD == N and N % 4 == 0
+    if (lm or cm) and sB > ext and x_img.data_ptr() % 16 == 0:
         return x_img
     return x_img.contiguous()
 

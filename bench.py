@@ -153,16 +153,15 @@ def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20):
         v, q = vqa_amd.coattention(x_img, Qs, *args)
         torch.autograd.backward([v, q], [gv, gq])
 
-    for _ in range(3):
+    for _ in range(2 * iters):                     # clock warm-up (see roofline_leg): ~40 ms of back-to-back calls
         fb()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
     e0.record()
-    for _ in range(iters):
+    for _ in range(3 * iters):
         fb()
     e1.record()
     torch.cuda.synchronize()
-    t_dev = e0.elapsed_time(e1) * 1e-3 / iters
+    t_dev = e0.elapsed_time(e1) * 1e-3 / (3 * iters)
     fwd = bwd = 0.0
     for it in range(iters + 3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -179,7 +178,7 @@ def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20):
             "coattn_fwd_bwd_wall_tflops": round(flop / ((fwd + bwd) / iters) / 1e12, 2)}
 
 
-def roofline_leg(device, B=160, N=196, T=26, d=512, L=3, iters=50, layout="lm"):
+def roofline_leg(device, B=160, N=196, T=26, d=512, L=3, iters=100, layout="lm"):
     """Average launch duration of the affinity+softmax+reduce forward kernel(s), HIP events on the
     launch stream (= torch's current stream, which the C-ABI call is given).  layout: physical layout of the
     image features, "lm" [B,N,d] (channels_last encoder: the train step's default) or "cm" [B,d,N] (NCHW)."""
@@ -207,13 +206,22 @@ def roofline_leg(device, B=160, N=196, T=26, d=512, L=3, iters=50, layout="lm"):
     _lib.check(lib.coattn_forward(*args), "coattn_forward")          # fills P_v / P_q in `saved`
     for _ in range(5):
         _lib.check(lib.coattn_attention_forward(*args), "coattn_attention_forward")
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
+    # Warm-up: the set-up above (weight init, synthetic features, the projection GEMMs) leaves the GPU idle for
+    # milliseconds and its clocks ramp back over the first ~30 ms of load -- 100-call windows started cold read
+    # 97-101, 91, 87 us per call; so 3 x `iters` untimed calls first, then three timed windows of `iters` calls each,
+    # the median window's average (all three are in the line: `windows_us`).
+    for _ in range(3 * iters):
         lib.coattn_attention_forward(*args)
-    e1.record()
-    torch.cuda.synchronize()
-    t = e0.elapsed_time(e1) * 1e-3 / iters
+    ts = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            lib.coattn_attention_forward(*args)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e-3 / iters)
+    t = sorted(ts)[1]
     alg = B * L * ALG_BYTES_PER_PAIR_LEVEL(N, T, d)
     ach = alg / t / 1e9
     traffic = None                                 # HBM bytes per launch from the committed rocprofv3 PMC passes
@@ -231,6 +239,7 @@ def roofline_leg(device, B=160, N=196, T=26, d=512, L=3, iters=50, layout="lm"):
             "kernel": "coattn_attention_fwd (affinity+tanh, H_v/H_q, scores, row-softmax, attended reductions)"
                       + (" [fused]" if fused else " [general-shape kernel sequence]"),
             "shape": {"B": B, "N": N, "T": T, "d": d, "L": L}, "v_layout": layout, "avg_launch_us": round(t * 1e6, 2),
+            "windows_us": [round(x * 1e6, 2) for x in ts], "calls_per_window": iters,
             "algorithmic_bytes": alg}
 
 
@@ -256,19 +265,25 @@ def projection_leg(device, B=160, N=196, d=512, iters=50):
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for _ in range(5):
         _lib.check(lib.coattn_gemm_f32(C.byref(gd), stream), "coattn_gemm_f32")
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
+    for _ in range(3 * iters):                     # clock warm-up, as in roofline_leg
         lib.coattn_gemm_f32(C.byref(gd), stream)
-    e1.record()
-    torch.cuda.synchronize()
-    t = e0.elapsed_time(e1) * 1e-3 / iters
+    ts = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            lib.coattn_gemm_f32(C.byref(gd), stream)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e-3 / iters)
+    t = sorted(ts)[1]
     flop = 2.0 * B * N * d * d
     split = os.environ.get("COATTN_GEMM_X3", "1") != "0" and N % 4 == 0
     ach = flop / t / 1e12
     return {"bound": "mfma", "achieved": round(ach, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(ach / 157.3, 4),
             "traffic": None, "kernel": "P_v projection GEMM (gemm_f32_vec_kernel%s)" % (", 3-way bf16 split" if split else ""),
-            "shape": {"M": B * N, "N": d, "K": d}, "avg_launch_us": round(t * 1e6, 2), "algorithmic_flops": flop,
+            "shape": {"M": B * N, "N": d, "K": d}, "avg_launch_us": round(t * 1e6, 2),
+            "windows_us": [round(x * 1e6, 2) for x in ts], "calls_per_window": iters, "algorithmic_flops": flop,
             "bf16_mfma_frac": round(6.0 * ach / 2500.0, 4) if split else None}
 
 

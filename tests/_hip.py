@@ -31,7 +31,7 @@ LAYOUTS = ("cm", "lm")      # channel-major [B,d,N] (the reference's NCHW encode
 
 
 def run_hip(V, Qs, P, gv=None, gq=None, impl="general", need_dv=True, accumulate=0, grads_init=None, bf16_proj=False,
-            layout="cm", return_ws=False):
+            layout="cm"):
     """V [B,d,N] (channel-major values; `layout` selects the PHYSICAL layout handed to the C-ABI: "cm" as is, "lm" a
     [B,N,d] buffer), Qs list of [B,T,d], P dict of reference-named params (CPU or CUDA tensors).
     Returns dict with v,q and saved state; with gv/gq also all gradients (dV_phys always as [B,d,N] values)."""
@@ -87,6 +87,4 @@ def run_hip(V, Qs, P, gv=None, gq=None, impl="general", need_dv=True, accumulate
     out["dQ"] = torch.stack(dQs)
     for k, g in zip(names, grads):
         out["d" + k] = g
-    if return_ws:
-        out["_ws_bwd"] = ws2                            # the backward workspace, for developer probes
     return out

@@ -288,6 +288,109 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
   }
 }
 
+// dQ_l[b][t][k] = a_q,l[t] gq_l[k] + sum_n dA_l[t][n] V[b][n][k]   (the image-feature part of dQ; dP_q W_q is added by
+// the GEMM that follows), location-major V.  One workgroup per (sample, 128-channel slice, level), 4 waves: a wave owns 32 channels and walks the
+// location tiles; the V fragment (accumulator-shaped: 128 contiguous bytes per half wave and load, three tiles ahead)
+// is split and used as the B operand (contraction over its row index = locations), the A operand is dA_l, split
+// once per workgroup into an LDS image [piece][t][n] whose n order inside every group of 16 is the accumulator row
+// order of a lane half (one 16-byte read per piece and k-step).
+template <int NT>
+__global__ __launch_bounds__(256) void bwd_dq32_kernel(const DqArgs a) {
+  constexpr int NPAD = 32 * NT;
+  constexpr int LDR = NPAD + 8;                      // image row stride (bf16): 8 consecutive rows cover the banks once
+  constexpr int PIECE = kTRows * LDR;                // rows t < 28 only: four workgroups fit a CU's LDS (lanes of rows
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 28 .. 31 read the next piece / the tail: finite, dropped)
+  short* img = reinterpret_cast<short*>(smem);
+  float* aqs = reinterpret_cast<float*>(smem + 3 * PIECE * 2 + 4 * LDR * 2);
+  // blocks i and i + 8 share an XCD (round-robin dispatch): the L levels of one (sample, channel slice) take
+  // consecutive slots of one XCD, so that V comes from HBM once and from that XCD's L2 for the other levels
+  int item, l;
+  if (!block_to_pair(blockIdx.x, a.B * (a.d / 128), a.L, item, l)) return;
+  const int nslice = a.d / 128, b = item / nslice, slice = item - b * nslice;
+  const int N = a.N, T = a.T, d = a.d;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const size_t pair = (size_t)l * a.B + b;
+  const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(a.V + (size_t)b * a.v_sB, (unsigned)N * d * 4u);
+  const __amdgpu_buffer_rsrc_t rs_da = make_rsrc(a.dA + pair * (size_t)T * N, (unsigned)T * N * 4u);
+  const int c0 = slice * 128 + 32 * w;
+  // fragment of tile nt: V[32 nt + crow(g, h)][c0 + r]; rows >= N read 0
+  auto load_tile = [&](int nt, f32x16& dst) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) dst[g] = buf_load1(rs_v, (crow(g, h) * d + c0 + r) * 4, 32 * nt * d * 4);
+  };
+  const int ntiles = (N + 31) >> 5;
+  f32x16 ring[4];                                    // three tiles in flight (a wave has <= 7 of them); <= 120 VGPRs keep
+  load_tile(0, ring[0]);                             // four workgroups on a CU
+  load_tile(1, ring[1]);
+  load_tile(2, ring[2]);
+  // ---- dA_l -> image: a thread takes (t, two neighbouring n); rows >= T and columns >= N read 0
+  constexpr int PER = (kTRows * (NPAD / 2) + 255) / 256;   // items per thread
+  float x0[PER], x1[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {                    // all the loads first: one memory latency, not PER of them
+    const int e = tid + 256 * k, t = e / (NPAD / 2), n = 2 * (e - t * (NPAD / 2));   // t >= 28: outside the buffer
+    x0[k] = buf_load1(rs_da, n < N ? (t * N + n) * 4 : 0x40000000, 0);
+    x1[k] = buf_load1(rs_da, n + 1 < N ? (t * N + n + 1) * 4 : 0x40000000, 0);
+  }
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int e = tid + 256 * k, t = e / (NPAD / 2), n = 2 * (e - t * (NPAD / 2));
+    unsigned hh, mm, ll;
+    split3_pair(x0[k], x1[k], hh, mm, ll);
+    const int m16 = n & 15;                          // n order inside a group of 16: bits 2 and 3 trade places
+    const int off = t * LDR + (n & ~15) + ((m16 & 3) | ((m16 & 4) << 1) | ((m16 & 8) >> 1));
+    if (t < kTRows) {                                // (the last sweep is partial)
+      *reinterpret_cast<unsigned*>(img + off) = hh;
+      *reinterpret_cast<unsigned*>(img + PIECE + off) = mm;
+      *reinterpret_cast<unsigned*>(img + 2 * PIECE + off) = ll;
+    }
+  }
+  if (tid < 32) aqs[tid] = tid < T ? a.aq[pair * (size_t)T + tid] : 0.f;
+  lds_barrier();
+  f32x16 acc;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+  auto tile = [&](int nt, const f32x16& v) {
+    bf16x8 b0[3], b1[3], a0[3], a1[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      a0[p] = *reinterpret_cast<const bf16x8*>(img + p * PIECE + r * LDR + 32 * nt + 8 * h);
+      a1[p] = *reinterpret_cast<const bf16x8*>(img + p * PIECE + r * LDR + 32 * nt + 16 + 8 * h);
+    }
+    split3(f32x8{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]}, b0);
+    split3(f32x8{v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]}, b1);
+    acc = mfma32_x3(a0, b0, acc);
+    acc = mfma32_x3(a1, b1, acc);
+  };
+#pragma unroll 1
+  for (int nt = 0; nt < ntiles; nt += 4) {
+    load_tile(nt + 3, ring[3]);
+    tile(nt, ring[0]);
+    if (nt + 1 < ntiles) { load_tile(nt + 4, ring[0]); tile(nt + 1, ring[1]); }
+    if (nt + 2 < ntiles) { load_tile(nt + 5, ring[1]); tile(nt + 2, ring[2]); }
+    if (nt + 3 < ntiles) { load_tile(nt + 6, ring[2]); tile(nt + 3, ring[3]); }
+  }
+  // dQ_l[b][t][c0 + r] = acc + a_q[t] gq[c0 + r]; rows t >= T lie outside the buffer
+  const __amdgpu_buffer_rsrc_t rs_dq = make_rsrc(a.dQ[l] + (size_t)b * T * d, (unsigned)T * d * 4u);
+  const float gqv = a.gq[pair * (size_t)d + c0 + r];
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    float v = fmaf(aqs[crow(g, h)], gqv, acc[g]);
+    asm volatile("" : "+v"(v));                      // (opaque scalar: see bwd_nat32_kernel's epilogue)
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_dq, (crow(g, h) * d + c0 + r) * 4, 0, 0);
+  }
+}
+
+template <int NT>
+int launch_dq32(const DqArgs& a, hipStream_t s) {
+  constexpr int NPAD = 32 * NT;
+  const size_t lds = (size_t)(3 * kTRows + 4) * (NPAD + 8) * 2 + 32 * 4;   // + 4 rows: what lanes 28 .. 31 of the last piece read
+  const int items = a.B * (a.d / 128);
+  hipLaunchKernelGGL((bwd_dq32_kernel<NT>), dim3(((items + 7) / 8) * a.L * 8), dim3(256), lds, s, a);
+  CA_CHECK_LAUNCH("bwd_dq32");
+  return 0;
+}
+
 template <int NT, int NW>
 int launch_nat32(const BwdArgs& a, hipStream_t s) {
   constexpr int NPAD = 32 * NT;
@@ -304,4 +407,8 @@ int launch_bwd_nat32(const BwdArgs& a, hipStream_t s) {
   const bool small_n = a.N <= 64;
   if (a.d % 512 == 0) return small_n ? launch_nat32<2, 4>(a, s) : launch_nat32<7, 4>(a, s);
   return small_n ? launch_nat32<2, 2>(a, s) : launch_nat32<7, 2>(a, s);
+}
+
+int launch_bwd_dq32(const DqArgs& a, hipStream_t s) {
+  return a.N <= 64 ? launch_dq32<2>(a, s) : launch_dq32<7>(a, s);
 }

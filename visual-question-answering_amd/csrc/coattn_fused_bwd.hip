@@ -348,11 +348,6 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc_kernel(const BwdArgs a) {
 // dQ_l[b][t][k] = a_q,l[t] gq_l[k] + sum_n dA_l[t][n] V[b][k][n]   for all levels with one pass over V.
 // grid (d/128, B); a wave owns 32 channels (two 16-wide MFMA column tiles); dA of the three levels is
 // staged zero-padded in LDS and read as MFMA A operands (16 bytes = 4 k-steps per ds_read_b128).
-struct DqArgs {
-  const float* V; long v_sB; const float* dA; const float* aq; const float* gq;
-  float* dQ[8];
-  int B, N, T, d, L;
-};
 
 // LM: V location-major [N][d] (dword loads, 64 contiguous bytes per 16 lanes); else channel-major [d][N].
 template <int NT, bool ALIGNED, bool LM = false>
@@ -543,7 +538,9 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     da.B = B; da.N = N; da.T = T; da.d = d; da.L = L;
     const bool al = (N % 4) == 0;
     dim3 grid(d / 128, B), block(256);
-    if (small_n) {
+    if (lm) {
+      CA_TRY(launch_bwd_dq32(da, s));                // location-major features: bf16 MFMA kernel (coattn_bwd32.hip)
+    } else if (small_n) {
       const size_t lds = (size_t)(3 * kTRows * (64 + 4) + 96) * sizeof(float);
       if (lm && al) hipLaunchKernelGGL((bwd_dq_kernel<4, true, true>), grid, block, lds, s, da);
       else if (lm) hipLaunchKernelGGL((bwd_dq_kernel<4, false, true>), grid, block, lds, s, da);

@@ -184,6 +184,15 @@ struct BwdArgs {
 // dP_q on the bf16 MFMA 32x32x16 with the exact 3-way split (coattn_bwd32.hip); same shapes as the fused forward
 int launch_bwd_nat32(const BwdArgs& a, hipStream_t s);
 
+// arguments of the dQ kernels (bwd_dq_kernel in coattn_fused_bwd.hip, bwd_dq32_kernel in coattn_bwd32.hip)
+struct DqArgs {
+  const float* V; long v_sB; const float* dA; const float* aq; const float* gq;
+  float* dQ[8];
+  int B, N, T, d, L;
+};
+// dQ_l = a_q (x) gq + dA_l V for location-major V on the bf16 MFMA with the exact 3-way split
+int launch_bwd_dq32(const DqArgs& a, hipStream_t s);
+
 // bf16-split forward kernel on the 32x32x16 MFMA (coattn_fwd32.hip)
 int fused32_forward(const FwdArgs& a, hipStream_t s);
 int launch_attend_v_lm(const float* V, long v_sB, const float* av, float* v_out, int B, int N, int d, int L, hipStream_t s);

@@ -288,8 +288,8 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
   }
 }
 
-// dQ_l[b][t][k] = a_q,l[t] gq_l[k] + sum_n dA_l[t][n] V[b][n][k]   (the image-feature part of dQ; dP_q W_q is added by
-// the GEMM that follows), location-major V.  One workgroup per (sample, 128-channel slice, level), 4 waves: a wave owns 32 channels and walks the
+// dQ_l[b][t][k] (+)= a_q,l[t] gq_l[k] + sum_n dA_l[t][n] V[b][n][k]   (the image-feature part of dQ, added onto the
+// dP_q W_q the projection GEMM has already written there when a.accumulate is set), location-major V.  One workgroup per (sample, 128-channel slice, level), 4 waves: a wave owns 32 channels and walks the
 // location tiles; the V fragment (accumulator-shaped: 128 contiguous bytes per half wave and load, three tiles ahead)
 // is split and used as the B operand (contraction over its row index = locations), the A operand is dA_l, split
 // once per workgroup into an LDS image [piece][t][n] whose n order inside every group of 16 is the accumulator row
@@ -373,9 +373,13 @@ __global__ __launch_bounds__(256) void bwd_dq32_kernel(const DqArgs a) {
   // dQ_l[b][t][c0 + r] = acc + a_q[t] gq[c0 + r]; rows t >= T lie outside the buffer
   const __amdgpu_buffer_rsrc_t rs_dq = make_rsrc(a.dQ[l] + (size_t)b * T * d, (unsigned)T * d * 4u);
   const float gqv = a.gq[pair * (size_t)d + c0 + r];
+  float prev[16];
+#pragma unroll
+  for (int g = 0; g < 16; ++g)
+    prev[g] = a.accumulate ? buf_load1(rs_dq, (crow(g, h) * d + c0 + r) * 4, 0) : 0.f;
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
-    float v = fmaf(aqs[crow(g, h)], gqv, acc[g]);
+    float v = fmaf(aqs[crow(g, h)], gqv, acc[g]) + prev[g];
     asm volatile("" : "+v"(v));                      // (opaque scalar: see bwd_nat32_kernel's epilogue)
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_dq, (crow(g, h) * d + c0 + r) * 4, 0, 0);
   }

@@ -530,9 +530,24 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     CA_TRY(launch_sum_all(ws + wo.dcs_part, (float*)pg->dc_v, (int64_t)L * B, accumulate, s));
     CA_TRY(launch_sum_all(ws + wo.dcs_part + (size_t)L * B, (float*)pg->dc_q, (int64_t)L * B, accumulate, s));
   }
+  // dQ_l (+)= dP_q,l W_q for all levels in one launch (batch z = level, C through the pointer table)
+  auto dq_projection = [&](bool onto_dq) -> int {
+    coattn_gemm_desc g = {};
+    g.A = ws + wo.dPq; g.a_sz = (int64_t)BTd; g.a_sm = d; g.a_sk = 1;
+    g.B = p->W_q; g.b_sk = d; g.b_sn = 1;
+    for (int l = 0; l < L; ++l) { g.c_ptrs[l] = dQ[l]; if (onto_dq) g.cin_ptrs[l] = dQ[l]; }
+    if (onto_dq) { g.cin_sm = d; g.cin_sn = 1; g.beta = 1.f; }
+    g.c_sm = d; g.c_sn = 1;
+    g.M = B * T; g.N = d; g.K = d; g.batch = L;
+    return gemm_proj(g);
+  };
   // 4. dQ_l = a_q (x) gq + dA V^T + dP_q W_q ;  dV = sum_l (a_v (x) gv + Q^T dA) + (sum_l dP_v) W_v
+  //    Location-major features: the projection writes dQ first and the dA V kernel adds onto it (the GEMM is 24 us
+  //    faster without an accumulate input); channel-major: the other way round.
+  if (lm) CA_TRY(dq_projection(false));
   {
     DqArgs da;
+    da.accumulate = lm ? 1 : 0;
     da.V = V; da.v_sB = vl.sB; da.dA = ws + wo.dA; da.aq = saved + so.aq; da.gq = gq;
     for (int l = 0; l < 8; ++l) da.dQ[l] = l < L ? dQ[l] : nullptr;
     da.B = B; da.N = N; da.T = T; da.d = d; da.L = L;
@@ -577,17 +592,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
       CA_TRY(launch_gemm_f32(g, s));
     }
   }
-  {
-    // dQ_l += dP_q,l W_q for all levels in one launch (batch z = level, C through the pointer table)
-    coattn_gemm_desc g = {};
-    g.A = ws + wo.dPq; g.a_sz = (int64_t)BTd; g.a_sm = d; g.a_sk = 1;
-    g.B = p->W_q; g.b_sk = d; g.b_sn = 1;
-    for (int l = 0; l < L; ++l) { g.c_ptrs[l] = dQ[l]; g.cin_ptrs[l] = dQ[l]; }
-    g.cin_sm = d; g.cin_sn = 1; g.beta = 1.f;
-    g.c_sm = d; g.c_sn = 1;
-    g.M = B * T; g.N = d; g.K = d; g.batch = L;
-    CA_TRY(gemm_proj(g));
-  }
+  if (!lm) CA_TRY(dq_projection(true));
   // sum dP_v over the levels in place into level 0 (one streaming pass for L = 3; folding the sum into
   // the weight-gradient GEMM's operand loads was measured slower: 302 vs 170 + 50 us)
   float* dPv = ws + wo.dPv;

@@ -189,6 +189,7 @@ struct DqArgs {
   const float* V; long v_sB; const float* dA; const float* aq; const float* gq;
   float* dQ[8];
   int B, N, T, d, L;
+  int accumulate;        // bwd_dq32_kernel: add onto dQ (which then already holds dP_q W_q) instead of overwriting it
 };
 // dQ_l = a_q (x) gq + dA_l V for location-major V on the bf16 MFMA with the exact 3-way split
 int launch_bwd_dq32(const DqArgs& a, hipStream_t s);

@@ -3,18 +3,21 @@
 //
 // "affinity + softmax + reduce" (model.py:377-392 after the projections), one workgroup per (sample b, level l),
 // NW = d/128 waves (4 at d = 512), two workgroups per CU:
-//   phase 1  A = Q V^T, K (= d) split over the waves: a wave streams its 128-channel slices of V straight from HBM
-//            into MFMA B operands (location-major V [N][d]: two 16-byte loads per lane and 16-channel step;
-//            channel-major V [d][N]: eight dword loads) and its slice of Q as A operands; the [32 x N] partial
-//            tiles are summed across waves through LDS in a fixed tree order; C = tanh(A) goes to `saved` and, split
+//   phase 1  A = Q V^T, K (= d) split over the waves: a wave streams its 128-channel slices of V and Q from HBM into a
+//            per-wave LDS ring by LDS-DMA (location-major V [N][d]: units of 32 rows x 128 bytes, every DMA instruction
+//            covers 8 whole cache lines; channel-major V [d][N]: units of 16 channel rows x 128 bytes) and reads them
+//            back as MFMA operands one unit ahead; the [32 x N] partial tiles are summed across waves through LDS in a
+//            fixed order; C = tanh(A) goes to `saved` and, split
 //            once into its three bf16 pieces, into ONE LDS image [piece][n][t] (64-byte rows, 16-byte chunks
 //            XOR-swizzled by (n >> 2) & 3) that serves both orientations conflict-free: row reads (ds_read_b128)
 //            give C^T as the A operand of H_v, transposing reads (ds_read_b64_tr_b16) give C as the A operand of H_q.
 //   phase 2  two passes per 128-channel slice (64 channels each), loop over 32-location tiles of P_v [N][d] (read
 //            once): the raw tile is split and is the B operand of H_q += C . P_v (contraction over n: the
 //            accumulator layout of a 32x32 tile IS the B-operand layout of the next MFMA), then the same registers
-//            accumulate H_v = P_v + C^T P_q (contraction over t, one 32-deep step); tanh, and
-//            s_v[n] += H_v[n][:] . w_v without ever writing H_v.
+//            accumulate H_v = P_v + C^T P_q (contraction over t, one 32-deep step); the score
+//            s_v[n] += H_v[n][:] . w_v is taken from 1 / (1 + e^{2 H}) without ever writing H_v (or the tanh), the
+//            16 score registers of a tile are summed over their channel lanes by a transposing butterfly;
+//            the H_q accumulators start from P_q.
 //   phase 3  score reduction over waves / passes in a fixed order, un-masked row softmax over N and over T
 //            (model.py:387-388) by wave shuffles, H_q saved, q = a_q^T Q.
 //   attend_v_lm_kernel : v_l = a_{v,l}^T V for all levels with one more pass over a location-major V.
@@ -22,19 +25,15 @@
 
 #include <stdlib.h>
 
-// Phase 1: number of 32-location tiles per k-step that run on the bf16 MFMA with the 3-way split (the others take the
-// f32 MFMA).  -1: the default share (6 of 7); tuning builds override it.
+// Developer switches of the phase-1 experiments (diagnostic builds only).
 #ifndef COATTN_P1_NODMA
 #define COATTN_P1_NODMA 0      // developer switches of the phase-1 experiments (wrong results when set)
 #endif
 #ifndef COATTN_P1_NOMATH
 #define COATTN_P1_NOMATH 0
 #endif
-#ifndef COATTN_P1_NB
+#ifndef COATTN_P1_NB          // channel-major stream: tiles per k-step on the bf16 MFMA (the others on the f32 MFMA); -1 = all
 #define COATTN_P1_NB -1
-#endif
-#ifndef COATTN_P1_RING
-#define COATTN_P1_RING 4
 #endif
 
 namespace {

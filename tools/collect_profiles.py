@@ -26,7 +26,8 @@ def one(pattern):
 line = [l for l in open(os.path.join(SRC, "bench.json")) if l.startswith("{")][-1]
 json.loads(line)
 open(os.path.join(DST, "%s_bench.json" % tag), "w").write(line)
-for leg, name in (("roofline", "roofline"), ("hot", "hot_path"), ("step", "full_step"), ("bench_stats", "bench")):
+for leg, name in (("roofline", "roofline"), ("hot", "hot_path"), ("step", "full_step"), ("bench_stats", "bench"),
+                  ("headline", "headline")):
     shutil.copy(one("%s/**/*kernel_stats.csv" % leg), os.path.join(DST, "%s_%s_kernel_stats.csv" % (tag, name)))
 shutil.copy(os.path.join(SRC, "pmc_traffic.json"), os.path.join(DST, "pmc_traffic.json"))
 

@@ -10,6 +10,8 @@ python3 bench.py > $O/bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- python3 bench.py --no-cpu-baseline > $O/bench_stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/roofline -- python3 bench.py --only roofline > $O/roofline.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/hot -- python3 bench.py --only hot > $O/hot.log 2>&1
+# the headline kernel alone (cfg-2 shape, location-major), timed exactly as bench.py's roofline leg times it
+ITERS=100 rocprofv3 --kernel-trace --stats --output-format csv -d $O/headline -- python3 tools/probe_fwd_one.py > $O/headline.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/step -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/step.log 2>&1
 rm -f $O/*/*/*kernel_trace.csv $O/hot/*/*_trace.csv
 # counter passes of the headline kernel: the cfg-2 shape, location-major features, nothing else in the process

@@ -177,16 +177,7 @@ typedef struct coattn_gemm_desc {
   const void* a_ptrs[8]; const void* b_ptrs[8]; void* c_ptrs[8]; const void* cin_ptrs[8];
   int ptr_by_inner; int b_imod;
   int kband_n; int kband_lo[3]; int kband_hi[3];
-  /* Optional: an operand also given as the three bf16 pieces of its exact split (x = hi + mid + lo; planes hi, mid,
-   * lo of 2-byte elements in the element layout of the fp32 tensor, plane p at + p * plane elements; 8-byte aligned).
-   * The fp32-accurate split kernel then stages the pieces as they are instead of splitting every element again in
-   * every workgroup (weights, and gradients produced by the fused kernels).  Paths that do not use the split
-   * kernel read A / B, which must still be valid. */
-  const void* a_split; const void* b_split; int64_t a_split_plane, b_split_plane;
 } coattn_gemm_desc;
-
-/* x[0..n) -> its three bf16 planes (n % 4 == 0; out: 3 * plane elements of 2 bytes, plane >= n, 8-byte aligned). */
-int coattn_split_planes(const void* x, void* out, int64_t n, int64_t plane, void* stream);
 
 int coattn_gemm_f32(const coattn_gemm_desc* g, void* stream);
 

@@ -178,51 +178,3 @@ def test_gemm_small_tile_dispatch(a_m, b_n):
     _gemm(kw)
     ref = (A.double().transpose(1, 2) if a_m else A.double()) @ (Bm.double() if b_n else Bm.double().transpose(1, 2))
     assert _rel(Cm, ref) < 2e-6
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("which", ["b", "a", "ab"])
-@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
-def test_presplit_operands_equal_in_kernel_split(which, layout):
-    """An operand handed over as the three bf16 planes of its exact split (coattn_split_planes) gives bit-identical
-    results to letting the split kernel split it: weights (B) and gradients (A) of the fused path."""
-    import ctypes as C
-    from vqa_amd import _lib
-    lib = _lib.load()
-    dev = torch.device("cuda:0")
-    torch.manual_seed(5)
-    M, N, K = 384, 256, 512
-    A = torch.randn(M, K, device=dev) if layout != "tn" else torch.randn(K, M, device=dev)
-    Bm = torch.randn(N, K, device=dev) if layout == "nt" else torch.randn(K, N, device=dev)
-    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-    def planes(x):
-        n = x.numel()
-        out = torch.empty(3 * n, dtype=torch.int16, device=dev)
-        _lib.check(lib.coattn_split_planes(x.data_ptr(), out.data_ptr(), n, n, stream), "coattn_split_planes")
-        return out
-
-    def run(pre_a, pre_b):
-        g = _lib.GemmDesc()
-        out = torch.full((M, N), float("nan"), device=dev)
-        g.A, g.B, g.C = A.data_ptr(), Bm.data_ptr(), out.data_ptr()
-        g.M, g.N, g.K, g.batch = M, N, K, 1
-        g.a_sm, g.a_sk = (K, 1) if layout != "tn" else (1, M)
-        g.b_sk, g.b_sn = (1, K) if layout == "nt" else (N, 1)
-        g.c_sm, g.c_sn = N, 1
-        keep = []
-        if pre_a:
-            keep.append(planes(A)); g.a_split, g.a_split_plane = keep[-1].data_ptr(), A.numel()
-        if pre_b:
-            keep.append(planes(Bm)); g.b_split, g.b_split_plane = keep[-1].data_ptr(), Bm.numel()
-        _lib.check(lib.coattn_gemm_f32(C.byref(g), stream), "coattn_gemm_f32")
-        torch.cuda.synchronize()
-        return out
-
-    ref = run(False, False)
-    got = run("a" in which, "b" in which)
-    assert torch.equal(ref, got)
-    a2 = A if layout != "tn" else A.t()
-    b2 = Bm.t() if layout == "nt" else Bm
-    exact = a2.double() @ b2.double()
-    assert (got.double() - exact).abs().max() <= 2e-6 * exact.abs().max()

@@ -13,7 +13,6 @@ CSRC = os.path.join(_HERE, "csrc")
 # every symbol include/coattn.h declares
 EXPORTS = ("coattn_version", "coattn_last_error", "coattn_fused_supported", "coattn_workspace_bytes",
            "coattn_forward", "coattn_attention_forward", "coattn_backward", "coattn_gemm_f32", "coattn_gemm_bf16",
-           "coattn_split_planes",
            "coattn_phrase_workspace_bytes", "coattn_phrase_forward", "coattn_phrase_backward",
            "coattn_ce_workspace_bytes", "coattn_ce_forward")
 
@@ -48,9 +47,7 @@ class GemmDesc(C.Structure):
                                             "cin_sm", "cin_sn", "cin_sz", "cin_mdiv", "cin_sdiv")]
                 + [("a_ptrs", C.c_void_p * 8), ("b_ptrs", C.c_void_p * 8), ("c_ptrs", C.c_void_p * 8),
                    ("cin_ptrs", C.c_void_p * 8), ("ptr_by_inner", C.c_int), ("b_imod", C.c_int),
-                   ("kband_n", C.c_int), ("kband_lo", C.c_int * 3), ("kband_hi", C.c_int * 3),
-                   ("a_split", C.c_void_p), ("b_split", C.c_void_p), ("a_split_plane", C.c_int64),
-                   ("b_split_plane", C.c_int64)])
+                   ("kband_n", C.c_int), ("kband_lo", C.c_int * 3), ("kband_hi", C.c_int * 3)])
 
 
 def build(verbose: bool = False) -> str:
@@ -87,7 +84,6 @@ def load() -> C.CDLL:
     lib.coattn_forward.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(Params),
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]
     lib.coattn_attention_forward.argtypes = lib.coattn_forward.argtypes
-    lib.coattn_split_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     lib.coattn_backward.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(Params),
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                     C.POINTER(C.c_void_p), C.POINTER(ParamGrads), C.c_int,

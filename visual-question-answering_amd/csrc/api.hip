@@ -87,11 +87,6 @@ extern "C" int coattn_gemm_f32(const coattn_gemm_desc* g, void* stream) {
   return launch_gemm_f32(*g, (hipStream_t)stream);
 }
 
-extern "C" int coattn_split_planes(const void* x, void* out, int64_t n, int64_t plane, void* stream) {
-  CA_CHECK_ARG(x && out, "split_planes: null argument");
-  return launch_split_planes((const float*)x, nullptr, (short*)out, n, plane, (hipStream_t)stream);
-}
-
 extern "C" int coattn_gemm_bf16(const coattn_gemm_desc* g, void* stream) {
   CA_CHECK_ARG(g != nullptr, "gemm: null descriptor");
   return launch_gemm_bf16in(*g, (hipStream_t)stream);

@@ -163,8 +163,6 @@ int launch_dtanh(const float* dC, const float* C, float* out, int64_t n, hipStre
 int launch_add_inplace(float* y, const float* x, int64_t n, int accumulate, hipStream_t s);
 // y += x1 + x2 in one pass
 int launch_add3_inplace(float* y, const float* x1, const float* x2, int64_t n, hipStream_t s);
-// x0 (and x1, or NULL) -> bf16 planes hi, mid, lo of the exact 3-way split: out[j][p][plane], n % 4 == 0
-int launch_split_planes(const float* x0, const float* x1, short* out, int64_t n, int64_t plane, hipStream_t s);
 // out[z][i][j] (+)= a[z][i] * g[z][j] with strides (o_sz, o_si, o_sj)
 int launch_rank1(const float* a, const float* g, float* out, int Z, int I, int J,
                  int64_t o_sz, int64_t o_si, int64_t o_sj, int accumulate, hipStream_t s);

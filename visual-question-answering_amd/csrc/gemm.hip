@@ -30,9 +30,6 @@ struct GemmK {
   const float* a_ptrs[8]; const float* b_ptrs[8]; float* c_ptrs[8]; const float* cin_ptrs[8];
   int ptr_by_inner, b_imod, xcd_group;
   int kband_n, kband_lo[3], kband_hi[3];
-  // MODE 2 only: an operand given as its three bf16 pieces (planes hi, mid, lo in the element layout of the f32
-  // tensor, plane p at + p * plane elements): staged as they are, no split arithmetic in the kernel
-  const short* Apre; const short* Bpre; long a_plane, b_plane;
 };
 
 // The split-row case and the precise tanh are kept OUT OF LINE: the epilogues below are fully unrolled over the
@@ -336,9 +333,6 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   f32x4 ra[FA], rb[4];
-  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  u32x2 rap[FA][3], rbp[4][3];                     // pre-split operands (MODE 2): four bf16 per piece
-  const bool a_pre = MODE == 2 && g.Apre != nullptr, b_pre = MODE == 2 && g.Bpre != nullptr;
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
   // operand base pointers of inner index ii (table lookups happen only here, not per K-step)
   auto base_a = [&](int ii) -> const float* {
@@ -354,29 +348,8 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
                                               : (long)z * g.b_sz + (long)ii * g.b_si)) + (long)kbeg * g.b_sk;
   };
   auto load_regs = [&](const float* Ab, const float* Bb, int klim) {     // K range % 4 == 0 on this path
-    if (a_pre) {
-      const short* Ash = g.Apre + (Ab - g.A);
-#pragma unroll
-      for (int i = 0; i < FA; ++i) {
-        const bool ok = a_ok[i] && a_k[i] < klim;
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          rap[i][p] = ok ? *reinterpret_cast<const u32x2*>(Ash + p * g.a_plane + a_off[i]) : u32x2{0u, 0u};
-      }
-    }
-    if (b_pre) {
-      const short* Bsh = g.Bpre + (Bb - g.B);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bool ok = b_ok[i] && b_k[i] < klim;
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          rbp[i][p] = ok ? *reinterpret_cast<const u32x2*>(Bsh + p * g.b_plane + b_off[i]) : u32x2{0u, 0u};
-      }
-    }
 #pragma unroll
     for (int i = 0; i < FA; ++i) {
-      if (a_pre) break;
       if constexpr (AM && BF && !TRA) {                          // 4 consecutive k of one row: strided dword loads
         const bool ok = a_ok[i] && a_k[i] < klim;
 #pragma unroll
@@ -387,7 +360,6 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (b_pre) break;
       if constexpr (BN_ && BF && !TRB) {
         const bool ok = b_ok[i] && b_k[i] < klim;
 #pragma unroll
@@ -421,24 +393,10 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
         *reinterpret_cast<u32x2*>(img + piece + off) = u32x2{m[0], m[1]};
         *reinterpret_cast<u32x2*>(img + 2 * piece + off) = u32x2{l[0], l[1]};
       };
-      if (a_pre) {
 #pragma unroll
-        for (int i = 0; i < FA; ++i)
+      for (int i = 0; i < FA; ++i) put(Ah, AIMG, a_lds[i], ra[i]);
 #pragma unroll
-          for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(Ah + p * AIMG + a_lds[i]) = rap[i][p];
-      } else {
-#pragma unroll
-        for (int i = 0; i < FA; ++i) put(Ah, AIMG, a_lds[i], ra[i]);
-      }
-      if (b_pre) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(Bh + p * BIMG + b_lds[i]) = rbp[i][p];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) put(Bh, BIMG, b_lds[i], rb[i]);
-      }
+      for (int i = 0; i < 4; ++i) put(Bh, BIMG, b_lds[i], rb[i]);
       return;
     }
     if constexpr (MODE == 1) {
@@ -794,15 +752,6 @@ static int launch_gemm_impl(const coattn_gemm_desc& d, hipStream_t s, int bf16) 
     g.c_ptrs[t] = (float*)d.c_ptrs[t]; g.cin_ptrs[t] = (const float*)d.cin_ptrs[t];
   }
   g.ptr_by_inner = d.ptr_by_inner; g.b_imod = d.b_imod;
-  // pre-split operands: honoured by the 3-way-split kernel only (bf16 == 2); every other path reads the f32 operand,
-  // which therefore has to be there unless the caller knows the shape takes the split kernel
-  g.Apre = bf16 == 2 ? (const short*)d.a_split : nullptr; g.a_plane = d.a_split_plane;
-  g.Bpre = bf16 == 2 ? (const short*)d.b_split : nullptr; g.b_plane = d.b_split_plane;
-  CA_CHECK_ARG(!(d.a_split && d.a_ptrs[0]) && !(d.b_split && (d.b_ptrs[0] || d.b_imod > 0)),
-               "gemm: pre-split operands do not combine with pointer tables / wrapped inner strides");
-  CA_CHECK_ARG((!d.a_split || (((uintptr_t)d.a_split | (uintptr_t)(2 * d.a_split_plane)) & 7) == 0) &&
-               (!d.b_split || (((uintptr_t)d.b_split | (uintptr_t)(2 * d.b_split_plane)) & 7) == 0),
-               "gemm: pre-split planes must be 8-byte aligned");
   g.kband_n = d.kband_n;
   if (d.kband_n > 0) {
     CA_CHECK_ARG(d.kband_n % 128 == 0 && (d.N + d.kband_n - 1) / d.kband_n <= 3, "gemm: kband_n must be a multiple of 128 with at most 3 bands");

@@ -2,7 +2,7 @@
 // (model.py:387-388), attended-feature reductions (model.py:391-392) and the element-wise
 // pieces of the hand-derived backward.  All HBM-bound; lanes run along
 // the contiguous axis, reductions are wave64 shuffles, results are deterministic (no atomics).
-#include "fused.h"
+#include "common.h"
 
 namespace {
 
@@ -190,22 +190,6 @@ __global__ __launch_bounds__(256) void add3_inplace_kernel(float* y, const float
   *yp = (*yp + reinterpret_cast<const f32x4*>(x1)[idx]) + reinterpret_cast<const f32x4*>(x2)[idx];
 }
 
-// x -> the three bf16 planes of its exact split (fused.h: split3_pair); up to two tensors of n4 float4 each per launch
-// (blockIdx.y), planes of tensor j at out + j * 3 * plane
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* x0, const float* x1, short* out, long n4, long plane) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= n4) return;
-  const f32x4 v = reinterpret_cast<const f32x4*>(blockIdx.y ? x1 : x0)[idx];
-  unsigned h[2], m[2], l[2];
-  split3_pair(v[0], v[1], h[0], m[0], l[0]);
-  split3_pair(v[2], v[3], h[1], m[1], l[1]);
-  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  short* o = out + (long)blockIdx.y * 3 * plane + 4 * idx;
-  *reinterpret_cast<u32x2*>(o) = u32x2{h[0], h[1]};
-  *reinterpret_cast<u32x2*>(o + plane) = u32x2{m[0], m[1]};
-  *reinterpret_cast<u32x2*>(o + 2 * plane) = u32x2{l[0], l[1]};
-}
-
 __global__ __launch_bounds__(256) void sum_all_kernel(const float* x, float* out, long n, int accumulate) {
   __shared__ float red[4];
   float acc = 0.f;
@@ -351,16 +335,6 @@ int launch_add_inplace(float* y, const float* x, int64_t n, int accumulate, hipS
   hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, x, (long)n,
                      accumulate);
   CA_CHECK_LAUNCH("add_inplace");
-  return 0;
-}
-
-int launch_split_planes(const float* x0, const float* x1, short* out, int64_t n, int64_t plane, hipStream_t s) {
-  CA_CHECK_ARG(n > 0 && (n & 3) == 0 && plane >= n && (plane & 3) == 0 &&
-                   ((((uintptr_t)x0) | ((uintptr_t)x1)) & 15) == 0 && (((uintptr_t)out) & 7) == 0,
-               "split_planes: n and plane must be multiples of 4, pointers aligned");
-  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n / 4 + 255) / 256), x1 ? 2 : 1), dim3(256), 0, s, x0, x1, out,
-                     (long)(n / 4), (long)plane);
-  CA_CHECK_LAUNCH("split_planes");
   return 0;
 }
 

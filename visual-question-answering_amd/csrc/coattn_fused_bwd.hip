@@ -527,8 +527,8 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     const float* src[4] = {ws + wo.dwv_part, ws + wo.dbv_part, ws + wo.dbq_part, ws + wo.dwq_part};
     float* dst[4] = {(float*)pg->dw_v, (float*)pg->db_v, (float*)pg->db_q, (float*)pg->dw_q};
     CA_TRY(launch_reduce_jobs(src, dst, 4, L * B, d, accumulate, s));
-    CA_TRY(launch_sum_all(ws + wo.dcs_part, (float*)pg->dc_v, (int64_t)L * B, accumulate, s));
-    CA_TRY(launch_sum_all(ws + wo.dcs_part + (size_t)L * B, (float*)pg->dc_q, (int64_t)L * B, accumulate, s));
+    CA_TRY(launch_sum_all2(ws + wo.dcs_part, (float*)pg->dc_v, ws + wo.dcs_part + (size_t)L * B, (float*)pg->dc_q,
+                           (int64_t)L * B, accumulate, s));
   }
   // dQ_l (+)= dP_q,l W_q for all levels in one launch (batch z = level, C through the pointer table)
   auto dq_projection = [&](bool onto_dq) -> int {

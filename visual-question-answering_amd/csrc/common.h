@@ -155,6 +155,7 @@ int launch_reduce_jobs(const float* const* src, float* const* dst, int njobs, in
                        hipStream_t s);
 // total (+)= sum of x[0..n)   (single block)
 int launch_sum_all(const float* x, float* out, int64_t n, int accumulate, hipStream_t s);
+int launch_sum_all2(const float* x0, float* out0, const float* x1, float* out1, int64_t n, int accumulate, hipStream_t s);
 // H[z][r][j] = ds[z][r] * w[j] * (1 - H^2)      (in place or out of place)
 int launch_dz(const float* ds, const float* w, const float* H, float* out, int64_t rows, int d, hipStream_t s);
 // dA = dC * (1 - C^2)

@@ -190,7 +190,11 @@ __global__ __launch_bounds__(256) void add3_inplace_kernel(float* y, const float
   *yp = (*yp + reinterpret_cast<const f32x4*>(x1)[idx]) + reinterpret_cast<const f32x4*>(x2)[idx];
 }
 
-__global__ __launch_bounds__(256) void sum_all_kernel(const float* x, float* out, long n, int accumulate) {
+// one workgroup per job (blockIdx.x): out_j = sum of x_j[0 .. n)   (fixed order)
+__global__ __launch_bounds__(256) void sum_all_kernel(const float* x0, float* out0, const float* x1, float* out1, long n,
+                                                      int accumulate) {
+  const float* x = blockIdx.x ? x1 : x0;
+  float* out = blockIdx.x ? out1 : out0;
   __shared__ float red[4];
   float acc = 0.f;
   for (long i = threadIdx.x; i < n; i += 256) acc += x[i];
@@ -307,8 +311,16 @@ int launch_reduce_partials(const float* part, float* out, int nparts, int64_t n,
 }
 
 int launch_sum_all(const float* x, float* out, int64_t n, int accumulate, hipStream_t s) {
-  hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(256), 0, s, x, out, (long)n, accumulate);
+  hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(256), 0, s, x, out, (const float*)nullptr, (float*)nullptr, (long)n,
+                     accumulate);
   CA_CHECK_LAUNCH("sum_all");
+  return 0;
+}
+
+// two sums of the same length in one launch
+int launch_sum_all2(const float* x0, float* out0, const float* x1, float* out1, int64_t n, int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(sum_all_kernel, dim3(2), dim3(256), 0, s, x0, out0, x1, out1, (long)n, accumulate);
+  CA_CHECK_LAUNCH("sum_all2");
   return 0;
 }
 

@@ -21,7 +21,9 @@ def _shapes():
            (3, 49, 26, 768, 3), (1, 196, 26, 1024, 2),
            # every tile count of the fused kernels' unit loops (1 .. 7 tiles of 32 locations; both tile-count templates)
            (2, 32, 5, 512, 3), (2, 33, 26, 512, 1), (1, 65, 3, 512, 2), (2, 97, 26, 512, 3), (1, 129, 7, 256, 3),
-           (2, 161, 26, 512, 2), (1, 193, 28, 512, 3)]
+           (2, 161, 26, 512, 2), (1, 193, 28, 512, 3),
+           # the widest hidden sizes the fused kernels take (4 and 8 channel slices per wave)
+           (1, 196, 26, 2048, 3), (1, 64, 28, 4096, 1)]
     for _ in range(14):
         d = rng.choice([4, 20, 36, 64, 100, 256, 512])
         out.append((rng.randint(1, 5), rng.randint(1, 210), rng.randint(1, 30), d, rng.randint(1, 3)))

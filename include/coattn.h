@@ -155,7 +155,7 @@ int coattn_ce_forward(const void* logits, const void* labels, void* loss, void* 
 /* ---- building blocks (exported for the per-kernel parity tests) ------------------------ */
 
 /* Strided, batched fp32 GEMM on the f32 MFMA:
- *   C[z](m,n) = act( sum_{i<inner} sum_k A[z,i](m,k) * B[z,i](k,n) + bias_n[n] + bias_m[m]
+ *   C[z](m,n) = act( out_scale * (sum_{i<inner} sum_k A[z,i](m,k) * B[z,i](k,n) + bias_n[n] + bias_m[m])
  *                    + beta * Cin[z](m,n) )
  * Row m of A / C / Cin lives at (m / mdiv) * sdiv + (m % mdiv) * sm (mdiv = 0: plain m * sm).
  * ksplit > 0: batch index z selects the k range [z*ksplit, min(K,(z+1)*ksplit)) instead.
@@ -177,6 +177,7 @@ typedef struct coattn_gemm_desc {
   const void* a_ptrs[8]; const void* b_ptrs[8]; void* c_ptrs[8]; const void* cin_ptrs[8];
   int ptr_by_inner; int b_imod;
   int kband_n; int kband_lo[3]; int kband_hi[3];
+  float out_scale;          /* 0 or 1: plain; else C = act(out_scale * (products + biases) + beta * Cin) */
 } coattn_gemm_desc;
 
 int coattn_gemm_f32(const coattn_gemm_desc* g, void* stream);

@@ -15,6 +15,8 @@ def _al64(n):
 
 
 def saved_views(saved, B, N, T, d, L):
+    # (P_v / P_q: on the fused path they are stored multiplied by 2 log2(e) -- csrc/fused.h, kPScale; tests do not
+    #  compare them with the oracle)
     o = 0
     out = {}
     for name, shape in (("P_v", (B, N, d)), ("P_q", (L, B, T, d)), ("C", (L, B, T, N)), ("a_v", (L, B, N)),

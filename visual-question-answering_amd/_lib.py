@@ -47,7 +47,8 @@ class GemmDesc(C.Structure):
                                             "cin_sm", "cin_sn", "cin_sz", "cin_mdiv", "cin_sdiv")]
                 + [("a_ptrs", C.c_void_p * 8), ("b_ptrs", C.c_void_p * 8), ("c_ptrs", C.c_void_p * 8),
                    ("cin_ptrs", C.c_void_p * 8), ("ptr_by_inner", C.c_int), ("b_imod", C.c_int),
-                   ("kband_n", C.c_int), ("kband_lo", C.c_int * 3), ("kband_hi", C.c_int * 3)])
+                   ("kband_n", C.c_int), ("kband_lo", C.c_int * 3), ("kband_hi", C.c_int * 3),
+                   ("out_scale", C.c_float)])
 
 
 def build(verbose: bool = False) -> str:

@@ -102,6 +102,7 @@ struct Ctx {
   hipStream_t s;
   VLayout vl;                 // element strides of x_img[B,N,d]
   bool bf16_proj = false;     // COATTN_FLAG_BF16_PROJ: the projections and their gradients on the bf16 MFMA
+  float pscale = 1.f;         // factor on P_v, P_q as stored (fused path: kPScale, fused.h)
 };
 
 int launch_proj(const Ctx& c, const coattn_gemm_desc& g) {
@@ -111,7 +112,7 @@ int launch_proj(const Ctx& c, const coattn_gemm_desc& g) {
 // P_v = V W_v^T + b_v   (model.py:380/384, evaluated once per sample)
 int proj_v(const Ctx& c, const float* V, const float* Wv, const float* bv, float* Pv) {
   coattn_gemm_desc g = {};
-  g.A = V; g.B = Wv; g.C = Pv; g.bias_n = bv;
+  g.A = V; g.B = Wv; g.C = Pv; g.bias_n = bv; g.out_scale = c.pscale;
   g.M = c.B * c.N; g.N = c.d; g.K = c.d; g.batch = 1;
   g.a_sm = c.vl.sN; g.a_sk = c.vl.sD;            // row m = (b, n): split rows unless the samples abut
   if (c.vl.sB != (int64_t)c.N * c.vl.sN) { g.a_mdiv = c.N; g.a_sdiv = c.vl.sB; }
@@ -166,7 +167,7 @@ int general_projections(const Ctx& c, const float* V, const float* const* Q, con
   // P_q of all levels in one launch: batch z = level, A from the pointer table
   coattn_gemm_desc g = {};
   for (int l = 0; l < c.L; ++l) g.a_ptrs[l] = Q[l];
-  g.B = p->W_q; g.C = sv + sp.Pq; g.c_sz = (int64_t)BTd; g.bias_n = p->b_q;
+  g.B = p->W_q; g.C = sv + sp.Pq; g.c_sz = (int64_t)BTd; g.bias_n = p->b_q; g.out_scale = c.pscale;
   g.M = c.B * c.T; g.N = c.d; g.K = c.d; g.batch = c.L;
   g.a_sm = c.d; g.a_sk = 1;
   g.b_sk = 1; g.b_sn = c.d;
@@ -386,6 +387,7 @@ static int forward_impl(const void* V, const VLayout& vl, const void* const* Q, 
   float* tail = (float*)ws + sp.total;
   Ctx c{B, N, T, d, L, (hipStream_t)stream, vl};
   c.bf16_proj = (flags & COATTN_FLAG_BF16_PROJ) != 0;
+  c.pscale = fused ? kPScale : 1.f;
   if (do_proj) CA_TRY(general_projections(c, (const float*)V, (const float* const*)Q, p, sv));
   if (!do_attn) return 0;
   if (fused)

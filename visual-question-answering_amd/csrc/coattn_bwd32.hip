@@ -163,7 +163,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
         __builtin_amdgcn_sched_barrier(0);
       }
       auto dz_reg = [&](const int g) {
-        const float rr = sig2_fast(cur[g]);
+        const float rr = sig2_scaled(cur[g]);
         const float ds = dsn[g >> 2][g & 3];
         dwacc = fmaf(ds, fmaf(-2.0f, rr, 1.0f), dwacc);               // ds_v[n] H_v[n][k]
         cur[g] = fmaf(-rr, rr, rr) * ds * wv4;                        // r (1 - r) = (1 - tanh^2) / 4

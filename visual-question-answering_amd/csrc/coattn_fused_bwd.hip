@@ -258,8 +258,10 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc_kernel(const BwdArgs a) {
     f32x4 pqA[2], dzqA[2];                         // A[i = t = 16tt + j][k = d = db + 4*q4 + r]
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
-      pqA[tt] = buf_load4(rs_pq, ((16 * tt + j) * d + 4 * q4) * 4, db * 4);
-      dzqA[tt] = buf_load4(rs_dzq, ((16 * tt + j) * d + 4 * q4) * 4, db * 4);
+      // dC needs P_q and P_v themselves: the saved ones carry the factor kPScale (fused.h), divided out here of P_q
+      // and -- through its partner -- of P_v
+      pqA[tt] = buf_load4(rs_pq, ((16 * tt + j) * d + 4 * q4) * 4, db * 4) * (1.0f / kPScale);
+      dzqA[tt] = buf_load4(rs_dzq, ((16 * tt + j) * d + 4 * q4) * 4, db * 4) * (1.0f / kPScale);
     }
     const f32x4 wv4 = *reinterpret_cast<const f32x4*>(a.wv + db + 4 * q4);
     // transposed tiles, C/D layout: col = j <-> n, row = 4*q4 + r <-> channel db + 4*q4 + r
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc_kernel(const BwdArgs a) {
       f32x4 dzv;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float h = tanh_fast(hv[r]);
+        const float h = tanh_scaled(hv[r]);
         dzv[r] = dsn * wv4[r] * (1.0f - h * h);
       }
       // dC[t][n] += sum_r P_q[t][db+4q4+r] dZ_v[n][..] + dZ_q[t][..] P_v[n][..]

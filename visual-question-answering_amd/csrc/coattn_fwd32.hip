@@ -602,8 +602,8 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
           }
           if (m >= 4 && m < 20) {                    // register g = m - 4 of unit u-1: its score term
             const int g = m - 4;
-            if (ct == 1) svp[g] = sig2_fast(prev[g]) * wvr[0];                    // u-1 was a first channel half
-            else svp[g] = fmaf(sig2_fast(prev[g]), wvr[1], svp[g]);              // second half: add the first
+            if (ct == 1) svp[g] = sig2_scaled(prev[g]) * wvr[0];                    // u-1 was a first channel half
+            else svp[g] = fmaf(sig2_scaled(prev[g]), wvr[1], svp[g]);              // second half: add the first
             asm volatile("" : "+v"(svp[g]));         // computed HERE (machine sinking would move it to its use)
           }
           if (ct == 0) {                             // the tile's 16 score registers: transposing sum over the row
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
       auto finish_last = [&](const f32x16& pv) -> float {
         float x[16];
 #pragma unroll
-        for (int g = 0; g < 16; ++g) x[g] = fmaf(sig2_fast(pv[g]), wvr[1], svp[g]);
+        for (int g = 0; g < 16; ++g) x[g] = fmaf(sig2_scaled(pv[g]), wvr[1], svp[g]);
         return row16_sum16(x, lane);
       };
       CA_STAMP(8 + 3 * pi);
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
           const float wq = a.wq[c0 + 32 * ct + r];
 #pragma unroll
           for (int g = 0; g < 16; ++g) {
-            const float hq = tanh_fast(accq[ct][g]);
+            const float hq = tanh_scaled(accq[ct][g]);          // P_q, P_v carry the factor 2 log2(e) (fused.h: kPScale)
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hq), rs_hq, eoff(g, ct), c0 * 4, 0);
             part[g] = ct ? fmaf(hq, wq, part[g]) : hq * wq;
           }

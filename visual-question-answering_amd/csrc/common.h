@@ -87,6 +87,10 @@ __device__ __forceinline__ float sig2_fast(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
 }
 
+// the same for an argument that already carries the factor 2 log2(e) (fused.h: kPScale)
+__device__ __forceinline__ float sig2_scaled(float xs) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xs)); }
+__device__ __forceinline__ float tanh_scaled(float xs) { return fmaf(-2.0f, sig2_scaled(xs), 1.0f); }
+
 // sum over the 16 lanes of a DPP row (lanes sharing lane>>4); result valid in every lane
 __device__ __forceinline__ float row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]

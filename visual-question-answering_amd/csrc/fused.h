@@ -45,6 +45,12 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
 
 
 // ---- shared by the fused forward / backward translation units -------------------------------
+// The fused path keeps the projections P_v, P_q in `saved` MULTIPLIED by 2 log2(e): every consumer needs them only
+// inside tanh(P_v + C^T P_q) / tanh(P_q + C P_v) = 1 - 2 / (1 + 2^(scaled argument)), so the scale -- applied once by
+// the projection GEMMs' epilogue -- saves the multiplication in front of every exponential of the forward and the
+// backward; the two places that need P itself (the dC terms of bwd_dc_kernel) divide it out of their 16 operands.
+// The general-shape path keeps plain P_v, P_q.
+constexpr float kPScale = 2.8853900817779268f;
 constexpr int kTS = 7;       // k-steps of 4 over T: T <= 28
 constexpr int kTRows = 28;   // rows of C kept in LDS
 constexpr int kSlotRows = 32; // rows of a cross-wave reduction slot (both 16-row MFMA tiles)

@@ -21,7 +21,7 @@ struct GemmK {
   const float* A; const float* B; const float* Cin; float* C;
   const float* bias_n; const float* bias_m;
   int M, N, K, inner, inner_total, ksplit, act;
-  float beta;
+  float beta, oscale;                    // oscale: the products + biases are multiplied by it before Cin / act (1 = plain)
   int a_mfast, b_nfast;
   long a_sm, a_sk, a_sz, a_si, a_mdiv, a_sdiv;
   long b_sk, b_sn, b_sz, b_si;
@@ -185,6 +185,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmK g) {
         if (row < g.M && col < g.N) {
           float v = acc[i][j][r] + bn;
           if (g.bias_m) v += g.bias_m[row];
+          v *= g.oscale;
           if (Cinb) v += g.beta * Cinb[row_off(row, g.cin_sm, g.cin_mdiv, g.cin_sdiv) + (long)col * g.cin_sn];
           if (g.act == 1) v = tanh_outlined(v);
           Cb[row_off(row, g.c_sm, g.c_mdiv, g.c_sdiv) + (long)col * g.c_sn] = v;
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const GemmK g) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         if (!cok[j]) continue;
-        float v = acc[i][j][r] + bn[j] + bm;
+        float v = (acc[i][j][r] + bn[j] + bm) * g.oscale;
         if (cinrow) v += g.beta * cinrow[cincol[j]];
         if (g.act == 1) v = tanh_outlined(v);
         crow[ccol[j]] = v;
@@ -722,7 +723,7 @@ __global__ __launch_bounds__(256) void gemm_bf16in_kernel(const GemmK g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < g.M && col < g.N) Cb[row_off(row, g.c_sm, g.c_mdiv, g.c_sdiv) + (long)col * g.c_sn] = acc[i][j][r] + bn;
+        if (row < g.M && col < g.N) Cb[row_off(row, g.c_sm, g.c_mdiv, g.c_sdiv) + (long)col * g.c_sn] = (acc[i][j][r] + bn) * g.oscale;
       }
     }
 }
@@ -742,7 +743,7 @@ static int launch_gemm_impl(const coattn_gemm_desc& d, hipStream_t s, int bf16) 
   g.A = (const float*)d.A; g.B = (const float*)d.B; g.Cin = (const float*)d.Cin; g.C = (float*)d.C;
   g.bias_n = (const float*)d.bias_n; g.bias_m = (const float*)d.bias_m;
   g.M = d.M; g.N = d.N; g.K = d.K; g.inner = d.inner > 0 ? d.inner : 1; g.inner_total = d.inner_total;
-  g.ksplit = d.ksplit; g.act = d.act; g.beta = d.beta;
+  g.ksplit = d.ksplit; g.act = d.act; g.beta = d.beta; g.oscale = d.out_scale != 0.f ? d.out_scale : 1.f;
   g.a_sm = d.a_sm; g.a_sk = d.a_sk; g.a_sz = d.a_sz; g.a_si = d.a_si; g.a_mdiv = d.a_mdiv; g.a_sdiv = d.a_sdiv;
   g.b_sk = d.b_sk; g.b_sn = d.b_sn; g.b_sz = d.b_sz; g.b_si = d.b_si;
   g.c_sm = d.c_sm; g.c_sn = d.c_sn; g.c_sz = d.c_sz; g.c_mdiv = d.c_mdiv; g.c_sdiv = d.c_sdiv;
@@ -882,7 +883,7 @@ int launch_gemm_bf16in(const coattn_gemm_desc& d, hipStream_t s) {
   GemmK g = {};
   g.A = (const float*)d.A; g.B = (const float*)d.B; g.C = (float*)d.C; g.bias_n = (const float*)d.bias_n;
   for (int t = 0; t < 8; ++t) g.a_ptrs[t] = (const float*)d.a_ptrs[t];
-  g.M = d.M; g.N = d.N; g.K = d.K;
+  g.M = d.M; g.N = d.N; g.K = d.K; g.oscale = d.out_scale != 0.f ? d.out_scale : 1.f;
   g.a_sm = d.a_sm; g.a_sk = d.a_sk; g.a_sz = d.a_sz; g.a_mdiv = d.a_mdiv; g.a_sdiv = d.a_sdiv;
   g.b_sk = d.b_sk; g.b_sn = d.b_sn; g.b_sz = d.b_sz;
   g.c_sm = d.c_sm; g.c_sn = d.c_sn; g.c_sz = d.c_sz; g.c_mdiv = d.c_mdiv; g.c_sdiv = d.c_sdiv;

@@ -288,6 +288,194 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
   }
 }
 
+// dC = P_q dZ_v^T + dZ_q P_v^T, dA = dC (.) (1 - C^2)   -- the part of the backward that contracts over the CHANNELS, in
+// the orientation [channels][locations], on the bf16 MFMA with the exact 3-way split.
+// bwd_dc32_kernel<NT,NW>: one workgroup per (sample, level); the NW waves split the channels (128-channel slices, units
+// of 32), the location tiles are taken in groups of up to four (their dC accumulators: 64 registers).  A unit:
+//   * the transposed fragment P_v^T[k0 + crow(g, h)][32 nt + r] (16-byte loads, a lane per location row) is the
+//     accumulator of H_v^T = P_v^T + P_q^T C (A = P_q^T in its natural lane = channel order, B = C^T rows of the image)
+//     and, split, the B operand of dC += dZ_q P_v^T (contraction over the fragment's row index = channels);
+//   * dZ_v^T = 4 ds_v r (1 - r) in place (w_v is folded into the P_q operand), split, is the B operand of
+//     dC += (P_q w_v) dZ_v^T.
+// The saved P_v, P_q carry the factor kPScale (fused.h): right for the exponential, divided out of the two dC operands.
+// Cross-wave sum per location tile through LDS in a fixed order; rows t >= T / n >= N: loads 0, stores dropped.
+template <int NT, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void bwd_dc32_kernel(const BwdArgs a) {
+  constexpr int NPAD = 32 * NT, PIECE = NPAD * 32, NTHR = NW * 64, SLD = 36;
+  constexpr int GT = NT > 4 ? 4 : NT;                // location tiles per group
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  short* Cimg = reinterpret_cast<short*>(smem);
+  float* dsvs = reinterpret_cast<float*>(smem + 3 * PIECE * 2);      // [NPAD] ds_v, zero padded
+  float* slots = dsvs + NPAD;                                        // [NW][32 n][SLD]: one location tile per wave
+  int b, l;
+  if (!block_to_pair(blockIdx.x, a.B, a.L, b, l)) return;
+  const int N = a.N, T = a.T, d = a.d;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int tid = w * 64 + lane, r = lane & 31, h = lane >> 5;
+  const size_t pair = (size_t)l * a.B + b;
+  const __amdgpu_buffer_rsrc_t rs_pv = make_rsrc(a.Pv + (size_t)b * N * d, (unsigned)N * d * 4u);
+  const __amdgpu_buffer_rsrc_t rs_pq = make_rsrc(a.Pq + pair * (size_t)T * d, (unsigned)T * d * 4u);
+  const __amdgpu_buffer_rsrc_t rs_dzq = make_rsrc(a.dZq + pair * (size_t)T * d, (unsigned)T * d * 4u);
+  const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(a.C + pair * (size_t)T * N, (unsigned)T * N * 4u);
+  const __amdgpu_buffer_rsrc_t rs_da = make_rsrc(a.dA + pair * (size_t)T * N, (unsigned)T * N * 4u);
+  const int nsl = d / (128 * NW);
+  // ---- the image of C (as in bwd_nat32_kernel) and ds_v
+  {
+    constexpr int PER = 8 * NPAD / NTHR;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int e = tid + k * NTHR, tq = e / NPAD, n = e - tq * NPAD;
+      const int cvoff = n < N ? (4 * tq * N + n) * 4 : 0x40000000;
+      float c[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) c[i] = buf_load1(rs_c, cvoff, i * N * 4);
+      unsigned hh[2], mm[2], ll[2];
+      split3_pair(c[0], c[1], hh[0], mm[0], ll[0]);
+      split3_pair(c[2], c[3], hh[1], mm[1], ll[1]);
+      const int off = n * 32 + 8 * ((tq >> 1) ^ ((n >> 2) & 3)) + 4 * (tq & 1);
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      *reinterpret_cast<u32x2*>(Cimg + off) = u32x2{hh[0], hh[1]};
+      *reinterpret_cast<u32x2*>(Cimg + PIECE + off) = u32x2{mm[0], mm[1]};
+      *reinterpret_cast<u32x2*>(Cimg + 2 * PIECE + off) = u32x2{ll[0], ll[1]};
+    }
+    const float* dg = a.dsv + pair * (size_t)N;
+    for (int e = tid; e < NPAD; e += NTHR) dsvs[e] = e < N ? dg[e] : 0.f;
+  }
+  lds_barrier();
+  const int ntiles = (N + 31) >> 5;
+  const int rk = (r >> 2) & 3;
+  auto read_ca = [&](const short* img, const int ks, bf16x8 (&ca)[3]) {      // C^T rows: lane = location, 8 tokens
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      ca[p] = *reinterpret_cast<const bf16x8*>(img + p * PIECE + r * 32 + 8 * ((2 * ks + h) ^ rk));
+  };
+  auto split16 = [&](const f32x16& x, bf16x8 (&p0)[3], bf16x8 (&p1)[3]) {
+    split3(f32x8{x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]}, p0);
+    split3(f32x8{x[8], x[9], x[10], x[11], x[12], x[13], x[14], x[15]}, p1);
+  };
+  // the transposed fragment of tile nt, channels k0 ..: register 4 c + j <-> channel k0 + 8 c + 4 h + j = k0 + crow
+  auto load_frag = [&](int nt, int k0, f32x16& x) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const f32x4 v = buf_load4(rs_pv, (r * d + 4 * h) * 4, (32 * nt * d + k0 + 8 * c) * 4);
+      x[4 * c] = v[0]; x[4 * c + 1] = v[1]; x[4 * c + 2] = v[2]; x[4 * c + 3] = v[3];
+    }
+  };
+  constexpr float kInv = 1.0f / kPScale;
+
+#pragma unroll 1
+  for (int t0 = 0; t0 < ntiles; t0 += GT) {          // groups of location tiles
+    const int gt = ntiles - t0 < GT ? ntiles - t0 : GT;
+    f32x16 dC[GT];
+#pragma unroll
+    for (int ti = 0; ti < GT; ++ti)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) dC[ti][g] = 0.f;
+#pragma unroll 1
+    for (int cu = 0; cu < 4 * nsl; ++cu) {           // this wave's channel units of 32
+      const int k0 = ((cu >> 2) * NW + w) * 128 + 32 * (cu & 3);
+      bf16x8 pqB[2][3], pqA[2][3], zqA[2][3];
+      {
+        f32x8 raw[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) raw[ks][i] = buf_load1(rs_pq, (8 * h * d + r) * 4, (k0 + (16 * ks + i) * d) * 4);
+        f32x4 qa[2][2], za[2][2], wa[2][2];          // lane = token r: channels k0 + 16 ks + 4 h + {0..3}, + 8
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            qa[ks][u] = buf_load4(rs_pq, (r * d + 4 * h) * 4, (k0 + 16 * ks + 8 * u) * 4);
+            za[ks][u] = buf_load4(rs_dzq, (r * d + 4 * h) * 4, (k0 + 16 * ks + 8 * u) * 4);
+            wa[ks][u] = *reinterpret_cast<const f32x4*>(a.wv + k0 + 16 * ks + 8 * u + 4 * h);
+          }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          split3(raw[ks], pqB[ks]);
+          f32x8 x, z;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            x[i] = qa[ks][i >> 2][i & 3] * kInv * wa[ks][i >> 2][i & 3];
+            z[i] = za[ks][i >> 2][i & 3] * kInv;
+          }
+          split3(x, pqA[ks]);
+          split3(z, zqA[ks]);
+        }
+      }
+      f32x16 cur, nxt;
+      load_frag(t0, k0, nxt);
+#pragma unroll
+      for (int ti = 0; ti < GT; ++ti) {
+        if (ti >= gt) break;
+        const int nt = t0 + ti;
+        cur = nxt;
+        if (ti + 1 < GT) load_frag(nt + 1, k0, nxt);  // (past the group's last tile: a harmless extra request)
+        const short* img = Cimg + 32 * nt * 32;
+        bf16x8 F0[3], F1[3], Z0[3], Z1[3], ca[3];
+        split16(cur, F0, F1);
+        read_ca(img, 0, ca);
+        cur = mfma32_x3(pqB[0], ca, cur);
+        read_ca(img, 1, ca);
+        cur = mfma32_x3(pqB[1], ca, cur);
+        const float ds4 = 4.0f * dsvs[32 * nt + r];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const float rr = sig2_scaled(cur[g]);
+          cur[g] = fmaf(-rr, rr, rr) * ds4;
+        }
+        split16(cur, Z0, Z1);
+        dC[ti] = mfma32_x3(pqA[0], Z0, dC[ti]);
+        dC[ti] = mfma32_x3(pqA[1], Z1, dC[ti]);
+        dC[ti] = mfma32_x3(zqA[0], F0, dC[ti]);
+        dC[ti] = mfma32_x3(zqA[1], F1, dC[ti]);
+      }
+    }
+    // ---- the group's tiles: cross-wave sum in a fixed order, dA = dC (1 - C^2)
+#pragma unroll
+    for (int ti = 0; ti < GT; ++ti) {
+      if (ti >= gt) break;
+      const int nt = t0 + ti;
+      float* mine = slots + w * 32 * SLD;
+#pragma unroll
+      for (int gg = 0; gg < 4; ++gg)                 // registers 4 gg .. 4 gg + 3: four consecutive tokens of location r
+        *reinterpret_cast<f32x4*>(&mine[r * SLD + 8 * gg + 4 * h]) =
+            f32x4{dC[ti][4 * gg], dC[ti][4 * gg + 1], dC[ti][4 * gg + 2], dC[ti][4 * gg + 3]};
+      lds_barrier();
+      for (int tq = tid >> 5; tq < 8; tq += NTHR / 32) {
+        const int n = tid & 31;
+        f32x4 s = *reinterpret_cast<const f32x4*>(&slots[n * SLD + 4 * tq]);
+        s += *reinterpret_cast<const f32x4*>(&slots[32 * SLD + n * SLD + 4 * tq]);
+        if constexpr (NW == 4) {
+          f32x4 s2 = *reinterpret_cast<const f32x4*>(&slots[2 * 32 * SLD + n * SLD + 4 * tq]);
+          s2 += *reinterpret_cast<const f32x4*>(&slots[3 * 32 * SLD + n * SLD + 4 * tq]);
+          s += s2;
+        }
+        const int col = 32 * nt + n;
+        const int voff = col < N ? (4 * tq * N + col) * 4 : 0x40000000;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float c = buf_load1(rs_c, voff, i * N * 4);
+          const float v = s[i] * (1.0f - c * c);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_da, voff, i * N * 4, 0);
+        }
+      }
+      lds_barrier();
+    }
+  }
+}
+
+template <int NT, int NW>
+int launch_dc32(const BwdArgs& a, hipStream_t s) {
+  constexpr int NPAD = 32 * NT;
+  const size_t lds = (size_t)3 * NPAD * 32 * 2 + (size_t)NPAD * 4 + (size_t)NW * 32 * 36 * 4;
+  const int groups = (a.B + 7) / 8;
+  hipLaunchKernelGGL((bwd_dc32_kernel<NT, NW>), dim3(groups * a.L * 8), dim3(NW * 64), lds, s, a);
+  CA_CHECK_LAUNCH("bwd_dc32");
+  return 0;
+}
+
 // dQ_l[b][t][k] (+)= a_q,l[t] gq_l[k] + sum_n dA_l[t][n] V[b][n][k]   (the image-feature part of dQ, added onto the
 // dP_q W_q the projection GEMM has already written there when a.accumulate is set), location-major V.  One workgroup per (sample, 128-channel slice, level), 4 waves: a wave owns 32 channels and walks the
 // location tiles; the V fragment (accumulator-shaped: 128 contiguous bytes per half wave and load, three tiles ahead)
@@ -415,4 +603,10 @@ int launch_bwd_nat32(const BwdArgs& a, hipStream_t s) {
 
 int launch_bwd_dq32(const DqArgs& a, hipStream_t s) {
   return a.N <= 64 ? launch_dq32<2>(a, s) : launch_dq32<7>(a, s);
+}
+
+int launch_bwd_dc32(const BwdArgs& a, hipStream_t s) {
+  const bool small_n = a.N <= 64;
+  if (a.d % 512 == 0) return small_n ? launch_dc32<2, 4>(a, s) : launch_dc32<7, 4>(a, s);
+  return small_n ? launch_dc32<2, 2>(a, s) : launch_dc32<7, 2>(a, s);
 }

@@ -18,6 +18,8 @@
 //   (sum_l dP_v) W_v (skipped when the image features need no gradient);  dW_v, dW_q, biases.
 #include "fused.h"
 
+#include <stdlib.h>
+
 
 namespace {
 
@@ -471,6 +473,11 @@ int launch_main(const BwdArgs& a, hipStream_t s) {
   const size_t lds_dc = (size_t)((NSLOT * kSlotRows + kTRows) * LD + 16 * NT) * sizeof(float);
   static DeviceOnce once;                            // the attribute is per device
   CA_TRY(once.run([&] { return set_lds(bwd_dc_kernel<NT, NW>, lds_dc); }, "bwd_dc"));
+  static const bool dc_f32 = getenv("COATTN_BWD_DC_F32") != nullptr;     // developer switch: the exact-f32 MFMA dC kernel
+  if (!dc_f32) {
+    CA_TRY(launch_bwd_dc32(a, s));                   // dC, dA on the bf16 MFMA (coattn_bwd32.hip)
+    return launch_bwd_nat32(a, s);
+  }
   const int groups = (a.B + 7) / 8;
   dim3 grid(groups * a.L * 8), block(NW * 64);
   hipLaunchKernelGGL((bwd_dc_kernel<NT, NW>), grid, block, lds_dc, s, a);

@@ -189,6 +189,8 @@ struct BwdArgs {
 
 // dP_q on the bf16 MFMA 32x32x16 with the exact 3-way split (coattn_bwd32.hip); same shapes as the fused forward
 int launch_bwd_nat32(const BwdArgs& a, hipStream_t s);
+// dC and dA in the [channels][locations] orientation on the bf16 MFMA (coattn_bwd32.hip)
+int launch_bwd_dc32(const BwdArgs& a, hipStream_t s);
 
 // arguments of the dQ kernels (bwd_dq_kernel in coattn_fused_bwd.hip, bwd_dq32_kernel in coattn_bwd32.hip)
 struct DqArgs {

@@ -17,6 +17,10 @@
 // (dC, which contracts over the channels, needs the transposed orientation: bwd_dc_kernel, coattn_fused_bwd.hip.)
 #include "fused.h"
 
+#ifndef COATTN_DC_GT          // bwd_dc32_kernel: location tiles per group (their dC accumulators: 16 registers each)
+#define COATTN_DC_GT 4
+#endif
+
 namespace {
 
 template <int NT, int NW>
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
 template <int NT, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void bwd_dc32_kernel(const BwdArgs a) {
   constexpr int NPAD = 32 * NT, PIECE = NPAD * 32, NTHR = NW * 64, SLD = 36;
-  constexpr int GT = NT > 4 ? 4 : NT;                // location tiles per group
+  constexpr int GT = NT > COATTN_DC_GT ? COATTN_DC_GT : NT;   // location tiles per group
   extern __shared__ __attribute__((aligned(16))) char smem[];
   short* Cimg = reinterpret_cast<short*>(smem);
   float* dsvs = reinterpret_cast<float*>(smem + 3 * PIECE * 2);      // [NPAD] ds_v, zero padded
@@ -404,14 +408,16 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc32_kernel(const BwdArgs a) {
           split3(z, zqA[ks]);
         }
       }
-      f32x16 cur, nxt;
+      f32x16 cur, nxt, nx2;                          // two fragments in flight: nothing else hides their latency
       load_frag(t0, k0, nxt);
+      load_frag(t0 + 1, k0, nx2);
 #pragma unroll
       for (int ti = 0; ti < GT; ++ti) {
         if (ti >= gt) break;
         const int nt = t0 + ti;
         cur = nxt;
-        if (ti + 1 < GT) load_frag(nt + 1, k0, nxt);  // (past the group's last tile: a harmless extra request)
+        nxt = nx2;
+        if (ti + 2 < GT) load_frag(nt + 2, k0, nx2);  // (past the group's last tile: a harmless extra request)
         const short* img = Cimg + 32 * nt * 32;
         bf16x8 F0[3], F1[3], Z0[3], Z1[3], ca[3];
         split16(cur, F0, F1);

@@ -1,15 +1,15 @@
 // Fused backward of the parallel co-attention (hand-derived; SURVEY.md section 8, checked
-// against autograd of the reference by the oracle).  fp32; the kernels of this file use the exact-f32 MFMA 16x16x4.
+// against autograd of the reference by the oracle).  fp32 results; bwd_dq_kernel (channel-major V) uses the exact-f32
+// MFMA 16x16x4, the big kernels live in coattn_bwd32.hip on the bf16 MFMA.
 //
 // H_v [N,d] is never stored: both big kernels recompute it from P_v, P_q and C (saved).
 //
 //   bwd_pre_kernel  (per sample, all levels)  one pass over V: da_v = V gv -> softmax backward
 //                   ds_v; da_q = Q gq -> ds_q; dZ_q = ds_q (x) w_q (.) (1 - H_q^2); dw_q / dc partials.
-//   bwd_dc_kernel   (per sample x level; the wave owns 128 channels, outer loop over 16-channel
-//                   tiles, inner over 16-location tiles, orientation [d][n]):
-//                   H_v^T tile = P_v^T + P_q^T C -> dZ_v^T, and dC += P_q dZ_v^T + dZ_q P_v^T with the
-//                   dZ_v^T / P_v^T accumulator registers reused directly as MFMA B operands (contraction
-//                   over d); cross-wave tree sum through LDS, dA = dC (.) (1 - C^2).
+//   bwd_dc32_kernel (coattn_bwd32.hip; per sample x level, orientation [d][n], bf16 MFMA with the exact 3-way
+//                   split): H_v^T tile = P_v^T + P_q^T C -> dZ_v^T, and dC += P_q dZ_v^T + dZ_q P_v^T with the
+//                   dZ_v^T / P_v^T fragments as MFMA B operands (contraction over d); cross-wave sum through
+//                   LDS, dA = dC (.) (1 - C^2).
 //   bwd_nat32_kernel (coattn_bwd32.hip; per sample x level, orientation [n][d], the loop of forward phase 2, on
 //                   the bf16 MFMA with the exact 3-way split): H_v tile -> dZ_v tile, which is the B operand of
 //                   dP_q += C dZ_v (contraction over N) and then the accumulator of dP_v = dZ_v + C^T dZ_q
@@ -18,7 +18,6 @@
 //   (sum_l dP_v) W_v (skipped when the image features need no gradient);  dW_v, dW_q, biases.
 #include "fused.h"
 
-#include <stdlib.h>
 
 
 namespace {
@@ -192,163 +191,6 @@ __global__ __launch_bounds__(256) void bwd_pre_kernel(const PreArgs a) {
 }
 
 
-// stage C (zero padded to kTRows x NPAD) and ds_v (zero padded) into LDS: one wave per row, lanes along n
-template <int NPAD, int LD, int NTHREADS>
-__device__ __forceinline__ void stage_c(const BwdArgs& a, size_t pair, float* Cbuf, float* dsvs, int tid) {
-  const float* Cg = a.C + pair * (size_t)a.T * a.N;
-  const int lane = tid & 63, w = tid >> 6;
-  const bool al = (a.N & 3) == 0;
-  for (int row = w; row < kTRows; row += NTHREADS / 64) {
-    const bool live = row < a.T;
-    const float* src = Cg + (size_t)row * a.N;
-    float* dst = Cbuf + row * LD;
-    if (al) {
-      for (int c4 = lane; c4 < NPAD / 4; c4 += 64) {
-        const int col = 4 * c4;
-        *reinterpret_cast<f32x4*>(dst + col) =
-            (live && col < a.N) ? *reinterpret_cast<const f32x4*>(src + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    } else {
-      for (int col = lane; col < NPAD; col += 64) dst[col] = (live && col < a.N) ? src[col] : 0.f;
-    }
-  }
-  const float* dg = a.dsv + pair * (size_t)a.N;
-  for (int e = tid; e < NPAD; e += NTHREADS) dsvs[e] = (e < a.N) ? dg[e] : 0.f;
-}
-
-template <int NT, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void bwd_dc_kernel(const BwdArgs a) {
-  constexpr int NPAD = 16 * NT;
-  constexpr int LD = NPAD + 4;
-  constexpr int NSLOT = (NW / 2 > 2) ? NW / 2 : 2;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* slots = lds;                                // NSLOT x kTRows x LD
-  float* Cbuf = lds + NSLOT * kSlotRows * LD;           // kTRows x LD
-  float* dsvs = Cbuf + kTRows * LD;                  // NPAD
-  int b, l;
-  if (!block_to_pair(blockIdx.x, a.B, a.L, b, l)) return;
-  const int N = a.N, T = a.T, d = a.d;
-  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 15, q4 = lane >> 4;
-  const size_t pair = (size_t)l * a.B + b;
-  const float* Pvp = a.Pv + (size_t)b * N * d;
-  const float* Pqp = a.Pq + pair * (size_t)T * d;
-  const float* dZqp = a.dZq + pair * (size_t)T * d;
-  // rows n >= N fall outside these buffers: loads give 0, stores are dropped
-  const __amdgpu_buffer_rsrc_t rs_pv = make_rsrc(Pvp, (unsigned)N * d * 4u);
-  const __amdgpu_buffer_rsrc_t rs_pq = make_rsrc(Pqp, (unsigned)T * d * 4u);
-  const __amdgpu_buffer_rsrc_t rs_dzq = make_rsrc(dZqp, (unsigned)T * d * 4u);
-  const int voff = (j * d + 4 * q4) * 4;             // lane's row n = 16nt + j, channels db + 4q4..+3
-  stage_c<NPAD, LD, NW * 64>(a, pair, Cbuf, dsvs, tid);
-  __syncthreads();
-
-  f32x4 acc[2][NT];
-#pragma unroll
-  for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[tt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nsl = d / (128 * NW);                    // 128-channel slices per wave (1 at d = 512)
-  for (int dt = 0; dt < 8 * nsl; ++dt) {
-    const int db = ((dt >> 3) * NW + w) * 128 + 16 * (dt & 7);
-    // per-channel-tile operands
-    float pqB[kTS];                                // A[i = d = db + j][k = t = 4s + q4]
-#pragma unroll
-    for (int s = 0; s < kTS; ++s)                  // rows t >= T lie outside the buffers: read 0
-      pqB[s] = buf_load1(rs_pq, ((4 * s + q4) * d + j) * 4, db * 4);
-    f32x4 pqA[2], dzqA[2];                         // A[i = t = 16tt + j][k = d = db + 4*q4 + r]
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      // dC needs P_q and P_v themselves: the saved ones carry the factor kPScale (fused.h), divided out here of P_q
-      // and -- through its partner -- of P_v
-      pqA[tt] = buf_load4(rs_pq, ((16 * tt + j) * d + 4 * q4) * 4, db * 4) * (1.0f / kPScale);
-      dzqA[tt] = buf_load4(rs_dzq, ((16 * tt + j) * d + 4 * q4) * 4, db * 4) * (1.0f / kPScale);
-    }
-    const f32x4 wv4 = *reinterpret_cast<const f32x4*>(a.wv + db + 4 * q4);
-    // transposed tiles, C/D layout: col = j <-> n, row = 4*q4 + r <-> channel db + 4*q4 + r
-    auto load_pvT = [&](int nt) { return buf_load4(rs_pv, voff, (16 * nt * d + db) * 4); };
-    f32x4 pvT_q[3];                                    // prefetch ring, two tiles ahead
-    pvT_q[0] = load_pvT(0);
-    if (NT > 1) pvT_q[1] = load_pvT(1);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      if (nt + 2 < NT) pvT_q[(nt + 2) % 3] = load_pvT(nt + 2);
-      __builtin_amdgcn_sched_barrier(0);               // pin the prefetch ahead of this tile's math
-      const f32x4 pvT = pvT_q[nt % 3];
-      float cB[kTS];                                 // B[k = t][j = n]
-#pragma unroll
-      for (int s = 0; s < kTS; ++s) cB[s] = Cbuf[(4 * s + q4) * LD + 16 * nt + j];
-      // two interleaved accumulation chains (even / odd k-steps): a 16x16x4 MFMA can issue every 32 cycles
-      // but a dependent one only after 40
-      f32x4 hv = pvT, hv2 = zero4;
-#pragma unroll
-      for (int s = 0; s < kTS; ++s) {
-        if (s & 1) hv2 = mfma16(pqB[s], cB[s], hv2); else hv = mfma16(pqB[s], cB[s], hv);
-      }
-      hv += hv2;
-      const float dsn = dsvs[16 * nt + j];
-      f32x4 dzv;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float h = tanh_scaled(hv[r]);
-        dzv[r] = dsn * wv4[r] * (1.0f - h * h);
-      }
-      // dC[t][n] += sum_r P_q[t][db+4q4+r] dZ_v[n][..] + dZ_q[t][..] P_v[n][..]
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        acc[0][nt] = mfma16(pqA[0][r], dzv[r], acc[0][nt]);
-        acc[1][nt] = mfma16(pqA[1][r], dzv[r], acc[1][nt]);
-        acc[0][nt] = mfma16(dzqA[0][r], pvT[r], acc[0][nt]);
-        acc[1][nt] = mfma16(dzqA[1][r], pvT[r], acc[1][nt]);
-      }
-      __builtin_amdgcn_sched_barrier(0);               // keep live ranges per tile (no cross-tile hoisting)
-    }
-  }
-
-  // cross-wave sum of dC in a fixed tree order, then dA = dC (1 - C^2)
-  auto put = [&](float* slot) {
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          slot[(16 * tt + 4 * q4 + r) * LD + 16 * t + j] = acc[tt][t][r];
-        }
-  };
-  auto add = [&](const float* slot) {
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          acc[tt][t][r] += slot[(16 * tt + 4 * q4 + r) * LD + 16 * t + j];
-        }
-  };
-#pragma unroll
-  for (int stride = 1; stride < NW / 2; stride <<= 1) {
-    const int m = 2 * stride - 1;
-    if (stride > 1) __syncthreads();
-    if ((w & m) == stride) put(slots + (w / (2 * stride)) * kSlotRows * LD);
-    __syncthreads();
-    if ((w & m) == 0) add(slots + (w / (2 * stride)) * kSlotRows * LD);
-  }
-  if (NW > 2) __syncthreads();
-  if (w == NW / 2) put(slots);
-  if (w == 0) put(slots + kSlotRows * LD);
-  __syncthreads();
-  float* dAg = a.dA + pair * (size_t)T * N;
-  for (int e = tid; e < T * NPAD; e += NW * 64) {
-    const int row = e / NPAD, col = e - row * NPAD;
-    if (col < N) {
-      const float c = Cbuf[row * LD + col];
-      dAg[(size_t)row * N + col] = (slots[row * LD + col] + slots[kSlotRows * LD + row * LD + col]) * (1.0f - c * c);
-    }
-  }
-}
-
 // dQ_l[b][t][k] = a_q,l[t] gq_l[k] + sum_n dA_l[t][n] V[b][k][n]   for all levels with one pass over V.
 // grid (d/128, B); a wave owns 32 channels (two 16-wide MFMA column tiles); dA of the three levels is
 // staged zero-padded in LDS and read as MFMA A operands (16 bytes = 4 k-steps per ds_read_b128).
@@ -466,26 +308,6 @@ int launch_pre(const PreArgs& a, hipStream_t s) {
   return 0;
 }
 
-template <int NT, int NW>
-int launch_main(const BwdArgs& a, hipStream_t s) {
-  constexpr int LD = 16 * NT + 4;
-  constexpr int NSLOT = (NW / 2 > 2) ? NW / 2 : 2;
-  const size_t lds_dc = (size_t)((NSLOT * kSlotRows + kTRows) * LD + 16 * NT) * sizeof(float);
-  static DeviceOnce once;                            // the attribute is per device
-  CA_TRY(once.run([&] { return set_lds(bwd_dc_kernel<NT, NW>, lds_dc); }, "bwd_dc"));
-  static const bool dc_f32 = getenv("COATTN_BWD_DC_F32") != nullptr;     // developer switch: the exact-f32 MFMA dC kernel
-  if (!dc_f32) {
-    CA_TRY(launch_bwd_dc32(a, s));                   // dC, dA on the bf16 MFMA (coattn_bwd32.hip)
-    return launch_bwd_nat32(a, s);
-  }
-  const int groups = (a.B + 7) / 8;
-  dim3 grid(groups * a.L * 8), block(NW * 64);
-  hipLaunchKernelGGL((bwd_dc_kernel<NT, NW>), grid, block, lds_dc, s, a);
-  CA_CHECK_LAUNCH("bwd_dc");
-  return launch_bwd_nat32(a, s);                     // dP_q, dP_v, dw_v, db_v, db_q (coattn_bwd32.hip)
-  return 0;
-}
-
 }  // namespace
 
 size_t fused_bwd_ws_floats(int B, int N, int T, int d, int L) { return fused_bwd_off(B, N, T, d, L).total; }
@@ -526,11 +348,8 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   ba.dPv = ws + wo.dPv; ba.dPq = ws + wo.dPq; ba.dA = ws + wo.dA; ba.dwv_part = ws + wo.dwv_part;
   ba.dbv_part = ws + wo.dbv_part; ba.dbq_part = ws + wo.dbq_part;
   ba.B = B; ba.N = N; ba.T = T; ba.d = d; ba.L = L;
-  if (d % 512 == 0) {
-    CA_TRY(small_n ? (launch_main<4, 4>(ba, s)) : (launch_main<13, 4>(ba, s)));
-  } else {
-    CA_TRY(small_n ? (launch_main<4, 2>(ba, s)) : (launch_main<13, 2>(ba, s)));
-  }
+  CA_TRY(launch_bwd_dc32(ba, s));                    // dC, dA                       (coattn_bwd32.hip)
+  CA_TRY(launch_bwd_nat32(ba, s));                   // dP_q, dP_v, dw_v, db_v, db_q (coattn_bwd32.hip)
   // 3. small parameter gradients from the per-(sample, level) partials, one launch
   {
     const float* src[4] = {ws + wo.dwv_part, ws + wo.dbv_part, ws + wo.dbq_part, ws + wo.dwq_part};

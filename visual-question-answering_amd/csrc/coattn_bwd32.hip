@@ -1,5 +1,9 @@
-// Fused backward in the orientation [locations][channels]: dP_q = dZ_q + C dZ_v, dP_v = dZ_v + C^T dZ_q, dw_v, db_v, db_q
-// (autograd of model.py:380-388; SURVEY.md section 8 "Backward").
+// The three big kernels of the fused backward (autograd of model.py:377-392; SURVEY.md section 8 "Backward"), all on
+// the bf16 MFMA 32x32x16 with the exact 3-way split (fused.h):
+//   bwd_nat32_kernel  orientation [locations][channels]: dP_q = dZ_q + C dZ_v, dP_v = dZ_v + C^T dZ_q, dw_v, db_v, db_q
+//   bwd_dc32_kernel   orientation [channels][locations]: dC = P_q dZ_v^T + dZ_q P_v^T, dA = dC (.) (1 - C^2)
+//   bwd_dq32_kernel   dQ_l (+)= a_q (x) gq + dA_l V for location-major image features
+// (an accumulator tile feeds the next MFMA only along its row index, hence the two orientations: each recomputes H_v).
 //
 // bwd_nat32_kernel<NT,NW>: one workgroup per (sample, level), NW waves owning 128-channel slices, on the bf16 MFMA
 // 32x32x16 with the exact 3-way split (fused.h) -- the backward twin of the forward kernel's phase 2
@@ -14,7 +18,6 @@
 //     the accumulator of dP_v, stored as it lies (whole 128-byte row segments);
 //   * the dP_q accumulators start from dZ_q; dw_v, db_v, db_q partials are in-lane sums over the accumulator rows.
 // H_v is never stored.  Rows t >= T / n >= N fall outside the per-sample buffer descriptors (loads 0, stores dropped).
-// (dC, which contracts over the channels, needs the transposed orientation: bwd_dc_kernel, coattn_fused_bwd.hip.)
 #include "fused.h"
 
 #ifndef COATTN_DC_GT          // bwd_dc32_kernel: location tiles per group (their dC accumulators: 16 registers each)

@@ -279,3 +279,32 @@ def test_large_batch_backward_workspace():
     # the plan itself: bytes reported >= what bwd_dav_kernel writes behind the other regions
     _, _, bb = _lib.workspace_bytes(B, N, T, d, 3, _lib.IMPL_FUSED)
     assert bb // 4 >= B * (d // 64) * 3 * N
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(23, 196, 26, 512, "lm"), (9, 49, 26, 512, "cm"), (3, 100, 17, 1024, "lm")])
+def test_repeated_runs_are_bitwise_identical(shape):
+    """no float atomics, fixed summation orders -- forward outputs and every gradient (image features
+    included) of repeated runs on the same inputs are bit-for-bit the same (also a check on the LDS-only barriers and
+    counted waits of the fused kernels: a race would show here)."""
+    import vqa_amd
+    B, N, T, d, lay = shape
+    torch.manual_seed(7)
+    co = vqa_amd.ParallelCoAttention(d).cuda()
+    x = (torch.randn(B, d, N, device="cuda") * 0.5).permute(0, 2, 1)
+    if lay == "lm":
+        x = x.contiguous()
+    x.requires_grad_(True)
+    Qs = [(torch.randn(B, T, d, device="cuda") * 0.5).requires_grad_(True) for _ in range(3)]
+    ref = None
+    for _ in range(12):
+        for t in [x] + Qs + list(co.parameters()):
+            t.grad = None
+        v, q = co(x, Qs)
+        (sum((a * a).sum() for a in v) + sum((a * (a + 1)).sum() for a in q)).backward()
+        outs = [t.detach().clone() for t in v + q] + [x.grad.clone()] + [t.grad.clone() for t in Qs] + \
+               [p.grad.clone() for p in co.parameters() if p.grad is not None]
+        if ref is None:
+            ref = outs
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(ref, outs))

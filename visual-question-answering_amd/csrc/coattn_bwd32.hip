@@ -2,7 +2,7 @@
 // the bf16 MFMA 32x32x16 with the exact 3-way split (fused.h):
 //   bwd_nat32_kernel  orientation [locations][channels]: dP_q = dZ_q + C dZ_v, dP_v = dZ_v + C^T dZ_q, dw_v, db_v, db_q
 //   bwd_dc32_kernel   orientation [channels][locations]: dC = P_q dZ_v^T + dZ_q P_v^T, dA = dC (.) (1 - C^2)
-//   bwd_dq32_kernel   dQ_l (+)= a_q (x) gq + dA_l V for location-major image features
+//   bwd_dq32_kernel   dQ_l (+)= a_q (x) gq + dA_l V (location-major image features; channel-major when N % 4 == 0)
 // (an accumulator tile feeds the next MFMA only along its row index, hence the two orientations: each recomputes H_v).
 //
 // bwd_nat32_kernel<NT,NW>: one workgroup per (sample, level), NW waves owning 128-channel slices, on the bf16 MFMA
@@ -491,7 +491,7 @@ int launch_dc32(const BwdArgs& a, hipStream_t s) {
 // is split and used as the B operand (contraction over its row index = locations), the A operand is dA_l, split
 // once per workgroup into an LDS image [piece][t][n] whose n order inside every group of 16 is the accumulator row
 // order of a lane half (one 16-byte read per piece and k-step).
-template <int NT>
+template <int NT, bool LM>
 __global__ __launch_bounds__(256) void bwd_dq32_kernel(const DqArgs a) {
   constexpr int NPAD = 32 * NT;
   constexpr int LDR = NPAD + 8;                      // image row stride (bf16): 8 consecutive rows cover the banks once
@@ -507,13 +507,24 @@ __global__ __launch_bounds__(256) void bwd_dq32_kernel(const DqArgs a) {
   const int N = a.N, T = a.T, d = a.d;
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const size_t pair = (size_t)l * a.B + b;
-  const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(a.V + (size_t)b * a.v_sB, (unsigned)N * d * 4u);
+  const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(a.V + (size_t)b * a.v_sB, (unsigned)N * d * 4u);   // either layout: N d floats
   const __amdgpu_buffer_rsrc_t rs_da = make_rsrc(a.dA + pair * (size_t)T * N, (unsigned)T * N * 4u);
   const int c0 = slice * 128 + 32 * w;
-  // fragment of tile nt: V[32 nt + crow(g, h)][c0 + r]; rows >= N read 0
+  // fragment of tile nt: register g of lane (r, h) <-> V[location 32 nt + crow(g, h)][channel c0 + r].  Location-major
+  // V [N][d]: dword loads, 128 contiguous bytes per half wave (rows >= N read 0).  Channel-major V [d][N] (N % 4 == 0):
+  // the lane's channel row, four consecutive locations per 16-byte load (locations >= N read the next row's head:
+  // finite junk against zero columns of the dA image).
   auto load_tile = [&](int nt, f32x16& dst) {
+    if constexpr (LM) {
 #pragma unroll
-    for (int g = 0; g < 16; ++g) dst[g] = buf_load1(rs_v, (crow(g, h) * d + c0 + r) * 4, 32 * nt * d * 4);
+      for (int g = 0; g < 16; ++g) dst[g] = buf_load1(rs_v, (crow(g, h) * d + c0 + r) * 4, 32 * nt * d * 4);
+    } else {
+#pragma unroll
+      for (int gg = 0; gg < 4; ++gg) {
+        const f32x4 v = buf_load4(rs_v, ((c0 + r) * N + 4 * h) * 4, (32 * nt + 8 * gg) * 4);
+        dst[4 * gg] = v[0]; dst[4 * gg + 1] = v[1]; dst[4 * gg + 2] = v[2]; dst[4 * gg + 3] = v[3];
+      }
+    }
   };
   const int ntiles = (N + 31) >> 5;
   f32x16 ring[4];                                    // three tiles in flight (a wave has <= 7 of them); <= 120 VGPRs keep
@@ -582,12 +593,12 @@ __global__ __launch_bounds__(256) void bwd_dq32_kernel(const DqArgs a) {
   }
 }
 
-template <int NT>
+template <int NT, bool LM>
 int launch_dq32(const DqArgs& a, hipStream_t s) {
   constexpr int NPAD = 32 * NT;
   const size_t lds = (size_t)(3 * kTRows + 4) * (NPAD + 8) * 2 + 32 * 4;   // + 4 rows: what lanes 28 .. 31 of the last piece read
   const int items = a.B * (a.d / 128);
-  hipLaunchKernelGGL((bwd_dq32_kernel<NT>), dim3(((items + 7) / 8) * a.L * 8), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((bwd_dq32_kernel<NT, LM>), dim3(((items + 7) / 8) * a.L * 8), dim3(256), lds, s, a);
   CA_CHECK_LAUNCH("bwd_dq32");
   return 0;
 }
@@ -610,8 +621,9 @@ int launch_bwd_nat32(const BwdArgs& a, hipStream_t s) {
   return small_n ? launch_nat32<2, 2>(a, s) : launch_nat32<7, 2>(a, s);
 }
 
-int launch_bwd_dq32(const DqArgs& a, hipStream_t s) {
-  return a.N <= 64 ? launch_dq32<2>(a, s) : launch_dq32<7>(a, s);
+int launch_bwd_dq32(const DqArgs& a, int lm, hipStream_t s) {
+  if (lm) return a.N <= 64 ? launch_dq32<2, true>(a, s) : launch_dq32<7, true>(a, s);
+  return a.N <= 64 ? launch_dq32<2, false>(a, s) : launch_dq32<7, false>(a, s);
 }
 
 int launch_bwd_dc32(const BwdArgs& a, hipStream_t s) {

@@ -370,19 +370,21 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     return gemm_proj(g);
   };
   // 4. dQ_l = a_q (x) gq + dA V^T + dP_q W_q ;  dV = sum_l (a_v (x) gv + Q^T dA) + (sum_l dP_v) W_v
-  //    Location-major features: the projection writes dQ first and the dA V kernel adds onto it (the GEMM is 24 us
-  //    faster without an accumulate input); channel-major: the other way round.
-  if (lm) CA_TRY(dq_projection(false));
+  //    The projection writes dQ first and the bf16 dA V kernel adds onto it (the GEMM is 24 us faster without an
+  //    accumulate input); channel-major features with unaligned rows (N % 4 != 0): the exact-f32 kernel first, then
+  //    the projection onto it.
+  const bool dq32 = lm || (N % 4) == 0;              // the bf16 dA V kernel takes both layouts (channel-major: aligned rows)
+  if (dq32) CA_TRY(dq_projection(false));
   {
     DqArgs da;
-    da.accumulate = lm ? 1 : 0;
+    da.accumulate = dq32 ? 1 : 0;
     da.V = V; da.v_sB = vl.sB; da.dA = ws + wo.dA; da.aq = saved + so.aq; da.gq = gq;
     for (int l = 0; l < 8; ++l) da.dQ[l] = l < L ? dQ[l] : nullptr;
     da.B = B; da.N = N; da.T = T; da.d = d; da.L = L;
     const bool al = (N % 4) == 0;
     dim3 grid(d / 128, B), block(256);
-    if (lm) {
-      CA_TRY(launch_bwd_dq32(da, s));                // location-major features: bf16 MFMA kernel (coattn_bwd32.hip)
+    if (dq32) {
+      CA_TRY(launch_bwd_dq32(da, lm ? 1 : 0, s));    // bf16 MFMA kernel (coattn_bwd32.hip)
     } else if (small_n) {
       const size_t lds = (size_t)(3 * kTRows * (64 + 4) + 96) * sizeof(float);
       if (lm && al) hipLaunchKernelGGL((bwd_dq_kernel<4, true, true>), grid, block, lds, s, da);
@@ -420,7 +422,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
       CA_TRY(launch_gemm_f32(g, s));
     }
   }
-  if (!lm) CA_TRY(dq_projection(true));
+  if (!dq32) CA_TRY(dq_projection(true));
   // sum dP_v over the levels in place into level 0 (one streaming pass for L = 3; folding the sum into
   // the weight-gradient GEMM's operand loads was measured slower: 302 vs 170 + 50 us)
   float* dPv = ws + wo.dPv;

@@ -199,8 +199,9 @@ struct DqArgs {
   int B, N, T, d, L;
   int accumulate;        // bwd_dq32_kernel: add onto dQ (which then already holds dP_q W_q) instead of overwriting it
 };
-// dQ_l = a_q (x) gq + dA_l V for location-major V on the bf16 MFMA with the exact 3-way split
-int launch_bwd_dq32(const DqArgs& a, hipStream_t s);
+// dQ_l = a_q (x) gq + dA_l V on the bf16 MFMA with the exact 3-way split: location-major V (lm), or channel-major V
+// whose rows are 16-byte multiples (N % 4 == 0)
+int launch_bwd_dq32(const DqArgs& a, int lm, hipStream_t s);
 
 // bf16-split forward kernel on the 32x32x16 MFMA (coattn_fwd32.hip)
 int fused32_forward(const FwdArgs& a, hipStream_t s);

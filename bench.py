@@ -149,7 +149,11 @@ def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20):
     gv = torch.ones(3, B, d, device=device)
     gq = torch.ones(3, B, d, device=device)
 
+    leaves = list(args) + list(Qs)
+
     def fb():
+        for p in leaves:                           # optimizer.zero_grad() of the train loop (set_to_none): without it
+            p.grad = None                          # autograd adds each new gradient onto the old one (11 add kernels)
         v, q = vqa_amd.coattention(x_img, Qs, *args)
         torch.autograd.backward([v, q], [gv, gq])
 
@@ -166,6 +170,8 @@ def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20):
     for it in range(iters + 3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         v, q = vqa_amd.coattention(x_img, Qs, *args)
+        for p in leaves:
+            p.grad = None
         torch.cuda.synchronize(); t1 = time.perf_counter()
         torch.autograd.backward([v, q], [gv, gq])
         torch.cuda.synchronize(); t3 = time.perf_counter()

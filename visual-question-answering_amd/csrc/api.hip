@@ -51,6 +51,18 @@ static BwdPlan plan_bwd(int B, int N, int T, int d, int L) {
   return p;
 }
 
+static size_t fwd_ws_floats(int B, int N, int T, int d, int L) {
+  return plan_saved(B, N, T, d, L).total + al64((size_t)B * N * d);
+}
+static size_t bwd_ws_floats(int B, int N, int T, int d, int L) {
+  size_t bw = plan_bwd(B, N, T, d, L).total;
+  if (fused_supported(B, N, T, d, L)) {
+    const size_t fb = fused_bwd_ws_floats(B, N, T, d, L);
+    if (fb > bw) bw = fb;
+  }
+  return bw;
+}
+
 static int check_shape(int B, int N, int T, int d, int L, int dtype) {
   CA_CHECK_ARG(dtype == COATTN_F32, "unsupported dtype %d (only COATTN_F32)", dtype);
   CA_CHECK_ARG(B > 0 && B <= 65535, "bad batch size B=%d", B);
@@ -70,15 +82,10 @@ extern "C" int coattn_workspace_bytes(int B, int N, int T, int d, int L, int dty
   (void)flags;
   CA_TRY(check_shape(B, N, T, d, L, dtype));
   const SavedPlan sp = plan_saved(B, N, T, d, L);
-  const BwdPlan bp = plan_bwd(B, N, T, d, L);
   if (saved) *saved = sp.total * sizeof(float);
-  if (ws_fwd) *ws_fwd = (sp.total + al64((size_t)B * N * d)) * sizeof(float);
-  size_t bw = bp.total;
-  if (fused_supported(B, N, T, d, L)) {
-    const size_t fb = fused_bwd_ws_floats(B, N, T, d, L);
-    if (fb > bw) bw = fb;
-  }
-  if (ws_bwd) *ws_bwd = bw * sizeof(float);
+  // both workspaces end with room for two pre-split weight images (gemm_w.hip)
+  if (ws_fwd) *ws_fwd = fwd_ws_floats(B, N, T, d, L) * sizeof(float) + 2 * wsplit_bytes(d, d);
+  if (ws_bwd) *ws_bwd = bwd_ws_floats(B, N, T, d, L) * sizeof(float) + 2 * wsplit_bytes(d, d);
   return 0;
 }
 
@@ -160,10 +167,36 @@ int c_times(const Ctx& c, const float* C, const float* Y, const float* X, float*
   return launch_gemm_f32(g, c.s);
 }
 
-int general_projections(const Ctx& c, const float* V, const float* const* Q, const coattn_params* p, float* sv) {
+// COATTN_GEMM_W=0 (developer switch): the projections through gemm.hip instead of the pre-split-weight kernel
+static bool gemm_w_enabled() {
+  static const int on = [] { const char* e = getenv("COATTN_GEMM_W"); return e ? atoi(e) : 1; }();
+  return on != 0;
+}
+
+// wimg: room for two pre-split weight images (wsplit_bytes(d, d) each) at the end of the forward workspace
+int general_projections(const Ctx& c, const float* V, const float* const* Q, const coattn_params* p, float* sv, char* wimg) {
   const SavedPlan sp = plan_saved(c.B, c.N, c.T, c.d, c.L);
   const size_t BTd = (size_t)c.B * c.T * c.d;
-  CA_TRY(proj_v(c, V, (const float*)p->W_v, (const float*)p->b_v, sv + sp.Pv));
+  // fp32 projections of row-major activations: the weight is split once, the GEMM reads it as MFMA fragments
+  WGemm wv = {}, wq = {};
+  wv.A = V; wv.a_sm = (int)c.vl.sN; wv.Wf = wimg; wv.C = sv + sp.Pv; wv.c_sm = c.d;
+  wv.bias_n = (const float*)p->b_v; wv.out_scale = c.pscale; wv.M = c.B * c.N; wv.N = c.d; wv.K = c.d; wv.batch = 1;
+  for (int l = 0; l < c.L; ++l) wq.a_ptrs[l] = Q[l];
+  wq.a_sm = c.d; wq.Wf = wimg + wsplit_bytes(c.d, c.d); wq.C = sv + sp.Pq; wq.c_sz = (long)BTd; wq.c_sm = c.d;
+  wq.bias_n = (const float*)p->b_q; wq.out_scale = c.pscale; wq.M = c.B * c.T; wq.N = c.d; wq.K = c.d; wq.batch = c.L;
+  const bool w_ok = !c.bf16_proj && gemm_w_enabled();
+  const bool v_w = w_ok && c.vl.sD == 1 && c.vl.sB == (long)c.N * c.vl.sN && c.vl.sN < (1L << 24) && gemm_w_supported(wv);
+  const bool q_w = w_ok && gemm_w_supported(wq);
+  if (v_w || q_w) {
+    WSplit jobs[2];
+    int nj = 0;
+    if (v_w) jobs[nj++] = WSplit{(const float*)p->W_v, const_cast<void*>(wv.Wf), c.d, c.d, 0, c.d};
+    if (q_w) jobs[nj++] = WSplit{(const float*)p->W_q, const_cast<void*>(wq.Wf), c.d, c.d, 0, c.d};
+    CA_TRY(launch_wsplit(jobs, nj, c.s));
+  }
+  if (v_w) CA_TRY(launch_gemm_w(wv, c.s));
+  else CA_TRY(proj_v(c, V, (const float*)p->W_v, (const float*)p->b_v, sv + sp.Pv));
+  if (q_w) return launch_gemm_w(wq, c.s);
   // P_q of all levels in one launch: batch z = level, A from the pointer table
   coattn_gemm_desc g = {};
   for (int l = 0; l < c.L; ++l) g.a_ptrs[l] = Q[l];
@@ -388,7 +421,9 @@ static int forward_impl(const void* V, const VLayout& vl, const void* const* Q, 
   Ctx c{B, N, T, d, L, (hipStream_t)stream, vl};
   c.bf16_proj = (flags & COATTN_FLAG_BF16_PROJ) != 0;
   c.pscale = fused ? kPScale : 1.f;
-  if (do_proj) CA_TRY(general_projections(c, (const float*)V, (const float* const*)Q, p, sv));
+  if (do_proj)
+    CA_TRY(general_projections(c, (const float*)V, (const float* const*)Q, p, sv,
+                               (char*)ws + fwd_ws_floats(B, N, T, d, L) * sizeof(float)));
   if (!do_attn) return 0;
   if (fused)
     return fused_attention_forward(B, N, T, d, L, (const float*)V, vl, (const float* const*)Q, p, (float*)v_out,
@@ -433,7 +468,8 @@ extern "C" int coattn_backward(const void* V, int64_t v_sB, int64_t v_sN, int64_
   if (fused && fused_backward_supported(B, N, T, d, L))
     return fused_backward(B, N, T, d, L, (const float*)V, vl, (const float* const*)Q, p, (const float*)saved,
                           (const float*)gv, (const float*)gq, (float*)dV, dvl, (float* const*)dQ, pg, accumulate,
-                          (float*)ws, c.s, c.bf16_proj ? 1 : 0);
+                          (float*)ws, c.s, c.bf16_proj ? 1 : 0,
+                          gemm_w_enabled() ? (char*)ws + bwd_ws_floats(B, N, T, d, L) * sizeof(float) : nullptr);
   return backward_general(c, (const float*)V, (const float* const*)Q, p, (const float*)saved, (const float*)gv,
                           (const float*)gq, (float*)dV, dvl, (float* const*)dQ, pg, accumulate, (float*)ws);
 }

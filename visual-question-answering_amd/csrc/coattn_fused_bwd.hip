@@ -317,7 +317,7 @@ int fused_backward_supported(int B, int N, int T, int d, int L) { return fused_s
 int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLayout& vl, const float* const* Q,
                    const coattn_params* p, const float* saved, const float* gv, const float* gq, float* dV,
                    const VLayout& dvl, float* const* dQ, const coattn_param_grads* pg, int accumulate, float* ws,
-                   hipStream_t s, int bf16_proj) {
+                   hipStream_t s, int bf16_proj, char* wimg) {
   CA_CHECK_ARG(fused_backward_supported(B, N, T, d, L), "fused backward: unsupported shape");
   const bool lm = v_is_lm(vl, N, d);
   CA_CHECK_ARG(lm || v_is_cm(vl, N, d), "fused backward: image features must be channel-major [B,d,N] or location-major [B,N,d]");
@@ -360,6 +360,17 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   }
   // dQ_l (+)= dP_q,l W_q for all levels in one launch (batch z = level, C through the pointer table)
   auto dq_projection = [&](bool onto_dq) -> int {
+    if (!onto_dq && !bf16_proj && wimg) {            // W_q split once, read as MFMA fragments (gemm_w.hip)
+      WGemm w = {};
+      w.A = ws + wo.dPq; w.a_sz = (long)BTd; w.a_sm = d; w.Wf = wimg;
+      for (int l = 0; l < L; ++l) w.c_ptrs[l] = dQ[l];
+      w.c_sm = d; w.M = B * T; w.N = d; w.K = d; w.batch = L;
+      if (gemm_w_supported(w)) {
+        const WSplit job{(const float*)p->W_q, wimg, d, d, 1, d};
+        CA_TRY(launch_wsplit(&job, 1, s));
+        return launch_gemm_w(w, s);
+      }
+    }
     coattn_gemm_desc g = {};
     g.A = ws + wo.dPq; g.a_sz = (int64_t)BTd; g.a_sm = d; g.a_sk = 1;
     g.B = p->W_q; g.b_sk = d; g.b_sn = 1;

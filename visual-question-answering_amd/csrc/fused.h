@@ -22,7 +22,7 @@ int fused_backward_supported(int B, int N, int T, int d, int L);
 int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLayout& vl, const float* const* Q,
                    const coattn_params* p, const float* saved, const float* gv, const float* gq, float* dV,
                    const VLayout& dvl, float* const* dQ, const coattn_param_grads* pg, int accumulate, float* ws,
-                   hipStream_t s, int bf16_proj);
+                   hipStream_t s, int bf16_proj, char* wimg);
 
 // Diagnostic build only (tools/probe_stamps.py, -DCOATTN_STAMPS=1): wave 0 of every workgroup writes the
 // 100 MHz constant clock at its phase boundaries into the (otherwise unused) forward workspace tail.
@@ -126,6 +126,20 @@ __device__ __forceinline__ void buf_store4(f32x4 v, __amdgpu_buffer_rsrc_t r, in
 __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
+
+// ---- GEMM against a pre-split weight (gemm_w.hip) ---------------------------------------------------------------
+struct WSplit { const float* W; void* out; int N, K, trans, ld; };   // Bw(k,n) = trans ? W[k*ld+n] : W[n*ld+k]
+struct WGemm {
+  const float* A; const float* a_ptrs[8]; long a_sz; int a_sm;       // A[z][m][k], k contiguous; z from the table or a_sz
+  const void* Wf;                                                    // wsplit image of Bw [K x N]
+  float* C; float* c_ptrs[8]; long c_sz; int c_sm;                   // C[z][m][n], n contiguous
+  const float* bias_n; float out_scale;
+  int M, N, K, batch;
+};
+size_t wsplit_bytes(int N, int K);
+int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s);
+int gemm_w_supported(const WGemm& d);
+int launch_gemm_w(const WGemm& d, hipStream_t s);
 
 // XCD-aware block -> (b, l): blocks i and i+8 share an XCD (round-robin dispatch), so give the
 // L levels of one sample consecutive slots on one XCD.  Speed only; any mapping is correct.

@@ -458,6 +458,15 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     // dW_v[j][k] = sum_{b,n} dP_v[b][n][j] V[b][k][n]
     coattn_gemm_desc g = {};
     int S;
+    TnGemm tn = {};
+    tn.A = dPv; tn.a_ld = d; tn.B = V; tn.b_ld = (int)vl.sN; tn.C = part; tn.M = d; tn.N = d; tn.K = B * N; tn.levels = 1;
+    if (wimg && !bf16_proj && lm && vl.sB == (long)N * vl.sN && vl.sN < (1L << 24) && gemm_tn_supported(tn)) {
+      // both operands row-major over the B*N contraction rows: the hand-scheduled A^T B kernel (gemm_tn.hip)
+      int ks;
+      const int parts = gemm_tn_plan(tn, kMaxParts, &ks, &S);
+      CA_TRY(launch_gemm_tn(tn, ks, S, s));
+      CA_TRY(launch_reduce_partials(part, (float*)pg->dW_v, parts, (int64_t)d * d, accumulate, s));
+    } else {
     if (lm && vl.sB == (long)N * d) {
       // location-major, samples abutting: one flat contraction over m = (b, n), split-K over the B*N rows
       const int K = B * N;
@@ -478,11 +487,21 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     g.C = part; g.c_sz = (int64_t)d * d; g.c_sm = d; g.c_sn = 1;
     CA_TRY(gemm_proj(g));
     CA_TRY(launch_reduce_partials(part, (float*)pg->dW_v, S, (int64_t)d * d, accumulate, s));
+    }
   }
   {
     // dW_q[j][k] = sum_l sum_m dP_q,l[m][j] Q_l[m][k]: levels as the inner loop (B from the pointer
     // table), split-K over the B*T rows
     const int K = B * T;
+    TnGemm tn = {};
+    tn.A = ws + wo.dPq; tn.a_sl = (long)BTd; tn.a_ld = d; tn.b_ld = d; tn.C = part; tn.M = d; tn.N = d; tn.K = K; tn.levels = L;
+    for (int l = 0; l < L; ++l) tn.b_ptrs[l] = Q[l];
+    if (wimg && !bf16_proj && gemm_tn_supported(tn)) {         // levels as extra split-K parts (gemm_tn.hip)
+      int ks, S;
+      const int parts = gemm_tn_plan(tn, kMaxParts, &ks, &S);
+      CA_TRY(launch_gemm_tn(tn, ks, S, s));
+      return launch_reduce_partials(part, (float*)pg->dW_q, parts, (int64_t)d * d, accumulate, s);
+    }
     int ks = (K + 31) / 32;
     ks = (ks + 15) / 16 * 16;
     const int S = (K + ks - 1) / ks;

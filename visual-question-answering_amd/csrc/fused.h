@@ -141,6 +141,17 @@ int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s);
 int gemm_w_supported(const WGemm& d);
 int launch_gemm_w(const WGemm& d, hipStream_t s);
 
+// ---- weight-gradient GEMM C = A^T B with split-K parts (gemm_tn.hip) ---------------------------------------------
+struct TnGemm {
+  const float* A; long a_sl; int a_ld;                               // A_l[k][m] at A + l * a_sl, row stride a_ld
+  const float* B; const float* b_ptrs[8]; long b_sl; int b_ld;       // B_l[k][n]: table entry l, or B + l * b_sl
+  float* C;                                                          // parts [levels * S][M][N]
+  int M, N, K, levels;
+};
+int gemm_tn_supported(const TnGemm& d);
+int gemm_tn_plan(const TnGemm& d, int max_parts, int* ksplit, int* S);   // returns the number of parts
+int launch_gemm_tn(const TnGemm& d, int ksplit, int S, hipStream_t s);
+
 // XCD-aware block -> (b, l): blocks i and i+8 share an XCD (round-robin dispatch), so give the
 // L levels of one sample consecutive slots on one XCD.  Speed only; any mapping is correct.
 __device__ __forceinline__ bool block_to_pair(int bid, int B, int L, int& b, int& l) {
@@ -243,6 +254,7 @@ inline SavedOff saved_off(int B, int N, int T, int d, int L) {   // the one layo
 struct FusedBwdOff {
   size_t dsv, dZq, dPq, dPv, dA, dwv_part, dbv_part, dbq_part, dwq_part, dcs_part, part, total;
 };
+constexpr int kMaxParts = 48;   // split-K parts of a weight-gradient GEMM
 inline FusedBwdOff fused_bwd_off(int B, int N, int T, int d, int L) {
   FusedBwdOff p;
   size_t o = 0;
@@ -256,9 +268,9 @@ inline FusedBwdOff fused_bwd_off(int B, int N, int T, int d, int L) {
   p.dbq_part = o; o += fal64((size_t)L * B * d);
   p.dwq_part = o; o += fal64((size_t)L * B * d);
   p.dcs_part = o; o += fal64((size_t)L * B * 2);
-  // shared scratch: split-K partials of the weight-gradient GEMMs (<= 32 x d x d) and, before them, the da_v
+  // shared scratch: split-K partials of the weight-gradient GEMMs (<= kMaxParts x d x d) and, before them, the da_v
   // partials of bwd_dav_kernel ([B][d/64][3][N]), which outgrow the former at large B
-  const size_t part_gemm = (size_t)32 * d * d, part_dav = (size_t)B * (d / 64) * 3 * N;
+  const size_t part_gemm = (size_t)kMaxParts * d * d, part_dav = (size_t)B * (d / 64) * 3 * N;
   p.part = o; o += fal64(part_gemm > part_dav ? part_gemm : part_dav);
   p.total = o;
   return p;

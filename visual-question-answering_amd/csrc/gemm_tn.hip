@@ -1,0 +1,222 @@
+// fp32-accurate weight-gradient GEMM  C = A^T B  on v_mfma_f32_32x32x16_bf16 (gfx950).
+//
+//   part[z][m][n] = sum_{k in chunk(z)} A_l[k][m] * B_l[k][n]        A_l, B_l row-major, rows = contraction index
+//
+// dW_v = dP_v^T V (k = (sample, location)) and dW_q = sum_l dP_q,l^T Q_l (k = (sample, word)) of the co-attention
+// backward (the nn.Linear weight gradients of model.py:380-384): a d x d result contracted over tens of thousands
+// of rows, so the parallelism is split-K -- part z = (level l, chunk p) covers rows [p ksplit, (p+1) ksplit) of
+// level l, and a deterministic reduce adds the parts (launch_reduce_partials).
+//
+// Tile 128 x 128 per 256-thread workgroup (4 waves, 2 x 2 MFMA tiles each), BK = 16.  Both operands arrive
+// contiguous along their TILE index, not along k: each float4 (4 consecutive m of one k) is split into its three
+// exact bf16 pieces and staged as [k][m] images; the MFMA fragments (8 consecutive k of one row) come back through
+// ds_read_b64_tr_b16, the transposing LDS read of gfx950.  LDS images and fragment registers are double-buffered:
+// one barrier per step, and everything of step s + 1 (split arithmetic, LDS writes, the fragment reads after the
+// barrier) and the global loads of step s + 2 sit behind the 24 MFMAs of step s, placed by hand (one scheduling
+// fence per MFMA).  Numerics: the six partial products of gemm.hip's split mode, same order.
+#include "common.h"
+#include "fused.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDT = BM + 32;                   // [k][row] image row stride (elements): conflict-free writes + transposed reads
+constexpr int IMG = BK * LDT;                  // one piece image
+constexpr int OPER = 3 * IMG;                  // the three pieces of one operand
+
+struct TnArgs {
+  const float* A; long a_sl; int a_ld;         // level l at A + l * a_sl
+  const float* B; const float* b_ptrs[8]; long b_sl; int b_ld;
+  float* C;                                    // parts [L * S][M][N]
+  int M, N, K, ksplit, S;
+};
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs g) {
+  __shared__ __attribute__((aligned(16))) short lds[2][2 * OPER];          // [buffer][A pieces | B pieces]: 61,440 B
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
+  // the tiles of one part share an XCD (ids equal mod 8): they read the same rows of A and B
+  const int ntn = g.N / BN, ntiles = (g.M / BM) * ntn;
+  int z, t;
+  {
+    const int id = blockIdx.x, nz8 = (gridDim.x / ntiles) & ~7;            // parts covered by the XCD-grouped range
+    if (id < nz8 * ntiles) { z = (id & 7) + 8 * (id / (8 * ntiles)); t = (id >> 3) % ntiles; }
+    else { const int r = id - nz8 * ntiles; z = nz8 + r / ntiles; t = r % ntiles; }
+  }
+  const int m0 = (t / ntn) * BM, n0 = (t % ntn) * BN;
+  const int lvl = z / g.S, p = z % g.S;
+  const int kbeg = p * g.ksplit, kend = min(g.K, kbeg + g.ksplit);
+  const int steps = (kend - kbeg + BK - 1) / BK;
+  const float* Ab = g.A + (long)lvl * g.a_sl;
+  const float* Bb = g.b_ptrs[0] ? g.b_ptrs[lvl & 7] : g.B + (long)lvl * g.b_sl;
+  // rows past K read 0 (resource bound); rows past kend belong to the next part: ksplit % 16 == 0, so a step never straddles
+  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(Ab, (unsigned)((long)g.K * g.a_ld * 4));
+  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(Bb, (unsigned)((long)g.K * g.b_ld * 4));
+
+  // staging: per operand and step 2 float4 per thread; a wave's load covers 2 k-rows x 512 B
+  const int sk = tid >> 5, sm = (tid & 31) * 4;
+  const int a_voff = ((kbeg + sk) * g.a_ld + m0 + sm) * 4, b_voff = ((kbeg + sk) * g.b_ld + n0 + sm) * 4;
+  const int a_step = BK * g.a_ld * 4, b_step = BK * g.b_ld * 4, a_half = 8 * g.a_ld * 4, b_half = 8 * g.b_ld * 4;
+  const int st_off = sk * LDT + sm;                                        // + 8 * LDT for the second float4
+  // transposed fragment read: each 16-lane group fetches a 4 (k) x 16 (rows) block; lane 4q+p of the group supplies
+  // the address of block row q, columns 4p..4p+3, and receives the 4 k of row (lane & 15)
+  const int tr_off = (8 * lh + ((lane & 15) >> 2)) * LDT + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const int a_rd = tr_off + wr * 64, b_rd = OPER + tr_off + wc * 64;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 raw[4];                                  // A k 0..7, A k 8..15, B k 0..7, B k 8..15 of the step being staged
+  bf16x4 fa[2][3][2][2], fb[2][3][2][2];         // [set][piece][tile][k half]: fragment = {lo, hi}
+  unsigned ph[2], pm[2], pl[2];
+  float ra[2], rb[2];
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};      // smallest terms first (gemm.hip's order)
+  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+  auto load_raw = [&](int x, int s) {            // x: 0,1 = A halves, 2,3 = B halves; step s of this part
+    // (the step goes into the VECTOR offset: the resource's range check does not see the scalar offset)
+    if (x < 2) raw[x] = buf_load4(rs_a, a_voff + (x & 1) * a_half + s * a_step, 0);
+    else raw[x] = buf_load4(rs_b, b_voff + (x & 1) * b_half + s * b_step, 0);
+  };
+  auto stage = [&](int x, int e, int st) {       // split of raw[x], pair e, in three stages of 5, 5 and 1 VALU
+    if (st == 0) {
+      ph[e] = cvt_pk_bf16(raw[x][2 * e], raw[x][2 * e + 1]);
+      ra[e] = sub1(raw[x][2 * e], __builtin_bit_cast(float, ph[e] << 16));
+      rb[e] = sub1(raw[x][2 * e + 1], __builtin_bit_cast(float, ph[e] & 0xffff0000u));
+    } else if (st == 1) {
+      pm[e] = cvt_pk_bf16(ra[e], rb[e]);
+      ra[e] = sub1(ra[e], __builtin_bit_cast(float, pm[e] << 16));
+      rb[e] = sub1(rb[e], __builtin_bit_cast(float, pm[e] & 0xffff0000u));
+    } else {
+      pl[e] = cvt_pk_bf16(ra[e], rb[e]);
+    }
+  };
+  auto write_piece = [&](short* buf, int x, int q) {
+    const u32x2 v = q == 0 ? u32x2{ph[0], ph[1]} : (q == 1 ? u32x2{pm[0], pm[1]} : u32x2{pl[0], pl[1]});
+    *reinterpret_cast<u32x2*>(&buf[(x >> 1) * OPER + q * IMG + (x & 1) * 8 * LDT + st_off]) = v;
+  };
+  // fragment reads in the order of first use: a2, b0, a0, b2, a1, b1 (tile 0, tile 1; lo, hi): r = 0..23
+  auto read_frag = [&](auto SETc, const short* buf, int r) {
+    constexpr int SET = decltype(SETc)::value;
+    constexpr int QA[3] = {2, 0, 1}, QB[3] = {0, 2, 1};
+    const int grp = r >> 2, isb = grp & 1, q = isb ? QB[grp >> 1] : QA[grp >> 1], tile = (r >> 1) & 1, hi = r & 1;
+    const short* ptr = buf + q * IMG + (isb ? b_rd : a_rd) + tile * 32 + hi * 4 * LDT;
+    if (isb) fb[SET][q][tile][hi] = lds_tr16(ptr);
+    else fa[SET][q][tile][hi] = lds_tr16(ptr);
+  };
+  auto frag = [&](const bf16x4 (&f)[2]) { return bf16x8{f[0][0], f[0][1], f[0][2], f[0][3], f[1][0], f[1][1], f[1][2], f[1][3]}; };
+  // one 16-k step: MFMAs on fragment set SET; raw (step s + 1) is split into image `nxt`, re-requested for step
+  // s + 2, and after the barrier the fragments of step s + 1 are read into the other set
+  auto step = [&](auto SETc, int s, short* nxt) {
+    constexpr int SET = decltype(SETc)::value;
+    using OTHER = std::integral_constant<int, SET ^ 1>;
+#pragma unroll
+    for (int n = 0; n < 24; ++n) {
+      const int tt = n >> 2, i = (n >> 1) & 1, j = n & 1;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(fa[SET][PA[tt]][i]), frag(fb[SET][PB[tt]][j]), acc[i][j], 0, 0, 0);
+      // raw[x]: pair 0 stages in slots 4x, 4x+1, 4x+2; pair 1 in 4x+1, 4x+2, 4x+3; pieces written in 4x+3 .. 4x+5
+      if (n < 16) {
+        const int x = n >> 2, u = n & 3;
+        if (u <= 2) stage(x, 0, u);
+        if (u >= 1) stage(x, 1, u - 1);
+        if (u == 3) load_raw(x, s + 2);
+      }
+      if (n >= 3 && n < 18) {
+        const int w = n - 3, x = w >> 2, q = w & 3;
+        if (q < 3) write_piece(nxt, x, q);
+      }
+      if (n == 18) lds_barrier();
+      if (n >= 18) {
+#pragma unroll
+        for (int r = 4 * (n - 18); r < 4 * (n - 17); ++r) read_frag(OTHER{}, nxt, r);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  short* const img0 = &lds[0][0];
+  short* const img1 = &lds[1][0];
+  // prologue: step 0 into image 0, raw = step 1, fragments of step 0 in set 0
+#pragma unroll
+  for (int x = 0; x < 4; ++x) load_raw(x, 0);
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int st = 0; st < 3; ++st) stage(x, e, st);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) write_piece(img0, x, q);
+    load_raw(x, 1);
+  }
+  lds_barrier();
+#pragma unroll
+  for (int r = 0; r < 24; ++r) read_frag(I0{}, img0, r);
+  // (loads past the part's last step read rows of the next part or 0; they are split into the idle image and never used)
+  int s = 0;
+  for (; s + 2 <= steps; s += 2) {               // (one loop exit: the accumulators stay in place)
+    step(I0{}, s, img1);
+    step(I1{}, s + 1, img0);
+  }
+  if (s < steps) step(I0{}, s, img1);
+
+  float* Cb = g.C + (long)z * g.M * g.N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      float* crow = Cb + (long)row * g.N + n0 + wc * 64 + li;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) crow[j * 32] = acc[i][j][r];
+    }
+}
+
+}  // namespace
+
+int gemm_tn_supported(const TnGemm& d) {
+  auto pal = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+  bool ok = d.M > 0 && d.N > 0 && (d.M % BM) == 0 && (d.N % BN) == 0 && d.K >= BK && d.levels >= 1 && d.levels <= 8 &&
+            (d.a_ld & 3) == 0 && (d.b_ld & 3) == 0 && (d.a_sl & 3) == 0 && (d.b_sl & 3) == 0 && pal(d.A) &&
+            (d.b_ptrs[0] ? true : pal(d.B)) && (long)(d.K + 2 * BK) * d.a_ld * 4 < 0x40000000L &&
+            (long)(d.K + 2 * BK) * d.b_ld * 4 < 0x40000000L;
+  for (int t = 0; t < 8; ++t) ok = ok && pal(d.b_ptrs[t]);
+  return ok ? 1 : 0;
+}
+
+// parts = levels * S with S = ceil(K / ksplit); ksplit is chosen so that the grid fills the 512 workgroup slots once
+int gemm_tn_plan(const TnGemm& d, int max_parts, int* ksplit, int* S) {
+  const int ntiles = (d.M / BM) * (d.N / BN);
+  int want = (512 + ntiles - 1) / ntiles / d.levels;          // parts per level
+  if (want * d.levels > max_parts) want = max_parts / d.levels;
+  if (want < 1) want = 1;
+  int ks = (d.K + want - 1) / want;
+  ks = (ks + BK - 1) / BK * BK;
+  *ksplit = ks;
+  *S = (d.K + ks - 1) / ks;
+  return d.levels * *S;
+}
+
+int launch_gemm_tn(const TnGemm& d, int ksplit, int S, hipStream_t s) {
+  CA_CHECK_ARG(gemm_tn_supported(d), "gemm_tn: unsupported shape M=%d N=%d K=%d", d.M, d.N, d.K);
+  CA_CHECK_ARG(d.A && (d.B || d.b_ptrs[0]) && d.C && ksplit > 0 && (ksplit % BK) == 0 && (long)S * ksplit >= d.K, "gemm_tn: bad arguments");
+  TnArgs g = {};
+  g.A = d.A; g.a_sl = d.a_sl; g.a_ld = d.a_ld;
+  g.B = d.B; g.b_sl = d.b_sl; g.b_ld = d.b_ld;
+  for (int t = 0; t < 8; ++t) g.b_ptrs[t] = d.b_ptrs[t];
+  g.C = d.C; g.M = d.M; g.N = d.N; g.K = d.K; g.ksplit = ksplit; g.S = S;
+  const long nblk = (long)(d.M / BM) * (d.N / BN) * d.levels * S;
+  CA_CHECK_ARG(nblk < 2147483647L, "gemm_tn: grid too large");
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)nblk), dim3(256), 0, s, g);
+  CA_CHECK_LAUNCH("gemm_tn");
+  return 0;
+}

@@ -437,7 +437,15 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   // sum dP_v over the levels in place into level 0 (one streaming pass for L = 3; folding the sum into
   // the weight-gradient GEMM's operand loads was measured slower: 302 vs 170 + 50 us)
   float* dPv = ws + wo.dPv;
-  if (L == 3) {
+  float* part = ws + wo.part;
+  TnGemm tnv = {};
+  tnv.A = dPv; tnv.a_ld = d; tnv.B = V; tnv.b_ld = (int)vl.sN; tnv.C = part; tnv.M = d; tnv.N = d; tnv.K = B * N; tnv.levels = 1;
+  const bool tn_v = wimg && !bf16_proj && lm && vl.sB == (long)N * vl.sN && vl.sN < (1L << 24) && gemm_tn_supported(tnv);
+  // (the frozen-encoder default needs no dV: the weight-gradient kernel then adds the three levels while staging them)
+  const bool sum_in_gemm = tn_v && L == 3 && !dV;
+  if (sum_in_gemm) {
+    tnv.a_term = (long)BNd;
+  } else if (L == 3) {
     CA_TRY(launch_add3_inplace(dPv, dPv + BNd, dPv + 2 * BNd, (int64_t)BNd, s));
   } else {
     for (int l = 1; l < L; ++l) CA_TRY(launch_add_inplace(dPv, dPv + l * BNd, (int64_t)BNd, 1, s));
@@ -453,18 +461,15 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     CA_TRY(gemm_proj(g));
   }
   // 5. weight gradients
-  float* part = ws + wo.part;
   {
     // dW_v[j][k] = sum_{b,n} dP_v[b][n][j] V[b][k][n]
     coattn_gemm_desc g = {};
     int S;
-    TnGemm tn = {};
-    tn.A = dPv; tn.a_ld = d; tn.B = V; tn.b_ld = (int)vl.sN; tn.C = part; tn.M = d; tn.N = d; tn.K = B * N; tn.levels = 1;
-    if (wimg && !bf16_proj && lm && vl.sB == (long)N * vl.sN && vl.sN < (1L << 24) && gemm_tn_supported(tn)) {
+    if (tn_v) {
       // both operands row-major over the B*N contraction rows: the hand-scheduled A^T B kernel (gemm_tn.hip)
       int ks;
-      const int parts = gemm_tn_plan(tn, kMaxParts, &ks, &S);
-      CA_TRY(launch_gemm_tn(tn, ks, S, s));
+      const int parts = gemm_tn_plan(tnv, kMaxParts, &ks, &S);
+      CA_TRY(launch_gemm_tn(tnv, ks, S, s));
       CA_TRY(launch_reduce_partials(part, (float*)pg->dW_v, parts, (int64_t)d * d, accumulate, s));
     } else {
     if (lm && vl.sB == (long)N * d) {

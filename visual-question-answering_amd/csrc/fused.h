@@ -144,6 +144,7 @@ int launch_gemm_w(const WGemm& d, hipStream_t s);
 // ---- weight-gradient GEMM C = A^T B with split-K parts (gemm_tn.hip) ---------------------------------------------
 struct TnGemm {
   const float* A; long a_sl; int a_ld;                               // A_l[k][m] at A + l * a_sl, row stride a_ld
+  long a_term;                                                       // != 0: A = sum of the 3 arrays A + t * a_term
   const float* B; const float* b_ptrs[8]; long b_sl; int b_ld;       // B_l[k][n]: table entry l, or B + l * b_sl
   float* C;                                                          // parts [levels * S][M][N]
   int M, N, K, levels;

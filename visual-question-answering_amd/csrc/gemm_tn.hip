@@ -27,6 +27,7 @@ constexpr int OPER = 3 * IMG;                  // the three pieces of one operan
 
 struct TnArgs {
   const float* A; long a_sl; int a_ld;         // level l at A + l * a_sl
+  long a_term;                                 // SUM3: A = A0 + A1 + A2, term t at A + t * a_term
   const float* B; const float* b_ptrs[8]; long b_sl; int b_ld;
   float* C;                                    // parts [L * S][M][N]
   int M, N, K, ksplit, S;
@@ -34,6 +35,9 @@ struct TnArgs {
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+// SUM3: the A operand is the sum of three equally shaped arrays, added while staging (dP_v of the three question
+// levels: saves the separate pass that would sum them in memory)
+template <bool SUM3>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs g) {
   __shared__ __attribute__((aligned(16))) short lds[2][2 * OPER];          // [buffer][A pieces | B pieces]: 61,440 B
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -55,6 +59,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs g) {
   // rows past K read 0 (resource bound); rows past kend belong to the next part: ksplit % 16 == 0, so a step never straddles
   const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(Ab, (unsigned)((long)g.K * g.a_ld * 4));
   const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(Bb, (unsigned)((long)g.K * g.b_ld * 4));
+  const __amdgpu_buffer_rsrc_t rs_a1 = make_rsrc(Ab + (SUM3 ? g.a_term : 0), (unsigned)((long)g.K * g.a_ld * 4));
+  const __amdgpu_buffer_rsrc_t rs_a2 = make_rsrc(Ab + (SUM3 ? 2 * g.a_term : 0), (unsigned)((long)g.K * g.a_ld * 4));
 
   // staging: per operand and step 2 float4 per thread; a wave's load covers 2 k-rows x 512 B
   const int sk = tid >> 5, sm = (tid & 31) * 4;
@@ -75,6 +81,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   f32x4 raw[4];                                  // A k 0..7, A k 8..15, B k 0..7, B k 8..15 of the step being staged
+  f32x4 rawt[2][2];                              // SUM3: the other two terms of raw[0], raw[1]
   bf16x4 fa[2][3][2][2], fb[2][3][2][2];         // [set][piece][tile][k half]: fragment = {lo, hi}
   unsigned ph[2], pm[2], pl[2];
   float ra[2], rb[2];
@@ -82,11 +89,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs g) {
   constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
   auto load_raw = [&](int x, int s) {            // x: 0,1 = A halves, 2,3 = B halves; step s of this part
     // (the step goes into the VECTOR offset: the resource's range check does not see the scalar offset)
-    if (x < 2) raw[x] = buf_load4(rs_a, a_voff + (x & 1) * a_half + s * a_step, 0);
-    else raw[x] = buf_load4(rs_b, b_voff + (x & 1) * b_half + s * b_step, 0);
+    if (x < 2) {
+      raw[x] = buf_load4(rs_a, a_voff + (x & 1) * a_half + s * a_step, 0);
+      if (SUM3) {
+        rawt[x][0] = buf_load4(rs_a1, a_voff + (x & 1) * a_half + s * a_step, 0);
+        rawt[x][1] = buf_load4(rs_a2, a_voff + (x & 1) * a_half + s * a_step, 0);
+      }
+    } else raw[x] = buf_load4(rs_b, b_voff + (x & 1) * b_half + s * b_step, 0);
   };
   auto stage = [&](int x, int e, int st) {       // split of raw[x], pair e, in three stages of 5, 5 and 1 VALU
     if (st == 0) {
+      if (SUM3 && x < 2) {                       // (level order 0 + 1 + 2, as the separate summing pass adds them)
+        raw[x][2 * e] = (raw[x][2 * e] + rawt[x][0][2 * e]) + rawt[x][1][2 * e];
+        raw[x][2 * e + 1] = (raw[x][2 * e + 1] + rawt[x][0][2 * e + 1]) + rawt[x][1][2 * e + 1];
+      }
       ph[e] = cvt_pk_bf16(raw[x][2 * e], raw[x][2 * e + 1]);
       ra[e] = sub1(raw[x][2 * e], __builtin_bit_cast(float, ph[e] << 16));
       rb[e] = sub1(raw[x][2 * e + 1], __builtin_bit_cast(float, ph[e] & 0xffff0000u));
@@ -186,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs g) {
 int gemm_tn_supported(const TnGemm& d) {
   auto pal = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
   bool ok = d.M > 0 && d.N > 0 && (d.M % BM) == 0 && (d.N % BN) == 0 && d.K >= BK && d.levels >= 1 && d.levels <= 8 &&
-            (d.a_ld & 3) == 0 && (d.b_ld & 3) == 0 && (d.a_sl & 3) == 0 && (d.b_sl & 3) == 0 && pal(d.A) &&
+            (d.a_ld & 3) == 0 && (d.b_ld & 3) == 0 && (d.a_term & 3) == 0 && (d.a_sl & 3) == 0 && (d.b_sl & 3) == 0 && pal(d.A) &&
             (d.b_ptrs[0] ? true : pal(d.B)) && (long)(d.K + 2 * BK) * d.a_ld * 4 < 0x40000000L &&
             (long)(d.K + 2 * BK) * d.b_ld * 4 < 0x40000000L;
   for (int t = 0; t < 8; ++t) ok = ok && pal(d.b_ptrs[t]);
@@ -216,7 +232,9 @@ int launch_gemm_tn(const TnGemm& d, int ksplit, int S, hipStream_t s) {
   g.C = d.C; g.M = d.M; g.N = d.N; g.K = d.K; g.ksplit = ksplit; g.S = S;
   const long nblk = (long)(d.M / BM) * (d.N / BN) * d.levels * S;
   CA_CHECK_ARG(nblk < 2147483647L, "gemm_tn: grid too large");
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)nblk), dim3(256), 0, s, g);
+  g.a_term = d.a_term;
+  if (d.a_term) hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, g);
   CA_CHECK_LAUNCH("gemm_tn");
   return 0;
 }

@@ -194,9 +194,13 @@ int general_projections(const Ctx& c, const float* V, const float* const* Q, con
     if (q_w) jobs[nj++] = WSplit{(const float*)p->W_q, const_cast<void*>(wq.Wf), c.d, c.d, 0, c.d};
     CA_TRY(launch_wsplit(jobs, nj, c.s));
   }
-  if (v_w) CA_TRY(launch_gemm_w(wv, c.s));
+  if (v_w && q_w) {                                   // both projections in one launch
+    const WGemm both[2] = {wv, wq};
+    return launch_gemm_w(both, 2, c.s);
+  }
+  if (v_w) CA_TRY(launch_gemm_w(&wv, 1, c.s));
   else CA_TRY(proj_v(c, V, (const float*)p->W_v, (const float*)p->b_v, sv + sp.Pv));
-  if (q_w) return launch_gemm_w(wq, c.s);
+  if (q_w) return launch_gemm_w(&wq, 1, c.s);
   // P_q of all levels in one launch: batch z = level, A from the pointer table
   coattn_gemm_desc g = {};
   for (int l = 0; l < c.L; ++l) g.a_ptrs[l] = Q[l];

@@ -368,7 +368,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
       if (gemm_w_supported(w)) {
         const WSplit job{(const float*)p->W_q, wimg, d, d, 1, d};
         CA_TRY(launch_wsplit(&job, 1, s));
-        return launch_gemm_w(w, s);
+        return launch_gemm_w(&w, 1, s);
       }
     }
     coattn_gemm_desc g = {};
@@ -461,6 +461,28 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     CA_TRY(gemm_proj(g));
   }
   // 5. weight gradients
+  TnGemm tnq = {};
+  tnq.A = ws + wo.dPq; tnq.a_sl = (long)BTd; tnq.a_ld = d; tnq.b_ld = d; tnq.M = d; tnq.N = d; tnq.K = B * T; tnq.levels = L;
+  for (int l = 0; l < L; ++l) tnq.b_ptrs[l] = Q[l];
+  const bool tn_q = wimg && !bf16_proj && gemm_tn_supported(tnq);       // levels as extra split-K parts (gemm_tn.hip)
+  if (tn_v && tn_q) {
+    // both weight gradients in one launch: 32 split-K parts (x 16 tiles = the 512 workgroup slots) shared in
+    // proportion to the contraction lengths, so that all workgroups run about equally long
+    const double kv = (double)B * N, kq = (double)L * B * T;
+    int pv = (int)(32.0 * kv / (kv + kq) + 0.5);
+    pv = pv < 1 ? 1 : (pv > 31 ? 31 : pv);
+    const int pq = (32 - pv) / L > 0 ? (32 - pv) / L * L : L;
+    int ks[2], S[2];
+    const int parts_v = gemm_tn_plan(tnv, pv, &ks[0], &S[0]);
+    tnq.C = part + (size_t)parts_v * d * d;
+    const int parts_q = gemm_tn_plan(tnq, pq, &ks[1], &S[1]);
+    CA_CHECK_ARG(parts_v + parts_q <= kMaxParts, "fused backward: %d split-K parts exceed the workspace", parts_v + parts_q);
+    const TnGemm both[2] = {tnv, tnq};
+    CA_TRY(launch_gemm_tn(both, ks, S, 2, s));
+    CA_TRY(launch_reduce_partials(part, (float*)pg->dW_v, parts_v, (int64_t)d * d, accumulate, s));
+    return launch_reduce_partials(tnq.C, (float*)pg->dW_q, parts_q, (int64_t)d * d, accumulate, s);
+  }
+  tnq.C = part;
   {
     // dW_v[j][k] = sum_{b,n} dP_v[b][n][j] V[b][k][n]
     coattn_gemm_desc g = {};
@@ -468,8 +490,8 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     if (tn_v) {
       // both operands row-major over the B*N contraction rows: the hand-scheduled A^T B kernel (gemm_tn.hip)
       int ks;
-      const int parts = gemm_tn_plan(tnv, kMaxParts, &ks, &S);
-      CA_TRY(launch_gemm_tn(tnv, ks, S, s));
+      const int parts = gemm_tn_plan(tnv, 32, &ks, &S);
+      CA_TRY(launch_gemm_tn(&tnv, &ks, &S, 1, s));
       CA_TRY(launch_reduce_partials(part, (float*)pg->dW_v, parts, (int64_t)d * d, accumulate, s));
     } else {
     if (lm && vl.sB == (long)N * d) {
@@ -498,13 +520,10 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     // dW_q[j][k] = sum_l sum_m dP_q,l[m][j] Q_l[m][k]: levels as the inner loop (B from the pointer
     // table), split-K over the B*T rows
     const int K = B * T;
-    TnGemm tn = {};
-    tn.A = ws + wo.dPq; tn.a_sl = (long)BTd; tn.a_ld = d; tn.b_ld = d; tn.C = part; tn.M = d; tn.N = d; tn.K = K; tn.levels = L;
-    for (int l = 0; l < L; ++l) tn.b_ptrs[l] = Q[l];
-    if (wimg && !bf16_proj && gemm_tn_supported(tn)) {         // levels as extra split-K parts (gemm_tn.hip)
+    if (tn_q) {
       int ks, S;
-      const int parts = gemm_tn_plan(tn, kMaxParts, &ks, &S);
-      CA_TRY(launch_gemm_tn(tn, ks, S, s));
+      const int parts = gemm_tn_plan(tnq, 32, &ks, &S);
+      CA_TRY(launch_gemm_tn(&tnq, &ks, &S, 1, s));
       return launch_reduce_partials(part, (float*)pg->dW_q, parts, (int64_t)d * d, accumulate, s);
     }
     int ks = (K + 31) / 32;

@@ -139,7 +139,7 @@ struct WGemm {
 size_t wsplit_bytes(int N, int K);
 int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s);
 int gemm_w_supported(const WGemm& d);
-int launch_gemm_w(const WGemm& d, hipStream_t s);
+int launch_gemm_w(const WGemm* d, int n, hipStream_t s);          // n = 1 or 2 GEMMs in one launch
 
 // ---- weight-gradient GEMM C = A^T B with split-K parts (gemm_tn.hip) ---------------------------------------------
 struct TnGemm {
@@ -151,7 +151,7 @@ struct TnGemm {
 };
 int gemm_tn_supported(const TnGemm& d);
 int gemm_tn_plan(const TnGemm& d, int max_parts, int* ksplit, int* S);   // returns the number of parts
-int launch_gemm_tn(const TnGemm& d, int ksplit, int S, hipStream_t s);
+int launch_gemm_tn(const TnGemm* d, const int* ksplit, const int* S, int n, hipStream_t s);   // n = 1 or 2 per launch
 
 // XCD-aware block -> (b, l): blocks i and i+8 share an XCD (round-robin dispatch), so give the
 // L levels of one sample consecutive slots on one XCD.  Speed only; any mapping is correct.
@@ -255,7 +255,7 @@ inline SavedOff saved_off(int B, int N, int T, int d, int L) {   // the one layo
 struct FusedBwdOff {
   size_t dsv, dZq, dPq, dPv, dA, dwv_part, dbv_part, dbq_part, dwq_part, dcs_part, part, total;
 };
-constexpr int kMaxParts = 48;   // split-K parts of a weight-gradient GEMM
+constexpr int kMaxParts = 64;   // split-K parts of a weight-gradient GEMM
 inline FusedBwdOff fused_bwd_off(int B, int N, int T, int d, int L) {
   FusedBwdOff p;
   size_t o = 0;

@@ -33,12 +33,19 @@ struct TnArgs {
   int M, N, K, ksplit, S;
 };
 
+struct TnJobs { TnArgs job[2]; int first1; };  // blocks [0, first1) work on job 0, the rest on job 1
+
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // SUM3: the A operand is the sum of three equally shaped arrays, added while staging (dP_v of the three question
-// levels: saves the separate pass that would sum them in memory)
+// levels: saves the separate pass that would sum them in memory).  A job with a_term == 0 in a SUM3 launch reads
+// its two extra terms through an empty buffer resource: zeros, without memory traffic.
+// Up to two jobs per launch (dW_v and dW_q): the second one's workgroups fill the slots the first leaves idle.
 template <bool SUM3>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs g) {
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnJobs jobs) {
+  const int jb = (int)blockIdx.x >= jobs.first1 ? 1 : 0;
+  const TnArgs& g = jobs.job[jb];
+  const int bid = (int)blockIdx.x - (jb ? jobs.first1 : 0), nblk = jb ? (int)gridDim.x - jobs.first1 : jobs.first1;
   __shared__ __attribute__((aligned(16))) short lds[2][2 * OPER];          // [buffer][A pieces | B pieces]: 61,440 B
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
@@ -46,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs g) {
   const int ntn = g.N / BN, ntiles = (g.M / BM) * ntn;
   int z, t;
   {
-    const int id = blockIdx.x, nz8 = (gridDim.x / ntiles) & ~7;            // parts covered by the XCD-grouped range
+    const int id = bid, nz8 = (nblk / ntiles) & ~7;                        // parts covered by the XCD-grouped range
     if (id < nz8 * ntiles) { z = (id & 7) + 8 * (id / (8 * ntiles)); t = (id >> 3) % ntiles; }
     else { const int r = id - nz8 * ntiles; z = nz8 + r / ntiles; t = r % ntiles; }
   }
@@ -59,8 +66,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs g) {
   // rows past K read 0 (resource bound); rows past kend belong to the next part: ksplit % 16 == 0, so a step never straddles
   const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(Ab, (unsigned)((long)g.K * g.a_ld * 4));
   const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(Bb, (unsigned)((long)g.K * g.b_ld * 4));
-  const __amdgpu_buffer_rsrc_t rs_a1 = make_rsrc(Ab + (SUM3 ? g.a_term : 0), (unsigned)((long)g.K * g.a_ld * 4));
-  const __amdgpu_buffer_rsrc_t rs_a2 = make_rsrc(Ab + (SUM3 ? 2 * g.a_term : 0), (unsigned)((long)g.K * g.a_ld * 4));
+  const unsigned tbytes = (SUM3 && g.a_term) ? (unsigned)((long)g.K * g.a_ld * 4) : 0u;
+  const __amdgpu_buffer_rsrc_t rs_a1 = make_rsrc(Ab + (SUM3 ? g.a_term : 0), tbytes);
+  const __amdgpu_buffer_rsrc_t rs_a2 = make_rsrc(Ab + (SUM3 ? 2 * g.a_term : 0), tbytes);
 
   // staging: per operand and step 2 float4 per thread; a wave's load covers 2 k-rows x 512 B
   const int sk = tid >> 5, sm = (tid & 31) * 4;
@@ -222,19 +230,33 @@ int gemm_tn_plan(const TnGemm& d, int max_parts, int* ksplit, int* S) {
   return d.levels * *S;
 }
 
-int launch_gemm_tn(const TnGemm& d, int ksplit, int S, hipStream_t s) {
+static int fill_job(const TnGemm& d, int ksplit, int S, TnArgs& g, long* nblk) {
   CA_CHECK_ARG(gemm_tn_supported(d), "gemm_tn: unsupported shape M=%d N=%d K=%d", d.M, d.N, d.K);
   CA_CHECK_ARG(d.A && (d.B || d.b_ptrs[0]) && d.C && ksplit > 0 && (ksplit % BK) == 0 && (long)S * ksplit >= d.K, "gemm_tn: bad arguments");
-  TnArgs g = {};
-  g.A = d.A; g.a_sl = d.a_sl; g.a_ld = d.a_ld;
+  g = TnArgs{};
+  g.A = d.A; g.a_sl = d.a_sl; g.a_ld = d.a_ld; g.a_term = d.a_term;
   g.B = d.B; g.b_sl = d.b_sl; g.b_ld = d.b_ld;
   for (int t = 0; t < 8; ++t) g.b_ptrs[t] = d.b_ptrs[t];
   g.C = d.C; g.M = d.M; g.N = d.N; g.K = d.K; g.ksplit = ksplit; g.S = S;
-  const long nblk = (long)(d.M / BM) * (d.N / BN) * d.levels * S;
-  CA_CHECK_ARG(nblk < 2147483647L, "gemm_tn: grid too large");
-  g.a_term = d.a_term;
-  if (d.a_term) hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, g);
-  else hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, g);
+  *nblk = (long)(d.M / BM) * (d.N / BN) * d.levels * S;
+  return 0;
+}
+
+// one launch for n = 1 or 2 GEMMs (ksplit[i], S[i] from gemm_tn_plan)
+int launch_gemm_tn(const TnGemm* d, const int* ksplit, const int* S, int n, hipStream_t s) {
+  CA_CHECK_ARG(n == 1 || n == 2, "gemm_tn: 1 or 2 jobs per launch");
+  TnJobs jobs = {};
+  long nb[2] = {0, 0};
+  bool sum3 = false;
+  for (int i = 0; i < n; ++i) {
+    CA_TRY(fill_job(d[i], ksplit[i], S[i], jobs.job[i], &nb[i]));
+    sum3 = sum3 || d[i].a_term != 0;
+  }
+  CA_CHECK_ARG(nb[0] + nb[1] < 2147483647L, "gemm_tn: grid too large");
+  jobs.first1 = (int)nb[0];
+  const dim3 grid((unsigned)(nb[0] + nb[1]));
+  if (sum3) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, s, jobs);
+  else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, s, jobs);
   CA_CHECK_LAUNCH("gemm_tn");
   return 0;
 }

@@ -35,6 +35,8 @@ struct WArgs {
   int M, N, K, xcd_group;
 };
 
+struct WJobs { WArgs job[2]; int first1; };   // blocks [0, first1) work on job 0, the rest on job 1
+
 struct SplitJob { const float* W; void* out; int N, K, trans, ld; };
 struct SplitArgs { SplitJob job[2]; int njobs; };
 
@@ -64,7 +66,11 @@ __global__ __launch_bounds__(256) void wsplit_kernel(const SplitArgs a) {
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(256, 2) void gemm_w_kernel(const WArgs g) {
+// Up to two independent GEMMs per launch (P_v and P_q of the forward): the second one's workgroups fill the slots
+// the first one's last, partial round of workgroups would leave idle.
+__global__ __launch_bounds__(256, 2) void gemm_w_kernel(const WJobs jobs) {
+  const int jb = (int)blockIdx.x >= jobs.first1 ? 1 : 0;
+  const WArgs& g = jobs.job[jb];
   __shared__ __attribute__((aligned(16))) short Ah[2][3][BM * LDR];      // 61,440 B: two workgroups per CU
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void gemm_w_kernel(const WArgs g) {
   int m0, n0, z;
   {
     const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
-    const int id = blockIdx.x, x = id & 7, slot = id >> 3;
+    const int id = (int)blockIdx.x - (jb ? jobs.first1 : 0), x = id & 7, slot = id >> 3;
     if (!g.xcd_group) {
       const int per = ntm * ntn;
       z = id / per;
@@ -292,10 +298,10 @@ int gemm_w_supported(const WGemm& d) {
   return ok ? 1 : 0;
 }
 
-int launch_gemm_w(const WGemm& d, hipStream_t s) {
+static int fill_job(const WGemm& d, WArgs& g, long* nblk) {
   CA_CHECK_ARG(gemm_w_supported(d), "gemm_w: unsupported shape M=%d N=%d K=%d", d.M, d.N, d.K);
   CA_CHECK_ARG((d.A || d.a_ptrs[0]) && d.Wf && (d.C || d.c_ptrs[0]), "gemm_w: null operand");
-  WArgs g = {};
+  g = WArgs{};
   g.A = d.A; g.a_sz = d.a_sz; g.a_sm = d.a_sm;
   g.Wf = d.Wf; g.wf_bytes = (unsigned)wsplit_bytes(d.N, d.K);
   g.C = d.C; g.c_sz = d.c_sz; g.c_sm = d.c_sm;
@@ -304,9 +310,19 @@ int launch_gemm_w(const WGemm& d, hipStream_t s) {
   g.M = d.M; g.N = d.N; g.K = d.K;
   const long ntn = (d.N + BN - 1) / BN, ntm = (d.M + BM - 1) / BM;
   g.xcd_group = ntm >= 32 ? 1 : 0;
-  const long nblk = g.xcd_group ? (long)d.batch * ntn * ((ntm + 7) / 8) * 8 : (long)d.batch * ntn * ntm;
-  CA_CHECK_ARG(nblk < 2147483647L, "gemm_w: grid too large");
-  hipLaunchKernelGGL(gemm_w_kernel, dim3((unsigned)nblk), dim3(256), 0, s, g);
+  *nblk = g.xcd_group ? (long)d.batch * ntn * ((ntm + 7) / 8) * 8 : (long)d.batch * ntn * ntm;
+  return 0;
+}
+
+// one launch for n = 1 or 2 GEMMs
+int launch_gemm_w(const WGemm* d, int n, hipStream_t s) {
+  CA_CHECK_ARG(n == 1 || n == 2, "gemm_w: 1 or 2 jobs per launch");
+  WJobs jobs = {};
+  long nb[2] = {0, 0};
+  for (int i = 0; i < n; ++i) CA_TRY(fill_job(d[i], jobs.job[i], &nb[i]));
+  CA_CHECK_ARG(nb[0] + nb[1] < 2147483647L, "gemm_w: grid too large");
+  jobs.first1 = (int)nb[0];
+  hipLaunchKernelGGL(gemm_w_kernel, dim3((unsigned)(nb[0] + nb[1])), dim3(256), 0, s, jobs);
   CA_CHECK_LAUNCH("gemm_w");
   return 0;
 }

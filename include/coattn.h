@@ -182,6 +182,18 @@ typedef struct coattn_gemm_desc {
 
 int coattn_gemm_f32(const coattn_gemm_desc* g, void* stream);
 
+/* ---- nn.Linear against a pre-split weight ----------------------------------------------------------------
+ * y[M][N] = out_scale * (x[M][K] W[N][K]^T + bias[N]) in fp32 accuracy (the W_v / W_q projections of
+ * ParallelCoAttention.forward, model.py:380-384: x rows ld_x floats apart, W as nn.Linear stores it).
+ * The weight is split once into its three bf16 pieces in MFMA-fragment order (`wimg`, device scratch of
+ * coattn_linear_workspace_bytes(N, K) bytes) and the GEMM reads the fragments in place (gemm_w.hip) -- the
+ * kernel pair coattn_forward uses for both projections.  flags bit 0: `wimg` already holds the image of this
+ * W (skip the split).  K % 32 == 0, M >= 128, x 16-byte aligned with ld_x % 4 == 0; other shapes: error -1
+ * (use coattn_gemm_f32).  bias may be NULL; out_scale 0 means 1. */
+size_t coattn_linear_workspace_bytes(int N, int K);
+int coattn_linear_forward(const void* x, int64_t ld_x, const void* W, const void* bias, void* y, void* wimg,
+                          int M, int N, int K, float out_scale, int flags, void* stream);
+
 /* Same contract with the operands rounded to bf16 (round to nearest even) while they are staged and
  * contracted on v_mfma_f32_32x32x16_bf16 (fp32 accumulate / output): the arithmetic of
  * COATTN_FLAG_BF16_PROJ.  Shapes the bf16 kernels do not take (unaligned strides, M < 128) are computed

@@ -178,3 +178,54 @@ def test_gemm_small_tile_dispatch(a_m, b_n):
     _gemm(kw)
     ref = (A.double().transpose(1, 2) if a_m else A.double()) @ (Bm.double() if b_n else Bm.double().transpose(1, 2))
     assert _rel(Cm, ref) < 2e-6
+
+
+# ---- coattn_linear_forward: nn.Linear against a pre-split weight (gemm_w.hip) ----------------------------------
+def _linear(x, ld, W, bias, M, N, K, scale=0.0, flags=0, wimg=None):
+    from vqa_amd import _lib
+    lib = _lib.load()
+    y = torch.full((M, N), float("nan"), device="cuda")
+    if wimg is None:
+        wimg = torch.empty(lib.coattn_linear_workspace_bytes(N, K) // 4, device="cuda")
+    rc = lib.coattn_linear_forward(x.data_ptr(), ld, W.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                   y.data_ptr(), wimg.data_ptr(), M, N, K, scale, flags,
+                                   C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    return rc, y, wimg
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (4160, 512, 512), (1000, 96, 64), (129, 200, 160), (31360, 512, 512)])
+def test_linear_presplit_weight(M, N, K):
+    from vqa_amd import _lib
+    torch.manual_seed(11)
+    x = torch.randn(M, K, device="cuda")
+    W = torch.randn(N, K, device="cuda") / K ** 0.5
+    b = torch.randn(N, device="cuda")
+    rc, y, _ = _linear(x, K, W, b, M, N, K)
+    _lib.check(rc, "coattn_linear_forward")
+    ref = x.double() @ W.double().t() + b.double()
+    assert _rel(y, ref) < 2e-6            # fp32 accuracy: the exact 3-way split, fp32 accumulation
+
+
+def test_linear_strided_rows_scale_and_image_reuse():
+    """Rows ld_x > K apart, out_scale, no bias; a second call reuses the weight image (flags bit 0)."""
+    from vqa_amd import _lib
+    torch.manual_seed(12)
+    M, N, K, ld = 777, 256, 96, 128
+    xs = torch.randn(M, ld, device="cuda")
+    W = torch.randn(N, K, device="cuda")
+    rc, y, wimg = _linear(xs, ld, W, None, M, N, K, scale=2.5)
+    _lib.check(rc, "coattn_linear_forward")
+    ref = 2.5 * (xs[:, :K].double() @ W.double().t())
+    assert _rel(y, ref) < 2e-6
+    x2 = torch.randn(M, ld, device="cuda")
+    rc, y2, _ = _linear(x2, ld, torch.zeros_like(W), None, M, N, K, scale=2.5, flags=1, wimg=wimg)   # W ignored: image reused
+    _lib.check(rc, "coattn_linear_forward")
+    assert _rel(y2, 2.5 * (x2[:, :K].double() @ W.double().t())) < 2e-6
+
+
+def test_linear_rejects_unsupported_shapes():
+    from vqa_amd import _lib
+    x = torch.randn(64, 48, device="cuda"); W = torch.randn(32, 48, device="cuda")
+    rc, _, _ = _linear(x, 48, W, None, 64, 32, 48)          # K % 32 != 0, M < 128
+    assert rc == -1 and b"not supported" in _lib.load().coattn_last_error()

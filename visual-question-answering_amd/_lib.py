@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 EXPORTS = ("coattn_version", "coattn_last_error", "coattn_fused_supported", "coattn_workspace_bytes",
            "coattn_forward", "coattn_attention_forward", "coattn_backward", "coattn_gemm_f32", "coattn_gemm_bf16",
            "coattn_phrase_workspace_bytes", "coattn_phrase_forward", "coattn_phrase_backward",
-           "coattn_ce_workspace_bytes", "coattn_ce_forward")
+           "coattn_ce_workspace_bytes", "coattn_ce_forward", "coattn_linear_workspace_bytes", "coattn_linear_forward")
 
 F32 = 0
 IMPL_AUTO, IMPL_GENERAL, IMPL_FUSED = 0, 1, 2
@@ -99,6 +99,10 @@ def load() -> C.CDLL:
                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.coattn_ce_workspace_bytes.argtypes = [C.c_int] * 3 + [C.POINTER(C.c_size_t)]
     lib.coattn_ce_forward.argtypes = [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p]
+    lib.coattn_linear_workspace_bytes.argtypes = [C.c_int, C.c_int]
+    lib.coattn_linear_workspace_bytes.restype = C.c_size_t
+    lib.coattn_linear_forward.argtypes = ([C.c_void_p, C.c_int64] + [C.c_void_p] * 4 + [C.c_int] * 3
+                                          + [C.c_float, C.c_int, C.c_void_p])
     _lib = lib
     return lib
 

@@ -94,6 +94,22 @@ extern "C" int coattn_gemm_f32(const coattn_gemm_desc* g, void* stream) {
   return launch_gemm_f32(*g, (hipStream_t)stream);
 }
 
+extern "C" size_t coattn_linear_workspace_bytes(int N, int K) { return (N > 0 && K > 0) ? wsplit_bytes(N, K) : 0; }
+
+extern "C" int coattn_linear_forward(const void* x, int64_t ld_x, const void* W, const void* bias, void* y, void* wimg,
+                                     int M, int N, int K, float out_scale, int flags, void* stream) {
+  CA_CHECK_ARG(x && W && y && wimg && M > 0 && N > 0 && K > 0 && ld_x >= K && ld_x < (1L << 24), "linear: bad argument");
+  WGemm g = {};
+  g.A = (const float*)x; g.a_sm = (int)ld_x; g.Wf = wimg; g.C = (float*)y; g.c_sm = N; g.bias_n = (const float*)bias;
+  g.out_scale = out_scale; g.M = M; g.N = N; g.K = K; g.batch = 1;
+  CA_CHECK_ARG(gemm_w_supported(g), "linear: shape M=%d N=%d K=%d ld=%ld not supported (see coattn.h)", M, N, K, (long)ld_x);
+  if (!(flags & 1)) {
+    const WSplit job{(const float*)W, wimg, N, K, 0, K};
+    CA_TRY(launch_wsplit(&job, 1, (hipStream_t)stream));
+  }
+  return launch_gemm_w(&g, 1, (hipStream_t)stream);
+}
+
 extern "C" int coattn_gemm_bf16(const coattn_gemm_desc* g, void* stream) {
   CA_CHECK_ARG(g != nullptr, "gemm: null descriptor");
   return launch_gemm_bf16in(*g, (hipStream_t)stream);

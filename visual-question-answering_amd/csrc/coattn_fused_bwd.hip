@@ -354,9 +354,10 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   {
     const float* src[4] = {ws + wo.dwv_part, ws + wo.dbv_part, ws + wo.dbq_part, ws + wo.dwq_part};
     float* dst[4] = {(float*)pg->dw_v, (float*)pg->db_v, (float*)pg->db_q, (float*)pg->dw_q};
-    CA_TRY(launch_reduce_jobs(src, dst, 4, L * B, d, accumulate, s));
-    CA_TRY(launch_sum_all2(ws + wo.dcs_part, (float*)pg->dc_v, ws + wo.dcs_part + (size_t)L * B, (float*)pg->dc_q,
-                           (int64_t)L * B, accumulate, s));
+    // (dc_v, dc_q: whole-array sums of the per-(sample, level) partials, rows of the same launch)
+    const float* sx[2] = {ws + wo.dcs_part, ws + wo.dcs_part + (size_t)L * B};
+    float* so2[2] = {(float*)pg->dc_v, (float*)pg->dc_q};
+    CA_TRY(launch_reduce_jobs(src, dst, 4, L * B, d, accumulate, s, sx, so2, (int64_t)L * B));
   }
   // dQ_l (+)= dP_q,l W_q for all levels in one launch (batch z = level, C through the pointer table)
   auto dq_projection = [&](bool onto_dq) -> int {
@@ -479,8 +480,8 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     CA_CHECK_ARG(parts_v + parts_q <= kMaxParts, "fused backward: %d split-K parts exceed the workspace", parts_v + parts_q);
     const TnGemm both[2] = {tnv, tnq};
     CA_TRY(launch_gemm_tn(both, ks, S, 2, s));
-    CA_TRY(launch_reduce_partials(part, (float*)pg->dW_v, parts_v, (int64_t)d * d, accumulate, s));
-    return launch_reduce_partials(tnq.C, (float*)pg->dW_q, parts_q, (int64_t)d * d, accumulate, s);
+    return launch_reduce_partials2(part, (float*)pg->dW_v, parts_v, tnq.C, (float*)pg->dW_q, parts_q, (int64_t)d * d,
+                                   accumulate, s);
   }
   tnq.C = part;
   {

@@ -154,9 +154,12 @@ int launch_colsum_partial(const float* s, const float* X, float* part, int R, in
                           int* nchunks, hipStream_t s_);
 // out[j] (+)= sum_c part[c][j]   (n = elements per partial)
 int launch_reduce_partials(const float* part, float* out, int nparts, int64_t n, int accumulate, hipStream_t s);
+int launch_reduce_partials2(const float* part0, float* out0, int nparts0, const float* part1, float* out1, int nparts1,
+                            int64_t n, int accumulate, hipStream_t s);
 // up to 4 reductions dst[i][j] (+)= sum_c src[i][c][j] in one launch
 int launch_reduce_jobs(const float* const* src, float* const* dst, int njobs, int nparts, int64_t n, int accumulate,
-                       hipStream_t s);
+                       hipStream_t s, const float* const* sum_x = nullptr, float* const* sum_out = nullptr,
+                       int64_t sum_n = 0);
 // total (+)= sum of x[0..n)   (single block)
 int launch_sum_all(const float* x, float* out, int64_t n, int accumulate, hipStream_t s);
 int launch_sum_all2(const float* x0, float* out0, const float* x1, float* out1, int64_t n, int accumulate, hipStream_t s);

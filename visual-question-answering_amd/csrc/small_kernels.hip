@@ -124,8 +124,11 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* part,
 }
 
 // out[j] (+)= sum_c part[c][j], four float columns per thread (n % 4 == 0, 16-byte aligned)
+// (blockIdx.y = 1: the second job, same n)
 __global__ __launch_bounds__(256) void reduce_partials4_kernel(const float* part, float* out, int nparts, long n,
-                                                               int accumulate) {
+                                                               int accumulate, const float* part1, float* out1,
+                                                               int nparts1) {
+  if (blockIdx.y) { part = part1; out = out1; nparts = nparts1; }
   const long j = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (j >= n) return;
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -143,13 +146,33 @@ __global__ __launch_bounds__(256) void reduce_partials4_kernel(const float* part
 }
 
 // up to 4 independent reductions of [nparts][n] partial buffers in one launch (blockIdx.y = job)
+// plus up to 2 whole-array sums (rows blockIdx.y >= njobs, block x = 0 only): out = sum of sum_x[0 .. sum_n)
 struct ReduceJobs {
   const float* src[4];
   float* dst[4];
+  int njobs;
+  const float* sum_x[2];
+  float* sum_out[2];
+  long sum_n;
 };
 __global__ __launch_bounds__(256) void reduce_jobs_kernel(const ReduceJobs jobs, int nparts, long n, int accumulate) {
   // 64 columns per block; the four waves take interleaved parts and are combined in a fixed order
   __shared__ float red[4][64];
+  if ((int)blockIdx.y >= jobs.njobs) {               // whole-array sum (fixed order: as sum_all_kernel)
+    if (blockIdx.x) return;
+    const float* x = jobs.sum_x[blockIdx.y - jobs.njobs];
+    float* out = jobs.sum_out[blockIdx.y - jobs.njobs];
+    float acc = 0.f;
+    for (long i = threadIdx.x; i < jobs.sum_n; i += 256) acc += x[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float t = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+      out[0] = accumulate ? out[0] + t : t;
+    }
+    return;
+  }
   const float* part = jobs.src[blockIdx.y];
   float* out = jobs.dst[blockIdx.y];
   const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -286,12 +309,17 @@ int launch_colsum_partial(const float* sv, const float* X, float* part, int R, i
   return 0;
 }
 
+// sum_x / sum_out (may be NULL): two whole-array sums of sum_n floats each, done by the same launch
 int launch_reduce_jobs(const float* const* src, float* const* dst, int njobs, int nparts, int64_t n, int accumulate,
-                       hipStream_t s) {
+                       hipStream_t s, const float* const* sum_x, float* const* sum_out, int64_t sum_n) {
   CA_CHECK_ARG(njobs >= 1 && njobs <= 4, "reduce_jobs: 1..4 jobs");
-  ReduceJobs jobs;
+  ReduceJobs jobs = {};
   for (int i = 0; i < 4; ++i) { jobs.src[i] = i < njobs ? src[i] : nullptr; jobs.dst[i] = i < njobs ? dst[i] : nullptr; }
-  hipLaunchKernelGGL(reduce_jobs_kernel, dim3((unsigned)((n + 63) / 64), njobs), dim3(256), 0, s, jobs, nparts,
+  jobs.njobs = njobs;
+  const int nsum = sum_x ? 2 : 0;
+  for (int i = 0; i < nsum; ++i) { jobs.sum_x[i] = sum_x[i]; jobs.sum_out[i] = sum_out[i]; }
+  jobs.sum_n = (long)sum_n;
+  hipLaunchKernelGGL(reduce_jobs_kernel, dim3((unsigned)((n + 63) / 64), njobs + nsum), dim3(256), 0, s, jobs, nparts,
                      (long)n, accumulate);
   CA_CHECK_LAUNCH("reduce_jobs");
   return 0;
@@ -300,13 +328,27 @@ int launch_reduce_jobs(const float* const* src, float* const* dst, int njobs, in
 int launch_reduce_partials(const float* part, float* out, int nparts, int64_t n, int accumulate, hipStream_t s) {
   if ((n & 3) == 0 && ((((uintptr_t)part) | ((uintptr_t)out)) & 15) == 0) {
     hipLaunchKernelGGL(reduce_partials4_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, part, out,
-                       nparts, (long)n, accumulate);
+                       nparts, (long)n, accumulate, (const float*)nullptr, (float*)nullptr, 0);
     CA_CHECK_LAUNCH("reduce_partials4");
     return 0;
   }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, out, nparts,
                      (long)n, accumulate);
   CA_CHECK_LAUNCH("reduce_partials");
+  return 0;
+}
+
+// two reductions of equal width n in one launch (n % 4 == 0, 16-byte aligned buffers)
+int launch_reduce_partials2(const float* part0, float* out0, int nparts0, const float* part1, float* out1, int nparts1,
+                            int64_t n, int accumulate, hipStream_t s) {
+  const bool al = (n & 3) == 0 && ((((uintptr_t)part0) | ((uintptr_t)out0) | ((uintptr_t)part1) | ((uintptr_t)out1)) & 15) == 0;
+  if (!al) {
+    CA_TRY(launch_reduce_partials(part0, out0, nparts0, n, accumulate, s));
+    return launch_reduce_partials(part1, out1, nparts1, n, accumulate, s);
+  }
+  hipLaunchKernelGGL(reduce_partials4_kernel, dim3((unsigned)((n / 4 + 255) / 256), 2), dim3(256), 0, s, part0, out0,
+                     nparts0, (long)n, accumulate, part1, out1, nparts1);
+  CA_CHECK_LAUNCH("reduce_partials4");
   return 0;
 }
 

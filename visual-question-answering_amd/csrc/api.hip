@@ -201,7 +201,13 @@ int general_projections(const Ctx& c, const float* V, const float* const* Q, con
   wq.a_sm = c.d; wq.Wf = wimg + wsplit_bytes(c.d, c.d); wq.C = sv + sp.Pq; wq.c_sz = (long)BTd; wq.c_sm = c.d;
   wq.bias_n = (const float*)p->b_q; wq.out_scale = c.pscale; wq.M = c.B * c.T; wq.N = c.d; wq.K = c.d; wq.batch = c.L;
   const bool w_ok = !c.bf16_proj && gemm_w_enabled();
-  const bool v_w = w_ok && c.vl.sD == 1 && c.vl.sB == (long)c.N * c.vl.sN && c.vl.sN < (1L << 24) && gemm_w_supported(wv);
+  bool v_w = false;
+  if (w_ok && c.vl.sD == 1 && c.vl.sB == (long)c.N * c.vl.sN && c.vl.sN < (1L << 24)) {
+    v_w = gemm_w_supported(wv) != 0;                 // location-major rows, samples abutting
+  } else if (w_ok && c.vl.sN == 1 && c.vl.sD < (1L << 24)) {
+    wv.a_sm = 0; wv.a_sk = (int)c.vl.sD; wv.a_mdiv = c.N; wv.a_sdiv = c.vl.sB;   // channel-major, read in place
+    v_w = gemm_w_supported(wv) != 0;
+  }
   const bool q_w = w_ok && gemm_w_supported(wq);
   if (v_w || q_w) {
     WSplit jobs[2];

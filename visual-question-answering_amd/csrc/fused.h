@@ -131,6 +131,8 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, int voff, i
 struct WSplit { const float* W; void* out; int N, K, trans, ld; };   // Bw(k,n) = trans ? W[k*ld+n] : W[n*ld+k]
 struct WGemm {
   const float* A; const float* a_ptrs[8]; long a_sz; int a_sm;       // A[z][m][k], k contiguous; z from the table or a_sz
+  int a_sk, a_mdiv; long a_sdiv;                                     // a_sk != 0: A contiguous along m instead, element
+                                                                     // (m, k) at (m / a_mdiv) * a_sdiv + m % a_mdiv + k * a_sk
   const void* Wf;                                                    // wsplit image of Bw [K x N]
   float* C; float* c_ptrs[8]; long c_sz; int c_sm;                   // C[z][m][n], n contiguous
   const float* bias_n; float out_scale;

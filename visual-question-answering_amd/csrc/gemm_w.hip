@@ -29,6 +29,7 @@ constexpr int kChunkBytes = 3 * kFragBytes;    // the three pieces of one (colum
 
 struct WArgs {
   const float* A; const float* a_ptrs[8]; long a_sz; int a_sm;
+  int a_sk, a_mdiv; long a_sdiv;               // AM: element (m, k) at (m / a_mdiv) * a_sdiv + m % a_mdiv + k * a_sk
   const void* Wf; unsigned wf_bytes;
   float* C; float* c_ptrs[8]; long c_sz; int c_sm;
   const float* bias_n; float oscale;
@@ -66,19 +67,20 @@ __global__ __launch_bounds__(256) void wsplit_kernel(const SplitArgs a) {
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-// Up to two independent GEMMs per launch (P_v and P_q of the forward): the second one's workgroups fill the slots
-// the first one's last, partial round of workgroups would leave idle.
-__global__ __launch_bounds__(256, 2) void gemm_w_kernel(const WJobs jobs) {
-  const int jb = (int)blockIdx.x >= jobs.first1 ? 1 : 0;
-  const WArgs& g = jobs.job[jb];
-  __shared__ __attribute__((aligned(16))) short Ah[2][3][BM * LDR];      // 61,440 B: two workgroups per CU
+constexpr int LDT = BM + 32;                   // AM: [k][row] image row stride (conflict-free writes + transposed reads)
+
+// AM = false: A rows contiguous along k ([row][k] images, one ds_read_b128 per fragment).
+// AM = true : A contiguous along m -- channel-major image features [B, d, N] read in place (model.py:215-217),
+//             row m = (sample, location) split by a_mdiv: [k][row] images, fragments through ds_read_b64_tr_b16.
+template <bool AM>
+__device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short* const smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
   // XCD-aware tile order (as gemm.hip): the column tiles of one row tile share an XCD's L2
   int m0, n0, z;
   {
     const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
-    const int id = (int)blockIdx.x - (jb ? jobs.first1 : 0), x = id & 7, slot = id >> 3;
+    const int x = id & 7, slot = id >> 3;
     if (!g.xcd_group) {
       const int per = ntm * ntn;
       z = id / per;
@@ -94,18 +96,28 @@ __global__ __launch_bounds__(256, 2) void gemm_w_kernel(const WJobs jobs) {
     }
   }
   const float* Ab = g.a_ptrs[0] ? g.a_ptrs[z & 7] : g.A + (long)z * g.a_sz;
-  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(Ab, (unsigned)(((long)(g.M - 1) * g.a_sm + g.K) * 4));
+  const long a_bytes = AM ? ((long)((g.M - 1) / g.a_mdiv) * g.a_sdiv + (g.a_mdiv - 1) + (long)(g.K - 1) * g.a_sk + 1) * 4
+                          : ((long)(g.M - 1) * g.a_sm + g.K) * 4;
+  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(Ab, (unsigned)a_bytes);
   const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(g.Wf, g.wf_bytes);
   const int KS = g.K / BK;                       // K % 32 == 0 (host check)
 
   // A staging: 4 float4 per thread and step; a wave's load covers 8 rows x 128 B (whole lines)
+  // (AM: float4 = 4 consecutive rows of one k; a wave's load covers 2 k x 512 B; a_mdiv % 4 == 0 keeps the 4 rows in one sample)
   int a_voff[4], a_lds[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int m = (tid >> 3) + 32 * i, k = (tid & 7) * 4;
-    a_voff[i] = (m0 + m) < g.M ? ((m0 + m) * g.a_sm + k) * 4 : 0x40000000;     // rows past M read 0
-    a_lds[i] = m * LDR + k;
+    if (AM) {
+      const int k = (tid >> 5) + 8 * i, m = (tid & 31) * 4, row = m0 + m;
+      a_voff[i] = row < g.M ? (int)(((long)(row / g.a_mdiv) * g.a_sdiv + row % g.a_mdiv + (long)k * g.a_sk) * 4) : 0x40000000;
+      a_lds[i] = k * LDT + m;
+    } else {
+      const int m = (tid >> 3) + 32 * i, k = (tid & 7) * 4;
+      a_voff[i] = (m0 + m) < g.M ? ((m0 + m) * g.a_sm + k) * 4 : 0x40000000;   // rows past M read 0
+      a_lds[i] = m * LDR + k;
+    }
   }
+  const int a_kstep = AM ? BK * g.a_sk * 4 : BK * 4;                            // bytes per 32-k step
   // B fragments: tile j of this wave, chunk (nt, ks16) at ((nt * K/16 + ks16) * 3 + piece) * 1 KB
   int w_voff[2];
 #pragma unroll
@@ -113,7 +125,10 @@ __global__ __launch_bounds__(256, 2) void gemm_w_kernel(const WJobs jobs) {
     const int nt = (n0 + wc * 64) / 32 + j;
     w_voff[j] = nt * (g.K / 16) * kChunkBytes + lane * 16;                      // tiles past N lie outside the image: 0
   }
-  const int a_rd = (wr * 64 + li) * LDR + 8 * lh;
+  // AM: transposed fragment read -- each 16-lane group fetches a 4 (k) x 16 (rows) block; lane 4q+p of the group
+  // supplies the address of block row q, columns 4p..4p+3, and receives the 4 k of row (lane & 15)
+  const int a_rd = AM ? (8 * lh + ((lane & 15) >> 2)) * LDT + 16 * ((lane >> 4) & 1) + 4 * (lane & 3) + wr * 64
+                      : (wr * 64 + li) * LDR + 8 * lh;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -140,14 +155,20 @@ __global__ __launch_bounds__(256, 2) void gemm_w_kernel(const WJobs jobs) {
   constexpr int PB[6] = {0, 2, 1, 0, 1, 0};      // (gemm.hip's order)
   constexpr int RQ[3] = {2, 0, 1};               // fragment read order = order of first use
   constexpr int IMG = BM * LDR;                  // elements of one piece image
-  auto load_a = [&](int i, int s) { raw[i] = buf_load4(rs_a, a_voff[i], s * (BK * 4)); };
+  auto load_a = [&](int i, int s) { raw[i] = buf_load4(rs_a, a_voff[i], s * a_kstep); };
   auto load_b = [&](int ring, int k, int half) {
     const int j = k / 3, q = k % 3;
     bq[ring][j][q] = __builtin_bit_cast(bf16x8, buf_load4(rs_w, w_voff[j] + q * kFragBytes, half * kChunkBytes));
   };
   auto read_a = [&](const short* img, int h, int k) {
     const int q = RQ[k >> 1], i = k & 1;
-    af[h][q][i] = *reinterpret_cast<const bf16x8*>(&img[q * IMG + a_rd + i * 32 * LDR + 16 * h]);
+    if (AM) {
+      const short* ptr = img + q * IMG + a_rd + i * 32 + 16 * h * LDT;
+      const bf16x4 lo = lds_tr16(ptr), hi = lds_tr16(ptr + 4 * LDT);
+      af[h][q][i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    } else {
+      af[h][q][i] = *reinterpret_cast<const bf16x8*>(&img[q * IMG + a_rd + i * 32 * LDR + 16 * h]);
+    }
   };
   // split of raw[i], pair e (0 | 1), in three stages of 5, 5 and 1 VALU instructions
   auto stage = [&](int i, int e, int st) {
@@ -213,8 +234,8 @@ __global__ __launch_bounds__(256, 2) void gemm_w_kernel(const WJobs jobs) {
   for (int i = 0; i < 4; ++i) load_a(i, 0);
 #pragma unroll
   for (int k = 0; k < 6; ++k) { load_b(0, k, 0); load_b(1, k, 1); }
-  short* const img0 = &Ah[0][0][0];
-  short* const img1 = &Ah[1][0][0];
+  short* const img0 = smem;
+  short* const img1 = smem + 3 * IMG;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -269,6 +290,16 @@ __global__ __launch_bounds__(256, 2) void gemm_w_kernel(const WJobs jobs) {
     }
 }
 
+// Up to two independent GEMMs per launch (P_v and P_q of the forward): the second one's workgroups fill the slots
+// the first one's last, partial round of workgroups would leave idle.  AM0: layout of job 0's A operand.
+template <bool AM0>
+__global__ __launch_bounds__(256, 2) void gemm_w_kernel(const WJobs jobs) {
+  __shared__ __attribute__((aligned(16))) short smem[2 * 3 * BM * LDR];  // 61,440 B: two workgroups per CU
+  static_assert(BM * LDR == BK * LDT, "both image layouts have the same size");
+  if ((int)blockIdx.x < jobs.first1) gemm_w_body<AM0>(jobs.job[0], (int)blockIdx.x, smem);
+  else gemm_w_body<false>(jobs.job[1], (int)blockIdx.x - jobs.first1, smem);
+}
+
 }  // namespace
 
 size_t wsplit_bytes(int N, int K) { return (size_t)((N + 31) / 32) * ((K + 15) / 16) * kChunkBytes; }
@@ -291,9 +322,14 @@ int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s) {
 
 int gemm_w_supported(const WGemm& d) {
   auto pal = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
-  bool ok = d.M >= 128 && d.N > 0 && d.K >= BK && (d.K % BK) == 0 && (d.a_sm & 3) == 0 && (d.a_sz & 3) == 0 && d.batch >= 1 &&
-            d.batch <= 8 && ((long)d.M * d.a_sm + d.K) * 4 < 0x40000000L && wsplit_bytes(d.N, d.K) < 0x40000000UL &&
-            (d.a_ptrs[0] ? true : pal(d.A));
+  bool ok = d.M >= 128 && d.N > 0 && d.K >= BK && (d.K % BK) == 0 && (d.a_sz & 3) == 0 && d.batch >= 1 && d.batch <= 8 &&
+            wsplit_bytes(d.N, d.K) < 0x40000000UL && (d.a_ptrs[0] ? true : pal(d.A));
+  if (d.a_sk) {      // A contiguous along m, rows split by a_mdiv
+    ok = ok && d.a_mdiv > 0 && (d.a_mdiv & 3) == 0 && (d.a_sk & 3) == 0 && (d.a_sdiv & 3) == 0 && (d.M & 3) == 0 &&
+         ((long)((d.M - 1) / d.a_mdiv + 1) * d.a_sdiv + (long)d.K * d.a_sk) * 4 < 0x40000000L;
+  } else {
+    ok = ok && (d.a_sm & 3) == 0 && ((long)d.M * d.a_sm + d.K) * 4 < 0x40000000L;
+  }
   for (int t = 0; t < 8; ++t) ok = ok && pal(d.a_ptrs[t]);
   return ok ? 1 : 0;
 }
@@ -302,7 +338,7 @@ static int fill_job(const WGemm& d, WArgs& g, long* nblk) {
   CA_CHECK_ARG(gemm_w_supported(d), "gemm_w: unsupported shape M=%d N=%d K=%d", d.M, d.N, d.K);
   CA_CHECK_ARG((d.A || d.a_ptrs[0]) && d.Wf && (d.C || d.c_ptrs[0]), "gemm_w: null operand");
   g = WArgs{};
-  g.A = d.A; g.a_sz = d.a_sz; g.a_sm = d.a_sm;
+  g.A = d.A; g.a_sz = d.a_sz; g.a_sm = d.a_sm; g.a_sk = d.a_sk; g.a_mdiv = d.a_mdiv; g.a_sdiv = d.a_sdiv;
   g.Wf = d.Wf; g.wf_bytes = (unsigned)wsplit_bytes(d.N, d.K);
   g.C = d.C; g.c_sz = d.c_sz; g.c_sm = d.c_sm;
   for (int t = 0; t < 8; ++t) { g.a_ptrs[t] = d.a_ptrs[t]; g.c_ptrs[t] = d.c_ptrs[t]; }
@@ -322,7 +358,9 @@ int launch_gemm_w(const WGemm* d, int n, hipStream_t s) {
   for (int i = 0; i < n; ++i) CA_TRY(fill_job(d[i], jobs.job[i], &nb[i]));
   CA_CHECK_ARG(nb[0] + nb[1] < 2147483647L, "gemm_w: grid too large");
   jobs.first1 = (int)nb[0];
-  hipLaunchKernelGGL(gemm_w_kernel, dim3((unsigned)(nb[0] + nb[1])), dim3(256), 0, s, jobs);
+  CA_CHECK_ARG(n == 1 || d[1].a_sk == 0, "gemm_w: only the first job may have an m-contiguous A operand");
+  if (d[0].a_sk) hipLaunchKernelGGL(gemm_w_kernel<true>, dim3((unsigned)(nb[0] + nb[1])), dim3(256), 0, s, jobs);
+  else hipLaunchKernelGGL(gemm_w_kernel<false>, dim3((unsigned)(nb[0] + nb[1])), dim3(256), 0, s, jobs);
   CA_CHECK_LAUNCH("gemm_w");
   return 0;
 }

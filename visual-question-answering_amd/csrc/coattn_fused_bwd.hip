@@ -441,7 +441,13 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   float* part = ws + wo.part;
   TnGemm tnv = {};
   tnv.A = dPv; tnv.a_ld = d; tnv.B = V; tnv.b_ld = (int)vl.sN; tnv.C = part; tnv.M = d; tnv.N = d; tnv.K = B * N; tnv.levels = 1;
-  const bool tn_v = wimg && !bf16_proj && lm && vl.sB == (long)N * vl.sN && vl.sN < (1L << 24) && gemm_tn_supported(tnv);
+  bool tn_v = false;
+  if (wimg && !bf16_proj && lm && vl.sB == (long)N * vl.sN && vl.sN < (1L << 24)) {
+    tn_v = gemm_tn_supported(tnv) != 0;              // location-major rows, samples abutting
+  } else if (wimg && !bf16_proj && !lm && vl.sD < (1L << 24)) {
+    tnv.b_ld = (int)vl.sD; tnv.b_kdiv = N; tnv.b_sdiv = vl.sB;          // channel-major, read in place
+    tn_v = gemm_tn_supported(tnv) != 0;
+  }
   // (the frozen-encoder default needs no dV: the weight-gradient kernel then adds the three levels while staging them)
   const bool sum_in_gemm = tn_v && L == 3 && !dV;
   if (sum_in_gemm) {

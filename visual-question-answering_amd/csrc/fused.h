@@ -148,6 +148,8 @@ struct TnGemm {
   const float* A; long a_sl; int a_ld;                               // A_l[k][m] at A + l * a_sl, row stride a_ld
   long a_term;                                                       // != 0: A = sum of the 3 arrays A + t * a_term
   const float* B; const float* b_ptrs[8]; long b_sl; int b_ld;       // B_l[k][n]: table entry l, or B + l * b_sl
+  int b_kdiv; long b_sdiv;                                           // b_kdiv != 0: B contiguous along k instead, element
+                                                                     // (k, n) at (k / b_kdiv) * b_sdiv + k % b_kdiv + n * b_ld
   float* C;                                                          // parts [levels * S][M][N]
   int M, N, K, levels;
 };

@@ -24,11 +24,15 @@ constexpr int BM = 128, BN = 128, BK = 16;
 constexpr int LDT = BM + 32;                   // [k][row] image row stride (elements): conflict-free writes + transposed reads
 constexpr int IMG = BK * LDT;                  // one piece image
 constexpr int OPER = 3 * IMG;                  // the three pieces of one operand
+// BCM (B contiguous along the contraction index: channel-major image features): [col][k] images, 48-byte rows
+// (conflict-free ds_read_b128 fragments)
+constexpr int LDRB = 24, IMGB = BN * LDRB, OPERB = 3 * IMGB;
 
 struct TnArgs {
   const float* A; long a_sl; int a_ld;         // level l at A + l * a_sl
   long a_term;                                 // SUM3: A = A0 + A1 + A2, term t at A + t * a_term
   const float* B; const float* b_ptrs[8]; long b_sl; int b_ld;
+  int b_kdiv; long b_sdiv; unsigned b_bytes;   // BCM: element (k, n) at (k / b_kdiv) * b_sdiv + k % b_kdiv + n * b_ld
   float* C;                                    // parts [L * S][M][N]
   int M, N, K, ksplit, S;
 };
@@ -41,12 +45,11 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // levels: saves the separate pass that would sum them in memory).  A job with a_term == 0 in a SUM3 launch reads
 // its two extra terms through an empty buffer resource: zeros, without memory traffic.
 // Up to two jobs per launch (dW_v and dW_q): the second one's workgroups fill the slots the first leaves idle.
-template <bool SUM3>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnJobs jobs) {
-  const int jb = (int)blockIdx.x >= jobs.first1 ? 1 : 0;
-  const TnArgs& g = jobs.job[jb];
-  const int bid = (int)blockIdx.x - (jb ? jobs.first1 : 0), nblk = jb ? (int)gridDim.x - jobs.first1 : jobs.first1;
-  __shared__ __attribute__((aligned(16))) short lds[2][2 * OPER];          // [buffer][A pieces | B pieces]: 61,440 B
+// BCM: the B operand is contiguous along k inside groups of b_kdiv rows (channel-major image features [B, d, N]:
+// k = (sample, location), n = channel): float4 = 4 consecutive k of one column, [col][k] images, ds_read_b128.
+template <bool SUM3, bool BCM>
+__device__ __forceinline__ void gemm_tn_body(const TnArgs& g, const int bid, const int nblk, short* const lds) {
+  constexpr int BUF = OPER + (BCM ? OPERB : OPER);                         // elements of one LDS buffer
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
   // the tiles of one part share an XCD (ids equal mod 8): they read the same rows of A and B
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnJobs jobs) {
   const float* Bb = g.b_ptrs[0] ? g.b_ptrs[lvl & 7] : g.B + (long)lvl * g.b_sl;
   // rows past K read 0 (resource bound); rows past kend belong to the next part: ksplit % 16 == 0, so a step never straddles
   const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(Ab, (unsigned)((long)g.K * g.a_ld * 4));
-  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(Bb, (unsigned)((long)g.K * g.b_ld * 4));
+  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(Bb, BCM ? g.b_bytes : (unsigned)((long)g.K * g.b_ld * 4));
   const unsigned tbytes = (SUM3 && g.a_term) ? (unsigned)((long)g.K * g.a_ld * 4) : 0u;
   const __amdgpu_buffer_rsrc_t rs_a1 = make_rsrc(Ab + (SUM3 ? g.a_term : 0), tbytes);
   const __amdgpu_buffer_rsrc_t rs_a2 = make_rsrc(Ab + (SUM3 ? 2 * g.a_term : 0), tbytes);
@@ -75,10 +78,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnJobs jobs) {
   const int a_voff = ((kbeg + sk) * g.a_ld + m0 + sm) * 4, b_voff = ((kbeg + sk) * g.b_ld + n0 + sm) * 4;
   const int a_step = BK * g.a_ld * 4, b_step = BK * g.b_ld * 4, a_half = 8 * g.a_ld * 4, b_half = 8 * g.b_ld * 4;
   const int st_off = sk * LDT + sm;                                        // + 8 * LDT for the second float4
+  // BCM staging: 4 lanes cover the 16 k (64 B) of one column, 16 columns per wave load; the second float4 is
+  // column + 64.  The (sample, row) position of the k group is tracked step by step (no division in the loop).
+  const int bc_col = tid >> 2, bc_kq = tid & 3;
+  int bc_n = 0, bc_voff = 0;
+  if (BCM) {
+    const int kg = kbeg + 4 * bc_kq;
+    bc_n = kg % g.b_kdiv;
+    bc_voff = (int)(((long)(kg / g.b_kdiv) * g.b_sdiv + bc_n + (long)(n0 + bc_col) * g.b_ld) * 4);
+  }
+  const int bc_st = OPER + bc_col * LDRB + 4 * bc_kq;                      // + 64 * LDRB for the second float4
   // transposed fragment read: each 16-lane group fetches a 4 (k) x 16 (rows) block; lane 4q+p of the group supplies
   // the address of block row q, columns 4p..4p+3, and receives the 4 k of row (lane & 15)
   const int tr_off = (8 * lh + ((lane & 15) >> 2)) * LDT + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-  const int a_rd = tr_off + wr * 64, b_rd = OPER + tr_off + wc * 64;
+  const int a_rd = tr_off + wr * 64;
+  const int b_rd = BCM ? OPER + (wc * 64 + li) * LDRB + 8 * lh : OPER + tr_off + wc * 64;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -103,6 +117,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnJobs jobs) {
         rawt[x][0] = buf_load4(rs_a1, a_voff + (x & 1) * a_half + s * a_step, 0);
         rawt[x][1] = buf_load4(rs_a2, a_voff + (x & 1) * a_half + s * a_step, 0);
       }
+    } else if (BCM) {
+      raw[x] = buf_load4(rs_b, bc_voff + (x & 1) * 64 * g.b_ld * 4, 0);
+      if (x == 3) {                              // both columns of this step requested: on to the next 16 k
+        bc_n += BK; bc_voff += BK * 4;
+        if (bc_n >= g.b_kdiv) { bc_n -= g.b_kdiv; bc_voff += (int)((g.b_sdiv - g.b_kdiv) * 4); }
+      }
     } else raw[x] = buf_load4(rs_b, b_voff + (x & 1) * b_half + s * b_step, 0);
   };
   auto stage = [&](int x, int e, int st) {       // split of raw[x], pair e, in three stages of 5, 5 and 1 VALU
@@ -124,13 +144,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnJobs jobs) {
   };
   auto write_piece = [&](short* buf, int x, int q) {
     const u32x2 v = q == 0 ? u32x2{ph[0], ph[1]} : (q == 1 ? u32x2{pm[0], pm[1]} : u32x2{pl[0], pl[1]});
-    *reinterpret_cast<u32x2*>(&buf[(x >> 1) * OPER + q * IMG + (x & 1) * 8 * LDT + st_off]) = v;
+    if (BCM && x >= 2) *reinterpret_cast<u32x2*>(&buf[q * IMGB + (x & 1) * 64 * LDRB + bc_st]) = v;
+    else *reinterpret_cast<u32x2*>(&buf[(x >> 1) * OPER + q * IMG + (x & 1) * 8 * LDT + st_off]) = v;
   };
   // fragment reads in the order of first use: a2, b0, a0, b2, a1, b1 (tile 0, tile 1; lo, hi): r = 0..23
   auto read_frag = [&](auto SETc, const short* buf, int r) {
     constexpr int SET = decltype(SETc)::value;
     constexpr int QA[3] = {2, 0, 1}, QB[3] = {0, 2, 1};
     const int grp = r >> 2, isb = grp & 1, q = isb ? QB[grp >> 1] : QA[grp >> 1], tile = (r >> 1) & 1, hi = r & 1;
+    if (BCM && isb) {                            // one 16-byte read per fragment (issued with its first half)
+      if (hi == 0) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(buf + q * IMGB + b_rd + tile * 32 * LDRB);
+        fb[SET][q][tile][0] = bf16x4{v[0], v[1], v[2], v[3]};
+        fb[SET][q][tile][1] = bf16x4{v[4], v[5], v[6], v[7]};
+      }
+      return;
+    }
     const short* ptr = buf + q * IMG + (isb ? b_rd : a_rd) + tile * 32 + hi * 4 * LDT;
     if (isb) fb[SET][q][tile][hi] = lds_tr16(ptr);
     else fa[SET][q][tile][hi] = lds_tr16(ptr);
@@ -167,8 +196,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnJobs jobs) {
 
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
-  short* const img0 = &lds[0][0];
-  short* const img1 = &lds[1][0];
+  short* const img0 = lds;
+  short* const img1 = lds + BUF;
   // prologue: step 0 into image 0, raw = step 1, fragments of step 0 in set 0
 #pragma unroll
   for (int x = 0; x < 4; ++x) load_raw(x, 0);
@@ -205,14 +234,28 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnJobs jobs) {
     }
 }
 
+// Up to two jobs per launch (dW_v and dW_q): the second one's workgroups fill the slots the first leaves idle.
+// SUM3 / BCM describe job 0; job 1 is always plain.
+template <bool SUM3, bool BCM>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnJobs jobs) {
+  extern __shared__ __attribute__((aligned(16))) short lds_dyn[];          // 2 buffers: 61,440 B (BCM: 67,584 B)
+  if ((int)blockIdx.x < jobs.first1) gemm_tn_body<SUM3, BCM>(jobs.job[0], (int)blockIdx.x, jobs.first1, lds_dyn);
+  else gemm_tn_body<false, false>(jobs.job[1], (int)blockIdx.x - jobs.first1, (int)gridDim.x - jobs.first1, lds_dyn);
+}
+
 }  // namespace
 
 int gemm_tn_supported(const TnGemm& d) {
   auto pal = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
   bool ok = d.M > 0 && d.N > 0 && (d.M % BM) == 0 && (d.N % BN) == 0 && d.K >= BK && d.levels >= 1 && d.levels <= 8 &&
             (d.a_ld & 3) == 0 && (d.b_ld & 3) == 0 && (d.a_term & 3) == 0 && (d.a_sl & 3) == 0 && (d.b_sl & 3) == 0 && pal(d.A) &&
-            (d.b_ptrs[0] ? true : pal(d.B)) && (long)(d.K + 2 * BK) * d.a_ld * 4 < 0x40000000L &&
-            (long)(d.K + 2 * BK) * d.b_ld * 4 < 0x40000000L;
+            (d.b_ptrs[0] ? true : pal(d.B)) && (long)(d.K + 2 * BK) * d.a_ld * 4 < 0x40000000L;
+  if (d.b_kdiv) {    // B contiguous along k inside groups of b_kdiv rows
+    ok = ok && d.levels == 1 && !d.b_ptrs[0] && d.b_kdiv >= BK && (d.b_kdiv & 3) == 0 && (d.b_sdiv & 3) == 0 &&
+         (d.K % d.b_kdiv) == 0 && ((long)(d.K / d.b_kdiv + 2) * d.b_sdiv + (long)d.N * d.b_ld) * 4 < 0x40000000L;
+  } else {
+    ok = ok && (long)(d.K + 2 * BK) * d.b_ld * 4 < 0x40000000L;
+  }
   for (int t = 0; t < 8; ++t) ok = ok && pal(d.b_ptrs[t]);
   return ok ? 1 : 0;
 }
@@ -236,6 +279,7 @@ static int fill_job(const TnGemm& d, int ksplit, int S, TnArgs& g, long* nblk) {
   g = TnArgs{};
   g.A = d.A; g.a_sl = d.a_sl; g.a_ld = d.a_ld; g.a_term = d.a_term;
   g.B = d.B; g.b_sl = d.b_sl; g.b_ld = d.b_ld;
+  g.b_kdiv = d.b_kdiv; g.b_sdiv = d.b_sdiv; g.b_bytes = d.b_kdiv ? (unsigned)((long)(d.K / d.b_kdiv) * d.b_sdiv * 4) : 0u;
   for (int t = 0; t < 8; ++t) g.b_ptrs[t] = d.b_ptrs[t];
   g.C = d.C; g.M = d.M; g.N = d.N; g.K = d.K; g.ksplit = ksplit; g.S = S;
   *nblk = (long)(d.M / BM) * (d.N / BN) * d.levels * S;
@@ -247,16 +291,25 @@ int launch_gemm_tn(const TnGemm* d, const int* ksplit, const int* S, int n, hipS
   CA_CHECK_ARG(n == 1 || n == 2, "gemm_tn: 1 or 2 jobs per launch");
   TnJobs jobs = {};
   long nb[2] = {0, 0};
-  bool sum3 = false;
-  for (int i = 0; i < n; ++i) {
-    CA_TRY(fill_job(d[i], ksplit[i], S[i], jobs.job[i], &nb[i]));
-    sum3 = sum3 || d[i].a_term != 0;
-  }
+  for (int i = 0; i < n; ++i) CA_TRY(fill_job(d[i], ksplit[i], S[i], jobs.job[i], &nb[i]));
   CA_CHECK_ARG(nb[0] + nb[1] < 2147483647L, "gemm_tn: grid too large");
   jobs.first1 = (int)nb[0];
+  CA_CHECK_ARG(n == 1 || (d[1].a_term == 0 && d[1].b_kdiv == 0), "gemm_tn: only the first job may sum three A terms or have a k-contiguous B");
+  const bool sum3 = d[0].a_term != 0, bcm = d[0].b_kdiv != 0;
   const dim3 grid((unsigned)(nb[0] + nb[1]));
-  if (sum3) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, s, jobs);
-  else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, s, jobs);
+  const size_t lds = (size_t)2 * (OPER + (bcm ? OPERB : OPER)) * sizeof(short);
+  if (bcm) {                                             // 67,584 B of dynamic LDS: above the 64 KB default limit
+    static DeviceOnce once;
+    CA_TRY(once.run([&] {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      return e;
+    }, "gemm_tn"));
+  }
+  if (sum3 && bcm) hipLaunchKernelGGL((gemm_tn_kernel<true, true>), grid, dim3(256), lds, s, jobs);
+  else if (bcm) hipLaunchKernelGGL((gemm_tn_kernel<false, true>), grid, dim3(256), lds, s, jobs);
+  else if (sum3) hipLaunchKernelGGL((gemm_tn_kernel<true, false>), grid, dim3(256), lds, s, jobs);
+  else hipLaunchKernelGGL((gemm_tn_kernel<false, false>), grid, dim3(256), lds, s, jobs);
   CA_CHECK_LAUNCH("gemm_tn");
   return 0;
 }

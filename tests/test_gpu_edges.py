@@ -308,3 +308,22 @@ def test_repeated_runs_are_bitwise_identical(shape):
             ref = outs
         else:
             assert all(torch.equal(a, b) for a, b in zip(ref, outs))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout,N", [("lm", 196), ("cm", 196), ("lm", 49)])
+def test_gradients_do_not_depend_on_whether_dV_is_requested(layout, N):
+    """Without dV (the frozen-encoder default) the weight-gradient kernel adds the three levels of dP_v while it
+    stages them; with dV a separate pass sums them first.  Same additions in the same order: every other gradient
+    must be bit-for-bit the same either way, on both feature layouts."""
+    from tests._hip import run_hip
+    B, T, d = 24, 26, 512
+    P = O.make_params(d, 21)
+    V, Qs = O.make_inputs(B, N, T, d, 31, lens=sorted([T] + [2 + (3 * i) % 24 for i in range(B - 1)], reverse=True),
+                          scale_q=(2.0 / d) ** 0.5)
+    gv = torch.from_numpy(O.hash_normal((3, B, d), 41)).float()
+    gq = torch.from_numpy(O.hash_normal((3, B, d), 42)).float()
+    a = run_hip(V, Qs, P, gv, gq, impl="fused", layout=layout, need_dv=True)
+    b = run_hip(V, Qs, P, gv, gq, impl="fused", layout=layout, need_dv=False)
+    for k in ("dQ", "dW_v.weight", "dW_q.weight", "dw_v.weight", "dw_q.weight", "dW_v.bias", "dW_q.bias"):
+        assert torch.equal(a[k], b[k]), k

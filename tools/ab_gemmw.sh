@@ -9,7 +9,7 @@ f=sorted(glob.glob("gpurun_out/gw_%s/**/*kernel_trace.csv" % sys.argv[1], recurs
 agg=collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     n=r["Kernel_Name"]
-    if "gemm" in n or "wsplit" in n:
+    if "gemm_w" in n:
         agg[(n[:60], r["Grid_Size_X"])].append((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3)
 for k,v in sorted(agg.items()):
     v2=sorted(v[len(v)//2:]); print("%-8s %-60s grid %8s n %4d med %7.1f min %7.1f" % (sys.argv[1],k[0],k[1],len(v2),v2[len(v2)//2],v2[0]))

@@ -83,9 +83,9 @@ extern "C" int coattn_workspace_bytes(int B, int N, int T, int d, int L, int dty
   CA_TRY(check_shape(B, N, T, d, L, dtype));
   const SavedPlan sp = plan_saved(B, N, T, d, L);
   if (saved) *saved = sp.total * sizeof(float);
-  // both workspaces end with room for two pre-split weight images (gemm_w.hip)
+  // the forward workspace ends with room for two pre-split weight images (gemm_w.hip)
   if (ws_fwd) *ws_fwd = fwd_ws_floats(B, N, T, d, L) * sizeof(float) + 2 * wsplit_bytes(d, d);
-  if (ws_bwd) *ws_bwd = bwd_ws_floats(B, N, T, d, L) * sizeof(float) + 2 * wsplit_bytes(d, d);
+  if (ws_bwd) *ws_bwd = bwd_ws_floats(B, N, T, d, L) * sizeof(float);
   return 0;
 }
 
@@ -190,7 +190,9 @@ static bool gemm_w_enabled() {
 }
 
 // wimg: room for two pre-split weight images (wsplit_bytes(d, d) each) at the end of the forward workspace
-int general_projections(const Ctx& c, const float* V, const float* const* Q, const coattn_params* p, float* sv, char* wimg) {
+// keep_wqT: also split W_q the other way round into the saved state (sp.wqT) for the backward's dQ projection
+int general_projections(const Ctx& c, const float* V, const float* const* Q, const coattn_params* p, float* sv, char* wimg,
+                        bool keep_wqT) {
   const SavedPlan sp = plan_saved(c.B, c.N, c.T, c.d, c.L);
   const size_t BTd = (size_t)c.B * c.T * c.d;
   // fp32 projections of row-major activations: the weight is split once, the GEMM reads it as MFMA fragments
@@ -210,10 +212,11 @@ int general_projections(const Ctx& c, const float* V, const float* const* Q, con
   }
   const bool q_w = w_ok && gemm_w_supported(wq);
   if (v_w || q_w) {
-    WSplit jobs[2];
+    WSplit jobs[3];
     int nj = 0;
     if (v_w) jobs[nj++] = WSplit{(const float*)p->W_v, const_cast<void*>(wv.Wf), c.d, c.d, 0, c.d};
     if (q_w) jobs[nj++] = WSplit{(const float*)p->W_q, const_cast<void*>(wq.Wf), c.d, c.d, 0, c.d};
+    if (q_w && keep_wqT) jobs[nj++] = WSplit{(const float*)p->W_q, sv + sp.wqT, c.d, c.d, 1, c.d};
     CA_TRY(launch_wsplit(jobs, nj, c.s));
   }
   if (v_w && q_w) {                                   // both projections in one launch
@@ -449,7 +452,7 @@ static int forward_impl(const void* V, const VLayout& vl, const void* const* Q, 
   c.pscale = fused ? kPScale : 1.f;
   if (do_proj)
     CA_TRY(general_projections(c, (const float*)V, (const float* const*)Q, p, sv,
-                               (char*)ws + fwd_ws_floats(B, N, T, d, L) * sizeof(float)));
+                               (char*)ws + fwd_ws_floats(B, N, T, d, L) * sizeof(float), saved != nullptr));
   if (!do_attn) return 0;
   if (fused)
     return fused_attention_forward(B, N, T, d, L, (const float*)V, vl, (const float* const*)Q, p, (float*)v_out,
@@ -495,7 +498,7 @@ extern "C" int coattn_backward(const void* V, int64_t v_sB, int64_t v_sN, int64_
     return fused_backward(B, N, T, d, L, (const float*)V, vl, (const float* const*)Q, p, (const float*)saved,
                           (const float*)gv, (const float*)gq, (float*)dV, dvl, (float* const*)dQ, pg, accumulate,
                           (float*)ws, c.s, c.bf16_proj ? 1 : 0,
-                          gemm_w_enabled() ? (char*)ws + bwd_ws_floats(B, N, T, d, L) * sizeof(float) : nullptr);
+                          gemm_w_enabled() ? 1 : 0);
   return backward_general(c, (const float*)V, (const float* const*)Q, p, (const float*)saved, (const float*)gv,
                           (const float*)gq, (float*)dV, dvl, (float* const*)dQ, pg, accumulate, (float*)ws);
 }

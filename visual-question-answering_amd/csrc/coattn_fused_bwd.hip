@@ -317,7 +317,7 @@ int fused_backward_supported(int B, int N, int T, int d, int L) { return fused_s
 int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLayout& vl, const float* const* Q,
                    const coattn_params* p, const float* saved, const float* gv, const float* gq, float* dV,
                    const VLayout& dvl, float* const* dQ, const coattn_param_grads* pg, int accumulate, float* ws,
-                   hipStream_t s, int bf16_proj, char* wimg) {
+                   hipStream_t s, int bf16_proj, int wgemm) {
   CA_CHECK_ARG(fused_backward_supported(B, N, T, d, L), "fused backward: unsupported shape");
   const bool lm = v_is_lm(vl, N, d);
   CA_CHECK_ARG(lm || v_is_cm(vl, N, d), "fused backward: image features must be channel-major [B,d,N] or location-major [B,N,d]");
@@ -361,16 +361,14 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   }
   // dQ_l (+)= dP_q,l W_q for all levels in one launch (batch z = level, C through the pointer table)
   auto dq_projection = [&](bool onto_dq) -> int {
-    if (!onto_dq && !bf16_proj && wimg) {            // W_q split once, read as MFMA fragments (gemm_w.hip)
+    if (!onto_dq && !bf16_proj && wgemm) {           // W_q split once, read as MFMA fragments (gemm_w.hip)
       WGemm w = {};
-      w.A = ws + wo.dPq; w.a_sz = (long)BTd; w.a_sm = d; w.Wf = wimg;
+      // (the image of W_q for this product was written into the saved state by the forward's split launch: the
+      //  same shape test decided there, api.hip general_projections)
+      w.A = ws + wo.dPq; w.a_sz = (long)BTd; w.a_sm = d; w.Wf = saved + so.wqT;
       for (int l = 0; l < L; ++l) w.c_ptrs[l] = dQ[l];
       w.c_sm = d; w.M = B * T; w.N = d; w.K = d; w.batch = L;
-      if (gemm_w_supported(w)) {
-        const WSplit job{(const float*)p->W_q, wimg, d, d, 1, d};
-        CA_TRY(launch_wsplit(&job, 1, s));
-        return launch_gemm_w(&w, 1, s);
-      }
+      if (gemm_w_supported(w)) return launch_gemm_w(&w, 1, s);
     }
     coattn_gemm_desc g = {};
     g.A = ws + wo.dPq; g.a_sz = (int64_t)BTd; g.a_sm = d; g.a_sk = 1;
@@ -442,9 +440,9 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   TnGemm tnv = {};
   tnv.A = dPv; tnv.a_ld = d; tnv.B = V; tnv.b_ld = (int)vl.sN; tnv.C = part; tnv.M = d; tnv.N = d; tnv.K = B * N; tnv.levels = 1;
   bool tn_v = false;
-  if (wimg && !bf16_proj && lm && vl.sB == (long)N * vl.sN && vl.sN < (1L << 24)) {
+  if (wgemm && !bf16_proj && lm && vl.sB == (long)N * vl.sN && vl.sN < (1L << 24)) {
     tn_v = gemm_tn_supported(tnv) != 0;              // location-major rows, samples abutting
-  } else if (wimg && !bf16_proj && !lm && vl.sD < (1L << 24)) {
+  } else if (wgemm && !bf16_proj && !lm && vl.sD < (1L << 24)) {
     tnv.b_ld = (int)vl.sD; tnv.b_kdiv = N; tnv.b_sdiv = vl.sB;          // channel-major, read in place
     tn_v = gemm_tn_supported(tnv) != 0;
   }
@@ -471,7 +469,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   TnGemm tnq = {};
   tnq.A = ws + wo.dPq; tnq.a_sl = (long)BTd; tnq.a_ld = d; tnq.b_ld = d; tnq.M = d; tnq.N = d; tnq.K = B * T; tnq.levels = L;
   for (int l = 0; l < L; ++l) tnq.b_ptrs[l] = Q[l];
-  const bool tn_q = wimg && !bf16_proj && gemm_tn_supported(tnq);       // levels as extra split-K parts (gemm_tn.hip)
+  const bool tn_q = wgemm && !bf16_proj && gemm_tn_supported(tnq);       // levels as extra split-K parts (gemm_tn.hip)
   if (tn_v && tn_q) {
     // both weight gradients in one launch: 32 split-K parts (x 16 tiles = the 512 workgroup slots) shared in
     // proportion to the contraction lengths, so that all workgroups run about equally long

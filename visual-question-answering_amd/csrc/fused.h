@@ -22,7 +22,7 @@ int fused_backward_supported(int B, int N, int T, int d, int L);
 int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLayout& vl, const float* const* Q,
                    const coattn_params* p, const float* saved, const float* gv, const float* gq, float* dV,
                    const VLayout& dvl, float* const* dQ, const coattn_param_grads* pg, int accumulate, float* ws,
-                   hipStream_t s, int bf16_proj, char* wimg);
+                   hipStream_t s, int bf16_proj, int wgemm);   // wgemm: gemm_w / gemm_tn enabled
 
 // Diagnostic build only (tools/probe_stamps.py, -DCOATTN_STAMPS=1): wave 0 of every workgroup writes the
 // 100 MHz constant clock at its phase boundaries into the (otherwise unused) forward workspace tail.
@@ -240,7 +240,7 @@ int launch_attend_v_lm(const float* V, long v_sB, const float* av, float* v_out,
 inline size_t fal64(size_t n) { return (n + 63) & ~(size_t)63; }
 
 struct SavedOff {
-  size_t Pv, Pq, C, av, aq, Hq, total;
+  size_t Pv, Pq, C, av, aq, Hq, wqT, total;
 };
 inline SavedOff saved_off(int B, int N, int T, int d, int L) {   // the one layout of `saved`
   SavedOff p;
@@ -251,6 +251,9 @@ inline SavedOff saved_off(int B, int N, int T, int d, int L) {   // the one layo
   p.av = o; o += fal64((size_t)L * B * N);
   p.aq = o; o += fal64((size_t)L * B * T);
   p.Hq = o; o += fal64((size_t)L * B * T * d);
+  // W_q split for the backward's dQ projection (gemm_w.hip, wsplit_bytes(d, d)): written by the forward's weight-split
+  // launch, so that the backward has no split launch of its own
+  p.wqT = o; o += fal64((size_t)((d + 31) / 32) * ((d + 15) / 16) * 768);
   p.total = o;
   return p;
 }

@@ -39,7 +39,7 @@ struct WArgs {
 struct WJobs { WArgs job[2]; int first1; };   // blocks [0, first1) work on job 0, the rest on job 1
 
 struct SplitJob { const float* W; void* out; int N, K, trans, ld; };
-struct SplitArgs { SplitJob job[2]; int njobs; };
+struct SplitArgs { SplitJob job[3]; int njobs; };
 
 // One wave per (32-column tile nt, 16-k step ks): lane (li = lane & 31, lh = lane >> 5) holds
 // Bw(k = 16 ks + 8 lh + e, n = 32 nt + li), e = 0..7 -- the B operand layout of v_mfma_f32_32x32x16_bf16.
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void gemm_w_kernel(const WJobs jobs) {
 size_t wsplit_bytes(int N, int K) { return (size_t)((N + 31) / 32) * ((K + 15) / 16) * kChunkBytes; }
 
 int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s) {
-  CA_CHECK_ARG(njobs >= 1 && njobs <= 2, "wsplit: 1 or 2 jobs per launch");
+  CA_CHECK_ARG(njobs >= 1 && njobs <= 3, "wsplit: 1 to 3 jobs per launch");
   SplitArgs a = {};
   a.njobs = njobs;
   int chunks = 0;

@@ -33,7 +33,12 @@ shutil.copy(os.path.join(SRC, "pmc_traffic.json"), os.path.join(DST, "pmc_traffi
 
 # MFMA-busy pass: mean counter value per kernel, and MFMA busy fraction = MFMA_BUSY / (32 * SQ_BUSY)
 vals = {}
-for f in glob.glob(os.path.join(SRC, "pmc_mfma", "**", "*counter_collection.csv"), recursive=True):
+def newest(pattern):                                # gpurun merges accumulate older runs' files locally: newest only
+    hits = glob.glob(os.path.join(SRC, pattern), recursive=True)
+    return [max(hits, key=os.path.getmtime)] if hits else []
+
+
+for f in newest("pmc_mfma/**/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         kern = ("coattn_fwd32_kernel" if "coattn_fwd32" in k else "attend_v_lm_kernel" if "attend_v" in k else None)
@@ -51,7 +56,7 @@ if vals:
     json.dump(out, open(os.path.join(DST, "%s_pmc_mfma.json" % tag), "w"), indent=1)
 # the same counters over the whole isolated hot path (bench.py --only hot): one entry per kernel of the HIP library
 hot = {}
-for f in glob.glob(os.path.join(SRC, "pmc_hot", "**", "*counter_collection.csv"), recursive=True):
+for f in newest("pmc_hot/**/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "anonymous namespace" not in k or "at::native" in k or "softmax_warp" in k:

@@ -14,6 +14,8 @@
 // [row][k] bf16 images, one ds_read_b128 per fragment), double-buffered so that a K step has one barrier.
 //
 // Tile 128 x 128 per 256-thread workgroup, 4 waves as 2 x 2, each wave 2 x 2 MFMA tiles; BK = 32.
+// Developer switches (tools/ab_gemmw.sh, never in the shipped library): -DGEMMW_NOB / _NOSPLIT / _NOMFMA compile the
+// B-fragment loads / the split arithmetic / the MFMAs out (wrong results) to price them.
 // Numerics: the six partial products of gemm.hip's split mode in the same order (exact operand pieces,
 // fp32 accumulation), so the two kernels agree to accumulation order.
 #include "common.h"

@@ -350,15 +350,21 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   ba.B = B; ba.N = N; ba.T = T; ba.d = d; ba.L = L;
   CA_TRY(launch_bwd_dc32(ba, s));                    // dC, dA                       (coattn_bwd32.hip)
   CA_TRY(launch_bwd_nat32(ba, s));                   // dP_q, dP_v, dw_v, db_v, db_q (coattn_bwd32.hip)
-  // 3. small parameter gradients from the per-(sample, level) partials, one launch
+  // 3. small parameter gradients from the per-(sample, level) partials (dw_v, db_v, db_q, dw_q, and dc_v, dc_q as
+  //    whole-array sums): a few short workgroups -- riding along in the weight-gradient launch of step 5 when that
+  //    is the hand-scheduled one, else a launch of their own
+  TnReduce small = {};
   {
     const float* src[4] = {ws + wo.dwv_part, ws + wo.dbv_part, ws + wo.dbq_part, ws + wo.dwq_part};
     float* dst[4] = {(float*)pg->dw_v, (float*)pg->db_v, (float*)pg->db_q, (float*)pg->dw_q};
-    // (dc_v, dc_q: whole-array sums of the per-(sample, level) partials, rows of the same launch)
-    const float* sx[2] = {ws + wo.dcs_part, ws + wo.dcs_part + (size_t)L * B};
-    float* so2[2] = {(float*)pg->dc_v, (float*)pg->dc_q};
-    CA_TRY(launch_reduce_jobs(src, dst, 4, L * B, d, accumulate, s, sx, so2, (int64_t)L * B));
+    for (int i = 0; i < 4; ++i) { small.src[i] = src[i]; small.dst[i] = dst[i]; }
+    small.njobs = 4; small.nparts = L * B; small.n = d; small.accumulate = accumulate;
+    small.sum_x[0] = ws + wo.dcs_part; small.sum_x[1] = ws + wo.dcs_part + (size_t)L * B;
+    small.sum_out[0] = (float*)pg->dc_v; small.sum_out[1] = (float*)pg->dc_q; small.sum_n = (long)L * B;
   }
+  auto small_reductions = [&]() -> int {
+    return launch_reduce_jobs(small.src, small.dst, 4, L * B, d, accumulate, s, small.sum_x, small.sum_out, small.sum_n);
+  };
   // dQ_l (+)= dP_q,l W_q for all levels in one launch (batch z = level, C through the pointer table)
   auto dq_projection = [&](bool onto_dq) -> int {
     if (!onto_dq && !bf16_proj && wgemm) {           // W_q split once, read as MFMA fragments (gemm_w.hip)
@@ -483,11 +489,12 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     const int parts_q = gemm_tn_plan(tnq, pq, &ks[1], &S[1]);
     CA_CHECK_ARG(parts_v + parts_q <= kMaxParts, "fused backward: %d split-K parts exceed the workspace", parts_v + parts_q);
     const TnGemm both[2] = {tnv, tnq};
-    CA_TRY(launch_gemm_tn(both, ks, S, 2, s));
+    CA_TRY(launch_gemm_tn(both, ks, S, 2, s, &small));
     return launch_reduce_partials2(part, (float*)pg->dW_v, parts_v, tnq.C, (float*)pg->dW_q, parts_q, (int64_t)d * d,
                                    accumulate, s);
   }
   tnq.C = part;
+  CA_TRY(small_reductions());
   {
     // dW_v[j][k] = sum_{b,n} dP_v[b][n][j] V[b][k][n]
     coattn_gemm_desc g = {};

@@ -74,6 +74,60 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- small reductions shared by reduce_jobs_kernel (small_kernels.hip) and gemm_tn_kernel (extra workgroups) ----
+// up to 4 independent reductions of [nparts][n] partial buffers (row `by` = job, 64 columns per block `bx`)
+// plus up to 2 whole-array sums (rows by >= njobs, block bx = 0 only): out = sum of sum_x[0 .. sum_n)
+struct ReduceJobs {
+  const float* src[4];
+  float* dst[4];
+  int njobs;
+  const float* sum_x[2];
+  float* sum_out[2];
+  long sum_n;
+};
+__device__ __forceinline__ void reduce_jobs_block(const ReduceJobs& jobs, int nparts, long n, int accumulate, int bx,
+                                                  int by, float (*red)[64]) {
+  // the four waves take interleaved parts and are combined in a fixed order
+  if (by >= jobs.njobs) {                            // whole-array sum (fixed order: as sum_all_kernel)
+    if (bx) return;
+    const float* x = jobs.sum_x[by - jobs.njobs];
+    float* out = jobs.sum_out[by - jobs.njobs];
+    float acc = 0.f;
+    for (long i = threadIdx.x; i < jobs.sum_n; i += 256) acc += x[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float t = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+      out[0] = accumulate ? out[0] + t : t;
+    }
+    return;
+  }
+  const float* part = jobs.src[by];
+  float* out = jobs.dst[by];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const long j = (long)bx * 64 + col;
+  float acc = 0.f;
+  if (j < n) {
+    int c = grp;
+    for (; c + 28 < nparts; c += 32) {               // 8 loads in flight per thread
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(long)(c + 4 * u) * n + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; c < nparts; c += 4) acc += part[(long)c * n + j];
+  }
+  red[grp][col] = acc;
+  __syncthreads();
+  if (grp == 0 && j < n) {
+    const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+    out[j] = accumulate ? out[j] + t : t;
+  }
+}
+
+
 // tanh with ~2e-7 absolute error: 1 v_exp + 1 v_rcp.  (1-e)/(1+e), e = exp(-2|x|) in (0,1].
 // (__fdividef lowers to the full IEEE division sequence on gfx950; v_rcp_f32 is 1 ulp.)
 // 5 VALU ops: tanh(x) = 1 - 2 / (1 + exp(2x)); saturates cleanly (exp -> inf gives 1, -> 0 gives -1).

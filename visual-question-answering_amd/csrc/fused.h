@@ -155,7 +155,12 @@ struct TnGemm {
 };
 int gemm_tn_supported(const TnGemm& d);
 int gemm_tn_plan(const TnGemm& d, int max_parts, int* ksplit, int* S);   // returns the number of parts
-int launch_gemm_tn(const TnGemm* d, const int* ksplit, const int* S, int n, hipStream_t s);   // n = 1 or 2 per launch
+struct TnReduce {                                                    // launch_reduce_jobs's arguments (common.h)
+  const float* src[4]; float* dst[4]; int njobs, nparts; long n; int accumulate;
+  const float* sum_x[2]; float* sum_out[2]; long sum_n;
+};
+// n = 1 or 2 GEMMs per launch; red (may be NULL): small reductions done by extra workgroups of the same launch
+int launch_gemm_tn(const TnGemm* d, const int* ksplit, const int* S, int n, hipStream_t s, const TnReduce* red = nullptr);
 
 // XCD-aware block -> (b, l): blocks i and i+8 share an XCD (round-robin dispatch), so give the
 // L levels of one sample consecutive slots on one XCD.  Speed only; any mapping is correct.

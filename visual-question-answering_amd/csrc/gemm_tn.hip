@@ -37,7 +37,9 @@ struct TnArgs {
   int M, N, K, ksplit, S;
 };
 
-struct TnJobs { TnArgs job[2]; int first1; };  // blocks [0, first1) work on job 0, the rest on job 1
+// blocks [0, nred): the small reductions riding along (reduce_jobs_block, red_bx blocks per row); then
+// [nred, nred + first1): job 0; the rest: job 1
+struct TnJobs { TnArgs job[2]; int first1; ReduceJobs red; int nred, red_bx, red_nparts, red_acc; long red_n; };
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
@@ -239,8 +241,14 @@ __device__ __forceinline__ void gemm_tn_body(const TnArgs& g, const int bid, con
 template <bool SUM3, bool BCM>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnJobs jobs) {
   extern __shared__ __attribute__((aligned(16))) short lds_dyn[];          // 2 buffers: 61,440 B (BCM: 67,584 B)
-  if ((int)blockIdx.x < jobs.first1) gemm_tn_body<SUM3, BCM>(jobs.job[0], (int)blockIdx.x, jobs.first1, lds_dyn);
-  else gemm_tn_body<false, false>(jobs.job[1], (int)blockIdx.x - jobs.first1, (int)gridDim.x - jobs.first1, lds_dyn);
+  const int id = (int)blockIdx.x - jobs.nred, ngemm = (int)gridDim.x - jobs.nred;
+  if (id < 0) {                                      // the backward's small parameter-gradient reductions: a few
+    reduce_jobs_block(jobs.red, jobs.red_nparts, jobs.red_n, jobs.red_acc, (int)blockIdx.x % jobs.red_bx,   // short
+                      (int)blockIdx.x / jobs.red_bx, reinterpret_cast<float(*)[64]>(lds_dyn));   // workgroups, first in the grid
+    return;
+  }
+  if (id < jobs.first1) gemm_tn_body<SUM3, BCM>(jobs.job[0], id, jobs.first1, lds_dyn);
+  else gemm_tn_body<false, false>(jobs.job[1], id - jobs.first1, ngemm - jobs.first1, lds_dyn);
 }
 
 }  // namespace
@@ -287,16 +295,28 @@ static int fill_job(const TnGemm& d, int ksplit, int S, TnArgs& g, long* nblk) {
 }
 
 // one launch for n = 1 or 2 GEMMs (ksplit[i], S[i] from gemm_tn_plan)
-int launch_gemm_tn(const TnGemm* d, const int* ksplit, const int* S, int n, hipStream_t s) {
+// red (may be NULL): small reductions done by extra workgroups of the same launch (launch_reduce_jobs's arguments)
+int launch_gemm_tn(const TnGemm* d, const int* ksplit, const int* S, int n, hipStream_t s, const TnReduce* red) {
   CA_CHECK_ARG(n == 1 || n == 2, "gemm_tn: 1 or 2 jobs per launch");
   TnJobs jobs = {};
+  if (red) {
+    CA_CHECK_ARG(red->njobs >= 1 && red->njobs <= 4 && red->n > 0, "gemm_tn: bad reduction jobs");
+    for (int i = 0; i < red->njobs; ++i) { jobs.red.src[i] = red->src[i]; jobs.red.dst[i] = red->dst[i]; }
+    jobs.red.njobs = red->njobs;
+    const int nsum = red->sum_x[0] ? 2 : 0;
+    for (int i = 0; i < nsum; ++i) { jobs.red.sum_x[i] = red->sum_x[i]; jobs.red.sum_out[i] = red->sum_out[i]; }
+    jobs.red.sum_n = red->sum_n;
+    jobs.red_bx = (int)((red->n + 63) / 64);
+    jobs.nred = jobs.red_bx * (red->njobs + nsum);
+    jobs.red_nparts = red->nparts; jobs.red_n = red->n; jobs.red_acc = red->accumulate;
+  }
   long nb[2] = {0, 0};
   for (int i = 0; i < n; ++i) CA_TRY(fill_job(d[i], ksplit[i], S[i], jobs.job[i], &nb[i]));
   CA_CHECK_ARG(nb[0] + nb[1] < 2147483647L, "gemm_tn: grid too large");
   jobs.first1 = (int)nb[0];
   CA_CHECK_ARG(n == 1 || (d[1].a_term == 0 && d[1].b_kdiv == 0), "gemm_tn: only the first job may sum three A terms or have a k-contiguous B");
   const bool sum3 = d[0].a_term != 0, bcm = d[0].b_kdiv != 0;
-  const dim3 grid((unsigned)(nb[0] + nb[1]));
+  const dim3 grid((unsigned)(jobs.nred + nb[0] + nb[1]));
   const size_t lds = (size_t)2 * (OPER + (bcm ? OPERB : OPER)) * sizeof(short);
   if (bcm) {                                             // 67,584 B of dynamic LDS: above the 64 KB default limit
     static DeviceOnce once;

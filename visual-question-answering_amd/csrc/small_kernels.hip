@@ -145,56 +145,9 @@ __global__ __launch_bounds__(256) void reduce_partials4_kernel(const float* part
   *o = accumulate ? *o + acc : acc;
 }
 
-// up to 4 independent reductions of [nparts][n] partial buffers in one launch (blockIdx.y = job)
-// plus up to 2 whole-array sums (rows blockIdx.y >= njobs, block x = 0 only): out = sum of sum_x[0 .. sum_n)
-struct ReduceJobs {
-  const float* src[4];
-  float* dst[4];
-  int njobs;
-  const float* sum_x[2];
-  float* sum_out[2];
-  long sum_n;
-};
 __global__ __launch_bounds__(256) void reduce_jobs_kernel(const ReduceJobs jobs, int nparts, long n, int accumulate) {
-  // 64 columns per block; the four waves take interleaved parts and are combined in a fixed order
   __shared__ float red[4][64];
-  if ((int)blockIdx.y >= jobs.njobs) {               // whole-array sum (fixed order: as sum_all_kernel)
-    if (blockIdx.x) return;
-    const float* x = jobs.sum_x[blockIdx.y - jobs.njobs];
-    float* out = jobs.sum_out[blockIdx.y - jobs.njobs];
-    float acc = 0.f;
-    for (long i = threadIdx.x; i < jobs.sum_n; i += 256) acc += x[i];
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const float t = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-      out[0] = accumulate ? out[0] + t : t;
-    }
-    return;
-  }
-  const float* part = jobs.src[blockIdx.y];
-  float* out = jobs.dst[blockIdx.y];
-  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const long j = (long)blockIdx.x * 64 + col;
-  float acc = 0.f;
-  if (j < n) {
-    int c = grp;
-    for (; c + 28 < nparts; c += 32) {               // 8 loads in flight per thread
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = part[(long)(c + 4 * u) * n + j];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc += v[u];
-    }
-    for (; c < nparts; c += 4) acc += part[(long)c * n + j];
-  }
-  red[grp][col] = acc;
-  __syncthreads();
-  if (grp == 0 && j < n) {
-    const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
-    out[j] = accumulate ? out[j] + t : t;
-  }
+  reduce_jobs_block(jobs, nparts, n, accumulate, (int)blockIdx.x, (int)blockIdx.y, red);
 }
 
 __global__ __launch_bounds__(256) void add4_inplace_kernel(float* y, const float* x, long n4, int accumulate) {

@@ -350,6 +350,30 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   ba.B = B; ba.N = N; ba.T = T; ba.d = d; ba.L = L;
   CA_TRY(launch_bwd_dc32(ba, s));                    // dC, dA                       (coattn_bwd32.hip)
   CA_TRY(launch_bwd_nat32(ba, s));                   // dP_q, dP_v, dw_v, db_v, db_q (coattn_bwd32.hip)
+  // which of the backward's GEMMs take the hand-scheduled kernels (decided here: when all three do, they share ONE
+  // launch in step 5 -- weight gradients, the dQ projection's tiles and the small reductions)
+  float* dPv = ws + wo.dPv;
+  float* part = ws + wo.part;
+  TnGemm tnv = {};
+  tnv.A = dPv; tnv.a_ld = d; tnv.B = V; tnv.b_ld = (int)vl.sN; tnv.C = part; tnv.M = d; tnv.N = d; tnv.K = B * N; tnv.levels = 1;
+  bool tn_v = false;
+  if (wgemm && !bf16_proj && lm && vl.sB == (long)N * vl.sN && vl.sN < (1L << 24)) {
+    tn_v = gemm_tn_supported(tnv) != 0;              // location-major rows, samples abutting
+  } else if (wgemm && !bf16_proj && !lm && vl.sD < (1L << 24)) {
+    tnv.b_ld = (int)vl.sD; tnv.b_kdiv = N; tnv.b_sdiv = vl.sB;          // channel-major, read in place
+    tn_v = gemm_tn_supported(tnv) != 0;
+  }
+  TnGemm tnq = {};
+  tnq.A = ws + wo.dPq; tnq.a_sl = (long)BTd; tnq.a_ld = d; tnq.b_ld = d; tnq.M = d; tnq.N = d; tnq.K = B * T; tnq.levels = L;
+  for (int l = 0; l < L; ++l) tnq.b_ptrs[l] = Q[l];
+  const bool tn_q = wgemm && !bf16_proj && gemm_tn_supported(tnq);       // levels as extra split-K parts (gemm_tn.hip)
+  const bool dq32 = lm || (N % 4) == 0;              // the bf16 dA V kernel takes both layouts (channel-major: aligned rows)
+  WGemm wdq = {};                                    // dQ_l = dP_q,l W_q against the W_q image the forward left in `saved`
+  wdq.A = ws + wo.dPq; wdq.a_sz = (long)BTd; wdq.a_sm = d; wdq.Wf = saved + so.wqT;
+  for (int l = 0; l < L; ++l) wdq.c_ptrs[l] = dQ[l];
+  wdq.c_sm = d; wdq.M = B * T; wdq.N = d; wdq.K = d; wdq.batch = L;
+  const bool wdq_ok = !bf16_proj && wgemm && gemm_w_supported(wdq);
+  const bool combine = dq32 && wdq_ok && tn_v && tn_q;
   // 3. small parameter gradients from the per-(sample, level) partials (dw_v, db_v, db_q, dw_q, and dc_v, dc_q as
   //    whole-array sums): a few short workgroups -- riding along in the weight-gradient launch of step 5 when that
   //    is the hand-scheduled one, else a launch of their own
@@ -367,15 +391,9 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   };
   // dQ_l (+)= dP_q,l W_q for all levels in one launch (batch z = level, C through the pointer table)
   auto dq_projection = [&](bool onto_dq) -> int {
-    if (!onto_dq && !bf16_proj && wgemm) {           // W_q split once, read as MFMA fragments (gemm_w.hip)
-      WGemm w = {};
-      // (the image of W_q for this product was written into the saved state by the forward's split launch: the
-      //  same shape test decided there, api.hip general_projections)
-      w.A = ws + wo.dPq; w.a_sz = (long)BTd; w.a_sm = d; w.Wf = saved + so.wqT;
-      for (int l = 0; l < L; ++l) w.c_ptrs[l] = dQ[l];
-      w.c_sm = d; w.M = B * T; w.N = d; w.K = d; w.batch = L;
-      if (gemm_w_supported(w)) return launch_gemm_w(&w, 1, s);
-    }
+    // (W_q split once by the forward's launch -- the same shape test decided there, api.hip general_projections --
+    //  and read as MFMA fragments, gemm_w.hip)
+    if (!onto_dq && wdq_ok) return launch_gemm_w(&wdq, 1, s);
     coattn_gemm_desc g = {};
     g.A = ws + wo.dPq; g.a_sz = (int64_t)BTd; g.a_sm = d; g.a_sk = 1;
     g.B = p->W_q; g.b_sk = d; g.b_sn = 1;
@@ -389,9 +407,9 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   //    The projection writes dQ first and the bf16 dA V kernel adds onto it (the GEMM is 24 us faster without an
   //    accumulate input); channel-major features with unaligned rows (N % 4 != 0): the exact-f32 kernel first, then
   //    the projection onto it.
-  const bool dq32 = lm || (N % 4) == 0;              // the bf16 dA V kernel takes both layouts (channel-major: aligned rows)
-  if (dq32) CA_TRY(dq_projection(false));
-  {
+  //    When the projection shares the weight-gradient launch (step 5), the dA V kernel runs after that launch.
+  if (dq32 && !combine) CA_TRY(dq_projection(false));
+  auto run_dq = [&]() -> int {
     DqArgs da;
     da.accumulate = dq32 ? 1 : 0;
     da.V = V; da.v_sB = vl.sB; da.dA = ws + wo.dA; da.aq = saved + so.aq; da.gq = gq;
@@ -423,7 +441,9 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
       else hipLaunchKernelGGL((bwd_dq_kernel<13, false>), grid, block, lds, s, da);
     }
     CA_CHECK_LAUNCH("bwd_dq");
-  }
+    return 0;
+  };
+  if (!combine) CA_TRY(run_dq());
   if (dV) {
     for (int l = 0; l < L; ++l) {
       const float* dA = ws + wo.dA + l * BTN;
@@ -441,17 +461,6 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   if (!dq32) CA_TRY(dq_projection(true));
   // sum dP_v over the levels in place into level 0 (one streaming pass for L = 3; folding the sum into
   // the weight-gradient GEMM's operand loads was measured slower: 302 vs 170 + 50 us)
-  float* dPv = ws + wo.dPv;
-  float* part = ws + wo.part;
-  TnGemm tnv = {};
-  tnv.A = dPv; tnv.a_ld = d; tnv.B = V; tnv.b_ld = (int)vl.sN; tnv.C = part; tnv.M = d; tnv.N = d; tnv.K = B * N; tnv.levels = 1;
-  bool tn_v = false;
-  if (wgemm && !bf16_proj && lm && vl.sB == (long)N * vl.sN && vl.sN < (1L << 24)) {
-    tn_v = gemm_tn_supported(tnv) != 0;              // location-major rows, samples abutting
-  } else if (wgemm && !bf16_proj && !lm && vl.sD < (1L << 24)) {
-    tnv.b_ld = (int)vl.sD; tnv.b_kdiv = N; tnv.b_sdiv = vl.sB;          // channel-major, read in place
-    tn_v = gemm_tn_supported(tnv) != 0;
-  }
   // (the frozen-encoder default needs no dV: the weight-gradient kernel then adds the three levels while staging them)
   const bool sum_in_gemm = tn_v && L == 3 && !dV;
   if (sum_in_gemm) {
@@ -472,10 +481,6 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     CA_TRY(gemm_proj(g));
   }
   // 5. weight gradients
-  TnGemm tnq = {};
-  tnq.A = ws + wo.dPq; tnq.a_sl = (long)BTd; tnq.a_ld = d; tnq.b_ld = d; tnq.M = d; tnq.N = d; tnq.K = B * T; tnq.levels = L;
-  for (int l = 0; l < L; ++l) tnq.b_ptrs[l] = Q[l];
-  const bool tn_q = wgemm && !bf16_proj && gemm_tn_supported(tnq);       // levels as extra split-K parts (gemm_tn.hip)
   if (tn_v && tn_q) {
     // both weight gradients in one launch: 32 split-K parts (x 16 tiles = the 512 workgroup slots) shared in
     // proportion to the contraction lengths, so that all workgroups run about equally long
@@ -489,7 +494,8 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     const int parts_q = gemm_tn_plan(tnq, pq, &ks[1], &S[1]);
     CA_CHECK_ARG(parts_v + parts_q <= kMaxParts, "fused backward: %d split-K parts exceed the workspace", parts_v + parts_q);
     const TnGemm both[2] = {tnv, tnq};
-    CA_TRY(launch_gemm_tn(both, ks, S, 2, s, &small));
+    CA_TRY(launch_gemm_tn(both, ks, S, 2, s, &small, combine ? &wdq : nullptr));
+    if (combine) CA_TRY(run_dq());
     return launch_reduce_partials2(part, (float*)pg->dW_v, parts_v, tnq.C, (float*)pg->dW_q, parts_q, (int64_t)d * d,
                                    accumulate, s);
   }

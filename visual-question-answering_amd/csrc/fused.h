@@ -160,7 +160,9 @@ struct TnReduce {                                                    // launch_r
   const float* sum_x[2]; float* sum_out[2]; long sum_n;
 };
 // n = 1 or 2 GEMMs per launch; red (may be NULL): small reductions done by extra workgroups of the same launch
-int launch_gemm_tn(const TnGemm* d, const int* ksplit, const int* S, int n, hipStream_t s, const TnReduce* red = nullptr);
+// wextra (may be NULL): one pre-split-weight GEMM (row-major A) whose tiles run as the last workgroups of the launch
+int launch_gemm_tn(const TnGemm* d, const int* ksplit, const int* S, int n, hipStream_t s, const TnReduce* red = nullptr,
+                   const WGemm* wextra = nullptr);
 
 // XCD-aware block -> (b, l): blocks i and i+8 share an XCD (round-robin dispatch), so give the
 // L levels of one sample consecutive slots on one XCD.  Speed only; any mapping is correct.

@@ -16,6 +16,7 @@
 // fence per MFMA).  Numerics: the six partial products of gemm.hip's split mode, same order.
 #include "common.h"
 #include "fused.h"
+#include "gemm_w_body.h"
 #include <type_traits>
 
 namespace {
@@ -39,7 +40,11 @@ struct TnArgs {
 
 // blocks [0, nred): the small reductions riding along (reduce_jobs_block, red_bx blocks per row); then
 // [nred, nred + first1): job 0; the rest: job 1
-struct TnJobs { TnArgs job[2]; int first1; ReduceJobs red; int nred, red_bx, red_nparts, red_acc; long red_n; };
+// the last nw blocks: tiles of a pre-split-weight GEMM (gemm_w_body.h) sharing the launch (dQ = dP_q W_q of the backward)
+struct TnJobs {
+  TnArgs job[2]; int first1; ReduceJobs red; int nred, red_bx, red_nparts, red_acc; long red_n;
+  gw::WArgs wj; int nw;
+};
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
@@ -237,11 +242,16 @@ __device__ __forceinline__ void gemm_tn_body(const TnArgs& g, const int bid, con
 }
 
 // Up to two jobs per launch (dW_v and dW_q): the second one's workgroups fill the slots the first leaves idle.
-// SUM3 / BCM describe job 0; job 1 is always plain.
+// SUM3 / BCM describe job 0; job 1 is always plain.  The backward's whole GEMM work is ONE launch of this kernel:
+// [small reductions][dW_v parts][dW_q parts][tiles of dQ = dP_q W_q on the gemm_w body].
 template <bool SUM3, bool BCM>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnJobs jobs) {
   extern __shared__ __attribute__((aligned(16))) short lds_dyn[];          // 2 buffers: 61,440 B (BCM: 67,584 B)
-  const int id = (int)blockIdx.x - jobs.nred, ngemm = (int)gridDim.x - jobs.nred;
+  const int id = (int)blockIdx.x - jobs.nred, ngemm = (int)gridDim.x - jobs.nred - jobs.nw;
+  if (id >= ngemm) {                                 // (61,440 B of the dynamic LDS)
+    gw::gemm_w_body<false>(jobs.wj, id - ngemm, lds_dyn);
+    return;
+  }
   if (id < 0) {                                      // the backward's small parameter-gradient reductions: a few
     reduce_jobs_block(jobs.red, jobs.red_nparts, jobs.red_n, jobs.red_acc, (int)blockIdx.x % jobs.red_bx,   // short
                       (int)blockIdx.x / jobs.red_bx, reinterpret_cast<float(*)[64]>(lds_dyn));   // workgroups, first in the grid
@@ -296,9 +306,17 @@ static int fill_job(const TnGemm& d, int ksplit, int S, TnArgs& g, long* nblk) {
 
 // one launch for n = 1 or 2 GEMMs (ksplit[i], S[i] from gemm_tn_plan)
 // red (may be NULL): small reductions done by extra workgroups of the same launch (launch_reduce_jobs's arguments)
-int launch_gemm_tn(const TnGemm* d, const int* ksplit, const int* S, int n, hipStream_t s, const TnReduce* red) {
+// wextra (may be NULL): one pre-split-weight GEMM (row-major A) whose tiles run as the last workgroups of the launch
+int launch_gemm_tn(const TnGemm* d, const int* ksplit, const int* S, int n, hipStream_t s, const TnReduce* red,
+                   const WGemm* wextra) {
   CA_CHECK_ARG(n == 1 || n == 2, "gemm_tn: 1 or 2 jobs per launch");
   TnJobs jobs = {};
+  if (wextra) {
+    long nbw = 0;
+    CA_CHECK_ARG(wextra->a_sk == 0, "gemm_tn: the extra GEMM's A operand must be row-major");
+    CA_TRY(gemm_w_fill_job(*wextra, jobs.wj, &nbw));
+    jobs.nw = (int)nbw;
+  }
   if (red) {
     CA_CHECK_ARG(red->njobs >= 1 && red->njobs <= 4 && red->n > 0, "gemm_tn: bad reduction jobs");
     for (int i = 0; i < red->njobs; ++i) { jobs.red.src[i] = red->src[i]; jobs.red.dst[i] = red->dst[i]; }
@@ -316,7 +334,7 @@ int launch_gemm_tn(const TnGemm* d, const int* ksplit, const int* S, int n, hipS
   jobs.first1 = (int)nb[0];
   CA_CHECK_ARG(n == 1 || (d[1].a_term == 0 && d[1].b_kdiv == 0), "gemm_tn: only the first job may sum three A terms or have a k-contiguous B");
   const bool sum3 = d[0].a_term != 0, bcm = d[0].b_kdiv != 0;
-  const dim3 grid((unsigned)(jobs.nred + nb[0] + nb[1]));
+  const dim3 grid((unsigned)(jobs.nred + nb[0] + nb[1] + jobs.nw));
   const size_t lds = (size_t)2 * (OPER + (bcm ? OPERB : OPER)) * sizeof(short);
   if (bcm) {                                             // 67,584 B of dynamic LDS: above the 64 KB default limit
     static DeviceOnce once;

@@ -24,10 +24,9 @@ namespace {
 
 // partial da_v over 64 channel rows: part[b][kc][l][n] = sum_{k in chunk kc} V[b][k][n] gv[l][b][k].
 // grid (d/64, B); thread <-> location n (rows of V are contiguous in n: fully coalesced).
-__global__ __launch_bounds__(256) void bwd_dav_kernel(const float* V, long v_sB, const float* gv, float* part, int B,
-                                                      int N, int d, int L) {
-  const int b = blockIdx.y, kc = blockIdx.x, n = threadIdx.x;
-  __shared__ float g[3][64];
+__device__ __forceinline__ void dav_cm_block(const float* V, long v_sB, const float* gv, float* part, int B, int N, int d,
+                                             int L, int kc, int b, int nkc, float (*g)[64]) {
+  const int n = threadIdx.x;
   if (threadIdx.x < 192) {
     const int l = threadIdx.x >> 6, k = threadIdx.x & 63;
     g[l][k] = (l < L) ? gv[((size_t)l * B + b) * d + kc * 64 + k] : 0.f;
@@ -43,18 +42,18 @@ __global__ __launch_bounds__(256) void bwd_dav_kernel(const float* V, long v_sB,
     a1 = fmaf(x, g[1][k], a1);
     a2 = fmaf(x, g[2][k], a2);
   }
-  float* o = part + (((size_t)b * gridDim.x + kc) * 3) * N + n;
+  float* o = part + (((size_t)b * nkc + kc) * 3) * N + n;
   o[0] = a0; o[N] = a1; o[2 * (size_t)N] = a2;
 }
 
 // location-major V [N][d]: da_v[l][n] = V[n][:] . gv[l][:], whole rows -> part[b][0][l][n] (one "chunk").
 // grid (ceil(N / 16), B); a wave takes 4 rows, lanes along the channels (float4), three wave sums per row.
-__global__ __launch_bounds__(256) void bwd_dav_lm_kernel(const float* V, long v_sB, const float* gv, float* part, int B,
-                                                         int N, int d, int L) {
-  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+__device__ __forceinline__ void dav_lm_block(const float* V, long v_sB, const float* gv, float* part, int B, int N, int d,
+                                             int L, int bx, int b) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float* Vb = V + (size_t)b * v_sB;
   for (int i = 0; i < 4; ++i) {
-    const int n = blockIdx.x * 16 + 4 * w + i;
+    const int n = bx * 16 + 4 * w + i;
     if (n >= N) break;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     for (int k = 4 * lane; k < d; k += 256) {
@@ -85,6 +84,8 @@ struct PreArgs {
   const float* av; const float* aq;      // saved
   const float* Hq;                       // saved [L][B][T][d]
   const float* wq;
+  // the da_v blocks ride along in the same launch (blocks past L*B): dav_gx blocks per sample
+  const float* V; long v_sB; const float* gv; float* dav_out; int dav_lm, dav_gx;
   float* dsv;                            // [L][B][N]
   float* dZq;                            // [L][B][T][d]
   float* dwq_part;                       // [L*B][d]
@@ -92,45 +93,58 @@ struct PreArgs {
   int B, N, T, d, L;
 };
 
-// One workgroup (256 threads) per (sample, level): softmax backward of a_v (from the da_v
-// partials) and of a_q (da_q = Q gq), dZ_q = ds_q (x) w_q (.) (1 - H_q^2), dw_q / dc partials.
+// Image side, one wave per (sample, level): da_v = sum of the channel-chunk partials; ds_v = a_v (da_v - <a_v, da_v>);
+// dc_v partial.  (A launch of its own behind bwd_pre_kernel, whose extra blocks produce the partials.)
+__global__ __launch_bounds__(64) void bwd_prev_kernel(const PreArgs a) {
+  const int N = a.N, B = a.B;
+  const int pairi = blockIdx.x, l = pairi / B, b = pairi - l * B, lane = threadIdx.x;
+  const size_t pair = (size_t)pairi;
+  const int nkc = a.nkc;
+  const float* pp = a.dav_part + (size_t)b * nkc * 3 * N + (size_t)l * N;
+  const float* avp = a.av + pair * N;
+  float da[4], avv[4];
+  float dot = 0.f, tot_v = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int n = lane + 64 * k;
+    float sacc = 0.f;
+    if (n < N)
+      for (int kc = 0; kc < nkc; ++kc) sacc += pp[(size_t)kc * 3 * N + n];
+    da[k] = sacc;
+    avv[k] = (n < N) ? avp[n] : 0.f;
+    dot = fmaf(avv[k], sacc, dot);
+  }
+  dot = wave_sum(dot);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int n = lane + 64 * k;
+    const float v = avv[k] * (da[k] - dot);
+    if (n < N) a.dsv[pair * N + n] = v;
+    tot_v += v;
+  }
+  tot_v = wave_sum(tot_v);
+  if (lane == 0) a.dcs_part[pair] = tot_v;          // [2][L*B]
+}
+
+// Blocks [0, L*B): one workgroup (256 threads) per (sample, level), question side -- softmax backward of a_q
+// (da_q = Q gq), dZ_q = ds_q (x) w_q (.) (1 - H_q^2), dw_q / dc_q partials.  Blocks past L*B: the da_v partials
+// (one pass over V for all levels, independent of the question side: they fill the idle half of the chip).
 __global__ __launch_bounds__(256) void bwd_pre_kernel(const PreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int d = a.d, N = a.N, T = a.T, B = a.B;
+  const int d = a.d, T = a.T, B = a.B;
+  if ((int)blockIdx.x >= a.L * B) {
+    const int id = (int)blockIdx.x - a.L * B;
+    if (a.dav_lm) dav_lm_block(a.V, a.v_sB, a.gv, a.dav_out, B, a.N, d, a.L, id % a.dav_gx, id / a.dav_gx);
+    else dav_cm_block(a.V, a.v_sB, a.gv, a.dav_out, B, a.N, d, a.L, id % a.dav_gx, id / a.dav_gx, a.dav_gx,
+                      reinterpret_cast<float(*)[64]>(lds));
+    return;
+  }
   float* daq = lds;                       // 32
   float* dsq = daq + 32;                  // 32
   float* dwr = dsq + 32;                  // d   (second row group's dw_q partial)
   const int pairi = blockIdx.x, l = pairi / B, b = pairi - l * B;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const size_t pair = (size_t)pairi;
-  // ---- image side (wave 0): da_v = sum of the channel-chunk partials; ds_v = a_v (da_v - <a_v, da_v>)
-  float tot_v = 0.f;
-  if (w == 0) {
-    const int nkc = a.nkc;
-    const float* pp = a.dav_part + (size_t)b * nkc * 3 * N + (size_t)l * N;
-    const float* avp = a.av + pair * N;
-    float da[4], avv[4];
-    float dot = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int n = lane + 64 * k;
-      float sacc = 0.f;
-      if (n < N)
-        for (int kc = 0; kc < nkc; ++kc) sacc += pp[(size_t)kc * 3 * N + n];
-      da[k] = sacc;
-      avv[k] = (n < N) ? avp[n] : 0.f;
-      dot = fmaf(avv[k], sacc, dot);
-    }
-    dot = wave_sum(dot);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int n = lane + 64 * k;
-      const float v = avv[k] * (da[k] - dot);
-      if (n < N) a.dsv[pair * N + n] = v;
-      tot_v += v;
-    }
-    tot_v = wave_sum(tot_v);
-  }
   // ---- question side: da_q[t] = Q[t] . gq, one wave per row
   const float* Qp = a.Q[l] + (size_t)b * T * d;
   const float* gqp = a.gq + pair * d;
@@ -152,10 +166,7 @@ __global__ __launch_bounds__(256) void bwd_pre_kernel(const PreArgs a) {
     const float sq = aqv * (x - dq);
     if (lane < 32) dsq[lane] = sq;
     const float tot_q = wave_sum(sq);
-    if (lane == 0) {
-      a.dcs_part[pair] = tot_v;                      // [2][L*B]
-      a.dcs_part[(size_t)a.L * B + pair] = tot_q;
-    }
+    if (lane == 0) a.dcs_part[(size_t)a.L * B + pair] = tot_q;       // [2][L*B]
   }
   __syncthreads();
   // ---- dZ_q rows and the dw_q partial: 128 threads x float4 cover d = 512; two row groups
@@ -302,9 +313,11 @@ hipError_t set_lds(K kern, size_t bytes) {
 }
 
 int launch_pre(const PreArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)(64 + a.d) * sizeof(float);
-  hipLaunchKernelGGL(bwd_pre_kernel, dim3(a.L * a.B), dim3(256), lds, s, a);
+  const size_t lds = (size_t)(64 + a.d) * sizeof(float);           // (>= the 768 B of a channel-major da_v block)
+  hipLaunchKernelGGL(bwd_pre_kernel, dim3(a.L * a.B + a.dav_gx * a.B), dim3(256), lds, s, a);
   CA_CHECK_LAUNCH("bwd_pre");
+  hipLaunchKernelGGL(bwd_prev_kernel, dim3(a.L * a.B), dim3(64), 0, s, a);
+  CA_CHECK_LAUNCH("bwd_prev");
   return 0;
 }
 
@@ -327,12 +340,11 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   const FusedBwdOff wo = fused_bwd_off(B, N, T, d, L);
   const size_t BTd = (size_t)B * T * d, BTN = (size_t)B * T * N, BNd = (size_t)B * N * d, Bd = (size_t)B * d;
   const bool small_n = N <= 64;
-  // 1. per-sample pre-pass
+  // 1. per-sample pre-pass: one launch for the question side and the da_v partials, a small one for the image side
   CA_CHECK_ARG(N <= 256, "fused backward: N > 256");
-  if (lm) hipLaunchKernelGGL(bwd_dav_lm_kernel, dim3((N + 15) / 16, B), dim3(256), 0, s, V, vl.sB, gv, ws + wo.part, B, N, d, L);
-  else hipLaunchKernelGGL(bwd_dav_kernel, dim3(d / 64, B), dim3(256), 0, s, V, vl.sB, gv, ws + wo.part, B, N, d, L);
-  CA_CHECK_LAUNCH("bwd_dav");
   PreArgs pa;
+  pa.V = V; pa.v_sB = vl.sB; pa.gv = gv; pa.dav_out = ws + wo.part; pa.dav_lm = lm ? 1 : 0;
+  pa.dav_gx = lm ? (N + 15) / 16 : d / 64;
   pa.dav_part = ws + wo.part;
   pa.nkc = lm ? 1 : d / 64;
   for (int l = 0; l < 8; ++l) pa.Q[l] = l < L ? Q[l] : nullptr;

@@ -16,7 +16,7 @@ void coattn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int coattn_version(void) { return 300; }   // 0.3.0: V strides (coattn_forward_strided / _backward_strided)
+extern "C" int coattn_version(void) { return 310; }   // 0.3.1: coattn_linear_forward; `saved` carries the W_q image (0.3.0: V strides)
 extern "C" const char* coattn_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------------------------------

@@ -194,6 +194,15 @@ size_t coattn_linear_workspace_bytes(int N, int K);
 int coattn_linear_forward(const void* x, int64_t ld_x, const void* W, const void* bias, void* y, void* wimg,
                           int M, int N, int K, float out_scale, int flags, void* stream);
 
+/* Weight gradient of the same layer: dW[n_out][n_in] (+)= dY[M][n_out]^T X[M][n_in] in fp32 accuracy
+ * (autograd of the W_v / W_q projections, main.py:219-220): split-K parts on the hand-scheduled A^T B kernel
+ * (gemm_tn.hip) + a deterministic reduce -- the kernel pair coattn_backward uses for dW_v and dW_q.
+ * dY rows ld_dy floats apart, X rows ld_x; `ws`: device scratch of coattn_linear_wgrad_workspace_bytes bytes.
+ * n_out, n_in multiples of 128, M >= 16, 16-byte aligned operands with ld % 4 == 0; other shapes: error -1. */
+size_t coattn_linear_wgrad_workspace_bytes(int n_out, int n_in);
+int coattn_linear_weight_grad(const void* dy, int64_t ld_dy, const void* x, int64_t ld_x, void* dW, void* ws, int M,
+                              int n_out, int n_in, int accumulate, void* stream);
+
 /* Same contract with the operands rounded to bf16 (round to nearest even) while they are staged and
  * contracted on v_mfma_f32_32x32x16_bf16 (fp32 accumulate / output): the arithmetic of
  * COATTN_FLAG_BF16_PROJ.  Shapes the bf16 kernels do not take (unaligned strides, M < 128) are computed

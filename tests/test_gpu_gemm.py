@@ -229,3 +229,51 @@ def test_linear_rejects_unsupported_shapes():
     x = torch.randn(64, 48, device="cuda"); W = torch.randn(32, 48, device="cuda")
     rc, _, _ = _linear(x, 48, W, None, 64, 32, 48)          # K % 32 != 0, M < 128
     assert rc == -1 and b"not supported" in _lib.load().coattn_last_error()
+
+
+# ---- coattn_linear_weight_grad: dW = dY^T X on the split-K A^T B kernel (gemm_tn.hip) --------------------------
+def _wgrad(dy, ld_dy, x, ld_x, M, n_out, n_in, accumulate=0, dW=None):
+    from vqa_amd import _lib
+    lib = _lib.load()
+    if dW is None:
+        dW = torch.full((n_out, n_in), float("nan"), device="cuda")
+    ws = torch.empty(lib.coattn_linear_wgrad_workspace_bytes(n_out, n_in) // 4, device="cuda")
+    rc = lib.coattn_linear_weight_grad(dy.data_ptr(), ld_dy, x.data_ptr(), ld_x, dW.data_ptr(), ws.data_ptr(), M, n_out,
+                                       n_in, accumulate, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    return rc, dW
+
+
+@pytest.mark.parametrize("M,n_out,n_in", [(16, 128, 128), (17, 128, 256), (1000, 256, 128), (4160, 512, 512),
+                                          (31360, 512, 512), (12345, 128, 384)])
+def test_linear_weight_grad(M, n_out, n_in):
+    """Contraction lengths that end inside a 16-row step and inside a split-K part; one to many parts."""
+    from vqa_amd import _lib
+    torch.manual_seed(21)
+    dy = torch.randn(M, n_out, device="cuda") * 0.1
+    x = torch.randn(M, n_in, device="cuda")
+    rc, dW = _wgrad(dy, n_out, x, n_in, M, n_out, n_in)
+    _lib.check(rc, "coattn_linear_weight_grad")
+    ref = dy.double().t() @ x.double()
+    assert _rel(dW, ref) < 2e-6
+
+
+def test_linear_weight_grad_strided_accumulate_and_repeatable():
+    from vqa_amd import _lib
+    torch.manual_seed(22)
+    M, n_out, n_in, ld_dy, ld_x = 3001, 128, 256, 160, 320
+    dy = torch.randn(M, ld_dy, device="cuda"); x = torch.randn(M, ld_x, device="cuda")
+    base = torch.randn(n_out, n_in, device="cuda")
+    rc, dW = _wgrad(dy, ld_dy, x, ld_x, M, n_out, n_in, accumulate=1, dW=base.clone())
+    _lib.check(rc, "coattn_linear_weight_grad")
+    ref = base.double() + dy[:, :n_out].double().t() @ x[:, :n_in].double()
+    assert _rel(dW, ref) < 2e-6
+    rc, dW2 = _wgrad(dy, ld_dy, x, ld_x, M, n_out, n_in, accumulate=1, dW=base.clone())
+    assert torch.equal(dW, dW2)                              # fixed split-K partition and reduction order
+
+
+def test_linear_weight_grad_rejects_unsupported_shapes():
+    from vqa_amd import _lib
+    dy = torch.randn(64, 96, device="cuda"); x = torch.randn(64, 128, device="cuda")
+    rc, _ = _wgrad(dy, 96, x, 128, 64, 96, 128)               # n_out not a multiple of 128
+    assert rc == -1 and b"not supported" in _lib.load().coattn_last_error()

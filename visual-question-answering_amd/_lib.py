@@ -14,7 +14,8 @@ CSRC = os.path.join(_HERE, "csrc")
 EXPORTS = ("coattn_version", "coattn_last_error", "coattn_fused_supported", "coattn_workspace_bytes",
            "coattn_forward", "coattn_attention_forward", "coattn_backward", "coattn_gemm_f32", "coattn_gemm_bf16",
            "coattn_phrase_workspace_bytes", "coattn_phrase_forward", "coattn_phrase_backward",
-           "coattn_ce_workspace_bytes", "coattn_ce_forward", "coattn_linear_workspace_bytes", "coattn_linear_forward")
+           "coattn_ce_workspace_bytes", "coattn_ce_forward", "coattn_linear_workspace_bytes", "coattn_linear_forward",
+           "coattn_linear_wgrad_workspace_bytes", "coattn_linear_weight_grad")
 
 F32 = 0
 IMPL_AUTO, IMPL_GENERAL, IMPL_FUSED = 0, 1, 2
@@ -103,6 +104,10 @@ def load() -> C.CDLL:
     lib.coattn_linear_workspace_bytes.restype = C.c_size_t
     lib.coattn_linear_forward.argtypes = ([C.c_void_p, C.c_int64] + [C.c_void_p] * 4 + [C.c_int] * 3
                                           + [C.c_float, C.c_int, C.c_void_p])
+    lib.coattn_linear_wgrad_workspace_bytes.argtypes = [C.c_int, C.c_int]
+    lib.coattn_linear_wgrad_workspace_bytes.restype = C.c_size_t
+    lib.coattn_linear_weight_grad.argtypes = ([C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+                                              + [C.c_int] * 4 + [C.c_void_p])
     _lib = lib
     return lib
 

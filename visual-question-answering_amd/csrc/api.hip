@@ -110,6 +110,24 @@ extern "C" int coattn_linear_forward(const void* x, int64_t ld_x, const void* W,
   return launch_gemm_w(&g, 1, (hipStream_t)stream);
 }
 
+extern "C" size_t coattn_linear_wgrad_workspace_bytes(int n_out, int n_in) {
+  return (n_out > 0 && n_in > 0) ? (size_t)32 * n_out * n_in * sizeof(float) : 0;
+}
+
+extern "C" int coattn_linear_weight_grad(const void* dy, int64_t ld_dy, const void* x, int64_t ld_x, void* dW, void* ws,
+                                         int M, int n_out, int n_in, int accumulate, void* stream) {
+  CA_CHECK_ARG(dy && x && dW && ws && M > 0 && n_out > 0 && n_in > 0 && ld_dy >= n_out && ld_x >= n_in &&
+               ld_dy < (1L << 24) && ld_x < (1L << 24), "linear weight grad: bad argument");
+  TnGemm g = {};
+  g.A = (const float*)dy; g.a_ld = (int)ld_dy; g.B = (const float*)x; g.b_ld = (int)ld_x; g.C = (float*)ws;
+  g.M = n_out; g.N = n_in; g.K = M; g.levels = 1;
+  CA_CHECK_ARG(gemm_tn_supported(g), "linear weight grad: shape M=%d n_out=%d n_in=%d not supported (see coattn.h)", M, n_out, n_in);
+  int ks, S;
+  const int parts = gemm_tn_plan(g, 32, &ks, &S);
+  CA_TRY(launch_gemm_tn(&g, &ks, &S, 1, (hipStream_t)stream));
+  return launch_reduce_partials((const float*)ws, (float*)dW, parts, (int64_t)n_out * n_in, accumulate, (hipStream_t)stream);
+}
+
 extern "C" int coattn_gemm_bf16(const coattn_gemm_desc* g, void* stream) {
   CA_CHECK_ARG(g != nullptr, "gemm: null descriptor");
   return launch_gemm_bf16in(*g, (hipStream_t)stream);

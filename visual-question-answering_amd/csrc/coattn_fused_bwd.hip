@@ -384,7 +384,10 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   wdq.A = ws + wo.dPq; wdq.a_sz = (long)BTd; wdq.a_sm = d; wdq.Wf = saved + so.wqT;
   for (int l = 0; l < L; ++l) wdq.c_ptrs[l] = dQ[l];
   wdq.c_sm = d; wdq.M = B * T; wdq.N = d; wdq.K = d; wdq.batch = L;
-  const bool wdq_ok = !bf16_proj && wgemm && gemm_w_supported(wdq);
+  // (exactly the forward's test for writing that image, api.hip general_projections: same shape, and its A rows were Q_l)
+  bool q_al = true;
+  for (int l = 0; l < L; ++l) q_al = q_al && (((uintptr_t)Q[l]) & 15) == 0;
+  const bool wdq_ok = !bf16_proj && wgemm && q_al && gemm_w_supported(wdq);
   const bool combine = dq32 && wdq_ok && tn_v && tn_q;
   // 3. small parameter gradients from the per-(sample, level) partials (dw_v, db_v, db_q, dw_q, and dc_v, dc_q as
   //    whole-array sums): a few short workgroups -- riding along in the weight-gradient launch of step 5 when that

@@ -327,3 +327,32 @@ def test_gradients_do_not_depend_on_whether_dV_is_requested(layout, N):
     b = run_hip(V, Qs, P, gv, gq, impl="fused", layout=layout, need_dv=False)
     for k in ("dQ", "dW_v.weight", "dW_q.weight", "dw_v.weight", "dw_q.weight", "dW_v.bias", "dW_q.bias"):
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.gpu
+def test_question_features_not_16_byte_aligned():
+    """Q_l at a 4-byte offset: the pre-split-weight GEMMs (which need 16-byte rows) must step aside in the forward AND in
+    the backward's dQ projection -- whose weight image only exists when the forward took that kernel."""
+    import vqa_amd
+    B, N, T, d = 6, 196, 26, 512
+    torch.manual_seed(3)
+    co = vqa_amd.ParallelCoAttention(d).cuda()
+    x = (torch.randn(B, N, d, device="cuda") * 0.5)
+    base = [torch.randn(B * T * d + 1, device="cuda") * 0.5 for _ in range(3)]
+    gv = torch.randn(3, B, d, device="cuda"); gq = torch.randn(3, B, d, device="cuda")
+
+    def run(qs):
+        for p in co.parameters():
+            p.grad = None
+        qs = [q.detach().requires_grad_(True) for q in qs]
+        v, q = co(x, qs)
+        (sum((v[l] * gv[l]).sum() + (q[l] * gq[l]).sum() for l in range(3))).backward()
+        return torch.stack(v), torch.stack(q), torch.stack([t.grad for t in qs]), co.W_q.weight.grad.clone(), co.W_v.weight.grad.clone()
+
+    off = [b[1:].view(B, T, d) for b in base]                    # data_ptr % 16 == 4
+    assert all(t.data_ptr() % 16 == 4 for t in off)
+    a = run(off)
+    b = run([t.clone() for t in off])                            # the same values, aligned
+    for u, w in zip(a, b):
+        assert torch.isfinite(u).all()
+        assert (u - w).abs().max().item() <= 2e-5 * max(1e-3, w.abs().max().item())

@@ -19,6 +19,7 @@
 //   * the dP_q accumulators start from dZ_q; dw_v, db_v, db_q partials are in-lane sums over the accumulator rows.
 // H_v is never stored.  Rows t >= T / n >= N fall outside the per-sample buffer descriptors (loads 0, stores dropped).
 #include "fused.h"
+#include <stdlib.h>
 
 #ifndef COATTN_DC_GT          // bwd_dc32_kernel: location tiles per group (their dC accumulators: 16 registers each)
 #define COATTN_DC_GT 4
@@ -593,6 +594,123 @@ __global__ __launch_bounds__(256) void bwd_dq32_kernel(const DqArgs a) {
   }
 }
 
+// The same for ALL levels of a (sample, channel slice) in one workgroup -- small location counts only (N <= 64: the
+// dA images of the three levels together are 36 KB): the V fragments are loaded and split ONCE and serve the three
+// levels' MFMAs (the split is what bwd_dq32_kernel spends its issue slots on: 88 VALU per 12 MFMAs there, per 36 here),
+// and V is read once per sample instead of once per level.
+template <int NT, bool LM>
+__global__ __launch_bounds__(256) void bwd_dq32x_kernel(const DqArgs a) {
+  static_assert(NT <= 2, "the images of all levels must fit the LDS of several workgroups per CU");
+  constexpr int NPAD = 32 * NT;
+  constexpr int LDR = NPAD + 8;
+  constexpr int PIECE = kTRows * LDR;
+  constexpr int LEVEL = 3 * PIECE + 4 * LDR;         // + 4 rows: what lanes 28 .. 31 of the last piece read
+  constexpr int ML = 3;                              // levels (L <= 3)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  short* img = reinterpret_cast<short*>(smem);
+  float* aqs = reinterpret_cast<float*>(smem + ML * LEVEL * 2);
+  const int nslice = a.d / 128, item = blockIdx.x, b = item / nslice, slice = item - b * nslice;
+  const int N = a.N, T = a.T, d = a.d, L = a.L;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(a.V + (size_t)b * a.v_sB, (unsigned)N * d * 4u);
+  const int c0 = slice * 128 + 32 * w;
+  f32x16 vt[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {                  // (the fragment layouts of bwd_dq32_kernel)
+    if constexpr (LM) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) vt[nt][g] = buf_load1(rs_v, (crow(g, h) * d + c0 + r) * 4, 32 * nt * d * 4);
+    } else {
+#pragma unroll
+      for (int gg = 0; gg < 4; ++gg) {
+        const f32x4 v = buf_load4(rs_v, ((c0 + r) * N + 4 * h) * 4, (32 * nt + 8 * gg) * 4);
+        vt[nt][4 * gg] = v[0]; vt[nt][4 * gg + 1] = v[1]; vt[nt][4 * gg + 2] = v[2]; vt[nt][4 * gg + 3] = v[3];
+      }
+    }
+  }
+  // ---- dA_l -> images, all levels: a thread takes (level, t, two neighbouring n); rows >= T and columns >= N read 0
+  constexpr int PER = (kTRows * (NPAD / 2) + 255) / 256;
+  float x0[ML][PER], x1[ML][PER];
+#pragma unroll
+  for (int l = 0; l < ML; ++l) {
+    const __amdgpu_buffer_rsrc_t rs_da = make_rsrc(a.dA + ((size_t)(l < L ? l : 0) * a.B + b) * (size_t)T * N, l < L ? (unsigned)T * N * 4u : 0u);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int e = tid + 256 * k, t = e / (NPAD / 2), n = 2 * (e - t * (NPAD / 2));
+      x0[l][k] = buf_load1(rs_da, n < N ? (t * N + n) * 4 : 0x40000000, 0);
+      x1[l][k] = buf_load1(rs_da, n + 1 < N ? (t * N + n + 1) * 4 : 0x40000000, 0);
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < ML; ++l)
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int e = tid + 256 * k, t = e / (NPAD / 2), n = 2 * (e - t * (NPAD / 2));
+      unsigned hh, mm, ll;
+      split3_pair(x0[l][k], x1[l][k], hh, mm, ll);
+      const int m16 = n & 15;                        // n order inside a group of 16: bits 2 and 3 trade places
+      const int off = l * LEVEL + t * LDR + (n & ~15) + ((m16 & 3) | ((m16 & 4) << 1) | ((m16 & 8) >> 1));
+      if (t < kTRows) {
+        *reinterpret_cast<unsigned*>(img + off) = hh;
+        *reinterpret_cast<unsigned*>(img + PIECE + off) = mm;
+        *reinterpret_cast<unsigned*>(img + 2 * PIECE + off) = ll;
+      }
+    }
+  if (tid < 32 * ML) {
+    const int l = tid >> 5, t = tid & 31;
+    aqs[tid] = (l < L && t < T) ? a.aq[((size_t)l * a.B + b) * (size_t)T + t] : 0.f;
+  }
+  lds_barrier();
+  f32x16 acc[ML];
+#pragma unroll
+  for (int l = 0; l < ML; ++l)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc[l][g] = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    bf16x8 b0[3], b1[3];
+    split3(f32x8{vt[nt][0], vt[nt][1], vt[nt][2], vt[nt][3], vt[nt][4], vt[nt][5], vt[nt][6], vt[nt][7]}, b0);
+    split3(f32x8{vt[nt][8], vt[nt][9], vt[nt][10], vt[nt][11], vt[nt][12], vt[nt][13], vt[nt][14], vt[nt][15]}, b1);
+#pragma unroll
+    for (int l = 0; l < ML; ++l) {
+      bf16x8 a0[3], a1[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        a0[p] = *reinterpret_cast<const bf16x8*>(img + l * LEVEL + p * PIECE + r * LDR + 32 * nt + 8 * h);
+        a1[p] = *reinterpret_cast<const bf16x8*>(img + l * LEVEL + p * PIECE + r * LDR + 32 * nt + 16 + 8 * h);
+      }
+      acc[l] = mfma32_x3(a0, b0, acc[l]);
+      acc[l] = mfma32_x3(a1, b1, acc[l]);
+    }
+  }
+  // dQ_l[b][t][c0 + r] (+)= acc_l + a_q,l[t] gq_l[c0 + r]; rows t >= T lie outside the buffer
+#pragma unroll
+  for (int l = 0; l < ML; ++l) {
+    if (l >= L) break;
+    const __amdgpu_buffer_rsrc_t rs_dq = make_rsrc(a.dQ[l] + (size_t)b * T * d, (unsigned)T * d * 4u);
+    const float gqv = a.gq[((size_t)l * a.B + b) * (size_t)d + c0 + r];
+    float prev[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g)
+      prev[g] = a.accumulate ? buf_load1(rs_dq, (crow(g, h) * d + c0 + r) * 4, 0) : 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      float v = fmaf(aqs[32 * l + crow(g, h)], gqv, acc[l][g]) + prev[g];
+      asm volatile("" : "+v"(v));                    // (opaque scalar: see bwd_nat32_kernel's epilogue)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_dq, (crow(g, h) * d + c0 + r) * 4, 0, 0);
+    }
+  }
+}
+
+template <int NT, bool LM>
+int launch_dq32x(const DqArgs& a, hipStream_t s) {
+  constexpr int NPAD = 32 * NT;
+  const size_t lds = (size_t)3 * ((3 * kTRows + 4) * (NPAD + 8) * 2) + 3 * 32 * 4;
+  hipLaunchKernelGGL((bwd_dq32x_kernel<NT, LM>), dim3(a.B * (a.d / 128)), dim3(256), lds, s, a);
+  CA_CHECK_LAUNCH("bwd_dq32x");
+  return 0;
+}
+
 template <int NT, bool LM>
 int launch_dq32(const DqArgs& a, hipStream_t s) {
   constexpr int NPAD = 32 * NT;
@@ -622,6 +740,8 @@ int launch_bwd_nat32(const BwdArgs& a, hipStream_t s) {
 }
 
 int launch_bwd_dq32(const DqArgs& a, int lm, hipStream_t s) {
+  static const int shared = [] { const char* e = getenv("COATTN_DQ32X"); return e ? atoi(e) : 1; }();   // developer switch
+  if (a.N <= 64 && a.L <= 3 && shared) return lm ? launch_dq32x<2, true>(a, s) : launch_dq32x<2, false>(a, s);
   if (lm) return a.N <= 64 ? launch_dq32<2, true>(a, s) : launch_dq32<7, true>(a, s);
   return a.N <= 64 ? launch_dq32<2, false>(a, s) : launch_dq32<7, false>(a, s);
 }

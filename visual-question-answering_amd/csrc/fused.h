@@ -133,6 +133,7 @@ struct WGemm {
   const float* A; const float* a_ptrs[8]; long a_sz; int a_sm;       // A[z][m][k], k contiguous; z from the table or a_sz
   int a_sk, a_mdiv; long a_sdiv;                                     // a_sk != 0: A contiguous along m instead, element
                                                                      // (m, k) at (m / a_mdiv) * a_sdiv + m % a_mdiv + k * a_sk
+  int kband_n, kband_lo[3], kband_hi[3];                             // kband_n > 0: column band j contracts over k in [lo_j, hi_j)
   const void* Wf;                                                    // wsplit image of Bw [K x N]
   float* C; float* c_ptrs[8]; long c_sz; int c_sm;                   // C[z][m][n], n contiguous
   const float* bias_n; float out_scale;
@@ -152,6 +153,8 @@ struct TnGemm {
                                                                      // (k, n) at (k / b_kdiv) * b_sdiv + k % b_kdiv + n * b_ld
   float* C;                                                          // parts [levels * S][M][N]
   int M, N, K, levels;
+  int mask_blk; unsigned tile_mask;                                  // mask_blk > 0: tile (mt, nt) is computed only if bit
+                                                                     // (mt / mask_blk) * 3 + nt / mask_blk of tile_mask is set
 };
 int gemm_tn_supported(const TnGemm& d);
 int gemm_tn_plan(const TnGemm& d, int max_parts, int* ksplit, int* S);   // returns the number of parts

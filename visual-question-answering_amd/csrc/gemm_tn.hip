@@ -35,6 +35,7 @@ struct TnArgs {
   const float* B; const float* b_ptrs[8]; long b_sl; int b_ld;
   int b_kdiv; long b_sdiv; unsigned b_bytes;   // BCM: element (k, n) at (k / b_kdiv) * b_sdiv + k % b_kdiv + n * b_ld
   float* C;                                    // parts [L * S][M][N]
+  int mask_blk; unsigned tile_mask;            // mask_blk > 0: only the tiles whose (row, column) block bit is set exist
   int M, N, K, ksplit, S;
 };
 
@@ -67,6 +68,7 @@ __device__ __forceinline__ void gemm_tn_body(const TnArgs& g, const int bid, con
     if (id < nz8 * ntiles) { z = (id & 7) + 8 * (id / (8 * ntiles)); t = (id >> 3) % ntiles; }
     else { const int r = id - nz8 * ntiles; z = nz8 + r / ntiles; t = r % ntiles; }
   }
+  if (g.mask_blk > 0 && !((g.tile_mask >> (((t / ntn) / g.mask_blk) * 3 + (t % ntn) / g.mask_blk)) & 1u)) return;
   const int m0 = (t / ntn) * BM, n0 = (t % ntn) * BN;
   const int lvl = z / g.S, p = z % g.S;
   const int kbeg = p * g.ksplit, kend = min(g.K, kbeg + g.ksplit);
@@ -300,6 +302,7 @@ static int fill_job(const TnGemm& d, int ksplit, int S, TnArgs& g, long* nblk) {
   g.b_kdiv = d.b_kdiv; g.b_sdiv = d.b_sdiv; g.b_bytes = d.b_kdiv ? (unsigned)((long)(d.K / d.b_kdiv) * d.b_sdiv * 4) : 0u;
   for (int t = 0; t < 8; ++t) g.b_ptrs[t] = d.b_ptrs[t];
   g.C = d.C; g.M = d.M; g.N = d.N; g.K = d.K; g.ksplit = ksplit; g.S = S;
+  g.mask_blk = d.mask_blk; g.tile_mask = d.tile_mask;
   *nblk = (long)(d.M / BM) * (d.N / BN) * d.levels * S;
   return 0;
 }

@@ -105,6 +105,15 @@ int gemm_w_fill_job(const WGemm& d, gw::WArgs& g, long* nblk) {
   CA_CHECK_ARG((d.A || d.a_ptrs[0]) && d.Wf && (d.C || d.c_ptrs[0]), "gemm_w: null operand");
   g = WArgs{};
   g.A = d.A; g.a_sz = d.a_sz; g.a_sm = d.a_sm; g.a_sk = d.a_sk; g.a_mdiv = d.a_mdiv; g.a_sdiv = d.a_sdiv;
+  g.kband_n = d.kband_n;
+  if (d.kband_n > 0) {
+    CA_CHECK_ARG(d.kband_n % BN == 0 && (d.N + d.kband_n - 1) / d.kband_n <= 3, "gemm_w: kband_n must be a multiple of 128 with at most 3 bands");
+    for (int t = 0; t < 3; ++t) {
+      CA_CHECK_ARG(d.kband_lo[t] >= 0 && d.kband_hi[t] <= d.K && d.kband_lo[t] < d.kband_hi[t] && d.kband_lo[t] % BK == 0 && d.kband_hi[t] % BK == 0,
+                   "gemm_w: k bands must lie in [0,K] and be multiples of 32");
+      g.kband_lo[t] = d.kband_lo[t]; g.kband_hi[t] = d.kband_hi[t];
+    }
+  }
   g.Wf = d.Wf; g.wf_bytes = (unsigned)wsplit_bytes(d.N, d.K);
   g.C = d.C; g.c_sz = d.c_sz; g.c_sm = d.c_sm;
   for (int t = 0; t < 8; ++t) { g.a_ptrs[t] = d.a_ptrs[t]; g.c_ptrs[t] = d.c_ptrs[t]; }

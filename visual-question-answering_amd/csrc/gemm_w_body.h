@@ -14,6 +14,7 @@ constexpr int kChunkBytes = 3 * kFragBytes;    // the three pieces of one (colum
 struct WArgs {
   const float* A; const float* a_ptrs[8]; long a_sz; int a_sm;
   int a_sk, a_mdiv; long a_sdiv;               // AM: element (m, k) at (m / a_mdiv) * a_sdiv + m % a_mdiv + k * a_sk
+  int kband_n, kband_lo[3], kband_hi[3];       // kband_n > 0: columns [j kband_n, (j+1) kband_n) contract over k in [lo_j, hi_j)
   const void* Wf; unsigned wf_bytes;
   float* C; float* c_ptrs[8]; long c_sz; int c_sm;
   const float* bias_n; float oscale;
@@ -55,7 +56,12 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
                           : ((long)(g.M - 1) * g.a_sm + g.K) * 4;
   const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(Ab, (unsigned)a_bytes);
   const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(g.Wf, g.wf_bytes);
-  const int KS = g.K / BK;                       // K % 32 == 0 (host check)
+  int s0 = 0, KS = g.K / BK;                     // K % 32 == 0 (host check)
+  if (g.kband_n > 0) {                           // (bands are multiples of 128 columns and of 32 k: one band per tile)
+    const int band = n0 / g.kband_n;
+    s0 = g.kband_lo[band] / BK;
+    KS = (g.kband_hi[band] - g.kband_lo[band]) / BK;
+  }
 
   // A staging: 4 float4 per thread and step; a wave's load covers 8 rows x 128 B (whole lines)
   // (AM: float4 = 4 consecutive rows of one k; a wave's load covers 2 k x 512 B; a_mdiv % 4 == 0 keeps the 4 rows in one sample)
@@ -110,10 +116,10 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
   constexpr int PB[6] = {0, 2, 1, 0, 1, 0};      // (gemm.hip's order)
   constexpr int RQ[3] = {2, 0, 1};               // fragment read order = order of first use
   constexpr int IMG = BM * LDR;                  // elements of one piece image
-  auto load_a = [&](int i, int s) { raw[i] = buf_load4(rs_a, a_voff[i], s * a_kstep); };
+  auto load_a = [&](int i, int s) { raw[i] = buf_load4(rs_a, a_voff[i], (s + s0) * a_kstep); };
   auto load_b = [&](int ring, int k, int half) {
     const int j = k / 3, q = k % 3;
-    bq[ring][j][q] = __builtin_bit_cast(bf16x8, buf_load4(rs_w, w_voff[j] + q * kFragBytes, half * kChunkBytes));
+    bq[ring][j][q] = __builtin_bit_cast(bf16x8, buf_load4(rs_w, w_voff[j] + q * kFragBytes, (half + 2 * s0) * kChunkBytes));
   };
   auto read_a = [&](const short* img, int h, int k) {
     const int q = RQ[k >> 1], i = k & 1;

@@ -12,6 +12,8 @@
 //            dXcat = dZ Wcat;  dx[t] = dXcat[t+1, 0:E] + dXcat[t, E:2E] + dXcat[t-1, 2E:3E].
 // Padding follows the reference's ConstantPad1d: bigram (1,0), trigram (1,1) (model.py:313-321).
 #include "common.h"
+#include "fused.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256) void phrase_unpack_db_kernel(const float* __re
 inline size_t al256(size_t n) { return (n + 255) & ~(size_t)255; }
 
 struct PhrasePlan {
-  size_t xcat, z, wcat, bcat, part, bpart, total_fwd, total_bwd;
+  size_t xcat, z, wcat, bcat, wimg, part, bpart, total_fwd, total_bwd;
   int ksplit, nsplit, rows_per_chunk, nchunks;
 };
 
@@ -149,6 +151,7 @@ PhrasePlan plan_phrase(int B, int T, int E) {
   p.z = o; o += al256(bt * e3 * 4);
   p.wcat = o; o += al256(e3 * e3 * 4);
   p.bcat = o; o += al256(e3 * 4);
+  p.wimg = o; o += al256(wsplit_bytes(3 * E, 3 * E));       // Wcat split into MFMA-fragment order (gemm_w.hip)
   p.total_fwd = o;
   // split-K of dWcat = dZ^T Xcat over the B*T rows: ~8 slices, each a multiple of 32 rows
   const long K = (long)bt;
@@ -162,6 +165,12 @@ PhrasePlan plan_phrase(int B, int T, int E) {
   p.bpart = o; o += al256((size_t)p.nchunks * e3 * 4);
   p.total_bwd = o;
   return p;
+}
+
+// COATTN_GEMM_W=0 (developer switch): the general GEMM of gemm.hip instead of the hand-scheduled kernels
+bool hand_gemms() {
+  static const int on = [] { const char* e = getenv("COATTN_GEMM_W"); return e ? atoi(e) : 1; }();
+  return on != 0;
 }
 
 int check_phrase(const void* X, const coattn_phrase_params* p, int B, int T, int E, int dtype) {
@@ -226,7 +235,21 @@ extern "C" int coattn_phrase_forward(const void* X, const coattn_phrase_params* 
     g.kband_lo[1] = 0; g.kband_hi[1] = 2 * E;
     g.kband_lo[2] = 0; g.kband_hi[2] = 3 * E;
   }
-  CA_TRY(gemm(g));
+  // fp32, 128-aligned channels: the pre-split-weight kernel (Wcat split once into MFMA-fragment order; its zero tap
+  // blocks are never read)
+  WGemm wg = {};
+  wg.A = reinterpret_cast<const float*>(w + pl.xcat); wg.a_sm = 3 * E; wg.Wf = w + pl.wimg;
+  wg.C = reinterpret_cast<float*>(w + pl.z); wg.c_sm = 3 * E; wg.bias_n = reinterpret_cast<const float*>(w + pl.bcat);
+  wg.M = B * T; wg.N = 3 * E; wg.K = 3 * E; wg.batch = 1;
+  wg.kband_n = g.kband_n;
+  for (int t = 0; t < 3; ++t) { wg.kband_lo[t] = g.kband_lo[t]; wg.kband_hi[t] = g.kband_hi[t]; }
+  if (!bf16 && hand_gemms() && E % 128 == 0 && gemm_w_supported(wg)) {
+    const WSplit job{reinterpret_cast<const float*>(w + pl.wcat), w + pl.wimg, 3 * E, 3 * E, 0, 3 * E};
+    CA_TRY(launch_wsplit(&job, 1, s));
+    CA_TRY(launch_gemm_w(&wg, 1, s));
+  } else {
+    CA_TRY(gemm(g));
+  }
   const long n = (long)B * T * E;
   hipLaunchKernelGGL(phrase_pool_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
                      reinterpret_cast<const float*>(w + pl.z), (float*)out, (unsigned char*)saved, n);
@@ -263,7 +286,26 @@ extern "C" int coattn_phrase_backward(const void* X, const coattn_phrase_params*
   CA_CHECK_LAUNCH("phrase_unpack_db");
   // dWcat partials = dZ^T Xcat over split row ranges
   // one launch per n-gram: only the tap blocks that exist (uni: x[t]; bi: x[t-1..t]; tri: all three)
-  for (int gr = 0; gr < 3; ++gr) {
+  // fp32, 128-aligned channels: ONE split-K launch of the hand-scheduled A^T B kernel over the [3E x 3E] result with
+  // the three absent tap blocks masked out (gemm_tn.hip); parts [S][3E][3E] as the unpack kernel reads them
+  int nparts = pl.nsplit;
+  TnGemm tn = {};
+  tn.A = dZ; tn.a_ld = 3 * E; tn.B = reinterpret_cast<const float*>(w + pl.xcat); tn.b_ld = 3 * E;
+  tn.C = reinterpret_cast<float*>(w + pl.part); tn.M = 3 * E; tn.N = 3 * E; tn.K = (int)bt; tn.levels = 1;
+  tn.mask_blk = E / 128;                             // rows: n-gram (uni, bi, tri); columns: tap x[t-1], x[t], x[t+1]
+  tn.tile_mask = (1u << 1) | (3u << 3) | (7u << 6);
+  const bool tn_ok = !bf16 && hand_gemms() && E % 128 == 0 && gemm_tn_supported(tn);
+  if (tn_ok) {
+    const int live = 6 * (E / 128) * (E / 128);      // tiles that exist
+    int S = (512 + live - 1) / live;
+    if (S > pl.nsplit) S = pl.nsplit;
+    int ks = (int)((bt + S - 1) / S);
+    ks = (ks + 15) / 16 * 16;
+    S = (int)((bt + ks - 1) / ks);
+    CA_TRY(launch_gemm_tn(&tn, &ks, &S, 1, s));
+    nparts = S;
+  }
+  for (int gr = 0; gr < 3 && !tn_ok; ++gr) {
     const int lo = gr == 0 ? E : 0, hi = gr == 0 ? 2 * E : (gr == 1 ? 2 * E : 3 * E);
     coattn_gemm_desc g = {};
     g.A = dZ + (long)gr * E;
@@ -275,7 +317,7 @@ extern "C" int coattn_phrase_backward(const void* X, const coattn_phrase_params*
   }
   const long nt = 6L * E * E;
   hipLaunchKernelGGL(phrase_unpack_dw_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s,
-                     reinterpret_cast<const float*>(w + pl.part), pl.nsplit, (float*)pg->dW1, (float*)pg->dW2,
+                     reinterpret_cast<const float*>(w + pl.part), nparts, (float*)pg->dW1, (float*)pg->dW2,
                      (float*)pg->dW3, E, accumulate);
   CA_CHECK_LAUNCH("phrase_unpack_dw");
   if (dX) {
@@ -290,7 +332,18 @@ extern "C" int coattn_phrase_backward(const void* X, const coattn_phrase_params*
       h.kband_lo[1] = 0; h.kband_hi[1] = 3 * E;           // x[t]  : all
       h.kband_lo[2] = 2 * E; h.kband_hi[2] = 3 * E;       // x[t+1]: tri
     }
-    CA_TRY(gemm(h));
+    WGemm wg = {};                                       // (as the forward: Wcat split the other way round)
+    wg.A = dZ; wg.a_sm = 3 * E; wg.Wf = w + pl.wimg; wg.C = reinterpret_cast<float*>(w + pl.xcat); wg.c_sm = 3 * E;
+    wg.M = (int)bt; wg.N = 3 * E; wg.K = 3 * E; wg.batch = 1;
+    wg.kband_n = h.kband_n;
+    for (int t = 0; t < 3; ++t) { wg.kband_lo[t] = h.kband_lo[t]; wg.kband_hi[t] = h.kband_hi[t]; }
+    if (!bf16 && hand_gemms() && E % 128 == 0 && gemm_w_supported(wg)) {
+      const WSplit job{reinterpret_cast<const float*>(w + pl.wcat), w + pl.wimg, 3 * E, 3 * E, 1, 3 * E};
+      CA_TRY(launch_wsplit(&job, 1, s));
+      CA_TRY(launch_gemm_w(&wg, 1, s));
+    } else {
+      CA_TRY(gemm(h));
+    }
     hipLaunchKernelGGL(phrase_col2im_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
                        reinterpret_cast<const float*>(w + pl.xcat), (float*)dX, T, E, n);
     CA_CHECK_LAUNCH("phrase_col2im");

@@ -84,6 +84,7 @@ struct ReduceJobs {
   const float* sum_x[2];
   float* sum_out[2];
   long sum_n;
+  long ld;                                           // row stride of the partial buffers (0: n)
 };
 __device__ __forceinline__ void reduce_jobs_block(const ReduceJobs& jobs, int nparts, long n, int accumulate, int bx,
                                                   int by, float (*red)[64]) {
@@ -106,18 +107,18 @@ __device__ __forceinline__ void reduce_jobs_block(const ReduceJobs& jobs, int np
   const float* part = jobs.src[by];
   float* out = jobs.dst[by];
   const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const long j = (long)bx * 64 + col;
+  const long j = (long)bx * 64 + col, ld = jobs.ld ? jobs.ld : n;
   float acc = 0.f;
   if (j < n) {
     int c = grp;
     for (; c + 28 < nparts; c += 32) {               // 8 loads in flight per thread
       float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = part[(long)(c + 4 * u) * n + j];
+      for (int u = 0; u < 8; ++u) v[u] = part[(long)(c + 4 * u) * ld + j];
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc += v[u];
     }
-    for (; c < nparts; c += 4) acc += part[(long)c * n + j];
+    for (; c < nparts; c += 4) acc += part[(long)c * ld + j];
   }
   red[grp][col] = acc;
   __syncthreads();

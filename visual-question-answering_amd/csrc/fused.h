@@ -161,6 +161,7 @@ int gemm_tn_plan(const TnGemm& d, int max_parts, int* ksplit, int* S);   // retu
 struct TnReduce {                                                    // launch_reduce_jobs's arguments (common.h)
   const float* src[4]; float* dst[4]; int njobs, nparts; long n; int accumulate;
   const float* sum_x[2]; float* sum_out[2]; long sum_n;
+  long ld;                                                           // row stride of the partial buffers (0: n)
 };
 // n = 1 or 2 GEMMs per launch; red (may be NULL): small reductions done by extra workgroups of the same launch
 // wextra (may be NULL): one pre-split-weight GEMM (row-major A) whose tiles run as the last workgroups of the launch

@@ -326,7 +326,7 @@ int launch_gemm_tn(const TnGemm* d, const int* ksplit, const int* S, int n, hipS
     jobs.red.njobs = red->njobs;
     const int nsum = red->sum_x[0] ? 2 : 0;
     for (int i = 0; i < nsum; ++i) { jobs.red.sum_x[i] = red->sum_x[i]; jobs.red.sum_out[i] = red->sum_out[i]; }
-    jobs.red.sum_n = red->sum_n;
+    jobs.red.sum_n = red->sum_n; jobs.red.ld = red->ld;
     jobs.red_bx = (int)((red->n + 63) / 64);
     jobs.nred = jobs.red_bx * (red->njobs + nsum);
     jobs.red_nparts = red->nparts; jobs.red_n = red->n; jobs.red_acc = red->accumulate;

@@ -33,6 +33,7 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
   // XCD-aware tile order (as gemm.hip): the column tiles of one row tile share an XCD's L2
+  // (with k bands the column tiles are taken from the right: the bands with the long contractions start first)
   int m0, n0, z;
   {
     const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
@@ -41,13 +42,13 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
       const int per = ntm * ntn;
       z = id / per;
       const int t = id % per;
-      m0 = (t / ntn) * BM; n0 = (t % ntn) * BN;
+      m0 = (t / ntn) * BM; n0 = (g.kband_n > 0 ? ntn - 1 - t % ntn : t % ntn) * BN;
     } else {
       const int per = ntn * ((ntm + 7) / 8);
       z = slot / per;
       const int t = slot % per;
       const int mt = (t / ntn) * 8 + x;
-      m0 = mt * BM; n0 = (t % ntn) * BN;
+      m0 = mt * BM; n0 = (g.kband_n > 0 ? ntn - 1 - t % ntn : t % ntn) * BN;
       if (mt >= ntm) return;
     }
   }

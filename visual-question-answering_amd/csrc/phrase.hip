@@ -160,8 +160,8 @@ PhrasePlan plan_phrase(int B, int T, int E) {
   p.ksplit = (int)ks;
   p.nsplit = (int)((K + ks - 1) / ks);
   p.part = o; o += al256((size_t)p.nsplit * e3 * e3 * 4);
-  p.rows_per_chunk = 64;
-  p.nchunks = (int)((bt + 63) / 64);
+  p.rows_per_chunk = 32;
+  p.nchunks = (int)((bt + 31) / 32);
   p.bpart = o; o += al256((size_t)p.nchunks * e3 * 4);
   p.total_bwd = o;
   return p;
@@ -280,10 +280,6 @@ extern "C" int coattn_phrase_backward(const void* X, const coattn_phrase_params*
   int nchunks = 0;
   CA_TRY(launch_colsum_partial(nullptr, dZ, reinterpret_cast<float*>(w + pl.bpart), (int)bt, 3 * E, pl.rows_per_chunk,
                                &nchunks, s));
-  hipLaunchKernelGGL(phrase_unpack_db_kernel, dim3((unsigned)((3 * E + 255) / 256)), dim3(256), 0, s,
-                     reinterpret_cast<const float*>(w + pl.bpart), nchunks, (float*)pg->db1, (float*)pg->db2,
-                     (float*)pg->db3, E, accumulate);
-  CA_CHECK_LAUNCH("phrase_unpack_db");
   // dWcat partials = dZ^T Xcat over split row ranges
   // one launch per n-gram: only the tap blocks that exist (uni: x[t]; bi: x[t-1..t]; tri: all three)
   // fp32, 128-aligned channels: ONE split-K launch of the hand-scheduled A^T B kernel over the [3E x 3E] result with
@@ -302,8 +298,18 @@ extern "C" int coattn_phrase_backward(const void* X, const coattn_phrase_params*
     int ks = (int)((bt + S - 1) / S);
     ks = (ks + 15) / 16 * 16;
     S = (int)((bt + ks - 1) / ks);
-    CA_TRY(launch_gemm_tn(&tn, &ks, &S, 1, s));
+    // (the bias-gradient partials are summed by a few extra workgroups of the same launch)
+    TnReduce red = {};
+    float* db[3] = {(float*)pg->db1, (float*)pg->db2, (float*)pg->db3};
+    for (int i = 0; i < 3; ++i) { red.src[i] = reinterpret_cast<const float*>(w + pl.bpart) + (long)i * E; red.dst[i] = db[i]; }
+    red.njobs = 3; red.nparts = nchunks; red.n = E; red.ld = 3L * E; red.accumulate = accumulate;
+    CA_TRY(launch_gemm_tn(&tn, &ks, &S, 1, s, &red));
     nparts = S;
+  } else {
+    hipLaunchKernelGGL(phrase_unpack_db_kernel, dim3((unsigned)((3 * E + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float*>(w + pl.bpart), nchunks, (float*)pg->db1, (float*)pg->db2,
+                       (float*)pg->db3, E, accumulate);
+    CA_CHECK_LAUNCH("phrase_unpack_db");
   }
   for (int gr = 0; gr < 3 && !tn_ok; ++gr) {
     const int lo = gr == 0 ? E : 0, hi = gr == 0 ? 2 * E : (gr == 1 ? 2 * E : 3 * E);

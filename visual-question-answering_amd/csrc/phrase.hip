@@ -13,6 +13,7 @@
 // Padding follows the reference's ConstantPad1d: bigram (1,0), trigram (1,1) (model.py:313-321).
 #include "common.h"
 #include "fused.h"
+#include "gemm_w_body.h"
 #include <stdlib.h>
 
 namespace {
@@ -136,6 +137,38 @@ __global__ __launch_bounds__(256) void phrase_unpack_db_kernel(const float* __re
   *dst = accumulate ? *dst + v : v;
 }
 
+// Wcat straight into the MFMA-fragment image gemm_w reads (gemm_w.hip: wsplit_kernel's layout), without materialising
+// it: one wave per (32-column tile, 16-k step) chunk of Bw(k, n) = Wcat[n][k] (trans = 0: Z = Xcat Wcat^T) or
+// Wcat[k][n] (trans = 1: dXcat = dZ Wcat).  Chunks inside an absent tap block are skipped (never read: k bands).
+__global__ __launch_bounds__(256) void phrase_wsplit_kernel(const float* __restrict__ W1, const float* __restrict__ W2,
+                                                            const float* __restrict__ W3, const float* __restrict__ b1,
+                                                            const float* __restrict__ b2, const float* __restrict__ b3,
+                                                            char* __restrict__ img, float* __restrict__ bcat, int E,
+                                                            int trans) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (bcat && gid < 3 * E) bcat[gid] = gid < E ? b1[gid] : (gid < 2 * E ? b2[gid - E] : b3[gid - 2 * E]);
+  const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  const int ks16 = 3 * E / 16, chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (chunk >= ks16 * (3 * E / 32)) return;
+  const int nt = chunk / ks16, ks = chunk % ks16;
+  const int n = 32 * nt + li, k0 = 16 * ks + 8 * lh;
+  // (c, col) = (output channel of cat(uni, bi, tri), column of Xcat); a chunk lies inside one E x E block (E % 32 == 0)
+  const int c = trans ? k0 : n, col0 = trans ? n : k0;
+  const int g = c / E, jb = col0 / E;
+  if ((g == 0 && jb != 1) || (g == 1 && jb == 2)) return;
+  f32x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int cc = (trans ? k0 + e : n) % E, i = (trans ? n : k0 + e) % E;
+    v[e] = g == 0 ? W1[(long)cc * E + i] : (g == 1 ? W2[((long)cc * E + i) * 2 + jb] : W3[((long)cc * E + i) * 3 + jb]);
+  }
+  bf16x8 pz[3];
+  split3(v, pz);
+  char* out = img + (size_t)chunk * gw::kChunkBytes + lane * 16;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x8*>(out + q * gw::kFragBytes) = pz[q];
+}
+
 inline size_t al256(size_t n) { return (n + 255) & ~(size_t)255; }
 
 struct PhrasePlan {
@@ -181,8 +214,10 @@ int check_phrase(const void* X, const coattn_phrase_params* p, int B, int T, int
   return 0;
 }
 
+// wimg_trans < 0: Wcat and bcat as fp32 arrays (general GEMM); 0 / 1: the weight image of gemm_w for the forward /
+// the dXcat product instead (+ bcat)
 int build_operands(const float* X, const coattn_phrase_params* p, char* ws, const PhrasePlan& pl, int B, int T, int E,
-                   hipStream_t s) {
+                   hipStream_t s, int wimg_trans = -1) {
   const long bt = (long)B * T;
   float* Xcat = reinterpret_cast<float*>(ws + pl.xcat);
   if ((E & 3) == 0 && ((((uintptr_t)X) | ((uintptr_t)Xcat)) & 15) == 0) {
@@ -193,6 +228,14 @@ int build_operands(const float* X, const coattn_phrase_params* p, char* ws, cons
     hipLaunchKernelGGL(phrase_im2col_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, X, Xcat, T, E, n);
   }
   CA_CHECK_LAUNCH("phrase_im2col");
+  if (wimg_trans >= 0) {
+    const int chunks = (3 * E / 16) * (3 * E / 32);
+    hipLaunchKernelGGL(phrase_wsplit_kernel, dim3((unsigned)((chunks + 3) / 4)), dim3(256), 0, s, (const float*)p->W1,
+                       (const float*)p->W2, (const float*)p->W3, (const float*)p->b1, (const float*)p->b2,
+                       (const float*)p->b3, ws + pl.wimg, reinterpret_cast<float*>(ws + pl.bcat), E, wimg_trans);
+    CA_CHECK_LAUNCH("phrase_wsplit");
+    return 0;
+  }
   const long nw = 9L * E * E;
   hipLaunchKernelGGL(phrase_pack_w_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s,
                      (const float*)p->W1, (const float*)p->W2, (const float*)p->W3, (const float*)p->b1,
@@ -224,7 +267,12 @@ extern "C" int coattn_phrase_forward(const void* X, const coattn_phrase_params* 
   auto gemm = [&](const coattn_gemm_desc& g) { return bf16 ? launch_gemm_bf16in(g, s) : launch_gemm_f32(g, s); };
   const PhrasePlan pl = plan_phrase(B, T, E);
   char* w = static_cast<char*>(ws);
-  CA_TRY(build_operands((const float*)X, p, w, pl, B, T, E, s));
+  WGemm wg = {};
+  wg.A = reinterpret_cast<const float*>(w + pl.xcat); wg.a_sm = 3 * E; wg.Wf = w + pl.wimg;
+  wg.C = reinterpret_cast<float*>(w + pl.z); wg.c_sm = 3 * E; wg.bias_n = reinterpret_cast<const float*>(w + pl.bcat);
+  wg.M = B * T; wg.N = 3 * E; wg.K = 3 * E; wg.batch = 1;
+  const bool hand = !bf16 && hand_gemms() && E % 128 == 0 && gemm_w_supported(wg);
+  CA_TRY(build_operands((const float*)X, p, w, pl, B, T, E, s, hand ? 0 : -1));
   coattn_gemm_desc g = {};
   g.A = w + pl.xcat; g.B = w + pl.wcat; g.C = w + pl.z; g.bias_n = w + pl.bcat;
   g.M = B * T; g.N = 3 * E; g.K = 3 * E; g.batch = 1; g.inner = 1;
@@ -237,15 +285,9 @@ extern "C" int coattn_phrase_forward(const void* X, const coattn_phrase_params* 
   }
   // fp32, 128-aligned channels: the pre-split-weight kernel (Wcat split once into MFMA-fragment order; its zero tap
   // blocks are never read)
-  WGemm wg = {};
-  wg.A = reinterpret_cast<const float*>(w + pl.xcat); wg.a_sm = 3 * E; wg.Wf = w + pl.wimg;
-  wg.C = reinterpret_cast<float*>(w + pl.z); wg.c_sm = 3 * E; wg.bias_n = reinterpret_cast<const float*>(w + pl.bcat);
-  wg.M = B * T; wg.N = 3 * E; wg.K = 3 * E; wg.batch = 1;
   wg.kband_n = g.kband_n;
   for (int t = 0; t < 3; ++t) { wg.kband_lo[t] = g.kband_lo[t]; wg.kband_hi[t] = g.kband_hi[t]; }
-  if (!bf16 && hand_gemms() && E % 128 == 0 && gemm_w_supported(wg)) {
-    const WSplit job{reinterpret_cast<const float*>(w + pl.wcat), w + pl.wimg, 3 * E, 3 * E, 0, 3 * E};
-    CA_TRY(launch_wsplit(&job, 1, s));
+  if (hand) {
     CA_TRY(launch_gemm_w(&wg, 1, s));
   } else {
     CA_TRY(gemm(g));
@@ -271,8 +313,12 @@ extern "C" int coattn_phrase_backward(const void* X, const coattn_phrase_params*
   const PhrasePlan pl = plan_phrase(B, T, E);
   char* w = static_cast<char*>(ws);
   const long bt = (long)B * T, n = bt * E;
-  CA_TRY(build_operands((const float*)X, p, w, pl, B, T, E, s));
   float* dZ = reinterpret_cast<float*>(w + pl.z);
+  WGemm wdx = {};                                        // dXcat = dZ Wcat (as the forward: Wcat split the other way round)
+  wdx.A = dZ; wdx.a_sm = 3 * E; wdx.Wf = w + pl.wimg; wdx.C = reinterpret_cast<float*>(w + pl.xcat); wdx.c_sm = 3 * E;
+  wdx.M = (int)bt; wdx.N = 3 * E; wdx.K = 3 * E; wdx.batch = 1;
+  const bool hand_dx = dX && !bf16 && hand_gemms() && E % 128 == 0 && gemm_w_supported(wdx);
+  CA_TRY(build_operands((const float*)X, p, w, pl, B, T, E, s, hand_dx ? 1 : -1));
   hipLaunchKernelGGL(phrase_dz_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)g_out,
                      (const float*)out, (const unsigned char*)saved, dZ, n);
   CA_CHECK_LAUNCH("phrase_dz");
@@ -338,15 +384,10 @@ extern "C" int coattn_phrase_backward(const void* X, const coattn_phrase_params*
       h.kband_lo[1] = 0; h.kband_hi[1] = 3 * E;           // x[t]  : all
       h.kband_lo[2] = 2 * E; h.kband_hi[2] = 3 * E;       // x[t+1]: tri
     }
-    WGemm wg = {};                                       // (as the forward: Wcat split the other way round)
-    wg.A = dZ; wg.a_sm = 3 * E; wg.Wf = w + pl.wimg; wg.C = reinterpret_cast<float*>(w + pl.xcat); wg.c_sm = 3 * E;
-    wg.M = (int)bt; wg.N = 3 * E; wg.K = 3 * E; wg.batch = 1;
-    wg.kband_n = h.kband_n;
-    for (int t = 0; t < 3; ++t) { wg.kband_lo[t] = h.kband_lo[t]; wg.kband_hi[t] = h.kband_hi[t]; }
-    if (!bf16 && hand_gemms() && E % 128 == 0 && gemm_w_supported(wg)) {
-      const WSplit job{reinterpret_cast<const float*>(w + pl.wcat), w + pl.wimg, 3 * E, 3 * E, 1, 3 * E};
-      CA_TRY(launch_wsplit(&job, 1, s));
-      CA_TRY(launch_gemm_w(&wg, 1, s));
+    wdx.kband_n = h.kband_n;
+    for (int t = 0; t < 3; ++t) { wdx.kband_lo[t] = h.kband_lo[t]; wdx.kband_hi[t] = h.kband_hi[t]; }
+    if (hand_dx) {
+      CA_TRY(launch_gemm_w(&wdx, 1, s));
     } else {
       CA_TRY(gemm(h));
     }

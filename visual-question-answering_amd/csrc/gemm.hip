@@ -1,8 +1,9 @@
-// Strided, batched fp32 GEMM on the gfx950 f32 MFMA (v_mfma_f32_32x32x2_f32).
+// General strided, batched fp32 GEMM of the library: the exact 3-way bf16 split on v_mfma_f32_32x32x16_bf16 for
+// aligned shapes (MODE 2), the gfx950 f32 MFMA (v_mfma_f32_32x32x2_f32) otherwise.
 //
-// Workhorse of the co-attention path outside the fused kernels: projections
-// P_v = V W_v^T + b_v and P_q = Q W_q^T + b_q (model.py:380-384), the projection / weight
-// gradients of the backward, and every contraction of the general-shape implementation.
+// Every contraction of the general-shape implementation, dV, and whatever the two hand-scheduled kernels do not
+// take (gemm_w.hip: projections P_v = V W_v^T + b_v, P_q = Q W_q^T + b_q of model.py:380-384 and dQ = dP_q W_q;
+// gemm_tn.hip: the weight gradients): M < 128, K % 32, channel counts that are not multiples of 128, unaligned rows.
 // Operands are addressed through element strides so that V is consumed in its physical
 // channel-major [B,d,N] layout (model.py:215-217) without a transpose pass.
 //

@@ -1,6 +1,8 @@
 // PhraseConvPool (reference model.py:301-334) on gfx950: the three n-gram Conv1d + tanh + the
 // reference's max over 3 CONSECUTIVE channels of the concatenated [uni|bi|tri] vector, forward and
-// backward, as ONE dense contraction per direction on the fp32 MFMA GEMM of gemm.hip:
+// backward, as ONE dense contraction per direction -- on the hand-scheduled bf16-MFMA GEMMs (gemm_w.hip with k bands,
+// gemm_tn.hip with a tile mask; fp32-accurate 3-way split) when the channel count is a multiple of 128, else on the
+// general GEMM of gemm.hip:
 //
 //   Xcat[bt] = [x[t-1] | x[t] | x[t+1]]                 (zero rows outside 0 <= t < T)      [B*T, 3E]
 //   Wcat[c]  = taps of output channel c of cat(uni, bi, tri) laid out against Xcat          [3E, 3E]

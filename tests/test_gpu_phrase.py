@@ -24,7 +24,9 @@ def _case(B, T, E, seed):
     return mod, ref, x, g
 
 
-@pytest.mark.parametrize("shape", [(3, 26, 64), (2, 5, 20), (1, 1, 4), (4, 26, 512), (2, 7, 36)],
+# (12, 26, 512) and (40, 13, 384): >= 128 rows and 128-aligned channels -> the hand-scheduled GEMMs (k bands with 4 / 3
+# column tiles per band, masked split-K weight gradient); (4, 26, 512): weight gradient only; the rest: general GEMM
+@pytest.mark.parametrize("shape", [(3, 26, 64), (2, 5, 20), (1, 1, 4), (4, 26, 512), (2, 7, 36), (12, 26, 512), (40, 13, 384)],
                          ids=lambda s: "B%d_T%d_E%d" % s)
 def test_phrase_conv_pool_vs_oracle(shape):
     B, T, E = shape

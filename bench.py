@@ -18,7 +18,8 @@ contract fields it carries
                 host cores on a bounded sample (rank 0, N=1 only); cpu_baseline_hot_path: the oracle
                 port of the isolated hot path (co-attention + MLP + CE fwd+bwd) at N=196 and N=49
   roofline_projection  the MFMA-bound P_v projection GEMM (gemm_w_kernel), timed the same way: fp32-equivalent
-                TFLOP/s against the dense bf16 MFMA peak / 6 (six bf16 products per fp32 product)
+                TFLOP/s against the dense bf16 MFMA peak / 6 (six bf16 products per fp32 product);
+                roofline_weight_grad: the same for its weight gradient dW_v (gemm_tn_kernel + reduce)
   hot_path      isolated co-attention (+MLP+CE) fwd+bwd rates on device-resident features, N=196
                 and N=49, both feature layouts; the HIP op's fwd+bwd device time (pipelined calls) and the
                 wall time of single synchronised calls.
@@ -305,6 +306,51 @@ def projection_leg(device, B=160, N=196, d=512, iters=50):
             "weight_split_us": round(max(t_with_split - t, 0.0) * 1e6, 2)}
 
 
+def weight_grad_leg(device, B=160, N=196, d=512, iters=50):
+    """The other MFMA-bound kernel of the path: dW_v = dP_v^T V (the weight gradient of the P_v projection, autograd of
+    model.py:380/384) through coattn_linear_weight_grad -- split-K parts on gemm_tn_kernel + the deterministic
+    reduce, the pair coattn_backward uses (there the launch also carries dW_q, the dQ projection and the small
+    reductions).  The timed region is both launches; same warm-up, windows and roofline as projection_leg."""
+    import ctypes as C
+    from vqa_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(6)
+    dP = (torch.randn(B * N, d, generator=g) * 0.05).to(device)
+    V = torch.randn(B * N, d, generator=g).to(device)
+    dW = torch.empty(d, d, device=device)
+    ws = torch.empty(lib.coattn_linear_wgrad_workspace_bytes(d, d) // 4, device=device)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def call():
+        return lib.coattn_linear_weight_grad(dP.data_ptr(), d, V.data_ptr(), d, dW.data_ptr(), ws.data_ptr(), B * N, d, d,
+                                             0, stream)
+
+    _lib.check(call(), "coattn_linear_weight_grad")
+    ref = dP[:, :64].double().t() @ V.double()
+    if not torch.allclose(dW[:64].double(), ref, rtol=1e-5, atol=1e-4):
+        raise SystemExit("bench.py: weight-gradient leg: coattn_linear_weight_grad disagrees with the fp64 product")
+    for _ in range(3 * iters):
+        call()
+    ts = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e-3 / iters)
+    t = sorted(ts)[1]
+    flop = 2.0 * B * N * d * d
+    ach = flop / t / 1e12
+    peak = 2500.0 / 6.0
+    return {"bound": "mfma", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "peak_note": "fp32-equivalent: dense bf16 MFMA peak 2500 TFLOP/s / 6 partial products per fp32 product",
+            "traffic": None, "kernel": "dW_v weight-gradient GEMM (gemm_tn_kernel, 32 split-K parts) + reduce_partials4_kernel",
+            "shape": {"M": d, "N": d, "K": B * N}, "avg_launch_us": round(t * 1e6, 2),
+            "windows_us": [round(x * 1e6, 2) for x in ts], "calls_per_window": iters, "algorithmic_flops": flop}
+
+
 def host_cores() -> int:
     """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
     from vqa_amd.train import usable_cpus
@@ -430,7 +476,8 @@ def main():
         res = ({"roofline": roofline_leg(dev), "roofline_channel_major": roofline_leg(dev, layout="cm"),
                 "roofline_at_step_shape": roofline_leg(dev, N=49),
                 "roofline_at_step_shape_channel_major": roofline_leg(dev, N=49, layout="cm"),
-                "roofline_projection": projection_leg(dev)} if args.only == "roofline"
+                "roofline_projection": projection_leg(dev), "roofline_weight_grad": weight_grad_leg(dev)}
+               if args.only == "roofline"
                else [hot_path_leg(dev, n, lay) for n in (196, 49) for lay in ("lm", "cm")])
         print(json.dumps(res))
         return
@@ -501,6 +548,7 @@ def main():
         out["roofline_at_step_shape"] = roofline_leg(device, B=args.batch, N=(args.image_size // 32) ** 2,
                                                      T=args.seq_len)
         out["roofline_projection"] = projection_leg(device)
+        out["roofline_weight_grad"] = weight_grad_leg(device)
         if world == 1:
             out["hot_path"] = [hot_path_leg(device, n, lay) for n in (196, 49) for lay in ("lm", "cm")]
     if rank == 0:

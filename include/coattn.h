@@ -78,8 +78,8 @@ const char* coattn_last_error(void);
 /* 1 if a fused-kernel configuration exists for this shape (for channel-major or location-major V), else 0 */
 int coattn_fused_supported(int B, int N, int T, int d, int L, int dtype);
 
-/* Buffer sizes in bytes.  saved: forward -> backward state (P_v, P_q, C, a_v, a_q, H_q);
- * ws_fwd / ws_bwd: scratch, contents undefined after the call. */
+/* Buffer sizes in bytes.  saved: forward -> backward state (P_v, P_q, C, a_v, a_q, H_q, and W_q split into bf16
+ * pieces for the backward's dQ projection); ws_fwd / ws_bwd: scratch, contents undefined after the call. */
 int coattn_workspace_bytes(int B, int N, int T, int d, int L, int dtype, int flags,
                            size_t* saved, size_t* ws_fwd, size_t* ws_bwd);
 
@@ -105,7 +105,9 @@ int coattn_attention_forward(const void* V, int64_t v_sB, int64_t v_sN, int64_t 
  *           features need no gradient (frozen encoder, model.py:239-241);
  *   dQ    : host array of L device pointers [B,T,d] (overwritten).
  *   pg    : parameter gradients; accumulate = 0 overwrites, 1 adds into them (grads of the
- *           three levels are always summed: one weight set is shared, model.py:167, :372). */
+ *           three levels are always summed: one weight set is shared, model.py:167, :372).
+ *   saved : of a coattn_forward call with the SAME inputs, parameter values and flags (it holds projections of
+ *           them and an image of W_q; autograd's forward -> backward order guarantees this). */
 int coattn_backward(const void* V, int64_t v_sB, int64_t v_sN, int64_t v_sD, const void* const* Q,
                     const coattn_params* p, const void* saved, const void* gv, const void* gq,
                     void* dV, int64_t dv_sB, int64_t dv_sN, int64_t dv_sD, void* const* dQ,

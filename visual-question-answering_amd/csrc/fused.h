@@ -273,7 +273,7 @@ inline SavedOff saved_off(int B, int N, int T, int d, int L) {   // the one layo
 struct FusedBwdOff {
   size_t dsv, dZq, dPq, dPv, dA, dwv_part, dbv_part, dbq_part, dwq_part, dcs_part, part, total;
 };
-constexpr int kMaxParts = 64;   // split-K parts of a weight-gradient GEMM
+constexpr int kMaxParts = 40;   // split-K parts of the weight-gradient GEMMs (32 shared by dW_v and dW_q, rounded up per level)
 inline FusedBwdOff fused_bwd_off(int B, int N, int T, int d, int L) {
   FusedBwdOff p;
   size_t o = 0;

@@ -22,3 +22,13 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+def pytest_report_header(config):
+    """Which GPU ran the suite (a result that differs box to box can then be tied to a device: DESIGN.md section 4)."""
+    import torch
+
+    if not torch.cuda.is_available():
+        return "gpu: none visible"
+    p = torch.cuda.get_device_properties(0)
+    return "gpu: %s uuid %s (%d CUs)" % (p.name, getattr(p, "uuid", "unknown"), p.multi_processor_count)

@@ -123,13 +123,12 @@ def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20):
         x_img = x_img.contiguous()
     Qs = [q.requires_grad_(True) for q in Qs]
     label = (torch.arange(B, device=device) * 7) % (K + 1)
-    crit = torch.nn.CrossEntropyLoss()
     params = [p for p in list(co.parameters()) + list(mlp.parameters())]
 
-    def step():
+    def step():                                      # as Trainer.step: logits and loss out of the answer head's one call
         for p in params:
             p.grad = None
-        loss = crit(mlp(*co(x_img, Qs)), label)
+        _, loss = mlp.forward_loss(*co(x_img, Qs), label)
         loss.backward()
 
     for _ in range(5):

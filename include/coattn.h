@@ -146,13 +146,48 @@ int coattn_phrase_backward(const void* X, const coattn_phrase_params* p, const v
 /* ---- cross entropy of the train step ------------------------------------------------
  * coattn_ce_forward replaces `nn.CrossEntropyLoss()(logits, label)` (main.py:94, :214; mean over the batch)
  * together with its gradient.  The MLPClassifier that produces the logits (model.py:400-434) stays on the stock
- * PyTorch-ROCm modules. */
+ * PyTorch-ROCm modules unless the fused head below is used (coattn_head_forward). */
 /* Mean cross entropy over B rows of [B,K] logits with int64 labels in [0,K) (a label outside makes the loss NaN):
  * loss[0] = mean_i (logsumexp(z_i) - z_i[label_i]);  dlogits [B,K] = (softmax(z) - onehot) / B, or NULL to skip.
  * ws: coattn_ce_workspace_bytes. */
 int coattn_ce_workspace_bytes(int B, int K, int dtype, size_t* ws);
 int coattn_ce_forward(const void* logits, const void* labels, void* loss, void* dlogits, void* ws, int B, int K,
                       int dtype, void* stream);
+
+/* ---- answer head: MLPClassifier + cross entropy and their backward ----------------------------
+ * coattn_head_forward replaces `MLPClassifier.forward` (model.py:414-434, called at model.py:185 with the two lists
+ * co-attention returns) and, when labels are given, `criterion(logits, label)` (main.py:214):
+ *     h_w = tanh(W_w (q_w + v_w) + b_w); h_p = tanh(W_p [q_p + v_p | h_w] + b_p); h_s = tanh(W_s [q_s + v_s | h_p] + b_s);
+ *     logits = W_h h_s + b_h;  loss = mean cross entropy.
+ * coattn_head_backward replaces their autograd graph (main.py:219-220).  The adds, the concatenations, bias + tanh and
+ * tanh' are folded into the operand addressing / epilogues of 32 x 32-tile products on the exact-fp32 MFMA (head.hip):
+ * 4 launches + 2 for the loss forward, 4 launches backward.
+ *   v, q   : host arrays of 3 device pointers [B,d] each (word, phrase, sentence: the rows of co-attention's v_out /
+ *            q_out, or any three tensors);  W_w [d,d], W_p [d,2d], W_s [mlp,2d], W_h [K,mlp] as nn.Linear stores them.
+ *   labels : int64 [B] or NULL (then loss must be NULL too: logits only, e.g. validation's argmax).
+ *   logits : [B,K] (written);  loss: [1] (written).  A label outside [0,K) makes the loss NaN.
+ *   saved  : forward -> backward state (h_w, h_p, h_s, d loss / d logits, row losses): coattn_head_workspace_bytes.
+ * Backward: g_loss [1] (device) scales the saved d loss / d logits; g_logits [B,K] (may be NULL) is added to it -- the two
+ * upstream gradients autograd can hand over; at least one must be given.  dv, dq: host arrays of 3 device pointers [B,d]
+ * (overwritten; the gradient of q_l + v_l goes to both; dq may be NULL or equal dv: stored once; dv NULL: no input
+ * gradients).  pg: the eight parameter gradients (accumulate = 0 overwrites, 1 adds).  ws: scratch of `ws_bwd` bytes. */
+typedef struct coattn_head_params {
+  const void* W_w; const void* b_w;   /* model.py:409 */
+  const void* W_p; const void* b_p;   /* model.py:410 */
+  const void* W_s; const void* b_s;   /* model.py:411 */
+  const void* W_h; const void* b_h;   /* model.py:412 */
+} coattn_head_params;
+typedef struct coattn_head_param_grads {
+  void* dW_w; void* db_w; void* dW_p; void* db_p; void* dW_s; void* db_s; void* dW_h; void* db_h;
+} coattn_head_param_grads;
+int coattn_head_workspace_bytes(int B, int d, int mlp, int K, int dtype, size_t* saved, size_t* ws_bwd);
+int coattn_head_forward(const void* const* v, const void* const* q, const coattn_head_params* p, const void* labels,
+                        void* logits, void* loss, void* saved, int B, int d, int mlp, int K, int dtype, int flags,
+                        void* stream);
+int coattn_head_backward(const void* const* v, const void* const* q, const coattn_head_params* p, const void* saved,
+                         const void* g_loss, const void* g_logits, void* const* dv, void* const* dq,
+                         const coattn_head_param_grads* pg, int accumulate, void* ws, int B, int d, int mlp, int K,
+                         int dtype, int flags, void* stream);
 
 /* ---- building blocks (exported for the per-kernel parity tests) ------------------------ */
 

@@ -9,5 +9,6 @@ tensors raises.
 from . import _lib  # noqa: F401
 from .coattention import ParallelCoAttention, coattention  # noqa: F401
 from .loss import CrossEntropyLoss, cross_entropy  # noqa: F401
+from .head import answer_head  # noqa: F401
 
-__all__ = ["ParallelCoAttention", "coattention", "cross_entropy", "CrossEntropyLoss", "_lib"]
+__all__ = ["ParallelCoAttention", "coattention", "answer_head", "cross_entropy", "CrossEntropyLoss", "_lib"]

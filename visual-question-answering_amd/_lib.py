@@ -15,7 +15,8 @@ EXPORTS = ("coattn_version", "coattn_last_error", "coattn_fused_supported", "coa
            "coattn_forward", "coattn_attention_forward", "coattn_backward", "coattn_gemm_f32", "coattn_gemm_bf16",
            "coattn_phrase_workspace_bytes", "coattn_phrase_forward", "coattn_phrase_backward",
            "coattn_ce_workspace_bytes", "coattn_ce_forward", "coattn_linear_workspace_bytes", "coattn_linear_forward",
-           "coattn_linear_wgrad_workspace_bytes", "coattn_linear_weight_grad")
+           "coattn_linear_wgrad_workspace_bytes", "coattn_linear_weight_grad",
+           "coattn_head_workspace_bytes", "coattn_head_forward", "coattn_head_backward")
 
 F32 = 0
 IMPL_AUTO, IMPL_GENERAL, IMPL_FUSED = 0, 1, 2
@@ -36,6 +37,14 @@ class PhraseParams(C.Structure):
 
 class PhraseParamGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("dW1", "db1", "dW2", "db2", "dW3", "db3")]
+
+
+class HeadParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("W_w", "b_w", "W_p", "b_p", "W_s", "b_s", "W_h", "b_h")]
+
+
+class HeadParamGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("dW_w", "db_w", "dW_p", "db_p", "dW_s", "db_s", "dW_h", "db_h")]
 
 
 class GemmDesc(C.Structure):
@@ -108,6 +117,13 @@ def load() -> C.CDLL:
     lib.coattn_linear_wgrad_workspace_bytes.restype = C.c_size_t
     lib.coattn_linear_weight_grad.argtypes = ([C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
                                               + [C.c_int] * 4 + [C.c_void_p])
+    lib.coattn_head_workspace_bytes.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_size_t)] * 2
+    lib.coattn_head_forward.argtypes = ([C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(HeadParams)]
+                                        + [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p])
+    lib.coattn_head_backward.argtypes = ([C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(HeadParams)]
+                                         + [C.c_void_p] * 3 + [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                                               C.POINTER(HeadParamGrads), C.c_int, C.c_void_p]
+                                         + [C.c_int] * 6 + [C.c_void_p])
     _lib = lib
     return lib
 

@@ -53,6 +53,15 @@ inline size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
 
 }  // namespace
 
+// rows + mean for the answer head (head.hip): row_loss [B] scratch, dlogits [B,K] or NULL
+int launch_ce_rows(const float* logits, const void* labels, float* row_loss, float* dlogits, float* loss, int B, int K,
+                   hipStream_t s) {
+  hipLaunchKernelGGL(ce_rows_kernel, dim3(B), dim3(256), 0, s, logits, (const long long*)labels, row_loss, dlogits, K,
+                     1.0f / (float)B);
+  CA_CHECK_LAUNCH("ce_rows");
+  return launch_sum_all(row_loss, loss, B, 0, s);
+}
+
 extern "C" int coattn_ce_workspace_bytes(int B, int K, int dtype, size_t* ws) {
   CA_CHECK_ARG(dtype == COATTN_F32, "unsupported dtype %d (only COATTN_F32)", dtype);
   CA_CHECK_ARG(B > 0 && K > 0, "bad B=%d / K=%d", B, K);

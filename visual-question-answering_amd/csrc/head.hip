@@ -1,0 +1,560 @@
+// Answer head of the attention model on gfx950: MLPClassifier (reference model.py:400-434) + nn.CrossEntropyLoss
+// (main.py:94, :214) + their backward, behind the C-ABI coattn_head_forward / coattn_head_backward.
+//
+//   h_w = tanh(W_w (q_w + v_w) + b_w)                        [B, d]         model.py:428
+//   h_p = tanh(W_p [q_p + v_p | h_w] + b_p)                  [B, d]         model.py:429
+//   h_s = tanh(W_s [q_s + v_s | h_p] + b_s)                  [B, mlp]       model.py:430
+//   logits = W_h h_s + b_h                                   [B, K]         model.py:433
+//   loss = mean_i (logsumexp(logits_i) - logits_i[label_i])                main.py:214
+//
+// The batch is ONE short M dimension (B = 160 rows), so every product is a small GEMM that a single 128 x 128-tile
+// launch cannot spread over the chip (round 1's composition of the general GEMM: thirty launches, 0.53 ms).  Here a
+// product is cut into 32 x 32 output tiles, one 512-thread workgroup each, with the CONTRACTION split over the eight
+// waves (cross-wave sum in a fixed order through LDS): 80-160 tiles per layer.  The q_l + v_l adds and the concatenations
+// are folded into the A-operand addressing, bias + tanh into the epilogue, tanh' of the backward into the epilogue of the
+// product that yields d h; every backward launch carries the dX tiles of a layer (the dependent chain) AND the tiles of
+// that layer's weight gradient dW = dY^T X (+ the bias gradient), which depend on nothing the launch itself produces and
+// fill the CUs the chain leaves idle.  Forward: 4 launches + cross entropy (2); backward: 4 launches.
+//
+// Arithmetic: exact fp32 on v_mfma_f32_32x32x2_f32 (one rounding per product, as an fmaf chain).  The products are too
+// small for the bf16 3-way split of the big GEMMs to pay: every operand element is used by one 32 x 32 tile only, so the
+// 11 VALU operations per split pair would cost more than the 64-cycle f32 MFMAs they replace.
+// Operands that are contiguous along the contraction index (activations and nn.Linear weights in the forward, dY in dX)
+// are fetched as whole 128-byte lines (8 rows per wave instruction), staged in a per-wave LDS image with padded rows and
+// read back as fragments (ds_read_b128, conflict-free); operands contiguous along the tile index (the weight in dX, both
+// operands of dW) go straight to registers (a lane per column: 128-byte row segments).  Deterministic: no atomics.
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int kWaves = 8, kThreads = 64 * kWaves;
+constexpr int KC = 32;            // contraction chunk per wave step: 16 MFMAs of 32x32x2
+constexpr int LDR = KC + 4;       // padded LDS row (floats): 16-byte aligned, rows 4 banks apart
+
+__device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ constexpr int crow32(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
+
+// ---- operands through buffer descriptors -------------------------------------------------------------------------------
+// Every load is a raw buffer load: the descriptor covers [rows x ld] floats, so a row past the end is out of range and
+// reads 0 (the hardware's range check includes the scalar offset: checked on gfx950), a column past the end gets the
+// out-of-range vector offset kOut -- no per-lane condition ever guards a load (hipcc branches around a guarded load and
+// waits for it alone: dozens of dependent round trips per chunk, 44 us per backward launch instead of 9), and no load
+// needs a 64-bit address register: lane part in voffset, the wave-uniform row / chunk part in the scalar offset.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr int kOut = (int)0xC0000000u;      // beyond every descriptor; scalar offsets stay below 1 GB, so no wrap-around
+__device__ __forceinline__ rsrc_t mk_rsrc(const void* p, long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, p ? (unsigned)bytes : 0u, 0x00020000);
+}
+// (the scalar offsets are wave-uniform by construction; under SGPR pressure hipcc moves such arithmetic to the VALU and
+//  then wraps every load in a waterfall loop -- the readfirstlane keeps the load a single instruction)
+__device__ __forceinline__ float bl1(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, __builtin_amdgcn_readfirstlane(soff), 0));
+}
+__device__ __forceinline__ f32x4 bl4(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, __builtin_amdgcn_readfirstlane(soff), 0));
+}
+
+// activation operand with the reference's adds and concatenation folded in (model.py:428-430):
+//   X(m, k) = k < ksplit ? x0[m][k] + x1[m][k] : h[m][k - ksplit]            (x1 may be NULL; rows ld0 / ldh apart)
+struct Comp {
+  const float* x0; const float* x1; const float* h;
+  int ksplit, ld0, ldh;
+};
+// upstream gradient operand: dY(m, n) = p[m][n] * (scale ? scale[0] : 1) + (add ? add[m][n] : 0)
+struct DY {
+  const float* p; const float* scale; const float* add; int ld;
+};
+struct CompR {                    // Comp with descriptors over M rows, K columns in all
+  rsrc_t x0, x1, h; int ksplit, ld0, ldh, K; bool two;
+};
+__device__ __forceinline__ CompR comp_rsrc(const Comp& c, int M, int K) {
+  CompR r;
+  r.x0 = mk_rsrc(c.x0, (long)M * c.ld0 * 4); r.x1 = mk_rsrc(c.x1, (long)M * c.ld0 * 4); r.h = mk_rsrc(c.h, (long)M * c.ldh * 4);
+  r.ksplit = c.ksplit; r.ld0 = c.ld0; r.ldh = c.ldh; r.K = K; r.two = c.x1 != nullptr;
+  return r;
+}
+struct DYR { rsrc_t p, add; int ld, N; bool has_add; float sc; };
+__device__ __forceinline__ DYR dy_rsrc(const DY& d, int M, int N) {
+  DYR r;
+  r.p = mk_rsrc(d.p, (long)M * d.ld * 4); r.add = mk_rsrc(d.add, (long)M * d.ld * 4);
+  r.ld = d.ld; r.N = N; r.has_add = d.add != nullptr; r.sc = d.scale ? d.scale[0] : 1.f;
+  return r;
+}
+
+// ---- staging of a [32 rows][KC] block, contiguous along k, into the wave's LDS image ---------------------------------
+// VEC: whole 128-byte lines, lane (r = lane >> 3, c = lane & 7) of instruction t fetches 16 bytes of row 8 t + r.
+// Otherwise (any shape / alignment): two rows per instruction, a lane per k.
+struct Stage {
+  f32x4 v[4];                     // 16 floats per lane either way: 32 rows x KC / 64 lanes
+};
+// an operand that is the sum of two arrays keeps both register sets until the block is written to LDS: the addition
+// would otherwise wait for both loads right where they are issued, in front of the other operand's loads
+struct Stage2 {
+  Stage a, b; bool two; float sc;   // value = a * sc + (two ? b : 0)
+};
+// the lane's share of the block of a plain [rows x ld] matrix starting at (row0, k0); columns >= Klim read 0
+template <bool VEC>
+__device__ __forceinline__ void stage_lin(Stage& s, rsrc_t r, int ld, int Klim, int lane, int row0, int k0) {
+  if constexpr (VEC) {
+    const int rr = lane >> 3, kk = 4 * (lane & 7);
+    const int voff = k0 + kk < Klim ? (rr * ld + kk) * 4 : kOut;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) s.v[t] = bl4(r, voff, ((row0 + 8 * t) * ld + k0) * 4);
+  } else {
+    const int kk = lane & 31, half = lane >> 5;
+    const int voff = k0 + kk < Klim ? (half * ld + kk) * 4 : kOut;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s.v[t >> 2][t & 3] = bl1(r, voff, ((row0 + 2 * t) * ld + k0) * 4);
+  }
+}
+template <bool VEC>
+__device__ __forceinline__ void stage_comp(Stage2& s, const CompR& c, int lane, int m0, int k0) {
+  s.sc = 1.f;
+  s.two = false;
+  if (k0 + KC <= c.ksplit) {                                 // (wave-uniform branches: scalar control flow)
+    stage_lin<VEC>(s.a, c.x0, c.ld0, c.K, lane, m0, k0);
+    s.two = c.two;
+    if (c.two) stage_lin<VEC>(s.b, c.x1, c.ld0, c.K, lane, m0, k0);
+  } else if (k0 >= c.ksplit) {
+    stage_lin<VEC>(s.a, c.h, c.ldh, c.K - c.ksplit, lane, m0, k0 - c.ksplit);
+  } else {                                                   // the chunk straddles the concatenation (d % 32 != 0): never VEC
+    const int kk = lane & 31, half = lane >> 5, k = k0 + kk;
+    const int v0 = k < c.ksplit ? (half * c.ld0 + kk) * 4 : kOut;
+    const int vh = (k >= c.ksplit && k < c.K) ? (half * c.ldh + k - c.ksplit) * 4 : kOut;   // (scalar offsets stay >= 0)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int s0 = ((m0 + 2 * t) * c.ld0 + k0) * 4, sh = (m0 + 2 * t) * c.ldh * 4;
+      s.a.v[t >> 2][t & 3] = bl1(c.x0, v0, s0) + bl1(c.x1, v0, s0) + bl1(c.h, vh, sh);
+    }
+  }
+}
+template <bool VEC>
+__device__ __forceinline__ void stage_dy(Stage2& s, const DYR& y, int lane, int m0, int n0) {
+  s.sc = y.sc;
+  s.two = y.has_add;
+  stage_lin<VEC>(s.a, y.p, y.ld, y.N, lane, m0, n0);
+  if (y.has_add) stage_lin<VEC>(s.b, y.add, y.ld, y.N, lane, m0, n0);
+}
+template <bool VEC>
+__device__ __forceinline__ void stage_store(const Stage& s, float* img, int lane);
+template <bool VEC>
+__device__ __forceinline__ void stage_store(const Stage2& s, float* img, int lane) {
+  Stage t;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t.v[i] = s.two ? s.a.v[i] * s.sc + s.b.v[i] : s.a.v[i] * s.sc;
+  stage_store<VEC>(t, img, lane);
+}
+template <bool VEC>
+__device__ __forceinline__ void stage_store(const Stage& s, float* img, int lane) {
+  if constexpr (VEC) {
+    const int r = lane >> 3, c = lane & 7;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(img + (8 * t + r) * LDR + 4 * c) = s.v[t];
+  } else {
+    const int kk = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) img[(2 * t + half) * LDR + kk] = s.v[t >> 2][t & 3];
+  }
+}
+
+struct TileOut {
+  float* C; int ldc;              // plain output rows
+  const float* bias;              // [n] or NULL
+  int act;                        // 1: tanh
+  // dX epilogue: columns >= hsplit are gradients of a hidden activation: multiplied by 1 - hid^2 and stored to Ch
+  int hsplit; const float* hid; int ldhid; float* Ch; int ldch;
+  float* C2;                      // second copy of the plain columns (dq beside dv), may be NULL
+};
+
+// cross-wave sum of the eight partial 32 x 32 accumulators in a fixed order + epilogue
+__device__ __forceinline__ void reduce_store(const f32x16& acc, float* red, const TileOut& o, int m0, int n0, int M, int N, int w) {
+  const int lane = threadIdx.x & 63;
+  __syncthreads();                                   // every wave is done with its staging images
+#pragma unroll
+  for (int g = 0; g < 16; ++g) red[(w * 16 + g) * 64 + lane] = acc[g];
+  __syncthreads();
+#pragma unroll
+  for (int gg = 0; gg < 2; ++gg) {
+    const int g = w + 8 * gg;
+    float s = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < kWaves; ++ww) s += red[(ww * 16 + g) * 64 + lane];
+    const int m = m0 + crow32(g, lane >> 5), n = n0 + (lane & 31);
+    if (m < M && n < N) {
+      if (o.bias) s += o.bias[n];
+      if (o.act) s = tanhf(s);
+      if (n >= o.hsplit) {
+        const float hv = o.hid[(long)m * o.ldhid + (n - o.hsplit)];
+        o.Ch[(long)m * o.ldch + (n - o.hsplit)] = s * (1.f - hv * hv);
+      } else {
+        if (o.C) o.C[(long)m * o.ldc + n] = s;
+        if (o.C2) o.C2[(long)m * o.ldc + n] = s;
+      }
+    }
+  }
+}
+
+// 16 MFMAs on the staged chunk: lane (li, lh) of MFMA (u, e) takes k = 8 u + 4 lh + e of its row
+__device__ __forceinline__ void mfma_chunk(f32x16& acc, const float* imgA, const float* imgB, int li, int lh) {
+#pragma unroll
+  for (int u = 0; u < KC / 8; ++u) {
+    const f32x4 fa = *reinterpret_cast<const f32x4*>(imgA + li * LDR + 8 * u + 4 * lh);
+    const f32x4 fb = *reinterpret_cast<const f32x4*>(imgB + li * LDR + 8 * u + 4 * lh);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = mfma2(fa[e], fb[e], acc);
+  }
+}
+
+// ---- forward tile: C[m][n] = act(sum_k X(m, k) W[n][k] + bias[n]) --------------------------------------------------
+template <bool VEC>
+__device__ __forceinline__ void fwd_tile(const Comp& A, const float* __restrict__ W, int ldw, const TileOut& o, int M, int N, int K,
+                                         int m0, int n0, float* smem) {
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 31, lh = lane >> 5;
+  float* imgA = smem + w * (2 * 32 * LDR);
+  float* imgB = imgA + 32 * LDR;
+  f32x16 acc = {};
+  const int nchunks = (K + KC - 1) / KC;
+  const CompR ar = comp_rsrc(A, M, K);
+  const rsrc_t wr = mk_rsrc(W, (long)N * ldw * 4);
+  Stage2 sa;
+  Stage sb;
+  int c = w;                                         // chunks interleaved over the waves: neighbouring lines together
+  if (c < nchunks) {
+    stage_comp<VEC>(sa, ar, lane, m0, c * KC);
+    stage_lin<VEC>(sb, wr, ldw, K, lane, n0, c * KC);
+  }
+  for (; c < nchunks; c += kWaves) {
+    stage_store<VEC>(sa, imgA, lane);
+    stage_store<VEC>(sb, imgB, lane);
+    if (c + kWaves < nchunks) {                      // next chunk's lines in flight behind this chunk's MFMAs
+      stage_comp<VEC>(sa, ar, lane, m0, (c + kWaves) * KC);
+      stage_lin<VEC>(sb, wr, ldw, K, lane, n0, (c + kWaves) * KC);
+    }
+    __builtin_amdgcn_wave_barrier();
+    mfma_chunk(acc, imgA, imgB, li, lh);
+    __builtin_amdgcn_wave_barrier();
+  }
+  reduce_store(acc, smem, o, m0, n0, M, N, w);
+}
+
+// ---- dX tile: dX[m][k'] = sum_n dY(m, n) W[n][k'] -------------------------------------------------------------------
+template <bool VEC>
+__device__ __forceinline__ void dx_tile(const DY& Y, const float* __restrict__ W, int ldw, const TileOut& o, int M, int Nc /* contraction */,
+                                        int Kout, int m0, int k0, float* smem) {
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 31, lh = lane >> 5;
+  float* imgA = smem + w * (2 * 32 * LDR);
+  f32x16 acc = {};
+  const DYR yr = dy_rsrc(Y, M, Nc);
+  const rsrc_t wr = mk_rsrc(W, (long)Nc * ldw * 4);
+  const int nchunks = (Nc + KC - 1) / KC;
+  const int bvoff = k0 + li < Kout ? (4 * lh * ldw + k0 + li) * 4 : kOut;   // a lane per output column: 128-byte row segments of W
+  Stage2 sa;
+  float fb0[16], fb1[16];
+  auto loadB = [&](float (&fb)[16], int nc) {               // contraction rows nc + 8 u + 4 lh + e (rows >= Nc: out of range, 0)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) fb[4 * u + e] = bl1(wr, bvoff, (nc + 8 * u + e) * ldw * 4);
+  };
+  auto compute = [&](const float (&fb)[16]) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < KC / 8; ++u) {
+      const f32x4 fa = *reinterpret_cast<const f32x4*>(imgA + li * LDR + 8 * u + 4 * lh);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = mfma2(fa[e], fb[4 * u + e], acc);
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  int c = w;
+  if (c < nchunks) {
+    stage_dy<VEC>(sa, yr, lane, m0, c * KC);
+    loadB(fb0, c * KC);
+  }
+  while (c < nchunks) {                                      // two chunks per trip: the register sets alternate
+    stage_store<VEC>(sa, imgA, lane);
+    int cn = c + kWaves;
+    if (cn < nchunks) {
+      stage_dy<VEC>(sa, yr, lane, m0, cn * KC);
+      loadB(fb1, cn * KC);
+    }
+    compute(fb0);
+    c = cn;
+    if (c >= nchunks) break;
+    stage_store<VEC>(sa, imgA, lane);
+    cn = c + kWaves;
+    if (cn < nchunks) {
+      stage_dy<VEC>(sa, yr, lane, m0, cn * KC);
+      loadB(fb0, cn * KC);
+    }
+    compute(fb1);
+    c = cn;
+  }
+  reduce_store(acc, smem, o, m0, k0, M, Kout, w);
+}
+
+// ---- dW tile (one WAVE): dW[n][k'] (+)= sum_m dY(m, n) X(m, k');  db[n] (+)= sum_m dY(m, n) for the tiles with k0 = 0 ----
+__device__ __forceinline__ void dw_tile(const DY& Y, const Comp& X, float* __restrict__ dW, int ldw, float* __restrict__ db, int M, int N, int Kin,
+                                        int n0, int k0, int accumulate) {
+  const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  const DYR yr = dy_rsrc(Y, M, N);
+  const CompR xr = comp_rsrc(X, M, Kin);
+  const bool a_ok = n0 + li < N;
+  // a lane per tile column, two batch rows per instruction (the lane halves); rows >= M are out of range and read 0
+  const int avoff = a_ok ? (lh * yr.ld + n0 + li) * 4 : kOut;
+  const int k = k0 + li;
+  const int v0 = k < xr.ksplit ? (lh * xr.ld0 + k) * 4 : kOut;
+  const int vh = (k >= xr.ksplit && k < Kin) ? (lh * xr.ldh + k - xr.ksplit) * 4 : kOut;
+  f32x16 acc = {};
+  float colsum = 0.f;
+  // the loop is specialised ONCE per tile on the arrays its columns touch (a branch per load, even a wave-uniform one,
+  // ends the basic block and hipcc waits for every load where it stands): 0 = q_l + v_l part, 1 = hidden part,
+  // 2 = everything (a tile across the concatenation, or an added upstream gradient)
+  auto run = [&](auto mode) {
+    constexpr int MODE = decltype(mode)::value;
+    float a0[16], b0[16], a1[16], b1[16];
+    auto load = [&](float (&fa)[16], float (&fb)[16], int mc) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int m = mc + 2 * s;
+        fa[s] = bl1(yr.p, avoff, m * yr.ld * 4);
+        if constexpr (MODE == 2) fa[s] = fa[s] * yr.sc + bl1(yr.add, avoff, m * yr.ld * 4);
+        if constexpr (MODE == 0) fb[s] = bl1(xr.x0, v0, m * xr.ld0 * 4) + bl1(xr.x1, v0, m * xr.ld0 * 4);
+        if constexpr (MODE == 1) fb[s] = bl1(xr.h, vh, m * xr.ldh * 4);
+        if constexpr (MODE == 2) fb[s] = bl1(xr.x0, v0, m * xr.ld0 * 4) + bl1(xr.x1, v0, m * xr.ld0 * 4) + bl1(xr.h, vh, m * xr.ldh * 4);
+      }
+    };
+    auto compute = [&](const float (&fa)[16], const float (&fb)[16]) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        acc = mfma2(fa[s], fb[s], acc);
+        colsum += fa[s];
+      }
+    };
+    load(a0, b0, 0);
+    for (int mc = 0; mc < M; mc += 64) {                      // two chunks per trip: the register sets alternate
+      if (mc + 32 < M) load(a1, b1, mc + 32);
+      compute(a0, b0);
+      if (mc + 32 >= M) break;
+      if (mc + 64 < M) load(a0, b0, mc + 64);
+      compute(a1, b1);
+    }
+  };
+  if (yr.has_add || (k0 < xr.ksplit && k0 + 32 > xr.ksplit)) run(std::integral_constant<int, 2>());
+  else if (k0 < xr.ksplit) run(std::integral_constant<int, 0>());
+  else run(std::integral_constant<int, 1>());
+  if (!yr.has_add) {                                          // modes 0, 1 leave the scale to the end: the products are linear in it
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc[g] *= yr.sc;
+    colsum *= yr.sc;
+  }
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int n = n0 + crow32(g, lh);
+    if (n < N && k < Kin) {
+      float* p = dW + (long)n * ldw + k;
+      *p = accumulate ? *p + acc[g] : acc[g];
+    }
+  }
+  if (db && k0 == 0) {
+    colsum += __shfl_xor(colsum, 32, 64);
+    if (lh == 0 && a_ok) db[n0 + li] = accumulate ? db[n0 + li] + colsum : colsum;
+  }
+}
+
+struct FwdLayer {
+  Comp A; const float* W; const float* bias; float* C; int ldc, act;
+  int M, N, K;
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void head_fwd_kernel(const FwdLayer L) {
+  __shared__ __attribute__((aligned(16))) float smem[kWaves * 2 * 32 * LDR];
+  const int ntn = (L.N + 31) / 32;
+  const int mt = blockIdx.x / ntn, nt = blockIdx.x % ntn;
+  TileOut o = {};
+  o.C = L.C; o.ldc = L.ldc; o.bias = L.bias; o.act = L.act; o.hsplit = 0x7fffffff;
+  fwd_tile<VEC>(L.A, L.W, L.K, o, L.M, L.N, L.K, 32 * mt, 32 * nt, smem);
+}
+
+struct BwdLayer {
+  DY Y;                           // dY [M][N] of this layer (pre-activation gradient)
+  const float* W;                 // [N][Kin]
+  Comp X;                         // the layer's input [M][Kin] (composed)
+  TileOut o;                      // where dX goes
+  float* dW; float* db;
+  int M, N, Kin, accumulate;
+  int nx;                         // number of dX workgroups (0: the layer's input needs no gradient)
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void head_bwd_kernel(const BwdLayer L) {
+  __shared__ __attribute__((aligned(16))) float smem[kWaves * 2 * 32 * LDR];
+  if ((int)blockIdx.x < L.nx) {
+    const int ntk = (L.Kin + 31) / 32;
+    const int mt = blockIdx.x / ntk, kt = blockIdx.x % ntk;
+    dx_tile<VEC>(L.Y, L.W, L.Kin, L.o, L.M, L.N, L.Kin, 32 * mt, 32 * kt, smem);
+    return;
+  }
+  const int ntk = (L.Kin + 31) / 32, ntn = (L.N + 31) / 32;
+  const int tile = ((int)blockIdx.x - L.nx) * kWaves + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (tile >= ntk * ntn) return;
+  dw_tile(L.Y, L.X, L.dW, L.Kin, L.db, L.M, L.N, L.Kin, 32 * (tile / ntk), 32 * (tile % ntk), L.accumulate);
+}
+
+inline size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
+struct HeadSaved { size_t hw, hp, hs, dl, rl, total; };
+inline HeadSaved head_saved(int B, int d, int mlp, int K) {
+  HeadSaved s;
+  size_t o = 0;
+  s.hw = o; o += al64((size_t)B * d);
+  s.hp = o; o += al64((size_t)B * d);
+  s.hs = o; o += al64((size_t)B * mlp);
+  s.dl = o; o += al64((size_t)B * K);      // d loss / d logits (written by the forward when labels are given)
+  s.rl = o; o += al64((size_t)B);          // row losses
+  s.total = o;
+  return s;
+}
+struct HeadBwd { size_t dzs, dzp, dzw, total; };
+inline HeadBwd head_bwd(int B, int d, int mlp) {
+  HeadBwd s;
+  size_t o = 0;
+  s.dzs = o; o += al64((size_t)B * mlp);
+  s.dzp = o; o += al64((size_t)B * d);
+  s.dzw = o; o += al64((size_t)B * d);
+  s.total = o;
+  return s;
+}
+
+bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+int check_dims(int B, int d, int mlp, int K, int dtype) {
+  CA_CHECK_ARG(dtype == COATTN_F32, "head: unsupported dtype %d (only COATTN_F32)", dtype);
+  CA_CHECK_ARG(B > 0 && B <= (1 << 20) && d > 0 && d <= 16384 && mlp > 0 && mlp <= 16384 && K > 0 && K <= (1 << 20),
+               "head: bad B=%d d=%d mlp=%d K=%d", B, d, mlp, K);
+  const long widest = 2L * d > mlp ? (2L * d > K ? 2L * d : K) : (mlp > K ? mlp : K);
+  // every operand is addressed through a buffer descriptor with 32-bit byte offsets below 1 GB
+  CA_CHECK_ARG((long)B * widest < (1L << 28) && (long)mlp * 2 * d < (1L << 28) && (long)K * mlp < (1L << 28),
+               "head: B=%d d=%d mlp=%d K=%d is beyond the 1 GB per operand this kernel addresses", B, d, mlp, K);
+  return 0;
+}
+
+int launch_fwd(const FwdLayer& L, bool vec, hipStream_t s) {
+  const unsigned grid = (unsigned)(((L.M + 31) / 32) * ((L.N + 31) / 32));
+  if (vec) hipLaunchKernelGGL(head_fwd_kernel<true>, dim3(grid), dim3(kThreads), 0, s, L);
+  else hipLaunchKernelGGL(head_fwd_kernel<false>, dim3(grid), dim3(kThreads), 0, s, L);
+  CA_CHECK_LAUNCH("head_fwd");
+  return 0;
+}
+int launch_bwd(BwdLayer& L, bool want_dx, bool vec, hipStream_t s) {
+  const int ntk = (L.Kin + 31) / 32, ntn = (L.N + 31) / 32;
+  L.nx = want_dx ? ((L.M + 31) / 32) * ntk : 0;
+  const unsigned grid = (unsigned)(L.nx + (ntk * ntn + kWaves - 1) / kWaves);
+  if (vec) hipLaunchKernelGGL(head_bwd_kernel<true>, dim3(grid), dim3(kThreads), 0, s, L);
+  else hipLaunchKernelGGL(head_bwd_kernel<false>, dim3(grid), dim3(kThreads), 0, s, L);
+  CA_CHECK_LAUNCH("head_bwd");
+  return 0;
+}
+
+}  // namespace
+
+// cross entropy rows + mean (ce.hip)
+int launch_ce_rows(const float* logits, const void* labels, float* row_loss, float* dlogits, float* loss, int B, int K, hipStream_t s);
+
+extern "C" int coattn_head_workspace_bytes(int B, int d, int mlp, int K, int dtype, size_t* saved, size_t* ws_bwd) {
+  CA_TRY(check_dims(B, d, mlp, K, dtype));
+  if (saved) *saved = head_saved(B, d, mlp, K).total * sizeof(float);
+  if (ws_bwd) *ws_bwd = head_bwd(B, d, mlp).total * sizeof(float);
+  return 0;
+}
+
+extern "C" int coattn_head_forward(const void* const* v, const void* const* q, const coattn_head_params* p, const void* labels,
+                                   void* logits, void* loss, void* saved, int B, int d, int mlp, int K, int dtype, int flags,
+                                   void* stream) {
+  (void)flags;
+  CA_TRY(check_dims(B, d, mlp, K, dtype));
+  CA_CHECK_ARG(v && q && p && logits && saved, "head_forward: null argument");
+  for (int l = 0; l < 3; ++l) CA_CHECK_ARG(v[l] && q[l], "head_forward: v[%d] / q[%d] is null", l, l);
+  CA_CHECK_ARG(p->W_w && p->b_w && p->W_p && p->b_p && p->W_s && p->b_s && p->W_h && p->b_h, "head_forward: null parameter pointer");
+  CA_CHECK_ARG((labels != nullptr) == (loss != nullptr), "head_forward: labels and loss go together");
+  hipStream_t s = (hipStream_t)stream;
+  float* sv = (float*)saved;
+  const HeadSaved hs = head_saved(B, d, mlp, K);
+  bool vec = (d % 32) == 0 && (mlp % 32) == 0 && al16(sv);
+  for (int l = 0; l < 3; ++l) vec = vec && al16(v[l]) && al16(q[l]);
+  vec = vec && al16(p->W_w) && al16(p->W_p) && al16(p->W_s) && al16(p->W_h);
+  FwdLayer L = {};
+  L.M = B;
+  // h_w = tanh(W_w (q_w + v_w) + b_w)
+  L.A = Comp{(const float*)q[0], (const float*)v[0], nullptr, d, d, 0};
+  L.W = (const float*)p->W_w; L.bias = (const float*)p->b_w; L.C = sv + hs.hw; L.ldc = d; L.act = 1; L.N = d; L.K = d;
+  CA_TRY(launch_fwd(L, vec, s));
+  // h_p = tanh(W_p [q_p + v_p | h_w] + b_p)
+  L.A = Comp{(const float*)q[1], (const float*)v[1], sv + hs.hw, d, d, d};
+  L.W = (const float*)p->W_p; L.bias = (const float*)p->b_p; L.C = sv + hs.hp; L.N = d; L.K = 2 * d;
+  CA_TRY(launch_fwd(L, vec, s));
+  // h_s = tanh(W_s [q_s + v_s | h_p] + b_s)
+  L.A = Comp{(const float*)q[2], (const float*)v[2], sv + hs.hp, d, d, d};
+  L.W = (const float*)p->W_s; L.bias = (const float*)p->b_s; L.C = sv + hs.hs; L.ldc = mlp; L.N = mlp; L.K = 2 * d;
+  CA_TRY(launch_fwd(L, vec, s));
+  // logits = W_h h_s + b_h
+  L.A = Comp{nullptr, nullptr, sv + hs.hs, 0, 0, mlp};
+  L.W = (const float*)p->W_h; L.bias = (const float*)p->b_h; L.C = (float*)logits; L.ldc = K; L.act = 0; L.N = K; L.K = mlp;
+  CA_TRY(launch_fwd(L, vec, s));
+  if (labels) CA_TRY(launch_ce_rows((const float*)logits, labels, sv + hs.rl, sv + hs.dl, (float*)loss, B, K, s));
+  return 0;
+}
+
+extern "C" int coattn_head_backward(const void* const* v, const void* const* q, const coattn_head_params* p, const void* saved,
+                                    const void* g_loss, const void* g_logits, void* const* dv, void* const* dq,
+                                    const coattn_head_param_grads* pg, int accumulate, void* ws, int B, int d, int mlp, int K,
+                                    int dtype, int flags, void* stream) {
+  (void)flags;
+  CA_TRY(check_dims(B, d, mlp, K, dtype));
+  CA_CHECK_ARG(v && q && p && saved && pg && ws, "head_backward: null argument");
+  CA_CHECK_ARG(g_loss || g_logits, "head_backward: neither g_loss nor g_logits given");
+  for (int l = 0; l < 3; ++l) CA_CHECK_ARG(v[l] && q[l], "head_backward: v[%d] / q[%d] is null", l, l);
+  if (dv) for (int l = 0; l < 3; ++l) CA_CHECK_ARG(dv[l], "head_backward: dv[%d] is null", l);
+  CA_CHECK_ARG(!dq || dv, "head_backward: dq without dv");
+  CA_CHECK_ARG(pg->dW_w && pg->db_w && pg->dW_p && pg->db_p && pg->dW_s && pg->db_s && pg->dW_h && pg->db_h,
+               "head_backward: null parameter-gradient pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const float* sv = (const float*)saved;
+  float* w = (float*)ws;
+  const HeadSaved hs = head_saved(B, d, mlp, K);
+  const HeadBwd hb = head_bwd(B, d, mlp);
+  bool vec = (d % 32) == 0 && (mlp % 32) == 0 && al16(sv) && al16(w);
+  const bool vec_h = vec && (K % 4) == 0 && (!g_logits || al16(g_logits));    // dY rows of the last layer: K floats
+  auto D = [&](int l) { return dv ? (float*)dv[l] : nullptr; };
+  auto D2 = [&](int l) { return (dq && dq[l] != dv[l]) ? (float*)dq[l] : nullptr; };
+  BwdLayer L = {};
+  L.M = B; L.accumulate = accumulate;
+  // logits = W_h h_s + b_h:  d h_s -> d z_s = d h_s (1 - h_s^2);  dW_h = dlogits^T h_s
+  if (g_loss) L.Y = DY{sv + hs.dl, (const float*)g_loss, (const float*)g_logits, K};
+  else L.Y = DY{(const float*)g_logits, nullptr, nullptr, K};
+  L.W = (const float*)p->W_h; L.X = Comp{nullptr, nullptr, sv + hs.hs, 0, 0, mlp};
+  L.o = TileOut{}; L.o.hsplit = 0; L.o.hid = sv + hs.hs; L.o.ldhid = mlp; L.o.Ch = w + hb.dzs; L.o.ldch = mlp;
+  L.dW = (float*)pg->dW_h; L.db = (float*)pg->db_h; L.N = K; L.Kin = mlp;
+  CA_TRY(launch_bwd(L, true, vec_h, s));
+  // h_s = tanh(W_s [q_s + v_s | h_p] + b_s):  d(q_s + v_s), d z_p;  dW_s
+  L.Y = DY{w + hb.dzs, nullptr, nullptr, mlp};
+  L.W = (const float*)p->W_s; L.X = Comp{(const float*)q[2], (const float*)v[2], sv + hs.hp, d, d, d};
+  L.o = TileOut{}; L.o.C = D(2); L.o.C2 = D2(2); L.o.ldc = d; L.o.hsplit = d; L.o.hid = sv + hs.hp; L.o.ldhid = d;
+  L.o.Ch = w + hb.dzp; L.o.ldch = d;
+  L.dW = (float*)pg->dW_s; L.db = (float*)pg->db_s; L.N = mlp; L.Kin = 2 * d;
+  CA_TRY(launch_bwd(L, true, vec, s));
+  // h_p = tanh(W_p [q_p + v_p | h_w] + b_p)
+  L.Y = DY{w + hb.dzp, nullptr, nullptr, d};
+  L.W = (const float*)p->W_p; L.X = Comp{(const float*)q[1], (const float*)v[1], sv + hs.hw, d, d, d};
+  L.o = TileOut{}; L.o.C = D(1); L.o.C2 = D2(1); L.o.ldc = d; L.o.hsplit = d; L.o.hid = sv + hs.hw; L.o.ldhid = d;
+  L.o.Ch = w + hb.dzw; L.o.ldch = d;
+  L.dW = (float*)pg->dW_p; L.db = (float*)pg->db_p; L.N = d; L.Kin = 2 * d;
+  CA_TRY(launch_bwd(L, true, vec, s));
+  // h_w = tanh(W_w (q_w + v_w) + b_w)
+  L.Y = DY{w + hb.dzw, nullptr, nullptr, d};
+  L.W = (const float*)p->W_w; L.X = Comp{(const float*)q[0], (const float*)v[0], nullptr, d, d, 0};
+  L.o = TileOut{}; L.o.C = D(0); L.o.C2 = D2(0); L.o.ldc = d; L.o.hsplit = 0x7fffffff;
+  L.dW = (float*)pg->dW_w; L.db = (float*)pg->db_w; L.N = d; L.Kin = d;
+  return launch_bwd(L, dv != nullptr, vec, s);
+}

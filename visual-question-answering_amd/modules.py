@@ -11,6 +11,9 @@ its checkpoints load and its training loop drives these modules unchanged:
   QuestionCoAttentionEncoder   model.py:246-298      QuestionBaselineEncoder   model.py:108-151
   PhraseConvPool               model.py:301-334      MLPClassifier             model.py:400-434
 
+(PhraseConvPool and MLPClassifier keep the reference's submodules and keys but compute through the HIP library on
+CUDA tensors: phrase.py, head.py.)
+
 torchvision is not installed here, so the VGG11-bn topology (cfg "A" + BatchNorm) is spelled
 out; a torchvision ``vgg11_bn`` state_dict file loads into it through ``weights_path``.
 """
@@ -25,6 +28,7 @@ import torch.nn.functional as F
 from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
 
 from .coattention import ParallelCoAttention
+from .head import answer_head
 
 _VGG11_CFG = (64, "M", 128, "M", 256, 256, "M", 512, 512, "M", 512, 512, "M")
 
@@ -259,7 +263,10 @@ class QuestionBertCoAttentionEncoder(nn.Module):
 
 
 class MLPClassifier(nn.Module):
-    """Recursive word -> phrase -> sentence answer head (model.py:414-434); stock PyTorch-ROCm (hipBLASLt) modules."""
+    """Recursive word -> phrase -> sentence answer head (model.py:400-434): same constructor, submodules and
+    state_dict keys as the reference class.  CUDA fp32 tensors take the HIP head (``head.answer_head``: adds,
+    concatenations, bias + tanh folded into tile products on the exact-fp32 MFMA); CPU tensors, or
+    ``VQA_HEAD_IMPL=stock``, the stock ``nn.Linear`` modules."""
 
     def __init__(self, hidden_dim, mlp_dim, K):
         super().__init__()
@@ -268,12 +275,29 @@ class MLPClassifier(nn.Module):
         self.W_s = nn.Linear(2 * hidden_dim, mlp_dim)
         self.W_h = nn.Linear(mlp_dim, K)
 
+    def _hip(self, x):
+        x0 = x if torch.is_tensor(x) else x[0]
+        return x0.is_cuda and os.environ.get("VQA_HEAD_IMPL", "hip") != "stock"
+
+    def _params(self):
+        return (self.W_w.weight, self.W_w.bias, self.W_p.weight, self.W_p.bias, self.W_s.weight, self.W_s.bias,
+                self.W_h.weight, self.W_h.bias)
+
     def forward(self, x_img_feats, x_ques_feats):
+        if self._hip(x_img_feats):
+            return answer_head(x_img_feats, x_ques_feats, *self._params())
         (q_w, q_p, q_s), (v_w, v_p, v_s) = x_ques_feats, x_img_feats
         h_w = torch.tanh(self.W_w(q_w + v_w))
         h_p = torch.tanh(self.W_p(torch.cat([q_p + v_p, h_w], dim=1)))
         h_s = torch.tanh(self.W_s(torch.cat([q_s + v_s, h_p], dim=1)))
         return self.W_h(h_s)
+
+    def forward_loss(self, x_img_feats, x_ques_feats, labels):
+        """(logits, nn.CrossEntropyLoss()(logits, labels)) -- main.py:211 + :214 -- in one call of the HIP head."""
+        if self._hip(x_img_feats):
+            return answer_head(x_img_feats, x_ques_feats, *self._params(), labels=labels)
+        logits = self.forward(x_img_feats, x_ques_feats)
+        return logits, F.cross_entropy(logits.float(), labels)
 
 
 class HierarchicalCoAttentionNet(nn.Module):
@@ -297,14 +321,17 @@ class HierarchicalCoAttentionNet(nn.Module):
     def forward(self, x_img, x_ques, x_ques_lens):
         return self.forward_features(self.image_encoder(x_img), x_ques, x_ques_lens)
 
-    def forward_features(self, x_img_features, x_ques, x_ques_lens):
+    def forward_features(self, x_img_features, x_ques, x_ques_lens, labels=None):
         """The forward pass from already-encoded image features [B,N,d] (model.py:171-187 minus the
         image encoder call): lets a frozen encoder run ahead on its own stream (train.Trainer).
-        `x_img_features` may be a zero-argument callable returning the features."""
+        `x_img_features` may be a zero-argument callable returning the features.  With `labels` (int64 [B]) the
+        mean cross entropy of main.py:214 comes out of the answer head's own call: returns (logits, loss)."""
         x_ques_features = list(self.question_encoder(x_ques, x_ques_lens))
         if callable(x_img_features):            # resolved only now: the question side is queued first
             x_img_features = x_img_features()
         x_img_attn, x_ques_attn = self.co_attention(x_img_features, x_ques_features)
+        if labels is not None:
+            return self.mlp_classify.forward_loss(x_img_attn, x_ques_attn, labels)
         return self.mlp_classify(x_img_attn, x_ques_attn)
 
 

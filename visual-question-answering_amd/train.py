@@ -284,13 +284,14 @@ class Trainer:
                 self._resident = image
                 if next_image is not None:
                     self._ahead = self._queue_encoder(next_image, next_ready)
-                # the question side is queued before the current stream waits for the image features
-                logits = self.model.forward_features((lambda: self._claim(mine)) if mine is not None else inline,
-                                                     question, ques_len)
+                # the question side is queued before the current stream waits for the image features; the loss comes
+                # out of the answer head's own call (main.py:211 + :214 in one)
+                logits, loss = self.model.forward_features((lambda: self._claim(mine)) if mine is not None else inline,
+                                                           question, ques_len, labels=label)
         else:
             with self._autocast():
                 logits = self.model(image, question, ques_len)
-        loss = self.criterion(logits.float(), label)
+            loss = self.criterion(logits.float(), label)
         self.optimizer.zero_grad()
         if self.reducer is not None:
             self.reducer.prepare()

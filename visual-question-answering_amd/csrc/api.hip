@@ -220,7 +220,8 @@ int general_projections(const Ctx& c, const float* V, const float* const* Q, con
   for (int l = 0; l < c.L; ++l) wq.a_ptrs[l] = Q[l];
   wq.a_sm = c.d; wq.Wf = wimg + wsplit_bytes(c.d, c.d); wq.C = sv + sp.Pq; wq.c_sz = (long)BTd; wq.c_sm = c.d;
   wq.bias_n = (const float*)p->b_q; wq.out_scale = c.pscale; wq.M = c.B * c.T; wq.N = c.d; wq.K = c.d; wq.batch = c.L;
-  const bool w_ok = !c.bf16_proj && gemm_w_enabled();
+  wv.bf16 = wq.bf16 = c.bf16_proj ? 1 : 0;          // reduced precision: the same kernels, hi pieces only, one MFMA per product
+  const bool w_ok = gemm_w_enabled();
   bool v_w = false;
   if (w_ok && c.vl.sD == 1 && c.vl.sB == (long)c.N * c.vl.sN && c.vl.sN < (1L << 24)) {
     v_w = gemm_w_supported(wv) != 0;                 // location-major rows, samples abutting

@@ -369,16 +369,18 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   TnGemm tnv = {};
   tnv.A = dPv; tnv.a_ld = d; tnv.B = V; tnv.b_ld = (int)vl.sN; tnv.C = part; tnv.M = d; tnv.N = d; tnv.K = B * N; tnv.levels = 1;
   bool tn_v = false;
-  if (wgemm && !bf16_proj && lm && vl.sB == (long)N * vl.sN && vl.sN < (1L << 24)) {
+  tnv.bf16 = bf16_proj;
+  if (wgemm && lm && vl.sB == (long)N * vl.sN && vl.sN < (1L << 24)) {
     tn_v = gemm_tn_supported(tnv) != 0;              // location-major rows, samples abutting
-  } else if (wgemm && !bf16_proj && !lm && vl.sD < (1L << 24)) {
+  } else if (wgemm && !lm && vl.sD < (1L << 24)) {
     tnv.b_ld = (int)vl.sD; tnv.b_kdiv = N; tnv.b_sdiv = vl.sB;          // channel-major, read in place
     tn_v = gemm_tn_supported(tnv) != 0;
   }
   TnGemm tnq = {};
   tnq.A = ws + wo.dPq; tnq.a_sl = (long)BTd; tnq.a_ld = d; tnq.b_ld = d; tnq.M = d; tnq.N = d; tnq.K = B * T; tnq.levels = L;
   for (int l = 0; l < L; ++l) tnq.b_ptrs[l] = Q[l];
-  const bool tn_q = wgemm && !bf16_proj && gemm_tn_supported(tnq);       // levels as extra split-K parts (gemm_tn.hip)
+  tnq.bf16 = bf16_proj;
+  const bool tn_q = wgemm && gemm_tn_supported(tnq);       // levels as extra split-K parts (gemm_tn.hip)
   const bool dq32 = lm || (N % 4) == 0;              // the bf16 dA V kernel takes both layouts (channel-major: aligned rows)
   WGemm wdq = {};                                    // dQ_l = dP_q,l W_q against the W_q image the forward left in `saved`
   wdq.A = ws + wo.dPq; wdq.a_sz = (long)BTd; wdq.a_sm = d; wdq.Wf = saved + so.wqT;
@@ -387,7 +389,8 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   // (exactly the forward's test for writing that image, api.hip general_projections: same shape, and its A rows were Q_l)
   bool q_al = true;
   for (int l = 0; l < L; ++l) q_al = q_al && (((uintptr_t)Q[l]) & 15) == 0;
-  const bool wdq_ok = !bf16_proj && wgemm && q_al && gemm_w_supported(wdq);
+  wdq.bf16 = bf16_proj;
+  const bool wdq_ok = wgemm && q_al && gemm_w_supported(wdq);
   const bool combine = dq32 && wdq_ok && tn_v && tn_q;
   // 3. small parameter gradients from the per-(sample, level) partials (dw_v, db_v, db_q, dw_q, and dc_v, dc_q as
   //    whole-array sums): a few short workgroups -- riding along in the weight-gradient launch of step 5 when that

@@ -138,6 +138,7 @@ struct WGemm {
   float* C; float* c_ptrs[8]; long c_sz; int c_sm;                   // C[z][m][n], n contiguous
   const float* bias_n; float out_scale;
   int M, N, K, batch;
+  int bf16;                                                          // 1: operands rounded to bf16, ONE MFMA per product (COATTN_FLAG_BF16_PROJ)
 };
 size_t wsplit_bytes(int N, int K);
 int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s);
@@ -155,6 +156,7 @@ struct TnGemm {
   int M, N, K, levels;
   int mask_blk; unsigned tile_mask;                                  // mask_blk > 0: tile (mt, nt) is computed only if bit
                                                                      // (mt / mask_blk) * 3 + nt / mask_blk of tile_mask is set
+  int bf16;                                                          // 1: operands rounded to bf16, ONE MFMA per product
 };
 int gemm_tn_supported(const TnGemm& d);
 int gemm_tn_plan(const TnGemm& d, int max_parts, int* ksplit, int* S);   // returns the number of parts

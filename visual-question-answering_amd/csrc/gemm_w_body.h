@@ -28,7 +28,10 @@ constexpr int LDT = BM + 32;                   // AM: [k][row] image row stride 
 // AM = false: A rows contiguous along k ([row][k] images, one ds_read_b128 per fragment).
 // AM = true : A contiguous along m -- channel-major image features [B, d, N] read in place (model.py:215-217),
 //             row m = (sample, location) split by a_mdiv: [k][row] images, fragments through ds_read_b64_tr_b16.
-template <bool AM>
+// P1 = true : reduced-precision mode (COATTN_FLAG_BF16_PROJ, the apex-O1 analogue): operands rounded to bf16 (the hi piece
+//             alone -- of A while it is staged, of the weight from its image), ONE MFMA per product; the schedule keeps
+//             its slots, the pieces that do not exist are neither computed, written, read nor multiplied.
+template <bool AM, bool P1 = false>
 __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short* const smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
@@ -120,10 +123,12 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
   auto load_a = [&](int i, int s) { raw[i] = buf_load4(rs_a, a_voff[i], (s + s0) * a_kstep); };
   auto load_b = [&](int ring, int k, int half) {
     const int j = k / 3, q = k % 3;
+    if (P1 && q != 0) return;
     bq[ring][j][q] = __builtin_bit_cast(bf16x8, buf_load4(rs_w, w_voff[j] + q * kFragBytes, (half + 2 * s0) * kChunkBytes));
   };
   auto read_a = [&](const short* img, int h, int k) {
     const int q = RQ[k >> 1], i = k & 1;
+    if (P1 && q != 0) return;
     if (AM) {
       const short* ptr = img + q * IMG + a_rd + i * 32 + 16 * h * LDT;
       const bf16x4 lo = lds_tr16(ptr), hi = lds_tr16(ptr + 4 * LDT);
@@ -134,6 +139,10 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
   };
   // split of raw[i], pair e (0 | 1), in three stages of 5, 5 and 1 VALU instructions
   auto stage = [&](int i, int e, int st) {
+    if (P1) {
+      if (st == 0) ph[e] = cvt_pk_bf16(raw[i][2 * e], raw[i][2 * e + 1]);
+      return;
+    }
 #ifdef GEMMW_NOSPLIT
     if (st == 0) ph[e] = pm[e] = pl[e] = cvt_pk_bf16(raw[i][2 * e], raw[i][2 * e + 1]);
 #else
@@ -151,6 +160,7 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
 #endif
   };
   auto write_a = [&](short* img, int i, int q) {
+    if (P1 && q != 0) return;
     const u32x2 v = q == 0 ? u32x2{ph[0], ph[1]} : (q == 1 ? u32x2{pm[0], pm[1]} : u32x2{pl[0], pl[1]});
     *reinterpret_cast<u32x2*>(&img[q * IMG + a_lds[i]]) = v;
   };
@@ -161,7 +171,7 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
     for (int n = 0; n < 24; ++n) {
       const int t = n >> 2, i = (n >> 1) & 1, j = n & 1;
 #ifndef GEMMW_NOMFMA
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[HH][PA[t]][i], bq[BU][j][PB[t]], acc[i][j], 0, 0, 0);
+      if (!P1 || t == 5) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[HH][PA[t]][i], bq[BU][j][PB[t]], acc[i][j], 0, 0, 0);
 #else
       if (t == 0) acc[i][j][0] += __builtin_bit_cast(float, (int)af[HH][PA[t]][i][0] ^ (int)bq[BU][j][PB[t]][0]);
 #endif

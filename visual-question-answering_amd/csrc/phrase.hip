@@ -273,7 +273,8 @@ extern "C" int coattn_phrase_forward(const void* X, const coattn_phrase_params* 
   wg.A = reinterpret_cast<const float*>(w + pl.xcat); wg.a_sm = 3 * E; wg.Wf = w + pl.wimg;
   wg.C = reinterpret_cast<float*>(w + pl.z); wg.c_sm = 3 * E; wg.bias_n = reinterpret_cast<const float*>(w + pl.bcat);
   wg.M = B * T; wg.N = 3 * E; wg.K = 3 * E; wg.batch = 1;
-  const bool hand = !bf16 && hand_gemms() && E % 128 == 0 && gemm_w_supported(wg);
+  wg.bf16 = bf16 ? 1 : 0;                                // reduced precision: the same kernels, one MFMA per product
+  const bool hand = hand_gemms() && E % 128 == 0 && gemm_w_supported(wg);
   CA_TRY(build_operands((const float*)X, p, w, pl, B, T, E, s, hand ? 0 : -1));
   coattn_gemm_desc g = {};
   g.A = w + pl.xcat; g.B = w + pl.wcat; g.C = w + pl.z; g.bias_n = w + pl.bcat;
@@ -319,7 +320,8 @@ extern "C" int coattn_phrase_backward(const void* X, const coattn_phrase_params*
   WGemm wdx = {};                                        // dXcat = dZ Wcat (as the forward: Wcat split the other way round)
   wdx.A = dZ; wdx.a_sm = 3 * E; wdx.Wf = w + pl.wimg; wdx.C = reinterpret_cast<float*>(w + pl.xcat); wdx.c_sm = 3 * E;
   wdx.M = (int)bt; wdx.N = 3 * E; wdx.K = 3 * E; wdx.batch = 1;
-  const bool hand_dx = dX && !bf16 && hand_gemms() && E % 128 == 0 && gemm_w_supported(wdx);
+  wdx.bf16 = bf16 ? 1 : 0;
+  const bool hand_dx = dX && hand_gemms() && E % 128 == 0 && gemm_w_supported(wdx);
   CA_TRY(build_operands((const float*)X, p, w, pl, B, T, E, s, hand_dx ? 1 : -1));
   hipLaunchKernelGGL(phrase_dz_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)g_out,
                      (const float*)out, (const unsigned char*)saved, dZ, n);
@@ -338,7 +340,8 @@ extern "C" int coattn_phrase_backward(const void* X, const coattn_phrase_params*
   tn.C = reinterpret_cast<float*>(w + pl.part); tn.M = 3 * E; tn.N = 3 * E; tn.K = (int)bt; tn.levels = 1;
   tn.mask_blk = E / 128;                             // rows: n-gram (uni, bi, tri); columns: tap x[t-1], x[t], x[t+1]
   tn.tile_mask = (1u << 1) | (3u << 3) | (7u << 6);
-  const bool tn_ok = !bf16 && hand_gemms() && E % 128 == 0 && gemm_tn_supported(tn);
+  tn.bf16 = bf16 ? 1 : 0;
+  const bool tn_ok = hand_gemms() && E % 128 == 0 && gemm_tn_supported(tn);
   if (tn_ok) {
     const int live = 6 * (E / 128) * (E / 128);      // tiles that exist
     int S = (512 + live - 1) / live;

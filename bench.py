@@ -108,7 +108,7 @@ def timed_steps(trainer, batch, steps, warmup, sync):
     return time.perf_counter() - t0
 
 
-def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20):
+def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20, bf16=False):
     """Isolated hot path (co-attention + MLPClassifier + CE, fwd+bwd) on resident features.
     layout: "lm" = x_img contiguous [B,N,d] (what the channels_last encoder of the train step hands over),
     "cm" = the permuted view of a channel-major [B,d,N] buffer (the reference's NCHW encoder, model.py:215-217)."""
@@ -116,6 +116,7 @@ def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20):
     from vqa_amd.modules import MLPClassifier
     torch.manual_seed(0)
     co = vqa_amd.ParallelCoAttention(d).to(device)
+    co.bf16_projections = bf16                       # the reduced-precision mode of --opt_lvl >= 1 (config 4)
     mlp = MLPClassifier(d, 1024, K + 1).to(device)
     V, Qs = synth_features(B, N, T, d, device)
     x_img = V.permute(0, 2, 1)
@@ -148,13 +149,15 @@ def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20):
             co.w_q.bias)
     gv = torch.ones(3, B, d, device=device)
     gq = torch.ones(3, B, d, device=device)
+    from vqa_amd import _lib
+    impl = _lib.FLAG_BF16_PROJ if bf16 else 0
 
     leaves = list(args) + list(Qs)
 
     def fb():
         for p in leaves:                           # optimizer.zero_grad() of the train loop (set_to_none): without it
             p.grad = None                          # autograd adds each new gradient onto the old one (11 add kernels)
-        v, q = vqa_amd.coattention(x_img, Qs, *args)
+        v, q = vqa_amd.coattention(x_img, Qs, *args, impl=impl)
         torch.autograd.backward([v, q], [gv, gq])
 
     for _ in range(2 * iters):                     # clock warm-up (see roofline_leg): ~40 ms of back-to-back calls
@@ -169,7 +172,7 @@ def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20):
     fwd = bwd = 0.0
     for it in range(iters + 3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        v, q = vqa_amd.coattention(x_img, Qs, *args)
+        v, q = vqa_amd.coattention(x_img, Qs, *args, impl=impl)
         for p in leaves:
             p.grad = None
         torch.cuda.synchronize(); t1 = time.perf_counter()
@@ -178,7 +181,8 @@ def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20):
         if it >= 3:
             fwd += t1 - t0; bwd += t3 - t1
     flop = 3.0 * B * (2 * N * d * d + 3 * 2 * T * d * d + 3 * (3 * 2 * T * N * d + 4 * (N + T) * d))
-    return {"N": N, "layout": layout, "pairs_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3),
+    return {"N": N, "d": d, "K": K, "layout": layout, "mode": "bf16 projections (one MFMA per product)" if bf16 else "fp32",
+            "pairs_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3),
             "coattn_fwd_bwd_ms": round(t_dev * 1e3, 4), "coattn_fwd_bwd_tflops": round(flop / t_dev / 1e12, 2),
             "coattn_fwd_wall_ms": round(fwd / iters * 1e3, 4), "coattn_bwd_wall_ms": round(bwd / iters * 1e3, 4),
             "coattn_fwd_bwd_wall_tflops": round(flop / ((fwd + bwd) / iters) / 1e12, 2)}
@@ -249,7 +253,7 @@ def roofline_leg(device, B=160, N=196, T=26, d=512, L=3, iters=100, layout="lm")
             "algorithmic_bytes": alg}
 
 
-def projection_leg(device, B=160, N=196, d=512, iters=50):
+def projection_leg(device, B=160, N=196, d=512, iters=50, bf16=False):
     """The dominant MFMA-bound kernel of the path: P_v = V W_v^T + b_v (model.py:380/384, once per sample) from
     location-major features, through coattn_linear_forward -- the weight split once into MFMA-fragment order, then
     gemm_w_kernel (the pair coattn_forward launches; the timed region re-uses the weight image, so it is the GEMM
@@ -269,13 +273,15 @@ def projection_leg(device, B=160, N=196, d=512, iters=50):
     wimg = torch.empty(lib.coattn_linear_workspace_bytes(d, d) // 4, device=device)
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+    mode = _lib.FLAG_BF16_PROJ if bf16 else 0
+
     def call(flags):
         return lib.coattn_linear_forward(V.data_ptr(), d, W.data_ptr(), bias.data_ptr(), Pv.data_ptr(), wimg.data_ptr(),
-                                         B * N, d, d, 0.0, flags, stream)
+                                         B * N, d, d, 0.0, flags | mode, stream)
 
     _lib.check(call(0), "coattn_linear_forward")
-    ref = V[:256].double() @ W.double().t()
-    if not torch.allclose(Pv[:256].double(), ref, rtol=1e-5, atol=1e-5):
+    ref = (V[:256].bfloat16().double() @ W.bfloat16().double().t()) if bf16 else V[:256].double() @ W.double().t()
+    if not torch.allclose(Pv[:256].double(), ref, rtol=1e-5, atol=1e-4 if bf16 else 1e-5):
         raise SystemExit("bench.py: projection leg: coattn_linear_forward disagrees with the fp64 product")
     for _ in range(3 * iters):                     # clock warm-up, as in roofline_leg
         call(1)
@@ -294,18 +300,20 @@ def projection_leg(device, B=160, N=196, d=512, iters=50):
     t_with_split = window(0)
     flop = 2.0 * B * N * d * d
     ach = flop / t / 1e12
-    peak = 2500.0 / 6.0                            # the bound that applies: dense bf16 MFMA peak / six products per fp32 product
+    # the bound that applies: dense bf16 MFMA peak -- divided by the six products per fp32 product in fp32 mode
+    peak = 2500.0 if bf16 else 2500.0 / 6.0
     return {"bound": "mfma", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            "peak_note": "fp32-equivalent: dense bf16 MFMA peak 2500 TFLOP/s / 6 partial products per fp32 product",
+            "peak_note": ("dense bf16 MFMA peak (operands rounded to bf16, one MFMA per product, fp32 accumulation)" if bf16 else
+                          "fp32-equivalent: dense bf16 MFMA peak 2500 TFLOP/s / 6 partial products per fp32 product"),
             "frac_of_fp32_matrix_peak": round(ach / 157.3, 4),
-            "traffic": None, "kernel": "P_v projection GEMM (gemm_w_kernel: pre-split weight, 3-way bf16 split)",
+            "traffic": None, "kernel": "P_v projection GEMM (gemm_w_kernel: pre-split weight, %s)" % ("bf16 hi pieces only" if bf16 else "3-way bf16 split"),
             "shape": {"M": B * N, "N": d, "K": d}, "avg_launch_us": round(t * 1e6, 2),
             "windows_us": [round(x * 1e6, 2) for x in ts], "calls_per_window": iters, "algorithmic_flops": flop,
-            "bf16_mfma_frac": round(6.0 * ach / 2500.0, 4),
+            "bf16_mfma_frac": round((1.0 if bf16 else 6.0) * ach / 2500.0, 4),
             "weight_split_us": round(max(t_with_split - t, 0.0) * 1e6, 2)}
 
 
-def weight_grad_leg(device, B=160, N=196, d=512, iters=50):
+def weight_grad_leg(device, B=160, N=196, d=512, iters=50, bf16=False):
     """The other MFMA-bound kernel of the path: dW_v = dP_v^T V (the weight gradient of the P_v projection, autograd of
     model.py:380/384) through coattn_linear_weight_grad -- split-K parts on gemm_tn_kernel + the deterministic
     reduce, the pair coattn_backward uses (there the launch also carries dW_q, the dQ projection and the small
@@ -322,11 +330,11 @@ def weight_grad_leg(device, B=160, N=196, d=512, iters=50):
 
     def call():
         return lib.coattn_linear_weight_grad(dP.data_ptr(), d, V.data_ptr(), d, dW.data_ptr(), ws.data_ptr(), B * N, d, d,
-                                             0, stream)
+                                             _lib.FLAG_BF16_PROJ if bf16 else 0, stream)
 
     _lib.check(call(), "coattn_linear_weight_grad")
-    ref = dP[:, :64].double().t() @ V.double()
-    if not torch.allclose(dW[:64].double(), ref, rtol=1e-5, atol=1e-4):
+    ref = (dP[:, :64].bfloat16().double().t() @ V.bfloat16().double()) if bf16 else dP[:, :64].double().t() @ V.double()
+    if not torch.allclose(dW[:64].double(), ref, rtol=1e-5, atol=1e-3 if bf16 else 1e-4):
         raise SystemExit("bench.py: weight-gradient leg: coattn_linear_weight_grad disagrees with the fp64 product")
     for _ in range(3 * iters):
         call()
@@ -342,9 +350,10 @@ def weight_grad_leg(device, B=160, N=196, d=512, iters=50):
     t = sorted(ts)[1]
     flop = 2.0 * B * N * d * d
     ach = flop / t / 1e12
-    peak = 2500.0 / 6.0
+    peak = 2500.0 if bf16 else 2500.0 / 6.0
     return {"bound": "mfma", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-            "peak_note": "fp32-equivalent: dense bf16 MFMA peak 2500 TFLOP/s / 6 partial products per fp32 product",
+            "peak_note": ("dense bf16 MFMA peak (operands rounded to bf16, one MFMA per product)" if bf16 else
+                          "fp32-equivalent: dense bf16 MFMA peak 2500 TFLOP/s / 6 partial products per fp32 product"),
             "traffic": None, "kernel": "dW_v weight-gradient GEMM (gemm_tn_kernel, 32 split-K parts) + reduce_partials4_kernel",
             "shape": {"M": d, "N": d, "K": B * N}, "avg_launch_us": round(t * 1e6, 2),
             "windows_us": [round(x * 1e6, 2) for x in ts], "calls_per_window": iters, "algorithmic_flops": flop}
@@ -472,12 +481,22 @@ def main():
     from vqa_amd import train as T
     if args.only:
         dev = torch.device("cuda", 0)
-        res = ({"roofline": roofline_leg(dev), "roofline_channel_major": roofline_leg(dev, layout="cm"),
-                "roofline_at_step_shape": roofline_leg(dev, N=49),
-                "roofline_at_step_shape_channel_major": roofline_leg(dev, N=49, layout="cm"),
-                "roofline_projection": projection_leg(dev), "roofline_weight_grad": weight_grad_leg(dev)}
-               if args.only == "roofline"
-               else [hot_path_leg(dev, n, lay) for n in (196, 49) for lay in ("lm", "cm")])
+        n_step = (args.image_size // 32) ** 2
+        if args.model == "attention_resnet":             # config 4's shapes
+            bf = args.opt_lvl > 0
+            res = ({"roofline": roofline_leg(dev, B=args.batch, N=n_step, T=args.seq_len, d=2048),
+                    "roofline_projection": projection_leg(dev, B=args.batch, N=n_step, d=2048, bf16=bf),
+                    "roofline_weight_grad": weight_grad_leg(dev, B=args.batch, N=n_step, d=2048, bf16=bf)}
+                   if args.only == "roofline"
+                   else [hot_path_leg(dev, n_step, lay, B=args.batch, T=args.seq_len, d=2048, K=args.num_cls, bf16=bf)
+                         for lay in ("lm", "cm")])
+        else:
+            res = ({"roofline": roofline_leg(dev), "roofline_channel_major": roofline_leg(dev, layout="cm"),
+                    "roofline_at_step_shape": roofline_leg(dev, N=49),
+                    "roofline_at_step_shape_channel_major": roofline_leg(dev, N=49, layout="cm"),
+                    "roofline_projection": projection_leg(dev), "roofline_weight_grad": weight_grad_leg(dev)}
+                   if args.only == "roofline"
+                   else [hot_path_leg(dev, n, lay) for n in (196, 49) for lay in ("lm", "cm")])
         print(json.dumps(res))
         return
     torch.set_num_threads(max(1, min(4, host_cores())))   # the step is GPU work; do not oversubscribe host cores per rank
@@ -511,7 +530,7 @@ def main():
         value = world * args.batch * args.steps / dt
         n_grid = (args.image_size // 32) ** 2
         out = {
-            "metric": "QA-pairs/sec (train step, attention model, K=1000)", "value": round(value, 2),
+            "metric": "QA-pairs/sec (train step, attention model, K=%d)" % args.num_cls, "value": round(value, 2),
             "unit": "QA-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.opt_lvl == 0 else "bf16", "data": "synthetic",
@@ -538,18 +557,29 @@ def main():
     if rank == 0 and not args.no_extras:
         del trainer, model, batch
         torch.cuda.empty_cache()
-        # per-GPU kernel, the same on every rank; image features location-major [B,N,d], as the channels_last
-        # encoder of the timed step hands them over (no copy in between)
-        out["roofline"] = roofline_leg(device)
-        # the same kernel on the reference's own layout (NCHW encoder -> channel-major [B,d,N] behind a permuted view)
-        out["roofline_channel_major"] = roofline_leg(device, layout="cm")
-        # the same kernel at the timed step's own grid (224x224 -> 7x7 = 49 locations)
-        out["roofline_at_step_shape"] = roofline_leg(device, B=args.batch, N=(args.image_size // 32) ** 2,
-                                                     T=args.seq_len)
-        out["roofline_projection"] = projection_leg(device)
-        out["roofline_weight_grad"] = weight_grad_leg(device)
-        if world == 1:
-            out["hot_path"] = [hot_path_leg(device, n, lay) for n in (196, 49) for lay in ("lm", "cm")]
+        n_step = (args.image_size // 32) ** 2
+        if args.model == "attention_resnet":
+            # BASELINE config 4: 7x7x2048 grid, reduced precision (operands of the projections rounded to bf16, one MFMA
+            # per product); every leg at that shape
+            d4, bf = 2048, args.opt_lvl > 0
+            out["roofline"] = roofline_leg(device, B=args.batch, N=n_step, T=args.seq_len, d=d4)
+            out["roofline_projection"] = projection_leg(device, B=args.batch, N=n_step, d=d4, bf16=bf)
+            out["roofline_weight_grad"] = weight_grad_leg(device, B=args.batch, N=n_step, d=d4, bf16=bf)
+            if world == 1:
+                out["hot_path"] = [hot_path_leg(device, n_step, lay, B=args.batch, T=args.seq_len, d=d4, K=args.num_cls, bf16=bf)
+                                   for lay in ("lm", "cm")]
+        else:
+            # per-GPU kernel, the same on every rank; image features location-major [B,N,d], as the channels_last
+            # encoder of the timed step hands them over (no copy in between)
+            out["roofline"] = roofline_leg(device)
+            # the same kernel on the reference's own layout (NCHW encoder -> channel-major [B,d,N] behind a permuted view)
+            out["roofline_channel_major"] = roofline_leg(device, layout="cm")
+            # the same kernel at the timed step's own grid (224x224 -> 7x7 = 49 locations)
+            out["roofline_at_step_shape"] = roofline_leg(device, B=args.batch, N=n_step, T=args.seq_len)
+            out["roofline_projection"] = projection_leg(device)
+            out["roofline_weight_grad"] = weight_grad_leg(device)
+            if world == 1:
+                out["hot_path"] = [hot_path_leg(device, n, lay) for n in (196, 49) for lay in ("lm", "cm")]
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg(args)

@@ -54,7 +54,8 @@ extern "C" {
  * contractions that are their gradients (dQ += dP_q W_q, dV += dP_v W_v, dW_v, dW_q) on the bf16 MFMA
  * (v_mfma_f32_32x32x16_bf16): operands rounded to bf16 while staged, fp32 accumulation, fp32
  * results -- the reduced-precision mode that the reference reaches through apex AMP O1 (main.py:185).
- * Everything else stays exact fp32.  Parity then holds to bf16 tolerance (~1e-2), not 1e-4.
+ * Everything else stays exact fp32.  Parity then holds to bf16 tolerance (~1e-2), not 1e-4.  The projections run on
+ * the same hand-scheduled kernels as in fp32 mode (gemm_w.hip, gemm_tn.hip) with the hi pieces of the operands alone.
  * The same bit selects the bf16 MFMA for the three contractions of coattn_phrase_forward/backward. */
 #define COATTN_FLAG_BF16_PROJ 4
 typedef struct coattn_params {
@@ -225,7 +226,7 @@ int coattn_gemm_f32(const coattn_gemm_desc* g, void* stream);
  * The weight is split once into its three bf16 pieces in MFMA-fragment order (`wimg`, device scratch of
  * coattn_linear_workspace_bytes(N, K) bytes) and the GEMM reads the fragments in place (gemm_w.hip) -- the
  * kernel pair coattn_forward uses for both projections.  flags bit 0: `wimg` already holds the image of this
- * W (skip the split).  K % 32 == 0, M >= 128, x 16-byte aligned with ld_x % 4 == 0; other shapes: error -1
+ * W (skip the split); flags bit 2 (COATTN_FLAG_BF16_PROJ): operands rounded to bf16, one MFMA per product.  K % 32 == 0, M >= 128, x 16-byte aligned with ld_x % 4 == 0; other shapes: error -1
  * (use coattn_gemm_f32).  bias may be NULL; out_scale 0 means 1. */
 size_t coattn_linear_workspace_bytes(int N, int K);
 int coattn_linear_forward(const void* x, int64_t ld_x, const void* W, const void* bias, void* y, void* wimg,
@@ -235,7 +236,8 @@ int coattn_linear_forward(const void* x, int64_t ld_x, const void* W, const void
  * (autograd of the W_v / W_q projections, main.py:219-220): split-K parts on the hand-scheduled A^T B kernel
  * (gemm_tn.hip) + a deterministic reduce -- the kernel pair coattn_backward uses for dW_v and dW_q.
  * dY rows ld_dy floats apart, X rows ld_x; `ws`: device scratch of coattn_linear_wgrad_workspace_bytes bytes.
- * n_out, n_in multiples of 128, M >= 16, 16-byte aligned operands with ld % 4 == 0; other shapes: error -1. */
+ * n_out, n_in multiples of 128, M >= 16, 16-byte aligned operands with ld % 4 == 0; other shapes: error -1.
+ * accumulate: bit 0 adds onto dW; bit 2 (COATTN_FLAG_BF16_PROJ) selects the reduced-precision mode. */
 size_t coattn_linear_wgrad_workspace_bytes(int n_out, int n_in);
 int coattn_linear_weight_grad(const void* dy, int64_t ld_dy, const void* x, int64_t ld_x, void* dW, void* ws, int M,
                               int n_out, int n_in, int accumulate, void* stream);

@@ -16,7 +16,7 @@ void coattn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int coattn_version(void) { return 310; }   // 0.3.1: coattn_linear_forward; `saved` carries the W_q image (0.3.0: V strides)
+extern "C" int coattn_version(void) { return 400; }   // 0.4.0: coattn_head_forward/backward; the reduced-precision mode on the hand-scheduled GEMMs
 extern "C" const char* coattn_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------------------------------
@@ -102,6 +102,7 @@ extern "C" int coattn_linear_forward(const void* x, int64_t ld_x, const void* W,
   WGemm g = {};
   g.A = (const float*)x; g.a_sm = (int)ld_x; g.Wf = wimg; g.C = (float*)y; g.c_sm = N; g.bias_n = (const float*)bias;
   g.out_scale = out_scale; g.M = M; g.N = N; g.K = K; g.batch = 1;
+  g.bf16 = (flags & COATTN_FLAG_BF16_PROJ) ? 1 : 0;
   CA_CHECK_ARG(gemm_w_supported(g), "linear: shape M=%d N=%d K=%d ld=%ld not supported (see coattn.h)", M, N, K, (long)ld_x);
   if (!(flags & 1)) {
     const WSplit job{(const float*)W, wimg, N, K, 0, K};
@@ -121,6 +122,8 @@ extern "C" int coattn_linear_weight_grad(const void* dy, int64_t ld_dy, const vo
   TnGemm g = {};
   g.A = (const float*)dy; g.a_ld = (int)ld_dy; g.B = (const float*)x; g.b_ld = (int)ld_x; g.C = (float*)ws;
   g.M = n_out; g.N = n_in; g.K = M; g.levels = 1;
+  g.bf16 = (accumulate & COATTN_FLAG_BF16_PROJ) ? 1 : 0;
+  accumulate &= 1;
   CA_CHECK_ARG(gemm_tn_supported(g), "linear weight grad: shape M=%d n_out=%d n_in=%d not supported (see coattn.h)", M, n_out, n_in);
   int ks, S;
   const int parts = gemm_tn_plan(g, 32, &ks, &S);

@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline / hot_path legs")
     ap.add_argument("--only", type=str, default="", help="developer switch: run only 'roofline' or 'hot' legs")
-    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--cpu-batch", type=int, default=0, help="batch of the CPU baseline leg (0: the GPU step's own batch)")
     ap.add_argument("--no-runahead", dest="runahead", action="store_false",
                     help="run the frozen image encoder in series with the rest of the step (default: one step "
                          "ahead on its own HIP stream)")
@@ -388,7 +388,8 @@ def cpu_baseline_leg(args):
     torch.manual_seed(0)
     qp = dict(vocab_size=args.vocab, word_emb_dim=512, hidden_dim=512)
     net = NO.OracleHierarchicalCoAttentionNet(qp, dict(is_trainable=False, weights_path=None), K=args.num_cls + 1)
-    b = T.synthetic_batch(args.cpu_batch, (args.image_size,) * 2, args.seq_len, args.vocab, args.num_cls + 1, seed=1234)
+    cpu_batch = args.cpu_batch or args.batch             # the same inputs as the GPU step
+    b = T.synthetic_batch(cpu_batch, (args.image_size,) * 2, args.seq_len, args.vocab, args.num_cls + 1, seed=1234)
     image, question, label, lens = T.sort_batch(b["image"], b["question"], b["label"], b["ques_len"])
     batch = (image, question, lens, label)
     NO.train_steps(net, [batch] * CPU_WARM, lr=1e-4)
@@ -398,11 +399,11 @@ def cpu_baseline_leg(args):
         NO.train_steps(net, [batch], lr=1e-4)
         ts.append(time.perf_counter() - t0)
     dt = sorted(ts)[len(ts) // 2]
-    return {"value": round(args.cpu_batch / dt, 2), "unit": "QA-pairs/s", "cores": cores, "kind": "port",
+    return {"value": round(cpu_batch / dt, 2), "unit": "QA-pairs/s", "cores": cores, "kind": "port", "batch": cpu_batch,
             "cpu": cpu_model_string(),
             "sample": "oracle port of the same train step (reference op sequence incl. its 6x W_v(V) "
                       "re-evaluation), batch %d, %dx%d images, %d warm-up + %d timed steps (median), torch CPU fp32, "
-                      "%d threads" % (args.cpu_batch, args.image_size, args.image_size, CPU_WARM, CPU_TIMED, cores)}
+                      "%d threads" % (cpu_batch, args.image_size, args.image_size, CPU_WARM, CPU_TIMED, cores)}
 
 
 def cpu_hot_path_leg(N, B=160, T=26, d=512, K=1000):
@@ -447,21 +448,51 @@ def self_launch(args) -> int:
     import socket
     import subprocess
     n_dev = torch.cuda.device_count()                # does not initialise the GPU
-    if n_dev < args.gpus:
+    if n_dev < args.gpus and os.environ.get("VQA_BENCH_OVERSUBSCRIBE") != "1":   # (=1: rehearsal, ranks share devices; use with VQA_DIST_BACKEND=gloo)
         print("bench.py: --gpus %d needs %d visible GPUs, found %d" % (args.gpus, args.gpus, n_dev), file=sys.stderr)
         return 2
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0)
+    def start(port):
+        procs = []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(args.gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+        return procs
+
+    for attempt in range(3):                         # (the free port is found by bind-and-close: another process may take it first)
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        procs = start(port)
+        # poll ALL ranks: if one dies at start-up the others would sit in the rendezvous until its timeout
+        import threading
+        out0 = []
+        reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+        t0 = time.time()
+        failed = None
+        while any(p.poll() is None for p in procs):
+            bad = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+            if bad:
+                failed = bad
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                break
+            time.sleep(0.2)
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        reader.join(timeout=10)
+        rcs = [p.returncode for p in procs]
+        if failed and time.time() - t0 < 60 and attempt < 2:
+            print("bench.py: ranks failed at start-up %s; retrying on another port" % failed, file=sys.stderr)
+            continue
+        break
+    sys.stdout.write(out0[0] if out0 else "")
     sys.stdout.flush()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
@@ -550,9 +581,37 @@ def main():
                        "coattn_impl": "fused" if vqa_amd._lib.load().coattn_fused_supported(
                            args.batch, n_grid, args.seq_len, model.co_attention.hidden_dim, 3, 0) else "general"},
         }
+    if world > 1 and trainer.reducer is not None:
+        # the exchange step, measurable: the same step under RCCL's all-reduce (the timed run above), under the
+        # one-shot all-to-all / sum / all-gather pattern, and with no collective at all (compute-only: local
+        # gradients, timing only) -- fewer steps each; exposed time = step time minus the compute-only step time
+        ex_steps = max(4, args.steps // 2)
+        ex = {"allreduce": dt / args.steps * 1e3}
+        errors = {}
+        for mode in ("direct", "none"):
+            try:
+                trainer.reducer.reset(mode)
+                t_m = timed_steps(trainer, batch, ex_steps, 2, sync)
+                tt = torch.tensor([t_m], device=device, dtype=torch.float64)
+                torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+                ex[mode] = float(tt) / ex_steps * 1e3
+            except RuntimeError as e:                    # (a backend without this collective: the leg is reported as failed)
+                errors[mode] = str(e).splitlines()[0][:200]
+                ex[mode] = None
+        if rank == 0:
+            diff = lambda a, b: round(a - b, 3) if a is not None and b is not None else None   # noqa: E731
+            out["exchange"] = {"ms_per_step": {k: (round(v, 3) if v is not None else None) for k, v in ex.items()},
+                               "errors": errors or None,
+                               "allreduce_ms_exposed": diff(ex["allreduce"], ex["none"]),
+                               "direct_ms_exposed": diff(ex["direct"], ex["none"]),
+                               "steps_per_leg": {"allreduce": args.steps, "direct": ex_steps, "none": ex_steps},
+                               "world_size": torch.distributed.get_world_size(),
+                               "backend": torch.distributed.get_backend(),
+                               "note": "headline value = the allreduce run; 'none' keeps gradients local (timing only)"}
     if world > 1:
         if rank == 0 and trainer.reducer is not None:
             out["allreduce_payload_mb"] = round(trainer.reducer.payload_bytes() / 1e6, 2)
+            out["allreduce_buckets"] = len(trainer.reducer.buckets or [])
         vdist.shutdown()
     if rank == 0 and not args.no_extras:
         del trainer, model, batch
@@ -581,7 +640,7 @@ def main():
             if world == 1:
                 out["hot_path"] = [hot_path_leg(device, n, lay) for n in (196, 49) for lay in ("lm", "cm")]
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == "attention":   # (the oracle port has no ResNet encoder)
             out["cpu_baseline"] = cpu_baseline_leg(args)
             out["cpu_baseline_hot_path"] = [cpu_hot_path_leg(196), cpu_hot_path_leg(49)]
         print(json.dumps(out))

@@ -95,7 +95,8 @@ int coattn_forward(const void* V, int64_t v_sB, int64_t v_sN, int64_t v_sD, cons
 /* Second half of coattn_forward only: everything after the projections P_v, P_q (affinity +
  * tanh model.py:377, H_v/H_q :380-384, scores + row softmax :387-388, attended reductions
  * :391-392), reading P_v / P_q from a `saved` buffer that a previous coattn_forward on the same
- * inputs filled.  Exists so that tests and bench.py can time / check this kernel in isolation. */
+ * inputs filled -- with the SAME flags (the fused and the general-shape kernels keep P_v / P_q in different scalings).
+ * Exists so that tests and bench.py can time / check this kernel in isolation. */
 int coattn_attention_forward(const void* V, int64_t v_sB, int64_t v_sN, int64_t v_sD, const void* const* Q,
                              const coattn_params* p, void* v_out, void* q_out, void* saved, void* ws,
                              int B, int N, int T, int d, int L, int dtype, int flags, void* stream);
@@ -148,12 +149,16 @@ int coattn_phrase_backward(const void* X, const coattn_phrase_params* p, const v
  * coattn_ce_forward replaces `nn.CrossEntropyLoss()(logits, label)` (main.py:94, :214; mean over the batch)
  * together with its gradient.  The MLPClassifier that produces the logits (model.py:400-434) stays on the stock
  * PyTorch-ROCm modules unless the fused head below is used (coattn_head_forward). */
-/* Mean cross entropy over B rows of [B,K] logits with int64 labels in [0,K) (a label outside makes the loss NaN):
+/* Mean cross entropy over B rows of [B,K] logits with int64 labels in [0,K):
  * loss[0] = mean_i (logsumexp(z_i) - z_i[label_i]);  dlogits [B,K] = (softmax(z) - onehot) / B, or NULL to skip.
- * ws: coattn_ce_workspace_bytes. */
+ * ws: coattn_ce_workspace_bytes.  A label outside [0,K) -- where nn.CrossEntropyLoss raises -- makes the loss NaN and
+ * sets a status word in `ws`; the call itself stays asynchronous.  coattn_ce_status(ws, B, stream) SYNCHRONISES the
+ * stream and returns -2 (coattn_last_error names the row) if the last coattn_ce_forward on this `ws` met such a label,
+ * else 0: call it where the host synchronises anyway (reading the loss). */
 int coattn_ce_workspace_bytes(int B, int K, int dtype, size_t* ws);
 int coattn_ce_forward(const void* logits, const void* labels, void* loss, void* dlogits, void* ws, int B, int K,
                       int dtype, void* stream);
+int coattn_ce_status(const void* ws, int B, void* stream);
 
 /* ---- answer head: MLPClassifier + cross entropy and their backward ----------------------------
  * coattn_head_forward replaces `MLPClassifier.forward` (model.py:414-434, called at model.py:185 with the two lists
@@ -166,7 +171,8 @@ int coattn_ce_forward(const void* logits, const void* labels, void* loss, void* 
  *   v, q   : host arrays of 3 device pointers [B,d] each (word, phrase, sentence: the rows of co-attention's v_out /
  *            q_out, or any three tensors);  W_w [d,d], W_p [d,2d], W_s [mlp,2d], W_h [K,mlp] as nn.Linear stores them.
  *   labels : int64 [B] or NULL (then loss must be NULL too: logits only, e.g. validation's argmax).
- *   logits : [B,K] (written);  loss: [1] (written).  A label outside [0,K) makes the loss NaN.
+ *   logits : [B,K] (written);  loss: [1] (written).  A label outside [0,K) makes the loss NaN and sets the status
+ *            word coattn_head_status(saved, ...) reports (-2; it synchronises the stream, like coattn_ce_status).
  *   saved  : forward -> backward state (h_w, h_p, h_s, d loss / d logits, row losses): coattn_head_workspace_bytes.
  * Backward: g_loss [1] (device) scales the saved d loss / d logits; g_logits [B,K] (may be NULL) is added to it -- the two
  * upstream gradients autograd can hand over; at least one must be given.  dv, dq: host arrays of 3 device pointers [B,d]
@@ -185,6 +191,7 @@ int coattn_head_workspace_bytes(int B, int d, int mlp, int K, int dtype, size_t*
 int coattn_head_forward(const void* const* v, const void* const* q, const coattn_head_params* p, const void* labels,
                         void* logits, void* loss, void* saved, int B, int d, int mlp, int K, int dtype, int flags,
                         void* stream);
+int coattn_head_status(const void* saved, int B, int d, int mlp, int K, void* stream);
 int coattn_head_backward(const void* const* v, const void* const* q, const coattn_head_params* p, const void* saved,
                          const void* g_loss, const void* g_logits, void* const* dv, void* const* dq,
                          const coattn_head_param_grads* pg, int accumulate, void* ws, int B, int d, int mlp, int K,

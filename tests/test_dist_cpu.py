@@ -129,6 +129,20 @@ def _worker3(rank, world, port, q):
         out[exchange] = [p.grad.clone().numpy() for p in model.parameters()]
         for h in red._hooks:
             h.remove()
+    # one reducer switched between the patterns (bench.py's timing legs): same values again; "none" leaves them local
+    red = vdist.GradReducer(model, bucket_mb=0.0001, exchange="allreduce")
+    for exchange in ("allreduce", "direct", "none"):
+        red.reset(exchange)
+        for step in range(2):
+            for p in model.parameters():
+                p.grad = None
+            red.prepare()
+            model(torch.full((4, 7), float(rank + 1 + step))).square().sum().backward()
+            if exchange == "none":
+                local = [p.grad.clone().numpy() for p in model.parameters()]
+            red.finish()
+        out["reset_" + exchange] = [p.grad.clone().numpy() for p in model.parameters()]
+    out["local"] = local
     q.put((rank, out))
     vdist.shutdown()
 
@@ -154,3 +168,9 @@ def test_direct_exchange_world3_matches_allreduce():
         for k in ("allreduce", "direct"):
             for a, b in zip(ref[k], out[k]):
                 assert (a == b).all()                                           # ranks hold identical gradients
+    for _, out in res:
+        for k in ("allreduce", "direct"):
+            for a, b in zip(out[k], out["reset_" + k]):
+                assert (a == b).all()                                           # a re-set reducer: the same values
+        for a, b in zip(out["local"], out["reset_none"]):
+            assert (a == b).all()                                               # "none": local gradients, untouched

@@ -142,6 +142,15 @@ def test_head_is_bitwise_repeatable_and_errors_are_loud():
     bad = labels.clone()
     bad[3] = K
     assert torch.isnan(_call(v, q, P, bad)["loss"])
+    # through the module: NaN now, IndexError at the status check (nn.CrossEntropyLoss raises there)
+    from vqa_amd import head as H
+    ps = [P[k].float().cuda() for k in NAMES]
+    H.answer_head(v.float().cuda(), q.float().cuda(), *ps, labels=labels.cuda())
+    H.check_labels()
+    _, l2 = H.answer_head(v.float().cuda(), q.float().cuda(), *ps, labels=bad.cuda())
+    assert torch.isnan(l2)
+    with pytest.raises(IndexError, match="row 3"):
+        H.check_labels()
 
 
 @pytest.mark.parametrize("impl", ["hip", "stock"])

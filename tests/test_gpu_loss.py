@@ -49,7 +49,8 @@ def test_mlp_head_and_cross_entropy_vs_oracle(shape):
 
 
 def test_cross_entropy_semantics():
-    """Mean reduction, upstream gradient scaling, no-grad / inference call, labels out of range -> NaN."""
+    """Mean reduction, upstream gradient scaling, no-grad / inference call, labels out of range -> NaN + IndexError at
+    the status check (nn.CrossEntropyLoss raises)."""
     from vqa_amd.loss import cross_entropy
     B, K = 37, 1001
     z = torch.from_numpy(O.hash_normal((B, K), 3, 3.0)).float().cuda()
@@ -62,9 +63,15 @@ def test_cross_entropy_semantics():
     with torch.no_grad():
         l0 = cross_entropy(z, lab)
     assert abs(l0.item() - torch.nn.functional.cross_entropy(z.double(), lab).item()) < 1e-5
+    from vqa_amd import loss as L
+    L.check_labels()                                   # all labels in range so far: no error
     bad = lab.clone()
     bad[3] = K
-    assert torch.isnan(cross_entropy(z, bad))
+    assert torch.isnan(cross_entropy(z, bad))          # asynchronous: NaN now, the error at the next check
+    with pytest.raises(IndexError, match="row 3"):
+        L.check_labels()
+    cross_entropy(z, lab)
+    L.check_labels()                                   # the status word is cleared by every call
     # rows with a huge logit: log-sum-exp stays finite
     z2 = z.clone()
     z2[0, 5] = 8.0e4

@@ -16,7 +16,8 @@ EXPORTS = ("coattn_version", "coattn_last_error", "coattn_fused_supported", "coa
            "coattn_phrase_workspace_bytes", "coattn_phrase_forward", "coattn_phrase_backward",
            "coattn_ce_workspace_bytes", "coattn_ce_forward", "coattn_linear_workspace_bytes", "coattn_linear_forward",
            "coattn_linear_wgrad_workspace_bytes", "coattn_linear_weight_grad",
-           "coattn_head_workspace_bytes", "coattn_head_forward", "coattn_head_backward")
+           "coattn_head_workspace_bytes", "coattn_head_forward", "coattn_head_backward", "coattn_head_status",
+           "coattn_ce_status")
 
 F32 = 0
 IMPL_AUTO, IMPL_GENERAL, IMPL_FUSED = 0, 1, 2
@@ -117,6 +118,8 @@ def load() -> C.CDLL:
     lib.coattn_linear_wgrad_workspace_bytes.restype = C.c_size_t
     lib.coattn_linear_weight_grad.argtypes = ([C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
                                               + [C.c_int] * 4 + [C.c_void_p])
+    lib.coattn_ce_status.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.coattn_head_status.argtypes = [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
     lib.coattn_head_workspace_bytes.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_size_t)] * 2
     lib.coattn_head_forward.argtypes = ([C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(HeadParams)]
                                         + [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p])
@@ -150,15 +153,22 @@ def workspace_bytes(B, N, T, d, L, flags=0):
 
 
 _scratch = {}
+_SCRATCH_MAX_STREAMS = 8
 
 
 def scratch(nbytes: int, device, stream_ptr: int):
     """Scratch workspace (contents undefined after a call) kept per (device, stream): calls on one stream run in
-    order, so they can share it; grown on demand, never shrunk."""
+    order, so they can share it; grown on demand.  At most _SCRATCH_MAX_STREAMS buffers are kept (least recently used
+    dropped: a process that touches many short-lived streams does not pile up workspaces), and nothing is cached while
+    the stream is capturing a graph (the allocation then belongs to the graph's private pool)."""
     import torch
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
     key = (device.index if device.index is not None else torch.cuda.current_device(), stream_ptr)
-    buf = _scratch.get(key)
+    buf = _scratch.pop(key, None)
     if buf is None or buf.numel() * 4 < nbytes:
         buf = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
-        _scratch[key] = buf
+    _scratch[key] = buf                                  # (re-inserted last: dict order = recency)
+    while len(_scratch) > _SCRATCH_MAX_STREAMS:
+        _scratch.pop(next(iter(_scratch)))
     return buf

@@ -35,9 +35,7 @@ def _native_layout(x_img: torch.Tensor) -> torch.Tensor:
     anything else is made contiguous -- location-major -- once.  That includes channel-major features at N = 49: their
     196-byte rows push the projection GEMMs onto dword loads (2 x 80 us per step), a 16 MB re-layout costs 8 us."""
     B, N, d = x_img.shape
-    sB, sN, sD = x_img.stride()
-    if B == 1:
-        sB = max(sB, N * d)                 # the stride of a size-1 dimension is arbitrary
+    sB, sN, sD = _strides(x_img)
     ext = (N - 1) * sN + (d - 1) * sD
     lm = sD == 1 and sN == d
     cm = sN == 1 and sD == N and N % 4 == 0
@@ -47,9 +45,17 @@ def _native_layout(x_img: torch.Tensor) -> torch.Tensor:
 
 
 def _strides(x: torch.Tensor):
+    """Element strides of x[B,N,d] for the C-ABI.  The stride torch reports for a size-1 dimension is arbitrary (and
+    ``.contiguous()`` keeps it): such dimensions get the stride a contiguous [B,N,d] tensor would have."""
     B, N, d = x.shape
     sB, sN, sD = x.stride()
-    return (max(sB, N * d) if B == 1 else sB), sN, sD
+    if d == 1:
+        sD = 1
+    if N == 1:
+        sN = d * sD if sD == 1 else 1
+    if B == 1:
+        sB = max(sB, (N - 1) * sN + (d - 1) * sD + 1, N * d)
+    return sB, sN, sD
 
 
 class _CoAttentionFn(torch.autograd.Function):

@@ -516,7 +516,9 @@ extern "C" int coattn_backward(const void* V, int64_t v_sB, int64_t v_sN, int64_
   CA_TRY(pick_impl(flags, B, N, T, d, L, vl, &fused));
   Ctx c{B, N, T, d, L, (hipStream_t)stream, vl};
   c.bf16_proj = (flags & COATTN_FLAG_BF16_PROJ) != 0;
-  if (fused && fused_backward_supported(B, N, T, d, L))
+  // (`saved` of the fused forward holds P_v, P_q scaled by kPScale: only the fused backward may read it)
+  CA_CHECK_ARG(!fused || fused_backward_supported(B, N, T, d, L), "backward: the fused forward's saved state has no fused backward for this shape");
+  if (fused)
     return fused_backward(B, N, T, d, L, (const float*)V, vl, (const float* const*)Q, p, (const float*)saved,
                           (const float*)gv, (const float*)gq, (float*)dV, dvl, (float* const*)dQ, pg, accumulate,
                           (float*)ws, c.s, c.bf16_proj ? 1 : 0,

@@ -26,10 +26,11 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 }
 
 // row_loss[i] = (logsumexp(z_i) - z_i[label_i]) * inv_b ; dlogits = (softmax(z_i) - onehot(label_i)) * inv_b.
-// A label outside [0, K) makes the row's loss NaN (nn.CrossEntropyLoss raises there).
+// A label outside [0, K) makes the row's loss NaN and raises the status word (nn.CrossEntropyLoss raises there:
+// coattn_ce_status reports it at the caller's next synchronisation point).
 __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
                                                       float* __restrict__ row_loss, float* __restrict__ dlogits, int K,
-                                                      float inv_b) {
+                                                      float inv_b, int* __restrict__ status) {
   __shared__ float sh[4];
   const int i = blockIdx.x;
   const float* z = logits + (long)i * K;
@@ -41,7 +42,10 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
   s = block_sum(s, sh);
   const long long lab = labels[i];
   const bool ok = lab >= 0 && lab < K;
-  if (threadIdx.x == 0) row_loss[i] = ok ? (logf(s) + m - z[lab]) * inv_b : NAN;
+  if (threadIdx.x == 0) {
+    row_loss[i] = ok ? (logf(s) + m - z[lab]) * inv_b : NAN;
+    if (!ok) status[0] = i + 1;                       // (any offending row: the writers race benignly)
+  }
   if (dlogits) {
     const float inv = inv_b / s;
     for (int k = threadIdx.x; k < K; k += 256)
@@ -55,9 +59,13 @@ inline size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
 
 // rows + mean for the answer head (head.hip): row_loss [B] scratch, dlogits [B,K] or NULL
 int launch_ce_rows(const float* logits, const void* labels, float* row_loss, float* dlogits, float* loss, int B, int K,
-                   hipStream_t s) {
+                   int* status, hipStream_t s) {
+  if (hipMemsetAsync(status, 0, 16, s) != hipSuccess) {       // (a memset node under graph capture)
+    coattn_set_error("ce: clearing the status word failed");
+    return -3;
+  }
   hipLaunchKernelGGL(ce_rows_kernel, dim3(B), dim3(256), 0, s, logits, (const long long*)labels, row_loss, dlogits, K,
-                     1.0f / (float)B);
+                     1.0f / (float)B, status);
   CA_CHECK_LAUNCH("ce_rows");
   return launch_sum_all(row_loss, loss, B, 0, s);
 }
@@ -65,9 +73,31 @@ int launch_ce_rows(const float* logits, const void* labels, float* row_loss, flo
 extern "C" int coattn_ce_workspace_bytes(int B, int K, int dtype, size_t* ws) {
   CA_CHECK_ARG(dtype == COATTN_F32, "unsupported dtype %d (only COATTN_F32)", dtype);
   CA_CHECK_ARG(B > 0 && K > 0, "bad B=%d / K=%d", B, K);
-  if (ws) *ws = al64((size_t)B) * sizeof(float);
+  if (ws) *ws = (al64((size_t)B) + 64) * sizeof(float);        // row losses + the status word (its own 256 bytes)
   return 0;
 }
+
+// Synchronises `stream` and reports whether the coattn_ce_forward / coattn_head_forward call that last used this
+// workspace / saved buffer met a label outside [0, K): -2 (message: the offending row) or 0.
+static int status_check(const int* status_dev, void* stream, const char* what) {
+  int host = 0;
+  if (hipMemcpyAsync(&host, status_dev, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+      hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+    coattn_set_error("%s: reading the status word failed", what);
+    return -3;
+  }
+  if (host != 0) {
+    coattn_set_error("%s: label of row %d is outside [0, K) (nn.CrossEntropyLoss: 'Target out of bounds')", what, host - 1);
+    return -2;
+  }
+  return 0;
+}
+
+extern "C" int coattn_ce_status(const void* ws, int B, void* stream) {
+  CA_CHECK_ARG(ws && B > 0, "ce_status: bad argument");
+  return status_check(reinterpret_cast<const int*>((const float*)ws + al64((size_t)B)), stream, "cross entropy");
+}
+int head_status_check(const int* status_dev, void* stream) { return status_check(status_dev, stream, "answer head"); }
 
 extern "C" int coattn_ce_forward(const void* logits, const void* labels, void* loss, void* dlogits, void* ws, int B,
                                  int K, int dtype, void* stream) {
@@ -75,8 +105,6 @@ extern "C" int coattn_ce_forward(const void* logits, const void* labels, void* l
   CA_CHECK_ARG(B > 0 && B <= (1 << 24) && K > 0, "bad B=%d / K=%d", B, K);
   CA_CHECK_ARG(logits && labels && loss && ws, "ce_forward: null argument");                   // dlogits may be NULL
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(ce_rows_kernel, dim3(B), dim3(256), 0, s, (const float*)logits, (const long long*)labels,
-                     (float*)ws, (float*)dlogits, K, 1.0f / (float)B);
-  CA_CHECK_LAUNCH("ce_rows");
-  return launch_sum_all((const float*)ws, (float*)loss, B, 0, s);
+  return launch_ce_rows((const float*)logits, labels, (float*)ws, (float*)dlogits, (float*)loss, B, K,
+                        reinterpret_cast<int*>((float*)ws + al64((size_t)B)), s);
 }

@@ -42,74 +42,20 @@ namespace {
 // wait until at most n of this wave's vector-memory operations (loads, stores, LDS-DMA: one in-order counter) are
 // still outstanding; hand-placed for the LDS-DMA ring, whose data dependences the compiler does not see.  n is a
 // constant after unrolling: one s_waitcnt remains.
+// (an "n"/"i" asm operand must be a constant before unrolling and __builtin_amdgcn_s_waitcnt would tell hipcc's own
+//  counter bookkeeping about these waits, so the count is spelled out per case; the switch folds to one instruction)
 __device__ __forceinline__ void vmcnt_wait(int n) {
+#define CA_VMW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
   switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
-    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
-    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
-    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
-    case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
-    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-    case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
-    case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
-    case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
-    case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-    case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
-    case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
-    case 27: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
-    case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
-    case 29: asm volatile("s_waitcnt vmcnt(29)" ::: "memory"); break;
-    case 30: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
-    case 31: asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); break;
-    case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
-    case 33: asm volatile("s_waitcnt vmcnt(33)" ::: "memory"); break;
-    case 34: asm volatile("s_waitcnt vmcnt(34)" ::: "memory"); break;
-    case 35: asm volatile("s_waitcnt vmcnt(35)" ::: "memory"); break;
-    case 36: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
-    case 37: asm volatile("s_waitcnt vmcnt(37)" ::: "memory"); break;
-    case 38: asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); break;
-    case 39: asm volatile("s_waitcnt vmcnt(39)" ::: "memory"); break;
-    case 40: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
-    case 41: asm volatile("s_waitcnt vmcnt(41)" ::: "memory"); break;
-    case 42: asm volatile("s_waitcnt vmcnt(42)" ::: "memory"); break;
-    case 43: asm volatile("s_waitcnt vmcnt(43)" ::: "memory"); break;
-    case 44: asm volatile("s_waitcnt vmcnt(44)" ::: "memory"); break;
-    case 45: asm volatile("s_waitcnt vmcnt(45)" ::: "memory"); break;
-    case 46: asm volatile("s_waitcnt vmcnt(46)" ::: "memory"); break;
-    case 47: asm volatile("s_waitcnt vmcnt(47)" ::: "memory"); break;
-    case 48: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
-    case 49: asm volatile("s_waitcnt vmcnt(49)" ::: "memory"); break;
-    case 50: asm volatile("s_waitcnt vmcnt(50)" ::: "memory"); break;
-    case 51: asm volatile("s_waitcnt vmcnt(51)" ::: "memory"); break;
-    case 52: asm volatile("s_waitcnt vmcnt(52)" ::: "memory"); break;
-    case 53: asm volatile("s_waitcnt vmcnt(53)" ::: "memory"); break;
-    case 54: asm volatile("s_waitcnt vmcnt(54)" ::: "memory"); break;
-    case 55: asm volatile("s_waitcnt vmcnt(55)" ::: "memory"); break;
-    case 56: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
-    case 57: asm volatile("s_waitcnt vmcnt(57)" ::: "memory"); break;
-    case 58: asm volatile("s_waitcnt vmcnt(58)" ::: "memory"); break;
-    case 59: asm volatile("s_waitcnt vmcnt(59)" ::: "memory"); break;
-    case 60: asm volatile("s_waitcnt vmcnt(60)" ::: "memory"); break;
-    case 61: asm volatile("s_waitcnt vmcnt(61)" ::: "memory"); break;
-    case 62: asm volatile("s_waitcnt vmcnt(62)" ::: "memory"); break;
-    case 63: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
+    CA_VMW(0) CA_VMW(1) CA_VMW(2) CA_VMW(3) CA_VMW(4) CA_VMW(5) CA_VMW(6) CA_VMW(7) CA_VMW(8) CA_VMW(9) CA_VMW(10) CA_VMW(11) CA_VMW(12)
+    CA_VMW(13) CA_VMW(14) CA_VMW(15) CA_VMW(16) CA_VMW(17) CA_VMW(18) CA_VMW(19) CA_VMW(20) CA_VMW(21) CA_VMW(22) CA_VMW(23) CA_VMW(24)
+    CA_VMW(25) CA_VMW(26) CA_VMW(27) CA_VMW(28) CA_VMW(29) CA_VMW(30) CA_VMW(31) CA_VMW(32) CA_VMW(33) CA_VMW(34) CA_VMW(35) CA_VMW(36)
+    CA_VMW(37) CA_VMW(38) CA_VMW(39) CA_VMW(40) CA_VMW(41) CA_VMW(42) CA_VMW(43) CA_VMW(44) CA_VMW(45) CA_VMW(46) CA_VMW(47) CA_VMW(48)
+    CA_VMW(49) CA_VMW(50) CA_VMW(51) CA_VMW(52) CA_VMW(53) CA_VMW(54) CA_VMW(55) CA_VMW(56) CA_VMW(57) CA_VMW(58) CA_VMW(59) CA_VMW(60)
+    CA_VMW(61) CA_VMW(62) CA_VMW(63)
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
+#undef CA_VMW
 }
 
 

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(kThreads) void head_bwd_kernel(const BwdLayer L) {
 }
 
 inline size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
-struct HeadSaved { size_t hw, hp, hs, dl, rl, total; };
+struct HeadSaved { size_t hw, hp, hs, dl, rl, st, total; };
 inline HeadSaved head_saved(int B, int d, int mlp, int K) {
   HeadSaved s;
   size_t o = 0;
@@ -413,6 +413,7 @@ inline HeadSaved head_saved(int B, int d, int mlp, int K) {
   s.hs = o; o += al64((size_t)B * mlp);
   s.dl = o; o += al64((size_t)B * K);      // d loss / d logits (written by the forward when labels are given)
   s.rl = o; o += al64((size_t)B);          // row losses
+  s.st = o; o += 64;                       // status word of the cross entropy (label out of range)
   s.total = o;
   return s;
 }
@@ -460,7 +461,8 @@ int launch_bwd(BwdLayer& L, bool want_dx, bool vec, hipStream_t s) {
 }  // namespace
 
 // cross entropy rows + mean (ce.hip)
-int launch_ce_rows(const float* logits, const void* labels, float* row_loss, float* dlogits, float* loss, int B, int K, hipStream_t s);
+int launch_ce_rows(const float* logits, const void* labels, float* row_loss, float* dlogits, float* loss, int B, int K, int* status, hipStream_t s);
+int head_status_check(const int* status_dev, void* stream);
 
 extern "C" int coattn_head_workspace_bytes(int B, int d, int mlp, int K, int dtype, size_t* saved, size_t* ws_bwd) {
   CA_TRY(check_dims(B, d, mlp, K, dtype));
@@ -502,8 +504,14 @@ extern "C" int coattn_head_forward(const void* const* v, const void* const* q, c
   L.A = Comp{nullptr, nullptr, sv + hs.hs, 0, 0, mlp};
   L.W = (const float*)p->W_h; L.bias = (const float*)p->b_h; L.C = (float*)logits; L.ldc = K; L.act = 0; L.N = K; L.K = mlp;
   CA_TRY(launch_fwd(L, vec, s));
-  if (labels) CA_TRY(launch_ce_rows((const float*)logits, labels, sv + hs.rl, sv + hs.dl, (float*)loss, B, K, s));
+  if (labels) CA_TRY(launch_ce_rows((const float*)logits, labels, sv + hs.rl, sv + hs.dl, (float*)loss, B, K, reinterpret_cast<int*>(sv + hs.st), s));
   return 0;
+}
+
+extern "C" int coattn_head_status(const void* saved, int B, int d, int mlp, int K, void* stream) {
+  CA_TRY(check_dims(B, d, mlp, K, COATTN_F32));
+  CA_CHECK_ARG(saved, "head_status: null argument");
+  return head_status_check(reinterpret_cast<const int*>((const float*)saved + head_saved(B, d, mlp, K).st), stream);
 }
 
 extern "C" int coattn_head_backward(const void* const* v, const void* const* q, const coattn_head_params* p, const void* saved,

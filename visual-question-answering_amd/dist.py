@@ -13,6 +13,8 @@ model shards naturally by QA pair, so the only exchange step is the gradient mea
   launched asynchronously as soon as its bucket is complete, overlapping with the rest of
   backward; xGMI is point-to-point, so buckets are kept large (default 16 MB: the ~49 MB
   gradient of the attention model goes out in 3-4 collectives).
+* ``bench.py --gpus N`` times the step under every exchange pattern (``reset``) plus a compute-only leg
+  (``exchange="none"``: buckets packed and unpacked, nothing sent) and reports the exposed time of each.
 * ``exchange="direct"`` (or ``VQA_GRAD_EXCHANGE=direct``) replaces the ring all-reduce by the
   one-shot pattern that fits a fully connected xGMI node: every rank owns 1/world of a bucket, an all-to-all
   sends shard j of every rank's bucket straight to rank j (all 7 peer links carry S/8 each at once instead of
@@ -87,14 +89,25 @@ class GradReducer:
         self.module = module
         self.group = group
         self.exchange = exchange or os.environ.get("VQA_GRAD_EXCHANGE", "allreduce")
-        if self.exchange not in ("allreduce", "direct"):
-            raise ValueError("exchange must be 'allreduce' or 'direct', got %r" % self.exchange)
+        if self.exchange not in ("allreduce", "direct", "none"):
+            raise ValueError("exchange must be 'allreduce', 'direct' or 'none', got %r" % self.exchange)
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.world = dist.get_world_size(group)
         self.buckets: List[_Bucket] | None = None      # built after the first backward
         self._where = {}
         self._hooks = []
         self.unused: List[str] = []
+
+    def reset(self, exchange: str) -> None:
+        """Switch the exchange pattern (bench.py times the step under each): hooks and buckets are dropped and rebuilt
+        on the next step.  "none" packs and unpacks the buckets but starts no collective -- the gradients stay LOCAL:
+        the compute-only leg of a timing comparison, never a training mode."""
+        if exchange not in ("allreduce", "direct", "none"):
+            raise ValueError("exchange must be 'allreduce', 'direct' or 'none', got %r" % exchange)
+        for h in self._hooks:
+            h.remove()
+        self._hooks, self._where, self.buckets = [], {}, None
+        self.exchange = exchange
 
     # -- bucket construction (after the first backward: only parameters that got a gradient) ----
     def _build(self):
@@ -127,7 +140,9 @@ class GradReducer:
     def _launch(self, b):
         """Pack a bucket whose gradients are all there (one multi-tensor copy) and start its all-reduce."""
         torch._foreach_copy_(b.views, [p.grad if p.grad is not None else torch.zeros_like(p) for p in b.params])
-        if self.exchange == "direct":
+        if self.exchange == "none":
+            b.work = False                              # timing leg: packed, nothing sent
+        elif self.exchange == "direct":
             # stage 1: shard j of this rank's bucket goes straight to rank j (stage 2 in finish())
             if b.recv is None:
                 b.recv = torch.empty_like(b.flat)
@@ -171,7 +186,7 @@ class GradReducer:
             for work, _ in gathers:
                 work.wait()
         for b in self.buckets:
-            if self.exchange != "direct":
+            if self.exchange == "allreduce":
                 b.work.wait()
                 b.flat.div_(self.world)
             for v, p in zip(b.views, b.params):

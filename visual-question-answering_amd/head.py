@@ -15,6 +15,7 @@ import torch
 from . import _lib
 
 _ws_cache = {}
+_last = None          # (saved, B, d, mlp, K, device) of the last forward with labels: check_labels() reads its status word
 
 
 def _workspace_bytes(B, d, mlp, K):
@@ -71,6 +72,9 @@ class _HeadFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.check(lib.coattn_head_forward(_rows(v), _rows(q), C.byref(p), _ptr(lab), _ptr(logits), _ptr(loss),
                                                _ptr(saved), B, d, mlp, K, _lib.F32, 0, stream), "coattn_head_forward")
+        if labels is not None:
+            global _last
+            _last = (saved, B, d, mlp, K, dev)
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(v, q, saved, *ps)
             ctx.dims = (B, d, mlp, K)
@@ -103,6 +107,21 @@ class _HeadFn(torch.autograd.Function):
                                                 _rows(dx) if need_in else None, None, C.byref(pg), 0, _ptr(ws),
                                                 B, d, mlp, K, _lib.F32, 0, C.c_void_p(stream)), "coattn_head_backward")
         return (dx if ctx.needs_input_grad[0] else None, dx if ctx.needs_input_grad[1] else None, *grads, None)
+
+
+def check_labels() -> None:
+    """nn.CrossEntropyLoss raises on a label outside [0, K); the HIP head stays asynchronous, makes the loss NaN and
+    sets a status word instead.  This SYNCHRONISES the current stream and raises IndexError if the last forward with
+    labels met such a label -- call it where the host synchronises anyway (when the loss is read)."""
+    if _last is None:
+        return
+    saved, B, d, mlp, K, dev = _last
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        rc = lib.coattn_head_status(_ptr(saved), B, d, mlp, K, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc == -2:
+        raise IndexError(lib.coattn_last_error().decode())
+    _lib.check(rc, "coattn_head_status")
 
 
 def _as_3bd(x) -> torch.Tensor:

@@ -16,6 +16,9 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+_last = None          # (ws, B, device) of the last call: check_labels() reads its status word
+
+
 class _CrossEntropyFn(torch.autograd.Function):
     """Mean cross entropy; the forward pass also produces d loss / d logits."""
 
@@ -41,6 +44,8 @@ class _CrossEntropyFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.check(lib.coattn_ce_forward(_ptr(z), _ptr(lab), _ptr(loss), _ptr(dz), _ptr(ws), B, K, _lib.F32,
                                              stream), "coattn_ce_forward")
+        global _last
+        _last = (ws, B, dev)
         if need:
             ctx.save_for_backward(dz)
         return loss
@@ -50,6 +55,21 @@ class _CrossEntropyFn(torch.autograd.Function):
     def backward(ctx, g):
         (dz,) = ctx.saved_tensors
         return dz * g, None
+
+
+def check_labels() -> None:
+    """``nn.CrossEntropyLoss`` raises on a label outside [0, K); the HIP kernel stays asynchronous, returns NaN and sets
+    a status word instead.  This SYNCHRONISES the current stream and raises IndexError if the last ``cross_entropy``
+    call met such a label -- call it where the host synchronises anyway (when the loss is read)."""
+    if _last is None:
+        return
+    ws, B, dev = _last
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        rc = lib.coattn_ce_status(_ptr(ws), B, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc == -2:
+        raise IndexError(lib.coattn_last_error().decode())
+    _lib.check(rc, "coattn_ce_status")
 
 
 def cross_entropy(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:

@@ -274,7 +274,10 @@ class Trainer:
             with self._autocast():
                 mine, self._ahead = self._ahead, None
                 if mine is not None and mine[0] is not image:
-                    mine = None                                  # queued for some other batch: drop it
+                    # queued for some other batch: drop it -- but its pass may still be running on the encoder stream
+                    # and updates the same BatchNorm running statistics as the inline pass below: wait for it
+                    torch.cuda.current_stream(self.device).wait_stream(self.enc_stream)
+                    mine = None
                 if mine is None:
                     with torch.no_grad():
                         inline = self.model.image_encoder(image)
@@ -300,6 +303,14 @@ class Trainer:
             self.reducer.finish()
         self.optimizer.step()
         return loss
+
+    def check_labels(self) -> None:
+        """Raise IndexError if a label of the last step lay outside [0, K) (the asynchronous HIP loss only sets a status
+        word where nn.CrossEntropyLoss raises); synchronises -- call it where the loss is read on the host."""
+        if self.device.type == "cuda":
+            from . import head, loss
+            head.check_labels()
+            loss.check_labels()
 
     @torch.no_grad()
     def validate(self, batches) -> Dict[str, float]:
@@ -395,6 +406,8 @@ def main(argv=None):
         # no encoder run-ahead across a validation: its BatchNorm statistics must be those of this step
         nxt, ready = (None, None) if validate_now else batches.peek_image()
         loss = trainer.step(image, question, ques_len, label, next_image=nxt, next_ready=ready)
+        if (step + 1) % args.log_interval == 0:
+            trainer.check_labels()                               # (the host synchronises here anyway to read the loss)
         if (step + 1) % args.log_interval == 0 and rank == 0:
             print(json.dumps({"step": step + 1, "loss": round(float(loss), 5),
                               "pairs_per_s": round(world * args.batch_size * (step + 1) / (time.time() - t0), 2)}))

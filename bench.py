@@ -22,7 +22,8 @@ contract fields it carries
                 roofline_weight_grad: the same for its weight gradient dW_v (gemm_tn_kernel + reduce)
   hot_path      isolated co-attention (+MLP+CE) fwd+bwd rates on device-resident features, N=196
                 and N=49, both feature layouts; the HIP op's fwd+bwd device time (pipelined calls) and the
-                wall time of single synchronised calls.
+                wall time of single synchronised calls; host_enqueue_ms = host time to queue one step; graph_*: the same
+                step replayed from one captured HIP graph (vqa_amd/graph.py).
 """
 from __future__ import annotations
 
@@ -108,6 +109,11 @@ def timed_steps(trainer, batch, steps, warmup, sync):
     return time.perf_counter() - t0
 
 
+def _lib_flag(bf16):
+    from vqa_amd import _lib
+    return _lib.FLAG_BF16_PROJ if bf16 else 0
+
+
 def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20, bf16=False):
     """Isolated hot path (co-attention + MLPClassifier + CE, fwd+bwd) on resident features.
     layout: "lm" = x_img contiguous [B,N,d] (what the channels_last encoder of the train step hands over),
@@ -132,14 +138,32 @@ def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20, b
         _, loss = mlp.forward_loss(*co(x_img, Qs), label)
         loss.backward()
 
-    for _ in range(5):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / iters
+    def timed(fn):
+        """(wall per step, host time to ENQUEUE a step) over `iters` pipelined steps."""
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters, (t1 - t0) / iters
+
+    dt, host = timed(step)
+    # the same step replayed from ONE captured HIP graph (graph.py: co-attention + head + loss, forward and backward)
+    from vqa_amd.graph import HotPathGraph
+    hp = HotPathGraph(co, mlp, B, N, T, flags=_lib_flag(bf16))
+
+    def gstep():
+        for p in params:
+            p.grad = None
+        for q in Qs:
+            q.grad = None
+        _, loss = hp(x_img, Qs, label)
+        loss.backward()
+
+    gdt, ghost = timed(gstep)
     # forward + backward of the HIP op alone (C-ABI calls through the autograd function):
     #  (a) device time of a pipelined run (HIP events around `iters` back-to-back fwd+bwd calls: what the train
     #      loop sees, the host runs ahead of the GPU);
@@ -182,7 +206,9 @@ def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20, b
             fwd += t1 - t0; bwd += t3 - t1
     flop = 3.0 * B * (2 * N * d * d + 3 * 2 * T * d * d + 3 * (3 * 2 * T * N * d + 4 * (N + T) * d))
     return {"N": N, "d": d, "K": K, "layout": layout, "mode": "bf16 projections (one MFMA per product)" if bf16 else "fp32",
-            "pairs_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3),
+            "pairs_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "host_enqueue_ms": round(host * 1e3, 3),
+            "graph_ms_per_step": round(gdt * 1e3, 3), "graph_host_enqueue_ms": round(ghost * 1e3, 3),
+            "graph_pairs_per_s": round(B / gdt, 1),
             "coattn_fwd_bwd_ms": round(t_dev * 1e3, 4), "coattn_fwd_bwd_tflops": round(flop / t_dev / 1e12, 2),
             "coattn_fwd_wall_ms": round(fwd / iters * 1e3, 4), "coattn_bwd_wall_ms": round(bwd / iters * 1e3, 4),
             "coattn_fwd_bwd_wall_tflops": round(flop / ((fwd + bwd) / iters) / 1e12, 2)}

@@ -1,0 +1,105 @@
+"""GPU: the hot path replayed from a captured HIP graph (graph.py): coattn_forward + answer head +
+their backward captured once, replayed 50 times -- every output bit for bit what the same C-ABI calls give when they
+are launched eagerly, also after the inputs and the parameters have changed in place; and the whole train step with
+``Trainer(graph=True)`` against the eager step."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _modules(d, mlp, K, seed=0):
+    import vqa_amd
+    from vqa_amd.modules import MLPClassifier
+    torch.manual_seed(seed)
+    return vqa_amd.ParallelCoAttention(d).cuda(), MLPClassifier(d, mlp, K).cuda()
+
+
+@pytest.mark.parametrize("N", [49, 196])
+def test_captured_hot_path_is_bitwise_the_eager_one(N):
+    from vqa_amd.graph import HotPathGraph
+    B, T, d, mlp, K = 160, 26, 512, 1024, 1001
+    co, head = _modules(d, mlp, K)
+    hp = HotPathGraph(co, head, B, N, T)
+    g = torch.Generator(device="cuda").manual_seed(1)
+
+    def fill():
+        hp.V.copy_(torch.randn(B, N, d, device="cuda", generator=g).clamp_min_(0))
+        for q in hp.Q:
+            q.copy_(torch.randn(B, T, d, device="cuda", generator=g) * 0.1)
+        hp.labels.copy_(torch.randint(0, K, (B,), device="cuda", generator=g))
+
+    def outputs():
+        return [t.clone() for t in [hp.logits, hp.loss, hp.v, hp.q, hp.dx] + hp.dQ + hp.co_grads + hp.head_grads]
+
+    fill()
+    hp.run_eager()
+    ref = outputs()
+    assert all(torch.isfinite(t).all() for t in ref)
+    for _ in range(50):
+        for t in [hp.logits, hp.loss] + hp.dQ + hp.co_grads + hp.head_grads:
+            t.fill_(float("nan"))
+        hp.replay()
+        assert all(torch.equal(a, b) for a, b in zip(ref, outputs()))
+    # new inputs, parameters updated in place (what Adam does): the graph reads them where they lie
+    fill()
+    with torch.no_grad():
+        for p in hp.co_params + hp.head_params:
+            p.mul_(1.01)
+    hp.run_eager()
+    ref2 = outputs()
+    assert not torch.equal(ref2[0], ref[0])
+    hp.replay()
+    assert all(torch.equal(a, b) for a, b in zip(ref2, outputs()))
+
+
+def test_graphed_function_matches_the_autograd_path():
+    """HotPathGraph.__call__ (autograd-aware) against co_attention -> mlp_classify.forward_loss through autograd:
+    same loss and gradients (upstream gradient != 1: the captured gradients are scaled)."""
+    from vqa_amd.graph import HotPathGraph
+    B, N, T, d, mlp, K = 12, 49, 26, 256, 128, 19
+    co, head = _modules(d, mlp, K, seed=3)
+    x = torch.randn(B, N, d, device="cuda").clamp_min_(0)
+    Qs = [(torch.randn(B, T, d, device="cuda") * 0.2).requires_grad_(True) for _ in range(3)]
+    lab = torch.arange(B, device="cuda") % K
+    params = list(co.parameters()) + list(head.parameters())
+
+    def grads():
+        return [q.grad.clone() for q in Qs] + [p.grad.clone() for p in params if p.grad is not None]
+
+    _, loss = head.forward_loss(*co(x, Qs), lab)
+    (loss * 3.0).backward()
+    ref, lref = grads(), loss.detach().clone()
+    for t in Qs + params:
+        t.grad = None
+    hp = HotPathGraph(co, head, B, N, T)
+    logits, loss2 = hp(x, Qs, lab)
+    (loss2 * 3.0).backward()
+    assert torch.equal(loss2, lref)
+    for a, b in zip(ref, grads()):
+        # (3 * g: one rounding apart; the biases of w_v / w_q have analytically zero gradients: rounding noise ~1e-8)
+        assert (a - b).abs().max() <= 1e-6 * a.abs().max().item() + 1e-7
+    # inputs at other addresses: a second graph pair is captured; a non-contiguous layout goes through the static inputs
+    x2 = x.clone()
+    _, l3 = hp(x2, [q.detach().clone() for q in Qs], lab)
+    _, l4 = hp(x.permute(0, 2, 1).contiguous().permute(0, 2, 1), [q.detach() for q in Qs], lab)
+    assert torch.equal(l3, lref) and torch.equal(l4, lref) and len(hp._pairs) == 3
+    assert co.W_b.weight.grad is None
+
+
+def test_trainer_graph_mode_matches_eager_training():
+    """Three Adam steps of the attention model with Trainer(graph=True) against the eager trainer: same losses."""
+    from vqa_amd import train as T
+    dev = torch.device("cuda:0")
+    losses = {}
+    for mode in (False, True):
+        torch.manual_seed(0)
+        model = T.build_model("attention", 100, 10).to(dev)
+        tr = T.Trainer(model, 1e-4, dev, graph=mode)
+        b = T.synthetic_batch(8, (64, 64), 26, 100, 11, seed=1)
+        im, qu, la, ln = T.sort_batch(b["image"], b["question"], b["label"], b["ques_len"])
+        im, qu, la = im.to(dev), qu.to(dev), la.to(dev)
+        losses[mode] = [float(tr.step(im, qu, ln, la, next_image=im)) for _ in range(3)]
+    assert model.hot_path_graph and len(model._graphs) == 1
+    for a, b in zip(losses[False], losses[True]):
+        assert abs(a - b) <= 1e-5 * abs(a)

@@ -1,0 +1,177 @@
+"""``HotPathGraph``: the fixed-shape launch sequence of the hot path -- co-attention forward + answer head + cross
+entropy, and their backward -- captured into HIP graphs and replayed per step (two host calls instead of ~25 kernel
+launches and two autograd round trips).
+
+What is captured are the C-ABI calls themselves (``coattn_forward`` + ``coattn_head_forward``; ``coattn_head_backward`` +
+``coattn_backward``: asynchronous on the stream they are given, no allocation, no synchronisation -> capture-safe).
+Outputs, saved state and workspaces are static buffers of this object; the INPUTS (image features, the three question
+levels, labels) are read where they lie: a graph pair is captured per set of input addresses (a training loop's
+allocator hands the same blocks back step after step; at most ``MAX_KEYS`` pairs, beyond that the inputs are copied
+into static buffers).  The upstream gradient of the loss is a device scalar the backward graph reads, so any
+``loss * k`` upstream works.  Values are bit-for-bit those of the eager C-ABI calls.
+
+    hp = HotPathGraph(co_attention, mlp_classify, B, N, T)          # modules of HierarchicalCoAttentionNet
+    logits, loss = hp(x_img, [Q_w, Q_p, Q_s], labels)               # autograd-aware; shapes fixed
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import torch
+
+from . import _lib
+from .head import _workspace_bytes as _head_ws
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class HotPathGraph:
+    MAX_KEYS = 8
+
+    def __init__(self, co_attention, mlp_classify, B: int, N: int, T: int, need_dv: bool = False, flags: int = 0):
+        self.co, self.mlp = co_attention, mlp_classify
+        d = co_attention.hidden_dim
+        mlp, K = mlp_classify.W_s.weight.shape[0], mlp_classify.W_h.weight.shape[0]
+        self.dims = (B, N, T, d, mlp, K)
+        dev = co_attention.W_v.weight.device
+        self.device = dev
+        self.flags = flags
+        f32 = dict(device=dev, dtype=torch.float32)
+        # static inputs, used when the caller's tensors are not taken in place (layout, alignment, too many address sets)
+        self.V = torch.zeros((B, N, d), **f32)
+        self.Q = [torch.zeros((B, T, d), **f32) for _ in range(3)]
+        self.labels = torch.zeros((B,), device=dev, dtype=torch.int64)
+        # static outputs
+        self.v = torch.empty((3, B, d), **f32); self.q = torch.empty((3, B, d), **f32)
+        self.logits = torch.empty((B, K), **f32); self.loss = torch.empty((), **f32)
+        self.dx = torch.empty((3, B, d), **f32)                      # d(q_l + v_l): upstream gradient of both v and q
+        self.dV = torch.empty((B, N, d), **f32) if need_dv else None
+        self.dQ = [torch.empty((B, T, d), **f32) for _ in range(3)]
+        self.co_params = [co_attention.W_v.weight, co_attention.W_v.bias, co_attention.W_q.weight, co_attention.W_q.bias,
+                          co_attention.w_v.weight, co_attention.w_v.bias, co_attention.w_q.weight, co_attention.w_q.bias]
+        self.head_params = [mlp_classify.W_w.weight, mlp_classify.W_w.bias, mlp_classify.W_p.weight, mlp_classify.W_p.bias,
+                            mlp_classify.W_s.weight, mlp_classify.W_s.bias, mlp_classify.W_h.weight, mlp_classify.W_h.bias]
+        for p in self.co_params + self.head_params:
+            if not p.is_contiguous() or p.dtype != torch.float32:
+                raise RuntimeError("HotPathGraph: parameters must be contiguous fp32")
+        self.co_grads = [torch.empty_like(p) for p in self.co_params]
+        self.head_grads = [torch.empty_like(p) for p in self.head_params]
+        sb, fb, bb = _lib.workspace_bytes(B, N, T, d, 3, flags)
+        hsb, hwb = _head_ws(B, d, mlp, K)
+        self.saved = torch.empty(sb // 4, **f32); self.ws = torch.empty(max(fb, bb) // 4, **f32)
+        self.hsaved = torch.empty(hsb // 4, **f32); self.hws = torch.empty(hwb // 4, **f32)
+        self.g_loss = torch.ones(1, **f32)                           # upstream gradient of the loss (device scalar)
+        self._pairs = {}                                             # input addresses -> (forward graph, backward graph)
+        self._warm = False
+        self._static = (self.V, self.Q[0], self.Q[1], self.Q[2], self.labels)
+        self.pair(self._static)
+
+    # the C-ABI calls on `stream`, reading the inputs `ins` = (V [B,N,d] contiguous, Q_w, Q_p, Q_s, labels)
+    def _enqueue(self, ins, stream, fwd=True, bwd=True):
+        lib = _lib.load()
+        B, N, T, d, mlp, K = self.dims
+        V, Qs, labels = ins[0], ins[1:4], ins[4]
+        st = C.c_void_p(stream)
+        qptr = (C.c_void_p * 3)(*[t.data_ptr() for t in Qs])
+        dqptr = (C.c_void_p * 3)(*[t.data_ptr() for t in self.dQ])
+        rows = lambda t: (C.c_void_p * 3)(*[t[l].data_ptr() for l in range(3)])   # noqa: E731
+        p = _lib.Params(*[t.data_ptr() for t in self.co_params])
+        pg = _lib.ParamGrads(*[t.data_ptr() for t in self.co_grads])
+        hp = _lib.HeadParams(*[t.data_ptr() for t in self.head_params])
+        hg = _lib.HeadParamGrads(*[t.data_ptr() for t in self.head_grads])
+        vs = (N * d, d, 1)
+        if fwd:
+            _lib.check(lib.coattn_forward(_ptr(V), *vs, qptr, C.byref(p), _ptr(self.v), _ptr(self.q), _ptr(self.saved),
+                                          _ptr(self.ws), B, N, T, d, 3, _lib.F32, self.flags, st), "coattn_forward")
+            _lib.check(lib.coattn_head_forward(rows(self.v), rows(self.q), C.byref(hp), _ptr(labels), _ptr(self.logits),
+                                               _ptr(self.loss), _ptr(self.hsaved), B, d, mlp, K, _lib.F32, 0, st),
+                       "coattn_head_forward")
+        if bwd:
+            _lib.check(lib.coattn_head_backward(rows(self.v), rows(self.q), C.byref(hp), _ptr(self.hsaved), _ptr(self.g_loss),
+                                                None, rows(self.dx), None, C.byref(hg), 0, _ptr(self.hws), B, d, mlp, K,
+                                                _lib.F32, 0, st), "coattn_head_backward")
+            _lib.check(lib.coattn_backward(_ptr(V), *vs, qptr, C.byref(p), _ptr(self.saved), _ptr(self.dx), _ptr(self.dx),
+                                           _ptr(self.dV), *(vs if self.dV is not None else (0, 0, 0)), dqptr, C.byref(pg),
+                                           0, _ptr(self.ws), B, N, T, d, 3, _lib.F32, self.flags, st), "coattn_backward")
+
+    def usable_in_place(self, ins) -> bool:
+        B, N, T, d, _, _ = self.dims
+        V, labels = ins[0], ins[4]
+        return (V.is_contiguous() and V.dtype == torch.float32 and V.data_ptr() % 16 == 0 and labels.is_contiguous()
+                and all(q.is_contiguous() and q.dtype == torch.float32 and q.data_ptr() % 16 == 0 for q in ins[1:4]))
+
+    def pair(self, ins):
+        """(forward graph, backward graph) reading the inputs at the addresses of `ins`; captured on first use, or
+        None when MAX_KEYS address sets are already held (the caller then copies into the static inputs)."""
+        key = tuple(t.data_ptr() for t in ins)
+        hit = self._pairs.get(key)
+        if hit is not None:
+            return hit
+        if len(self._pairs) >= self.MAX_KEYS:
+            return None
+        with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream(self.device)
+            if not self._warm:                                   # per-device one-time setup must happen outside capture
+                side = torch.cuda.Stream(self.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    self._enqueue(ins, side.cuda_stream)
+                cur.wait_stream(side)
+                self._warm = True
+            torch.cuda.synchronize(self.device)
+            gf, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gf):
+                self._enqueue(ins, torch.cuda.current_stream(self.device).cuda_stream, True, False)
+            with torch.cuda.graph(gb, pool=gf.pool()):
+                self._enqueue(ins, torch.cuda.current_stream(self.device).cuda_stream, False, True)
+        self._pairs[key] = (gf, gb)
+        return self._pairs[key]
+
+    def run_eager(self, ins=None):
+        """The same calls without the graphs (tests compare the two bit for bit)."""
+        self._enqueue(ins or self._static, torch.cuda.current_stream(self.device).cuda_stream)
+
+    def replay(self, ins=None):
+        gf, gb = self.pair(ins or self._static)
+        gf.replay()
+        gb.replay()
+
+    def __call__(self, x_img: torch.Tensor, x_ques: Sequence[torch.Tensor], labels: torch.Tensor):
+        return _HotPathFn.apply(self, x_img, labels, *x_ques, *self.co_params, *self.head_params)
+
+
+class _HotPathFn(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, hp: HotPathGraph, x_img, labels, Qw, Qp, Qs, *params):
+        B, N, T, d, mlp, K = hp.dims
+        if tuple(x_img.shape) != (B, N, d) or any(tuple(q.shape) != (B, T, d) for q in (Qw, Qp, Qs)) or tuple(labels.shape) != (B,):
+            raise RuntimeError("HotPathGraph: captured for x_img %s, questions %s" % ((B, N, d), (B, T, d)))
+        if ctx.needs_input_grad[1] and hp.dV is None:
+            raise RuntimeError("HotPathGraph: built with need_dv=False but the image features require a gradient")
+        ins = (x_img, Qw, Qp, Qs, labels)
+        pair = hp.pair(ins) if hp.usable_in_place(ins) else None
+        if pair is None:                                         # other layout / too many address sets: static inputs
+            hp.V.copy_(x_img)
+            torch._foreach_copy_(hp.Q, [Qw, Qp, Qs])
+            hp.labels.copy_(labels)
+            ins = hp._static
+            pair = hp.pair(ins)
+        pair[0].replay()
+        ctx.hp, ctx.pair = hp, pair
+        ctx.keep = ins                                           # the graphs read these addresses again in backward
+        ctx.mark_non_differentiable(hp.logits)
+        return hp.logits, hp.loss.clone()
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g_logits, g_loss):
+        hp = ctx.hp
+        hp.g_loss.copy_(g_loss.reshape(1))
+        ctx.pair[1].replay()
+        # (the static gradient buffers are handed out as they are: autograd accumulates / the optimiser consumes them
+        #  before the next step's backward overwrites them)
+        return (None, hp.dV, None, *hp.dQ, *hp.co_grads, *hp.head_grads)

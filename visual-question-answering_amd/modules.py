@@ -317,6 +317,8 @@ class HierarchicalCoAttentionNet(nn.Module):
             self.question_encoder = QuestionCoAttentionEncoder(**ques_enc_params)
         self.co_attention = ParallelCoAttention(self.hidden_dim)
         self.mlp_classify = MLPClassifier(self.hidden_dim, mlp_dim, K)
+        self.hot_path_graph = False                   # opt-in: replay the hot path from a captured HIP graph (graph.py)
+        self._graphs = {}
 
     def forward(self, x_img, x_ques, x_ques_lens):
         return self.forward_features(self.image_encoder(x_img), x_ques, x_ques_lens)
@@ -329,10 +331,26 @@ class HierarchicalCoAttentionNet(nn.Module):
         x_ques_features = list(self.question_encoder(x_ques, x_ques_lens))
         if callable(x_img_features):            # resolved only now: the question side is queued first
             x_img_features = x_img_features()
+        if labels is not None and self.hot_path_graph and x_img_features.is_cuda and torch.is_grad_enabled():
+            return self._graphed(x_img_features, x_ques_features, labels)
         x_img_attn, x_ques_attn = self.co_attention(x_img_features, x_ques_features)
         if labels is not None:
             return self.mlp_classify.forward_loss(x_img_attn, x_ques_attn, labels)
         return self.mlp_classify(x_img_attn, x_ques_attn)
+
+    def _graphed(self, x_img_features, x_ques_features, labels):
+        """co-attention + answer head + loss, forward AND backward, as one replay of a captured HIP graph (graph.py);
+        captured per (B, N, T) on first use.  Opt-in: ``net.hot_path_graph = True`` (``Trainer(graph=True)``)."""
+        from . import _lib
+        from .graph import HotPathGraph
+        B, N, _ = x_img_features.shape
+        T = x_ques_features[0].shape[1]
+        key = (B, N, T, bool(x_img_features.requires_grad), bool(self.co_attention.bf16_projections))
+        hp = self._graphs.get(key)
+        if hp is None:
+            hp = self._graphs[key] = HotPathGraph(self.co_attention, self.mlp_classify, B, N, T, need_dv=key[3],
+                                                  flags=_lib.FLAG_BF16_PROJ if key[4] else 0)
+        return hp(x_img_features, x_ques_features, labels)
 
 
 # ---- baseline model (BASELINE config 1: CPU plumbing, no custom kernels) ------------------

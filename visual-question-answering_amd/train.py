@@ -219,7 +219,7 @@ class Trainer:
     stream."""
 
     def __init__(self, model: nn.Module, lr: float = 1e-4, device=None, opt_lvl: int = 0,
-                 bucket_mb: float = 16.0, encoder_runahead: bool = True):
+                 bucket_mb: float = 16.0, encoder_runahead: bool = True, graph: bool = False):
         self.device = device or next(model.parameters()).device
         self.model = model
         self.criterion = CrossEntropyLoss()      # nn.CrossEntropyLoss() semantics (main.py:94); fused HIP kernel on CUDA
@@ -227,6 +227,10 @@ class Trainer:
         self.opt_lvl = opt_lvl
         if opt_lvl > 0 and hasattr(model, "co_attention"):      # AMP: projections on the bf16 MFMA as well
             model.co_attention.bf16_projections = True
+        # graph=True: co-attention + answer head + loss, forward and backward, replayed from one captured HIP graph
+        # (graph.py): one host call instead of ~25 launches; same values bit for bit
+        if graph and hasattr(model, "hot_path_graph") and self.device.type == "cuda":
+            model.hot_path_graph = True
         self.reducer = vdist.GradReducer(model, bucket_mb=bucket_mb) if vdist.world_size() > 1 else None
         enc = getattr(model, "image_encoder", None)
         self.runahead = bool(encoder_runahead and self.device.type == "cuda" and enc is not None

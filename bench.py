@@ -264,8 +264,9 @@ def roofline_leg(device, B=160, N=196, T=26, d=512, L=3, iters=100, layout="lm")
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             tr = json.load(fh)
-        if tr.get("shape") == {"B": B, "N": N, "T": T, "d": d, "L": L} and tr.get("layout", "cm") == layout:
-            traffic = tr["hbm_bytes_per_launch"]
+        for e in (tr["entries"] if "entries" in tr else [tr]):
+            if e.get("shape") == {"B": B, "N": N, "T": T, "d": d, "L": L} and e.get("layout", "cm") == layout:
+                traffic = e["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

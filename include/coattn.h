@@ -178,6 +178,9 @@ int coattn_ce_status(const void* ws, int B, void* stream);
  * upstream gradients autograd can hand over; at least one must be given.  dv, dq: host arrays of 3 device pointers [B,d]
  * (overwritten; the gradient of q_l + v_l goes to both; dq may be NULL or equal dv: stored once; dv NULL: no input
  * gradients).  pg: the eight parameter gradients (accumulate = 0 overwrites, 1 adds).  ws: scratch of `ws_bwd` bytes. */
+/* flags bit 0 of coattn_head_forward / coattn_head_backward: the layers of a direction as phases of ONE launch separated by
+ * grid-wide barriers instead of one launch per layer (same tiles, same values; measured slower or equal: opt-in). */
+#define COATTN_HEAD_PERSISTENT 1
 typedef struct coattn_head_params {
   const void* W_w; const void* b_w;   /* model.py:409 */
   const void* W_p; const void* b_p;   /* model.py:410 */

@@ -40,7 +40,8 @@ def _oracle(ref, v, q, labels, g_loss=1.0, g_logits=None):
     return z.detach(), loss.detach(), vr.grad, qr.grad, {k: p.grad.clone() for k, p in ref.named_parameters()}
 
 
-def _call(v, q, P, labels, g_loss=None, g_logits=None, separate_dq=False, accumulate=0, grads_init=None, want_dx=True):
+def _call(v, q, P, labels, g_loss=None, g_logits=None, separate_dq=False, accumulate=0, grads_init=None, want_dx=True,
+          flags=0):
     """Straight through the C-ABI.  v, q [3,B,d]; P: dict of reference-named parameters (any device)."""
     from vqa_amd import _lib
     lib = _lib.load()
@@ -60,7 +61,7 @@ def _call(v, q, P, labels, g_loss=None, g_logits=None, separate_dq=False, accumu
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     _lib.check(lib.coattn_head_forward(rows(v), rows(q), C.byref(p), lab.data_ptr() if lab is not None else None,
                                        logits.data_ptr(), loss.data_ptr() if loss is not None else None, saved.data_ptr(),
-                                       B, d, mlp, K, _lib.F32, 0, stream), "coattn_head_forward")
+                                       B, d, mlp, K, _lib.F32, flags, stream), "coattn_head_forward")
     torch.cuda.synchronize()
     out = {"logits": logits, "loss": loss}
     if g_loss is None and g_logits is None:
@@ -75,7 +76,7 @@ def _call(v, q, P, labels, g_loss=None, g_logits=None, separate_dq=False, accumu
     _lib.check(lib.coattn_head_backward(rows(v), rows(q), C.byref(p), saved.data_ptr(), gl.data_ptr() if gl is not None else None,
                                         gx.data_ptr() if gx is not None else None, rows(dv) if want_dx else None,
                                         rows(dq) if dq is not None else None, C.byref(pg), accumulate, ws.data_ptr(),
-                                        B, d, mlp, K, _lib.F32, 0, stream), "coattn_head_backward")
+                                        B, d, mlp, K, _lib.F32, flags, stream), "coattn_head_backward")
     torch.cuda.synchronize()
     out.update({"dv": dv, "dq": dq})
     out.update({"d" + k: g for k, g in zip(NAMES, grads)})
@@ -100,6 +101,23 @@ def test_head_vs_oracle(shape):
     assert torch.equal(r["dv"], r["dq"])                     # d(q_l + v_l) goes to both
     for k in NAMES:
         assert _rel(r["d" + k], gp[k]) < TOL, k
+
+
+@pytest.mark.parametrize("shape", [(160, 512, 1024, 1001), (3, 20, 12, 5), (70, 96, 160, 33), (300, 64, 64, 12)],
+                         ids=lambda s: "B%d_d%d_mlp%d_K%d" % s)
+def test_one_launch_form_gives_the_same_bits(shape):
+    """COATTN_HEAD_PERSISTENT: the layers as phases of one launch per direction behind grid-wide barriers -- the same
+    tiles, so every output is bit for bit that of the per-layer launches (also when a phase has more tiles than the
+    grid has workgroups, B = 300), run after run."""
+    B, d, mlp, K = shape
+    ref, v, q, labels = _case(B, d, mlp, K, seed=2)
+    P = ref.state_dict()
+    a = _call(v, q, P, labels, g_loss=1.3)
+    for _ in range(4):
+        b = _call(v, q, P, labels, g_loss=1.3, flags=1)
+        for k in a:
+            if a[k] is not None:
+                assert torch.equal(a[k], b[k]), k
 
 
 def test_head_logits_gradient_accumulate_and_no_input_grads():

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Copy the summaries produced by tools/refresh_profiles.sh (gpurun_out/refresh/) into profiles/.
 
-usage: tools/collect_profiles.py [round-tag, default r02]
+usage: tools/collect_profiles.py [round-tag, default r03]
 """
 import csv
 import glob
@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "refresh")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def one(pattern):
@@ -30,6 +30,13 @@ for leg, name in (("roofline", "roofline"), ("hot", "hot_path"), ("step", "full_
                   ("headline", "headline")):
     shutil.copy(one("%s/**/*kernel_stats.csv" % leg), os.path.join(DST, "%s_%s_kernel_stats.csv" % (tag, name)))
 shutil.copy(os.path.join(SRC, "pmc_traffic.json"), os.path.join(DST, "pmc_traffic.json"))
+# config 4's bench line and hot-path kernels, the answer head's kernels and its unprofiled timing
+c4 = [l for l in open(os.path.join(SRC, "cfg4_bench.json")) if l.startswith("{")][-1]
+json.loads(c4)
+open(os.path.join(DST, "%s_cfg4_bench.json" % tag), "w").write(c4)
+shutil.copy(one("cfg4_hot/**/*kernel_stats.csv"), os.path.join(DST, "%s_cfg4_hot_path_kernel_stats.csv" % tag))
+shutil.copy(one("head/**/*kernel_stats.csv"), os.path.join(DST, "%s_head_kernel_stats.csv" % tag))
+shutil.copy(os.path.join(SRC, "head_unprofiled.log"), os.path.join(DST, "%s_head_timing.log" % tag))
 
 # MFMA-busy pass: mean counter value per kernel, and MFMA busy fraction = MFMA_BUSY / (32 * SQ_BUSY)
 vals = {}

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected in SEPARATE runs of
-`tools/probe_fwd_one.py`: the headline shape and layout only) into profiles/pmc_traffic.json: HBM bytes per launch
+`tools/probe_fwd_one.py`: the headline shape and layout only) into an entry of profiles/pmc_traffic.json (one per shape and layout): HBM bytes per launch
 of the affinity+softmax+reduce forward (coattn_fwd32_kernel + attend_v_lm_kernel / attend_v_kernel).
 
 gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE is in KiB and reports 1/2 of the
@@ -37,6 +37,14 @@ out = {"shape": {"B": B, "N": N, "T": T, "d": d, "L": L}, "layout": layout,
        "raw_kib": {"%s.%s" % k: round(v, 1) for k, v in mean.items()},
        "note": "FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950 halves coalesced-read bytes); calibration on "
                "the attend_v kernel's exactly known read volume; counters from separate --pmc passes"}
-with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json"), "w") as fh:
-    json.dump(out, fh, indent=1)
+# profiles/pmc_traffic.json holds one entry per (shape, layout); an entry of the same key is replaced
+path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+try:
+    old = json.load(open(path))
+    entries = old["entries"] if "entries" in old else [old]
+except (OSError, ValueError):
+    entries = []
+entries = [e for e in entries if not (e.get("shape") == out["shape"] and e.get("layout") == layout)] + [out]
+with open(path, "w") as fh:
+    json.dump({"entries": entries}, fh, indent=1)
 print(json.dumps(out))

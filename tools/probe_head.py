@@ -68,21 +68,23 @@ rv, rq, rdx = rows(vd), rows(qd), rows(dx)
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def cabi():
-    lib.coattn_head_forward(rv, rq, C.byref(P), lab.data_ptr(), logits.data_ptr(), loss.data_ptr(), saved.data_ptr(), B, d, mlp, K, 0, 0, st)
-    lib.coattn_head_backward(rv, rq, C.byref(P), saved.data_ptr(), gl.data_ptr(), None, rdx, None, C.byref(G), 0, ws.data_ptr(), B, d, mlp, K, 0, 0, st)
+def cabi(flags):
+    lib.coattn_head_forward(rv, rq, C.byref(P), lab.data_ptr(), logits.data_ptr(), loss.data_ptr(), saved.data_ptr(), B, d, mlp, K, 0, flags, st)
+    lib.coattn_head_backward(rv, rq, C.byref(P), saved.data_ptr(), gl.data_ptr(), None, rdx, None, C.byref(G), 0, ws.data_ptr(), B, d, mlp, K, 0, flags, st)
 
 
+# interleaved rounds in one process: per-layer launches (10) against the one-launch-per-direction form (4 launches)
 for _ in range(50):
-    cabi()
+    cabi(0); cabi(1)
 torch.cuda.synchronize()
 for rep in range(3):
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(300):
-        cabi()
-    e1.record()
-    t1 = time.perf_counter()
-    torch.cuda.synchronize()
-    print("C-ABI head fwd+bwd: %.1f us per step between events; host enqueue %.1f us per step" % (e0.elapsed_time(e1) / 300 * 1e3, (t1 - t0) / 300 * 1e6), flush=True)
+    for flags, name in ((0, "per-layer launches"), (1, "one launch per direction (grid barriers)")):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(300):
+            cabi(flags)
+        e1.record()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        print("C-ABI head fwd+bwd, %s: %.1f us per step between events; host enqueue %.1f us per step" % (name, e0.elapsed_time(e1) / 300 * 1e3, (t1 - t0) / 300 * 1e6), flush=True)

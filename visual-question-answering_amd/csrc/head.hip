@@ -403,6 +403,71 @@ __global__ __launch_bounds__(kThreads) void head_bwd_kernel(const BwdLayer L) {
   dw_tile(L.Y, L.X, L.dW, L.Kin, L.db, L.M, L.N, L.Kin, 32 * (tile / ntk), 32 * (tile % ntk), L.accumulate);
 }
 
+// ---- the same tiles inside ONE launch per direction (COATTN_HEAD_PERSISTENT, opt-in) ---------------------------------
+// The layers of a direction are phases of one kernel, separated by a grid-wide barrier instead of a kernel boundary
+// (VERDICT r2 asked for this form first).  Placement-independent protocol (cdna_hip_programming.md Guideline 16): every
+// wave drains its stores, workgroup barrier, one lane's agent-scope release, a monotonic arrival counter (zeroed by a
+// memset node in front of the launch), relaxed polling with s_sleep, one agent-scope acquire, workgroup barrier.  The
+// grid is at most one workgroup per CU, so every workgroup is resident; the spin is bounded (a time-out raises bar[1]).
+// Measured against the per-layer launches in DESIGN.md 3.5; the launches are the default.
+__device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned target) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (ROCm 7.2 can drop the fence's own wait)
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > (1u << 24)) { __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+}
+
+struct FwdAll { FwdLayer L[4]; unsigned* bar; };
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void head_fwd_persistent_kernel(const FwdAll a) {
+  __shared__ __attribute__((aligned(16))) float smem[kWaves * 2 * 32 * LDR];
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    const FwdLayer& L = a.L[l];
+    const int ntn = (L.N + 31) / 32, ntiles = ((L.M + 31) / 32) * ntn;
+    TileOut o = {};
+    o.C = L.C; o.ldc = L.ldc; o.bias = L.bias; o.act = L.act; o.hsplit = 0x7fffffff;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+      fwd_tile<VEC>(L.A, L.W, L.K, o, L.M, L.N, L.K, 32 * (t / ntn), 32 * (t % ntn), smem);
+      __syncthreads();                                        // the reduction slots become staging images again
+    }
+    if (l < 3) grid_barrier(a.bar, (unsigned)(l + 1) * gridDim.x);
+  }
+}
+
+struct BwdAll { BwdLayer L[4]; unsigned* bar; bool vec0; };
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void head_bwd_persistent_kernel(const BwdAll a) {
+  __shared__ __attribute__((aligned(16))) float smem[kWaves * 2 * 32 * LDR];
+  for (int l = 0; l < 4; ++l) {
+    const BwdLayer& L = a.L[l];
+    const int ntk = (L.Kin + 31) / 32, ntn = (L.N + 31) / 32, ngroups = (ntk * ntn + kWaves - 1) / kWaves;
+    for (int wk = blockIdx.x; wk < L.nx + ngroups; wk += gridDim.x) {
+      if (wk < L.nx) {
+        // (the last layer's dY rows are K floats: whole-line staging only when the host found them aligned)
+        if (VEC && (l > 0 || a.vec0)) dx_tile<true>(L.Y, L.W, L.Kin, L.o, L.M, L.N, L.Kin, 32 * (wk / ntk), 32 * (wk % ntk), smem);
+        else dx_tile<false>(L.Y, L.W, L.Kin, L.o, L.M, L.N, L.Kin, 32 * (wk / ntk), 32 * (wk % ntk), smem);
+        __syncthreads();
+      } else {
+        const int tile = (wk - L.nx) * kWaves + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        if (tile < ntk * ntn) dw_tile(L.Y, L.X, L.dW, L.Kin, L.db, L.M, L.N, L.Kin, 32 * (tile / ntk), 32 * (tile % ntk), L.accumulate);
+      }
+    }
+    if (l < 3) grid_barrier(a.bar, (unsigned)(l + 1) * gridDim.x);
+  }
+}
+
 inline size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
 struct HeadSaved { size_t hw, hp, hs, dl, rl, st, total; };
 inline HeadSaved head_saved(int B, int d, int mlp, int K) {
@@ -467,14 +532,13 @@ int head_status_check(const int* status_dev, void* stream);
 extern "C" int coattn_head_workspace_bytes(int B, int d, int mlp, int K, int dtype, size_t* saved, size_t* ws_bwd) {
   CA_TRY(check_dims(B, d, mlp, K, dtype));
   if (saved) *saved = head_saved(B, d, mlp, K).total * sizeof(float);
-  if (ws_bwd) *ws_bwd = head_bwd(B, d, mlp).total * sizeof(float);
+  if (ws_bwd) *ws_bwd = (head_bwd(B, d, mlp).total + 64) * sizeof(float);       // + the barrier words of the one-launch form
   return 0;
 }
 
 extern "C" int coattn_head_forward(const void* const* v, const void* const* q, const coattn_head_params* p, const void* labels,
                                    void* logits, void* loss, void* saved, int B, int d, int mlp, int K, int dtype, int flags,
                                    void* stream) {
-  (void)flags;
   CA_TRY(check_dims(B, d, mlp, K, dtype));
   CA_CHECK_ARG(v && q && p && logits && saved, "head_forward: null argument");
   for (int l = 0; l < 3; ++l) CA_CHECK_ARG(v[l] && q[l], "head_forward: v[%d] / q[%d] is null", l, l);
@@ -486,24 +550,33 @@ extern "C" int coattn_head_forward(const void* const* v, const void* const* q, c
   bool vec = (d % 32) == 0 && (mlp % 32) == 0 && al16(sv);
   for (int l = 0; l < 3; ++l) vec = vec && al16(v[l]) && al16(q[l]);
   vec = vec && al16(p->W_w) && al16(p->W_p) && al16(p->W_s) && al16(p->W_h);
-  FwdLayer L = {};
-  L.M = B;
+  FwdLayer Ls[4] = {};
   // h_w = tanh(W_w (q_w + v_w) + b_w)
-  L.A = Comp{(const float*)q[0], (const float*)v[0], nullptr, d, d, 0};
-  L.W = (const float*)p->W_w; L.bias = (const float*)p->b_w; L.C = sv + hs.hw; L.ldc = d; L.act = 1; L.N = d; L.K = d;
-  CA_TRY(launch_fwd(L, vec, s));
+  Ls[0].A = Comp{(const float*)q[0], (const float*)v[0], nullptr, d, d, 0};
+  Ls[0].W = (const float*)p->W_w; Ls[0].bias = (const float*)p->b_w; Ls[0].C = sv + hs.hw; Ls[0].ldc = d; Ls[0].act = 1; Ls[0].N = d; Ls[0].K = d;
   // h_p = tanh(W_p [q_p + v_p | h_w] + b_p)
-  L.A = Comp{(const float*)q[1], (const float*)v[1], sv + hs.hw, d, d, d};
-  L.W = (const float*)p->W_p; L.bias = (const float*)p->b_p; L.C = sv + hs.hp; L.N = d; L.K = 2 * d;
-  CA_TRY(launch_fwd(L, vec, s));
+  Ls[1].A = Comp{(const float*)q[1], (const float*)v[1], sv + hs.hw, d, d, d};
+  Ls[1].W = (const float*)p->W_p; Ls[1].bias = (const float*)p->b_p; Ls[1].C = sv + hs.hp; Ls[1].ldc = d; Ls[1].act = 1; Ls[1].N = d; Ls[1].K = 2 * d;
   // h_s = tanh(W_s [q_s + v_s | h_p] + b_s)
-  L.A = Comp{(const float*)q[2], (const float*)v[2], sv + hs.hp, d, d, d};
-  L.W = (const float*)p->W_s; L.bias = (const float*)p->b_s; L.C = sv + hs.hs; L.ldc = mlp; L.N = mlp; L.K = 2 * d;
-  CA_TRY(launch_fwd(L, vec, s));
+  Ls[2].A = Comp{(const float*)q[2], (const float*)v[2], sv + hs.hp, d, d, d};
+  Ls[2].W = (const float*)p->W_s; Ls[2].bias = (const float*)p->b_s; Ls[2].C = sv + hs.hs; Ls[2].ldc = mlp; Ls[2].act = 1; Ls[2].N = mlp; Ls[2].K = 2 * d;
   // logits = W_h h_s + b_h
-  L.A = Comp{nullptr, nullptr, sv + hs.hs, 0, 0, mlp};
-  L.W = (const float*)p->W_h; L.bias = (const float*)p->b_h; L.C = (float*)logits; L.ldc = K; L.act = 0; L.N = K; L.K = mlp;
-  CA_TRY(launch_fwd(L, vec, s));
+  Ls[3].A = Comp{nullptr, nullptr, sv + hs.hs, 0, 0, mlp};
+  Ls[3].W = (const float*)p->W_h; Ls[3].bias = (const float*)p->b_h; Ls[3].C = (float*)logits; Ls[3].ldc = K; Ls[3].act = 0; Ls[3].N = K; Ls[3].K = mlp;
+  for (int l = 0; l < 4; ++l) Ls[l].M = B;
+  if (flags & COATTN_HEAD_PERSISTENT) {
+    FwdAll all = {};
+    int most = 0;
+    for (int l = 0; l < 4; ++l) { all.L[l] = Ls[l]; const int t = ((B + 31) / 32) * ((Ls[l].N + 31) / 32); most = t > most ? t : most; }
+    all.bar = reinterpret_cast<unsigned*>(sv + hs.st) + 8;          // (behind the cross entropy's status word)
+    CA_CHECK_ARG(hipMemsetAsync(all.bar, 0, 16, s) == hipSuccess, "head_forward: clearing the barrier words failed");
+    const unsigned grid = (unsigned)(most < 256 ? most : 256);      // at most one workgroup per CU: all resident
+    if (vec) hipLaunchKernelGGL(head_fwd_persistent_kernel<true>, dim3(grid), dim3(kThreads), 0, s, all);
+    else hipLaunchKernelGGL(head_fwd_persistent_kernel<false>, dim3(grid), dim3(kThreads), 0, s, all);
+    CA_CHECK_LAUNCH("head_fwd_persistent");
+  } else {
+    for (int l = 0; l < 4; ++l) CA_TRY(launch_fwd(Ls[l], vec, s));
+  }
   if (labels) CA_TRY(launch_ce_rows((const float*)logits, labels, sv + hs.rl, sv + hs.dl, (float*)loss, B, K, reinterpret_cast<int*>(sv + hs.st), s));
   return 0;
 }
@@ -518,7 +591,6 @@ extern "C" int coattn_head_backward(const void* const* v, const void* const* q, 
                                     const void* g_loss, const void* g_logits, void* const* dv, void* const* dq,
                                     const coattn_head_param_grads* pg, int accumulate, void* ws, int B, int d, int mlp, int K,
                                     int dtype, int flags, void* stream) {
-  (void)flags;
   CA_TRY(check_dims(B, d, mlp, K, dtype));
   CA_CHECK_ARG(v && q && p && saved && pg && ws, "head_backward: null argument");
   CA_CHECK_ARG(g_loss || g_logits, "head_backward: neither g_loss nor g_logits given");
@@ -536,33 +608,59 @@ extern "C" int coattn_head_backward(const void* const* v, const void* const* q, 
   const bool vec_h = vec && (K % 4) == 0 && (!g_logits || al16(g_logits));    // dY rows of the last layer: K floats
   auto D = [&](int l) { return dv ? (float*)dv[l] : nullptr; };
   auto D2 = [&](int l) { return (dq && dq[l] != dv[l]) ? (float*)dq[l] : nullptr; };
-  BwdLayer L = {};
-  L.M = B; L.accumulate = accumulate;
+  BwdLayer Ls[4] = {};
   // logits = W_h h_s + b_h:  d h_s -> d z_s = d h_s (1 - h_s^2);  dW_h = dlogits^T h_s
-  if (g_loss) L.Y = DY{sv + hs.dl, (const float*)g_loss, (const float*)g_logits, K};
-  else L.Y = DY{(const float*)g_logits, nullptr, nullptr, K};
-  L.W = (const float*)p->W_h; L.X = Comp{nullptr, nullptr, sv + hs.hs, 0, 0, mlp};
-  L.o = TileOut{}; L.o.hsplit = 0; L.o.hid = sv + hs.hs; L.o.ldhid = mlp; L.o.Ch = w + hb.dzs; L.o.ldch = mlp;
-  L.dW = (float*)pg->dW_h; L.db = (float*)pg->db_h; L.N = K; L.Kin = mlp;
-  CA_TRY(launch_bwd(L, true, vec_h, s));
+  {
+    BwdLayer& L = Ls[0];
+    if (g_loss) L.Y = DY{sv + hs.dl, (const float*)g_loss, (const float*)g_logits, K};
+    else L.Y = DY{(const float*)g_logits, nullptr, nullptr, K};
+    L.W = (const float*)p->W_h; L.X = Comp{nullptr, nullptr, sv + hs.hs, 0, 0, mlp};
+    L.o = TileOut{}; L.o.hsplit = 0; L.o.hid = sv + hs.hs; L.o.ldhid = mlp; L.o.Ch = w + hb.dzs; L.o.ldch = mlp;
+    L.dW = (float*)pg->dW_h; L.db = (float*)pg->db_h; L.N = K; L.Kin = mlp;
+  }
   // h_s = tanh(W_s [q_s + v_s | h_p] + b_s):  d(q_s + v_s), d z_p;  dW_s
-  L.Y = DY{w + hb.dzs, nullptr, nullptr, mlp};
-  L.W = (const float*)p->W_s; L.X = Comp{(const float*)q[2], (const float*)v[2], sv + hs.hp, d, d, d};
-  L.o = TileOut{}; L.o.C = D(2); L.o.C2 = D2(2); L.o.ldc = d; L.o.hsplit = d; L.o.hid = sv + hs.hp; L.o.ldhid = d;
-  L.o.Ch = w + hb.dzp; L.o.ldch = d;
-  L.dW = (float*)pg->dW_s; L.db = (float*)pg->db_s; L.N = mlp; L.Kin = 2 * d;
-  CA_TRY(launch_bwd(L, true, vec, s));
+  {
+    BwdLayer& L = Ls[1];
+    L.Y = DY{w + hb.dzs, nullptr, nullptr, mlp};
+    L.W = (const float*)p->W_s; L.X = Comp{(const float*)q[2], (const float*)v[2], sv + hs.hp, d, d, d};
+    L.o = TileOut{}; L.o.C = D(2); L.o.C2 = D2(2); L.o.ldc = d; L.o.hsplit = d; L.o.hid = sv + hs.hp; L.o.ldhid = d;
+    L.o.Ch = w + hb.dzp; L.o.ldch = d;
+    L.dW = (float*)pg->dW_s; L.db = (float*)pg->db_s; L.N = mlp; L.Kin = 2 * d;
+  }
   // h_p = tanh(W_p [q_p + v_p | h_w] + b_p)
-  L.Y = DY{w + hb.dzp, nullptr, nullptr, d};
-  L.W = (const float*)p->W_p; L.X = Comp{(const float*)q[1], (const float*)v[1], sv + hs.hw, d, d, d};
-  L.o = TileOut{}; L.o.C = D(1); L.o.C2 = D2(1); L.o.ldc = d; L.o.hsplit = d; L.o.hid = sv + hs.hw; L.o.ldhid = d;
-  L.o.Ch = w + hb.dzw; L.o.ldch = d;
-  L.dW = (float*)pg->dW_p; L.db = (float*)pg->db_p; L.N = d; L.Kin = 2 * d;
-  CA_TRY(launch_bwd(L, true, vec, s));
+  {
+    BwdLayer& L = Ls[2];
+    L.Y = DY{w + hb.dzp, nullptr, nullptr, d};
+    L.W = (const float*)p->W_p; L.X = Comp{(const float*)q[1], (const float*)v[1], sv + hs.hw, d, d, d};
+    L.o = TileOut{}; L.o.C = D(1); L.o.C2 = D2(1); L.o.ldc = d; L.o.hsplit = d; L.o.hid = sv + hs.hw; L.o.ldhid = d;
+    L.o.Ch = w + hb.dzw; L.o.ldch = d;
+    L.dW = (float*)pg->dW_p; L.db = (float*)pg->db_p; L.N = d; L.Kin = 2 * d;
+  }
   // h_w = tanh(W_w (q_w + v_w) + b_w)
-  L.Y = DY{w + hb.dzw, nullptr, nullptr, d};
-  L.W = (const float*)p->W_w; L.X = Comp{(const float*)q[0], (const float*)v[0], nullptr, d, d, 0};
-  L.o = TileOut{}; L.o.C = D(0); L.o.C2 = D2(0); L.o.ldc = d; L.o.hsplit = 0x7fffffff;
-  L.dW = (float*)pg->dW_w; L.db = (float*)pg->db_w; L.N = d; L.Kin = d;
-  return launch_bwd(L, dv != nullptr, vec, s);
+  {
+    BwdLayer& L = Ls[3];
+    L.Y = DY{w + hb.dzw, nullptr, nullptr, d};
+    L.W = (const float*)p->W_w; L.X = Comp{(const float*)q[0], (const float*)v[0], nullptr, d, d, 0};
+    L.o = TileOut{}; L.o.C = D(0); L.o.C2 = D2(0); L.o.ldc = d; L.o.hsplit = 0x7fffffff;
+    L.dW = (float*)pg->dW_w; L.db = (float*)pg->db_w; L.N = d; L.Kin = d;
+  }
+  for (int l = 0; l < 4; ++l) { Ls[l].M = B; Ls[l].accumulate = accumulate; }
+  if (flags & COATTN_HEAD_PERSISTENT) {
+    BwdAll all = {};
+    for (int l = 0; l < 4; ++l) {
+      all.L[l] = Ls[l];
+      all.L[l].nx = (l < 3 || dv) ? ((B + 31) / 32) * ((Ls[l].Kin + 31) / 32) : 0;
+    }
+    all.vec0 = vec_h;
+    all.bar = reinterpret_cast<unsigned*>(w + hb.total);            // two words behind the backward workspace
+    CA_CHECK_ARG(hipMemsetAsync(all.bar, 0, 16, s) == hipSuccess, "head_backward: clearing the barrier words failed");
+    if (vec) hipLaunchKernelGGL(head_bwd_persistent_kernel<true>, dim3(256), dim3(kThreads), 0, s, all);
+    else hipLaunchKernelGGL(head_bwd_persistent_kernel<false>, dim3(256), dim3(kThreads), 0, s, all);
+    CA_CHECK_LAUNCH("head_bwd_persistent");
+    return 0;
+  }
+  CA_TRY(launch_bwd(Ls[0], true, vec_h, s));
+  CA_TRY(launch_bwd(Ls[1], true, vec, s));
+  CA_TRY(launch_bwd(Ls[2], true, vec, s));
+  return launch_bwd(Ls[3], dv != nullptr, vec, s);
 }

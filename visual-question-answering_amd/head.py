@@ -8,6 +8,7 @@ tile products; with labels the loss and d loss / d logits come out of the same f
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -31,6 +32,11 @@ def _workspace_bytes(B, d, mlp, K):
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _flags() -> int:
+    """VQA_HEAD_PERSISTENT=1 (developer switch): one launch per direction with grid-wide barriers between the layers."""
+    return 1 if os.environ.get("VQA_HEAD_PERSISTENT", "0") not in ("0", "") else 0
 
 
 def _rows(t):
@@ -71,7 +77,7 @@ class _HeadFn(torch.autograd.Function):
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         with torch.cuda.device(dev):
             _lib.check(lib.coattn_head_forward(_rows(v), _rows(q), C.byref(p), _ptr(lab), _ptr(logits), _ptr(loss),
-                                               _ptr(saved), B, d, mlp, K, _lib.F32, 0, stream), "coattn_head_forward")
+                                               _ptr(saved), B, d, mlp, K, _lib.F32, _flags(), stream), "coattn_head_forward")
         if labels is not None:
             global _last
             _last = (saved, B, d, mlp, K, dev)
@@ -105,7 +111,7 @@ class _HeadFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.check(lib.coattn_head_backward(_rows(v), _rows(q), C.byref(p), _ptr(saved), _ptr(g_loss), _ptr(g_logits),
                                                 _rows(dx) if need_in else None, None, C.byref(pg), 0, _ptr(ws),
-                                                B, d, mlp, K, _lib.F32, 0, C.c_void_p(stream)), "coattn_head_backward")
+                                                B, d, mlp, K, _lib.F32, _flags(), C.c_void_p(stream)), "coattn_head_backward")
         return (dx if ctx.needs_input_grad[0] else None, dx if ctx.needs_input_grad[1] else None, *grads, None)
 
 

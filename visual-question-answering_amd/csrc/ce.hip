@@ -30,7 +30,7 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 // coattn_ce_status reports it at the caller's next synchronisation point).
 __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
                                                       float* __restrict__ row_loss, float* __restrict__ dlogits, int K,
-                                                      float inv_b, int* __restrict__ status) {
+                                                      float inv_b, int* __restrict__ status, int ldd) {
   __shared__ float sh[4];
   const int i = blockIdx.x;
   const float* z = logits + (long)i * K;
@@ -48,8 +48,8 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
   }
   if (dlogits) {
     const float inv = inv_b / s;
-    for (int k = threadIdx.x; k < K; k += 256)
-      dlogits[(long)i * K + k] = expf(z[k] - m) * inv - ((ok && k == lab) ? inv_b : 0.f);
+    for (int k = threadIdx.x; k < ldd; k += 256)     // rows ldd >= K floats apart, the padding zeroed
+      dlogits[(long)i * ldd + k] = k < K ? expf(z[k] - m) * inv - ((ok && k == lab) ? inv_b : 0.f) : 0.f;
   }
 }
 
@@ -57,15 +57,15 @@ inline size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
 
 }  // namespace
 
-// rows + mean for the answer head (head.hip): row_loss [B] scratch, dlogits [B,K] or NULL
+// rows + mean for the answer head (head.hip): row_loss [B] scratch, dlogits [B][ldd] (ldd = 0: K) or NULL
 int launch_ce_rows(const float* logits, const void* labels, float* row_loss, float* dlogits, float* loss, int B, int K,
-                   int* status, hipStream_t s) {
+                   int* status, hipStream_t s, int ldd) {
   if (hipMemsetAsync(status, 0, 16, s) != hipSuccess) {       // (a memset node under graph capture)
     coattn_set_error("ce: clearing the status word failed");
     return -3;
   }
   hipLaunchKernelGGL(ce_rows_kernel, dim3(B), dim3(256), 0, s, logits, (const long long*)labels, row_loss, dlogits, K,
-                     1.0f / (float)B, status);
+                     1.0f / (float)B, status, ldd > 0 ? ldd : K);
   CA_CHECK_LAUNCH("ce_rows");
   return launch_sum_all(row_loss, loss, B, 0, s);
 }
@@ -106,5 +106,5 @@ extern "C" int coattn_ce_forward(const void* logits, const void* labels, void* l
   CA_CHECK_ARG(logits && labels && loss && ws, "ce_forward: null argument");                   // dlogits may be NULL
   hipStream_t s = (hipStream_t)stream;
   return launch_ce_rows((const float*)logits, labels, (float*)ws, (float*)dlogits, (float*)loss, B, K,
-                        reinterpret_cast<int*>((float*)ws + al64((size_t)B)), s);
+                        reinterpret_cast<int*>((float*)ws + al64((size_t)B)), s, 0);
 }

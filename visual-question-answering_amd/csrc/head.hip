@@ -63,7 +63,7 @@ struct Comp {
 };
 // upstream gradient operand: dY(m, n) = p[m][n] * (scale ? scale[0] : 1) + (add ? add[m][n] : 0)
 struct DY {
-  const float* p; const float* scale; const float* add; int ld;
+  const float* p; const float* scale; const float* add; int ld, ld_add;    // rows of p / of add this many floats apart
 };
 struct CompR {                    // Comp with descriptors over M rows, K columns in all
   rsrc_t x0, x1, h; int ksplit, ld0, ldh, K; bool two;
@@ -74,11 +74,11 @@ __device__ __forceinline__ CompR comp_rsrc(const Comp& c, int M, int K) {
   r.ksplit = c.ksplit; r.ld0 = c.ld0; r.ldh = c.ldh; r.K = K; r.two = c.x1 != nullptr;
   return r;
 }
-struct DYR { rsrc_t p, add; int ld, N; bool has_add; float sc; };
+struct DYR { rsrc_t p, add; int ld, ld_add, N; bool has_add; float sc; };
 __device__ __forceinline__ DYR dy_rsrc(const DY& d, int M, int N) {
   DYR r;
-  r.p = mk_rsrc(d.p, (long)M * d.ld * 4); r.add = mk_rsrc(d.add, (long)M * d.ld * 4);
-  r.ld = d.ld; r.N = N; r.has_add = d.add != nullptr; r.sc = d.scale ? d.scale[0] : 1.f;
+  r.p = mk_rsrc(d.p, (long)M * d.ld * 4); r.add = mk_rsrc(d.add, (long)M * d.ld_add * 4);
+  r.ld = d.ld; r.ld_add = d.ld_add; r.N = N; r.has_add = d.add != nullptr; r.sc = d.scale ? d.scale[0] : 1.f;
   return r;
 }
 
@@ -134,7 +134,7 @@ __device__ __forceinline__ void stage_dy(Stage2& s, const DYR& y, int lane, int 
   s.sc = y.sc;
   s.two = y.has_add;
   stage_lin<VEC>(s.a, y.p, y.ld, y.N, lane, m0, n0);
-  if (y.has_add) stage_lin<VEC>(s.b, y.add, y.ld, y.N, lane, m0, n0);
+  if (y.has_add) stage_lin<VEC>(s.b, y.add, y.ld_add, y.N, lane, m0, n0);
 }
 template <bool VEC>
 __device__ __forceinline__ void stage_store(const Stage& s, float* img, int lane);
@@ -302,7 +302,7 @@ __device__ __forceinline__ void dw_tile(const DY& Y, const Comp& X, float* __res
   const CompR xr = comp_rsrc(X, M, Kin);
   const bool a_ok = n0 + li < N;
   // a lane per tile column, two batch rows per instruction (the lane halves); rows >= M are out of range and read 0
-  const int avoff = a_ok ? (lh * yr.ld + n0 + li) * 4 : kOut;
+  const int avoff = a_ok ? (lh * yr.ld + n0 + li) * 4 : kOut, avoff_add = a_ok ? (lh * yr.ld_add + n0 + li) * 4 : kOut;
   const int k = k0 + li;
   const int v0 = k < xr.ksplit ? (lh * xr.ld0 + k) * 4 : kOut;
   const int vh = (k >= xr.ksplit && k < Kin) ? (lh * xr.ldh + k - xr.ksplit) * 4 : kOut;
@@ -319,7 +319,7 @@ __device__ __forceinline__ void dw_tile(const DY& Y, const Comp& X, float* __res
       for (int s = 0; s < 16; ++s) {
         const int m = mc + 2 * s;
         fa[s] = bl1(yr.p, avoff, m * yr.ld * 4);
-        if constexpr (MODE == 2) fa[s] = fa[s] * yr.sc + bl1(yr.add, avoff, m * yr.ld * 4);
+        if constexpr (MODE == 2) fa[s] = fa[s] * yr.sc + bl1(yr.add, avoff_add, m * yr.ld_add * 4);
         if constexpr (MODE == 0) fb[s] = bl1(xr.x0, v0, m * xr.ld0 * 4) + bl1(xr.x1, v0, m * xr.ld0 * 4);
         if constexpr (MODE == 1) fb[s] = bl1(xr.h, vh, m * xr.ldh * 4);
         if constexpr (MODE == 2) fb[s] = bl1(xr.x0, v0, m * xr.ld0 * 4) + bl1(xr.x1, v0, m * xr.ld0 * 4) + bl1(xr.h, vh, m * xr.ldh * 4);
@@ -469,6 +469,7 @@ __global__ __launch_bounds__(kThreads) void head_bwd_persistent_kernel(const Bwd
 }
 
 inline size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
+inline int kpad(int K) { return (K + 3) & ~3; }   // row stride of the saved d loss / d logits: whole-line staging in the backward
 struct HeadSaved { size_t hw, hp, hs, dl, rl, st, total; };
 inline HeadSaved head_saved(int B, int d, int mlp, int K) {
   HeadSaved s;
@@ -476,7 +477,7 @@ inline HeadSaved head_saved(int B, int d, int mlp, int K) {
   s.hw = o; o += al64((size_t)B * d);
   s.hp = o; o += al64((size_t)B * d);
   s.hs = o; o += al64((size_t)B * mlp);
-  s.dl = o; o += al64((size_t)B * K);      // d loss / d logits (written by the forward when labels are given)
+  s.dl = o; o += al64((size_t)B * kpad(K)); // d loss / d logits (written by the forward when labels are given), rows padded to 16 bytes
   s.rl = o; o += al64((size_t)B);          // row losses
   s.st = o; o += 64;                       // status word of the cross entropy (label out of range)
   s.total = o;
@@ -526,7 +527,7 @@ int launch_bwd(BwdLayer& L, bool want_dx, bool vec, hipStream_t s) {
 }  // namespace
 
 // cross entropy rows + mean (ce.hip)
-int launch_ce_rows(const float* logits, const void* labels, float* row_loss, float* dlogits, float* loss, int B, int K, int* status, hipStream_t s);
+int launch_ce_rows(const float* logits, const void* labels, float* row_loss, float* dlogits, float* loss, int B, int K, int* status, hipStream_t s, int ldd);
 int head_status_check(const int* status_dev, void* stream);
 
 extern "C" int coattn_head_workspace_bytes(int B, int d, int mlp, int K, int dtype, size_t* saved, size_t* ws_bwd) {
@@ -577,7 +578,7 @@ extern "C" int coattn_head_forward(const void* const* v, const void* const* q, c
   } else {
     for (int l = 0; l < 4; ++l) CA_TRY(launch_fwd(Ls[l], vec, s));
   }
-  if (labels) CA_TRY(launch_ce_rows((const float*)logits, labels, sv + hs.rl, sv + hs.dl, (float*)loss, B, K, reinterpret_cast<int*>(sv + hs.st), s));
+  if (labels) CA_TRY(launch_ce_rows((const float*)logits, labels, sv + hs.rl, sv + hs.dl, (float*)loss, B, K, reinterpret_cast<int*>(sv + hs.st), s, kpad(K)));
   return 0;
 }
 
@@ -605,15 +606,16 @@ extern "C" int coattn_head_backward(const void* const* v, const void* const* q, 
   const HeadSaved hs = head_saved(B, d, mlp, K);
   const HeadBwd hb = head_bwd(B, d, mlp);
   bool vec = (d % 32) == 0 && (mlp % 32) == 0 && al16(sv) && al16(w);
-  const bool vec_h = vec && (K % 4) == 0 && (!g_logits || al16(g_logits));    // dY rows of the last layer: K floats
+  // dY rows of the last layer: the saved d loss / d logits has padded rows; an added g_logits has rows of K floats
+  const bool vec_h = vec && (!g_logits || ((K % 4) == 0 && al16(g_logits)));
   auto D = [&](int l) { return dv ? (float*)dv[l] : nullptr; };
   auto D2 = [&](int l) { return (dq && dq[l] != dv[l]) ? (float*)dq[l] : nullptr; };
   BwdLayer Ls[4] = {};
   // logits = W_h h_s + b_h:  d h_s -> d z_s = d h_s (1 - h_s^2);  dW_h = dlogits^T h_s
   {
     BwdLayer& L = Ls[0];
-    if (g_loss) L.Y = DY{sv + hs.dl, (const float*)g_loss, (const float*)g_logits, K};
-    else L.Y = DY{(const float*)g_logits, nullptr, nullptr, K};
+    if (g_loss) L.Y = DY{sv + hs.dl, (const float*)g_loss, (const float*)g_logits, kpad(K), K};
+    else L.Y = DY{(const float*)g_logits, nullptr, nullptr, K, K};
     L.W = (const float*)p->W_h; L.X = Comp{nullptr, nullptr, sv + hs.hs, 0, 0, mlp};
     L.o = TileOut{}; L.o.hsplit = 0; L.o.hid = sv + hs.hs; L.o.ldhid = mlp; L.o.Ch = w + hb.dzs; L.o.ldch = mlp;
     L.dW = (float*)pg->dW_h; L.db = (float*)pg->db_h; L.N = K; L.Kin = mlp;

@@ -58,12 +58,12 @@ __global__ __launch_bounds__(256) void wsplit_kernel(const SplitArgs a) {
 
 // Up to two independent GEMMs per launch (P_v and P_q of the forward): the second one's workgroups fill the slots
 // the first one's last, partial round of workgroups would leave idle.  AM0: layout of job 0's A operand.
-template <bool AM0, bool P1>
-__global__ __launch_bounds__(256, 2) void gemm_w_kernel(const WJobs jobs) {
-  __shared__ __attribute__((aligned(16))) short smem[2 * 3 * BM * LDR];  // 61,440 B: two workgroups per CU
+template <bool AM0, bool P1, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void gemm_w_kernel(const WJobs jobs) {
+  __shared__ __attribute__((aligned(16))) short smem[2 * 3 * BM * LDR];  // 61,440 B: two workgroups of 256 threads per CU
   static_assert(BM * LDR == BK * LDT, "both image layouts have the same size");
-  if ((int)blockIdx.x < jobs.first1) gemm_w_body<AM0, P1>(jobs.job[0], (int)blockIdx.x, smem);
-  else gemm_w_body<false, P1>(jobs.job[1], (int)blockIdx.x - jobs.first1, smem);
+  if ((int)blockIdx.x < jobs.first1) gemm_w_body<AM0, P1, NW>(jobs.job[0], (int)blockIdx.x, smem);
+  else gemm_w_body<false, P1, NW>(jobs.job[1], (int)blockIdx.x - jobs.first1, smem);
 }
 
 }  // namespace
@@ -100,14 +100,14 @@ int gemm_w_supported(const WGemm& d) {
   return ok ? 1 : 0;
 }
 
-int gemm_w_fill_job(const WGemm& d, gw::WArgs& g, long* nblk) {
+int gemm_w_fill_job(const WGemm& d, gw::WArgs& g, long* nblk, int bn) {
   CA_CHECK_ARG(gemm_w_supported(d), "gemm_w: unsupported shape M=%d N=%d K=%d", d.M, d.N, d.K);
   CA_CHECK_ARG((d.A || d.a_ptrs[0]) && d.Wf && (d.C || d.c_ptrs[0]), "gemm_w: null operand");
   g = WArgs{};
   g.A = d.A; g.a_sz = d.a_sz; g.a_sm = d.a_sm; g.a_sk = d.a_sk; g.a_mdiv = d.a_mdiv; g.a_sdiv = d.a_sdiv;
   g.kband_n = d.kband_n;
   if (d.kband_n > 0) {
-    CA_CHECK_ARG(d.kband_n % BN == 0 && (d.N + d.kband_n - 1) / d.kband_n <= 3, "gemm_w: kband_n must be a multiple of 128 with at most 3 bands");
+    CA_CHECK_ARG(d.kband_n % bn == 0 && (d.N + d.kband_n - 1) / d.kband_n <= 3, "gemm_w: kband_n must be a multiple of the tile width with at most 3 bands");
     for (int t = 0; t < 3; ++t) {
       CA_CHECK_ARG(d.kband_lo[t] >= 0 && d.kband_hi[t] <= d.K && d.kband_lo[t] < d.kband_hi[t] && d.kband_lo[t] % BK == 0 && d.kband_hi[t] % BK == 0,
                    "gemm_w: k bands must lie in [0,K] and be multiples of 32");
@@ -119,7 +119,7 @@ int gemm_w_fill_job(const WGemm& d, gw::WArgs& g, long* nblk) {
   for (int t = 0; t < 8; ++t) { g.a_ptrs[t] = d.a_ptrs[t]; g.c_ptrs[t] = d.c_ptrs[t]; }
   g.bias_n = d.bias_n; g.oscale = d.out_scale != 0.f ? d.out_scale : 1.f;
   g.M = d.M; g.N = d.N; g.K = d.K;
-  const long ntn = (d.N + BN - 1) / BN, ntm = (d.M + BM - 1) / BM;
+  const long ntn = (d.N + bn - 1) / bn, ntm = (d.M + BM - 1) / BM;
   g.xcd_group = ntm >= 32 ? 1 : 0;
   *nblk = g.xcd_group ? (long)d.batch * ntn * ((ntm + 7) / 8) * 8 : (long)d.batch * ntn * ntm;
   return 0;
@@ -130,13 +130,19 @@ int launch_gemm_w(const WGemm* d, int n, hipStream_t s) {
   CA_CHECK_ARG(n == 1 || n == 2, "gemm_w: 1 or 2 jobs per launch");
   WJobs jobs = {};
   long nb[2] = {0, 0};
-  for (int i = 0; i < n; ++i) CA_TRY(gemm_w_fill_job(d[i], jobs.job[i], &nb[i]));
+  // single-product mode with wide outputs: 128 x 256 tiles on 512 threads (the A rows are staged once for twice the columns)
+  bool wide = d[0].bf16 != 0;
+  for (int i = 0; i < n; ++i) wide = wide && d[i].N % 256 == 0 && (d[i].kband_n == 0 || d[i].kband_n % 256 == 0);
+  for (int i = 0; i < n; ++i) CA_TRY(gemm_w_fill_job(d[i], jobs.job[i], &nb[i], wide ? 256 : BN));
   CA_CHECK_ARG(nb[0] + nb[1] < 2147483647L, "gemm_w: grid too large");
   jobs.first1 = (int)nb[0];
   CA_CHECK_ARG(n == 1 || d[1].a_sk == 0, "gemm_w: only the first job may have an m-contiguous A operand");
   CA_CHECK_ARG(n == 1 || d[1].bf16 == d[0].bf16, "gemm_w: the jobs of a launch share the precision mode");
   const dim3 grid((unsigned)(nb[0] + nb[1]));
-  if (d[0].bf16) {
+  if (wide) {
+    if (d[0].a_sk) hipLaunchKernelGGL((gemm_w_kernel<true, true, 8>), grid, dim3(512), 0, s, jobs);
+    else hipLaunchKernelGGL((gemm_w_kernel<false, true, 8>), grid, dim3(512), 0, s, jobs);
+  } else if (d[0].bf16) {
     if (d[0].a_sk) hipLaunchKernelGGL((gemm_w_kernel<true, true>), grid, dim3(256), 0, s, jobs);
     else hipLaunchKernelGGL((gemm_w_kernel<false, true>), grid, dim3(256), 0, s, jobs);
   } else {

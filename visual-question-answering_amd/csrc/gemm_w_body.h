@@ -6,7 +6,7 @@
 
 namespace gw {
 
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int BM = 128, BN = 128, BK = 32;    // (BN: the four-wave tile; gemm_w_body<.., 8> takes 256 columns)
 constexpr int LDR = 40;                        // [row][k] bf16 image row stride (elements): conflict-free b128 reads
 constexpr int kFragBytes = 1024;               // one fragment: 64 lanes x 8 bf16
 constexpr int kChunkBytes = 3 * kFragBytes;    // the three pieces of one (column tile, 16-k step)
@@ -31,10 +31,14 @@ constexpr int LDT = BM + 32;                   // AM: [k][row] image row stride 
 // P1 = true : reduced-precision mode (COATTN_FLAG_BF16_PROJ, the apex-O1 analogue): operands rounded to bf16 (the hi piece
 //             alone -- of A while it is staged, of the weight from its image), ONE MFMA per product; the schedule keeps
 //             its slots, the pieces that do not exist are neither computed, written, read nor multiplied.
-template <bool AM, bool P1 = false>
+// NW = 8    : 512-thread workgroups, tile 128 x 256 (the eight waves as 2 x 4): the A rows staged once serve twice the
+//             columns -- for the single-product mode at d = 2048, where the L2 -> CU traffic of A re-read by every
+//             column tile is the bound, not the MFMAs.
+template <bool AM, bool P1 = false, int NW = 4>
 __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short* const smem) {
+  constexpr int WCN = NW / 2, BN = 64 * WCN, NT = 64 * NW, AP = 1024 / NT;   // waves per tile row, tile width, threads, A float4 per thread and step
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int wr = wave / WCN, wc = wave % WCN, li = lane & 31, lh = lane >> 5;
   // XCD-aware tile order (as gemm.hip): the column tiles of one row tile share an XCD's L2
   // (with k bands the column tiles are taken from the right: the bands with the long contractions start first)
   int m0, n0, z;
@@ -69,15 +73,15 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
 
   // A staging: 4 float4 per thread and step; a wave's load covers 8 rows x 128 B (whole lines)
   // (AM: float4 = 4 consecutive rows of one k; a wave's load covers 2 k x 512 B; a_mdiv % 4 == 0 keeps the 4 rows in one sample)
-  int a_voff[4], a_lds[4];
+  int a_voff[AP], a_lds[AP];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < AP; ++i) {
     if (AM) {
-      const int k = (tid >> 5) + 8 * i, m = (tid & 31) * 4, row = m0 + m;
+      const int k = (tid >> 5) + (NT / 32) * i, m = (tid & 31) * 4, row = m0 + m;
       a_voff[i] = row < g.M ? (int)(((long)(row / g.a_mdiv) * g.a_sdiv + row % g.a_mdiv + (long)k * g.a_sk) * 4) : 0x40000000;
       a_lds[i] = k * LDT + m;
     } else {
-      const int m = (tid >> 3) + 32 * i, k = (tid & 7) * 4;
+      const int m = (tid >> 3) + (NT / 8) * i, k = (tid & 7) * 4;
       a_voff[i] = (m0 + m) < g.M ? ((m0 + m) * g.a_sm + k) * 4 : 0x40000000;   // rows past M read 0
       a_lds[i] = m * LDR + k;
     }
@@ -111,7 +115,7 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
   //                consumed it, the split pieces go to the other LDS image; one barrier per step (in half 1),
   //                after it the A fragments of the next step's first half are read
   //   A fragments: af[h] for half h; those of half 1 are read during half 0
-  f32x4 raw[4];
+  f32x4 raw[AP];
   bf16x8 bq[3][2][3];                            // [ring][tile j][piece]
   bf16x8 af[2][3][2];                            // [half][piece][tile i]
   unsigned ph[2], pm[2], pl[2];                  // packed pieces of the raw[i] being split (its two pairs)
@@ -120,7 +124,7 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
   constexpr int PB[6] = {0, 2, 1, 0, 1, 0};      // (gemm.hip's order)
   constexpr int RQ[3] = {2, 0, 1};               // fragment read order = order of first use
   constexpr int IMG = BM * LDR;                  // elements of one piece image
-  auto load_a = [&](int i, int s) { raw[i] = buf_load4(rs_a, a_voff[i], (s + s0) * a_kstep); };
+  auto load_a = [&](int i, int s) { if (i < AP) raw[i] = buf_load4(rs_a, a_voff[i], (s + s0) * a_kstep); };
   auto load_b = [&](int ring, int k, int half) {
     const int j = k / 3, q = k % 3;
     if (P1 && q != 0) return;
@@ -139,6 +143,7 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
   };
   // split of raw[i], pair e (0 | 1), in three stages of 5, 5 and 1 VALU instructions
   auto stage = [&](int i, int e, int st) {
+    if (i >= AP) return;
     if (P1) {
       if (st == 0) ph[e] = cvt_pk_bf16(raw[i][2 * e], raw[i][2 * e + 1]);
       return;
@@ -160,6 +165,7 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
 #endif
   };
   auto write_a = [&](short* img, int i, int q) {
+    if (i >= AP) return;
     if (P1 && q != 0) return;
     const u32x2 v = q == 0 ? u32x2{ph[0], ph[1]} : (q == 1 ? u32x2{pm[0], pm[1]} : u32x2{pl[0], pl[1]});
     *reinterpret_cast<u32x2*>(&img[q * IMG + a_lds[i]]) = v;
@@ -203,13 +209,13 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
 
   // prologue: step 0 split into image 0, raw = step 1, B halves 0 and 1 in flight, fragments of half 0 read
 #pragma unroll
-  for (int i = 0; i < 4; ++i) load_a(i, 0);
+  for (int i = 0; i < AP; ++i) load_a(i, 0);
 #pragma unroll
   for (int k = 0; k < 6; ++k) { load_b(0, k, 0); load_b(1, k, 1); }
   short* const img0 = smem;
   short* const img1 = smem + 3 * IMG;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < AP; ++i) {
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
@@ -265,4 +271,4 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
 }  // namespace gw
 
 // host side (gemm_w.hip): checks `d`, fills the kernel arguments and the number of workgroups
-int gemm_w_fill_job(const WGemm& d, gw::WArgs& g, long* nblk);
+int gemm_w_fill_job(const WGemm& d, gw::WArgs& g, long* nblk, int bn = gw::BN);

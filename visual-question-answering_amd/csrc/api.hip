@@ -105,10 +105,10 @@ extern "C" int coattn_linear_forward(const void* x, int64_t ld_x, const void* W,
   g.bf16 = (flags & COATTN_FLAG_BF16_PROJ) ? 1 : 0;
   CA_CHECK_ARG(gemm_w_supported(g), "linear: shape M=%d N=%d K=%d ld=%ld not supported (see coattn.h)", M, N, K, (long)ld_x);
   if (!(flags & 1)) {
-    const WSplit job{(const float*)W, wimg, N, K, 0, K};
+    const WSplit job{(const float*)W, wimg, N, K, 0, K, wimg_pieces(g)};
     CA_TRY(launch_wsplit(&job, 1, (hipStream_t)stream));
   }
-  return launch_gemm_w(&g, 1, (hipStream_t)stream);
+  return launch_gemm_wx(&g, 1, (hipStream_t)stream);
 }
 
 extern "C" size_t coattn_linear_wgrad_workspace_bytes(int n_out, int n_in) {
@@ -236,18 +236,20 @@ int general_projections(const Ctx& c, const float* V, const float* const* Q, con
   if (v_w || q_w) {
     WSplit jobs[3];
     int nj = 0;
-    if (v_w) jobs[nj++] = WSplit{(const float*)p->W_v, const_cast<void*>(wv.Wf), c.d, c.d, 0, c.d};
-    if (q_w) jobs[nj++] = WSplit{(const float*)p->W_q, const_cast<void*>(wq.Wf), c.d, c.d, 0, c.d};
-    if (q_w && keep_wqT) jobs[nj++] = WSplit{(const float*)p->W_q, sv + sp.wqT, c.d, c.d, 1, c.d};
+    // (the image of W_q^T is read by the backward's dQ projection: a GEMM of P_q's shape with row-major A in the same
+    //  precision mode, so it runs on the same kernel as P_q and wants the same image format)
+    if (v_w) jobs[nj++] = WSplit{(const float*)p->W_v, const_cast<void*>(wv.Wf), c.d, c.d, 0, c.d, wimg_pieces(wv)};
+    if (q_w) jobs[nj++] = WSplit{(const float*)p->W_q, const_cast<void*>(wq.Wf), c.d, c.d, 0, c.d, wimg_pieces(wq)};
+    if (q_w && keep_wqT) jobs[nj++] = WSplit{(const float*)p->W_q, sv + sp.wqT, c.d, c.d, 1, c.d, wimg_pieces(wq)};
     CA_TRY(launch_wsplit(jobs, nj, c.s));
   }
   if (v_w && q_w) {                                   // both projections in one launch
     const WGemm both[2] = {wv, wq};
-    return launch_gemm_w(both, 2, c.s);
+    return launch_gemm_wx(both, 2, c.s);
   }
-  if (v_w) CA_TRY(launch_gemm_w(&wv, 1, c.s));
+  if (v_w) CA_TRY(launch_gemm_wx(&wv, 1, c.s));
   else CA_TRY(proj_v(c, V, (const float*)p->W_v, (const float*)p->b_v, sv + sp.Pv));
-  if (q_w) return launch_gemm_w(&wq, 1, c.s);
+  if (q_w) return launch_gemm_wx(&wq, 1, c.s);
   // P_q of all levels in one launch: batch z = level, A from the pointer table
   coattn_gemm_desc g = {};
   for (int l = 0; l < c.L; ++l) g.a_ptrs[l] = Q[l];

@@ -391,7 +391,8 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   for (int l = 0; l < L; ++l) q_al = q_al && (((uintptr_t)Q[l]) & 15) == 0;
   wdq.bf16 = bf16_proj;
   const bool wdq_ok = wgemm && q_al && gemm_w_supported(wdq);
-  const bool combine = dq32 && wdq_ok && tn_v && tn_q;
+  // (a dQ projection on gemm_bf.hip -- 512-thread workgroups -- cannot ride in the weight-gradient launch)
+  const bool combine = dq32 && wdq_ok && tn_v && tn_q && !gemm_bf_supported(wdq);
   // 3. small parameter gradients from the per-(sample, level) partials (dw_v, db_v, db_q, dw_q, and dc_v, dc_q as
   //    whole-array sums): a few short workgroups -- riding along in the weight-gradient launch of step 5 when that
   //    is the hand-scheduled one, else a launch of their own
@@ -411,7 +412,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   auto dq_projection = [&](bool onto_dq) -> int {
     // (W_q split once by the forward's launch -- the same shape test decided there, api.hip general_projections --
     //  and read as MFMA fragments, gemm_w.hip)
-    if (!onto_dq && wdq_ok) return launch_gemm_w(&wdq, 1, s);
+    if (!onto_dq && wdq_ok) return launch_gemm_wx(&wdq, 1, s);
     coattn_gemm_desc g = {};
     g.A = ws + wo.dPq; g.a_sz = (int64_t)BTd; g.a_sm = d; g.a_sk = 1;
     g.B = p->W_q; g.b_sk = d; g.b_sn = 1;

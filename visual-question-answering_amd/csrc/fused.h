@@ -128,7 +128,7 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, int voff, i
 }
 
 // ---- GEMM against a pre-split weight (gemm_w.hip) ---------------------------------------------------------------
-struct WSplit { const float* W; void* out; int N, K, trans, ld; };   // Bw(k,n) = trans ? W[k*ld+n] : W[n*ld+k]
+struct WSplit { const float* W; void* out; int N, K, trans, ld; int pieces; };   // Bw(k,n) = trans ? W[k*ld+n] : W[n*ld+k]; pieces: 3 (0 = 3), 1 = hi piece only (gemm_bf.hip)
 struct WGemm {
   const float* A; const float* a_ptrs[8]; long a_sz; int a_sm;       // A[z][m][k], k contiguous; z from the table or a_sz
   int a_sk, a_mdiv; long a_sdiv;                                     // a_sk != 0: A contiguous along m instead, element
@@ -144,6 +144,18 @@ size_t wsplit_bytes(int N, int K);
 int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s);
 int gemm_w_supported(const WGemm& d);
 int launch_gemm_w(const WGemm* d, int n, hipStream_t s);          // n = 1 or 2 GEMMs in one launch
+// single-product bf16 GEMM for wide shapes (gemm_bf.hip): reads a hi-piece-only weight image (WSplit.pieces = 1)
+int gemm_bf_supported(const WGemm& d);
+int launch_gemm_bf(const WGemm* d, int n, hipStream_t s);
+inline int wimg_pieces(const WGemm& d) { return gemm_bf_supported(d) ? 1 : 3; }
+// the kernel a pre-split-weight GEMM runs on: gemm_bf when it takes the shape, else gemm_w
+inline int launch_gemm_wx(const WGemm* d, int n, hipStream_t s) {
+  if (n == 2 && gemm_bf_supported(d[0]) != gemm_bf_supported(d[1])) {   // one job on each kernel: two launches
+    const int rc = launch_gemm_wx(&d[0], 1, s);
+    return rc ? rc : launch_gemm_wx(&d[1], 1, s);
+  }
+  return gemm_bf_supported(d[0]) ? launch_gemm_bf(d, n, s) : launch_gemm_w(d, n, s);
+}
 
 // ---- weight-gradient GEMM C = A^T B with split-K parts (gemm_tn.hip) ---------------------------------------------
 struct TnGemm {

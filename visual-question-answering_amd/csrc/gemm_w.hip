@@ -29,7 +29,7 @@ using namespace gw;
 
 struct WJobs { WArgs job[2]; int first1; };   // blocks [0, first1) work on job 0, the rest on job 1
 
-struct SplitJob { const float* W; void* out; int N, K, trans, ld; };
+struct SplitJob { const float* W; void* out; int N, K, trans, ld, pieces; };
 struct SplitArgs { SplitJob job[3]; int njobs; };
 
 // One wave per (32-column tile nt, 16-k step ks): lane (li = lane & 31, lh = lane >> 5) holds
@@ -51,6 +51,10 @@ __global__ __launch_bounds__(256) void wsplit_kernel(const SplitArgs a) {
   }
   bf16x8 p[3];
   split3(v, p);
+  if (j.pieces == 1) {                               // hi piece only (the value rounded to bf16), 1 KB chunks: gemm_bf.hip
+    *reinterpret_cast<bf16x8*>((char*)j.out + (size_t)chunk * kFragBytes + lane * 16) = p[0];
+    return;
+  }
   char* out = (char*)j.out + (size_t)chunk * kChunkBytes + lane * 16;
 #pragma unroll
   for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x8*>(out + q * kFragBytes) = p[q];
@@ -77,7 +81,7 @@ int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s) {
   int chunks = 0;
   for (int i = 0; i < njobs; ++i) {
     CA_CHECK_ARG(jobs[i].W && jobs[i].out && jobs[i].N > 0 && jobs[i].K > 0, "wsplit: bad job");
-    a.job[i] = SplitJob{jobs[i].W, jobs[i].out, jobs[i].N, jobs[i].K, jobs[i].trans, jobs[i].ld};
+    a.job[i] = SplitJob{jobs[i].W, jobs[i].out, jobs[i].N, jobs[i].K, jobs[i].trans, jobs[i].ld, jobs[i].pieces == 1 ? 1 : 3};
     const int c = ((jobs[i].N + 31) / 32) * ((jobs[i].K + 15) / 16);
     chunks = c > chunks ? c : chunks;
   }

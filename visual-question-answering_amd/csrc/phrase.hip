@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void phrase_wsplit_kernel(const float* __restr
                                                             const float* __restrict__ W3, const float* __restrict__ b1,
                                                             const float* __restrict__ b2, const float* __restrict__ b3,
                                                             char* __restrict__ img, float* __restrict__ bcat, int E,
-                                                            int trans) {
+                                                            int trans, int pieces) {
   const int gid = blockIdx.x * 256 + threadIdx.x;
   if (bcat && gid < 3 * E) bcat[gid] = gid < E ? b1[gid] : (gid < 2 * E ? b2[gid - E] : b3[gid - 2 * E]);
   const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
@@ -166,6 +166,10 @@ __global__ __launch_bounds__(256) void phrase_wsplit_kernel(const float* __restr
   }
   bf16x8 pz[3];
   split3(v, pz);
+  if (pieces == 1) {                                 // hi piece only, 1 KB chunks: the image gemm_bf.hip reads
+    *reinterpret_cast<bf16x8*>(img + (size_t)chunk * gw::kFragBytes + lane * 16) = pz[0];
+    return;
+  }
   char* out = img + (size_t)chunk * gw::kChunkBytes + lane * 16;
 #pragma unroll
   for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x8*>(out + q * gw::kFragBytes) = pz[q];
@@ -219,7 +223,7 @@ int check_phrase(const void* X, const coattn_phrase_params* p, int B, int T, int
 // wimg_trans < 0: Wcat and bcat as fp32 arrays (general GEMM); 0 / 1: the weight image of gemm_w for the forward /
 // the dXcat product instead (+ bcat)
 int build_operands(const float* X, const coattn_phrase_params* p, char* ws, const PhrasePlan& pl, int B, int T, int E,
-                   hipStream_t s, int wimg_trans = -1) {
+                   hipStream_t s, int wimg_trans = -1, int pieces = 3) {
   const long bt = (long)B * T;
   float* Xcat = reinterpret_cast<float*>(ws + pl.xcat);
   if ((E & 3) == 0 && ((((uintptr_t)X) | ((uintptr_t)Xcat)) & 15) == 0) {
@@ -234,7 +238,7 @@ int build_operands(const float* X, const coattn_phrase_params* p, char* ws, cons
     const int chunks = (3 * E / 16) * (3 * E / 32);
     hipLaunchKernelGGL(phrase_wsplit_kernel, dim3((unsigned)((chunks + 3) / 4)), dim3(256), 0, s, (const float*)p->W1,
                        (const float*)p->W2, (const float*)p->W3, (const float*)p->b1, (const float*)p->b2,
-                       (const float*)p->b3, ws + pl.wimg, reinterpret_cast<float*>(ws + pl.bcat), E, wimg_trans);
+                       (const float*)p->b3, ws + pl.wimg, reinterpret_cast<float*>(ws + pl.bcat), E, wimg_trans, pieces);
     CA_CHECK_LAUNCH("phrase_wsplit");
     return 0;
   }
@@ -273,9 +277,15 @@ extern "C" int coattn_phrase_forward(const void* X, const coattn_phrase_params* 
   wg.A = reinterpret_cast<const float*>(w + pl.xcat); wg.a_sm = 3 * E; wg.Wf = w + pl.wimg;
   wg.C = reinterpret_cast<float*>(w + pl.z); wg.c_sm = 3 * E; wg.bias_n = reinterpret_cast<const float*>(w + pl.bcat);
   wg.M = B * T; wg.N = 3 * E; wg.K = 3 * E; wg.batch = 1;
-  wg.bf16 = bf16 ? 1 : 0;                                // reduced precision: the same kernels, one MFMA per product
+  wg.bf16 = bf16 ? 1 : 0;                                // reduced precision: one MFMA per product (gemm_bf.hip / gemm_w.hip)
+  if (E % 128 == 0) {                                    // (k bands first: the kernel and its weight-image format depend on them)
+    wg.kband_n = E;
+    wg.kband_lo[0] = E; wg.kband_hi[0] = 2 * E;
+    wg.kband_lo[1] = 0; wg.kband_hi[1] = 2 * E;
+    wg.kband_lo[2] = 0; wg.kband_hi[2] = 3 * E;
+  }
   const bool hand = hand_gemms() && E % 128 == 0 && gemm_w_supported(wg);
-  CA_TRY(build_operands((const float*)X, p, w, pl, B, T, E, s, hand ? 0 : -1));
+  CA_TRY(build_operands((const float*)X, p, w, pl, B, T, E, s, hand ? 0 : -1, wimg_pieces(wg)));
   coattn_gemm_desc g = {};
   g.A = w + pl.xcat; g.B = w + pl.wcat; g.C = w + pl.z; g.bias_n = w + pl.bcat;
   g.M = B * T; g.N = 3 * E; g.K = 3 * E; g.batch = 1; g.inner = 1;
@@ -288,10 +298,8 @@ extern "C" int coattn_phrase_forward(const void* X, const coattn_phrase_params* 
   }
   // fp32, 128-aligned channels: the pre-split-weight kernel (Wcat split once into MFMA-fragment order; its zero tap
   // blocks are never read)
-  wg.kband_n = g.kband_n;
-  for (int t = 0; t < 3; ++t) { wg.kband_lo[t] = g.kband_lo[t]; wg.kband_hi[t] = g.kband_hi[t]; }
   if (hand) {
-    CA_TRY(launch_gemm_w(&wg, 1, s));
+    CA_TRY(launch_gemm_wx(&wg, 1, s));
   } else {
     CA_TRY(gemm(g));
   }
@@ -321,8 +329,14 @@ extern "C" int coattn_phrase_backward(const void* X, const coattn_phrase_params*
   wdx.A = dZ; wdx.a_sm = 3 * E; wdx.Wf = w + pl.wimg; wdx.C = reinterpret_cast<float*>(w + pl.xcat); wdx.c_sm = 3 * E;
   wdx.M = (int)bt; wdx.N = 3 * E; wdx.K = 3 * E; wdx.batch = 1;
   wdx.bf16 = bf16 ? 1 : 0;
+  if (E % 128 == 0) {                                    // tap block j of dXcat receives only the n-grams that have that tap
+    wdx.kband_n = E;
+    wdx.kband_lo[0] = E; wdx.kband_hi[0] = 3 * E;        // x[t-1]: bi, tri
+    wdx.kband_lo[1] = 0; wdx.kband_hi[1] = 3 * E;        // x[t]  : all
+    wdx.kband_lo[2] = 2 * E; wdx.kband_hi[2] = 3 * E;    // x[t+1]: tri
+  }
   const bool hand_dx = dX && hand_gemms() && E % 128 == 0 && gemm_w_supported(wdx);
-  CA_TRY(build_operands((const float*)X, p, w, pl, B, T, E, s, hand_dx ? 1 : -1));
+  CA_TRY(build_operands((const float*)X, p, w, pl, B, T, E, s, hand_dx ? 1 : -1, wimg_pieces(wdx)));
   hipLaunchKernelGGL(phrase_dz_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)g_out,
                      (const float*)out, (const unsigned char*)saved, dZ, n);
   CA_CHECK_LAUNCH("phrase_dz");
@@ -389,10 +403,8 @@ extern "C" int coattn_phrase_backward(const void* X, const coattn_phrase_params*
       h.kband_lo[1] = 0; h.kband_hi[1] = 3 * E;           // x[t]  : all
       h.kband_lo[2] = 2 * E; h.kband_hi[2] = 3 * E;       // x[t+1]: tri
     }
-    wdx.kband_n = h.kband_n;
-    for (int t = 0; t < 3; ++t) { wdx.kband_lo[t] = h.kband_lo[t]; wdx.kband_hi[t] = h.kband_hi[t]; }
     if (hand_dx) {
-      CA_TRY(launch_gemm_w(&wdx, 1, s));
+      CA_TRY(launch_gemm_wx(&wdx, 1, s));
     } else {
       CA_TRY(gemm(h));
     }

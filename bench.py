@@ -605,6 +605,8 @@ def main():
                                       + ("" if args.stock_graph else ", ReLU after MaxPool, conv bias folded into BN running mean")),
                        "untimed_prime_steps": PRIME_STEPS,
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
+                       "gpu": "%s uuid %s" % (torch.cuda.get_device_properties(device).name,
+                                              getattr(torch.cuda.get_device_properties(device), "uuid", "unknown")),
                        "coattn_impl": "fused" if vqa_amd._lib.load().coattn_fused_supported(
                            args.batch, n_grid, args.seq_len, model.co_attention.hidden_dim, 3, 0) else "general"},
         }

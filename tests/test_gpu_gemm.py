@@ -277,3 +277,43 @@ def test_linear_weight_grad_rejects_unsupported_shapes():
     dy = torch.randn(64, 96, device="cuda"); x = torch.randn(64, 128, device="cuda")
     rc, _ = _wgrad(dy, 96, x, 128, 64, 96, 128)               # n_out not a multiple of 128
     assert rc == -1 and b"not supported" in _lib.load().coattn_last_error()
+
+
+# ---- the reduced-precision mode (COATTN_FLAG_BF16_PROJ) of the linear entry points -----------------------------------
+# operands rounded to bf16 (round to nearest even), one MFMA per product, fp32 accumulation: against the float64
+# product of the ROUNDED operands only the accumulation order differs (tolerance 2e-5 of max|.|)
+@pytest.mark.parametrize("M,N,K", [(7840, 2048, 2048), (300, 256, 64), (1000, 512, 192), (4160, 512, 512), (129, 200, 160)],
+                         ids=lambda v: str(v))
+def test_linear_reduced_precision(M, N, K):
+    """Wide shapes run on gemm_bf.hip (256 x 256 tiles, LDS-DMA weight image; ragged last row tile, one to many k
+    steps), the others on gemm_w.hip's single-piece mode."""
+    from vqa_amd import _lib
+    torch.manual_seed(31)
+    x = torch.randn(M, K, device="cuda")
+    W = torch.randn(N, K, device="cuda") / K ** 0.5
+    b = torch.randn(N, device="cuda")
+    rc, y, _ = _linear(x, K, W, b, M, N, K, flags=_lib.FLAG_BF16_PROJ)
+    _lib.check(rc, "coattn_linear_forward")
+    ref = x.bfloat16().double() @ W.bfloat16().double().t() + b.double()
+    assert _rel(y, ref) < 2e-5
+    assert _rel(y, x.double() @ W.double().t() + b.double()) > 1e-4        # it IS the reduced-precision product
+
+
+@pytest.mark.parametrize("M,n_out,n_in", [(7840, 2048, 2048), (64, 256, 256), (4160, 512, 768), (12345 // 32 * 32, 256, 512),
+                                          (1000, 256, 128)], ids=lambda v: str(v))
+def test_linear_weight_grad_reduced_precision(M, n_out, n_in):
+    """dW = dY^T X in the same mode: gemm_bf.hip's 256 x 256 split-K kernel where the shape allows (rows % 32 == 0,
+    256-multiples), gemm_tn.hip's single-piece mode otherwise; repeatable bit for bit."""
+    from vqa_amd import _lib
+    torch.manual_seed(32)
+    dy = torch.randn(M, n_out, device="cuda") * 0.1
+    x = torch.randn(M, n_in, device="cuda")
+    rc, dW = _wgrad(dy, n_out, x, n_in, M, n_out, n_in, accumulate=_lib.FLAG_BF16_PROJ)
+    _lib.check(rc, "coattn_linear_weight_grad")
+    ref = dy.bfloat16().double().t() @ x.bfloat16().double()
+    assert _rel(dW, ref) < 2e-5
+    rc, dW2 = _wgrad(dy, n_out, x, n_in, M, n_out, n_in, accumulate=_lib.FLAG_BF16_PROJ)
+    assert torch.equal(dW, dW2)
+    base = torch.ones(n_out, n_in, device="cuda")
+    rc, dW3 = _wgrad(dy, n_out, x, n_in, M, n_out, n_in, accumulate=_lib.FLAG_BF16_PROJ | 1, dW=base.clone())
+    assert _rel(dW3 - 1.0, ref) < 5e-5

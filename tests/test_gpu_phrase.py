@@ -76,11 +76,13 @@ def test_phrase_errors_are_loud():
         phrase_conv_pool(x.cuda(), W[1].cuda(), b.cuda(), W[1].cuda(), b.cuda(), W[2].cuda(), b.cuda())
 
 
-def test_phrase_bf16_mfma_mode():
+@pytest.mark.parametrize("B,T,E", [(6, 26, 256), (16, 26, 256), (32, 26, 512)], ids=lambda v: str(v))
+def test_phrase_bf16_mfma_mode(B, T, E):
     """bf16=True (what CUDA autocast selects): bf16-rounded operands on the bf16 MFMA, fp32 accumulation
-    -> values and gradients within bf16 tolerance of the float64 oracle, not identical to the fp32 mode."""
+    -> values and gradients within bf16 tolerance of the float64 oracle, not identical to the fp32 mode.
+    B = 6: gemm_w / gemm_tn in single-piece mode (B T rows: not a multiple of 256 / 32); B = 16, 32: the wide-shape
+    kernels of gemm_bf.hip for Z, dXcat (k bands) and dWcat (masked tap blocks)."""
     from vqa_amd.phrase import phrase_conv_pool
-    B, T, E = 6, 26, 256
     mod, ref, x, g = _case(B, T, E, 21)
     xr = x.double().requires_grad_(True)
     yr = ref(xr)

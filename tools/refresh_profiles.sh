@@ -5,7 +5,9 @@ set -u
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/refresh
-rm -rf $O && mkdir -p $O
+PART=${1:-all}                                    # 1: the default bench + kernel statistics; 2: config 4, head, counters
+mkdir -p $O
+if [ $PART != 2 ]; then
 python3 bench.py > $O/bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_stats -- python3 bench.py --no-cpu-baseline > $O/bench_stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/roofline -- python3 bench.py --only roofline > $O/roofline.log 2>&1
@@ -14,6 +16,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/hot -- python3 bench.
 ITERS=100 rocprofv3 --kernel-trace --stats --output-format csv -d $O/headline -- python3 tools/probe_fwd_one.py > $O/headline.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/step -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/step.log 2>&1
 rm -f $O/*/*/*kernel_trace.csv $O/hot/*/*_trace.csv
+tail -c 300 $O/bench.json
+fi
+if [ $PART = 1 ]; then exit 0; fi
 # config 4 (ResNet 7x7x2048 grid, reduced precision): its own bench line, and the kernels of its hot path
 python3 bench.py --model attention_resnet --opt-lvl 1 --num-cls 3000 --no-cpu-baseline > $O/cfg4_bench.json 2> $O/cfg4_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg4_hot -- python3 bench.py --model attention_resnet --opt-lvl 1 --num-cls 3000 --only hot > $O/cfg4_hot.log 2>&1
@@ -33,4 +38,4 @@ done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_mfma -- python3 tools/probe_fwd_one.py > $O/pmc_mfma.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU --output-format csv -d $O/pmc_hot -- python3 bench.py --only hot > $O/pmc_hot.log 2>&1
 cp profiles/pmc_traffic.json $O/pmc_traffic.json
-tail -c 600 $O/bench.json
+tail -c 300 $O/cfg4_bench.json

@@ -125,6 +125,14 @@ extern "C" int coattn_linear_weight_grad(const void* dy, int64_t ld_dy, const vo
   g.bf16 = (accumulate & COATTN_FLAG_BF16_PROJ) ? 1 : 0;
   accumulate &= 1;
   CA_CHECK_ARG(gemm_tn_supported(g), "linear weight grad: shape M=%d n_out=%d n_in=%d not supported (see coattn.h)", M, n_out, n_in);
+  if (gemm_bf_tn_supported(g)) {                     // reduced-precision mode, wide shape: the single-product kernel (gemm_bf.hip)
+    const int ntiles = (n_out / 256) * (n_in / 256);
+    int want = (bf_tn_rounds() * 256 + ntiles - 1) / ntiles, spp, parts;
+    want = want > 32 ? 32 : want;
+    parts = gemm_bf_tn_plan(g, want, &spp);
+    CA_TRY(launch_gemm_bf_tn(&g, &spp, &parts, 1, (hipStream_t)stream));
+    return launch_reduce_partials((const float*)ws, (float*)dW, parts, (int64_t)n_out * n_in, accumulate, (hipStream_t)stream);
+  }
   int ks, S;
   const int parts = gemm_tn_plan(g, 32, &ks, &S);
   CA_TRY(launch_gemm_tn(&g, &ks, &S, 1, (hipStream_t)stream));
@@ -139,6 +147,12 @@ extern "C" int coattn_gemm_bf16(const coattn_gemm_desc* g, void* stream) {
 // ---------------------------------------------------------------------------------------
 // general-shape implementation: MFMA GEMM composition
 // ---------------------------------------------------------------------------------------
+// COATTN_BF_TN_ROUNDS (developer switch): rounds of workgroups the split-K parts of gemm_bf.hip's weight-gradient kernel fill
+int bf_tn_rounds() {
+  static const int r = [] { const char* e = getenv("COATTN_BF_TN_ROUNDS"); return e ? atoi(e) : 1; }();   // (measured: 1 round 101 us, 2: 128, 3: 152 -- the partial results' round trip)
+  return r < 1 ? 1 : r;
+}
+
 namespace {
 
 struct Ctx {

@@ -500,6 +500,27 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     CA_TRY(gemm_proj(g));
   }
   // 5. weight gradients
+  if (tn_v && tn_q && gemm_bf_tn_supported(tnv) && gemm_bf_tn_supported(tnq)) {
+    // reduced-precision mode at wide shapes (config 4): the single-product kernel of gemm_bf.hip, 256 x 256 tiles; the
+    // parts of the two products share two rounds of workgroups in proportion to their contraction lengths
+    const int ntiles = (d / 256) * (d / 256);
+    int total = (bf_tn_rounds() * 256 + ntiles - 1) / ntiles;
+    total = total < 2 ? 2 : (total > kMaxParts ? kMaxParts : total);
+    const double kv = (double)B * N, kq = (double)L * B * T;
+    int pv = (int)(total * kv / (kv + kq) + 0.5);
+    pv = pv < 1 ? 1 : (pv > total - 1 ? total - 1 : pv);
+    int spp[2], parts[2];
+    parts[0] = gemm_bf_tn_plan(tnv, pv, &spp[0]);
+    tnq.C = part + (size_t)parts[0] * d * d;
+    parts[1] = gemm_bf_tn_plan(tnq, total - pv, &spp[1]);
+    CA_CHECK_ARG(parts[0] + parts[1] <= kMaxParts, "fused backward: %d split-K parts exceed the workspace", parts[0] + parts[1]);
+    CA_TRY(small_reductions());
+    const TnGemm both[2] = {tnv, tnq};
+    CA_TRY(launch_gemm_bf_tn(both, spp, parts, 2, s));
+    if (combine) CA_TRY(run_dq());
+    return launch_reduce_partials2(part, (float*)pg->dW_v, parts[0], tnq.C, (float*)pg->dW_q, parts[1], (int64_t)d * d,
+                                   accumulate, s);
+  }
   if (tn_v && tn_q) {
     // both weight gradients in one launch: 32 split-K parts (x 16 tiles = the 512 workgroup slots) shared in
     // proportion to the contraction lengths, so that all workgroups run about equally long

@@ -171,6 +171,11 @@ struct TnGemm {
   int bf16;                                                          // 1: operands rounded to bf16, ONE MFMA per product
 };
 int gemm_tn_supported(const TnGemm& d);
+// the same products in the reduced-precision mode at wide shapes (gemm_bf.hip): 256 x 256 tiles, parts over the concatenated levels
+int gemm_bf_tn_supported(const TnGemm& d);
+int bf_tn_rounds();
+int gemm_bf_tn_plan(const TnGemm& d, int want, int* spp);                 // returns the number of parts
+int launch_gemm_bf_tn(const TnGemm* d, const int* spp, const int* parts, int n, hipStream_t s);
 int gemm_tn_plan(const TnGemm& d, int max_parts, int* ksplit, int* S);   // returns the number of parts
 struct TnReduce {                                                    // launch_reduce_jobs's arguments (common.h)
   const float* src[4]; float* dst[4]; int njobs, nparts; long n; int accumulate;

@@ -191,6 +191,194 @@ __global__ __launch_bounds__(512, 2) void gemm_bf_kernel(const BfJobs jobs) {
   else gemm_bf_body(jobs.job[1], (int)blockIdx.x - jobs.first1, bf_smem);
 }
 
+// ---- weight gradients in the same mode:  part[z][m][n] = sum_{k in part z} bf16(A[k][m]) * bf16(B[k][n]) ----------------------
+// dW_v = dP_v^T V, dW_q = sum_l dP_q,l^T Q_l and the phrase level's dWcat = dZ^T Xcat at config 4's sizes: a 2048 x 2048
+// (6144 x 6144) result contracted over thousands of rows.  gemm_tn.hip's 128 x 128 tiles in single-piece mode fetch a byte
+// per 32 flops (16 k per barrier, both operands fp32): 0.23 of the bf16 peak.  Here: 256 x 256 tiles on 512 threads, 32 rows
+// per barrier, both operands contiguous along their tile index: float4 = 4 consecutive columns of one row k, rounded and
+// staged as [k][256 + 32] bf16 images (conflict-free 8-byte writes), fragments through the transposing LDS read
+// (ds_read_b64_tr_b16), LDS double-buffered.  Split-K parts run over the CONCATENATED levels (a part may cross from one
+// level's rows into the next: K % 32 == 0 per level), so that two rounds of workgroups fill the chip evenly; the partial
+// results are added by the same deterministic reduce as gemm_tn's.  SUM3: A is the sum of three arrays (dP_v of the levels).
+constexpr int TLD = 256 + 32;                     // bf16 elements per staged k-row
+constexpr int T_IMG = 32 * TLD;                   // one operand image: 18,432 B
+constexpr int T_BUF = 2 * T_IMG;                  // A and B
+
+struct BfTnArgs {
+  const float* A; long a_sl; int a_ld; long a_term;
+  const float* B; const float* b_ptrs[8]; long b_sl; int b_ld;
+  float* C;
+  int M, N, K, levels, spp, P;                    // K rows per level; spp: 32-row steps per part; P parts
+  int mask_blk; unsigned tile_mask;               // in units of 128 columns, as TnGemm
+};
+struct BfTnJobs { BfTnArgs job[2]; int first1; };
+
+template <bool SUM3>
+__device__ __forceinline__ void gemm_bf_tn_body(const BfTnArgs& g, const int id, short* const lds) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3, li = lane & 31, lh = lane >> 5;
+  const int ntn = g.N / 256, ntiles = (g.M / 256) * ntn;
+  const int z = id / ntiles, t = id % ntiles;
+  if (g.mask_blk > 0 && !((g.tile_mask >> ((((t / ntn) * 2) / g.mask_blk) * 3 + ((t % ntn) * 2) / g.mask_blk)) & 1u)) return;
+  const int m0 = (t / ntn) * 256, n0 = (t % ntn) * 256;
+  const int spl = g.K / 32, total = spl * g.levels;                  // steps per level, steps in all
+  const int g0 = z * g.spp, g1 = min(total, g0 + g.spp), steps = g1 - g0;
+  if (steps <= 0) return;
+  // staging: per operand and step 4 float4 per thread; a wave's load covers one k-row x 1 KB
+  const int sk = tid >> 6, sm = (tid & 63) * 4;
+  const int st_off = sk * TLD + sm;                                   // + 8 i rows
+  const int tr_off = (8 * lh + ((lane & 15) >> 2)) * TLD + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const int a_rd = tr_off + wr * 128, b_rd = T_IMG + tr_off + wc * 64;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[4], rb[4], rt[SUM3 ? 8 : 1];
+  auto load = [&](int gs) {                                           // global step gs -> (level, row)
+    const int lvl = gs / spl, k0 = (gs - lvl * spl) * 32;
+    const float* Ab = g.A + (long)lvl * g.a_sl;
+    const float* Bb = g.b_ptrs[0] ? g.b_ptrs[lvl & 7] : g.B + (long)lvl * g.b_sl;
+    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(Ab, (unsigned)((long)g.K * g.a_ld * 4));
+    const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(Bb, (unsigned)((long)g.K * g.b_ld * 4));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = buf_load4(rs_a, ((sk + 8 * i) * g.a_ld + m0 + sm) * 4, k0 * g.a_ld * 4);
+      rb[i] = buf_load4(rs_b, ((sk + 8 * i) * g.b_ld + n0 + sm) * 4, k0 * g.b_ld * 4);
+    }
+    if constexpr (SUM3) {
+      const __amdgpu_buffer_rsrc_t rs_1 = make_rsrc(Ab + g.a_term, (unsigned)((long)g.K * g.a_ld * 4));
+      const __amdgpu_buffer_rsrc_t rs_2 = make_rsrc(Ab + 2 * g.a_term, (unsigned)((long)g.K * g.a_ld * 4));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        rt[i] = buf_load4(rs_1, ((sk + 8 * i) * g.a_ld + m0 + sm) * 4, k0 * g.a_ld * 4);
+        rt[4 + i] = buf_load4(rs_2, ((sk + 8 * i) * g.a_ld + m0 + sm) * 4, k0 * g.a_ld * 4);
+      }
+    }
+  };
+  auto write = [&](short* buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4 a = ra[i];
+      if constexpr (SUM3) a = (a + rt[i]) + rt[4 + i];                // (level order 0 + 1 + 2, as the separate summing pass)
+      const u32x2 va = {cvt_pk_bf16(a[0], a[1]), cvt_pk_bf16(a[2], a[3])};
+      const u32x2 vb = {cvt_pk_bf16(rb[i][0], rb[i][1]), cvt_pk_bf16(rb[i][2], rb[i][3])};
+      *reinterpret_cast<u32x2*>(&buf[8 * i * TLD + st_off]) = va;
+      *reinterpret_cast<u32x2*>(&buf[T_IMG + 8 * i * TLD + st_off]) = vb;
+    }
+  };
+  auto frag = [&](const short* p) {
+    const bf16x4 lo = lds_tr16(p), hi = lds_tr16(p + 4 * TLD);
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  };
+  auto compute = [&](const short* buf) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bf[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = frag(buf + a_rd + 32 * i + 16 * ks * TLD);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = frag(buf + b_rd + 32 * j + 16 * ks * TLD);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  short* const buf0 = lds;
+  short* const buf1 = lds + T_BUF;
+  load(g0);
+  write(buf0);
+  if (steps > 1) load(g0 + 1);
+  lds_barrier();
+  for (int s = 0; s < steps; ++s) {
+    short* cur = (s & 1) ? buf1 : buf0;
+    short* nxt = (s & 1) ? buf0 : buf1;
+    compute(cur);
+    if (s + 1 < steps) write(nxt);                                    // rows of step s + 1, requested one step ago
+    if (s + 2 < steps) load(g0 + s + 2);
+    lds_barrier();
+  }
+  float* Cb = g.C + (long)z * g.M * g.N;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      float* crow = Cb + (long)row * g.N + n0 + wc * 64 + li;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) crow[j * 32] = acc[i][j][r];
+    }
+}
+
+template <bool SUM3>
+__global__ __launch_bounds__(512, 2) void gemm_bf_tn_kernel(const BfTnJobs jobs) {
+  extern __shared__ __attribute__((aligned(16))) short bf_tn_smem[];        // 2 x 36,864 B
+  if ((int)blockIdx.x < jobs.first1) gemm_bf_tn_body<SUM3>(jobs.job[0], (int)blockIdx.x, bf_tn_smem);
+  else gemm_bf_tn_body<false>(jobs.job[1], (int)blockIdx.x - jobs.first1, bf_tn_smem);
+}
+
+}  // namespace
+
+int gemm_bf_enabled();
+int gemm_bf_tn_supported(const TnGemm& d) {
+  auto pal = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+  bool ok = gemm_bf_enabled() && d.bf16 && !d.b_kdiv && d.M >= 256 && d.N >= 256 && (d.M % 256) == 0 && (d.N % 256) == 0 && d.K >= 32 &&
+            (d.K % 32) == 0 && d.levels >= 1 && d.levels <= 8 && (d.a_ld & 3) == 0 && (d.b_ld & 3) == 0 && (d.a_term & 3) == 0 &&
+            (d.a_sl & 3) == 0 && (d.b_sl & 3) == 0 && pal(d.A) && (d.b_ptrs[0] ? true : pal(d.B)) &&
+            (long)d.K * d.a_ld * 4 < 0x40000000L && (long)d.K * d.b_ld * 4 < 0x40000000L && (d.mask_blk == 0 || (d.mask_blk % 2) == 0);
+  for (int t = 0; t < 8; ++t) ok = ok && pal(d.b_ptrs[t]);
+  return ok ? 1 : 0;
+}
+
+// parts for a job: about `want` of them, each a whole number of 32-row steps over the concatenated levels
+int gemm_bf_tn_plan(const TnGemm& d, int want, int* spp) {
+  const int total = (d.K / 32) * d.levels;
+  if (want < 1) want = 1;
+  if (want > total) want = total;
+  *spp = (total + want - 1) / want;
+  return (total + *spp - 1) / *spp;
+}
+
+// n = 1 or 2 jobs; spp[i] / parts[i] from gemm_bf_tn_plan; d[i].C = the job's partial buffer [parts][M][N]
+int launch_gemm_bf_tn(const TnGemm* d, const int* spp, const int* parts, int n, hipStream_t s) {
+  CA_CHECK_ARG(n == 1 || n == 2, "gemm_bf_tn: 1 or 2 jobs per launch");
+  BfTnJobs jobs = {};
+  long nb[2] = {0, 0};
+  for (int i = 0; i < n; ++i) {
+    CA_CHECK_ARG(gemm_bf_tn_supported(d[i]) && d[i].A && (d[i].B || d[i].b_ptrs[0]) && d[i].C && spp[i] > 0 && parts[i] > 0,
+                 "gemm_bf_tn: unsupported job M=%d N=%d K=%d", d[i].M, d[i].N, d[i].K);
+    BfTnArgs& g = jobs.job[i];
+    g = BfTnArgs{};
+    g.A = d[i].A; g.a_sl = d[i].a_sl; g.a_ld = d[i].a_ld; g.a_term = d[i].a_term;
+    g.B = d[i].B; g.b_sl = d[i].b_sl; g.b_ld = d[i].b_ld;
+    for (int t = 0; t < 8; ++t) g.b_ptrs[t] = d[i].b_ptrs[t];
+    g.C = d[i].C; g.M = d[i].M; g.N = d[i].N; g.K = d[i].K; g.levels = d[i].levels; g.spp = spp[i]; g.P = parts[i];
+    g.mask_blk = d[i].mask_blk; g.tile_mask = d[i].tile_mask;
+    nb[i] = (long)(d[i].M / 256) * (d[i].N / 256) * parts[i];
+  }
+  CA_CHECK_ARG(n == 1 || d[1].a_term == 0, "gemm_bf_tn: only the first job may sum three A terms");
+  CA_CHECK_ARG(nb[0] + nb[1] < 2147483647L, "gemm_bf_tn: grid too large");
+  jobs.first1 = (int)nb[0];
+  const size_t lds = (size_t)2 * T_BUF * sizeof(short);
+  static DeviceOnce once;
+  CA_TRY(once.run([&] {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf_tn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf_tn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return e;
+  }, "gemm_bf_tn"));
+  const dim3 grid((unsigned)(nb[0] + nb[1]));
+  if (d[0].a_term) hipLaunchKernelGGL(gemm_bf_tn_kernel<true>, grid, dim3(512), lds, s, jobs);
+  else hipLaunchKernelGGL(gemm_bf_tn_kernel<false>, grid, dim3(512), lds, s, jobs);
+  CA_CHECK_LAUNCH("gemm_bf_tn");
+  return 0;
+}
+
+namespace {
 }  // namespace
 
 // COATTN_GEMM_BF=0 (developer switch): gemm_w's single-piece mode instead

@@ -356,7 +356,19 @@ extern "C" int coattn_phrase_backward(const void* X, const coattn_phrase_params*
   tn.tile_mask = (1u << 1) | (3u << 3) | (7u << 6);
   tn.bf16 = bf16 ? 1 : 0;
   const bool tn_ok = hand_gemms() && E % 128 == 0 && gemm_tn_supported(tn);
-  if (tn_ok) {
+  if (tn_ok && gemm_bf_tn_supported(tn)) {
+    // reduced-precision mode at wide shapes: the single-product 256 x 256 kernel of gemm_bf.hip (same mask, same part layout)
+    const int live = 6 * (E / 256) * (E / 256);
+    int want = (bf_tn_rounds() * 256 + live - 1) / live, spp;
+    if (want > pl.nsplit) want = pl.nsplit;
+    const int parts = gemm_bf_tn_plan(tn, want, &spp);
+    hipLaunchKernelGGL(phrase_unpack_db_kernel, dim3((unsigned)((3 * E + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float*>(w + pl.bpart), nchunks, (float*)pg->db1, (float*)pg->db2,
+                       (float*)pg->db3, E, accumulate);
+    CA_CHECK_LAUNCH("phrase_unpack_db");
+    CA_TRY(launch_gemm_bf_tn(&tn, &spp, &parts, 1, s));
+    nparts = parts;
+  } else if (tn_ok) {
     const int live = 6 * (E / 128) * (E / 128);      // tiles that exist
     int S = (512 + live - 1) / live;
     if (S > pl.nsplit) S = pl.nsplit;

@@ -9,6 +9,8 @@ One process, ITERS rounds.  Every round runs, interleaved,
   gemm_tn   coattn_linear_weight_grad at M = 31,360                  -- ::test_linear_weight_grad[31360-512-512]
   coattn    module forward + backward, three shapes                  -- test_gpu_edges.py::test_repeated_runs_are_bitwise_identical
   cfg2      coattention forward + backward at B=160, N=49, lm        -- test_gpu_parity.py::test_full_size_cfg2_properties[fused-lm-49]
+  gemm_bf   the reduced-precision GEMMs of gemm_bf.hip (LDS-DMA weight image, counted waits) at config 4's size,
+            M = 7,840, N = K = 2,048: coattn_linear_forward / coattn_linear_weight_grad with COATTN_FLAG_BF16_PROJ
 each held (a) to a float64 reference computed ONCE with stock torch ops on the same GPU, over every element, and (b) to
 bitwise equality with the first round.  The first mismatch of every check is printed with index, got, expected, the
 number of bad elements and the rows they sit in.  Prints the GPU UUID and clocks; exit code 1 on any mismatch.
@@ -116,6 +118,16 @@ t_ref = tdy.double().t() @ tx.double()
 t_ws = torch.empty(lib.coattn_linear_wgrad_workspace_bytes(512, 512) // 4, device=dev)
 
 
+torch.manual_seed(31)
+bM, bd = 7840, 2048
+bx = torch.randn(bM, bd, device=dev); bW = torch.randn(bd, bd, device=dev) / bd ** 0.5; bb = torch.randn(bd, device=dev)
+bdy = torch.randn(bM, bd, device=dev) * 0.1
+b_ref = bx.bfloat16().double() @ bW.bfloat16().double().t() + bb.double()
+bt_ref = bdy.bfloat16().double().t() @ bx.bfloat16().double()
+b_wimg = torch.empty(lib.coattn_linear_workspace_bytes(bd, bd) // 4, device=dev)
+bt_ws = torch.empty(lib.coattn_linear_wgrad_workspace_bytes(bd, bd) // 4, device=dev)
+
+
 def coattn_f64(x, Qs, co):
     """ParallelCoAttention.forward (reference model.py:372-392) in float64 with stock torch ops."""
     W_v, b_v, W_q, b_q = (t.double() for t in (co.W_v.weight, co.W_v.bias, co.W_q.weight, co.W_q.bias))
@@ -209,6 +221,18 @@ for it in range(args.iters):
                                              512, 0, stream), "wgrad")
     report("gemm_tn", it, dW, t_ref, 2e-6, first.get("t"))
     first.setdefault("t", dW.clone())
+    # gemm_bf.hip (reduced-precision mode), every 4th round (the float64 compare of 2 x 16M elements is the cost)
+    if it % 4 == 0:
+        y = torch.full((bM, bd), float("nan"), device=dev)
+        _lib.check(lib.coattn_linear_forward(bx.data_ptr(), bd, bW.data_ptr(), bb.data_ptr(), y.data_ptr(), b_wimg.data_ptr(),
+                                             bM, bd, bd, 0.0, _lib.FLAG_BF16_PROJ, stream), "linear bf16")
+        report("gemm_bf_nt", it, y, b_ref, 2e-5, first.get("bn"))
+        first.setdefault("bn", y.clone())
+        dW = torch.full((bd, bd), float("nan"), device=dev)
+        _lib.check(lib.coattn_linear_weight_grad(bdy.data_ptr(), bd, bx.data_ptr(), bd, dW.data_ptr(), bt_ws.data_ptr(), bM, bd,
+                                                 bd, _lib.FLAG_BF16_PROJ, stream), "wgrad bf16")
+        report("gemm_bf_tn", it, dW, bt_ref, 2e-5, first.get("bt"))
+        first.setdefault("bt", dW.clone())
     # fused co-attention forward + backward
     for c in cases:
         outs = c.run()

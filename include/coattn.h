@@ -58,6 +58,7 @@ extern "C" {
  * the same hand-scheduled kernels as in fp32 mode (gemm_w.hip, gemm_tn.hip) with the hi pieces of the operands alone.
  * The same bit selects the bf16 MFMA for the three contractions of coattn_phrase_forward/backward. */
 #define COATTN_FLAG_BF16_PROJ 4
+#define COATTN_FLAG_BF16_IN 8     /* coattn_linear_forward / coattn_linear_weight_grad, with COATTN_FLAG_BF16_PROJ: x (dy) is STORED as bf16 */
 typedef struct coattn_params {
   const void* W_v; const void* b_v;   /* model.py:350 */
   const void* W_q; const void* b_q;   /* model.py:351 */
@@ -237,7 +238,10 @@ int coattn_gemm_f32(const coattn_gemm_desc* g, void* stream);
  * coattn_linear_workspace_bytes(N, K) bytes) and the GEMM reads the fragments in place (gemm_w.hip) -- the
  * kernel pair coattn_forward uses for both projections.  flags bit 0: `wimg` already holds the image of this
  * W (skip the split); flags bit 2 (COATTN_FLAG_BF16_PROJ): operands rounded to bf16, one MFMA per product.  K % 32 == 0, M >= 128, x 16-byte aligned with ld_x % 4 == 0; other shapes: error -1
- * (use coattn_gemm_f32).  bias may be NULL; out_scale 0 means 1. */
+ * (use coattn_gemm_f32).  bias may be NULL; out_scale 0 means 1.
+ * flags bit 3 (COATTN_FLAG_BF16_IN, with bit 2): x holds bf16 elements (ld_x in elements, % 8 == 0) -- the activations of
+ * an autocast encoder, or the fused backward's own bf16 gradients -- read as they are by the wide-shape kernel
+ * (gemm_bf.hip: M >= 256, N % 256 == 0, K % 64 == 0; other shapes: error -1). */
 size_t coattn_linear_workspace_bytes(int N, int K);
 int coattn_linear_forward(const void* x, int64_t ld_x, const void* W, const void* bias, void* y, void* wimg,
                           int M, int N, int K, float out_scale, int flags, void* stream);
@@ -247,7 +251,8 @@ int coattn_linear_forward(const void* x, int64_t ld_x, const void* W, const void
  * (gemm_tn.hip) + a deterministic reduce -- the kernel pair coattn_backward uses for dW_v and dW_q.
  * dY rows ld_dy floats apart, X rows ld_x; `ws`: device scratch of coattn_linear_wgrad_workspace_bytes bytes.
  * n_out, n_in multiples of 128, M >= 16, 16-byte aligned operands with ld % 4 == 0; other shapes: error -1.
- * accumulate: bit 0 adds onto dW; bit 2 (COATTN_FLAG_BF16_PROJ) selects the reduced-precision mode. */
+ * accumulate: bit 0 adds onto dW; bit 2 (COATTN_FLAG_BF16_PROJ) selects the reduced-precision mode; bit 3
+ * (COATTN_FLAG_BF16_IN, with bit 2): dy holds bf16 elements (ld_dy % 8 == 0; n_out, n_in % 256 == 0, M % 32 == 0). */
 size_t coattn_linear_wgrad_workspace_bytes(int n_out, int n_in);
 int coattn_linear_weight_grad(const void* dy, int64_t ld_dy, const void* x, int64_t ld_x, void* dW, void* ws, int M,
                               int n_out, int n_in, int accumulate, void* stream);

@@ -196,8 +196,32 @@ def test_bf16_mfma_projections(shape):
     for k in ("dQ", "dW_v.weight", "dW_q.weight", "dV_phys"):
         scale = x[k].abs().max().item()
         err = (r[k] - x[k]).abs().max().item() / scale
-        assert err < 5e-2, (k, err)
+        l2 = ((r[k] - x[k]).double().norm() / x[k].double().norm()).item()
+        print("bf16 mode %s: max err / max|.| %.3e, relative L2 %.3e" % (k, err, l2))
+        assert err < 1e-1 and l2 < 4e-2, (k, err, l2)
     assert (r["dW_q.weight"] - x["dW_q.weight"]).abs().max().item() > 0
+
+
+def test_bf16_mode_stores_its_gemm_only_gradients_as_bf16():
+    """Reduced-precision mode at config 4's full size with a frozen image encoder (no dV): bwd_nat32 stores dP_v / dP_q
+    as bf16 and the three GEMMs that consume them read them as stored.  Every value is rounded at the same place as with
+    fp32 storage, so dQ and dW_q are BIT-identical to the run that keeps them in fp32 (the one that also asks for dV);
+    dW_v sums the three levels after the rounding instead of before it (bf16 tolerance)."""
+    from tests._hip import run_hip
+    B, N, T, d = 160, 49, 26, 2048
+    P = O.make_params(d, 12)
+    V, Qs = O.make_inputs(B, N, T, d, 62, lens=sorted([26] + [5] * (B - 1), reverse=True), scale_q=(2.0 / d) ** 0.5)
+    gv = torch.from_numpy(O.hash_normal((3, B, d), 5)).float()
+    gq = torch.from_numpy(O.hash_normal((3, B, d), 6)).float()
+    a = run_hip(V, Qs, P, gv, gq, impl="fused", bf16_proj=True, layout="lm", need_dv=False)
+    b = run_hip(V, Qs, P, gv, gq, impl="fused", bf16_proj=True, layout="lm", need_dv=True)
+    for k in ("dQ", "dW_q.weight", "dW_q.bias", "dW_v.bias", "dw_v.weight", "dw_q.weight"):
+        assert torch.equal(a[k], b[k]), k
+    l2 = ((a["dW_v.weight"] - b["dW_v.weight"]).double().norm() / b["dW_v.weight"].double().norm()).item()
+    print("dW_v, levels summed after / before the bf16 rounding: relative L2 %.3e" % l2)
+    assert 0 < l2 < 1e-2
+    a2 = run_hip(V, Qs, P, gv, gq, impl="fused", bf16_proj=True, layout="lm", need_dv=False)
+    assert torch.equal(a["dW_v.weight"], a2["dW_v.weight"])           # repeatable bit for bit
 
 
 def test_runs_on_the_callers_stream():

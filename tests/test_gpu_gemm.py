@@ -317,3 +317,43 @@ def test_linear_weight_grad_reduced_precision(M, n_out, n_in):
     base = torch.ones(n_out, n_in, device="cuda")
     rc, dW3 = _wgrad(dy, n_out, x, n_in, M, n_out, n_in, accumulate=_lib.FLAG_BF16_PROJ | 1, dW=base.clone())
     assert _rel(dW3 - 1.0, ref) < 5e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(12480, 2048, 2048), (300, 256, 64), (1000, 512, 192)], ids=lambda v: str(v))
+def test_linear_bf16_stored_activations(M, N, K):
+    """COATTN_FLAG_BF16_IN: x is STORED as bf16 (an autocast encoder's activations, the fused backward's own dP_q) and
+    read as it is -- bit for bit the result of the fp32-stored path fed the same (rounded) values; unsupported shapes
+    are refused."""
+    from vqa_amd import _lib
+    torch.manual_seed(33)
+    x = torch.randn(M, K, device="cuda")
+    W = torch.randn(N, K, device="cuda") / K ** 0.5
+    b = torch.randn(N, device="cuda")
+    xb = x.bfloat16().contiguous()
+    rc, y, _ = _linear(xb, K, W, b, M, N, K, flags=_lib.FLAG_BF16_PROJ | _lib.FLAG_BF16_IN)
+    _lib.check(rc, "coattn_linear_forward")
+    rc, y32, _ = _linear(xb.float(), K, W, b, M, N, K, flags=_lib.FLAG_BF16_PROJ)
+    _lib.check(rc, "coattn_linear_forward")
+    assert torch.equal(y, y32)
+    assert _rel(y, xb.double() @ W.bfloat16().double().t() + b.double()) < 2e-5
+    rc, _, _ = _linear(xb, K, W, b, M, N, K, flags=_lib.FLAG_BF16_IN)            # without the reduced-precision mode
+    assert rc != 0
+    rc, _, _ = _linear(xb[:128], K, W, b, 128, N, K, flags=_lib.FLAG_BF16_PROJ | _lib.FLAG_BF16_IN)   # not a gemm_bf shape
+    assert rc != 0
+
+
+@pytest.mark.parametrize("M,n_out,n_in", [(7840, 2048, 2048), (64, 256, 256), (12345 // 32 * 32, 256, 512)], ids=lambda v: str(v))
+def test_linear_weight_grad_bf16_stored_gradients(M, n_out, n_in):
+    """The same for dW = dY^T X with dY stored as bf16 (what bwd_nat32 writes in the reduced-precision mode)."""
+    from vqa_amd import _lib
+    torch.manual_seed(34)
+    dy = (torch.randn(M, n_out, device="cuda") * 0.1).bfloat16().contiguous()
+    x = torch.randn(M, n_in, device="cuda")
+    rc, dW = _wgrad(dy, n_out, x, n_in, M, n_out, n_in, accumulate=_lib.FLAG_BF16_PROJ | _lib.FLAG_BF16_IN)
+    _lib.check(rc, "coattn_linear_weight_grad")
+    rc, dW32 = _wgrad(dy.float(), n_out, x, n_in, M, n_out, n_in, accumulate=_lib.FLAG_BF16_PROJ)
+    _lib.check(rc, "coattn_linear_weight_grad")
+    assert torch.equal(dW, dW32)
+    assert _rel(dW, dy.double().t() @ x.bfloat16().double()) < 2e-5
+    rc, _ = _wgrad(dy, n_out, x, n_in, M, n_out, n_in, accumulate=_lib.FLAG_BF16_IN)
+    assert rc != 0

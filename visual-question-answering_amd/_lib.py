@@ -22,6 +22,7 @@ EXPORTS = ("coattn_version", "coattn_last_error", "coattn_fused_supported", "coa
 F32 = 0
 IMPL_AUTO, IMPL_GENERAL, IMPL_FUSED = 0, 1, 2
 FLAG_BF16_PROJ = 4
+FLAG_BF16_IN = 8          # linear entry points: x (dy) stored as bf16
 
 
 class Params(C.Structure):

@@ -103,7 +103,9 @@ extern "C" int coattn_linear_forward(const void* x, int64_t ld_x, const void* W,
   g.A = (const float*)x; g.a_sm = (int)ld_x; g.Wf = wimg; g.C = (float*)y; g.c_sm = N; g.bias_n = (const float*)bias;
   g.out_scale = out_scale; g.M = M; g.N = N; g.K = K; g.batch = 1;
   g.bf16 = (flags & COATTN_FLAG_BF16_PROJ) ? 1 : 0;
-  CA_CHECK_ARG(gemm_w_supported(g), "linear: shape M=%d N=%d K=%d ld=%ld not supported (see coattn.h)", M, N, K, (long)ld_x);
+  g.a_bf16 = (flags & COATTN_FLAG_BF16_IN) ? 1 : 0;
+  CA_CHECK_ARG(!g.a_bf16 || g.bf16, "linear: COATTN_FLAG_BF16_IN needs COATTN_FLAG_BF16_PROJ");
+  CA_CHECK_ARG(g.a_bf16 ? gemm_bf_supported(g) : gemm_w_supported(g), "linear: shape M=%d N=%d K=%d ld=%ld not supported (see coattn.h)", M, N, K, (long)ld_x);
   if (!(flags & 1)) {
     const WSplit job{(const float*)W, wimg, N, K, 0, K, wimg_pieces(g)};
     CA_TRY(launch_wsplit(&job, 1, (hipStream_t)stream));
@@ -123,8 +125,10 @@ extern "C" int coattn_linear_weight_grad(const void* dy, int64_t ld_dy, const vo
   g.A = (const float*)dy; g.a_ld = (int)ld_dy; g.B = (const float*)x; g.b_ld = (int)ld_x; g.C = (float*)ws;
   g.M = n_out; g.N = n_in; g.K = M; g.levels = 1;
   g.bf16 = (accumulate & COATTN_FLAG_BF16_PROJ) ? 1 : 0;
+  g.a_bf16 = (accumulate & COATTN_FLAG_BF16_IN) ? 1 : 0;
   accumulate &= 1;
-  CA_CHECK_ARG(gemm_tn_supported(g), "linear weight grad: shape M=%d n_out=%d n_in=%d not supported (see coattn.h)", M, n_out, n_in);
+  CA_CHECK_ARG(!g.a_bf16 || g.bf16, "linear weight grad: COATTN_FLAG_BF16_IN needs COATTN_FLAG_BF16_PROJ");
+  CA_CHECK_ARG(g.a_bf16 ? gemm_bf_tn_supported(g) : gemm_tn_supported(g), "linear weight grad: shape M=%d n_out=%d n_in=%d not supported (see coattn.h)", M, n_out, n_in);
   if (gemm_bf_tn_supported(g)) {                     // reduced-precision mode, wide shape: the single-product kernel (gemm_bf.hip)
     const int ntiles = (n_out / 256) * (n_in / 256);
     int want = (bf_tn_rounds() * 256 + ntiles - 1) / ntiles, spp, parts;
@@ -494,7 +498,7 @@ static int forward_impl(const void* V, const VLayout& vl, const void* const* Q, 
   if (!do_attn) return 0;
   if (fused)
     return fused_attention_forward(B, N, T, d, L, (const float*)V, vl, (const float* const*)Q, p, (float*)v_out,
-                                   (float*)q_out, sv, tail, c.s);
+                                   (float*)q_out, sv, tail, c.s, c.bf16_proj ? 1 : 0);
   return general_attention(c, (const float*)V, (const float* const*)Q, p, (float*)v_out, (float*)q_out, sv, tail);
 }
 

@@ -27,7 +27,10 @@
 
 namespace {
 
-template <int NT, int NW>
+// DPB (with SP): dP_v and dP_q are stored as bf16 (same index order, 2-byte elements) -- every consumer is a GEMM of the
+// reduced-precision mode, which would round them on its way in anyway.  Lane pairs (r, r + 1) meet through a DPP quad
+// permute, the even lane stores one dword for both channels.
+template <int NT, int NW, bool SP, bool DPB>
 __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) {
   constexpr int NPAD = 32 * NT;
   constexpr int PIECE = NPAD * 32;                   // bf16 elements of one piece of the C image [n][t = 32]
@@ -45,12 +48,25 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
   const __amdgpu_buffer_rsrc_t rs_pv = make_rsrc(a.Pv + (size_t)b * N * d, (unsigned)N * d * 4u);
   const __amdgpu_buffer_rsrc_t rs_pq = make_rsrc(a.Pq + pair * (size_t)T * d, (unsigned)T * d * 4u);
   const __amdgpu_buffer_rsrc_t rs_dzq = make_rsrc(a.dZq + pair * (size_t)T * d, (unsigned)T * d * 4u);
-  const __amdgpu_buffer_rsrc_t rs_dpq = make_rsrc(a.dPq + pair * (size_t)T * d, (unsigned)T * d * 4u);
+  constexpr int ES = DPB ? 2 : 4;                    // bytes of a stored dP element
+  const __amdgpu_buffer_rsrc_t rs_dpq = make_rsrc(reinterpret_cast<const char*>(a.dPq) + pair * (size_t)T * d * ES, (unsigned)T * d * ES);
   const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(a.C + pair * (size_t)T * N, (unsigned)T * N * 4u);
   const int nsl = d / (128 * NW);                    // 128-channel slices per wave (1 at d = 512)
   constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};   // smallest piece products first
 
-  const __amdgpu_buffer_rsrc_t rs_dpv = make_rsrc(a.dPv + pair * (size_t)N * d, (unsigned)N * d * 4u);
+  const __amdgpu_buffer_rsrc_t rs_dpv = make_rsrc(reinterpret_cast<const char*>(a.dPv) + pair * (size_t)N * d * ES, (unsigned)N * d * ES);
+  // the lane's channel inside a 32-channel unit as the stores see it: bf16 stores leave from the even lanes only (an odd
+  // lane's offset lies outside every buffer)
+  const int rst = DPB && (lane & 1) ? 0x20000000 : r;
+  // element (row, this lane's channel) of a dP array: row_elems = row * d (+ rst inside), so = the unit's scalar offset
+  auto store_dp = [&](const __amdgpu_buffer_rsrc_t rs, float v, const int row_elems, const int so_elems) {
+    if constexpr (DPB) {
+      const float nb = dpp_mov<0xB1, 0xF>(v, v);     // quad_perm [1,0,3,2]: the neighbouring channel
+      __builtin_amdgcn_raw_buffer_store_b32(cvt_pk_bf16(v, nb), rs, (row_elems + rst) * 2, so_elems * 2, 0);
+    } else {
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, (row_elems + rst) * 4, so_elems * 4, 0);
+    }
+  };
   // B operands of a pass (32 channels c0 .. c0 + 31, lane r <-> channel c0 + r): P_q in the k order of the C^T rows
   // (t = 16 ks + 8 h + i), raw; dZ_q accumulator-shaped (rows crow(g, h)), which is also the start of the dP_q
   // accumulators -- its B-operand order comes from one v_permlane32_swap per register pair (coattn_fwd32.hip).
@@ -86,8 +102,10 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
       const int off = n * 32 + 8 * ((tq >> 1) ^ ((n >> 2) & 3)) + 4 * (tq & 1);
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
       *reinterpret_cast<u32x2*>(Cimg + off) = u32x2{hh[0], hh[1]};
-      *reinterpret_cast<u32x2*>(Cimg + PIECE + off) = u32x2{mm[0], mm[1]};
-      *reinterpret_cast<u32x2*>(Cimg + 2 * PIECE + off) = u32x2{ll[0], ll[1]};
+      if (!SP) {
+        *reinterpret_cast<u32x2*>(Cimg + PIECE + off) = u32x2{mm[0], mm[1]};
+        *reinterpret_cast<u32x2*>(Cimg + 2 * PIECE + off) = u32x2{ll[0], ll[1]};
+      }
     }
     const float* dg = a.dsv + pair * (size_t)N;
     for (int e = tid; e < NPAD; e += NTHR) dsvs[e] = e < N ? dg[e] : 0.f;
@@ -102,7 +120,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
   const int rk = (r >> 2) & 3;
   auto read_cq = [&](const short* img, const int s2, bf16x8 (&cq)[3]) {     // A = C (tokens x locations)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < (SP ? 1 : 3); ++p) {
       const bf16x4 lo = lds_tr16(img + p * PIECE + 16 * s2 * 32 + tr_off0);
       const bf16x4 hi = lds_tr16(img + p * PIECE + 16 * s2 * 32 + tr_off1);
       cq[p] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -110,7 +128,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
   };
   auto read_ca = [&](const short* img, const int ks, bf16x8 (&ca)[3]) {      // A = C^T (locations x tokens)
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < (SP ? 1 : 3); ++p)
       ca[p] = *reinterpret_cast<const bf16x8*>(img + p * PIECE + r * 32 + 8 * ((2 * ks + h) ^ rk));
   };
 
@@ -156,7 +174,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
 #pragma unroll
       for (int m = 0; m < 12; ++m) {
         const int ks = m / 6, i = m % 6;
-        cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks ? ca1[PA[i]] : ca0[PA[i]], pqB[ks][PB[i]], cur, 0, 0, 0);
+        if (!SP || i == 5) cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks ? ca1[PA[i]] : ca0[PA[i]], pqB[ks][PB[i]], cur, 0, 0, 0);
         if (m == 1) read_ca(img, 1, ca1);           // operands are read one MFMA group ahead of their use
         if (m == 8) read_cq(imgp, 0, cq0);
         if (m == 11) {
@@ -181,7 +199,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
         const int ks = m / 6, i = m % 6;
         const bf16x8 bp = PB[i] == 0 ? __builtin_bit_cast(bf16x8, Ph[ks]) : PB[i] == 1 ? __builtin_bit_cast(bf16x8, Pm[ks])
                                                                                         : __builtin_bit_cast(bf16x8, Pl[ks]);
-        accq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks ? cq1[PA[i]] : cq0[PA[i]], bp, accq, 0, 0, 0);
+        if (!SP || i == 5) accq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks ? cq1[PA[i]] : cq0[PA[i]], bp, accq, 0, 0, 0);
         if (m == 1) read_cq(imgp, 1, cq1);
         if (m == 9) read_ca(imgp, 0, ca0);
         if (m == 11) read_ca(imgp, 1, ca1);
@@ -191,18 +209,18 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
 #pragma unroll
       for (int m = 0; m < 12; ++m) {
         const int ks = m / 6, i = m % 6;
-        dzp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks ? ca1[PA[i]] : ca0[PA[i]], zqB[ks][PB[i]], dzp, 0, 0, 0);
+        if (!SP || i == 5) dzp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks ? ca1[PA[i]] : ca0[PA[i]], zqB[ks][PB[i]], dzp, 0, 0, 0);
         if (m < 8) dz_reg(8 + m);
         __builtin_amdgcn_sched_barrier(0);
       }
       // dP_v(u-1) out (u = 0: zeros into rows that do not exist -- the offset lies outside the buffer)
-      const int so = u > 0 ? (32 * (u - 1) * d + c0) * 4 : 0x40000000;
+      const int so = u > 0 ? 32 * (u - 1) * d + c0 : 0x10000000;   // (elements: outside the buffer at either element size)
       const float live = u > 0 ? 1.f : 0.f;
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         float v = dzp[g];
         asm volatile("" : "+v"(v));                  // (opaque scalar: see the epilogue)
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_dpv, (crow(g, h) * d + r) * 4, so, 0);
+        store_dp(rs_dpv, v, crow(g, h) * d, so);
         dbacc = fmaf(live, v, dbacc);
       }
     };
@@ -249,16 +267,15 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
       read_ca(imgp, 1, ca1);
       split3(f32x8{dz[0], dz[1], dz[2], dz[3], dz[4], dz[5], dz[6], dz[7]}, b0);
       split3(f32x8{dz[8], dz[9], dz[10], dz[11], dz[12], dz[13], dz[14], dz[15]}, b1);
-      accq = mfma32_x3(cq0, b0, accq);
-      accq = mfma32_x3(cq1, b1, accq);
-      dz = mfma32_x3(ca0, zqB[0], dz);
-      dz = mfma32_x3(ca1, zqB[1], dz);
+      accq = mfma32_x3<SP>(cq0, b0, accq);
+      accq = mfma32_x3<SP>(cq1, b1, accq);
+      dz = mfma32_x3<SP>(ca0, zqB[0], dz);
+      dz = mfma32_x3<SP>(ca1, zqB[1], dz);
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         float v = dz[g];
         asm volatile("" : "+v"(v));
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_dpv, (crow(g, h) * d + r) * 4,
-                                              (32 * lu * d + c0) * 4, 0);
+        store_dp(rs_dpv, v, crow(g, h) * d, 32 * lu * d + c0);
         dbacc += v;
       }
     };
@@ -271,7 +288,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
     // epilogue: dP_q out; db_q = sum_t dP_q[t][:] (rows t >= T are exact zeros), dw_v, db_v partials of this
     // (sample, level): in-lane sums over the accumulator rows, then the two lane halves
     {
-      int hrow = (4 * h * d + r) * 4;
+      int hrow = 4 * h * d;
       asm volatile("" : "+v"(hrow));
       float s = 0.f;
 #pragma unroll
@@ -280,8 +297,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
         // times -- caught by the parity tests)
         float v = accq[g];
         asm volatile("" : "+v"(v));
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_dpq,
-                                              hrow + ((g & 3) + 8 * (g >> 2)) * d * 4, c0 * 4, 0);
+        store_dp(rs_dpq, v, hrow + ((g & 3) + 8 * (g >> 2)) * d, c0);
         s += v;
       }
       s += __shfl_xor(s, 32, 64);
@@ -307,7 +323,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
 //     dC += (P_q w_v) dZ_v^T.
 // The saved P_v, P_q carry the factor kPScale (fused.h): right for the exponential, divided out of the two dC operands.
 // Cross-wave sum per location tile through LDS in a fixed order; rows t >= T / n >= N: loads 0, stores dropped.
-template <int NT, int NW>
+template <int NT, int NW, bool SP>
 __global__ __launch_bounds__(NW * 64, 2) void bwd_dc32_kernel(const BwdArgs a) {
   constexpr int NPAD = 32 * NT, PIECE = NPAD * 32, NTHR = NW * 64, SLD = 36;
   constexpr int GT = NT > COATTN_DC_GT ? COATTN_DC_GT : NT;   // location tiles per group
@@ -344,8 +360,10 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc32_kernel(const BwdArgs a) {
       const int off = n * 32 + 8 * ((tq >> 1) ^ ((n >> 2) & 3)) + 4 * (tq & 1);
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
       *reinterpret_cast<u32x2*>(Cimg + off) = u32x2{hh[0], hh[1]};
-      *reinterpret_cast<u32x2*>(Cimg + PIECE + off) = u32x2{mm[0], mm[1]};
-      *reinterpret_cast<u32x2*>(Cimg + 2 * PIECE + off) = u32x2{ll[0], ll[1]};
+      if (!SP) {
+        *reinterpret_cast<u32x2*>(Cimg + PIECE + off) = u32x2{mm[0], mm[1]};
+        *reinterpret_cast<u32x2*>(Cimg + 2 * PIECE + off) = u32x2{ll[0], ll[1]};
+      }
     }
     const float* dg = a.dsv + pair * (size_t)N;
     for (int e = tid; e < NPAD; e += NTHR) dsvs[e] = e < N ? dg[e] : 0.f;
@@ -355,7 +373,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc32_kernel(const BwdArgs a) {
   const int rk = (r >> 2) & 3;
   auto read_ca = [&](const short* img, const int ks, bf16x8 (&ca)[3]) {      // C^T rows: lane = location, 8 tokens
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < (SP ? 1 : 3); ++p)
       ca[p] = *reinterpret_cast<const bf16x8*>(img + p * PIECE + r * 32 + 8 * ((2 * ks + h) ^ rk));
   };
   auto split16 = [&](const f32x16& x, bf16x8 (&p0)[3], bf16x8 (&p1)[3]) {
@@ -426,9 +444,9 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc32_kernel(const BwdArgs a) {
         bf16x8 F0[3], F1[3], Z0[3], Z1[3], ca[3];
         split16(cur, F0, F1);
         read_ca(img, 0, ca);
-        cur = mfma32_x3(pqB[0], ca, cur);
+        cur = mfma32_x3<SP>(pqB[0], ca, cur);
         read_ca(img, 1, ca);
-        cur = mfma32_x3(pqB[1], ca, cur);
+        cur = mfma32_x3<SP>(pqB[1], ca, cur);
         const float ds4 = 4.0f * dsvs[32 * nt + r];
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
@@ -436,10 +454,10 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc32_kernel(const BwdArgs a) {
           cur[g] = fmaf(-rr, rr, rr) * ds4;
         }
         split16(cur, Z0, Z1);
-        dC[ti] = mfma32_x3(pqA[0], Z0, dC[ti]);
-        dC[ti] = mfma32_x3(pqA[1], Z1, dC[ti]);
-        dC[ti] = mfma32_x3(zqA[0], F0, dC[ti]);
-        dC[ti] = mfma32_x3(zqA[1], F1, dC[ti]);
+        dC[ti] = mfma32_x3<SP>(pqA[0], Z0, dC[ti]);
+        dC[ti] = mfma32_x3<SP>(pqA[1], Z1, dC[ti]);
+        dC[ti] = mfma32_x3<SP>(zqA[0], F0, dC[ti]);
+        dC[ti] = mfma32_x3<SP>(zqA[1], F1, dC[ti]);
       }
     }
     // ---- the group's tiles: cross-wave sum in a fixed order, dA = dC (1 - C^2)
@@ -476,12 +494,12 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc32_kernel(const BwdArgs a) {
   }
 }
 
-template <int NT, int NW>
+template <int NT, int NW, bool SP>
 int launch_dc32(const BwdArgs& a, hipStream_t s) {
   constexpr int NPAD = 32 * NT;
   const size_t lds = (size_t)3 * NPAD * 32 * 2 + (size_t)NPAD * 4 + (size_t)NW * 32 * 36 * 4;
   const int groups = (a.B + 7) / 8;
-  hipLaunchKernelGGL((bwd_dc32_kernel<NT, NW>), dim3(groups * a.L * 8), dim3(NW * 64), lds, s, a);
+  hipLaunchKernelGGL((bwd_dc32_kernel<NT, NW, SP>), dim3(groups * a.L * 8), dim3(NW * 64), lds, s, a);
   CA_CHECK_LAUNCH("bwd_dc32");
   return 0;
 }
@@ -492,7 +510,7 @@ int launch_dc32(const BwdArgs& a, hipStream_t s) {
 // is split and used as the B operand (contraction over its row index = locations), the A operand is dA_l, split
 // once per workgroup into an LDS image [piece][t][n] whose n order inside every group of 16 is the accumulator row
 // order of a lane half (one 16-byte read per piece and k-step).
-template <int NT, bool LM>
+template <int NT, bool LM, bool SP>
 __global__ __launch_bounds__(256) void bwd_dq32_kernel(const DqArgs a) {
   constexpr int NPAD = 32 * NT;
   constexpr int LDR = NPAD + 8;                      // image row stride (bf16): 8 consecutive rows cover the banks once
@@ -550,8 +568,10 @@ __global__ __launch_bounds__(256) void bwd_dq32_kernel(const DqArgs a) {
     const int off = t * LDR + (n & ~15) + ((m16 & 3) | ((m16 & 4) << 1) | ((m16 & 8) >> 1));
     if (t < kTRows) {                                // (the last sweep is partial)
       *reinterpret_cast<unsigned*>(img + off) = hh;
-      *reinterpret_cast<unsigned*>(img + PIECE + off) = mm;
-      *reinterpret_cast<unsigned*>(img + 2 * PIECE + off) = ll;
+      if (!SP) {
+        *reinterpret_cast<unsigned*>(img + PIECE + off) = mm;
+        *reinterpret_cast<unsigned*>(img + 2 * PIECE + off) = ll;
+      }
     }
   }
   if (tid < 32) aqs[tid] = tid < T ? a.aq[pair * (size_t)T + tid] : 0.f;
@@ -562,14 +582,14 @@ __global__ __launch_bounds__(256) void bwd_dq32_kernel(const DqArgs a) {
   auto tile = [&](int nt, const f32x16& v) {
     bf16x8 b0[3], b1[3], a0[3], a1[3];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < (SP ? 1 : 3); ++p) {
       a0[p] = *reinterpret_cast<const bf16x8*>(img + p * PIECE + r * LDR + 32 * nt + 8 * h);
       a1[p] = *reinterpret_cast<const bf16x8*>(img + p * PIECE + r * LDR + 32 * nt + 16 + 8 * h);
     }
     split3(f32x8{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]}, b0);
     split3(f32x8{v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]}, b1);
-    acc = mfma32_x3(a0, b0, acc);
-    acc = mfma32_x3(a1, b1, acc);
+    acc = mfma32_x3<SP>(a0, b0, acc);
+    acc = mfma32_x3<SP>(a1, b1, acc);
   };
 #pragma unroll 1
   for (int nt = 0; nt < ntiles; nt += 4) {
@@ -598,7 +618,7 @@ __global__ __launch_bounds__(256) void bwd_dq32_kernel(const DqArgs a) {
 // dA images of the three levels together are 36 KB): the V fragments are loaded and split ONCE and serve the three
 // levels' MFMAs (the split is what bwd_dq32_kernel spends its issue slots on: 88 VALU per 12 MFMAs there, per 36 here),
 // and V is read once per sample instead of once per level.
-template <int NT, bool LM>
+template <int NT, bool LM, bool SP>
 __global__ __launch_bounds__(256) void bwd_dq32x_kernel(const DqArgs a) {
   static_assert(NT <= 2, "the images of all levels must fit the LDS of several workgroups per CU");
   constexpr int NPAD = 32 * NT;
@@ -652,8 +672,10 @@ __global__ __launch_bounds__(256) void bwd_dq32x_kernel(const DqArgs a) {
       const int off = l * LEVEL + t * LDR + (n & ~15) + ((m16 & 3) | ((m16 & 4) << 1) | ((m16 & 8) >> 1));
       if (t < kTRows) {
         *reinterpret_cast<unsigned*>(img + off) = hh;
-        *reinterpret_cast<unsigned*>(img + PIECE + off) = mm;
-        *reinterpret_cast<unsigned*>(img + 2 * PIECE + off) = ll;
+        if (!SP) {
+          *reinterpret_cast<unsigned*>(img + PIECE + off) = mm;
+          *reinterpret_cast<unsigned*>(img + 2 * PIECE + off) = ll;
+        }
       }
     }
   if (tid < 32 * ML) {
@@ -675,12 +697,12 @@ __global__ __launch_bounds__(256) void bwd_dq32x_kernel(const DqArgs a) {
     for (int l = 0; l < ML; ++l) {
       bf16x8 a0[3], a1[3];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
+      for (int p = 0; p < (SP ? 1 : 3); ++p) {
         a0[p] = *reinterpret_cast<const bf16x8*>(img + l * LEVEL + p * PIECE + r * LDR + 32 * nt + 8 * h);
         a1[p] = *reinterpret_cast<const bf16x8*>(img + l * LEVEL + p * PIECE + r * LDR + 32 * nt + 16 + 8 * h);
       }
-      acc[l] = mfma32_x3(a0, b0, acc[l]);
-      acc[l] = mfma32_x3(a1, b1, acc[l]);
+      acc[l] = mfma32_x3<SP>(a0, b0, acc[l]);
+      acc[l] = mfma32_x3<SP>(a1, b1, acc[l]);
     }
   }
   // dQ_l[b][t][c0 + r] (+)= acc_l + a_q,l[t] gq_l[c0 + r]; rows t >= T lie outside the buffer
@@ -702,52 +724,70 @@ __global__ __launch_bounds__(256) void bwd_dq32x_kernel(const DqArgs a) {
   }
 }
 
-template <int NT, bool LM>
+template <int NT, bool LM, bool SP>
 int launch_dq32x(const DqArgs& a, hipStream_t s) {
   constexpr int NPAD = 32 * NT;
   const size_t lds = (size_t)3 * ((3 * kTRows + 4) * (NPAD + 8) * 2) + 3 * 32 * 4;
-  hipLaunchKernelGGL((bwd_dq32x_kernel<NT, LM>), dim3(a.B * (a.d / 128)), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((bwd_dq32x_kernel<NT, LM, SP>), dim3(a.B * (a.d / 128)), dim3(256), lds, s, a);
   CA_CHECK_LAUNCH("bwd_dq32x");
   return 0;
 }
 
-template <int NT, bool LM>
+template <int NT, bool LM, bool SP>
 int launch_dq32(const DqArgs& a, hipStream_t s) {
   constexpr int NPAD = 32 * NT;
   const size_t lds = (size_t)(3 * kTRows + 4) * (NPAD + 8) * 2 + 32 * 4;   // + 4 rows: what lanes 28 .. 31 of the last piece read
   const int items = a.B * (a.d / 128);
-  hipLaunchKernelGGL((bwd_dq32_kernel<NT, LM>), dim3(((items + 7) / 8) * a.L * 8), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((bwd_dq32_kernel<NT, LM, SP>), dim3(((items + 7) / 8) * a.L * 8), dim3(256), lds, s, a);
   CA_CHECK_LAUNCH("bwd_dq32");
   return 0;
 }
 
-template <int NT, int NW>
+template <int NT, int NW, bool SP, bool DPB>
 int launch_nat32(const BwdArgs& a, hipStream_t s) {
   constexpr int NPAD = 32 * NT;
   const size_t lds = (size_t)3 * NPAD * 32 * 2 + (size_t)NPAD * 4;
   const int groups = (a.B + 7) / 8;
-  hipLaunchKernelGGL((bwd_nat32_kernel<NT, NW>), dim3(groups * a.L * 8), dim3(NW * 64), lds, s, a);
+  hipLaunchKernelGGL((bwd_nat32_kernel<NT, NW, SP, DPB>), dim3(groups * a.L * 8), dim3(NW * 64), lds, s, a);
   CA_CHECK_LAUNCH("bwd_nat32");
   return 0;
 }
 
 }  // namespace
 
+// The reduced-precision mode (a.bf16: one MFMA per product) exists for the four-wave kernels (d % 512 == 0); other widths
+// keep the exact split.
 int launch_bwd_nat32(const BwdArgs& a, hipStream_t s) {
   const bool small_n = a.N <= 64;
-  if (a.d % 512 == 0) return small_n ? launch_nat32<2, 4>(a, s) : launch_nat32<7, 4>(a, s);
-  return small_n ? launch_nat32<2, 2>(a, s) : launch_nat32<7, 2>(a, s);
+  if (a.d % 512 == 0) {
+    if (a.bf16 && a.dp_bf16) return small_n ? launch_nat32<2, 4, true, true>(a, s) : launch_nat32<7, 4, true, true>(a, s);
+    CA_CHECK_ARG(!a.dp_bf16, "bwd_nat32: bf16 dP storage exists in the reduced-precision mode only");
+    if (a.bf16) return small_n ? launch_nat32<2, 4, true, false>(a, s) : launch_nat32<7, 4, true, false>(a, s);
+    return small_n ? launch_nat32<2, 4, false, false>(a, s) : launch_nat32<7, 4, false, false>(a, s);
+  }
+  CA_CHECK_ARG(!a.dp_bf16, "bwd_nat32: bf16 dP storage needs d % 512 == 0");
+  return small_n ? launch_nat32<2, 2, false, false>(a, s) : launch_nat32<7, 2, false, false>(a, s);
 }
 
 int launch_bwd_dq32(const DqArgs& a, int lm, hipStream_t s) {
   static const int shared = [] { const char* e = getenv("COATTN_DQ32X"); return e ? atoi(e) : 1; }();   // developer switch
-  if (a.N <= 64 && a.L <= 3 && shared) return lm ? launch_dq32x<2, true>(a, s) : launch_dq32x<2, false>(a, s);
-  if (lm) return a.N <= 64 ? launch_dq32<2, true>(a, s) : launch_dq32<7, true>(a, s);
-  return a.N <= 64 ? launch_dq32<2, false>(a, s) : launch_dq32<7, false>(a, s);
+  if (a.N <= 64 && a.L <= 3 && shared) {
+    if (a.bf16) return lm ? launch_dq32x<2, true, true>(a, s) : launch_dq32x<2, false, true>(a, s);
+    return lm ? launch_dq32x<2, true, false>(a, s) : launch_dq32x<2, false, false>(a, s);
+  }
+  if (a.bf16) {
+    if (lm) return a.N <= 64 ? launch_dq32<2, true, true>(a, s) : launch_dq32<7, true, true>(a, s);
+    return a.N <= 64 ? launch_dq32<2, false, true>(a, s) : launch_dq32<7, false, true>(a, s);
+  }
+  if (lm) return a.N <= 64 ? launch_dq32<2, true, false>(a, s) : launch_dq32<7, true, false>(a, s);
+  return a.N <= 64 ? launch_dq32<2, false, false>(a, s) : launch_dq32<7, false, false>(a, s);
 }
 
 int launch_bwd_dc32(const BwdArgs& a, hipStream_t s) {
   const bool small_n = a.N <= 64;
-  if (a.d % 512 == 0) return small_n ? launch_dc32<2, 4>(a, s) : launch_dc32<7, 4>(a, s);
-  return small_n ? launch_dc32<2, 2>(a, s) : launch_dc32<7, 2>(a, s);
+  if (a.d % 512 == 0) {
+    if (a.bf16) return small_n ? launch_dc32<2, 4, true>(a, s) : launch_dc32<7, 4, true>(a, s);
+    return small_n ? launch_dc32<2, 4, false>(a, s) : launch_dc32<7, 4, false>(a, s);
+  }
+  return small_n ? launch_dc32<2, 2, false>(a, s) : launch_dc32<7, 2, false>(a, s);
 }

@@ -360,8 +360,9 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   ba.dPv = ws + wo.dPv; ba.dPq = ws + wo.dPq; ba.dA = ws + wo.dA; ba.dwv_part = ws + wo.dwv_part;
   ba.dbv_part = ws + wo.dbv_part; ba.dbq_part = ws + wo.dbq_part;
   ba.B = B; ba.N = N; ba.T = T; ba.d = d; ba.L = L;
+  ba.bf16 = bf16_proj;
+  ba.dp_bf16 = 0;
   CA_TRY(launch_bwd_dc32(ba, s));                    // dC, dA                       (coattn_bwd32.hip)
-  CA_TRY(launch_bwd_nat32(ba, s));                   // dP_q, dP_v, dw_v, db_v, db_q (coattn_bwd32.hip)
   // which of the backward's GEMMs take the hand-scheduled kernels (decided here: when all three do, they share ONE
   // launch in step 5 -- weight gradients, the dQ projection's tiles and the small reductions)
   float* dPv = ws + wo.dPv;
@@ -393,6 +394,23 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   const bool wdq_ok = wgemm && q_al && gemm_w_supported(wdq);
   // (a dQ projection on gemm_bf.hip -- 512-thread workgroups -- cannot ride in the weight-gradient launch)
   const bool combine = dq32 && wdq_ok && tn_v && tn_q && !gemm_bf_supported(wdq);
+  // Reduced-precision mode with a frozen image encoder (no dV) and all three consumers of dP_v / dP_q on gemm_bf.hip:
+  // bwd_nat32 stores both as bf16 -- the GEMMs would round them on their way in anyway -- halving what it writes and
+  // what they fetch.
+  {
+    TnGemm tv = tnv, tq = tnq;
+    WGemm wq = wdq;
+    tv.a_bf16 = tq.a_bf16 = wq.a_bf16 = 1;
+    tv.a_term = L == 3 ? (long)BNd : 0;
+    static const int off = [] { const char* e = getenv("COATTN_DP_BF16"); return e && atoi(e) == 0; }();   // developer switch
+    if (!off && bf16_proj && !dV && L == 3 && d % 512 == 0 && dq32 && wdq_ok && tn_v && tn_q && gemm_bf_tn_supported(tv) &&
+        gemm_bf_tn_supported(tq) && gemm_bf_supported(wq)) {
+      ba.dp_bf16 = 1;
+      tnv.a_bf16 = tnq.a_bf16 = wdq.a_bf16 = 1;
+      tnq.a_sl = (long)BTd; wdq.a_sz = (long)BTd;   // (elements, as before)
+    }
+  }
+  CA_TRY(launch_bwd_nat32(ba, s));                   // dP_q, dP_v, dw_v, db_v, db_q (coattn_bwd32.hip)
   // 3. small parameter gradients from the per-(sample, level) partials (dw_v, db_v, db_q, dw_q, and dc_v, dc_q as
   //    whole-array sums): a few short workgroups -- riding along in the weight-gradient launch of step 5 when that
   //    is the hand-scheduled one, else a launch of their own
@@ -434,6 +452,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     da.V = V; da.v_sB = vl.sB; da.dA = ws + wo.dA; da.aq = saved + so.aq; da.gq = gq;
     for (int l = 0; l < 8; ++l) da.dQ[l] = l < L ? dQ[l] : nullptr;
     da.B = B; da.N = N; da.T = T; da.d = d; da.L = L;
+    da.bf16 = bf16_proj;
     const bool al = (N % 4) == 0;
     dim3 grid(d / 128, B), block(256);
     if (dq32) {

@@ -59,7 +59,9 @@ __device__ __forceinline__ void vmcnt_wait(int n) {
 }
 
 
-template <int NT, int NW, bool LM>
+// SP (single product): the reduced-precision mode (COATTN_FLAG_BF16_PROJ) -- every operand rounded once to bf16, ONE MFMA per product
+// (the hi x hi term of the split; the mid / lo pieces are neither computed, stored in the LDS image nor read back).
+template <int NT, int NW, bool LM, bool SP>
 __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs a) {
   constexpr int NPAD = 32 * NT;
   constexpr int SLD = 36;                            // row stride of the f32 reduction slots [n][t = 32]: 16-byte accesses
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
 #pragma unroll
             for (int m = 0; m < 12; ++m) {
               const int ks = m / 6, i = m % 6;
-              acc[j - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks][PA[i]], b3[ks][PB[i]], acc[j - 1], 0, 0, 0);
+              if (!SP || i == 5) acc[j - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks][PA[i]], b3[ks][PB[i]], acc[j - 1], 0, 0, 0);
               if (jn != 0 && m >= 2 && m < 10) {     // the next unit is a V tile: split it under these MFMAs
                 const int pr = m - 2;
                 unsigned hh, mm, ll;
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
             u32x4 nh, nm, nl;
   #pragma unroll
             for (int m = 0; m < 6; ++m) {
-              acc[j - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[PA[m]], b3[PB[m]], acc[j - 1], 0, 0, 0);
+              if (!SP || m == 5) acc[j - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[PA[m]], b3[PB[m]], acc[j - 1], 0, 0, 0);
               if (next_bf && m < 4) {
                 unsigned hh, mm, ll;
                 split3_pair(nxt[2 * m], nxt[2 * m + 1], hh, mm, ll);
@@ -414,8 +416,10 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
       const int off = n * 32 + 8 * ((tq >> 1) ^ ((n >> 2) & 3)) + 4 * (tq & 1);
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
       *reinterpret_cast<u32x2*>(Cimg + off) = u32x2{hh[0], hh[1]};
-      *reinterpret_cast<u32x2*>(Cimg + PIECE + off) = u32x2{mm[0], mm[1]};
-      *reinterpret_cast<u32x2*>(Cimg + 2 * PIECE + off) = u32x2{ll[0], ll[1]};
+      if (!SP) {
+        *reinterpret_cast<u32x2*>(Cimg + PIECE + off) = u32x2{mm[0], mm[1]};
+        *reinterpret_cast<u32x2*>(Cimg + 2 * PIECE + off) = u32x2{ll[0], ll[1]};
+      }
     }
   }
   lds_barrier();
@@ -494,7 +498,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
       };
       auto read_cq = [&](const short* img, const int s2, bf16x8 (&cq)[3]) {     // A = C (tokens x locations)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < (SP ? 1 : 3); ++p) {
           const bf16x4 lo = lds_tr16(img + p * PIECE + 16 * s2 * 32 + tr_off0);
           const bf16x4 hi = lds_tr16(img + p * PIECE + 16 * s2 * 32 + tr_off1);
           cq[p] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
       };
       auto read_ca = [&](const short* img, const int ks, bf16x8 (&ca)[3]) {      // A = C^T (locations x tokens)
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < (SP ? 1 : 3); ++p)
           ca[p] = *reinterpret_cast<const bf16x8*>(img + p * PIECE + r * 32 + 8 * ((2 * ks + h) ^ rk));
       };
       auto store_scores = [&](int u, float mine) {   // u: the finished unit (second channel half of tile u >> 1)
@@ -527,7 +531,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
 #pragma unroll
         for (int m = 0; m < 24; ++m) {
           // ---- the MFMA
-          const int grp = m / 6, i = m % 6;
+          const int grp = SP && (m % 6) != 5 ? -1 : m / 6, i = m % 6;
           if (grp == 0) accq[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cq0[PA[i]], pb0[PB[i]], accq[ct], 0, 0, 0);
           if (grp == 1) {
             const bf16x8 b = PB[i] == 0 ? __builtin_bit_cast(bf16x8, h1) : PB[i] == 1 ? __builtin_bit_cast(bf16x8, m1)
@@ -785,7 +789,7 @@ __global__ __launch_bounds__(256) void attend_v_lm_kernel(const float* V, long v
   }
 }
 
-template <int NT, int NW, bool LM>
+template <int NT, int NW, bool LM, bool SP>
 int launch_fwd32(const FwdArgs& a, hipStream_t s) {
   constexpr int NPAD = 32 * NT;
   constexpr int RING_SLOTS = (NT + 1) * ((NT + 1 >= 6) ? 1 : 2);
@@ -793,12 +797,12 @@ int launch_fwd32(const FwdArgs& a, hipStream_t s) {
   const size_t lds = lds_p2 > lds_p1 ? lds_p2 : lds_p1;
   static DeviceOnce once;                            // the attribute is per device
   CA_TRY(once.run([&] {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(coattn_fwd32_kernel<NT, NW, LM>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(coattn_fwd32_kernel<NT, NW, LM, SP>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }, "coattn_fwd32"));
   const int groups = (a.B + 7) / 8;
   dim3 grid(groups * a.L * 8), block(NW * 64);
-  hipLaunchKernelGGL((coattn_fwd32_kernel<NT, NW, LM>), grid, block, lds, s, a);
+  hipLaunchKernelGGL((coattn_fwd32_kernel<NT, NW, LM, SP>), grid, block, lds, s, a);
   CA_CHECK_LAUNCH("coattn_fwd32");
   return 0;
 }
@@ -806,8 +810,11 @@ int launch_fwd32(const FwdArgs& a, hipStream_t s) {
 template <bool LM>
 int dispatch_fwd32(const FwdArgs& a, hipStream_t s) {
   const bool small_n = a.N <= 64;
-  if (a.d % 512 == 0) return small_n ? launch_fwd32<2, 4, LM>(a, s) : launch_fwd32<7, 4, LM>(a, s);
-  return small_n ? launch_fwd32<2, 2, LM>(a, s) : launch_fwd32<7, 2, LM>(a, s);
+  if (a.d % 512 == 0) {
+    if (a.bf16) return small_n ? launch_fwd32<2, 4, LM, true>(a, s) : launch_fwd32<7, 4, LM, true>(a, s);
+    return small_n ? launch_fwd32<2, 4, LM, false>(a, s) : launch_fwd32<7, 4, LM, false>(a, s);
+  }
+  return small_n ? launch_fwd32<2, 2, LM, false>(a, s) : launch_fwd32<7, 2, LM, false>(a, s);   // (exact at these widths)
 }
 
 }  // namespace

@@ -17,7 +17,7 @@ inline bool fused_layout_ok(const VLayout& v, int N, int d) { return v_is_lm(v, 
 // everything after the projections (P_v, P_q already in `saved`)
 int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, const VLayout& vl,
                             const float* const* Q, const coattn_params* p, float* v_out, float* q_out, float* saved,
-                            float* ws, hipStream_t s);
+                            float* ws, hipStream_t s, int bf16 = 0);   // bf16: reduced precision, one MFMA per product
 int fused_backward_supported(int B, int N, int T, int d, int L);
 int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLayout& vl, const float* const* Q,
                    const coattn_params* p, const float* saved, const float* gv, const float* gq, float* dV,
@@ -99,7 +99,10 @@ __device__ __forceinline__ void split3(const f32x8& v, bf16x8 (&p)[3]) {
 }
 // c += a . b over 16 k (32x32x16) with fp32 accuracy: the six partial products down to relative order 2^-16
 // (each bf16 x bf16 product is exact in the fp32 accumulator), smallest terms first
+// (SP, the reduced-precision mode: the hi x hi product alone -- the other pieces are dead code)
+template <bool SP = false>
 __device__ __forceinline__ f32x16 mfma32_x3(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c) {
+  if constexpr (SP) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
@@ -139,6 +142,7 @@ struct WGemm {
   const float* bias_n; float out_scale;
   int M, N, K, batch;
   int bf16;                                                          // 1: operands rounded to bf16, ONE MFMA per product (COATTN_FLAG_BF16_PROJ)
+  int a_bf16;                                                        // (gemm_bf_kernel) A is STORED as bf16; a_sm, a_sz stay in elements
 };
 size_t wsplit_bytes(int N, int K);
 int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s);
@@ -169,6 +173,7 @@ struct TnGemm {
   int mask_blk; unsigned tile_mask;                                  // mask_blk > 0: tile (mt, nt) is computed only if bit
                                                                      // (mt / mask_blk) * 3 + nt / mask_blk of tile_mask is set
   int bf16;                                                          // 1: operands rounded to bf16, ONE MFMA per product
+  int a_bf16;                                                        // (gemm_bf_tn_kernel) A is STORED as bf16; a_ld, a_sl, a_term in elements
 };
 int gemm_tn_supported(const TnGemm& d);
 // the same products in the reduced-precision mode at wide shapes (gemm_bf.hip): 256 x 256 tiles, parts over the concatenated levels
@@ -228,6 +233,7 @@ struct FwdArgs {
   float* q_out;          // [L][B][d]
   unsigned long long* stamps;   // diagnostic builds only
   int B, N, T, d, L;
+  int bf16;              // reduced-precision mode: operands rounded to bf16, one MFMA per product (d % 512 == 0)
 };
 
 // arguments of the two big fused backward kernels (coattn_fused_bwd.hip, coattn_bwd32.hip)
@@ -245,6 +251,8 @@ struct BwdArgs {
   float* dbv_part;        // [L*B][d]   sum_n dP_v[n][:]
   float* dbq_part;        // [L*B][d]   sum_t dP_q[t][:]
   int B, N, T, d, L;
+  int bf16;               // reduced-precision mode: one MFMA per product (d % 512 == 0)
+  int dp_bf16;            // (with bf16, bwd_nat32_kernel) dPv / dPq are bf16 arrays of the same index order
 };
 
 // dP_q on the bf16 MFMA 32x32x16 with the exact 3-way split (coattn_bwd32.hip); same shapes as the fused forward
@@ -258,6 +266,7 @@ struct DqArgs {
   float* dQ[8];
   int B, N, T, d, L;
   int accumulate;        // bwd_dq32_kernel: add onto dQ (which then already holds dP_q W_q) instead of overwriting it
+  int bf16;              // reduced-precision mode: one MFMA per product
 };
 // dQ_l = a_q (x) gq + dA_l V on the bf16 MFMA with the exact 3-way split: location-major V (lm), or channel-major V
 // whose rows are 16-byte multiples (N % 4 == 0)

@@ -41,6 +41,9 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 
 struct BfJobs { gw::WArgs job[2]; int first1; };
 
+// ABF: A is stored as bf16 (the fused backward's dP_q in the reduced-precision mode; bf16 activations through
+// coattn_linear_forward): 16-byte loads of 8 elements, half as many per step, written to the same image as they are.
+template <bool ABF>
 __device__ __forceinline__ void gemm_bf_body(const gw::WArgs& g, const int id, short* const smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3, li = lane & 31, lh = lane >> 5;
@@ -50,8 +53,13 @@ __device__ __forceinline__ void gemm_bf_body(const gw::WArgs& g, const int id, s
   const int z = slot / per, t = slot % per, mt = (t / ntn) * 8 + x;
   if (mt >= ntm) return;
   const int m0 = mt * TM, n0 = (g.kband_n > 0 ? ntn - 1 - t % ntn : t % ntn) * TN;
-  const float* Ab = g.a_ptrs[0] ? g.a_ptrs[z & 7] : g.A + (long)z * g.a_sz;
-  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(Ab, (unsigned)(((long)(g.M - 1) * g.a_sm + g.K) * 4));
+  constexpr int ES = ABF ? 2 : 4;                 // bytes of a stored A element
+  constexpr int NA = ABF ? 4 : 8;                 // 16-byte loads per thread and step
+  constexpr int RP = ABF ? 64 : 32;               // rows per load sweep of the workgroup
+  // (one select between a table entry and a computed address: a select between two LOADED fields of the by-value
+  //  argument struct makes hipcc copy the whole struct to scratch)
+  const char* Ab = g.a_ptrs[0] ? reinterpret_cast<const char*>(g.a_ptrs[z & 7]) : reinterpret_cast<const char*>(g.A) + (long)z * g.a_sz * ES;
+  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(Ab, (unsigned)(((long)(g.M - 1) * g.a_sm + g.K) * ES));
   const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(g.Wf, g.wf_bytes);
   int k_lo = 0, k_hi = g.K;
   if (g.kband_n > 0) {
@@ -60,12 +68,12 @@ __device__ __forceinline__ void gemm_bf_body(const gw::WArgs& g, const int id, s
   }
   const int KS = (k_hi - k_lo) / TK;              // (host check: multiples of 64)
 
-  // A staging: 8 float4 per thread and step; a wave's load covers 4 rows x 256 B
-  const int a_row = tid >> 4, a_k = (tid & 15) * 4;
-  int a_voff[8];
+  // A staging: 8 float4 per thread and step, a wave's load covers 4 rows x 256 B (bf16 A: 4 loads, 8 rows x 128 B)
+  const int a_row = ABF ? tid >> 3 : tid >> 4, a_k = ABF ? (tid & 7) * 8 : (tid & 15) * 4;
+  int a_voff[NA];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) a_voff[i] = (m0 + a_row + 32 * i) < g.M ? ((m0 + a_row + 32 * i) * g.a_sm + a_k) * 4 : 0x40000000;
-  const int a_wr = a_row * LDA + a_k;             // + 32 i rows
+  for (int i = 0; i < NA; ++i) a_voff[i] = (m0 + a_row + RP * i) < g.M ? ((m0 + a_row + RP * i) * g.a_sm + a_k) * ES : 0x40000000;
+  const int a_wr = a_row * LDA + a_k;             // + RP i rows
   const int a_rd = (wr * 128 + li) * LDA + 8 * lh;   // + 32 mt rows, + 16 ks
   // B: wave w moves the four 16-k chunks of column tile w of this step (lane-linear 1 KB each)
   const int b_src = ((n0 / 32 + wave) * (g.K / 16)) * kChunk;        // + (k / 16) chunks; lane part in the vector offset
@@ -80,10 +88,10 @@ __device__ __forceinline__ void gemm_bf_body(const gw::WArgs& g, const int id, s
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 raw[8];
+  f32x4 raw[NA];                                  // (bf16 A: 8 elements per register quad)
   auto load_a = [&](int s) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) raw[i] = buf_load4(rs_a, a_voff[i], (k_lo + s * TK) * 4);
+    for (int i = 0; i < NA; ++i) raw[i] = buf_load4(rs_a, a_voff[i], (k_lo + s * TK) * ES);
   };
   auto dma_b = [&](int s, short* buf) {
     const int c0 = b_src + ((k_lo + s * TK) / 16) * kChunk;
@@ -91,12 +99,17 @@ __device__ __forceinline__ void gemm_bf_body(const gw::WArgs& g, const int id, s
     for (int ks = 0; ks < 4; ++ks)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(buf + b_dst + ks * 512), 16, lane * 16, c0 + ks * kChunk, 0, 0);
   };
+  auto write_one = [&](int i, short* nxt) {
+    if constexpr (ABF) {
+      *reinterpret_cast<f32x4*>(&nxt[RP * i * LDA + a_wr]) = raw[i];
+    } else {
+      const u32x2 v = {cvt_pk_bf16(raw[i][0], raw[i][1]), cvt_pk_bf16(raw[i][2], raw[i][3])};
+      *reinterpret_cast<u32x2*>(&nxt[RP * i * LDA + a_wr]) = v;
+    }
+  };
   auto write_a = [&](short* buf) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const u32x2 v = {cvt_pk_bf16(raw[i][0], raw[i][1]), cvt_pk_bf16(raw[i][2], raw[i][3])};
-      *reinterpret_cast<u32x2*>(&buf[32 * i * LDA + a_wr]) = v;
-    }
+    for (int i = 0; i < NA; ++i) write_one(i, buf);
   };
   // One step: the 32 MFMAs of step s with everything else in their shadow, placed by hand (left alone the compiler puts
   // the staging behind the MFMAs, where both waves of a SIMD do it at the same time and the matrix pipe idles):
@@ -114,15 +127,13 @@ __device__ __forceinline__ void gemm_bf_body(const gw::WArgs& g, const int id, s
   // (hipcc cannot count its own loads past an LDS-DMA in flight and waits vmcnt(0) at the next use of one: so the staged
   //  rows are consumed in the FIRST half of a step, while no DMA is in flight, and the DMA of step s + 1 and the reloads
   //  for step s + 2 are issued in the second half, in this order -- the barrier's vmcnt(8) counts on it)
-  auto write_one = [&](int i, short* nxt) {
-    const u32x2 v = {cvt_pk_bf16(raw[i][0], raw[i][1]), cvt_pk_bf16(raw[i][2], raw[i][3])};
-    *reinterpret_cast<u32x2*>(&nxt[32 * i * LDA + a_wr]) = v;
-  };
-  auto reload_one = [&](int i, int s) { raw[i] = buf_load4(rs_a, a_voff[i], (k_lo + (s + 2) * TK) * 4); };
+  auto reload_one = [&](int i, int s) { raw[i] = buf_load4(rs_a, a_voff[i], (k_lo + (s + 2) * TK) * ES); };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
-  auto group = [&](auto SETc, const short* cur, short* nxt, int s, int ks, bool write, bool reload) {
-    constexpr int SET = decltype(SETc)::value;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  auto group = [&](auto SETc, const short* cur, short* nxt, int s, auto KSc, bool write, bool reload) {
+    constexpr int SET = decltype(SETc)::value, ks = decltype(KSc)::value;
     using OTHER = std::integral_constant<int, SET ^ 1>;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -130,17 +141,20 @@ __device__ __forceinline__ void gemm_bf_body(const gw::WArgs& g, const int id, s
       if (!(GEMMBF_KO & 4)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[SET][i], bf[SET][j], acc[i][j], 0, 0, 0);
       else if (m == 0) acc[i][j][0] += __builtin_bit_cast(float, (int)af[SET][i][0] ^ (int)bf[SET][j][0]);
       if (m == 0 && ks < 3 && !(GEMMBF_KO & 16)) read_frags(OTHER{}, cur, ks + 1);
-      if (ks < 2 && (m & 1) && write && !(GEMMBF_KO & 8)) write_one(4 * ks + (m >> 1), nxt);           // groups 0, 1: the eight staged float4
+      if (ks < 2 && (m & 1) && 4 * ks + (m >> 1) < NA && write && !(GEMMBF_KO & 8)) write_one(4 * ks + (m >> 1), nxt);   // groups 0, 1: the staged registers
       if (ks == 2 && m == 0 && write && !(GEMMBF_KO & 2)) dma_b(s + 1, nxt);                           // group 2: the weight chunks of step s + 1
-      if (ks >= 2 && (m & 1) && reload && !(GEMMBF_KO & 1)) reload_one(4 * (ks - 2) + (m >> 1), s);    // groups 2, 3: rows of step s + 2
+      if (ks >= 2 && (m & 1) && 4 * (ks - 2) + (m >> 1) < NA && reload && !(GEMMBF_KO & 1)) reload_one(4 * (ks - 2) + (m >> 1), s);   // groups 2, 3: rows of step s + 2
       __builtin_amdgcn_sched_barrier(0);
     }
   };
   // Every wave's LDS-DMA and LDS writes have landed, then all waves meet (the DMA is ordered only by the issuing wave's
   // vmcnt: the wait comes BEFORE the barrier, the reads after it).  vmcnt counts in issue order, so with the next-but-one
-  // step's eight A loads issued BEHIND the DMA, "all but the 8 youngest" retires the DMA and leaves those loads flying.
+  // step's NA A loads issued BEHIND the DMA, "all but the NA youngest" retires the DMA and leaves those loads flying.
   auto step_barrier = [&](bool a_in_flight) {
-    if (a_in_flight && !(GEMMBF_KO & 1)) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    if (a_in_flight && !(GEMMBF_KO & 1)) {
+      if constexpr (ABF) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    }
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -158,10 +172,10 @@ __device__ __forceinline__ void gemm_bf_body(const gw::WArgs& g, const int id, s
     const bool write = s + 1 < KS, reload = s + 2 < KS;   // (nxt was last read in step s - 1: every wave is past that barrier)
     read_frags(I0{}, cur, 0);
     __builtin_amdgcn_sched_barrier(0);
-    group(I0{}, cur, nxt, s, 0, write, reload);
-    group(I1{}, cur, nxt, s, 1, write, reload);
-    group(I0{}, cur, nxt, s, 2, write, reload);
-    group(I1{}, cur, nxt, s, 3, write, reload);
+    group(I0{}, cur, nxt, s, I0{}, write, reload);
+    group(I1{}, cur, nxt, s, I1{}, write, reload);
+    group(I0{}, cur, nxt, s, I2{}, write, reload);
+    group(I1{}, cur, nxt, s, I3{}, write, reload);
     step_barrier(reload);
   }
 
@@ -185,10 +199,11 @@ __device__ __forceinline__ void gemm_bf_body(const gw::WArgs& g, const int id, s
     }
 }
 
+template <bool ABF>
 __global__ __launch_bounds__(512, 2) void gemm_bf_kernel(const BfJobs jobs) {
   extern __shared__ __attribute__((aligned(16))) short bf_smem[];           // 2 x 69,632 B
-  if ((int)blockIdx.x < jobs.first1) gemm_bf_body(jobs.job[0], (int)blockIdx.x, bf_smem);
-  else gemm_bf_body(jobs.job[1], (int)blockIdx.x - jobs.first1, bf_smem);
+  if ((int)blockIdx.x < jobs.first1) gemm_bf_body<ABF>(jobs.job[0], (int)blockIdx.x, bf_smem);
+  else gemm_bf_body<ABF>(jobs.job[1], (int)blockIdx.x - jobs.first1, bf_smem);
 }
 
 // ---- weight gradients in the same mode:  part[z][m][n] = sum_{k in part z} bf16(A[k][m]) * bf16(B[k][n]) ----------------------
@@ -205,7 +220,7 @@ constexpr int T_IMG = 32 * TLD;                   // one operand image: 18,432 B
 constexpr int T_BUF = 2 * T_IMG;                  // A and B
 
 struct BfTnArgs {
-  const float* A; long a_sl; int a_ld; long a_term;
+  const float* A; long a_sl; int a_ld; long a_term;    // (ABF: A holds bf16 elements; a_sl, a_ld, a_term stay in elements)
   const float* B; const float* b_ptrs[8]; long b_sl; int b_ld;
   float* C;
   int M, N, K, levels, spp, P;                    // K rows per level; spp: 32-row steps per part; P parts
@@ -213,14 +228,25 @@ struct BfTnArgs {
 };
 struct BfTnJobs { BfTnArgs job[2]; int first1; };
 
-template <bool SUM3>
+// ABF: the A operand is stored as bf16 (the fused backward's dP arrays in the reduced-precision mode): 16-byte loads of 8
+// elements, no rounding on the way -- the image and everything after it are the same.
+template <bool SUM3, bool ABF>
 __device__ __forceinline__ void gemm_bf_tn_body(const BfTnArgs& g, const int id, short* const lds) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3, li = lane & 31, lh = lane >> 5;
   const int ntn = g.N / 256, ntiles = (g.M / 256) * ntn;
-  const int z = id / ntiles, t = id % ntiles;
-  if (g.mask_blk > 0 && !((g.tile_mask >> ((((t / ntn) * 2) / g.mask_blk) * 3 + ((t % ntn) * 2) / g.mask_blk)) & 1u)) return;
-  const int m0 = (t / ntn) * 256, n0 = (t % ntn) * 256;
+  // XCD-aware order (workgroup i runs on XCD i % 8): the (part, tile) pairs in part-major, row-tile-major order are cut
+  // into eight runs, one per XCD -- an XCD then works on one part's rows (or few) and on whole row tiles: its L2 serves
+  // the A rows (three reads per element under SUM3) to all the column tiles of a row tile, and the B rows of its part to
+  // its row tiles, instead of both coming from HBM once per tile
+  int z = id / ntiles, t = id % ntiles;
+  if ((g.P * ntiles) % 8 == 0) {
+    const int lin = (id & 7) * (g.P * ntiles / 8) + (id >> 3);
+    z = lin / ntiles; t = lin % ntiles;
+  }
+  const int mt = t / ntn, nt = t % ntn;
+  if (g.mask_blk > 0 && !((g.tile_mask >> (((mt * 2) / g.mask_blk) * 3 + (nt * 2) / g.mask_blk)) & 1u)) return;
+  const int m0 = mt * 256, n0 = nt * 256;
   const int spl = g.K / 32, total = spl * g.levels;                  // steps per level, steps in all
   const int g0 = z * g.spp, g1 = min(total, g0 + g.spp), steps = g1 - g0;
   if (steps <= 0) return;
@@ -238,37 +264,75 @@ __device__ __forceinline__ void gemm_bf_tn_body(const BfTnArgs& g, const int id,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 ra[4], rb[4], rt[SUM3 ? 8 : 1];
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  f32x4 ra[ABF ? 1 : 4], rb[4], rt[SUM3 && !ABF ? 8 : 1];
+  u32x4 ha[ABF ? 2 : 1], ht[SUM3 && ABF ? 4 : 1];                    // ABF: two 16-byte loads of 8 bf16 per thread and step
+  const int hk = tid >> 5, hm = (tid & 31) * 8;                       // ABF staging: a half wave covers one k-row x 512 B
   auto load = [&](int gs) {                                           // global step gs -> (level, row)
     const int lvl = gs / spl, k0 = (gs - lvl * spl) * 32;
-    const float* Ab = g.A + (long)lvl * g.a_sl;
     const float* Bb = g.b_ptrs[0] ? g.b_ptrs[lvl & 7] : g.B + (long)lvl * g.b_sl;
-    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(Ab, (unsigned)((long)g.K * g.a_ld * 4));
     const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(Bb, (unsigned)((long)g.K * g.b_ld * 4));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra[i] = buf_load4(rs_a, ((sk + 8 * i) * g.a_ld + m0 + sm) * 4, k0 * g.a_ld * 4);
-      rb[i] = buf_load4(rs_b, ((sk + 8 * i) * g.b_ld + n0 + sm) * 4, k0 * g.b_ld * 4);
-    }
-    if constexpr (SUM3) {
-      const __amdgpu_buffer_rsrc_t rs_1 = make_rsrc(Ab + g.a_term, (unsigned)((long)g.K * g.a_ld * 4));
-      const __amdgpu_buffer_rsrc_t rs_2 = make_rsrc(Ab + 2 * g.a_term, (unsigned)((long)g.K * g.a_ld * 4));
+    for (int i = 0; i < 4; ++i) rb[i] = buf_load4(rs_b, ((sk + 8 * i) * g.b_ld + n0 + sm) * 4, k0 * g.b_ld * 4);
+    if constexpr (ABF) {
+      const unsigned short* Ab = reinterpret_cast<const unsigned short*>(g.A) + (long)lvl * g.a_sl;
+      const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(Ab, (unsigned)((long)g.K * g.a_ld * 2));
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        rt[i] = buf_load4(rs_1, ((sk + 8 * i) * g.a_ld + m0 + sm) * 4, k0 * g.a_ld * 4);
-        rt[4 + i] = buf_load4(rs_2, ((sk + 8 * i) * g.a_ld + m0 + sm) * 4, k0 * g.a_ld * 4);
+      for (int i = 0; i < 2; ++i)
+        ha[i] = __builtin_bit_cast(u32x4, buf_load4(rs_a, ((hk + 16 * i) * g.a_ld + m0 + hm) * 2, k0 * g.a_ld * 2));
+      if constexpr (SUM3) {
+        const __amdgpu_buffer_rsrc_t rs_1 = make_rsrc(Ab + g.a_term, (unsigned)((long)g.K * g.a_ld * 2));
+        const __amdgpu_buffer_rsrc_t rs_2 = make_rsrc(Ab + 2 * g.a_term, (unsigned)((long)g.K * g.a_ld * 2));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          ht[i] = __builtin_bit_cast(u32x4, buf_load4(rs_1, ((hk + 16 * i) * g.a_ld + m0 + hm) * 2, k0 * g.a_ld * 2));
+          ht[2 + i] = __builtin_bit_cast(u32x4, buf_load4(rs_2, ((hk + 16 * i) * g.a_ld + m0 + hm) * 2, k0 * g.a_ld * 2));
+        }
+      }
+    } else {
+      const float* Ab = g.A + (long)lvl * g.a_sl;
+      const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(Ab, (unsigned)((long)g.K * g.a_ld * 4));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ra[i] = buf_load4(rs_a, ((sk + 8 * i) * g.a_ld + m0 + sm) * 4, k0 * g.a_ld * 4);
+      if constexpr (SUM3) {
+        const __amdgpu_buffer_rsrc_t rs_1 = make_rsrc(Ab + g.a_term, (unsigned)((long)g.K * g.a_ld * 4));
+        const __amdgpu_buffer_rsrc_t rs_2 = make_rsrc(Ab + 2 * g.a_term, (unsigned)((long)g.K * g.a_ld * 4));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          rt[i] = buf_load4(rs_1, ((sk + 8 * i) * g.a_ld + m0 + sm) * 4, k0 * g.a_ld * 4);
+          rt[4 + i] = buf_load4(rs_2, ((sk + 8 * i) * g.a_ld + m0 + sm) * 4, k0 * g.a_ld * 4);
+        }
       }
     }
   };
   auto write = [&](short* buf) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      f32x4 a = ra[i];
-      if constexpr (SUM3) a = (a + rt[i]) + rt[4 + i];                // (level order 0 + 1 + 2, as the separate summing pass)
-      const u32x2 va = {cvt_pk_bf16(a[0], a[1]), cvt_pk_bf16(a[2], a[3])};
       const u32x2 vb = {cvt_pk_bf16(rb[i][0], rb[i][1]), cvt_pk_bf16(rb[i][2], rb[i][3])};
-      *reinterpret_cast<u32x2*>(&buf[8 * i * TLD + st_off]) = va;
       *reinterpret_cast<u32x2*>(&buf[T_IMG + 8 * i * TLD + st_off]) = vb;
+    }
+    if constexpr (ABF) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        u32x4 v = ha[i];
+        if constexpr (SUM3) {                                         // (level order 0 + 1 + 2 in fp32, rounded once)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            auto lo = [](unsigned x) { return __builtin_bit_cast(float, x << 16); };
+            auto hi = [](unsigned x) { return __builtin_bit_cast(float, x & 0xffff0000u); };
+            v[e] = cvt_pk_bf16((lo(ha[i][e]) + lo(ht[i][e])) + lo(ht[2 + i][e]), (hi(ha[i][e]) + hi(ht[i][e])) + hi(ht[2 + i][e]));
+          }
+        }
+        *reinterpret_cast<u32x4*>(&buf[(hk + 16 * i) * TLD + hm]) = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 a = ra[i];
+        if constexpr (SUM3) a = (a + rt[i]) + rt[4 + i];              // (level order 0 + 1 + 2, as the separate summing pass)
+        const u32x2 va = {cvt_pk_bf16(a[0], a[1]), cvt_pk_bf16(a[2], a[3])};
+        *reinterpret_cast<u32x2*>(&buf[8 * i * TLD + st_off]) = va;
+      }
     }
   };
   auto frag = [&](const short* p) {
@@ -315,11 +379,11 @@ __device__ __forceinline__ void gemm_bf_tn_body(const BfTnArgs& g, const int id,
     }
 }
 
-template <bool SUM3>
+template <bool SUM3, bool ABF>
 __global__ __launch_bounds__(512, 2) void gemm_bf_tn_kernel(const BfTnJobs jobs) {
   extern __shared__ __attribute__((aligned(16))) short bf_tn_smem[];        // 2 x 36,864 B
-  if ((int)blockIdx.x < jobs.first1) gemm_bf_tn_body<SUM3>(jobs.job[0], (int)blockIdx.x, bf_tn_smem);
-  else gemm_bf_tn_body<false>(jobs.job[1], (int)blockIdx.x - jobs.first1, bf_tn_smem);
+  if ((int)blockIdx.x < jobs.first1) gemm_bf_tn_body<SUM3, ABF>(jobs.job[0], (int)blockIdx.x, bf_tn_smem);
+  else gemm_bf_tn_body<false, ABF>(jobs.job[1], (int)blockIdx.x - jobs.first1, bf_tn_smem);
 }
 
 }  // namespace
@@ -332,6 +396,7 @@ int gemm_bf_tn_supported(const TnGemm& d) {
             (d.a_sl & 3) == 0 && (d.b_sl & 3) == 0 && pal(d.A) && (d.b_ptrs[0] ? true : pal(d.B)) &&
             (long)d.K * d.a_ld * 4 < 0x40000000L && (long)d.K * d.b_ld * 4 < 0x40000000L && (d.mask_blk == 0 || (d.mask_blk % 2) == 0);
   for (int t = 0; t < 8; ++t) ok = ok && pal(d.b_ptrs[t]);
+  if (d.a_bf16) ok = ok && (d.a_ld & 7) == 0 && (d.a_term & 7) == 0 && (d.a_sl & 7) == 0;   // 16-byte loads of 8 elements
   return ok ? 1 : 0;
 }
 
@@ -367,13 +432,19 @@ int launch_gemm_bf_tn(const TnGemm* d, const int* spp, const int* parts, int n, 
   const size_t lds = (size_t)2 * T_BUF * sizeof(short);
   static DeviceOnce once;
   CA_TRY(once.run([&] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf_tn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf_tn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf_tn_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf_tn_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf_tn_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf_tn_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     return e;
   }, "gemm_bf_tn"));
   const dim3 grid((unsigned)(nb[0] + nb[1]));
-  if (d[0].a_term) hipLaunchKernelGGL(gemm_bf_tn_kernel<true>, grid, dim3(512), lds, s, jobs);
-  else hipLaunchKernelGGL(gemm_bf_tn_kernel<false>, grid, dim3(512), lds, s, jobs);
+  const bool abf = d[0].a_bf16 != 0;
+  CA_CHECK_ARG(n == 1 || (d[1].a_bf16 != 0) == abf, "gemm_bf_tn: the jobs of a launch store A alike");
+  if (d[0].a_term && abf) hipLaunchKernelGGL((gemm_bf_tn_kernel<true, true>), grid, dim3(512), lds, s, jobs);
+  else if (d[0].a_term) hipLaunchKernelGGL((gemm_bf_tn_kernel<true, false>), grid, dim3(512), lds, s, jobs);
+  else if (abf) hipLaunchKernelGGL((gemm_bf_tn_kernel<false, true>), grid, dim3(512), lds, s, jobs);
+  else hipLaunchKernelGGL((gemm_bf_tn_kernel<false, false>), grid, dim3(512), lds, s, jobs);
   CA_CHECK_LAUNCH("gemm_bf_tn");
   return 0;
 }
@@ -393,6 +464,7 @@ int gemm_bf_supported(const WGemm& d) {
             (d.a_sm & 3) == 0 && (d.a_sz & 3) == 0 && d.batch >= 1 && d.batch <= 8 && (d.a_ptrs[0] ? true : pal(d.A)) &&
             ((long)d.M * d.a_sm + d.K) * 4 < 0x40000000L && wsplit_bytes(d.N, d.K) / 3 < 0x40000000UL;
   for (int t = 0; t < 8; ++t) ok = ok && pal(d.a_ptrs[t]);
+  if (d.a_bf16) ok = ok && (d.a_sm & 7) == 0 && (d.a_sz & 7) == 0;      // 16-byte loads of 8 elements
   if (d.kband_n > 0) {
     ok = ok && (d.kband_n % TN) == 0 && (d.N + d.kband_n - 1) / d.kband_n <= 3;
     for (int t = 0; t < 3 && ok; ++t)
@@ -425,9 +497,14 @@ int launch_gemm_bf(const WGemm* d, int n, hipStream_t s) {
   jobs.first1 = (int)nb[0];
   const size_t lds = (size_t)2 * BUF * sizeof(short);
   static DeviceOnce once;
-  CA_TRY(once.run([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); },
-                  "gemm_bf"));
-  hipLaunchKernelGGL(gemm_bf_kernel, dim3((unsigned)(nb[0] + nb[1])), dim3(512), lds, s, jobs);
+  CA_TRY(once.run([&] {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return e;
+  }, "gemm_bf"));
+  CA_CHECK_ARG(n == 1 || (d[0].a_bf16 != 0) == (d[1].a_bf16 != 0), "gemm_bf: the jobs of a launch store A alike");
+  if (d[0].a_bf16) hipLaunchKernelGGL(gemm_bf_kernel<true>, dim3((unsigned)(nb[0] + nb[1])), dim3(512), lds, s, jobs);
+  else hipLaunchKernelGGL(gemm_bf_kernel<false>, dim3((unsigned)(nb[0] + nb[1])), dim3(512), lds, s, jobs);
   CA_CHECK_LAUNCH("gemm_bf");
   return 0;
 }

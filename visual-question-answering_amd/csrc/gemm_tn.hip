@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnJobs jobs) {
 
 int gemm_tn_supported(const TnGemm& d) {
   auto pal = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
-  bool ok = d.M > 0 && d.N > 0 && (d.M % BM) == 0 && (d.N % BN) == 0 && d.K >= BK && d.levels >= 1 && d.levels <= 8 &&
+  bool ok = !d.a_bf16 && d.M > 0 && d.N > 0 && (d.M % BM) == 0 && (d.N % BN) == 0 && d.K >= BK && d.levels >= 1 && d.levels <= 8 &&
             (d.a_ld & 3) == 0 && (d.b_ld & 3) == 0 && (d.a_term & 3) == 0 && (d.a_sl & 3) == 0 && (d.b_sl & 3) == 0 && pal(d.A) &&
             (d.b_ptrs[0] ? true : pal(d.B)) && (long)(d.K + 2 * BK) * d.a_ld * 4 < 0x40000000L;
   if (d.b_kdiv) {    // B contiguous along k inside groups of b_kdiv rows

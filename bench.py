@@ -205,7 +205,7 @@ def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20, b
         if it >= 3:
             fwd += t1 - t0; bwd += t3 - t1
     flop = 3.0 * B * (2 * N * d * d + 3 * 2 * T * d * d + 3 * (3 * 2 * T * N * d + 4 * (N + T) * d))
-    return {"N": N, "d": d, "K": K, "layout": layout, "mode": "bf16 projections (one MFMA per product)" if bf16 else "fp32",
+    return {"N": N, "d": d, "K": K, "layout": layout, "mode": "reduced precision (every product ONE bf16 MFMA, fp32 accumulation; dP_v / dP_q stored as bf16)" if bf16 else "fp32",
             "pairs_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "host_enqueue_ms": round(host * 1e3, 3),
             "graph_ms_per_step": round(gdt * 1e3, 3), "graph_host_enqueue_ms": round(ghost * 1e3, 3),
             "graph_pairs_per_s": round(B / gdt, 1),
@@ -333,7 +333,10 @@ def projection_leg(device, B=160, N=196, d=512, iters=50, bf16=False):
             "peak_note": ("dense bf16 MFMA peak (operands rounded to bf16, one MFMA per product, fp32 accumulation)" if bf16 else
                           "fp32-equivalent: dense bf16 MFMA peak 2500 TFLOP/s / 6 partial products per fp32 product"),
             "frac_of_fp32_matrix_peak": round(ach / 157.3, 4),
-            "traffic": None, "kernel": "P_v projection GEMM (gemm_w_kernel: pre-split weight, %s)" % ("bf16 hi pieces only" if bf16 else "3-way bf16 split"),
+            "traffic": None,
+            "kernel": ("P_v projection GEMM (gemm_bf_kernel at N % 256 == 0, K % 64 == 0, else gemm_w_kernel's single-piece mode: "
+                       "weight pre-rounded into a hi-only fragment image, one MFMA per product)" if bf16 else
+                       "P_v projection GEMM (gemm_w_kernel: pre-split weight, 3-way bf16 split)"),
             "shape": {"M": B * N, "N": d, "K": d}, "avg_launch_us": round(t * 1e6, 2),
             "windows_us": [round(x * 1e6, 2) for x in ts], "calls_per_window": iters, "algorithmic_flops": flop,
             "bf16_mfma_frac": round((1.0 if bf16 else 6.0) * ach / 2500.0, 4),
@@ -381,7 +384,10 @@ def weight_grad_leg(device, B=160, N=196, d=512, iters=50, bf16=False):
     return {"bound": "mfma", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "peak_note": ("dense bf16 MFMA peak (operands rounded to bf16, one MFMA per product)" if bf16 else
                           "fp32-equivalent: dense bf16 MFMA peak 2500 TFLOP/s / 6 partial products per fp32 product"),
-            "traffic": None, "kernel": "dW_v weight-gradient GEMM (gemm_tn_kernel, 32 split-K parts) + reduce_partials4_kernel",
+            "traffic": None,
+            "kernel": ("dW_v weight-gradient GEMM (gemm_bf_tn_kernel at 256-multiples, else gemm_tn_kernel's single-piece mode; one round "
+                       "of split-K parts) + reduce_partials4_kernel" if bf16 else
+                       "dW_v weight-gradient GEMM (gemm_tn_kernel, 32 split-K parts) + reduce_partials4_kernel"),
             "shape": {"M": d, "N": d, "K": B * N}, "avg_launch_us": round(t * 1e6, 2),
             "windows_us": [round(x * 1e6, 2) for x in ts], "calls_per_window": iters, "algorithmic_flops": flop}
 

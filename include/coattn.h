@@ -50,12 +50,14 @@ extern "C" {
 #define COATTN_IMPL_AUTO 0
 #define COATTN_IMPL_GENERAL 1
 #define COATTN_IMPL_FUSED 2
-/* flags bit 2: run the projections P_v, P_q (model.py:380-384) and, in the backward, the d x d
- * contractions that are their gradients (dQ += dP_q W_q, dV += dP_v W_v, dW_v, dW_q) on the bf16 MFMA
- * (v_mfma_f32_32x32x16_bf16): operands rounded to bf16 while staged, fp32 accumulation, fp32
- * results -- the reduced-precision mode that the reference reaches through apex AMP O1 (main.py:185).
- * Everything else stays exact fp32.  Parity then holds to bf16 tolerance (~1e-2), not 1e-4.  The projections run on
- * the same hand-scheduled kernels as in fp32 mode (gemm_w.hip, gemm_tn.hip) with the hi pieces of the operands alone.
+/* flags bit 2: the reduced-precision mode that the reference reaches through apex AMP O1 (main.py:185).  The projections
+ * P_v, P_q (model.py:380-384) and, in the backward, the d x d contractions that are their gradients (dQ += dP_q W_q,
+ * dV += dP_v W_v, dW_v, dW_q) run on the bf16 MFMA (v_mfma_f32_32x32x16_bf16) with operands rounded to bf16 while staged,
+ * ONE MFMA per product, fp32 accumulation and fp32 results (gemm_bf.hip at wide shapes, else the single-piece modes of
+ * gemm_w.hip / gemm_tn.hip).  On the fused path with d % 512 == 0 the affinity / attention contractions of the fused
+ * kernels do the same (single-product instantiations; other widths and the general-shape path keep those exact), and the
+ * backward's workspace holds dP_v / dP_q as bf16 when only GEMMs consume them.  Inputs, `saved` and outputs are fp32 in
+ * either mode.  Parity then holds to bf16 tolerance (~1e-2), not 1e-4.
  * The same bit selects the bf16 MFMA for the three contractions of coattn_phrase_forward/backward. */
 #define COATTN_FLAG_BF16_PROJ 4
 #define COATTN_FLAG_BF16_IN 8     /* coattn_linear_forward / coattn_linear_weight_grad, with COATTN_FLAG_BF16_PROJ: x (dy) is STORED as bf16 */

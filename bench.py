@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline / hot_path legs")
     ap.add_argument("--only", type=str, default="", help="developer switch: run only 'roofline' or 'hot' legs")
     ap.add_argument("--cpu-batch", type=int, default=0, help="batch of the CPU baseline leg (0: the GPU step's own batch)")
+    ap.add_argument("--exchange-p2p", action="store_true",
+                    help="N > 1: also time the step under exchange='p2p' (peer-mapped buckets + csrc/p2p.hip)")
     ap.add_argument("--no-runahead", dest="runahead", action="store_false",
                     help="run the frozen image encoder in series with the rest of the step (default: one step "
                          "ahead on its own HIP stream)")
@@ -623,7 +625,10 @@ def main():
         ex_steps = max(4, args.steps // 2)
         ex = {"allreduce": dt / args.steps * 1e3}
         errors = {}
-        for mode in ("direct", "none"):
+        # (the peer-mapped one-shot exchange, exchange="p2p", is timed only on request: it has run with ranks sharing ONE
+        #  GPU only, and a first run between GPUs belongs in a session of its own, not in the scaling measurement)
+        p2p = args.exchange_p2p or os.environ.get("VQA_BENCH_P2P", "0") == "1"
+        for mode in ("direct",) + (("p2p",) if p2p else ()) + ("none",):
             try:
                 trainer.reducer.reset(mode)
                 t_m = timed_steps(trainer, batch, ex_steps, 2, sync)
@@ -639,7 +644,8 @@ def main():
                                "errors": errors or None,
                                "allreduce_ms_exposed": diff(ex["allreduce"], ex["none"]),
                                "direct_ms_exposed": diff(ex["direct"], ex["none"]),
-                               "steps_per_leg": {"allreduce": args.steps, "direct": ex_steps, "none": ex_steps},
+                               "p2p_ms_exposed": diff(ex["p2p"], ex["none"]) if p2p else "not run (opt-in: --exchange-p2p)",
+                               "steps_per_leg": dict({"allreduce": args.steps, "direct": ex_steps, "none": ex_steps}, **({"p2p": ex_steps} if p2p else {})),
                                "world_size": torch.distributed.get_world_size(),
                                "backend": torch.distributed.get_backend(),
                                "note": "headline value = the allreduce run; 'none' keeps gradients local (timing only)"}

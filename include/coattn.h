@@ -265,6 +265,23 @@ int coattn_linear_weight_grad(const void* dy, int64_t ld_dy, const void* x, int6
  * in exact fp32 instead. */
 int coattn_gemm_bf16(const coattn_gemm_desc* g, void* stream);
 
+/* ---- one-shot gradient exchange over peer-mapped buckets (data-parallel training) -----------
+ * The reference trains on one GPU (multi-GPU is a TODO: main.py:71, :102-106).  The co-attention model shards by QA
+ * pair, so the only exchange is the gradient mean; on a fully connected xGMI node the pattern that fits is one shot:
+ * every rank maps its peers' gradient buckets (HIP IPC, once) and two bandwidth kernels read peer memory directly.
+ * peer_bufs[r] = rank r's bucket (world * shard_elems floats) as mapped in THIS process, peer_bufs[rank] its own.
+ *   coattn_p2p_reduce_scatter  own bucket, shard `rank`  <-  scale * sum_r peer_bufs[r][shard `rank`], summed in rank
+ *                              order (identical and repeatable on every rank);
+ *   coattn_p2p_all_gather      own bucket, shard r  <-  peer_bufs[r][shard r] for every r != rank.
+ * Both only ENQUEUE on `stream`; the caller orders the phases across ranks (every bucket packed before the first call,
+ * every reduce done before the gather, every gather done before a bucket is packed again -- dist.py: a one-element
+ * all-reduce on the stream under RCCL).  shard_elems % 4 == 0, 16-byte aligned buckets, world <= 8; else error -1. */
+int coattn_p2p_enable_peer(int peer_device);   /* peer access from the current device to the device a mapped bucket lives on
+                                                * (once per pair, before the first call below); -1 if they cannot reach each other */
+int coattn_p2p_reduce_scatter(const void* const* peer_bufs, int world, int rank, int64_t shard_elems, float scale,
+                              void* stream);
+int coattn_p2p_all_gather(const void* const* peer_bufs, int world, int rank, int64_t shard_elems, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,6 +1,7 @@
 """Child process of tests/test_gpu_dist.py: one rank of an RCCL ("nccl") process group on cuda:LOCAL_RANK.
 
-    python tests/_dist_child.py --mode {net,sub} --world W --rank R --port P --exchange {none,allreduce,direct} --out F
+    python tests/_dist_child.py --mode {net,sub} --world W --rank R --port P --exchange {none,allreduce,direct,p2p} --out F
+                                [--backend gloo --same-gpu]
 
 mode net: two `Trainer.step`s of the full attention model (frozen VGG + question encoder + HIP co-attention + MLP)
           with a `GradReducer` attached (exchange none: no process group, no reducer -- the reference run);
@@ -50,6 +51,8 @@ def main():
     ap.add_argument("--port", type=int, default=29541)
     ap.add_argument("--exchange", default="allreduce")
     ap.add_argument("--out", required=True)
+    ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--same-gpu", action="store_true", help="every rank on cuda:0 (gloo; the p2p exchange over IPC on one GPU)")
     a = ap.parse_args()
     os.environ.update(RANK=str(a.rank), WORLD_SIZE=str(a.world), LOCAL_RANK=str(a.rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(a.port), HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -57,10 +60,12 @@ def main():
     import torch
     import torch.distributed as dist
     from vqa_amd import dist as vdist, train as T
-    dev = torch.device("cuda", a.rank)
+    dev = torch.device("cuda", 0 if a.same_gpu else a.rank)
     torch.cuda.set_device(dev)
-    if a.exchange != "none":
+    if a.exchange != "none" and a.backend == "nccl":
         dist.init_process_group("nccl", rank=a.rank, world_size=a.world, device_id=dev)
+    elif a.exchange != "none":
+        dist.init_process_group(a.backend, rank=a.rank, world_size=a.world)
     out = {}
     if a.mode == "net":
         torch.manual_seed(0)
@@ -108,6 +113,7 @@ def main():
             out["p." + n] = p.detach().cpu().numpy()
         if red is not None:
             out["n_buckets"] = np.asarray([len(red.buckets)])
+            red.reset("none")                                          # (p2p: unmaps the peers' buckets, in step)
     np.savez(a.out, **out)
     if a.exchange != "none":
         dist.destroy_process_group()

@@ -25,11 +25,11 @@ def _free_port():
     return p
 
 
-def _run_ranks(tmp_path, mode, world, exchange, tag):
+def _run_ranks(tmp_path, mode, world, exchange, tag, extra=()):
     port = _free_port()
     outs = [str(tmp_path / ("%s_%s_%d.npz" % (tag, exchange, r))) for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_child.py"), "--mode", mode, "--world", str(world),
-                               "--rank", str(r), "--port", str(port), "--exchange", exchange, "--out", outs[r]],
+                               "--rank", str(r), "--port", str(port), "--exchange", exchange, "--out", outs[r], *extra],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     logs = [p.communicate(timeout=600)[0] for p in procs]
     for r, p in enumerate(procs):
@@ -52,20 +52,66 @@ def test_nccl_world1_trainer_steps(tmp_path):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("exchange", ["allreduce", "direct"])
+@pytest.mark.parametrize("exchange", ["allreduce", "direct", "p2p"])
 def test_nccl_world2_equals_full_batch(tmp_path, exchange):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs 2 GPUs")
     full = _run_ranks(tmp_path, "sub", 1, "none", "full")[0]
-    r0, r1 = _run_ranks(tmp_path, "sub", 2, exchange, "w2")
+    _check_against_full_batch(full, _run_ranks(tmp_path, "sub", 2, exchange, "w2"))
+
+
+def _check_against_full_batch(full, ranks):
+    r0 = ranks[0]
     assert int(r0["n_buckets"][0]) > 1
     for k in full:
         if k.startswith("g."):
             scale = max(1e-6, float(np.abs(full[k]).max()))
-            assert np.array_equal(r0[k], r1[k]), k                                       # identical on every rank
+            for r in ranks[1:]:
+                assert np.array_equal(r0[k], r[k]), k                                    # identical on every rank
             assert np.abs(r0[k] - full[k]).max() <= 2e-5 * scale + 1e-7, k               # == full-batch gradient
         elif k.startswith("p."):
-            assert np.array_equal(r0[k], r1[k]), k                                       # lockstep
+            for r in ranks[1:]:
+                assert np.array_equal(r0[k], r[k]), k                                    # lockstep
             if k.endswith("w_v.bias") or k.endswith("w_q.bias"):
                 continue                 # analytically zero gradient: Adam turns rounding noise into +-lr steps
-            assert np.allclose(r0[k], full[k], atol=2e-5), k
+            # three Adam steps of lr 1e-3: an element whose gradient is rounding noise may move by lr per step in either
+            # run; everywhere else the parameters agree closely
+            diff = np.abs(r0[k] - full[k])
+            assert diff.max() <= 3.1e-3 and diff.mean() <= 2e-5, (k, float(diff.max()), float(diff.mean()))
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 4])
+def test_p2p_exchange_ranks_sharing_one_gpu(tmp_path, world):
+    """The one-shot exchange over peer-mapped buckets (exchange="p2p": HIP IPC + csrc/p2p.hip, no collective on the data
+    path) with `world` processes on this ONE GPU (gloo for the handles and the phase barriers): the averaged gradients
+    equal the single-process full-batch gradients, identical on every rank, three Adam steps in lockstep."""
+    full = _run_ranks(tmp_path, "sub", 1, "none", "full")[0]
+    ranks = _run_ranks(tmp_path, "sub", world, "p2p", "p2p%d" % world, extra=("--backend", "gloo", "--same-gpu"))
+    _check_against_full_batch(full, ranks)
+
+
+@pytest.mark.parametrize("world,shard", [(1, 1024), (2, 4), (3, 1000), (8, 260096)])
+def test_p2p_kernels_in_one_process(world, shard):
+    """csrc/p2p.hip by itself: `world` buckets in one process stand for the ranks (the phases of the ranks run one after the
+    other, which is what the cross-rank barriers guarantee): every bucket ends as the rank-ordered mean, bit for bit."""
+    import ctypes as C
+    from vqa_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(world)
+    bufs = [torch.randn(world * shard, device="cuda") for _ in range(world)]
+    want = bufs[0].clone()
+    for r in range(1, world):
+        want += bufs[r]
+    want *= 1.0 / world
+    ptrs = (C.c_void_p * world)(*[b.data_ptr() for b in bufs])
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for r in range(world):
+        _lib.check(lib.coattn_p2p_reduce_scatter(ptrs, world, r, shard, 1.0 / world, stream), "coattn_p2p_reduce_scatter")
+    for r in range(world):
+        _lib.check(lib.coattn_p2p_all_gather(ptrs, world, r, shard, stream), "coattn_p2p_all_gather")
+    torch.cuda.synchronize()
+    for r in range(world):
+        assert torch.equal(bufs[r], want), r
+    assert lib.coattn_p2p_reduce_scatter(ptrs, world, 0, shard + 1, 1.0, stream) != 0        # shard not a multiple of 4
+    assert lib.coattn_p2p_reduce_scatter(ptrs, 9, 0, shard, 1.0, stream) != 0

@@ -16,7 +16,7 @@ void coattn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int coattn_version(void) { return 400; }   // 0.4.0: coattn_head_forward/backward; the reduced-precision mode on the hand-scheduled GEMMs
+extern "C" int coattn_version(void) { return 401; }   // 0.4.1: coattn_p2p_*, COATTN_FLAG_BF16_IN; the reduced-precision mode through the fused kernels
 extern "C" const char* coattn_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------------------------------

@@ -21,6 +21,14 @@ model shards naturally by QA pair, so the only exchange step is the gradient mea
   2 (w-1)/w S circling one ring), the owner sums the w pieces in rank order, and an all-gather returns the reduced
   shards.  Same values on every rank; opt-in until it has been timed against RCCL's own all-reduce on a
   multi-GPU node (a one-GPU box cannot).
+* ``exchange="p2p"``: the same one-shot pattern WITHOUT collectives on the data path -- every rank maps its peers' buckets
+  once (HIP IPC handles through ``torch.multiprocessing``'s reductions, exchanged with ``all_gather_object``) and the
+  library's two bandwidth kernels read peer memory directly (``csrc/p2p.hip``: ``coattn_p2p_reduce_scatter`` sums shard j
+  of all ranks in rank order on rank j, ``coattn_p2p_all_gather`` copies the reduced shards back).  The three phase
+  boundaries per step (buckets packed / shards reduced / shards gathered) are one-element all-reduces on the stream under
+  RCCL (stream-ordered, the host does not block) and barriers under gloo.  Tested with several ranks sharing ONE GPU
+  (``tests/test_gpu_dist.py``); between GPUs it relies on peer access, which ``_p2p_setup`` switches on and checks with a
+  copy through torch before any kernel dereferences a peer pointer.
 """
 from __future__ import annotations
 
@@ -63,6 +71,9 @@ def shutdown():
         dist.destroy_process_group()
 
 
+EXCHANGES = ("allreduce", "direct", "p2p", "none")
+
+
 class _Bucket:
     def __init__(self, params: List[torch.nn.Parameter], pad_to: int = 1):
         self.params = params
@@ -71,6 +82,8 @@ class _Bucket:
         n = (n + pad_to - 1) // pad_to * pad_to          # direct exchange: equal shards per rank
         self.flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
         self.recv = None                                  # direct exchange: the w pieces of this rank's shard
+        self.peers = None                                 # p2p exchange: every rank's bucket as mapped here (own: flat)
+        self.peer_ptrs = None
         self.views, o = [], 0
         for p in params:
             self.views.append(self.flat[o:o + p.numel()].view_as(p))
@@ -89,8 +102,8 @@ class GradReducer:
         self.module = module
         self.group = group
         self.exchange = exchange or os.environ.get("VQA_GRAD_EXCHANGE", "allreduce")
-        if self.exchange not in ("allreduce", "direct", "none"):
-            raise ValueError("exchange must be 'allreduce', 'direct' or 'none', got %r" % self.exchange)
+        if self.exchange not in EXCHANGES:
+            raise ValueError("exchange must be one of %s, got %r" % (", ".join(EXCHANGES), self.exchange))
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.world = dist.get_world_size(group)
         self.buckets: List[_Bucket] | None = None      # built after the first backward
@@ -102,8 +115,9 @@ class GradReducer:
         """Switch the exchange pattern (bench.py times the step under each): hooks and buckets are dropped and rebuilt
         on the next step.  "none" packs and unpacks the buckets but starts no collective -- the gradients stay LOCAL:
         the compute-only leg of a timing comparison, never a training mode."""
-        if exchange not in ("allreduce", "direct", "none"):
-            raise ValueError("exchange must be 'allreduce', 'direct' or 'none', got %r" % exchange)
+        if exchange not in EXCHANGES:
+            raise ValueError("exchange must be one of %s, got %r" % (", ".join(EXCHANGES), exchange))
+        self._p2p_release()
         for h in self._hooks:
             h.remove()
         self._hooks, self._where, self.buckets = [], {}, None
@@ -122,7 +136,7 @@ class GradReducer:
         if not (torch.equal(lo, sig) and torch.equal(hi, sig)):
             raise RuntimeError("ranks disagree on which parameters receive gradients")
         self.buckets, cur, size = [], [], 0
-        pad = self.world if self.exchange == "direct" else 1
+        pad = {"direct": self.world, "p2p": 4 * self.world}.get(self.exchange, 1)   # equal (p2p: 16-byte) shards
         for p in live:
             nbytes = p.numel() * p.element_size()
             if cur and (size + nbytes > self.bucket_bytes or p.dtype != cur[0].dtype):
@@ -136,12 +150,74 @@ class GradReducer:
             for pi, p in enumerate(b.params):
                 self._where[p] = (bi, pi)
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        if self.exchange == "p2p":
+            self._p2p_setup()
+
+    # -- p2p exchange: peer-mapped buckets ------------------------------------------------------
+    def _p2p_setup(self):
+        """Map every peer's buckets into this process (once per bucket layout)."""
+        import ctypes as C
+        from torch.multiprocessing.reductions import reduce_tensor
+        from . import _lib
+        self._lib = _lib.load()
+        self.rank = dist.get_rank(self.group)
+        for b in self.buckets:
+            if b.flat.dtype != torch.float32 or not b.flat.is_cuda:
+                raise RuntimeError("exchange='p2p' takes fp32 gradients on a GPU")
+        torch.cuda.synchronize()
+        mine = [reduce_tensor(b.flat) for b in self.buckets]           # (rebuild function, IPC handle + offset) per bucket
+        every = [None] * self.world
+        dist.all_gather_object(every, mine, group=self.group)
+        for bi, b in enumerate(self.buckets):
+            b.peers = [b.flat if r == self.rank else every[r][bi][0](*every[r][bi][1]) for r in range(self.world)]
+            for r, t in enumerate(b.peers):
+                if t.numel() != b.flat.numel():
+                    raise RuntimeError("rank %d maps a bucket of another size" % r)
+                if r != self.rank:
+                    # peer access from this rank's device to the bucket's (an error here, not a faulting kernel later),
+                    # then one small copy through torch as a check of the mapping
+                    with torch.cuda.device(b.flat.device):
+                        _lib.check(self._lib.coattn_p2p_enable_peer(t.device.index), "coattn_p2p_enable_peer")
+                    b.flat.new_empty(4).copy_(t[:4])
+            b.peer_ptrs = (C.c_void_p * self.world)(*[t.data_ptr() for t in b.peers])
+        self._tok = torch.zeros(1, device=self.buckets[0].flat.device)
+        self._p2p_sync()
+
+    def _p2p_sync(self):
+        """Every rank's work enqueued so far is done before any rank's later work starts."""
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_reduce(self._tok, group=self.group)              # on the stream: the host does not block
+        else:
+            torch.cuda.synchronize()
+            dist.barrier(group=self.group)
+
+    def _p2p_release(self):
+        if self.buckets is None or not any(b.peers is not None for b in self.buckets):
+            return
+        self._p2p_sync()
+        for b in self.buckets:
+            b.peers, b.peer_ptrs = None, None                          # unmap before the owners free
+        torch.cuda.synchronize()
+        dist.barrier(group=self.group)
+
+    def _p2p_finish(self):
+        from . import _lib
+        stream = torch.cuda.current_stream().cuda_stream
+        self._p2p_sync()                                               # every rank's buckets are packed
+        for b in self.buckets:
+            _lib.check(self._lib.coattn_p2p_reduce_scatter(b.peer_ptrs, self.world, self.rank, b.flat.numel() // self.world,
+                                                           1.0 / self.world, stream), "coattn_p2p_reduce_scatter")
+        self._p2p_sync()                                               # every shard is reduced
+        for b in self.buckets:
+            _lib.check(self._lib.coattn_p2p_all_gather(b.peer_ptrs, self.world, self.rank, b.flat.numel() // self.world,
+                                                       stream), "coattn_p2p_all_gather")
+        self._p2p_sync()                                               # nobody still reads a bucket that is packed next
 
     def _launch(self, b):
         """Pack a bucket whose gradients are all there (one multi-tensor copy) and start its all-reduce."""
         torch._foreach_copy_(b.views, [p.grad if p.grad is not None else torch.zeros_like(p) for p in b.params])
-        if self.exchange == "none":
-            b.work = False                              # timing leg: packed, nothing sent
+        if self.exchange in ("none", "p2p"):
+            b.work = False                              # packed; p2p: the exchange runs in finish(), "none": nothing sent
         elif self.exchange == "direct":
             # stage 1: shard j of this rank's bucket goes straight to rank j (stage 2 in finish())
             if b.recv is None:
@@ -172,6 +248,8 @@ class GradReducer:
         for b in self.buckets:
             if b.work is None:                          # a parameter of this bucket got no gradient this step
                 self._launch(b)
+        if self.exchange == "p2p":
+            self._p2p_finish()
         if self.exchange == "direct":
             # stage 2: sum the w pieces of the own shard in rank order, scale, gather the reduced shards
             gathers = []

@@ -126,6 +126,7 @@ def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20, b
     co = vqa_amd.ParallelCoAttention(d).to(device)
     co.bf16_projections = bf16                       # the reduced-precision mode of --opt_lvl >= 1 (config 4)
     mlp = MLPClassifier(d, 1024, K + 1).to(device)
+    mlp.bf16_products = bf16
     V, Qs = synth_features(B, N, T, d, device)
     x_img = V.permute(0, 2, 1)
     if layout == "lm":

@@ -184,6 +184,10 @@ int coattn_ce_status(const void* ws, int B, void* stream);
 /* flags bit 0 of coattn_head_forward / coattn_head_backward: the layers of a direction as phases of ONE launch separated by
  * grid-wide barriers instead of one launch per layer (same tiles, same values; measured slower or equal: opt-in). */
 #define COATTN_HEAD_PERSISTENT 1
+/* flags bit 2 (COATTN_FLAG_BF16_PROJ) of both: the reduced-precision mode -- the operands of the four products and of their
+ * gradients rounded to bf16 while they are fed to the matrix pipe (ONE v_mfma_f32_32x32x16_bf16 where the exact head issues
+ * eight v_mfma_f32_32x32x2_f32), fp32 accumulation, biases, tanh, cross entropy and bias gradients; bf16 tolerance.  Pass the
+ * same flag to the forward and the backward of a step.  (The one-launch form is exact only: bit 0 wins.) */
 typedef struct coattn_head_params {
   const void* W_w; const void* b_w;   /* model.py:409 */
   const void* W_p; const void* b_p;   /* model.py:410 */

@@ -120,6 +120,32 @@ def test_one_launch_form_gives_the_same_bits(shape):
                 assert torch.equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("shape", [(160, 2048, 1024, 3001), (160, 512, 1024, 1001), (3, 20, 12, 5), (70, 96, 160, 33)],
+                         ids=lambda s: "B%d_d%d_mlp%d_K%d" % s)
+def test_head_reduced_precision_mode(shape):
+    """flags bit 2 (COATTN_FLAG_BF16_PROJ): the operands of the four products and of their gradients rounded to bf16, one
+    bf16 MFMA where the exact head issues eight f32 ones -- within bf16 tolerance of the float64 oracle (stated: 2e-2 of
+    max|.| on every output, 1e-2 relative L2), not identical to the exact mode, repeatable bit for bit; config 4's shape,
+    cfg 2's, and shapes on the per-element staging path with ragged tiles."""
+    from vqa_amd import _lib
+    B, d, mlp, K = shape
+    ref, v, q, labels = _case(B, d, mlp, K, seed=4)
+    z, loss, gv, gq, gp = _oracle(ref, v, q, labels, g_loss=1.7)
+    P = ref.state_dict()
+    r = _call(v, q, P, labels, g_loss=1.7, flags=_lib.FLAG_BF16_PROJ)
+    x = _call(v, q, P, labels, g_loss=1.7)
+    l2 = lambda a, b: ((a.double().cpu() - b).norm() / b.norm()).item()   # noqa: E731
+    assert _rel(r["logits"], z) < 2e-2 and l2(r["logits"], z) < 1e-2 and abs(r["loss"].item() - loss.item()) < 2e-2 * abs(loss.item())
+    assert _rel(r["dv"], gv) < 2e-2 and l2(r["dv"], gv) < 1e-2
+    for k in NAMES:
+        assert _rel(r["d" + k], gp[k]) < 2e-2 and l2(r["d" + k], gp[k]) < 1e-2, (k, _rel(r["d" + k], gp[k]), l2(r["d" + k], gp[k]))
+    assert not torch.equal(r["logits"], x["logits"]) and _rel(x["logits"], z) < TOL
+    r2 = _call(v, q, P, labels, g_loss=1.7, flags=_lib.FLAG_BF16_PROJ)
+    for k in r:
+        if r[k] is not None:
+            assert torch.equal(r[k], r2[k]), k
+
+
 def test_head_logits_gradient_accumulate_and_no_input_grads():
     """The other upstream gradient (g_logits, alone and together with g_loss), accumulate = 1, dv = NULL."""
     B, d, mlp, K = 37, 64, 128, 19

@@ -19,11 +19,17 @@
 // Arithmetic: exact fp32 on v_mfma_f32_32x32x2_f32 (one rounding per product, as an fmaf chain).  The products are too
 // small for the bf16 3-way split of the big GEMMs to pay: every operand element is used by one 32 x 32 tile only, so the
 // 11 VALU operations per split pair would cost more than the 64-cycle f32 MFMAs they replace.
+// Reduced-precision mode (flags bit 2, COATTN_FLAG_BF16_PROJ -- the apex-O1 analogue, BASELINE config 4: d = 2048, K = 3000,
+// where the exact head is bound by the f32 matrix pipe: 25 GFLOP forward + backward at 76 TFLOP/s): the same tiles, loads
+// and staging, with eight operand values per lane rounded to bf16 (v_cvt_pk_bf16_f32) in front of ONE
+// v_mfma_f32_32x32x16_bf16 where the exact path issues eight v_mfma_f32_32x32x2_f32; fp32 accumulation, bias, tanh,
+// cross entropy and bias gradients as before.
 // Operands that are contiguous along the contraction index (activations and nn.Linear weights in the forward, dY in dX)
 // are fetched as whole 128-byte lines (8 rows per wave instruction), staged in a per-wave LDS image with padded rows and
 // read back as fragments (ds_read_b128, conflict-free); operands contiguous along the tile index (the weight in dX, both
 // operands of dW) go straight to registers (a lane per column: 128-byte row segments).  Deterministic: no atomics.
 #include "common.h"
+#include "fused.h"
 #include <type_traits>
 
 namespace {
@@ -195,19 +201,42 @@ __device__ __forceinline__ void reduce_store(const f32x16& acc, float* red, cons
   }
 }
 
-// 16 MFMAs on the staged chunk: lane (li, lh) of MFMA (u, e) takes k = 8 u + 4 lh + e of its row
+// eight consecutive floats -> one bf16 MFMA operand (round to nearest even)
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 v = {cvt_pk_bf16(a[0], a[1]), cvt_pk_bf16(a[2], a[3]), cvt_pk_bf16(b[0], b[1]), cvt_pk_bf16(b[2], b[3])};
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 pack8(const float* x) {
+  return pack8(f32x4{x[0], x[1], x[2], x[3]}, f32x4{x[4], x[5], x[6], x[7]});
+}
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+// the staged A fragment of 16-k step ks: lane (li, lh) takes k = 16 ks + 8 lh .. + 7 of its row
+__device__ __forceinline__ bf16x8 frag16(const float* img, int li, int lh, int ks) {
+  const float* p = img + li * LDR + 16 * ks + 8 * lh;
+  return pack8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4));
+}
+
+// the MFMAs on the staged chunk.  Exact: 16 of 32x32x2, lane (li, lh) of MFMA (u, e) takes k = 8 u + 4 lh + e of its row;
+// BF: 2 of 32x32x16 on rounded operands
+template <bool BF>
 __device__ __forceinline__ void mfma_chunk(f32x16& acc, const float* imgA, const float* imgB, int li, int lh) {
+  if constexpr (BF) {
 #pragma unroll
-  for (int u = 0; u < KC / 8; ++u) {
-    const f32x4 fa = *reinterpret_cast<const f32x4*>(imgA + li * LDR + 8 * u + 4 * lh);
-    const f32x4 fb = *reinterpret_cast<const f32x4*>(imgB + li * LDR + 8 * u + 4 * lh);
+    for (int ks = 0; ks < KC / 16; ++ks) acc = mfma16(frag16(imgA, li, lh, ks), frag16(imgB, li, lh, ks), acc);
+  } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc = mfma2(fa[e], fb[e], acc);
+    for (int u = 0; u < KC / 8; ++u) {
+      const f32x4 fa = *reinterpret_cast<const f32x4*>(imgA + li * LDR + 8 * u + 4 * lh);
+      const f32x4 fb = *reinterpret_cast<const f32x4*>(imgB + li * LDR + 8 * u + 4 * lh);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = mfma2(fa[e], fb[e], acc);
+    }
   }
 }
 
 // ---- forward tile: C[m][n] = act(sum_k X(m, k) W[n][k] + bias[n]) --------------------------------------------------
-template <bool VEC>
+template <bool VEC, bool BF>
 __device__ __forceinline__ void fwd_tile(const Comp& A, const float* __restrict__ W, int ldw, const TileOut& o, int M, int N, int K,
                                          int m0, int n0, float* smem) {
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 31, lh = lane >> 5;
@@ -232,14 +261,14 @@ __device__ __forceinline__ void fwd_tile(const Comp& A, const float* __restrict_
       stage_lin<VEC>(sb, wr, ldw, K, lane, n0, (c + kWaves) * KC);
     }
     __builtin_amdgcn_wave_barrier();
-    mfma_chunk(acc, imgA, imgB, li, lh);
+    mfma_chunk<BF>(acc, imgA, imgB, li, lh);
     __builtin_amdgcn_wave_barrier();
   }
   reduce_store(acc, smem, o, m0, n0, M, N, w);
 }
 
 // ---- dX tile: dX[m][k'] = sum_n dY(m, n) W[n][k'] -------------------------------------------------------------------
-template <bool VEC>
+template <bool VEC, bool BF>
 __device__ __forceinline__ void dx_tile(const DY& Y, const float* __restrict__ W, int ldw, const TileOut& o, int M, int Nc /* contraction */,
                                         int Kout, int m0, int k0, float* smem) {
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 31, lh = lane >> 5;
@@ -248,22 +277,26 @@ __device__ __forceinline__ void dx_tile(const DY& Y, const float* __restrict__ W
   const DYR yr = dy_rsrc(Y, M, Nc);
   const rsrc_t wr = mk_rsrc(W, (long)Nc * ldw * 4);
   const int nchunks = (Nc + KC - 1) / KC;
-  const int bvoff = k0 + li < Kout ? (4 * lh * ldw + k0 + li) * 4 : kOut;   // a lane per output column: 128-byte row segments of W
+  // a lane per output column: 128-byte row segments of W; the lane half takes 4 (BF: 8) consecutive contraction rows
+  const int bvoff = k0 + li < Kout ? ((BF ? 8 : 4) * lh * ldw + k0 + li) * 4 : kOut;
   Stage2 sa;
   float fb0[16], fb1[16];
-  auto loadB = [&](float (&fb)[16], int nc) {               // contraction rows nc + 8 u + 4 lh + e (rows >= Nc: out of range, 0)
+  auto loadB = [&](float (&fb)[16], int nc) {               // contraction rows nc + 8 u + 4 lh + e (BF: nc + 16 ks + 8 lh + i); rows >= Nc read 0
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) fb[4 * u + e] = bl1(wr, bvoff, (nc + 8 * u + e) * ldw * 4);
+    for (int j = 0; j < 16; ++j) fb[j] = bl1(wr, bvoff, (nc + (BF ? 16 * (j >> 3) + (j & 7) : 8 * (j >> 2) + (j & 3))) * ldw * 4);
   };
   auto compute = [&](const float (&fb)[16]) {
     __builtin_amdgcn_wave_barrier();
+    if constexpr (BF) {
 #pragma unroll
-    for (int u = 0; u < KC / 8; ++u) {
-      const f32x4 fa = *reinterpret_cast<const f32x4*>(imgA + li * LDR + 8 * u + 4 * lh);
+      for (int ks = 0; ks < KC / 16; ++ks) acc = mfma16(frag16(imgA, li, lh, ks), pack8(&fb[8 * ks]), acc);
+    } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc = mfma2(fa[e], fb[4 * u + e], acc);
+      for (int u = 0; u < KC / 8; ++u) {
+        const f32x4 fa = *reinterpret_cast<const f32x4*>(imgA + li * LDR + 8 * u + 4 * lh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = mfma2(fa[e], fb[4 * u + e], acc);
+      }
     }
     __builtin_amdgcn_wave_barrier();
   };
@@ -295,17 +328,20 @@ __device__ __forceinline__ void dx_tile(const DY& Y, const float* __restrict__ W
 }
 
 // ---- dW tile (one WAVE): dW[n][k'] (+)= sum_m dY(m, n) X(m, k');  db[n] (+)= sum_m dY(m, n) for the tiles with k0 = 0 ----
+template <bool BF>
 __device__ __forceinline__ void dw_tile(const DY& Y, const Comp& X, float* __restrict__ dW, int ldw, float* __restrict__ db, int M, int N, int Kin,
                                         int n0, int k0, int accumulate) {
   const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
   const DYR yr = dy_rsrc(Y, M, N);
   const CompR xr = comp_rsrc(X, M, Kin);
   const bool a_ok = n0 + li < N;
-  // a lane per tile column, two batch rows per instruction (the lane halves); rows >= M are out of range and read 0
-  const int avoff = a_ok ? (lh * yr.ld + n0 + li) * 4 : kOut, avoff_add = a_ok ? (lh * yr.ld_add + n0 + li) * 4 : kOut;
+  // a lane per tile column, two batch rows per instruction (the lane halves: rows m + lh; BF: rows m + 8 lh, eight
+  // consecutive rows per lane and MFMA); rows >= M are out of range and read 0
+  constexpr int HR = BF ? 8 : 1;
+  const int avoff = a_ok ? (HR * lh * yr.ld + n0 + li) * 4 : kOut, avoff_add = a_ok ? (HR * lh * yr.ld_add + n0 + li) * 4 : kOut;
   const int k = k0 + li;
-  const int v0 = k < xr.ksplit ? (lh * xr.ld0 + k) * 4 : kOut;
-  const int vh = (k >= xr.ksplit && k < Kin) ? (lh * xr.ldh + k - xr.ksplit) * 4 : kOut;
+  const int v0 = k < xr.ksplit ? (HR * lh * xr.ld0 + k) * 4 : kOut;
+  const int vh = (k >= xr.ksplit && k < Kin) ? (HR * lh * xr.ldh + k - xr.ksplit) * 4 : kOut;
   f32x16 acc = {};
   float colsum = 0.f;
   // the loop is specialised ONCE per tile on the arrays its columns touch (a branch per load, even a wave-uniform one,
@@ -317,7 +353,7 @@ __device__ __forceinline__ void dw_tile(const DY& Y, const Comp& X, float* __res
     auto load = [&](float (&fa)[16], float (&fb)[16], int mc) {
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
-        const int m = mc + 2 * s;
+        const int m = mc + (BF ? 16 * (s >> 3) + (s & 7) : 2 * s);
         fa[s] = bl1(yr.p, avoff, m * yr.ld * 4);
         if constexpr (MODE == 2) fa[s] = fa[s] * yr.sc + bl1(yr.add, avoff_add, m * yr.ld_add * 4);
         if constexpr (MODE == 0) fb[s] = bl1(xr.x0, v0, m * xr.ld0 * 4) + bl1(xr.x1, v0, m * xr.ld0 * 4);
@@ -328,8 +364,12 @@ __device__ __forceinline__ void dw_tile(const DY& Y, const Comp& X, float* __res
     auto compute = [&](const float (&fa)[16], const float (&fb)[16]) {
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
-        acc = mfma2(fa[s], fb[s], acc);
+        if constexpr (!BF) acc = mfma2(fa[s], fb[s], acc);
         colsum += fa[s];
+      }
+      if constexpr (BF) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) acc = mfma16(pack8(&fa[8 * ks]), pack8(&fb[8 * ks]), acc);
       }
     };
     load(a0, b0, 0);
@@ -368,14 +408,14 @@ struct FwdLayer {
   int M, N, K;
 };
 
-template <bool VEC>
+template <bool VEC, bool BF>
 __global__ __launch_bounds__(kThreads) void head_fwd_kernel(const FwdLayer L) {
   __shared__ __attribute__((aligned(16))) float smem[kWaves * 2 * 32 * LDR];
   const int ntn = (L.N + 31) / 32;
   const int mt = blockIdx.x / ntn, nt = blockIdx.x % ntn;
   TileOut o = {};
   o.C = L.C; o.ldc = L.ldc; o.bias = L.bias; o.act = L.act; o.hsplit = 0x7fffffff;
-  fwd_tile<VEC>(L.A, L.W, L.K, o, L.M, L.N, L.K, 32 * mt, 32 * nt, smem);
+  fwd_tile<VEC, BF>(L.A, L.W, L.K, o, L.M, L.N, L.K, 32 * mt, 32 * nt, smem);
 }
 
 struct BwdLayer {
@@ -388,19 +428,19 @@ struct BwdLayer {
   int nx;                         // number of dX workgroups (0: the layer's input needs no gradient)
 };
 
-template <bool VEC>
+template <bool VEC, bool BF>
 __global__ __launch_bounds__(kThreads) void head_bwd_kernel(const BwdLayer L) {
   __shared__ __attribute__((aligned(16))) float smem[kWaves * 2 * 32 * LDR];
   if ((int)blockIdx.x < L.nx) {
     const int ntk = (L.Kin + 31) / 32;
     const int mt = blockIdx.x / ntk, kt = blockIdx.x % ntk;
-    dx_tile<VEC>(L.Y, L.W, L.Kin, L.o, L.M, L.N, L.Kin, 32 * mt, 32 * kt, smem);
+    dx_tile<VEC, BF>(L.Y, L.W, L.Kin, L.o, L.M, L.N, L.Kin, 32 * mt, 32 * kt, smem);
     return;
   }
   const int ntk = (L.Kin + 31) / 32, ntn = (L.N + 31) / 32;
   const int tile = ((int)blockIdx.x - L.nx) * kWaves + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (tile >= ntk * ntn) return;
-  dw_tile(L.Y, L.X, L.dW, L.Kin, L.db, L.M, L.N, L.Kin, 32 * (tile / ntk), 32 * (tile % ntk), L.accumulate);
+  dw_tile<BF>(L.Y, L.X, L.dW, L.Kin, L.db, L.M, L.N, L.Kin, 32 * (tile / ntk), 32 * (tile % ntk), L.accumulate);
 }
 
 // ---- the same tiles inside ONE launch per direction (COATTN_HEAD_PERSISTENT, opt-in) ---------------------------------
@@ -439,7 +479,7 @@ __global__ __launch_bounds__(kThreads) void head_fwd_persistent_kernel(const Fwd
     TileOut o = {};
     o.C = L.C; o.ldc = L.ldc; o.bias = L.bias; o.act = L.act; o.hsplit = 0x7fffffff;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-      fwd_tile<VEC>(L.A, L.W, L.K, o, L.M, L.N, L.K, 32 * (t / ntn), 32 * (t % ntn), smem);
+      fwd_tile<VEC, false>(L.A, L.W, L.K, o, L.M, L.N, L.K, 32 * (t / ntn), 32 * (t % ntn), smem);
       __syncthreads();                                        // the reduction slots become staging images again
     }
     if (l < 3) grid_barrier(a.bar, (unsigned)(l + 1) * gridDim.x);
@@ -456,12 +496,12 @@ __global__ __launch_bounds__(kThreads) void head_bwd_persistent_kernel(const Bwd
     for (int wk = blockIdx.x; wk < L.nx + ngroups; wk += gridDim.x) {
       if (wk < L.nx) {
         // (the last layer's dY rows are K floats: whole-line staging only when the host found them aligned)
-        if (VEC && (l > 0 || a.vec0)) dx_tile<true>(L.Y, L.W, L.Kin, L.o, L.M, L.N, L.Kin, 32 * (wk / ntk), 32 * (wk % ntk), smem);
-        else dx_tile<false>(L.Y, L.W, L.Kin, L.o, L.M, L.N, L.Kin, 32 * (wk / ntk), 32 * (wk % ntk), smem);
+        if (VEC && (l > 0 || a.vec0)) dx_tile<true, false>(L.Y, L.W, L.Kin, L.o, L.M, L.N, L.Kin, 32 * (wk / ntk), 32 * (wk % ntk), smem);
+        else dx_tile<false, false>(L.Y, L.W, L.Kin, L.o, L.M, L.N, L.Kin, 32 * (wk / ntk), 32 * (wk % ntk), smem);
         __syncthreads();
       } else {
         const int tile = (wk - L.nx) * kWaves + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        if (tile < ntk * ntn) dw_tile(L.Y, L.X, L.dW, L.Kin, L.db, L.M, L.N, L.Kin, 32 * (tile / ntk), 32 * (tile % ntk), L.accumulate);
+        if (tile < ntk * ntn) dw_tile<false>(L.Y, L.X, L.dW, L.Kin, L.db, L.M, L.N, L.Kin, 32 * (tile / ntk), 32 * (tile % ntk), L.accumulate);
       }
     }
     if (l < 3) grid_barrier(a.bar, (unsigned)(l + 1) * gridDim.x);
@@ -507,19 +547,23 @@ int check_dims(int B, int d, int mlp, int K, int dtype) {
   return 0;
 }
 
-int launch_fwd(const FwdLayer& L, bool vec, hipStream_t s) {
-  const unsigned grid = (unsigned)(((L.M + 31) / 32) * ((L.N + 31) / 32));
-  if (vec) hipLaunchKernelGGL(head_fwd_kernel<true>, dim3(grid), dim3(kThreads), 0, s, L);
-  else hipLaunchKernelGGL(head_fwd_kernel<false>, dim3(grid), dim3(kThreads), 0, s, L);
+int launch_fwd(const FwdLayer& L, bool vec, bool bf, hipStream_t s) {
+  const dim3 grid((unsigned)(((L.M + 31) / 32) * ((L.N + 31) / 32))), block(kThreads);
+  if (vec && bf) hipLaunchKernelGGL((head_fwd_kernel<true, true>), grid, block, 0, s, L);
+  else if (vec) hipLaunchKernelGGL((head_fwd_kernel<true, false>), grid, block, 0, s, L);
+  else if (bf) hipLaunchKernelGGL((head_fwd_kernel<false, true>), grid, block, 0, s, L);
+  else hipLaunchKernelGGL((head_fwd_kernel<false, false>), grid, block, 0, s, L);
   CA_CHECK_LAUNCH("head_fwd");
   return 0;
 }
-int launch_bwd(BwdLayer& L, bool want_dx, bool vec, hipStream_t s) {
+int launch_bwd(BwdLayer& L, bool want_dx, bool vec, bool bf, hipStream_t s) {
   const int ntk = (L.Kin + 31) / 32, ntn = (L.N + 31) / 32;
   L.nx = want_dx ? ((L.M + 31) / 32) * ntk : 0;
-  const unsigned grid = (unsigned)(L.nx + (ntk * ntn + kWaves - 1) / kWaves);
-  if (vec) hipLaunchKernelGGL(head_bwd_kernel<true>, dim3(grid), dim3(kThreads), 0, s, L);
-  else hipLaunchKernelGGL(head_bwd_kernel<false>, dim3(grid), dim3(kThreads), 0, s, L);
+  const dim3 grid((unsigned)(L.nx + (ntk * ntn + kWaves - 1) / kWaves)), block(kThreads);
+  if (vec && bf) hipLaunchKernelGGL((head_bwd_kernel<true, true>), grid, block, 0, s, L);
+  else if (vec) hipLaunchKernelGGL((head_bwd_kernel<true, false>), grid, block, 0, s, L);
+  else if (bf) hipLaunchKernelGGL((head_bwd_kernel<false, true>), grid, block, 0, s, L);
+  else hipLaunchKernelGGL((head_bwd_kernel<false, false>), grid, block, 0, s, L);
   CA_CHECK_LAUNCH("head_bwd");
   return 0;
 }
@@ -576,7 +620,8 @@ extern "C" int coattn_head_forward(const void* const* v, const void* const* q, c
     else hipLaunchKernelGGL(head_fwd_persistent_kernel<false>, dim3(grid), dim3(kThreads), 0, s, all);
     CA_CHECK_LAUNCH("head_fwd_persistent");
   } else {
-    for (int l = 0; l < 4; ++l) CA_TRY(launch_fwd(Ls[l], vec, s));
+    const bool bf = (flags & COATTN_FLAG_BF16_PROJ) != 0;
+    for (int l = 0; l < 4; ++l) CA_TRY(launch_fwd(Ls[l], vec, bf, s));
   }
   if (labels) CA_TRY(launch_ce_rows((const float*)logits, labels, sv + hs.rl, sv + hs.dl, (float*)loss, B, K, reinterpret_cast<int*>(sv + hs.st), s, kpad(K)));
   return 0;
@@ -661,8 +706,9 @@ extern "C" int coattn_head_backward(const void* const* v, const void* const* q, 
     CA_CHECK_LAUNCH("head_bwd_persistent");
     return 0;
   }
-  CA_TRY(launch_bwd(Ls[0], true, vec_h, s));
-  CA_TRY(launch_bwd(Ls[1], true, vec, s));
-  CA_TRY(launch_bwd(Ls[2], true, vec, s));
-  return launch_bwd(Ls[3], dv != nullptr, vec, s);
+  const bool bf = (flags & COATTN_FLAG_BF16_PROJ) != 0;
+  CA_TRY(launch_bwd(Ls[0], true, vec_h, bf, s));
+  CA_TRY(launch_bwd(Ls[1], true, vec, bf, s));
+  CA_TRY(launch_bwd(Ls[2], true, vec, bf, s));
+  return launch_bwd(Ls[3], dv != nullptr, vec, bf, s);
 }

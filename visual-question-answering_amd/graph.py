@@ -39,6 +39,7 @@ class HotPathGraph:
         dev = co_attention.W_v.weight.device
         self.device = dev
         self.flags = flags
+        self.head_flags = _lib.FLAG_BF16_PROJ if getattr(mlp_classify, "bf16_products", False) else 0
         f32 = dict(device=dev, dtype=torch.float32)
         # static inputs, used when the caller's tensors are not taken in place (layout, alignment, too many address sets)
         self.V = torch.zeros((B, N, d), **f32)
@@ -87,12 +88,12 @@ class HotPathGraph:
             _lib.check(lib.coattn_forward(_ptr(V), *vs, qptr, C.byref(p), _ptr(self.v), _ptr(self.q), _ptr(self.saved),
                                           _ptr(self.ws), B, N, T, d, 3, _lib.F32, self.flags, st), "coattn_forward")
             _lib.check(lib.coattn_head_forward(rows(self.v), rows(self.q), C.byref(hp), _ptr(labels), _ptr(self.logits),
-                                               _ptr(self.loss), _ptr(self.hsaved), B, d, mlp, K, _lib.F32, 0, st),
+                                               _ptr(self.loss), _ptr(self.hsaved), B, d, mlp, K, _lib.F32, self.head_flags, st),
                        "coattn_head_forward")
         if bwd:
             _lib.check(lib.coattn_head_backward(rows(self.v), rows(self.q), C.byref(hp), _ptr(self.hsaved), _ptr(self.g_loss),
                                                 None, rows(self.dx), None, C.byref(hg), 0, _ptr(self.hws), B, d, mlp, K,
-                                                _lib.F32, 0, st), "coattn_head_backward")
+                                                _lib.F32, self.head_flags, st), "coattn_head_backward")
             _lib.check(lib.coattn_backward(_ptr(V), *vs, qptr, C.byref(p), _ptr(self.saved), _ptr(self.dx), _ptr(self.dx),
                                            _ptr(self.dV), *(vs if self.dV is not None else (0, 0, 0)), dqptr, C.byref(pg),
                                            0, _ptr(self.ws), B, N, T, d, 3, _lib.F32, self.flags, st), "coattn_backward")

@@ -50,7 +50,8 @@ class _HeadFn(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)     # fp32 island under autocast
-    def forward(ctx, v, q, W_w, b_w, W_p, b_p, W_s, b_s, W_h, b_h, labels):
+    def forward(ctx, v, q, W_w, b_w, W_p, b_p, W_s, b_s, W_h, b_h, labels, bf16=False):
+        ctx.flags = _flags() | (_lib.FLAG_BF16_PROJ if bf16 else 0)
         if not v.is_cuda:
             raise RuntimeError("answer_head (HIP) needs tensors on the GPU; there is no CPU fallback")
         if v.dtype != torch.float32 or q.dtype != torch.float32:
@@ -77,7 +78,7 @@ class _HeadFn(torch.autograd.Function):
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         with torch.cuda.device(dev):
             _lib.check(lib.coattn_head_forward(_rows(v), _rows(q), C.byref(p), _ptr(lab), _ptr(logits), _ptr(loss),
-                                               _ptr(saved), B, d, mlp, K, _lib.F32, _flags(), stream), "coattn_head_forward")
+                                               _ptr(saved), B, d, mlp, K, _lib.F32, ctx.flags, stream), "coattn_head_forward")
         if labels is not None:
             global _last
             _last = (saved, B, d, mlp, K, dev)
@@ -97,7 +98,7 @@ class _HeadFn(torch.autograd.Function):
         if not ctx.has_loss:
             g_loss = None
         if g_logits is None and g_loss is None:
-            return (None,) * 11
+            return (None,) * 12
         g_logits = g_logits.contiguous().float() if g_logits is not None else None
         g_loss = g_loss.contiguous().float() if g_loss is not None else None
         _, wb = _workspace_bytes(B, d, mlp, K)
@@ -111,8 +112,8 @@ class _HeadFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.check(lib.coattn_head_backward(_rows(v), _rows(q), C.byref(p), _ptr(saved), _ptr(g_loss), _ptr(g_logits),
                                                 _rows(dx) if need_in else None, None, C.byref(pg), 0, _ptr(ws),
-                                                B, d, mlp, K, _lib.F32, _flags(), C.c_void_p(stream)), "coattn_head_backward")
-        return (dx if ctx.needs_input_grad[0] else None, dx if ctx.needs_input_grad[1] else None, *grads, None)
+                                                B, d, mlp, K, _lib.F32, ctx.flags, C.c_void_p(stream)), "coattn_head_backward")
+        return (dx if ctx.needs_input_grad[0] else None, dx if ctx.needs_input_grad[1] else None, *grads, None, None)
 
 
 def check_labels() -> None:
@@ -147,8 +148,10 @@ def _as_3bd(x) -> torch.Tensor:
     return torch.stack(x)
 
 
-def answer_head(v, q, W_w, b_w, W_p, b_p, W_s, b_s, W_h, b_h, labels: Optional[torch.Tensor] = None):
+def answer_head(v, q, W_w, b_w, W_p, b_p, W_s, b_s, W_h, b_h, labels: Optional[torch.Tensor] = None, bf16: bool = False):
     """v, q: [3,B,d] tensors or sequences of three [B,d] tensors (attended image / question features of the word,
-    phrase and sentence levels).  Returns logits [B,K] -- and, with int64 labels [B], (logits, mean cross entropy)."""
-    logits, loss = _HeadFn.apply(_as_3bd(v), _as_3bd(q), W_w, b_w, W_p, b_p, W_s, b_s, W_h, b_h, labels)
+    phrase and sentence levels).  Returns logits [B,K] -- and, with int64 labels [B], (logits, mean cross entropy).
+    bf16: the reduced-precision mode (operands of the four products and of their gradients rounded to bf16, one bf16 MFMA
+    where the exact head issues eight f32 ones; fp32 accumulation, biases, tanh and loss) -- the apex-O1 analogue."""
+    logits, loss = _HeadFn.apply(_as_3bd(v), _as_3bd(q), W_w, b_w, W_p, b_p, W_s, b_s, W_h, b_h, labels, bf16)
     return logits if labels is None else (logits, loss)

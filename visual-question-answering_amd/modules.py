@@ -274,6 +274,7 @@ class MLPClassifier(nn.Module):
         self.W_p = nn.Linear(2 * hidden_dim, hidden_dim)
         self.W_s = nn.Linear(2 * hidden_dim, mlp_dim)
         self.W_h = nn.Linear(mlp_dim, K)
+        self.bf16_products = False       # reduced-precision mode of the HIP head (set with --opt_lvl >= 1, train.Trainer)
 
     def _hip(self, x):
         x0 = x if torch.is_tensor(x) else x[0]
@@ -285,7 +286,7 @@ class MLPClassifier(nn.Module):
 
     def forward(self, x_img_feats, x_ques_feats):
         if self._hip(x_img_feats):
-            return answer_head(x_img_feats, x_ques_feats, *self._params())
+            return answer_head(x_img_feats, x_ques_feats, *self._params(), bf16=self.bf16_products)
         (q_w, q_p, q_s), (v_w, v_p, v_s) = x_ques_feats, x_img_feats
         h_w = torch.tanh(self.W_w(q_w + v_w))
         h_p = torch.tanh(self.W_p(torch.cat([q_p + v_p, h_w], dim=1)))
@@ -295,7 +296,7 @@ class MLPClassifier(nn.Module):
     def forward_loss(self, x_img_feats, x_ques_feats, labels):
         """(logits, nn.CrossEntropyLoss()(logits, labels)) -- main.py:211 + :214 -- in one call of the HIP head."""
         if self._hip(x_img_feats):
-            return answer_head(x_img_feats, x_ques_feats, *self._params(), labels=labels)
+            return answer_head(x_img_feats, x_ques_feats, *self._params(), labels=labels, bf16=self.bf16_products)
         logits = self.forward(x_img_feats, x_ques_feats)
         return logits, F.cross_entropy(logits.float(), labels)
 
@@ -345,7 +346,8 @@ class HierarchicalCoAttentionNet(nn.Module):
         from .graph import HotPathGraph
         B, N, _ = x_img_features.shape
         T = x_ques_features[0].shape[1]
-        key = (B, N, T, bool(x_img_features.requires_grad), bool(self.co_attention.bf16_projections))
+        key = (B, N, T, bool(x_img_features.requires_grad), bool(self.co_attention.bf16_projections),
+               bool(self.mlp_classify.bf16_products))
         hp = self._graphs.get(key)
         if hp is None:
             hp = self._graphs[key] = HotPathGraph(self.co_attention, self.mlp_classify, B, N, T, need_dv=key[3],

@@ -227,6 +227,8 @@ class Trainer:
         self.opt_lvl = opt_lvl
         if opt_lvl > 0 and hasattr(model, "co_attention"):      # AMP: projections on the bf16 MFMA as well
             model.co_attention.bf16_projections = True
+            if hasattr(getattr(model, "mlp_classify", None), "bf16_products"):
+                model.mlp_classify.bf16_products = True
         # graph=True: co-attention + answer head + loss, forward and backward, replayed from one captured HIP graph
         # (graph.py): one host call instead of ~25 launches; same values bit for bit
         if graph and hasattr(model, "hot_path_graph") and self.device.type == "cuda":

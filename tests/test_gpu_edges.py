@@ -202,13 +202,14 @@ def test_bf16_mfma_projections(shape):
     assert (r["dW_q.weight"] - x["dW_q.weight"]).abs().max().item() > 0
 
 
-def test_bf16_mode_stores_its_gemm_only_gradients_as_bf16():
-    """Reduced-precision mode at config 4's full size with a frozen image encoder (no dV): bwd_nat32 stores dP_v / dP_q
+@pytest.mark.parametrize("shape", [(160, 49, 26, 2048), (16, 196, 26, 1024)], ids=lambda s: "B%d_N%d_T%d_d%d" % s)
+def test_bf16_mode_stores_its_gemm_only_gradients_as_bf16(shape):
+    """Reduced-precision mode at config 4's full size (and at the 14 x 14 grid) with a frozen image encoder (no dV): bwd_nat32 stores dP_v / dP_q
     as bf16 and the three GEMMs that consume them read them as stored.  Every value is rounded at the same place as with
     fp32 storage, so dQ and dW_q are BIT-identical to the run that keeps them in fp32 (the one that also asks for dV);
     dW_v sums the three levels after the rounding instead of before it (bf16 tolerance)."""
     from tests._hip import run_hip
-    B, N, T, d = 160, 49, 26, 2048
+    B, N, T, d = shape
     P = O.make_params(d, 12)
     V, Qs = O.make_inputs(B, N, T, d, 62, lens=sorted([26] + [5] * (B - 1), reverse=True), scale_q=(2.0 / d) ** 0.5)
     gv = torch.from_numpy(O.hash_normal((3, B, d), 5)).float()

@@ -60,8 +60,21 @@ def _worker(rank, world, port, q, exchange="allreduce"):
         red.finish()
         grads_step.append({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
         opt.step()
+    # the peer-mapped exchange needs GPU buckets: on CPU tensors it refuses on every rank alike (no rank left in a collective)
+    nb = len(red.buckets)
+    red.reset("p2p")
+    loss = crit(model(x[sl], [qq[sl] for qq in Qs]), label[sl])
+    opt.zero_grad()
+    red.prepare()
+    loss.backward()
+    try:
+        red.finish()
+        refused = False
+    except RuntimeError as e:
+        refused = "GPU" in str(e)
+    assert refused
     # plain numpy through the queue (tensor fd-sharing dies with the worker)
-    q.put((rank, red.unused, len(red.buckets), {n: g.numpy() for n, g in grads_step[0].items()},
+    q.put((rank, red.unused, nb, {n: g.numpy() for n, g in grads_step[0].items()},
            {n: p.detach().numpy().copy() for n, p in model.named_parameters()}))
     vdist.shutdown()
 

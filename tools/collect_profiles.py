@@ -61,23 +61,27 @@ if vals:
             m["derived_valu_active_per_wave"] = m["SQ_ACTIVE_INST_VALU"] / m["SQ_WAVE_CYCLES"]
         out[kern] = m
     json.dump(out, open(os.path.join(DST, "%s_pmc_mfma.json" % tag), "w"), indent=1)
-# the same counters over the whole isolated hot path (bench.py --only hot): one entry per kernel of the HIP library
-hot = {}
-for f in newest("pmc_hot/**/*counter_collection.csv"):
-    for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"]
-        if "anonymous namespace" not in k or "at::native" in k or "softmax_warp" in k:
-            continue                                   # stock PyTorch / MIOpen / rocBLAS kernels are not ours
-        name = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
-        hot.setdefault(name, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-if hot:
-    out = {}
-    for name, cs in sorted(hot.items()):
-        m = {c: sum(v) / len(v) for c, v in cs.items()}
-        m["dispatches"] = len(next(iter(cs.values())))
-        if m.get("SQ_BUSY_CYCLES") and "SQ_VALU_MFMA_BUSY_CYCLES" in m:
-            m["derived_mfma_busy_frac"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (32.0 * m["SQ_BUSY_CYCLES"]), 4)
-        out[name] = m
-    json.dump(out, open(os.path.join(DST, "%s_pmc_hot_path_kernels.json" % tag), "w"), indent=1)
+# the same counters over the whole isolated hot path (bench.py --only hot): one entry per kernel of the HIP library;
+# pmc_cfg4_hot: config 4's hot path (the reduced-precision instantiations)
+for src_dir, out_name in (("pmc_hot", "pmc_hot_path_kernels"), ("pmc_cfg4_hot", "pmc_cfg4_hot_path_kernels")):
+    hot = {}
+    for f in newest("%s/**/*counter_collection.csv" % src_dir):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if "anonymous namespace" not in k or "at::native" in k or "softmax_warp" in k:
+                continue                                   # stock PyTorch / MIOpen / rocBLAS kernels are not ours
+            name = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
+            hot.setdefault(name, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    if hot:
+        out = {}
+        for name, cs in sorted(hot.items()):
+            m = {c: sum(v) / len(v) for c, v in cs.items()}
+            m["dispatches"] = len(next(iter(cs.values())))
+            if m.get("SQ_BUSY_CYCLES") and "SQ_VALU_MFMA_BUSY_CYCLES" in m:
+                m["derived_mfma_busy_frac"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (32.0 * m["SQ_BUSY_CYCLES"]), 4)
+            if m.get("SQ_INSTS_MFMA") and "SQ_INSTS_VALU" in m:
+                m["derived_valu_per_mfma"] = round(m["SQ_INSTS_VALU"] / m["SQ_INSTS_MFMA"], 2)
+            out[name] = m
+        json.dump(out, open(os.path.join(DST, "%s_%s.json" % (tag, out_name)), "w"), indent=1)
 print("profiles/ refreshed from", SRC)
 print(line[:400])

@@ -33,7 +33,7 @@ LAYOUTS = ("cm", "lm")      # channel-major [B,d,N] (the reference's NCHW encode
 
 
 def run_hip(V, Qs, P, gv=None, gq=None, impl="general", need_dv=True, accumulate=0, grads_init=None, bf16_proj=False,
-            layout="cm"):
+            layout="cm", exact3=False):
     """V [B,d,N] (channel-major values; `layout` selects the PHYSICAL layout handed to the C-ABI: "cm" as is, "lm" a
     [B,N,d] buffer), Qs list of [B,T,d], P dict of reference-named params (CPU or CUDA tensors).
     Returns dict with v,q and saved state; with gv/gq also all gradients (dV_phys always as [B,d,N] values)."""
@@ -53,7 +53,7 @@ def run_hip(V, Qs, P, gv=None, gq=None, impl="general", need_dv=True, accumulate
     assert gv is None or gv.shape[0] == len(Qs)
     T = Qs[0].shape[1]
     L = len(Qs)
-    flag = IMPL[impl] | (_lib.FLAG_BF16_PROJ if bf16_proj else 0)
+    flag = IMPL[impl] | (_lib.FLAG_BF16_PROJ if bf16_proj else 0) | (_lib.FLAG_EXACT3 if exact3 else 0)
     sb, fb, bb = _lib.workspace_bytes(B, N, T, d, L, flag)
     v = torch.full((L, B, d), float("nan"), device=dev)
     q = torch.full((L, B, d), float("nan"), device=dev)

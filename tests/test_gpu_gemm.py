@@ -357,3 +357,51 @@ def test_linear_weight_grad_bf16_stored_gradients(M, n_out, n_in):
     assert _rel(dW, dy.double().t() @ x.bfloat16().double()) < 2e-5
     rc, _ = _wgrad(dy, n_out, x, n_in, M, n_out, n_in, accumulate=_lib.FLAG_BF16_IN)
     assert rc != 0
+
+
+# ---- the two-piece width (COATTN_FLAG_SPLIT2) of the linear entry points -------------------------------------------
+# operands truncated to their first two bf16 pieces (hi + mid, round to nearest at each step), the three partial
+# products hi*mid, mid*hi, hi*hi, fp32 accumulation: against the float64 value of exactly those products only the
+# accumulation order differs (2e-6 of max|.|); against the true product the error is ~2^-16 per product, random in sign
+def _two_piece(x):
+    h = x.bfloat16().float()
+    m = (x - h).bfloat16().float()
+    return h.double(), m.double()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (4160, 512, 512), (1000, 96, 64), (129, 200, 160), (31360, 512, 512)])
+def test_linear_two_piece_width(M, N, K):
+    from vqa_amd import _lib
+    torch.manual_seed(41)
+    x = torch.randn(M, K, device="cuda")
+    W = torch.randn(N, K, device="cuda") / K ** 0.5
+    b = torch.randn(N, device="cuda")
+    rc, y, _ = _linear(x, K, W, b, M, N, K, flags=_lib.FLAG_SPLIT2)
+    _lib.check(rc, "coattn_linear_forward")
+    xh, xm = _two_piece(x)
+    wh, wm = _two_piece(W)
+    ref2 = (xh + xm) @ wh.t() + xh @ wm.t() + b.double()
+    assert _rel(y, ref2) < 2e-6
+    true = x.double() @ W.double().t() + b.double()
+    e = _rel(y, true)
+    print("two-piece linear %s: %.2e of max|.| from the true product" % ((M, N, K), e))
+    assert 1e-7 < e < 3e-5                                  # it IS the two-piece product, and no worse than its budget
+
+
+@pytest.mark.parametrize("M,n_out,n_in", [(17, 128, 256), (4160, 512, 512), (31360, 512, 512), (12345, 128, 384)])
+def test_linear_weight_grad_two_piece_width(M, n_out, n_in):
+    from vqa_amd import _lib
+    torch.manual_seed(42)
+    dy = torch.randn(M, n_out, device="cuda") * 0.1
+    x = torch.randn(M, n_in, device="cuda")
+    rc, dW = _wgrad(dy, n_out, x, n_in, M, n_out, n_in, accumulate=_lib.FLAG_SPLIT2)
+    _lib.check(rc, "coattn_linear_weight_grad")
+    dh, dm = _two_piece(dy)
+    xh, xm = _two_piece(x)
+    ref2 = (dh + dm).t() @ xh + dh.t() @ xm
+    assert _rel(dW, ref2) < 2e-6
+    e = _rel(dW, dy.double().t() @ x.double())
+    print("two-piece weight grad %s: %.2e of max|.| from the true product" % ((M, n_out, n_in), e))
+    assert e < 3e-5
+    rc, dW2 = _wgrad(dy, n_out, x, n_in, M, n_out, n_in, accumulate=_lib.FLAG_SPLIT2)
+    assert torch.equal(dW, dW2)

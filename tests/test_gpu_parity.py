@@ -43,6 +43,25 @@ def test_forward_backward_vs_reference_golden(name):
             assert max(ge.values()) < GRAD_TOL, (impl, layout, ge)
 
 
+@pytest.mark.parametrize("name", sorted(G.CASES))
+def test_exact_split_flag_vs_reference_golden(name):
+    """COATTN_FLAG_EXACT3: every contraction on the three-piece split -- the goldens hold at fp32 rounding level."""
+    from tests._hip import run_hip
+    if "fused" not in _impls(name):
+        pytest.skip("general-shape path: always exact")
+    gold = G.load(name)
+    V, Qs, P, gv, gq = G.build_case(name, torch.float32)
+    r = run_hip(V, Qs, P, gv, gq, impl="fused", layout="lm", exact3=True)
+    fe, ge = G.fwd_errors(r, gold, "64"), G.grad_errors(r, gold, "64")
+    print(name, "exact3 fwd %.1e grad %.1e" % (max(fe.values()), max(ge.values())))
+    assert max(fe.values()) < 1e-5 and max(ge.values()) < 1e-5, (fe, ge)
+    # the default widths differ from it only inside their budget (tests/test_split_emulation.py)
+    r2 = run_hip(V, Qs, P, gv, gq, impl="fused", layout="lm")
+    for k in ("dQ", "dW_v.weight", "dW_q.weight"):
+        d = (r2[k] - r[k]).abs().max() / r[k].abs().max()
+        assert d < 5e-5, (k, float(d))
+
+
 @pytest.mark.parametrize("impl", ["general", "fused"])
 def test_module_dropin_autograd(impl, monkeypatch):
     """nn.Module surface (model.py:337-397): same state_dict keys, list-in/list-out, autograd; W_b dead."""

@@ -23,6 +23,8 @@ F32 = 0
 IMPL_AUTO, IMPL_GENERAL, IMPL_FUSED = 0, 1, 2
 FLAG_BF16_PROJ = 4
 FLAG_BF16_IN = 8          # linear entry points: x (dy) stored as bf16
+FLAG_EXACT3 = 16          # coattn_forward / coattn_backward: every contraction on the exact three-piece split
+FLAG_SPLIT2 = 32          # linear entry points: the two-piece width (hi + mid, three partial products)
 
 
 class Params(C.Structure):

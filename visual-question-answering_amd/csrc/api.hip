@@ -103,6 +103,7 @@ extern "C" int coattn_linear_forward(const void* x, int64_t ld_x, const void* W,
   g.A = (const float*)x; g.a_sm = (int)ld_x; g.Wf = wimg; g.C = (float*)y; g.c_sm = N; g.bias_n = (const float*)bias;
   g.out_scale = out_scale; g.M = M; g.N = N; g.K = K; g.batch = 1;
   g.bf16 = (flags & COATTN_FLAG_BF16_PROJ) ? 1 : 0;
+  g.np = (flags & COATTN_FLAG_SPLIT2) ? 2 : 3;
   g.a_bf16 = (flags & COATTN_FLAG_BF16_IN) ? 1 : 0;
   CA_CHECK_ARG(!g.a_bf16 || g.bf16, "linear: COATTN_FLAG_BF16_IN needs COATTN_FLAG_BF16_PROJ");
   CA_CHECK_ARG(g.a_bf16 ? gemm_bf_supported(g) : gemm_w_supported(g), "linear: shape M=%d N=%d K=%d ld=%ld not supported (see coattn.h)", M, N, K, (long)ld_x);
@@ -125,6 +126,7 @@ extern "C" int coattn_linear_weight_grad(const void* dy, int64_t ld_dy, const vo
   g.A = (const float*)dy; g.a_ld = (int)ld_dy; g.B = (const float*)x; g.b_ld = (int)ld_x; g.C = (float*)ws;
   g.M = n_out; g.N = n_in; g.K = M; g.levels = 1;
   g.bf16 = (accumulate & COATTN_FLAG_BF16_PROJ) ? 1 : 0;
+  g.np = (accumulate & COATTN_FLAG_SPLIT2) ? 2 : 3;
   g.a_bf16 = (accumulate & COATTN_FLAG_BF16_IN) ? 1 : 0;
   accumulate &= 1;
   CA_CHECK_ARG(!g.a_bf16 || g.bf16, "linear weight grad: COATTN_FLAG_BF16_IN needs COATTN_FLAG_BF16_PROJ");
@@ -220,6 +222,20 @@ int c_times(const Ctx& c, const float* C, const float* Y, const float* X, float*
   g.C = out; g.c_sz = (int64_t)c.T * c.d; g.c_sm = c.d; g.c_sn = 1;
   g.M = c.T; g.N = c.d; g.K = c.N; g.batch = c.B; g.act = act;
   return launch_gemm_f32(g, c.s);
+}
+
+// Width of the fp32 mode's contractions (fused.h).  Default: the mixed widths of DESIGN.md section 3 -- the affinity and
+// the projections on the exact split, the backward's contractions on two pieces.  COATTN_FLAG_EXACT3 (or the developer
+// switch COATTN_SPLIT=3) puts every contraction on the exact split; COATTN_SPLIT_FWD=2 (developer switch) also runs the
+// forward kernel's phase 2 on two pieces.
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static int np_bwd(int flags) {
+  static const int split = env_int("COATTN_SPLIT", 2);
+  return ((flags & COATTN_FLAG_EXACT3) || split == 3) ? 3 : 2;
+}
+static int np_fwd(int flags) {
+  static const int split = env_int("COATTN_SPLIT", 2), fwd = env_int("COATTN_SPLIT_FWD", 3);
+  return ((flags & COATTN_FLAG_EXACT3) || split == 3) ? 3 : (fwd == 2 ? 2 : 3);
 }
 
 // COATTN_GEMM_W=0 (developer switch): the projections through gemm.hip instead of the pre-split-weight kernel
@@ -498,7 +514,7 @@ static int forward_impl(const void* V, const VLayout& vl, const void* const* Q, 
   if (!do_attn) return 0;
   if (fused)
     return fused_attention_forward(B, N, T, d, L, (const float*)V, vl, (const float* const*)Q, p, (float*)v_out,
-                                   (float*)q_out, sv, tail, c.s, c.bf16_proj ? 1 : 0);
+                                   (float*)q_out, sv, tail, c.s, c.bf16_proj ? 1 : 0, np_fwd(flags));
   return general_attention(c, (const float*)V, (const float* const*)Q, p, (float*)v_out, (float*)q_out, sv, tail);
 }
 
@@ -542,7 +558,7 @@ extern "C" int coattn_backward(const void* V, int64_t v_sB, int64_t v_sN, int64_
     return fused_backward(B, N, T, d, L, (const float*)V, vl, (const float* const*)Q, p, (const float*)saved,
                           (const float*)gv, (const float*)gq, (float*)dV, dvl, (float* const*)dQ, pg, accumulate,
                           (float*)ws, c.s, c.bf16_proj ? 1 : 0,
-                          gemm_w_enabled() ? 1 : 0);
+                          gemm_w_enabled() ? 1 : 0, np_bwd(flags));
   return backward_general(c, (const float*)V, (const float* const*)Q, p, (const float*)saved, (const float*)gv,
                           (const float*)gq, (float*)dV, dvl, (float* const*)dQ, pg, accumulate, (float*)ws);
 }

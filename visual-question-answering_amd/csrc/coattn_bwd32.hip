@@ -20,6 +20,7 @@
 // H_v is never stored.  Rows t >= T / n >= N fall outside the per-sample buffer descriptors (loads 0, stores dropped).
 #include "fused.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #ifndef COATTN_DC_GT          // bwd_dc32_kernel: location tiles per group (their dC accumulators: 16 registers each)
 #define COATTN_DC_GT 4
@@ -27,11 +28,13 @@
 
 namespace {
 
+// NP: width of the contractions (fused.h: 3 = exact split, 2 = hi + mid, 1 = the reduced-precision mode SP).
 // DPB (with SP): dP_v and dP_q are stored as bf16 (same index order, 2-byte elements) -- every consumer is a GEMM of the
 // reduced-precision mode, which would round them on its way in anyway.  Lane pairs (r, r + 1) meet through a DPP quad
 // permute, the even lane stores one dword for both channels.
-template <int NT, int NW, bool SP, bool DPB>
+template <int NT, int NW, int NP, bool DPB>
 __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) {
+  static_assert(!DPB || NP == 1, "bf16 dP storage belongs to the reduced-precision mode");
   constexpr int NPAD = 32 * NT;
   constexpr int PIECE = NPAD * 32;                   // bf16 elements of one piece of the C image [n][t = 32]
   constexpr int NTHR = NW * 64;
@@ -52,8 +55,6 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
   const __amdgpu_buffer_rsrc_t rs_dpq = make_rsrc(reinterpret_cast<const char*>(a.dPq) + pair * (size_t)T * d * ES, (unsigned)T * d * ES);
   const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(a.C + pair * (size_t)T * N, (unsigned)T * N * 4u);
   const int nsl = d / (128 * NW);                    // 128-channel slices per wave (1 at d = 512)
-  constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};   // smallest piece products first
-
   const __amdgpu_buffer_rsrc_t rs_dpv = make_rsrc(reinterpret_cast<const char*>(a.dPv) + pair * (size_t)N * d * ES, (unsigned)N * d * ES);
   // the lane's channel inside a 32-channel unit as the stores see it: bf16 stores leave from the even lanes only (an odd
   // lane's offset lies outside every buffer)
@@ -96,16 +97,14 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
       float c[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) c[i] = buf_load1(rs_c, cvoff, i * N * 4);
-      unsigned hh[2], mm[2], ll[2];
-      split3_pair(c[0], c[1], hh[0], mm[0], ll[0]);
-      split3_pair(c[2], c[3], hh[1], mm[1], ll[1]);
+      unsigned hh[2] = {0, 0}, mm[2] = {0, 0}, ll[2] = {0, 0};
+      split_pair<NP>(c[0], c[1], hh[0], mm[0], ll[0]);
+      split_pair<NP>(c[2], c[3], hh[1], mm[1], ll[1]);
       const int off = n * 32 + 8 * ((tq >> 1) ^ ((n >> 2) & 3)) + 4 * (tq & 1);
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
       *reinterpret_cast<u32x2*>(Cimg + off) = u32x2{hh[0], hh[1]};
-      if (!SP) {
-        *reinterpret_cast<u32x2*>(Cimg + PIECE + off) = u32x2{mm[0], mm[1]};
-        *reinterpret_cast<u32x2*>(Cimg + 2 * PIECE + off) = u32x2{ll[0], ll[1]};
-      }
+      if (NP >= 2) *reinterpret_cast<u32x2*>(Cimg + PIECE + off) = u32x2{mm[0], mm[1]};
+      if (NP == 3) *reinterpret_cast<u32x2*>(Cimg + 2 * PIECE + off) = u32x2{ll[0], ll[1]};
     }
     const float* dg = a.dsv + pair * (size_t)N;
     for (int e = tid; e < NPAD; e += NTHR) dsvs[e] = e < N ? dg[e] : 0.f;
@@ -120,7 +119,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
   const int rk = (r >> 2) & 3;
   auto read_cq = [&](const short* img, const int s2, bf16x8 (&cq)[3]) {     // A = C (tokens x locations)
 #pragma unroll
-    for (int p = 0; p < (SP ? 1 : 3); ++p) {
+    for (int p = 0; p < NP; ++p) {
       const bf16x4 lo = lds_tr16(img + p * PIECE + 16 * s2 * 32 + tr_off0);
       const bf16x4 hi = lds_tr16(img + p * PIECE + 16 * s2 * 32 + tr_off1);
       cq[p] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -128,7 +127,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
   };
   auto read_ca = [&](const short* img, const int ks, bf16x8 (&ca)[3]) {      // A = C^T (locations x tokens)
 #pragma unroll
-    for (int p = 0; p < (SP ? 1 : 3); ++p)
+    for (int p = 0; p < NP; ++p)
       ca[p] = *reinterpret_cast<const bf16x8*>(img + p * PIECE + r * 32 + 8 * ((2 * ks + h) ^ rk));
   };
 
@@ -141,7 +140,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
     f32x16 accq = zq_frag;                           // dP_q = dZ_q + C dZ_v
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      split3(pq_raw[ks], pqB[ks]);
+      splitn<NP>(pq_raw[ks], pqB[ks]);
       f32x8 x;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -150,7 +149,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
         x[k] = lo;
         x[4 + k] = hi;
       }
-      split3(x, zqB[ks]);
+      splitn<NP>(x, zqB[ks]);
     }
     float dwacc = 0.f, dbacc = 0.f;                  // this lane's column sums over its rows: dw_v, db_v
     f32x16 ring[4];
@@ -174,7 +173,8 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
 #pragma unroll
       for (int m = 0; m < 12; ++m) {
         const int ks = m / 6, i = m % 6;
-        if (!SP || i == 5) cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks ? ca1[PA[i]] : ca0[PA[i]], pqB[ks][PB[i]], cur, 0, 0, 0);
+        const int k = slot_product<NP>(i);         // (width 2: an MFMA in every other slot)
+        if (k >= 0) cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks ? ca1[piece_a<NP>(k)] : ca0[piece_a<NP>(k)], pqB[ks][piece_b<NP>(k)], cur, 0, 0, 0);
         if (m == 1) read_ca(img, 1, ca1);           // operands are read one MFMA group ahead of their use
         if (m == 8) read_cq(imgp, 0, cq0);
         if (m == 11) {
@@ -182,8 +182,8 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
           for (int gg = 0; gg < 4; ++gg) dsn[gg] = *reinterpret_cast<const f32x4*>(&dsvs[32 * u + 8 * gg + 4 * h]);
         }
         if (m < 8) {                                 // split pair m of dZ_v(u-1)
-          unsigned hh, mm, ll;
-          split3_pair(dzp[2 * m], dzp[2 * m + 1], hh, mm, ll);
+          unsigned hh = 0, mm = 0, ll = 0;
+          split_pair<NP>(dzp[2 * m], dzp[2 * m + 1], hh, mm, ll);
           Ph[m >> 2][m & 3] = hh; Pm[m >> 2][m & 3] = mm; Pl[m >> 2][m & 3] = ll;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -197,9 +197,10 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
 #pragma unroll
       for (int m = 0; m < 12; ++m) {
         const int ks = m / 6, i = m % 6;
-        const bf16x8 bp = PB[i] == 0 ? __builtin_bit_cast(bf16x8, Ph[ks]) : PB[i] == 1 ? __builtin_bit_cast(bf16x8, Pm[ks])
-                                                                                        : __builtin_bit_cast(bf16x8, Pl[ks]);
-        if (!SP || i == 5) accq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks ? cq1[PA[i]] : cq0[PA[i]], bp, accq, 0, 0, 0);
+        const int k = slot_product<NP>(i), kk = k < 0 ? 0 : k;
+        const bf16x8 bp = piece_b<NP>(kk) == 0 ? __builtin_bit_cast(bf16x8, Ph[ks]) : piece_b<NP>(kk) == 1 ? __builtin_bit_cast(bf16x8, Pm[ks])
+                                                                                                          : __builtin_bit_cast(bf16x8, Pl[ks]);
+        if (k >= 0) accq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks ? cq1[piece_a<NP>(kk)] : cq0[piece_a<NP>(kk)], bp, accq, 0, 0, 0);
         if (m == 1) read_cq(imgp, 1, cq1);
         if (m == 9) read_ca(imgp, 0, ca0);
         if (m == 11) read_ca(imgp, 1, ca1);
@@ -209,7 +210,8 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
 #pragma unroll
       for (int m = 0; m < 12; ++m) {
         const int ks = m / 6, i = m % 6;
-        if (!SP || i == 5) dzp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks ? ca1[PA[i]] : ca0[PA[i]], zqB[ks][PB[i]], dzp, 0, 0, 0);
+        const int k = slot_product<NP>(i);
+        if (k >= 0) dzp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks ? ca1[piece_a<NP>(k)] : ca0[piece_a<NP>(k)], zqB[ks][piece_b<NP>(k)], dzp, 0, 0, 0);
         if (m < 8) dz_reg(8 + m);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -265,12 +267,12 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
       read_cq(imgp, 1, cq1);
       read_ca(imgp, 0, ca0);
       read_ca(imgp, 1, ca1);
-      split3(f32x8{dz[0], dz[1], dz[2], dz[3], dz[4], dz[5], dz[6], dz[7]}, b0);
-      split3(f32x8{dz[8], dz[9], dz[10], dz[11], dz[12], dz[13], dz[14], dz[15]}, b1);
-      accq = mfma32_x3<SP>(cq0, b0, accq);
-      accq = mfma32_x3<SP>(cq1, b1, accq);
-      dz = mfma32_x3<SP>(ca0, zqB[0], dz);
-      dz = mfma32_x3<SP>(ca1, zqB[1], dz);
+      splitn<NP>(f32x8{dz[0], dz[1], dz[2], dz[3], dz[4], dz[5], dz[6], dz[7]}, b0);
+      splitn<NP>(f32x8{dz[8], dz[9], dz[10], dz[11], dz[12], dz[13], dz[14], dz[15]}, b1);
+      accq = mfma32_xn<NP>(cq0, b0, accq);
+      accq = mfma32_xn<NP>(cq1, b1, accq);
+      dz = mfma32_xn<NP>(ca0, zqB[0], dz);
+      dz = mfma32_xn<NP>(ca1, zqB[1], dz);
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         float v = dz[g];
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
 //     dC += (P_q w_v) dZ_v^T.
 // The saved P_v, P_q carry the factor kPScale (fused.h): right for the exponential, divided out of the two dC operands.
 // Cross-wave sum per location tile through LDS in a fixed order; rows t >= T / n >= N: loads 0, stores dropped.
-template <int NT, int NW, bool SP>
+template <int NT, int NW, int NP>
 __global__ __launch_bounds__(NW * 64, 2) void bwd_dc32_kernel(const BwdArgs a) {
   constexpr int NPAD = 32 * NT, PIECE = NPAD * 32, NTHR = NW * 64, SLD = 36;
   constexpr int GT = NT > COATTN_DC_GT ? COATTN_DC_GT : NT;   // location tiles per group
@@ -354,16 +356,14 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc32_kernel(const BwdArgs a) {
       float c[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) c[i] = buf_load1(rs_c, cvoff, i * N * 4);
-      unsigned hh[2], mm[2], ll[2];
-      split3_pair(c[0], c[1], hh[0], mm[0], ll[0]);
-      split3_pair(c[2], c[3], hh[1], mm[1], ll[1]);
+      unsigned hh[2] = {0, 0}, mm[2] = {0, 0}, ll[2] = {0, 0};
+      split_pair<NP>(c[0], c[1], hh[0], mm[0], ll[0]);
+      split_pair<NP>(c[2], c[3], hh[1], mm[1], ll[1]);
       const int off = n * 32 + 8 * ((tq >> 1) ^ ((n >> 2) & 3)) + 4 * (tq & 1);
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
       *reinterpret_cast<u32x2*>(Cimg + off) = u32x2{hh[0], hh[1]};
-      if (!SP) {
-        *reinterpret_cast<u32x2*>(Cimg + PIECE + off) = u32x2{mm[0], mm[1]};
-        *reinterpret_cast<u32x2*>(Cimg + 2 * PIECE + off) = u32x2{ll[0], ll[1]};
-      }
+      if (NP >= 2) *reinterpret_cast<u32x2*>(Cimg + PIECE + off) = u32x2{mm[0], mm[1]};
+      if (NP == 3) *reinterpret_cast<u32x2*>(Cimg + 2 * PIECE + off) = u32x2{ll[0], ll[1]};
     }
     const float* dg = a.dsv + pair * (size_t)N;
     for (int e = tid; e < NPAD; e += NTHR) dsvs[e] = e < N ? dg[e] : 0.f;
@@ -373,12 +373,12 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc32_kernel(const BwdArgs a) {
   const int rk = (r >> 2) & 3;
   auto read_ca = [&](const short* img, const int ks, bf16x8 (&ca)[3]) {      // C^T rows: lane = location, 8 tokens
 #pragma unroll
-    for (int p = 0; p < (SP ? 1 : 3); ++p)
+    for (int p = 0; p < NP; ++p)
       ca[p] = *reinterpret_cast<const bf16x8*>(img + p * PIECE + r * 32 + 8 * ((2 * ks + h) ^ rk));
   };
   auto split16 = [&](const f32x16& x, bf16x8 (&p0)[3], bf16x8 (&p1)[3]) {
-    split3(f32x8{x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]}, p0);
-    split3(f32x8{x[8], x[9], x[10], x[11], x[12], x[13], x[14], x[15]}, p1);
+    splitn<NP>(f32x8{x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]}, p0);
+    splitn<NP>(f32x8{x[8], x[9], x[10], x[11], x[12], x[13], x[14], x[15]}, p1);
   };
   // the transposed fragment of tile nt, channels k0 ..: register 4 c + j <-> channel k0 + 8 c + 4 h + j = k0 + crow
   auto load_frag = [&](int nt, int k0, f32x16& x) {
@@ -419,15 +419,15 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc32_kernel(const BwdArgs a) {
           }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          split3(raw[ks], pqB[ks]);
+          splitn<NP>(raw[ks], pqB[ks]);
           f32x8 x, z;
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             x[i] = qa[ks][i >> 2][i & 3] * kInv * wa[ks][i >> 2][i & 3];
             z[i] = za[ks][i >> 2][i & 3] * kInv;
           }
-          split3(x, pqA[ks]);
-          split3(z, zqA[ks]);
+          splitn<NP>(x, pqA[ks]);
+          splitn<NP>(z, zqA[ks]);
         }
       }
       f32x16 cur, nxt, nx2;                          // two fragments in flight: nothing else hides their latency
@@ -444,9 +444,9 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc32_kernel(const BwdArgs a) {
         bf16x8 F0[3], F1[3], Z0[3], Z1[3], ca[3];
         split16(cur, F0, F1);
         read_ca(img, 0, ca);
-        cur = mfma32_x3<SP>(pqB[0], ca, cur);
+        cur = mfma32_xn<NP>(pqB[0], ca, cur);
         read_ca(img, 1, ca);
-        cur = mfma32_x3<SP>(pqB[1], ca, cur);
+        cur = mfma32_xn<NP>(pqB[1], ca, cur);
         const float ds4 = 4.0f * dsvs[32 * nt + r];
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
@@ -454,10 +454,10 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc32_kernel(const BwdArgs a) {
           cur[g] = fmaf(-rr, rr, rr) * ds4;
         }
         split16(cur, Z0, Z1);
-        dC[ti] = mfma32_x3<SP>(pqA[0], Z0, dC[ti]);
-        dC[ti] = mfma32_x3<SP>(pqA[1], Z1, dC[ti]);
-        dC[ti] = mfma32_x3<SP>(zqA[0], F0, dC[ti]);
-        dC[ti] = mfma32_x3<SP>(zqA[1], F1, dC[ti]);
+        dC[ti] = mfma32_xn<NP>(pqA[0], Z0, dC[ti]);
+        dC[ti] = mfma32_xn<NP>(pqA[1], Z1, dC[ti]);
+        dC[ti] = mfma32_xn<NP>(zqA[0], F0, dC[ti]);
+        dC[ti] = mfma32_xn<NP>(zqA[1], F1, dC[ti]);
       }
     }
     // ---- the group's tiles: cross-wave sum in a fixed order, dA = dC (1 - C^2)
@@ -494,12 +494,12 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc32_kernel(const BwdArgs a) {
   }
 }
 
-template <int NT, int NW, bool SP>
+template <int NT, int NW, int NP>
 int launch_dc32(const BwdArgs& a, hipStream_t s) {
   constexpr int NPAD = 32 * NT;
   const size_t lds = (size_t)3 * NPAD * 32 * 2 + (size_t)NPAD * 4 + (size_t)NW * 32 * 36 * 4;
   const int groups = (a.B + 7) / 8;
-  hipLaunchKernelGGL((bwd_dc32_kernel<NT, NW, SP>), dim3(groups * a.L * 8), dim3(NW * 64), lds, s, a);
+  hipLaunchKernelGGL((bwd_dc32_kernel<NT, NW, NP>), dim3(groups * a.L * 8), dim3(NW * 64), lds, s, a);
   CA_CHECK_LAUNCH("bwd_dc32");
   return 0;
 }
@@ -510,7 +510,7 @@ int launch_dc32(const BwdArgs& a, hipStream_t s) {
 // is split and used as the B operand (contraction over its row index = locations), the A operand is dA_l, split
 // once per workgroup into an LDS image [piece][t][n] whose n order inside every group of 16 is the accumulator row
 // order of a lane half (one 16-byte read per piece and k-step).
-template <int NT, bool LM, bool SP>
+template <int NT, bool LM, int NP>
 __global__ __launch_bounds__(256) void bwd_dq32_kernel(const DqArgs a) {
   constexpr int NPAD = 32 * NT;
   constexpr int LDR = NPAD + 8;                      // image row stride (bf16): 8 consecutive rows cover the banks once
@@ -562,16 +562,14 @@ __global__ __launch_bounds__(256) void bwd_dq32_kernel(const DqArgs a) {
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     const int e = tid + 256 * k, t = e / (NPAD / 2), n = 2 * (e - t * (NPAD / 2));
-    unsigned hh, mm, ll;
-    split3_pair(x0[k], x1[k], hh, mm, ll);
+    unsigned hh = 0, mm = 0, ll = 0;
+    split_pair<NP>(x0[k], x1[k], hh, mm, ll);
     const int m16 = n & 15;                          // n order inside a group of 16: bits 2 and 3 trade places
     const int off = t * LDR + (n & ~15) + ((m16 & 3) | ((m16 & 4) << 1) | ((m16 & 8) >> 1));
     if (t < kTRows) {                                // (the last sweep is partial)
       *reinterpret_cast<unsigned*>(img + off) = hh;
-      if (!SP) {
-        *reinterpret_cast<unsigned*>(img + PIECE + off) = mm;
-        *reinterpret_cast<unsigned*>(img + 2 * PIECE + off) = ll;
-      }
+      if (NP >= 2) *reinterpret_cast<unsigned*>(img + PIECE + off) = mm;
+      if (NP == 3) *reinterpret_cast<unsigned*>(img + 2 * PIECE + off) = ll;
     }
   }
   if (tid < 32) aqs[tid] = tid < T ? a.aq[pair * (size_t)T + tid] : 0.f;
@@ -582,14 +580,14 @@ __global__ __launch_bounds__(256) void bwd_dq32_kernel(const DqArgs a) {
   auto tile = [&](int nt, const f32x16& v) {
     bf16x8 b0[3], b1[3], a0[3], a1[3];
 #pragma unroll
-    for (int p = 0; p < (SP ? 1 : 3); ++p) {
+    for (int p = 0; p < NP; ++p) {
       a0[p] = *reinterpret_cast<const bf16x8*>(img + p * PIECE + r * LDR + 32 * nt + 8 * h);
       a1[p] = *reinterpret_cast<const bf16x8*>(img + p * PIECE + r * LDR + 32 * nt + 16 + 8 * h);
     }
-    split3(f32x8{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]}, b0);
-    split3(f32x8{v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]}, b1);
-    acc = mfma32_x3<SP>(a0, b0, acc);
-    acc = mfma32_x3<SP>(a1, b1, acc);
+    splitn<NP>(f32x8{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]}, b0);
+    splitn<NP>(f32x8{v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]}, b1);
+    acc = mfma32_xn<NP>(a0, b0, acc);
+    acc = mfma32_xn<NP>(a1, b1, acc);
   };
 #pragma unroll 1
   for (int nt = 0; nt < ntiles; nt += 4) {
@@ -618,7 +616,7 @@ __global__ __launch_bounds__(256) void bwd_dq32_kernel(const DqArgs a) {
 // dA images of the three levels together are 36 KB): the V fragments are loaded and split ONCE and serve the three
 // levels' MFMAs (the split is what bwd_dq32_kernel spends its issue slots on: 88 VALU per 12 MFMAs there, per 36 here),
 // and V is read once per sample instead of once per level.
-template <int NT, bool LM, bool SP>
+template <int NT, bool LM, int NP>
 __global__ __launch_bounds__(256) void bwd_dq32x_kernel(const DqArgs a) {
   static_assert(NT <= 2, "the images of all levels must fit the LDS of several workgroups per CU");
   constexpr int NPAD = 32 * NT;
@@ -666,16 +664,14 @@ __global__ __launch_bounds__(256) void bwd_dq32x_kernel(const DqArgs a) {
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
       const int e = tid + 256 * k, t = e / (NPAD / 2), n = 2 * (e - t * (NPAD / 2));
-      unsigned hh, mm, ll;
-      split3_pair(x0[l][k], x1[l][k], hh, mm, ll);
+      unsigned hh = 0, mm = 0, ll = 0;
+      split_pair<NP>(x0[l][k], x1[l][k], hh, mm, ll);
       const int m16 = n & 15;                        // n order inside a group of 16: bits 2 and 3 trade places
       const int off = l * LEVEL + t * LDR + (n & ~15) + ((m16 & 3) | ((m16 & 4) << 1) | ((m16 & 8) >> 1));
       if (t < kTRows) {
         *reinterpret_cast<unsigned*>(img + off) = hh;
-        if (!SP) {
-          *reinterpret_cast<unsigned*>(img + PIECE + off) = mm;
-          *reinterpret_cast<unsigned*>(img + 2 * PIECE + off) = ll;
-        }
+        if (NP >= 2) *reinterpret_cast<unsigned*>(img + PIECE + off) = mm;
+        if (NP == 3) *reinterpret_cast<unsigned*>(img + 2 * PIECE + off) = ll;
       }
     }
   if (tid < 32 * ML) {
@@ -691,18 +687,18 @@ __global__ __launch_bounds__(256) void bwd_dq32x_kernel(const DqArgs a) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     bf16x8 b0[3], b1[3];
-    split3(f32x8{vt[nt][0], vt[nt][1], vt[nt][2], vt[nt][3], vt[nt][4], vt[nt][5], vt[nt][6], vt[nt][7]}, b0);
-    split3(f32x8{vt[nt][8], vt[nt][9], vt[nt][10], vt[nt][11], vt[nt][12], vt[nt][13], vt[nt][14], vt[nt][15]}, b1);
+    splitn<NP>(f32x8{vt[nt][0], vt[nt][1], vt[nt][2], vt[nt][3], vt[nt][4], vt[nt][5], vt[nt][6], vt[nt][7]}, b0);
+    splitn<NP>(f32x8{vt[nt][8], vt[nt][9], vt[nt][10], vt[nt][11], vt[nt][12], vt[nt][13], vt[nt][14], vt[nt][15]}, b1);
 #pragma unroll
     for (int l = 0; l < ML; ++l) {
       bf16x8 a0[3], a1[3];
 #pragma unroll
-      for (int p = 0; p < (SP ? 1 : 3); ++p) {
+      for (int p = 0; p < NP; ++p) {
         a0[p] = *reinterpret_cast<const bf16x8*>(img + l * LEVEL + p * PIECE + r * LDR + 32 * nt + 8 * h);
         a1[p] = *reinterpret_cast<const bf16x8*>(img + l * LEVEL + p * PIECE + r * LDR + 32 * nt + 16 + 8 * h);
       }
-      acc[l] = mfma32_x3<SP>(a0, b0, acc[l]);
-      acc[l] = mfma32_x3<SP>(a1, b1, acc[l]);
+      acc[l] = mfma32_xn<NP>(a0, b0, acc[l]);
+      acc[l] = mfma32_xn<NP>(a1, b1, acc[l]);
     }
   }
   // dQ_l[b][t][c0 + r] (+)= acc_l + a_q,l[t] gq_l[c0 + r]; rows t >= T lie outside the buffer
@@ -724,31 +720,31 @@ __global__ __launch_bounds__(256) void bwd_dq32x_kernel(const DqArgs a) {
   }
 }
 
-template <int NT, bool LM, bool SP>
+template <int NT, bool LM, int NP>
 int launch_dq32x(const DqArgs& a, hipStream_t s) {
   constexpr int NPAD = 32 * NT;
   const size_t lds = (size_t)3 * ((3 * kTRows + 4) * (NPAD + 8) * 2) + 3 * 32 * 4;
-  hipLaunchKernelGGL((bwd_dq32x_kernel<NT, LM, SP>), dim3(a.B * (a.d / 128)), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((bwd_dq32x_kernel<NT, LM, NP>), dim3(a.B * (a.d / 128)), dim3(256), lds, s, a);
   CA_CHECK_LAUNCH("bwd_dq32x");
   return 0;
 }
 
-template <int NT, bool LM, bool SP>
+template <int NT, bool LM, int NP>
 int launch_dq32(const DqArgs& a, hipStream_t s) {
   constexpr int NPAD = 32 * NT;
   const size_t lds = (size_t)(3 * kTRows + 4) * (NPAD + 8) * 2 + 32 * 4;   // + 4 rows: what lanes 28 .. 31 of the last piece read
   const int items = a.B * (a.d / 128);
-  hipLaunchKernelGGL((bwd_dq32_kernel<NT, LM, SP>), dim3(((items + 7) / 8) * a.L * 8), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((bwd_dq32_kernel<NT, LM, NP>), dim3(((items + 7) / 8) * a.L * 8), dim3(256), lds, s, a);
   CA_CHECK_LAUNCH("bwd_dq32");
   return 0;
 }
 
-template <int NT, int NW, bool SP, bool DPB>
+template <int NT, int NW, int NP, bool DPB>
 int launch_nat32(const BwdArgs& a, hipStream_t s) {
   constexpr int NPAD = 32 * NT;
   const size_t lds = (size_t)3 * NPAD * 32 * 2 + (size_t)NPAD * 4;
   const int groups = (a.B + 7) / 8;
-  hipLaunchKernelGGL((bwd_nat32_kernel<NT, NW, SP, DPB>), dim3(groups * a.L * 8), dim3(NW * 64), lds, s, a);
+  hipLaunchKernelGGL((bwd_nat32_kernel<NT, NW, NP, DPB>), dim3(groups * a.L * 8), dim3(NW * 64), lds, s, a);
   CA_CHECK_LAUNCH("bwd_nat32");
   return 0;
 }
@@ -756,38 +752,42 @@ int launch_nat32(const BwdArgs& a, hipStream_t s) {
 }  // namespace
 
 // The reduced-precision mode (a.bf16: one MFMA per product) exists for the four-wave kernels (d % 512 == 0); other widths
-// keep the exact split.
+// run the fp32 mode.  a.np = 2 selects the two-piece width of the fp32 mode (fused.h), anything else the exact split.
 int launch_bwd_nat32(const BwdArgs& a, hipStream_t s) {
-  const bool small_n = a.N <= 64;
+  const bool small_n = a.N <= 64, w2 = a.np == 2;
   if (a.d % 512 == 0) {
-    if (a.bf16 && a.dp_bf16) return small_n ? launch_nat32<2, 4, true, true>(a, s) : launch_nat32<7, 4, true, true>(a, s);
+    if (a.bf16 && a.dp_bf16) return small_n ? launch_nat32<2, 4, 1, true>(a, s) : launch_nat32<7, 4, 1, true>(a, s);
     CA_CHECK_ARG(!a.dp_bf16, "bwd_nat32: bf16 dP storage exists in the reduced-precision mode only");
-    if (a.bf16) return small_n ? launch_nat32<2, 4, true, false>(a, s) : launch_nat32<7, 4, true, false>(a, s);
-    return small_n ? launch_nat32<2, 4, false, false>(a, s) : launch_nat32<7, 4, false, false>(a, s);
+    if (a.bf16) return small_n ? launch_nat32<2, 4, 1, false>(a, s) : launch_nat32<7, 4, 1, false>(a, s);
+    if (w2) return small_n ? launch_nat32<2, 4, 2, false>(a, s) : launch_nat32<7, 4, 2, false>(a, s);
+    return small_n ? launch_nat32<2, 4, 3, false>(a, s) : launch_nat32<7, 4, 3, false>(a, s);
   }
   CA_CHECK_ARG(!a.dp_bf16, "bwd_nat32: bf16 dP storage needs d % 512 == 0");
-  return small_n ? launch_nat32<2, 2, false, false>(a, s) : launch_nat32<7, 2, false, false>(a, s);
+  if (w2) return small_n ? launch_nat32<2, 2, 2, false>(a, s) : launch_nat32<7, 2, 2, false>(a, s);
+  return small_n ? launch_nat32<2, 2, 3, false>(a, s) : launch_nat32<7, 2, 3, false>(a, s);
 }
 
 int launch_bwd_dq32(const DqArgs& a, int lm, hipStream_t s) {
   static const int shared = [] { const char* e = getenv("COATTN_DQ32X"); return e ? atoi(e) : 1; }();   // developer switch
-  if (a.N <= 64 && a.L <= 3 && shared) {
-    if (a.bf16) return lm ? launch_dq32x<2, true, true>(a, s) : launch_dq32x<2, false, true>(a, s);
-    return lm ? launch_dq32x<2, true, false>(a, s) : launch_dq32x<2, false, false>(a, s);
-  }
-  if (a.bf16) {
-    if (lm) return a.N <= 64 ? launch_dq32<2, true, true>(a, s) : launch_dq32<7, true, true>(a, s);
-    return a.N <= 64 ? launch_dq32<2, false, true>(a, s) : launch_dq32<7, false, true>(a, s);
-  }
-  if (lm) return a.N <= 64 ? launch_dq32<2, true, false>(a, s) : launch_dq32<7, true, false>(a, s);
-  return a.N <= 64 ? launch_dq32<2, false, false>(a, s) : launch_dq32<7, false, false>(a, s);
+  const int np = a.bf16 ? 1 : (a.np == 2 ? 2 : 3);
+  auto go = [&](auto NPc) -> int {
+    constexpr int NP = decltype(NPc)::value;
+    if (a.N <= 64 && a.L <= 3 && shared) return lm ? launch_dq32x<2, true, NP>(a, s) : launch_dq32x<2, false, NP>(a, s);
+    if (lm) return a.N <= 64 ? launch_dq32<2, true, NP>(a, s) : launch_dq32<7, true, NP>(a, s);
+    return a.N <= 64 ? launch_dq32<2, false, NP>(a, s) : launch_dq32<7, false, NP>(a, s);
+  };
+  if (np == 1) return go(std::integral_constant<int, 1>());
+  if (np == 2) return go(std::integral_constant<int, 2>());
+  return go(std::integral_constant<int, 3>());
 }
 
 int launch_bwd_dc32(const BwdArgs& a, hipStream_t s) {
-  const bool small_n = a.N <= 64;
+  const bool small_n = a.N <= 64, w2 = a.np == 2;
   if (a.d % 512 == 0) {
-    if (a.bf16) return small_n ? launch_dc32<2, 4, true>(a, s) : launch_dc32<7, 4, true>(a, s);
-    return small_n ? launch_dc32<2, 4, false>(a, s) : launch_dc32<7, 4, false>(a, s);
+    if (a.bf16) return small_n ? launch_dc32<2, 4, 1>(a, s) : launch_dc32<7, 4, 1>(a, s);
+    if (w2) return small_n ? launch_dc32<2, 4, 2>(a, s) : launch_dc32<7, 4, 2>(a, s);
+    return small_n ? launch_dc32<2, 4, 3>(a, s) : launch_dc32<7, 4, 3>(a, s);
   }
-  return small_n ? launch_dc32<2, 2, false>(a, s) : launch_dc32<7, 2, false>(a, s);
+  if (w2) return small_n ? launch_dc32<2, 2, 2>(a, s) : launch_dc32<7, 2, 2>(a, s);
+  return small_n ? launch_dc32<2, 2, 3>(a, s) : launch_dc32<7, 2, 3>(a, s);
 }

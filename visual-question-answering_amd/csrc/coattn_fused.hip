@@ -57,7 +57,7 @@ int fused_supported(int B, int N, int T, int d, int L) {
 
 int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, const VLayout& vl,
                             const float* const* Q, const coattn_params* p, float* v_out, float* q_out, float* saved,
-                            float* ws, hipStream_t s, int bf16) {
+                            float* ws, hipStream_t s, int bf16, int np) {
   CA_CHECK_ARG(fused_supported(B, N, T, d, L), "fused forward: unsupported shape");
   const bool lm = v_is_lm(vl, N, d);
   CA_CHECK_ARG(lm || v_is_cm(vl, N, d), "fused forward: image features must be channel-major [B,d,N] or location-major [B,N,d]");
@@ -72,6 +72,7 @@ int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, c
   a.stamps = COATTN_STAMPS ? reinterpret_cast<unsigned long long*>(ws) : nullptr;
   a.B = B; a.N = N; a.T = T; a.d = d; a.L = L;
   a.bf16 = bf16;
+  a.np = (np == 2 && !bf16) ? 2 : 3;
   CA_TRY(fused32_forward(a, s));
   if (lm) return launch_attend_v_lm(V, vl.sB, a.av, v_out, B, N, d, L, s);
   dim3 grid(d / 64, B);

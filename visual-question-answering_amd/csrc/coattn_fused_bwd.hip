@@ -330,7 +330,10 @@ int fused_backward_supported(int B, int N, int T, int d, int L) { return fused_s
 int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLayout& vl, const float* const* Q,
                    const coattn_params* p, const float* saved, const float* gv, const float* gq, float* dV,
                    const VLayout& dvl, float* const* dQ, const coattn_param_grads* pg, int accumulate, float* ws,
-                   hipStream_t s, int bf16_proj, int wgemm) {
+                   hipStream_t s, int bf16_proj, int wgemm, int np) {
+  // np: width of the fp32 mode's contractions (fused.h): 2 = hi + mid in the three fused kernels and in the GEMM launch
+  // (dW_v, dW_q, dQ = dP_q W_q), 3 = the exact split everywhere; dV (general GEMM) is always exact
+  np = (np == 2 && !bf16_proj) ? 2 : 3;
   CA_CHECK_ARG(fused_backward_supported(B, N, T, d, L), "fused backward: unsupported shape");
   const bool lm = v_is_lm(vl, N, d);
   CA_CHECK_ARG(lm || v_is_cm(vl, N, d), "fused backward: image features must be channel-major [B,d,N] or location-major [B,N,d]");
@@ -361,6 +364,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   ba.dbv_part = ws + wo.dbv_part; ba.dbq_part = ws + wo.dbq_part;
   ba.B = B; ba.N = N; ba.T = T; ba.d = d; ba.L = L;
   ba.bf16 = bf16_proj;
+  ba.np = np;
   ba.dp_bf16 = 0;
   CA_TRY(launch_bwd_dc32(ba, s));                    // dC, dA                       (coattn_bwd32.hip)
   // which of the backward's GEMMs take the hand-scheduled kernels (decided here: when all three do, they share ONE
@@ -370,7 +374,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   TnGemm tnv = {};
   tnv.A = dPv; tnv.a_ld = d; tnv.B = V; tnv.b_ld = (int)vl.sN; tnv.C = part; tnv.M = d; tnv.N = d; tnv.K = B * N; tnv.levels = 1;
   bool tn_v = false;
-  tnv.bf16 = bf16_proj;
+  tnv.bf16 = bf16_proj; tnv.np = np;
   if (wgemm && lm && vl.sB == (long)N * vl.sN && vl.sN < (1L << 24)) {
     tn_v = gemm_tn_supported(tnv) != 0;              // location-major rows, samples abutting
   } else if (wgemm && !lm && vl.sD < (1L << 24)) {
@@ -380,7 +384,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   TnGemm tnq = {};
   tnq.A = ws + wo.dPq; tnq.a_sl = (long)BTd; tnq.a_ld = d; tnq.b_ld = d; tnq.M = d; tnq.N = d; tnq.K = B * T; tnq.levels = L;
   for (int l = 0; l < L; ++l) tnq.b_ptrs[l] = Q[l];
-  tnq.bf16 = bf16_proj;
+  tnq.bf16 = bf16_proj; tnq.np = np;
   const bool tn_q = wgemm && gemm_tn_supported(tnq);       // levels as extra split-K parts (gemm_tn.hip)
   const bool dq32 = lm || (N % 4) == 0;              // the bf16 dA V kernel takes both layouts (channel-major: aligned rows)
   WGemm wdq = {};                                    // dQ_l = dP_q,l W_q against the W_q image the forward left in `saved`
@@ -390,7 +394,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   // (exactly the forward's test for writing that image, api.hip general_projections: same shape, and its A rows were Q_l)
   bool q_al = true;
   for (int l = 0; l < L; ++l) q_al = q_al && (((uintptr_t)Q[l]) & 15) == 0;
-  wdq.bf16 = bf16_proj;
+  wdq.bf16 = bf16_proj; wdq.np = np;
   const bool wdq_ok = wgemm && q_al && gemm_w_supported(wdq);
   // (a dQ projection on gemm_bf.hip -- 512-thread workgroups -- cannot ride in the weight-gradient launch)
   const bool combine = dq32 && wdq_ok && tn_v && tn_q && !gemm_bf_supported(wdq);
@@ -452,7 +456,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     da.V = V; da.v_sB = vl.sB; da.dA = ws + wo.dA; da.aq = saved + so.aq; da.gq = gq;
     for (int l = 0; l < 8; ++l) da.dQ[l] = l < L ? dQ[l] : nullptr;
     da.B = B; da.N = N; da.T = T; da.d = d; da.L = L;
-    da.bf16 = bf16_proj;
+    da.bf16 = bf16_proj; da.np = np;
     const bool al = (N % 4) == 0;
     dim3 grid(d / 128, B), block(256);
     if (dq32) {

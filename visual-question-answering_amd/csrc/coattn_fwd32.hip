@@ -59,10 +59,14 @@ __device__ __forceinline__ void vmcnt_wait(int n) {
 }
 
 
-// SP (single product): the reduced-precision mode (COATTN_FLAG_BF16_PROJ) -- every operand rounded once to bf16, ONE MFMA per product
-// (the hi x hi term of the split; the mid / lo pieces are neither computed, stored in the LDS image nor read back).
-template <int NT, int NW, bool LM, bool SP>
+// NP: width of the phase-2 contractions C^T P_q, C P_v (fused.h: 3 = the exact split, 2 = hi + mid).  The affinity of
+// phase 1 always keeps the exact split in the fp32 mode: it is the one contraction whose error the tanh amplifies.
+// NP = 1 (SP, single product): the reduced-precision mode (COATTN_FLAG_BF16_PROJ) -- every operand of BOTH phases rounded once
+// to bf16, ONE MFMA per product (the hi x hi term of the split; the mid / lo pieces are neither computed, stored in the
+// LDS image nor read back).
+template <int NT, int NW, bool LM, int NP>
 __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs a) {
+  constexpr bool SP = NP == 1;
   constexpr int NPAD = 32 * NT;
   constexpr int SLD = 36;                            // row stride of the f32 reduction slots [n][t = 32]: 16-byte accesses
   constexpr int SLOT_FLOATS = NPAD * SLD;            //   of 8 consecutive rows cover the 32 banks once
@@ -410,16 +414,14 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
         c[i] = in ? th : 0.f;
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, th), rs_c, cvoff, i * N * 4, 0);
       }
-      unsigned hh[2], mm[2], ll[2];
-      split3_pair(c[0], c[1], hh[0], mm[0], ll[0]);
-      split3_pair(c[2], c[3], hh[1], mm[1], ll[1]);
+      unsigned hh[2] = {0, 0}, mm[2] = {0, 0}, ll[2] = {0, 0};
+      split_pair<NP>(c[0], c[1], hh[0], mm[0], ll[0]);
+      split_pair<NP>(c[2], c[3], hh[1], mm[1], ll[1]);
       const int off = n * 32 + 8 * ((tq >> 1) ^ ((n >> 2) & 3)) + 4 * (tq & 1);
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
       *reinterpret_cast<u32x2*>(Cimg + off) = u32x2{hh[0], hh[1]};
-      if (!SP) {
-        *reinterpret_cast<u32x2*>(Cimg + PIECE + off) = u32x2{mm[0], mm[1]};
-        *reinterpret_cast<u32x2*>(Cimg + 2 * PIECE + off) = u32x2{ll[0], ll[1]};
-      }
+      if (NP >= 2) *reinterpret_cast<u32x2*>(Cimg + PIECE + off) = u32x2{mm[0], mm[1]};
+      if (NP == 3) *reinterpret_cast<u32x2*>(Cimg + 2 * PIECE + off) = u32x2{ll[0], ll[1]};
     }
   }
   lds_barrier();
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
           x[k] = lo;
           x[4 + k] = hi;
         }
-        split3(x, pqB[ct][ks]);
+        splitn<NP>(x, pqB[ct][ks]);
       }
     }
   };
@@ -494,11 +496,11 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
       auto split_half = [&](const f32x16& pv, const int s2, bf16x8 (&pb)[3]) {
         const f32x8 x = f32x8{pv[8 * s2], pv[8 * s2 + 1], pv[8 * s2 + 2], pv[8 * s2 + 3],
                               pv[8 * s2 + 4], pv[8 * s2 + 5], pv[8 * s2 + 6], pv[8 * s2 + 7]};
-        split3(x, pb);
+        splitn<NP>(x, pb);
       };
       auto read_cq = [&](const short* img, const int s2, bf16x8 (&cq)[3]) {     // A = C (tokens x locations)
 #pragma unroll
-        for (int p = 0; p < (SP ? 1 : 3); ++p) {
+        for (int p = 0; p < NP; ++p) {
           const bf16x4 lo = lds_tr16(img + p * PIECE + 16 * s2 * 32 + tr_off0);
           const bf16x4 hi = lds_tr16(img + p * PIECE + 16 * s2 * 32 + tr_off1);
           cq[p] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
       };
       auto read_ca = [&](const short* img, const int ks, bf16x8 (&ca)[3]) {      // A = C^T (locations x tokens)
 #pragma unroll
-        for (int p = 0; p < (SP ? 1 : 3); ++p)
+        for (int p = 0; p < NP; ++p)
           ca[p] = *reinterpret_cast<const bf16x8*>(img + p * PIECE + r * 32 + 8 * ((2 * ks + h) ^ rk));
       };
       auto store_scores = [&](int u, float mine) {   // u: the finished unit (second channel half of tile u >> 1)
@@ -522,7 +524,6 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
       // work when left alone (a lone wave then pays both in series), so every (MFMA, chunk) pair is fenced.
       // Piece products of the exact split, smallest first: a0 b2, a2 b0, a1 b1, a0 b1, a1 b0, a0 b0.
       auto unit = [&](int u, const int ct, f32x16& cur, const f32x16& prev, const f32x16& next) {
-        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
         const short* img = Cimg + 32 * (u >> 1) * 32;
         bf16x8 cq0[3], cq1[3], ca0[3], ca1[3];       // A operands, read one MFMA group ahead of their use
         u32x4 h1, m1, l1, h0, m0, l0;                // pieces of pb1 (this unit, k-step 1) / the next unit's pb0
@@ -531,23 +532,24 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
 #pragma unroll
         for (int m = 0; m < 24; ++m) {
           // ---- the MFMA
-          const int grp = SP && (m % 6) != 5 ? -1 : m / 6, i = m % 6;
-          if (grp == 0) accq[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cq0[PA[i]], pb0[PB[i]], accq[ct], 0, 0, 0);
+          // (slot m % 6 of a group of six: every slot at width 3, every other one at width 2, the last at width 1)
+          const int kp = slot_product<NP>(m % 6), grp = kp < 0 ? -1 : m / 6, pa = piece_a<NP>(kp < 0 ? 0 : kp), pb = piece_b<NP>(kp < 0 ? 0 : kp);
+          if (grp == 0) accq[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cq0[pa], pb0[pb], accq[ct], 0, 0, 0);
           if (grp == 1) {
-            const bf16x8 b = PB[i] == 0 ? __builtin_bit_cast(bf16x8, h1) : PB[i] == 1 ? __builtin_bit_cast(bf16x8, m1)
-                                                                                      : __builtin_bit_cast(bf16x8, l1);
-            accq[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cq1[PA[i]], b, accq[ct], 0, 0, 0);
+            const bf16x8 b = pb == 0 ? __builtin_bit_cast(bf16x8, h1) : pb == 1 ? __builtin_bit_cast(bf16x8, m1)
+                                                                                : __builtin_bit_cast(bf16x8, l1);
+            accq[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cq1[pa], b, accq[ct], 0, 0, 0);
           }
-          if (grp == 2) cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca0[PA[i]], pqB[ct][0][PB[i]], cur, 0, 0, 0);
-          if (grp == 3) cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca1[PA[i]], pqB[ct][1][PB[i]], cur, 0, 0, 0);
+          if (grp == 2) cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca0[pa], pqB[ct][0][pb], cur, 0, 0, 0);
+          if (grp == 3) cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca1[pa], pqB[ct][1][pb], cur, 0, 0, 0);
           // ---- the next group's A operands
           if (m == 1) read_cq(img, 1, cq1);
           if (m == 7) read_ca(img, 0, ca0);
           if (m == 13) read_ca(img, 1, ca1);
           // ---- its VALU chunk
           if (m < 4) {                               // split pair m of this unit's second k-step (registers 8 .. 15)
-            unsigned hh, mm, ll;
-            split3_pair(cur[8 + 2 * m], cur[8 + 2 * m + 1], hh, mm, ll);
+            unsigned hh = 0, mm = 0, ll = 0;
+            split_pair<NP>(cur[8 + 2 * m], cur[8 + 2 * m + 1], hh, mm, ll);
             h1[m] = hh; m1[m] = mm; l1[m] = ll;
           }
           if (m >= 4 && m < 20) {                    // register g = m - 4 of unit u-1: its score term
@@ -564,8 +566,8 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
             if (m == 23) { w2[1] = bfly_c(z[1], z[3], lane); mine = bfly_d(w2[0], w2[1], lane); }
           }
           if (m >= 20) {                             // split pair m - 20 of the next unit's first k-step
-            unsigned hh, mm, ll;
-            split3_pair(next[2 * (m - 20)], next[2 * (m - 20) + 1], hh, mm, ll);
+            unsigned hh = 0, mm = 0, ll = 0;
+            split_pair<NP>(next[2 * (m - 20)], next[2 * (m - 20) + 1], hh, mm, ll);
             h0[m - 20] = hh; m0[m - 20] = mm; l0[m - 20] = ll;
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -789,7 +791,7 @@ __global__ __launch_bounds__(256) void attend_v_lm_kernel(const float* V, long v
   }
 }
 
-template <int NT, int NW, bool LM, bool SP>
+template <int NT, int NW, bool LM, int NP>
 int launch_fwd32(const FwdArgs& a, hipStream_t s) {
   constexpr int NPAD = 32 * NT;
   constexpr int RING_SLOTS = (NT + 1) * ((NT + 1 >= 6) ? 1 : 2);
@@ -797,12 +799,12 @@ int launch_fwd32(const FwdArgs& a, hipStream_t s) {
   const size_t lds = lds_p2 > lds_p1 ? lds_p2 : lds_p1;
   static DeviceOnce once;                            // the attribute is per device
   CA_TRY(once.run([&] {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(coattn_fwd32_kernel<NT, NW, LM, SP>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(coattn_fwd32_kernel<NT, NW, LM, NP>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }, "coattn_fwd32"));
   const int groups = (a.B + 7) / 8;
   dim3 grid(groups * a.L * 8), block(NW * 64);
-  hipLaunchKernelGGL((coattn_fwd32_kernel<NT, NW, LM, SP>), grid, block, lds, s, a);
+  hipLaunchKernelGGL((coattn_fwd32_kernel<NT, NW, LM, NP>), grid, block, lds, s, a);
   CA_CHECK_LAUNCH("coattn_fwd32");
   return 0;
 }
@@ -810,11 +812,14 @@ int launch_fwd32(const FwdArgs& a, hipStream_t s) {
 template <bool LM>
 int dispatch_fwd32(const FwdArgs& a, hipStream_t s) {
   const bool small_n = a.N <= 64;
+  const bool w2 = a.np == 2;                         // phase 2 on two pieces
   if (a.d % 512 == 0) {
-    if (a.bf16) return small_n ? launch_fwd32<2, 4, LM, true>(a, s) : launch_fwd32<7, 4, LM, true>(a, s);
-    return small_n ? launch_fwd32<2, 4, LM, false>(a, s) : launch_fwd32<7, 4, LM, false>(a, s);
+    if (a.bf16) return small_n ? launch_fwd32<2, 4, LM, 1>(a, s) : launch_fwd32<7, 4, LM, 1>(a, s);
+    if (w2) return small_n ? launch_fwd32<2, 4, LM, 2>(a, s) : launch_fwd32<7, 4, LM, 2>(a, s);
+    return small_n ? launch_fwd32<2, 4, LM, 3>(a, s) : launch_fwd32<7, 4, LM, 3>(a, s);
   }
-  return small_n ? launch_fwd32<2, 2, LM, false>(a, s) : launch_fwd32<7, 2, LM, false>(a, s);   // (exact at these widths)
+  if (w2) return small_n ? launch_fwd32<2, 2, LM, 2>(a, s) : launch_fwd32<7, 2, LM, 2>(a, s);
+  return small_n ? launch_fwd32<2, 2, LM, 3>(a, s) : launch_fwd32<7, 2, LM, 3>(a, s);   // (the fp32 mode at these widths)
 }
 
 }  // namespace

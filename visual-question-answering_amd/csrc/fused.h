@@ -17,12 +17,12 @@ inline bool fused_layout_ok(const VLayout& v, int N, int d) { return v_is_lm(v, 
 // everything after the projections (P_v, P_q already in `saved`)
 int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, const VLayout& vl,
                             const float* const* Q, const coattn_params* p, float* v_out, float* q_out, float* saved,
-                            float* ws, hipStream_t s, int bf16 = 0);   // bf16: reduced precision, one MFMA per product
+                            float* ws, hipStream_t s, int bf16 = 0, int np = 3);   // bf16: reduced precision, one MFMA per product; np: width of phase 2
 int fused_backward_supported(int B, int N, int T, int d, int L);
 int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLayout& vl, const float* const* Q,
                    const coattn_params* p, const float* saved, const float* gv, const float* gq, float* dV,
                    const VLayout& dvl, float* const* dQ, const coattn_param_grads* pg, int accumulate, float* ws,
-                   hipStream_t s, int bf16_proj, int wgemm);   // wgemm: gemm_w / gemm_tn enabled
+                   hipStream_t s, int bf16_proj, int wgemm, int np = 3);   // wgemm: gemm_w / gemm_tn enabled; np: width of the contractions (3 | 2)
 
 // Diagnostic build only (tools/probe_stamps.py, -DCOATTN_STAMPS=1): wave 0 of every workgroup writes the
 // 100 MHz constant clock at its phase boundaries into the (otherwise unused) forward workspace tail.
@@ -97,18 +97,59 @@ __device__ __forceinline__ void split3(const f32x8& v, bf16x8 (&p)[3]) {
   p[1] = __builtin_bit_cast(bf16x8, m);
   p[2] = __builtin_bit_cast(bf16x8, l);
 }
-// c += a . b over 16 k (32x32x16) with fp32 accuracy: the six partial products down to relative order 2^-16
-// (each bf16 x bf16 product is exact in the fp32 accumulator), smallest terms first
-// (SP, the reduced-precision mode: the hi x hi product alone -- the other pieces are dead code)
-template <bool SP = false>
-__device__ __forceinline__ f32x16 mfma32_x3(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c) {
-  if constexpr (SP) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+// The width of a contraction = bf16 pieces kept per operand (NP):
+//   3  the exact split: six partial products down to relative order 2^-16, fp32-accurate (the affinity A = Q V^T);
+//   2  hi + mid: 16 significand bits per operand, the three products hi*mid, mid*hi, hi*hi (~2^-16 relative per product,
+//      random in sign over a contraction) -- every contraction whose error the path does not amplify: 6 VALU operations
+//      per pair instead of 11, half the MFMAs (budget: tests/test_split_emulation.py);
+//   1  the reduced-precision mode (COATTN_FLAG_BF16_PROJ): the hi x hi product alone.
+// Pieces that a width does not use are neither computed, stored nor read.
+template <int NP>
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+  static_assert(NP >= 1 && NP <= 3, "pieces per operand");
+  if constexpr (NP == 3) { split3_pair(a, b, h, m, l); return; }
+  h = cvt_pk_bf16(a, b);
+  if constexpr (NP == 2) {
+    const float ra = sub1(a, __builtin_bit_cast(float, h << 16));
+    const float rb = sub1(b, __builtin_bit_cast(float, h & 0xffff0000u));
+    m = cvt_pk_bf16(ra, rb);
+  }
+}
+template <int NP>
+__device__ __forceinline__ void splitn(const f32x8& v, bf16x8 (&p)[3]) {
+  u32x4 h, m, l;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned hh = 0, mm = 0, ll = 0;
+    split_pair<NP>(v[2 * i], v[2 * i + 1], hh, mm, ll);
+    h[i] = hh; m[i] = mm; l[i] = ll;
+  }
+  p[0] = __builtin_bit_cast(bf16x8, h);
+  if constexpr (NP >= 2) p[1] = __builtin_bit_cast(bf16x8, m);
+  if constexpr (NP == 3) p[2] = __builtin_bit_cast(bf16x8, l);
+}
+// partial products of a width in the order they are issued (smallest first)
+template <int NP> __device__ __forceinline__ constexpr int n_products() { return NP == 3 ? 6 : NP == 2 ? 3 : 1; }
+template <int NP> __device__ __forceinline__ constexpr int piece_a(int k) {      // A-operand piece of product k
+  constexpr int A3[6] = {0, 2, 1, 0, 1, 0}, A2[3] = {0, 1, 0};
+  return NP == 3 ? A3[k] : NP == 2 ? A2[k] : 0;
+}
+template <int NP> __device__ __forceinline__ constexpr int piece_b(int k) {      // B-operand piece of product k
+  constexpr int B3[6] = {2, 0, 1, 1, 0, 0}, B2[3] = {1, 0, 0};
+  return NP == 3 ? B3[k] : NP == 2 ? B2[k] : 0;
+}
+// Slot i (0 .. 5) of a six-slot MFMA group under width NP: the index of the product issued there, or -1.
+// NP = 3: every slot; NP = 2: slots 1, 3, 5 (the VALU chunks of the empty slots keep their places); NP = 1: slot 5.
+template <int NP>
+__device__ __forceinline__ constexpr int slot_product(int i) {
+  return NP == 3 ? i : NP == 2 ? ((i & 1) ? i >> 1 : -1) : (i == 5 ? 0 : -1);
+}
+// c += a . b over 16 k (32x32x16) at width NP (each bf16 x bf16 product is exact in the fp32 accumulator)
+template <int NP>
+__device__ __forceinline__ f32x16 mfma32_xn(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c) {
+#pragma unroll
+  for (int k = 0; k < n_products<NP>(); ++k)
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[piece_a<NP>(k)], b[piece_b<NP>(k)], c, 0, 0, 0);
   return c;
 }
 
@@ -142,6 +183,7 @@ struct WGemm {
   const float* bias_n; float out_scale;
   int M, N, K, batch;
   int bf16;                                                          // 1: operands rounded to bf16, ONE MFMA per product (COATTN_FLAG_BF16_PROJ)
+  int np;                                                            // (bf16 = 0) bf16 pieces per operand: 0 / 3 = the exact split (six products), 2 = hi + mid (three products)
   int a_bf16;                                                        // (gemm_bf_kernel) A is STORED as bf16; a_sm, a_sz stay in elements
 };
 size_t wsplit_bytes(int N, int K);
@@ -173,6 +215,7 @@ struct TnGemm {
   int mask_blk; unsigned tile_mask;                                  // mask_blk > 0: tile (mt, nt) is computed only if bit
                                                                      // (mt / mask_blk) * 3 + nt / mask_blk of tile_mask is set
   int bf16;                                                          // 1: operands rounded to bf16, ONE MFMA per product
+  int np;                                                            // (bf16 = 0) bf16 pieces per operand: 0 / 3 = the exact split, 2 = hi + mid (three products)
   int a_bf16;                                                        // (gemm_bf_tn_kernel) A is STORED as bf16; a_ld, a_sl, a_term in elements
 };
 int gemm_tn_supported(const TnGemm& d);
@@ -234,6 +277,7 @@ struct FwdArgs {
   unsigned long long* stamps;   // diagnostic builds only
   int B, N, T, d, L;
   int bf16;              // reduced-precision mode: operands rounded to bf16, one MFMA per product (d % 512 == 0)
+  int np;                // (bf16 = 0) width of the phase-2 contractions C^T P_q, C P_v: 3 or 2 pieces (the affinity: always 3)
 };
 
 // arguments of the two big fused backward kernels (coattn_fused_bwd.hip, coattn_bwd32.hip)
@@ -252,6 +296,7 @@ struct BwdArgs {
   float* dbq_part;        // [L*B][d]   sum_t dP_q[t][:]
   int B, N, T, d, L;
   int bf16;               // reduced-precision mode: one MFMA per product (d % 512 == 0)
+  int np;                 // (bf16 = 0) width of the contractions: 3 or 2 pieces
   int dp_bf16;            // (with bf16, bwd_nat32_kernel) dPv / dPq are bf16 arrays of the same index order
 };
 
@@ -267,6 +312,7 @@ struct DqArgs {
   int B, N, T, d, L;
   int accumulate;        // bwd_dq32_kernel: add onto dQ (which then already holds dP_q W_q) instead of overwriting it
   int bf16;              // reduced-precision mode: one MFMA per product
+  int np;                // (bf16 = 0) width of the contraction: 3 or 2 pieces
 };
 // dQ_l = a_q (x) gq + dA_l V on the bf16 MFMA with the exact 3-way split: location-major V (lm), or channel-major V
 // whose rows are 16-byte multiples (N % 4 == 0)

@@ -55,9 +55,12 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // Up to two jobs per launch (dW_v and dW_q): the second one's workgroups fill the slots the first leaves idle.
 // BCM: the B operand is contiguous along k inside groups of b_kdiv rows (channel-major image features [B, d, N]:
 // k = (sample, location), n = channel): float4 = 4 consecutive k of one column, [col][k] images, ds_read_b128.
-// P1: reduced-precision mode (gemm_w_body.h): the hi pieces alone, one MFMA per product.
-template <bool SUM3, bool BCM, bool P1>
+// NP: bf16 pieces per operand (gemm_w_body.h) -- 3: the exact split, six products; 2: hi + mid, three products (every other
+// slot of the step carries an MFMA); 1: reduced-precision mode, the hi pieces alone, one MFMA per product.
+template <bool SUM3, bool BCM, int NP>
 __device__ __forceinline__ void gemm_tn_body(const TnArgs& g, const int bid, const int nblk, short* const lds) {
+  static_assert(NP >= 1 && NP <= 3, "pieces per operand");
+  constexpr bool P1 = NP == 1;
   constexpr int BUF = OPER + (BCM ? OPERB : OPER);                         // elements of one LDS buffer
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
@@ -148,14 +151,15 @@ __device__ __forceinline__ void gemm_tn_body(const TnArgs& g, const int bid, con
     } else if (P1) {
     } else if (st == 1) {
       pm[e] = cvt_pk_bf16(ra[e], rb[e]);
+      if (NP == 2) return;
       ra[e] = sub1(ra[e], __builtin_bit_cast(float, pm[e] << 16));
       rb[e] = sub1(rb[e], __builtin_bit_cast(float, pm[e] & 0xffff0000u));
-    } else {
+    } else if (NP == 3) {
       pl[e] = cvt_pk_bf16(ra[e], rb[e]);
     }
   };
   auto write_piece = [&](short* buf, int x, int q) {
-    if (P1 && q != 0) return;
+    if (q >= NP) return;
     const u32x2 v = q == 0 ? u32x2{ph[0], ph[1]} : (q == 1 ? u32x2{pm[0], pm[1]} : u32x2{pl[0], pl[1]});
     if (BCM && x >= 2) *reinterpret_cast<u32x2*>(&buf[q * IMGB + (x & 1) * 64 * LDRB + bc_st]) = v;
     else *reinterpret_cast<u32x2*>(&buf[(x >> 1) * OPER + q * IMG + (x & 1) * 8 * LDT + st_off]) = v;
@@ -165,7 +169,7 @@ __device__ __forceinline__ void gemm_tn_body(const TnArgs& g, const int bid, con
     constexpr int SET = decltype(SETc)::value;
     constexpr int QA[3] = {2, 0, 1}, QB[3] = {0, 2, 1};
     const int grp = r >> 2, isb = grp & 1, q = isb ? QB[grp >> 1] : QA[grp >> 1], tile = (r >> 1) & 1, hi = r & 1;
-    if (P1 && q != 0) return;
+    if (q >= NP) return;
     if (BCM && isb) {                            // one 16-byte read per fragment (issued with its first half)
       if (hi == 0) {
         const bf16x8 v = *reinterpret_cast<const bf16x8*>(buf + q * IMGB + b_rd + tile * 32 * LDRB);
@@ -186,8 +190,11 @@ __device__ __forceinline__ void gemm_tn_body(const TnArgs& g, const int bid, con
     using OTHER = std::integral_constant<int, SET ^ 1>;
 #pragma unroll
     for (int n = 0; n < 24; ++n) {
-      const int tt = n >> 2, i = (n >> 1) & 1, j = n & 1;
-      if (!P1 || tt == 5)
+      // the MFMA of slot n: all 24 (NP = 3), every other slot (NP = 2: products 3 .. 5), the last four (NP = 1)
+      const int mi = NP == 2 ? n >> 1 : n;
+      const bool mf = NP == 3 || (NP == 2 && (n & 1)) || (NP == 1 && n >= 20);
+      const int tt = NP == 2 ? 3 + (mi >> 2) : n >> 2, i = (mi >> 1) & 1, j = mi & 1;
+      if (mf)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(fa[SET][PA[tt]][i]), frag(fb[SET][PB[tt]][j]), acc[i][j], 0, 0, 0);
       // raw[x]: pair 0 stages in slots 4x, 4x+1, 4x+2; pair 1 in 4x+1, 4x+2, 4x+3; pieces written in 4x+3 .. 4x+5
       if (n < 16) {
@@ -252,12 +259,12 @@ __device__ __forceinline__ void gemm_tn_body(const TnArgs& g, const int bid, con
 // Up to two jobs per launch (dW_v and dW_q): the second one's workgroups fill the slots the first leaves idle.
 // SUM3 / BCM describe job 0; job 1 is always plain.  The backward's whole GEMM work is ONE launch of this kernel:
 // [small reductions][dW_v parts][dW_q parts][tiles of dQ = dP_q W_q on the gemm_w body].
-template <bool SUM3, bool BCM, bool P1>
+template <bool SUM3, bool BCM, int NP>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnJobs jobs) {
   extern __shared__ __attribute__((aligned(16))) short lds_dyn[];          // 2 buffers: 61,440 B (BCM: 67,584 B)
   const int id = (int)blockIdx.x - jobs.nred, ngemm = (int)gridDim.x - jobs.nred - jobs.nw;
   if (id >= ngemm) {                                 // (61,440 B of the dynamic LDS)
-    gw::gemm_w_body<false, P1>(jobs.wj, id - ngemm, lds_dyn);
+    gw::gemm_w_body<false, NP>(jobs.wj, id - ngemm, lds_dyn);
     return;
   }
   if (id < 0) {                                      // the backward's small parameter-gradient reductions: a few
@@ -265,8 +272,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnJobs jobs) {
                       (int)blockIdx.x / jobs.red_bx, reinterpret_cast<float(*)[64]>(lds_dyn));   // workgroups, first in the grid
     return;
   }
-  if (id < jobs.first1) gemm_tn_body<SUM3, BCM, P1>(jobs.job[0], id, jobs.first1, lds_dyn);
-  else gemm_tn_body<false, false, P1>(jobs.job[1], id - jobs.first1, ngemm - jobs.first1, lds_dyn);
+  if (id < jobs.first1) gemm_tn_body<SUM3, BCM, NP>(jobs.job[0], id, jobs.first1, lds_dyn);
+  else gemm_tn_body<false, false, NP>(jobs.job[1], id - jobs.first1, ngemm - jobs.first1, lds_dyn);
 }
 
 }  // namespace
@@ -345,26 +352,29 @@ int launch_gemm_tn(const TnGemm* d, const int* ksplit, const int* S, int n, hipS
   const bool sum3 = d[0].a_term != 0, bcm = d[0].b_kdiv != 0;
   const dim3 grid((unsigned)(jobs.nred + nb[0] + nb[1] + jobs.nw));
   const size_t lds = (size_t)2 * (OPER + (bcm ? OPERB : OPER)) * sizeof(short);
-  const bool p1 = d[0].bf16 != 0;
-  CA_CHECK_ARG((n == 1 || (d[1].bf16 != 0) == p1) && (!wextra || (wextra->bf16 != 0) == p1), "gemm_tn: the jobs of a launch share the precision mode");
+  const int np = d[0].bf16 ? 1 : (d[0].np == 2 ? 2 : 3);
+  auto np_of = [](int bf16, int npf) { return bf16 ? 1 : (npf == 2 ? 2 : 3); };
+  CA_CHECK_ARG((n == 1 || np_of(d[1].bf16, d[1].np) == np) && (!wextra || np_of(wextra->bf16, wextra->np) == np),
+               "gemm_tn: the jobs of a launch share the precision mode");
   if (bcm) {                                             // 67,584 B of dynamic LDS: above the 64 KB default limit
     static DeviceOnce once;
     CA_TRY(once.run([&] {
       hipError_t e = hipSuccess;
-      const void* fns[4] = {reinterpret_cast<const void*>(gemm_tn_kernel<true, true, false>), reinterpret_cast<const void*>(gemm_tn_kernel<false, true, false>),
-                            reinterpret_cast<const void*>(gemm_tn_kernel<true, true, true>), reinterpret_cast<const void*>(gemm_tn_kernel<false, true, true>)};
-      for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      const void* fns[6] = {reinterpret_cast<const void*>(gemm_tn_kernel<true, true, 3>), reinterpret_cast<const void*>(gemm_tn_kernel<false, true, 3>),
+                            reinterpret_cast<const void*>(gemm_tn_kernel<true, true, 2>), reinterpret_cast<const void*>(gemm_tn_kernel<false, true, 2>),
+                            reinterpret_cast<const void*>(gemm_tn_kernel<true, true, 1>), reinterpret_cast<const void*>(gemm_tn_kernel<false, true, 1>)};
+      for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       return e;
     }, "gemm_tn"));
   }
-  auto go = [&](auto P1c) {
-    constexpr bool P1 = decltype(P1c)::value;
-    if (sum3 && bcm) hipLaunchKernelGGL((gemm_tn_kernel<true, true, P1>), grid, dim3(256), lds, s, jobs);
-    else if (bcm) hipLaunchKernelGGL((gemm_tn_kernel<false, true, P1>), grid, dim3(256), lds, s, jobs);
-    else if (sum3) hipLaunchKernelGGL((gemm_tn_kernel<true, false, P1>), grid, dim3(256), lds, s, jobs);
-    else hipLaunchKernelGGL((gemm_tn_kernel<false, false, P1>), grid, dim3(256), lds, s, jobs);
+  auto go = [&](auto NPc) {
+    constexpr int NP = decltype(NPc)::value;
+    if (sum3 && bcm) hipLaunchKernelGGL((gemm_tn_kernel<true, true, NP>), grid, dim3(256), lds, s, jobs);
+    else if (bcm) hipLaunchKernelGGL((gemm_tn_kernel<false, true, NP>), grid, dim3(256), lds, s, jobs);
+    else if (sum3) hipLaunchKernelGGL((gemm_tn_kernel<true, false, NP>), grid, dim3(256), lds, s, jobs);
+    else hipLaunchKernelGGL((gemm_tn_kernel<false, false, NP>), grid, dim3(256), lds, s, jobs);
   };
-  if (p1) go(std::true_type()); else go(std::false_type());
+  if (np == 1) go(std::integral_constant<int, 1>()); else if (np == 2) go(std::integral_constant<int, 2>()); else go(std::integral_constant<int, 3>());
   CA_CHECK_LAUNCH("gemm_tn");
   return 0;
 }

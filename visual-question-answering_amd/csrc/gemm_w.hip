@@ -62,12 +62,12 @@ __global__ __launch_bounds__(256) void wsplit_kernel(const SplitArgs a) {
 
 // Up to two independent GEMMs per launch (P_v and P_q of the forward): the second one's workgroups fill the slots
 // the first one's last, partial round of workgroups would leave idle.  AM0: layout of job 0's A operand.
-template <bool AM0, bool P1, int NW = 4>
+template <bool AM0, int NP, int NW = 4>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_w_kernel(const WJobs jobs) {
   __shared__ __attribute__((aligned(16))) short smem[2 * 3 * BM * LDR];  // 61,440 B: two workgroups of 256 threads per CU
   static_assert(BM * LDR == BK * LDT, "both image layouts have the same size");
-  if ((int)blockIdx.x < jobs.first1) gemm_w_body<AM0, P1, NW>(jobs.job[0], (int)blockIdx.x, smem);
-  else gemm_w_body<false, P1, NW>(jobs.job[1], (int)blockIdx.x - jobs.first1, smem);
+  if ((int)blockIdx.x < jobs.first1) gemm_w_body<AM0, NP, NW>(jobs.job[0], (int)blockIdx.x, smem);
+  else gemm_w_body<false, NP, NW>(jobs.job[1], (int)blockIdx.x - jobs.first1, smem);
 }
 
 }  // namespace
@@ -141,17 +141,20 @@ int launch_gemm_w(const WGemm* d, int n, hipStream_t s) {
   CA_CHECK_ARG(nb[0] + nb[1] < 2147483647L, "gemm_w: grid too large");
   jobs.first1 = (int)nb[0];
   CA_CHECK_ARG(n == 1 || d[1].a_sk == 0, "gemm_w: only the first job may have an m-contiguous A operand");
-  CA_CHECK_ARG(n == 1 || d[1].bf16 == d[0].bf16, "gemm_w: the jobs of a launch share the precision mode");
+  CA_CHECK_ARG(n == 1 || (d[1].bf16 == d[0].bf16 && (d[1].np == 2) == (d[0].np == 2)), "gemm_w: the jobs of a launch share the precision mode");
   const dim3 grid((unsigned)(nb[0] + nb[1]));
   if (wide) {
-    if (d[0].a_sk) hipLaunchKernelGGL((gemm_w_kernel<true, true, 8>), grid, dim3(512), 0, s, jobs);
-    else hipLaunchKernelGGL((gemm_w_kernel<false, true, 8>), grid, dim3(512), 0, s, jobs);
+    if (d[0].a_sk) hipLaunchKernelGGL((gemm_w_kernel<true, 1, 8>), grid, dim3(512), 0, s, jobs);
+    else hipLaunchKernelGGL((gemm_w_kernel<false, 1, 8>), grid, dim3(512), 0, s, jobs);
   } else if (d[0].bf16) {
-    if (d[0].a_sk) hipLaunchKernelGGL((gemm_w_kernel<true, true>), grid, dim3(256), 0, s, jobs);
-    else hipLaunchKernelGGL((gemm_w_kernel<false, true>), grid, dim3(256), 0, s, jobs);
+    if (d[0].a_sk) hipLaunchKernelGGL((gemm_w_kernel<true, 1>), grid, dim3(256), 0, s, jobs);
+    else hipLaunchKernelGGL((gemm_w_kernel<false, 1>), grid, dim3(256), 0, s, jobs);
+  } else if (d[0].np == 2) {
+    if (d[0].a_sk) hipLaunchKernelGGL((gemm_w_kernel<true, 2>), grid, dim3(256), 0, s, jobs);
+    else hipLaunchKernelGGL((gemm_w_kernel<false, 2>), grid, dim3(256), 0, s, jobs);
   } else {
-    if (d[0].a_sk) hipLaunchKernelGGL((gemm_w_kernel<true, false>), grid, dim3(256), 0, s, jobs);
-    else hipLaunchKernelGGL((gemm_w_kernel<false, false>), grid, dim3(256), 0, s, jobs);
+    if (d[0].a_sk) hipLaunchKernelGGL((gemm_w_kernel<true, 3>), grid, dim3(256), 0, s, jobs);
+    else hipLaunchKernelGGL((gemm_w_kernel<false, 3>), grid, dim3(256), 0, s, jobs);
   }
   CA_CHECK_LAUNCH("gemm_w");
   return 0;

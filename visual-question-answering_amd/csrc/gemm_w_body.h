@@ -28,14 +28,20 @@ constexpr int LDT = BM + 32;                   // AM: [k][row] image row stride 
 // AM = false: A rows contiguous along k ([row][k] images, one ds_read_b128 per fragment).
 // AM = true : A contiguous along m -- channel-major image features [B, d, N] read in place (model.py:215-217),
 //             row m = (sample, location) split by a_mdiv: [k][row] images, fragments through ds_read_b64_tr_b16.
-// P1 = true : reduced-precision mode (COATTN_FLAG_BF16_PROJ, the apex-O1 analogue): operands rounded to bf16 (the hi piece
-//             alone -- of A while it is staged, of the weight from its image), ONE MFMA per product; the schedule keeps
-//             its slots, the pieces that do not exist are neither computed, written, read nor multiplied.
+// NP        : bf16 pieces per operand.  3: the exact split (six partial products, fp32-accurate).  2: hi + mid (16
+//             significand bits per operand; the three products mid*hi, hi*mid, hi*hi; ~2^-16 relative per product) --
+//             the backward's gradient GEMMs, whose error budget allows it (tests/test_split_emulation.py).
+//             1: reduced-precision mode (COATTN_FLAG_BF16_PROJ, the apex-O1 analogue): operands rounded to bf16 (the hi
+//             piece alone -- of A while it is staged, of the weight from its image), ONE MFMA per product.  The schedule
+//             keeps its 24 slots per half step; the pieces that do not exist are neither computed, written, read nor
+//             multiplied, and with two pieces the twelve MFMAs take every other slot.
 // NW = 8    : 512-thread workgroups, tile 128 x 256 (the eight waves as 2 x 4): the A rows staged once serve twice the
 //             columns -- for the single-product mode at d = 2048, where the L2 -> CU traffic of A re-read by every
 //             column tile is the bound, not the MFMAs.
-template <bool AM, bool P1 = false, int NW = 4>
+template <bool AM, int NP = 3, int NW = 4>
 __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short* const smem) {
+  static_assert(NP >= 1 && NP <= 3, "pieces per operand");
+  constexpr bool P1 = NP == 1;
   constexpr int WCN = NW / 2, BN = 64 * WCN, NT = 64 * NW, AP = 1024 / NT;   // waves per tile row, tile width, threads, A float4 per thread and step
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WCN, wc = wave % WCN, li = lane & 31, lh = lane >> 5;
@@ -127,12 +133,12 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
   auto load_a = [&](int i, int s) { if (i < AP) raw[i] = buf_load4(rs_a, a_voff[i], (s + s0) * a_kstep); };
   auto load_b = [&](int ring, int k, int half) {
     const int j = k / 3, q = k % 3;
-    if (P1 && q != 0) return;
+    if (q >= NP) return;
     bq[ring][j][q] = __builtin_bit_cast(bf16x8, buf_load4(rs_w, w_voff[j] + q * kFragBytes, (half + 2 * s0) * kChunkBytes));
   };
   auto read_a = [&](const short* img, int h, int k) {
     const int q = RQ[k >> 1], i = k & 1;
-    if (P1 && q != 0) return;
+    if (q >= NP) return;
     if (AM) {
       const short* ptr = img + q * IMG + a_rd + i * 32 + 16 * h * LDT;
       const bf16x4 lo = lds_tr16(ptr), hi = lds_tr16(ptr + 4 * LDT);
@@ -157,16 +163,17 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
       rb[e] = sub1(raw[i][2 * e + 1], __builtin_bit_cast(float, ph[e] & 0xffff0000u));
     } else if (st == 1) {
       pm[e] = cvt_pk_bf16(ra[e], rb[e]);
+      if (NP == 2) return;
       ra[e] = sub1(ra[e], __builtin_bit_cast(float, pm[e] << 16));
       rb[e] = sub1(rb[e], __builtin_bit_cast(float, pm[e] & 0xffff0000u));
-    } else {
+    } else if (NP == 3) {
       pl[e] = cvt_pk_bf16(ra[e], rb[e]);
     }
 #endif
   };
   auto write_a = [&](short* img, int i, int q) {
     if (i >= AP) return;
-    if (P1 && q != 0) return;
+    if (q >= NP) return;
     const u32x2 v = q == 0 ? u32x2{ph[0], ph[1]} : (q == 1 ? u32x2{pm[0], pm[1]} : u32x2{pl[0], pl[1]});
     *reinterpret_cast<u32x2*>(&img[q * IMG + a_lds[i]]) = v;
   };
@@ -175,11 +182,14 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
     constexpr int HH = decltype(HHc)::value, BU = decltype(BUc)::value, BL = decltype(BLc)::value;
 #pragma unroll
     for (int n = 0; n < 24; ++n) {
-      const int t = n >> 2, i = (n >> 1) & 1, j = n & 1;
+      // the MFMA of slot n: all 24 (NP = 3), every other slot (NP = 2: products 3 .. 5), the last four (NP = 1)
+      const int mi = NP == 2 ? n >> 1 : n;
+      const bool mf = NP == 3 || (NP == 2 && (n & 1)) || (NP == 1 && n >= 20);
+      const int t = NP == 2 ? 3 + (mi >> 2) : n >> 2, i = (mi >> 1) & 1, j = mi & 1;
 #ifndef GEMMW_NOMFMA
-      if (!P1 || t == 5) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[HH][PA[t]][i], bq[BU][j][PB[t]], acc[i][j], 0, 0, 0);
+      if (mf) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[HH][PA[t]][i], bq[BU][j][PB[t]], acc[i][j], 0, 0, 0);
 #else
-      if (t == 0) acc[i][j][0] += __builtin_bit_cast(float, (int)af[HH][PA[t]][i][0] ^ (int)bq[BU][j][PB[t]][0]);
+      if (n < 4) acc[i][j][0] += __builtin_bit_cast(float, (int)af[HH][PA[t]][i][0] ^ (int)bq[BU][j][PB[t]][0]);
 #endif
 #ifndef GEMMW_NOB
       if (n < 6) load_b(BL, n, 2 * s + HH + 2);

@@ -63,10 +63,11 @@ extern "C" {
 #define COATTN_FLAG_BF16_IN 8     /* coattn_linear_forward / coattn_linear_weight_grad, with COATTN_FLAG_BF16_PROJ: x (dy) is STORED as bf16 */
 /* Widths of the fp32 mode.  An fp32 product runs on the bf16 MFMA as partial products of bf16 PIECES of its operands:
  * three pieces each (hi + mid + lo = the value exactly, six partial products: fp32-accurate) or two (hi + mid: 16
- * significand bits, three partial products, ~2^-16 relative per product, random in sign).  By default coattn_forward keeps
- * the affinity A = Q V^T (model.py:377 -- the one contraction whose error the saturating tanh amplifies) and the
- * projections (model.py:380-384) on three pieces and coattn_backward runs the gradient contractions on two; the 1e-4
- * contract holds with a margin of > 5x on every golden case (tests/test_split_emulation.py has the budget).
+ * significand bits, three partial products, ~2^-16 relative per product, random in sign).  By default the affinity
+ * A = Q V^T (model.py:377 -- the one contraction whose error the saturating tanh amplifies) and the projections
+ * (model.py:380-384 -- their error reaches H_q summed over the N locations) keep three pieces; C^T P_q, C P_v of the forward
+ * and the gradient contractions of coattn_backward run on two.  On the golden cases: v, q within 1e-6, attention maps
+ * within 4e-7, gradients within 3e-5 of max|.| (the contract: 1e-4); tests/test_split_emulation.py has the budget row by row.
  * flags bit 4 (coattn_forward / coattn_backward): every contraction on three pieces. */
 #define COATTN_FLAG_EXACT3 16
 /* flags bit 5 (coattn_linear_forward; `accumulate` of coattn_linear_weight_grad): the two-piece width for this product. */

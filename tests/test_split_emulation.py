@@ -1,9 +1,9 @@
 """Error budget of the mixed-width bf16 split ("widths"), emulated on the CPU.
 
 The fp32 mode of the HIP kernels multiplies fp32 operands on the bf16 MFMA by splitting each value into bf16
-pieces (hi + mid + lo, exact) and summing partial products in fp32.  The forward (model.py:377-384: affinity,
-projections, H_v / H_q) keeps all three pieces (six products); the gradient contractions of the backward run on
-TWO pieces (hi + mid; products hi*mid, mid*hi, hi*hi).  This test restates the path in float64 with exactly
+pieces (hi + mid + lo, exact) and summing partial products in fp32.  The affinity and the projections
+(model.py:377, :380-384) keep all three pieces (six products); the H_v / H_q contractions against C and the
+gradient contractions of the backward run on TWO pieces (hi + mid; products hi*mid, mid*hi, hi*hi).  This test restates the path in float64 with exactly
 those operand truncations and dropped partial products and holds it to the reference's goldens at the
 contract's 1e-4 -- so that the widths are pinned by a test that runs without a GPU, and a change of the table
 (WIDTHS) shows its cost here first.  `python -m tests.test_split_emulation` prints the cost of each row."""
@@ -18,7 +18,7 @@ from . import _golden as G
 WIDTHS = {
     "affinity": 3,      # A = Q V^T                                   coattn_fwd32 phase 1
     "proj": 3,          # P_v = V W_v^T, P_q = Q W_q^T                gemm_w   (two pieces: H_q off by 2e-4, see below)
-    "h": 3,             # C^T P_q, C P_v                              coattn_fwd32 phase 2
+    "h": 2,             # C^T P_q, C P_v                              coattn_fwd32 phase 2
     "bwd": 2,           # recomputed C^T P_q, C dZ_v, C^T dZ_q, dC    bwd_nat32 / bwd_dc32
     "dq": 2,            # dA V                                        bwd_dq32(x)
     "gemm_bwd": 2,      # dP_q W_q, dW_v, dW_q                        gemm_tn launch

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Developer tool: the co-attention forward + backward alone at ONE shape (frozen image features: no dV), for a
+per-kernel profile: `rocprofv3 --kernel-trace --stats -- python3 tools/probe_hot.py 196 lm 200`.
+env: D (512), OPT (1 = reduced-precision mode).  Prints the wall time per iteration of the timed half."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import vqa_amd
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 196
+layout = sys.argv[2] if len(sys.argv) > 2 else "lm"
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+B, T, d = 160, 26, int(os.environ.get("D", "512"))
+dev = torch.device("cuda", 0)
+co = vqa_amd.ParallelCoAttention(d).to(dev)
+co.bf16_projections = os.environ.get("OPT", "0") == "1"
+torch.manual_seed(1)
+if layout == "lm":
+    x = torch.randn(B, N, d, device=dev).clamp_min_(0)
+else:
+    x = torch.randn(B, d, N, device=dev).clamp_min_(0).permute(0, 2, 1)
+Qs = [torch.randn(B, T, d, device=dev).requires_grad_(True) for _ in range(3)]
+g = None
+def it():
+    global g
+    vs, qs = co(x, Qs)
+    outs = list(vs) + list(qs)
+    if g is None:
+        g = [torch.ones_like(o) for o in outs]
+    torch.autograd.backward(outs, g)
+for _ in range(iters // 2):
+    it()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(iters):
+    it()
+torch.cuda.synchronize()
+print("N=%d %s d=%d: %.3f ms per forward + backward (wall)" % (N, layout, d, (time.perf_counter() - t0) / iters * 1e3))

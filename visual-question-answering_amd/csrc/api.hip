@@ -225,16 +225,16 @@ int c_times(const Ctx& c, const float* C, const float* Y, const float* X, float*
 }
 
 // Width of the fp32 mode's contractions (fused.h).  Default: the mixed widths of DESIGN.md section 3 -- the affinity and
-// the projections on the exact split, the backward's contractions on two pieces.  COATTN_FLAG_EXACT3 (or the developer
-// switch COATTN_SPLIT=3) puts every contraction on the exact split; COATTN_SPLIT_FWD=2 (developer switch) also runs the
-// forward kernel's phase 2 on two pieces.
+// the projections on the exact split, phase 2 of the forward kernel (C^T P_q, C P_v) and the backward's contractions on
+// two pieces.  COATTN_FLAG_EXACT3 (or the developer switch COATTN_SPLIT=3) puts every contraction on the exact split;
+// COATTN_SPLIT_FWD=3 (developer switch) only the forward kernel's phase 2.
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static int np_bwd(int flags) {
   static const int split = env_int("COATTN_SPLIT", 2);
   return ((flags & COATTN_FLAG_EXACT3) || split == 3) ? 3 : 2;
 }
 static int np_fwd(int flags) {
-  static const int split = env_int("COATTN_SPLIT", 2), fwd = env_int("COATTN_SPLIT_FWD", 3);
+  static const int split = env_int("COATTN_SPLIT", 2), fwd = env_int("COATTN_SPLIT_FWD", 2);
   return ((flags & COATTN_FLAG_EXACT3) || split == 3) ? 3 : (fwd == 2 ? 2 : 3);
 }
 

@@ -103,3 +103,86 @@ def test_trainer_graph_mode_matches_eager_training():
     assert model.hot_path_graph and len(model._graphs) == 1
     for a, b in zip(losses[False], losses[True]):
         assert abs(a - b) <= 1e-5 * abs(a)
+
+
+def test_channel_major_features_are_captured_in_place():
+    """The reference's layout -- x_img = the permuted view of a [B,d,N] buffer (model.py:215-217) -- is read where it
+    lies through the C-ABI's strides (no copy into the static input), bit for bit the eager module path."""
+    from vqa_amd.graph import HotPathGraph
+    B, N, T, d, mlp, K = 16, 196, 26, 512, 256, 37
+    co, head = _modules(d, mlp, K, seed=5)
+    buf = torch.randn(B, d, N, device="cuda").clamp_min_(0)
+    x = buf.permute(0, 2, 1)                                 # [B,N,d], strides (d N, 1, N)
+    Qs = [(torch.randn(B, T, d, device="cuda") * 0.2).requires_grad_(True) for _ in range(3)]
+    lab = torch.arange(B, device="cuda") % K
+    params = list(co.parameters()) + list(head.parameters())
+    _, loss = head.forward_loss(*co(x, Qs), lab)
+    loss.backward()
+    ref = [q.grad.clone() for q in Qs] + [p.grad.clone() for p in params if p.grad is not None]
+    for t in Qs + params:
+        t.grad = None
+    hp = HotPathGraph(co, head, B, N, T)
+    hp.V.fill_(float("nan"))                                 # the static input must not be what the graph reads
+    _, loss2 = hp(x, Qs, lab)
+    loss2.backward()
+    assert any(k[0] == buf.data_ptr() for k in hp._pairs), "the channel-major view was not captured in place"
+    assert torch.equal(loss2, loss.detach())
+    for a, b in zip(ref, [q.grad for q in Qs] + [p.grad for p in params if p.grad is not None]):
+        assert torch.equal(a, b)
+
+
+def test_graph_path_label_checks():
+    """int32 labels are converted through the static input (the kernels read int64 at the captured address), float
+    labels are refused, and a label outside [0, K) is reported by check_labels() as on the eager path."""
+    from vqa_amd import head as H
+    from vqa_amd.graph import HotPathGraph
+    B, N, T, d, mlp, K = 8, 49, 26, 256, 128, 11
+    co, head = _modules(d, mlp, K, seed=7)
+    x = torch.randn(B, N, d, device="cuda").clamp_min_(0)
+    Qs = [torch.randn(B, T, d, device="cuda") * 0.2 for _ in range(3)]
+    lab = torch.arange(B, device="cuda") % K
+    hp = HotPathGraph(co, head, B, N, T)
+    _, l64 = hp(x, Qs, lab)
+    _, l32 = hp(x, Qs, lab.to(torch.int32))
+    assert torch.equal(l64, l32) and torch.isfinite(l64)
+    with pytest.raises(RuntimeError, match="integer class indices"):
+        hp(x, Qs, lab.float())
+    H.check_labels()                                         # in range: nothing to report
+    bad = lab.clone()
+    bad[3] = K + 5
+    _, lbad = hp(x, Qs, bad)
+    assert torch.isnan(lbad)
+    with pytest.raises(IndexError):
+        H.check_labels()
+
+
+def test_capture_while_another_thread_allocates():
+    """train.DevicePrefetcher's worker pins and copies batches while the first step captures its graphs: the capture
+    runs in thread_local error mode, so those allocator / copy calls do not invalidate it."""
+    import threading
+    from vqa_amd.graph import HotPathGraph
+    B, N, T, d, mlp, K = 8, 49, 26, 256, 128, 11
+    co, head = _modules(d, mlp, K, seed=9)
+    stop = threading.Event()
+
+    def worker():
+        s = torch.cuda.Stream()
+        while not stop.is_set():
+            h = torch.empty(1 << 16).pin_memory()
+            with torch.cuda.stream(s):
+                h.to("cuda", non_blocking=True)
+            s.synchronize()
+
+    th = threading.Thread(target=worker)
+    th.start()
+    try:
+        x = torch.randn(B, N, d, device="cuda").clamp_min_(0)
+        Qs = [torch.randn(B, T, d, device="cuda") * 0.2 for _ in range(3)]
+        lab = torch.arange(B, device="cuda") % K
+        for _ in range(4):                                   # several captures (new address sets) under the noise
+            hp = HotPathGraph(co, head, B, N, T)
+            _, loss = hp(x.clone(), [q.clone() for q in Qs], lab.clone())
+            assert torch.isfinite(loss)
+    finally:
+        stop.set()
+        th.join()

@@ -5,9 +5,11 @@ launches and two autograd round trips).
 What is captured are the C-ABI calls themselves (``coattn_forward`` + ``coattn_head_forward``; ``coattn_head_backward`` +
 ``coattn_backward``: asynchronous on the stream they are given, no allocation, no synchronisation -> capture-safe).
 Outputs, saved state and workspaces are static buffers of this object; the INPUTS (image features, the three question
-levels, labels) are read where they lie: a graph pair is captured per set of input addresses (a training loop's
-allocator hands the same blocks back step after step; at most ``MAX_KEYS`` pairs, beyond that the inputs are copied
-into static buffers).  The upstream gradient of the loss is a device scalar the backward graph reads, so any
+levels, labels) are read where they lie: a graph pair is captured per set of input addresses and image-feature strides
+(a training loop's allocator hands the same blocks back step after step; at most ``MAX_KEYS`` pairs, beyond that the
+inputs are copied into static buffers).  The image features are taken in either physical layout the kernels run on --
+contiguous [B,N,d], or the permuted view of the reference's channel-major buffer (model.py:215-217) -- through the
+C-ABI's strides, without a copy.  The upstream gradient of the loss is a device scalar the backward graph reads, so any
 ``loss * k`` upstream works.  Values are bit-for-bit those of the eager C-ABI calls.
 
     hp = HotPathGraph(co_attention, mlp_classify, B, N, T)          # modules of HierarchicalCoAttentionNet
@@ -21,6 +23,8 @@ from typing import Sequence
 import torch
 
 from . import _lib
+from . import head as _head
+from .coattention import _native_layout, _strides
 from .head import _workspace_bytes as _head_ws
 
 
@@ -70,7 +74,7 @@ class HotPathGraph:
         self._static = (self.V, self.Q[0], self.Q[1], self.Q[2], self.labels)
         self.pair(self._static)
 
-    # the C-ABI calls on `stream`, reading the inputs `ins` = (V [B,N,d] contiguous, Q_w, Q_p, Q_s, labels)
+    # the C-ABI calls on `stream`, reading the inputs `ins` = (V [B,N,d] in a native layout, Q_w, Q_p, Q_s, labels)
     def _enqueue(self, ins, stream, fwd=True, bwd=True):
         lib = _lib.load()
         B, N, T, d, mlp, K = self.dims
@@ -83,7 +87,8 @@ class HotPathGraph:
         pg = _lib.ParamGrads(*[t.data_ptr() for t in self.co_grads])
         hp = _lib.HeadParams(*[t.data_ptr() for t in self.head_params])
         hg = _lib.HeadParamGrads(*[t.data_ptr() for t in self.head_grads])
-        vs = (N * d, d, 1)
+        vs = _strides(V)
+        dvs = (N * d, d, 1)                                  # the static dV buffer is location-major
         if fwd:
             _lib.check(lib.coattn_forward(_ptr(V), *vs, qptr, C.byref(p), _ptr(self.v), _ptr(self.q), _ptr(self.saved),
                                           _ptr(self.ws), B, N, T, d, 3, _lib.F32, self.flags, st), "coattn_forward")
@@ -95,19 +100,23 @@ class HotPathGraph:
                                                 None, rows(self.dx), None, C.byref(hg), 0, _ptr(self.hws), B, d, mlp, K,
                                                 _lib.F32, self.head_flags, st), "coattn_head_backward")
             _lib.check(lib.coattn_backward(_ptr(V), *vs, qptr, C.byref(p), _ptr(self.saved), _ptr(self.dx), _ptr(self.dx),
-                                           _ptr(self.dV), *(vs if self.dV is not None else (0, 0, 0)), dqptr, C.byref(pg),
+                                           _ptr(self.dV), *(dvs if self.dV is not None else (0, 0, 0)), dqptr, C.byref(pg),
                                            0, _ptr(self.ws), B, N, T, d, 3, _lib.F32, self.flags, st), "coattn_backward")
 
     def usable_in_place(self, ins) -> bool:
         B, N, T, d, _, _ = self.dims
         V, labels = ins[0], ins[4]
-        return (V.is_contiguous() and V.dtype == torch.float32 and V.data_ptr() % 16 == 0 and labels.is_contiguous()
-                and all(q.is_contiguous() and q.dtype == torch.float32 and q.data_ptr() % 16 == 0 for q in ins[1:4]))
+        # (labels: the kernels read `const long long*` at the captured address -- anything but contiguous int64 on this
+        #  device goes through the static copy, which converts)
+        return (V.dtype == torch.float32 and V.device == self.device and _native_layout(V) is V
+                and labels.is_contiguous() and labels.dtype == torch.int64 and labels.device == self.device
+                and all(q.is_contiguous() and q.dtype == torch.float32 and q.data_ptr() % 16 == 0 and q.device == self.device
+                        for q in ins[1:4]))
 
     def pair(self, ins):
         """(forward graph, backward graph) reading the inputs at the addresses of `ins`; captured on first use, or
         None when MAX_KEYS address sets are already held (the caller then copies into the static inputs)."""
-        key = tuple(t.data_ptr() for t in ins)
+        key = tuple(t.data_ptr() for t in ins) + tuple(ins[0].stride())
         hit = self._pairs.get(key)
         if hit is not None:
             return hit
@@ -124,9 +133,11 @@ class HotPathGraph:
                 self._warm = True
             torch.cuda.synchronize(self.device)
             gf, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gf):
+            # thread_local: other threads (train.DevicePrefetcher pins and copies batches concurrently) may keep calling
+            # the allocator and the copy engine while this thread captures
+            with torch.cuda.graph(gf, capture_error_mode="thread_local"):
                 self._enqueue(ins, torch.cuda.current_stream(self.device).cuda_stream, True, False)
-            with torch.cuda.graph(gb, pool=gf.pool()):
+            with torch.cuda.graph(gb, pool=gf.pool(), capture_error_mode="thread_local"):
                 self._enqueue(ins, torch.cuda.current_stream(self.device).cuda_stream, False, True)
         self._pairs[key] = (gf, gb)
         return self._pairs[key]
@@ -151,6 +162,8 @@ class _HotPathFn(torch.autograd.Function):
         B, N, T, d, mlp, K = hp.dims
         if tuple(x_img.shape) != (B, N, d) or any(tuple(q.shape) != (B, T, d) for q in (Qw, Qp, Qs)) or tuple(labels.shape) != (B,):
             raise RuntimeError("HotPathGraph: captured for x_img %s, questions %s" % ((B, N, d), (B, T, d)))
+        if labels.dtype.is_floating_point or labels.dtype == torch.bool:
+            raise RuntimeError("HotPathGraph: labels must be integer class indices (int64 [B]), got %s" % labels.dtype)
         if ctx.needs_input_grad[1] and hp.dV is None:
             raise RuntimeError("HotPathGraph: built with need_dv=False but the image features require a gradient")
         ins = (x_img, Qw, Qp, Qs, labels)
@@ -162,6 +175,8 @@ class _HotPathFn(torch.autograd.Function):
             ins = hp._static
             pair = hp.pair(ins)
         pair[0].replay()
+        # (as head.answer_head after a forward with labels: Trainer.check_labels() reads this step's status word)
+        _head._last = (hp.hsaved, B, d, mlp, K, hp.device)
         ctx.hp, ctx.pair = hp, pair
         ctx.keep = ins                                           # the graphs read these addresses again in backward
         ctx.mark_non_differentiable(hp.logits)

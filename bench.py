@@ -11,9 +11,15 @@ one step = forward + CrossEntropy + backward + Adam (+ RCCL gradient all-reduce 
 inputs resident in HBM before the timed region.  Rank 0 prints ONE JSON line; besides the
 contract fields it carries
   roofline      the fused affinity+softmax+reduce forward kernel, timed live with HIP events on
-                the launch stream at the headline kernel shape (B=160, N=196, T=26, d=512):
-                algorithmic bytes 913,408 B per (pair, level) / avg launch time,
-                against 8 TB/s HBM
+                the launch stream AT THE TIMED STEP'S OWN SHAPE (B=160, N=49, T=26, d=512, location-major as
+                the train step hands features over): algorithmic bytes per (pair, level) (SURVEY.md 8d's
+                formula at that N) / avg launch time, against 8 TB/s HBM;
+                roofline_reference_grid: the same kernel at the reference's default grid (N=196: 913,408 B
+                per (pair, level)), roofline_channel_major: on the reference's own layout
+  roofline_backward  every kernel of coattn_backward, at both grids: average time between HIP events the
+                library records around its launches (coattn_profile_begin / _end), algorithmic bytes
+                 against HBM -- the GEMM launch: algorithmic flops against the
+                dense bf16 MFMA peak / partial products per fp32 product of its width
   cpu_baseline  the CPU oracle port (oracle/net_oracle.py) of the same train step, timed on the
                 host cores on a bounded sample (rank 0, N=1 only); cpu_baseline_hot_path: the oracle
                 port of the isolated hot path (co-attention + MLP + CE fwd+bwd) at N=196 and N=49
@@ -283,6 +289,108 @@ def roofline_leg(device, B=160, N=196, T=26, d=512, L=3, iters=100, layout="lm")
             "algorithmic_bytes": alg}
 
 
+def backward_legs(device, B=160, N=196, T=26, d=512, L=3, iters=60, layout="lm", bf16=False):
+    """Every launch group of coattn_backward (frozen image encoder: no dV, the train step's case), timed by the HIP
+    events the library records between its launches (coattn_profile_begin / coattn_profile_end) -- averaged over `iters`
+    calls after a clock warm-up.  Algorithmic bytes per launch (fp32, per (pair, level) unless
+    stated): what each kernel must read and write once --
+      bwd_pre    V once per pair (da_v for the three levels) + per level Q, H_q read, dZ_q written
+      bwd_dc32   P_v, P_q, dZ_q, C read, dA written
+      bwd_nat32  P_v, P_q, dZ_q, C read, dP_v, dP_q written
+      bwd_dq     V, dA read, dQ read and written
+      bwd_gemm   MFMA-bound: 2 (B N d^2 + 2 L B T d^2) flops (dW_v, dW_q, dQ = dP_q W_q) against the dense bf16 peak /
+                 partial products per fp32 product (3 at the two-piece width, 6 at the exact split); its HBM bytes beside
+    against 8 TB/s."""
+    import ctypes as C
+    import vqa_amd
+    from vqa_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(0)
+    co = vqa_amd.ParallelCoAttention(d).to(device)
+    V, Qs = synth_features(B, N, T, d, device, seed=78, L=L)
+    vstr = (d * N, 1, N)
+    if layout == "lm":
+        V, vstr = V.permute(0, 2, 1).contiguous(), (N * d, d, 1)
+    ps = [t.detach().contiguous() for t in (co.W_v.weight, co.W_v.bias, co.W_q.weight, co.W_q.bias, co.w_v.weight,
+                                           co.w_v.bias, co.w_q.weight, co.w_q.bias)]
+    flags = _lib_flag(bf16)
+    sb, fb, bb = _lib.workspace_bytes(B, N, T, d, L, flags)
+    saved = torch.empty(sb // 4, device=device); ws = torch.empty(max(fb, bb) // 4, device=device)
+    v = torch.empty(L, B, d, device=device); q = torch.empty(L, B, d, device=device)
+    gv = torch.randn(L, B, d, device=device) * 0.1; gq = torch.randn(L, B, d, device=device) * 0.1
+    dQs = [torch.empty_like(t) for t in Qs]
+    grads = [torch.empty_like(t) for t in ps]
+    qptr = (C.c_void_p * L)(*[t.data_ptr() for t in Qs])
+    dqptr = (C.c_void_p * L)(*[t.data_ptr() for t in dQs])
+    p = _lib.Params(*[t.data_ptr() for t in ps])
+    pg = _lib.ParamGrads(*[t.data_ptr() for t in grads])
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.coattn_forward(V.data_ptr(), *vstr, qptr, C.byref(p), v.data_ptr(), q.data_ptr(), saved.data_ptr(),
+                                  ws.data_ptr(), B, N, T, d, L, _lib.F32, flags, stream), "coattn_forward")
+
+    def bwd():
+        return lib.coattn_backward(V.data_ptr(), *vstr, qptr, C.byref(p), saved.data_ptr(), gv.data_ptr(), gq.data_ptr(),
+                                   None, 0, 0, 0, dqptr, C.byref(pg), 0, ws.data_ptr(), B, N, T, d, L, _lib.F32, flags, stream)
+
+    _lib.check(bwd(), "coattn_backward")
+    for _ in range(2 * iters):                         # clock warm-up (see roofline_leg)
+        bwd()
+    us = (C.c_float * 48)()
+    names = C.create_string_buffer(2048)
+    tot, order = {}, []
+    for _ in range(iters):
+        _lib.check(lib.coattn_profile_begin(stream), "coattn_profile_begin")
+        bwd()
+        n = lib.coattn_profile_end(us, names, 2048, 48)
+        if n < 0:
+            _lib.check(n, "coattn_profile_end")
+        for i, nm in enumerate(names.value.decode().split("\n")[:n]):
+            if nm not in tot:
+                tot[nm] = 0.0
+                order.append(nm)
+            tot[nm] += us[i]
+    f4 = 4
+    per_level = {
+        "bwd_dc32": f4 * (N * d + 2 * T * d + T * N + T * N),
+        "bwd_nat32": f4 * (N * d + 2 * T * d + T * N + N * d + T * d),
+        "bwd_dq": f4 * (N * d + T * N + 2 * T * d),
+    }
+    alg = {k: B * L * b for k, b in per_level.items()}
+    alg["bwd_pre"] = B * f4 * (N * d + L * 3 * T * d)
+    # kernels behind a mark (the names rocprofv3 shows): for matching against profiles/*_kernel_stats.csv
+    kernels = {"bwd_pre": "bwd_pre_kernel + bwd_prev_kernel", "bwd_dc32": "bwd_dc32_kernel", "bwd_nat32": "bwd_nat32_kernel",
+               "bwd_dq": "bwd_dq32x_kernel" if N <= 64 else "bwd_dq32_kernel",
+               "bwd_gemm": "gemm_tn_kernel (dW_v + dW_q split-K parts, dQ = dP_q W_q tiles, small reductions)",
+               "bwd_gemm_dw": "gemm_tn_kernel / gemm_bf_tn_kernel (dW_v + dW_q)", "bwd_gemm_dq_projection": "gemm_w_kernel / gemm_bf_kernel (dQ = dP_q W_q)",
+               "reduce_partials": "reduce_partials4_kernel"}
+    np_prod = 1 if bf16 else (6 if os.environ.get("COATTN_SPLIT") == "3" else 3)
+    out = []
+    total = sum(tot.values()) / iters
+    for nm in order:
+        t = tot[nm] / iters * 1e-6
+        e = {"mark": nm, "kernel": kernels.get(nm, nm), "avg_launch_us": round(t * 1e6, 2), "share": round(t * 1e6 / total, 3)}
+        if nm in alg:
+            ach = alg[nm] / t / 1e9
+            e.update({"bound": "hbm", "algorithmic_bytes": alg[nm], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                      "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None})
+        elif nm.startswith("bwd_gemm"):
+            fl = {"bwd_gemm": 2.0 * d * d * (B * N + 2 * L * B * T), "bwd_gemm_dw": 2.0 * d * d * (B * N + L * B * T),
+                  "bwd_gemm_dq_projection": 2.0 * d * d * L * B * T}[nm]
+            peak = 2500.0 / np_prod
+            ach = fl / t / 1e12
+            hbm = f4 * (L * B * N * d + B * N * d + (3 * L * B * T * d if nm == "bwd_gemm" else 2 * L * B * T * d))
+            e.update({"bound": "mfma", "algorithmic_flops": fl, "achieved": round(ach, 1), "peak": round(peak, 1),
+                      "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                      "peak_note": "dense bf16 MFMA peak 2500 TFLOP/s / %d partial product(s) per product" % np_prod,
+                      "frac_of_fp32_matrix_peak": round(ach / 157.3, 4),
+                      "hbm_bytes": hbm, "hbm_frac_at_this_time": round(hbm / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": None})
+        out.append(e)
+    return {"shape": {"B": B, "N": N, "T": T, "d": d, "L": L}, "v_layout": layout, "calls": iters,
+            "total_us": round(total, 1), "kernels": out,
+            "note": "time between HIP events the library records after each launch group of coattn_backward "
+                    "(coattn_profile_begin / _end); dV not requested (frozen image encoder)"}
+
+
 def projection_leg(device, B=160, N=196, d=512, iters=50, bf16=False):
     """The dominant MFMA-bound kernel of the path: P_v = V W_v^T + b_v (model.py:380/384, once per sample) from
     location-major features, through coattn_linear_forward -- the weight split once into MFMA-fragment order, then
@@ -361,13 +469,16 @@ def weight_grad_leg(device, B=160, N=196, d=512, iters=50, bf16=False):
     ws = torch.empty(lib.coattn_linear_wgrad_workspace_bytes(d, d) // 4, device=device)
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+    # the width coattn_backward runs this product at: two pieces (three partial products) unless COATTN_SPLIT=3
+    two = not bf16 and os.environ.get("COATTN_SPLIT") != "3"
+
     def call():
         return lib.coattn_linear_weight_grad(dP.data_ptr(), d, V.data_ptr(), d, dW.data_ptr(), ws.data_ptr(), B * N, d, d,
-                                             _lib.FLAG_BF16_PROJ if bf16 else 0, stream)
+                                             _lib.FLAG_BF16_PROJ if bf16 else (_lib.FLAG_SPLIT2 if two else 0), stream)
 
     _lib.check(call(), "coattn_linear_weight_grad")
     ref = (dP[:, :64].bfloat16().double().t() @ V.bfloat16().double()) if bf16 else dP[:, :64].double().t() @ V.double()
-    if not torch.allclose(dW[:64].double(), ref, rtol=1e-5, atol=1e-3 if bf16 else 1e-4):
+    if not torch.allclose(dW[:64].double(), ref, rtol=1e-5, atol=1e-3 if bf16 else (3e-4 if two else 1e-4)):
         raise SystemExit("bench.py: weight-gradient leg: coattn_linear_weight_grad disagrees with the fp64 product")
     for _ in range(3 * iters):
         call()
@@ -383,10 +494,13 @@ def weight_grad_leg(device, B=160, N=196, d=512, iters=50, bf16=False):
     t = sorted(ts)[1]
     flop = 2.0 * B * N * d * d
     ach = flop / t / 1e12
-    peak = 2500.0 if bf16 else 2500.0 / 6.0
+    nprod = 1 if bf16 else (3 if two else 6)
+    peak = 2500.0 / nprod
     return {"bound": "mfma", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "peak_note": ("dense bf16 MFMA peak (operands rounded to bf16, one MFMA per product)" if bf16 else
-                          "fp32-equivalent: dense bf16 MFMA peak 2500 TFLOP/s / 6 partial products per fp32 product"),
+                          "fp32-equivalent: dense bf16 MFMA peak 2500 TFLOP/s / %d partial products per fp32 product (%s)"
+                          % (nprod, "two-piece width, as coattn_backward runs it" if two else "exact three-piece split")),
+            "frac_of_fp32_matrix_peak": round(ach / 157.3, 4), "bf16_mfma_frac": round(nprod * ach / 2500.0, 4),
             "traffic": None,
             "kernel": ("dW_v weight-gradient GEMM (gemm_bf_tn_kernel at 256-multiples, else gemm_tn_kernel's single-piece mode; one round "
                        "of split-K parts) + reduce_partials4_kernel" if bf16 else
@@ -553,15 +667,17 @@ def main():
             bf = args.opt_lvl > 0
             res = ({"roofline": roofline_leg(dev, B=args.batch, N=n_step, T=args.seq_len, d=2048),
                     "roofline_projection": projection_leg(dev, B=args.batch, N=n_step, d=2048, bf16=bf),
-                    "roofline_weight_grad": weight_grad_leg(dev, B=args.batch, N=n_step, d=2048, bf16=bf)}
+                    "roofline_weight_grad": weight_grad_leg(dev, B=args.batch, N=n_step, d=2048, bf16=bf),
+                    "roofline_backward": [backward_legs(dev, B=args.batch, N=n_step, T=args.seq_len, d=2048, bf16=bf)]}
                    if args.only == "roofline"
                    else [hot_path_leg(dev, n_step, lay, B=args.batch, T=args.seq_len, d=2048, K=args.num_cls, bf16=bf)
                          for lay in ("lm", "cm")])
         else:
-            res = ({"roofline": roofline_leg(dev), "roofline_channel_major": roofline_leg(dev, layout="cm"),
-                    "roofline_at_step_shape": roofline_leg(dev, N=49),
+            res = ({"roofline": roofline_leg(dev, N=49), "roofline_reference_grid": roofline_leg(dev),
+                    "roofline_channel_major": roofline_leg(dev, layout="cm"),
                     "roofline_at_step_shape_channel_major": roofline_leg(dev, N=49, layout="cm"),
-                    "roofline_projection": projection_leg(dev), "roofline_weight_grad": weight_grad_leg(dev)}
+                    "roofline_projection": projection_leg(dev), "roofline_weight_grad": weight_grad_leg(dev),
+                    "roofline_backward": [backward_legs(dev, N=49), backward_legs(dev)]}
                    if args.only == "roofline"
                    else [hot_path_leg(dev, n, lay) for n in (196, 49) for lay in ("lm", "cm")])
         print(json.dumps(res))
@@ -666,19 +782,22 @@ def main():
             out["roofline"] = roofline_leg(device, B=args.batch, N=n_step, T=args.seq_len, d=d4)
             out["roofline_projection"] = projection_leg(device, B=args.batch, N=n_step, d=d4, bf16=bf)
             out["roofline_weight_grad"] = weight_grad_leg(device, B=args.batch, N=n_step, d=d4, bf16=bf)
+            out["roofline_backward"] = [backward_legs(device, B=args.batch, N=n_step, T=args.seq_len, d=d4, bf16=bf)]
             if world == 1:
                 out["hot_path"] = [hot_path_leg(device, n_step, lay, B=args.batch, T=args.seq_len, d=d4, K=args.num_cls, bf16=bf)
                                    for lay in ("lm", "cm")]
         else:
             # per-GPU kernel, the same on every rank; image features location-major [B,N,d], as the channels_last
             # encoder of the timed step hands them over (no copy in between)
-            out["roofline"] = roofline_leg(device)
-            # the same kernel on the reference's own layout (NCHW encoder -> channel-major [B,d,N] behind a permuted view)
+            # THE roofline object: the dominant kernel at the shape the timed step runs it at (224x224 -> 7x7 = 49 locations)
+            out["roofline"] = roofline_leg(device, B=args.batch, N=n_step, T=args.seq_len)
+            # the same kernel at the reference's default grid (448x448 -> 14x14 = 196 locations: SURVEY 8d's per-unit figure)
+            out["roofline_reference_grid"] = roofline_leg(device)
+            # ... and on the reference's own layout (NCHW encoder -> channel-major [B,d,N] behind a permuted view)
             out["roofline_channel_major"] = roofline_leg(device, layout="cm")
-            # the same kernel at the timed step's own grid (224x224 -> 7x7 = 49 locations)
-            out["roofline_at_step_shape"] = roofline_leg(device, B=args.batch, N=n_step, T=args.seq_len)
             out["roofline_projection"] = projection_leg(device)
             out["roofline_weight_grad"] = weight_grad_leg(device)
+            out["roofline_backward"] = [backward_legs(device, B=args.batch, N=n_step, T=args.seq_len), backward_legs(device)]
             if world == 1:
                 out["hot_path"] = [hot_path_leg(device, n, lay) for n in (196, 49) for lay in ("lm", "cm")]
     if rank == 0:

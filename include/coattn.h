@@ -90,6 +90,14 @@ int coattn_version(void);
 /* last error message of the calling thread ("" if none) */
 const char* coattn_last_error(void);
 
+/* Per-kernel timing of the calls this THREAD makes between the two (bench.py's per-kernel roofline legs; nothing a
+ * training loop calls).  coattn_profile_begin records a HIP event on `stream`; every launch group of coattn_forward /
+ * coattn_backward issued afterwards on this thread records one more behind it.  coattn_profile_end synchronises on the
+ * last event and returns the number of marks n (<= max_marks), with us[i] = microseconds between mark i-1 and mark i and
+ * `names` = the n mark names joined by '\n' (truncated to names_bytes).  Not for use under graph capture. */
+int coattn_profile_begin(void* stream);
+int coattn_profile_end(float* us, char* names, int names_bytes, int max_marks);
+
 /* 1 if a fused-kernel configuration exists for this shape (for channel-major or location-major V), else 0 */
 int coattn_fused_supported(int B, int N, int T, int d, int L, int dtype);
 

@@ -60,19 +60,29 @@ def _worker(rank, world, port, q, exchange="allreduce"):
         red.finish()
         grads_step.append({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
         opt.step()
-    # the peer-mapped exchange needs GPU buckets: on CPU tensors it refuses on every rank alike (no rank left in a collective)
+    # the peer-mapped exchange needs GPU buckets: on CPU tensors every rank alike falls back to the all-reduce (no rank
+    # left in a collective, no exception in the middle of a run) and records why
     nb = len(red.buckets)
     red.reset("p2p")
-    loss = crit(model(x[sl], [qq[sl] for qq in Qs]), label[sl])
-    opt.zero_grad()
-    red.prepare()
-    loss.backward()
-    try:
+    for _ in range(2):                                   # the step that rebuilds the buckets, and a hooked one
+        loss = crit(model(x[sl], [qq[sl] for qq in Qs]), label[sl])
+        opt.zero_grad()
+        red.prepare()
+        loss.backward()
+        local = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
         red.finish()
-        refused = False
-    except RuntimeError as e:
-        refused = "GPU" in str(e)
-    assert refused
+    assert red.exchange == "allreduce" and "GPU" in red.fallback_reason
+    import torch.distributed as dist
+    for n, p in model.named_parameters():                # averaged: the mean of the ranks' local gradients
+        if p.grad is not None:
+            tot = local[n].clone()
+            dist.all_reduce(tot)
+            assert torch.allclose(p.grad, tot / world, atol=1e-7, rtol=1e-5), n
+    try:
+        vdist.GradReducer(model, exchange="none")        # a timing leg of bench.py (reset()), never a training mode
+        raise AssertionError("exchange='none' must be refused by the constructor")
+    except ValueError:
+        pass
     # plain numpy through the queue (tensor fd-sharing dies with the worker)
     q.put((rank, red.unused, nb, {n: g.numpy() for n, g in grads_step[0].items()},
            {n: p.detach().numpy().copy() for n, p in model.named_parameters()}))
@@ -187,3 +197,69 @@ def test_direct_exchange_world3_matches_allreduce():
                 assert (a == b).all()                                           # a re-set reducer: the same values
         for a, b in zip(out["local"], out["reset_none"]):
             assert (a == b).all()                                               # "none": local gradients, untouched
+
+
+def _worker8(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from vqa_amd import dist as vdist, train as T
+    vdist.init_from_env("gloo")
+    torch.manual_seed(0)
+    model = T.build_model("attention", 10000, 1000)      # BASELINE config 3's model: 12.18 M live trainable parameters
+    live = [(n, p) for n, p in model.named_parameters() if p.requires_grad and "W_b" not in n]
+
+    def backward(step):
+        # gradient of parameter i on rank r at step s = the constant (r + 1) * (i % 7 + 1) + s: a loss that is linear in
+        # the parameters gives exactly that through autograd (hooks fire as in a real backward), W_b gets none
+        loss = sum((p * float((rank + 1) * (i % 7 + 1) + step)).sum() for i, (_, p) in enumerate(live))
+        loss.backward()
+
+    out = {}
+    red = vdist.GradReducer(model, exchange="direct")     # default 16 MB buckets, as the trainer builds it
+    for exchange in ("direct", "p2p"):                    # (p2p on CPU: falls back to all-reduce on its 4 * world padding)
+        if exchange != "direct":
+            red.reset(exchange)
+        for step in range(2):
+            for _, p in live:
+                p.grad = None
+            red.prepare()
+            backward(step)
+            red.finish()
+        mean = (world + 1) / 2.0
+        ok = all(torch.allclose(p.grad, torch.full_like(p, mean * (i % 7 + 1) + 1.0), rtol=1e-6)
+                 for i, (_, p) in enumerate(live))
+        pad = world if exchange == "direct" else 4 * world
+        out[exchange] = dict(ok=ok, buckets=len(red.buckets), payload=red.payload_bytes(),
+                             padded=[b.flat.numel() for b in red.buckets], pad_ok=all(b.flat.numel() % pad == 0 for b in red.buckets),
+                             unused=red.unused, final=red.exchange)
+    q.put((rank, out))
+    vdist.shutdown()
+
+
+@pytest.mark.timeout(600)
+def test_world8_direct_exchange_at_the_real_payload():
+    """Eight ranks (the node the scaling run uses) over gloo, the attention model's real gradient layout -- 48.7 MB in
+    16 MB buckets: the one-shot exchange's shard arithmetic (bucket sizes padded to the world size; 4 x world for the
+    peer-mapped variant's 16-byte shards) gives the rank mean on every rank, through the hooked path too."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=540) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for _, out in res:
+        for ex in ("direct", "p2p"):
+            o = out[ex]
+            assert o["ok"] and o["pad_ok"], (ex, o)
+            assert o["unused"] == ["co_attention.W_b.weight", "co_attention.W_b.bias"]
+            assert o["payload"] == res[0][1][ex]["payload"] and 48e6 < o["payload"] < 49.5e6, o["payload"]
+            assert 3 <= o["buckets"] <= 4
+        assert out["direct"]["final"] == "direct" and out["p2p"]["final"] == "allreduce"

@@ -16,7 +16,61 @@ void coattn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int coattn_version(void) { return 401; }   // 0.4.1: coattn_p2p_*, COATTN_FLAG_BF16_IN; the reduced-precision mode through the fused kernels
+extern "C" int coattn_version(void) { return 500; }   // 0.5.0: widths of the fp32 mode (COATTN_FLAG_EXACT3 / _SPLIT2), coattn_profile_*
+
+// ---------------------------------------------------------------------------------------
+// per-kernel timing (bench.py's backward roofline legs): HIP events recorded between the launches of the calls made
+// on this thread between coattn_profile_begin and coattn_profile_end
+// ---------------------------------------------------------------------------------------
+namespace {
+constexpr int kProfMax = 48;
+struct Prof {
+  bool on = false;
+  int n = 0, created = 0;
+  hipEvent_t ev[kProfMax + 1];
+  const char* name[kProfMax];
+};
+thread_local Prof g_prof;
+}  // namespace
+
+void prof_mark(hipStream_t s, const char* name) {
+  Prof& p = g_prof;
+  if (!p.on || p.n >= kProfMax) return;
+  if (hipEventRecord(p.ev[p.n + 1], s) != hipSuccess) { p.on = false; return; }
+  p.name[p.n++] = name;
+}
+
+extern "C" int coattn_profile_begin(void* stream) {
+  Prof& p = g_prof;
+  while (p.created <= kProfMax) {
+    if (hipEventCreate(&p.ev[p.created]) != hipSuccess) { coattn_set_error("profile: hipEventCreate failed"); return -3; }
+    ++p.created;
+  }
+  p.n = 0;
+  if (hipEventRecord(p.ev[0], (hipStream_t)stream) != hipSuccess) { coattn_set_error("profile: hipEventRecord failed"); return -3; }
+  p.on = true;
+  return 0;
+}
+
+extern "C" int coattn_profile_end(float* us, char* names, int names_bytes, int max_marks) {
+  Prof& p = g_prof;
+  CA_CHECK_ARG(p.on || p.n > 0, "profile: no coattn_profile_begin on this thread (or an event could not be recorded)");
+  p.on = false;
+  CA_CHECK_ARG(us && max_marks >= p.n, "profile: room for %d marks needed", p.n);
+  if (p.n == 0) return 0;
+  if (hipEventSynchronize(p.ev[p.n]) != hipSuccess) { coattn_set_error("profile: hipEventSynchronize failed"); return -3; }
+  int o = 0;
+  if (names && names_bytes > 0) names[0] = 0;
+  for (int i = 0; i < p.n; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]) != hipSuccess) { coattn_set_error("profile: hipEventElapsedTime failed"); return -3; }
+    us[i] = ms * 1000.f;
+    if (names && o < names_bytes - 1) o += snprintf(names + o, (size_t)(names_bytes - o), "%s%s", i ? "\n" : "", p.name[i]);
+  }
+  const int n = p.n;
+  p.n = 0;
+  return n;
+}
 extern "C" const char* coattn_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------------------------------
@@ -276,10 +330,13 @@ int general_projections(const Ctx& c, const float* V, const float* const* Q, con
     if (q_w) jobs[nj++] = WSplit{(const float*)p->W_q, const_cast<void*>(wq.Wf), c.d, c.d, 0, c.d, wimg_pieces(wq)};
     if (q_w && keep_wqT) jobs[nj++] = WSplit{(const float*)p->W_q, sv + sp.wqT, c.d, c.d, 1, c.d, wimg_pieces(wq)};
     CA_TRY(launch_wsplit(jobs, nj, c.s));
+    prof_mark(c.s, "wsplit");
   }
   if (v_w && q_w) {                                   // both projections in one launch
     const WGemm both[2] = {wv, wq};
-    return launch_gemm_wx(both, 2, c.s);
+    CA_TRY(launch_gemm_wx(both, 2, c.s));
+    prof_mark(c.s, "projections");
+    return 0;
   }
   if (v_w) CA_TRY(launch_gemm_wx(&wv, 1, c.s));
   else CA_TRY(proj_v(c, V, (const float*)p->W_v, (const float*)p->b_v, sv + sp.Pv));

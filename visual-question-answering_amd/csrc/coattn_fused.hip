@@ -74,12 +74,18 @@ int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, c
   a.bf16 = bf16;
   a.np = (np == 2 && !bf16) ? 2 : 3;
   CA_TRY(fused32_forward(a, s));
-  if (lm) return launch_attend_v_lm(V, vl.sB, a.av, v_out, B, N, d, L, s);
+  prof_mark(s, "coattn_fwd32");
+  if (lm) {
+    CA_TRY(launch_attend_v_lm(V, vl.sB, a.av, v_out, B, N, d, L, s));
+    prof_mark(s, "attend_v");
+    return 0;
+  }
   dim3 grid(d / 64, B);
   if (N <= 64)
     hipLaunchKernelGGL(attend_v_kernel<4>, grid, dim3(256), 0, s, V, vl.sB, a.av, v_out, B, N, d, L);
   else
     hipLaunchKernelGGL(attend_v_kernel<13>, grid, dim3(256), 0, s, V, vl.sB, a.av, v_out, B, N, d, L);
   CA_CHECK_LAUNCH("attend_v");
+  prof_mark(s, "attend_v");
   return 0;
 }

@@ -356,6 +356,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   pa.dsv = ws + wo.dsv; pa.dZq = ws + wo.dZq; pa.dwq_part = ws + wo.dwq_part; pa.dcs_part = ws + wo.dcs_part;
   pa.B = B; pa.N = N; pa.T = T; pa.d = d; pa.L = L;
   CA_TRY(launch_pre(pa, s));
+  prof_mark(s, "bwd_pre");
   // 2. the two recompute kernels
   BwdArgs ba;
   ba.Pv = saved + so.Pv; ba.Pq = saved + so.Pq; ba.C = saved + so.C; ba.dsv = ws + wo.dsv; ba.dZq = ws + wo.dZq;
@@ -367,6 +368,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   ba.np = np;
   ba.dp_bf16 = 0;
   CA_TRY(launch_bwd_dc32(ba, s));                    // dC, dA                       (coattn_bwd32.hip)
+  prof_mark(s, "bwd_dc32");
   // which of the backward's GEMMs take the hand-scheduled kernels (decided here: when all three do, they share ONE
   // launch in step 5 -- weight gradients, the dQ projection's tiles and the small reductions)
   float* dPv = ws + wo.dPv;
@@ -415,6 +417,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     }
   }
   CA_TRY(launch_bwd_nat32(ba, s));                   // dP_q, dP_v, dw_v, db_v, db_q (coattn_bwd32.hip)
+  prof_mark(s, "bwd_nat32");
   // 3. small parameter gradients from the per-(sample, level) partials (dw_v, db_v, db_q, dw_q, and dc_v, dc_q as
   //    whole-array sums): a few short workgroups -- riding along in the weight-gradient launch of step 5 when that
   //    is the hand-scheduled one, else a launch of their own
@@ -449,7 +452,10 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   //    accumulate input); channel-major features with unaligned rows (N % 4 != 0): the exact-f32 kernel first, then
   //    the projection onto it.
   //    When the projection shares the weight-gradient launch (step 5), the dA V kernel runs after that launch.
-  if (dq32 && !combine) CA_TRY(dq_projection(false));
+  if (dq32 && !combine) {
+    CA_TRY(dq_projection(false));
+    prof_mark(s, "bwd_gemm_dq_projection");
+  }
   auto run_dq = [&]() -> int {
     DqArgs da;
     da.accumulate = dq32 ? 1 : 0;
@@ -483,6 +489,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
       else hipLaunchKernelGGL((bwd_dq_kernel<13, false>), grid, block, lds, s, da);
     }
     CA_CHECK_LAUNCH("bwd_dq");
+    prof_mark(s, "bwd_dq");
     return 0;
   };
   if (!combine) CA_TRY(run_dq());
@@ -540,9 +547,12 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     CA_TRY(small_reductions());
     const TnGemm both[2] = {tnv, tnq};
     CA_TRY(launch_gemm_bf_tn(both, spp, parts, 2, s));
+    prof_mark(s, "bwd_gemm_dw");
     if (combine) CA_TRY(run_dq());
-    return launch_reduce_partials2(part, (float*)pg->dW_v, parts[0], tnq.C, (float*)pg->dW_q, parts[1], (int64_t)d * d,
-                                   accumulate, s);
+    CA_TRY(launch_reduce_partials2(part, (float*)pg->dW_v, parts[0], tnq.C, (float*)pg->dW_q, parts[1], (int64_t)d * d,
+                                   accumulate, s));
+    prof_mark(s, "reduce_partials");
+    return 0;
   }
   if (tn_v && tn_q) {
     // both weight gradients in one launch: 32 split-K parts (x 16 tiles = the 512 workgroup slots) shared in
@@ -558,9 +568,12 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     CA_CHECK_ARG(parts_v + parts_q <= kMaxParts, "fused backward: %d split-K parts exceed the workspace", parts_v + parts_q);
     const TnGemm both[2] = {tnv, tnq};
     CA_TRY(launch_gemm_tn(both, ks, S, 2, s, &small, combine ? &wdq : nullptr));
+    prof_mark(s, combine ? "bwd_gemm" : "bwd_gemm_dw");
     if (combine) CA_TRY(run_dq());
-    return launch_reduce_partials2(part, (float*)pg->dW_v, parts_v, tnq.C, (float*)pg->dW_q, parts_q, (int64_t)d * d,
-                                   accumulate, s);
+    CA_TRY(launch_reduce_partials2(part, (float*)pg->dW_v, parts_v, tnq.C, (float*)pg->dW_q, parts_q, (int64_t)d * d,
+                                   accumulate, s));
+    prof_mark(s, "reduce_partials");
+    return 0;
   }
   tnq.C = part;
   CA_TRY(small_reductions());

@@ -62,6 +62,12 @@ struct DeviceOnce {
   }
 };
 
+// ---- per-kernel timing marks (coattn_profile_begin / _end, api.hip) ----------------------------------------------
+// Between coattn_profile_begin and coattn_profile_end on the calling thread, prof_mark(s, name) records a HIP event on `s`:
+// the time since the previous mark is attributed to `name` (the launches issued in between).  Off (one thread-local
+// load, no HIP call) otherwise -- in particular under graph capture.
+void prof_mark(hipStream_t s, const char* name);
+
 // ---- wave64 reductions ------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -32,6 +32,7 @@ model shards naturally by QA pair, so the only exchange step is the gradient mea
 """
 from __future__ import annotations
 
+import logging
 import os
 from typing import List
 
@@ -72,6 +73,8 @@ def shutdown():
 
 
 EXCHANGES = ("allreduce", "direct", "p2p", "none")
+TRAINING_EXCHANGES = ("allreduce", "direct", "p2p")    # "none" keeps gradients local: a timing leg (reset()), never a mode to train in
+log = logging.getLogger("vqa_amd.dist")
 
 
 class _Bucket:
@@ -102,8 +105,11 @@ class GradReducer:
         self.module = module
         self.group = group
         self.exchange = exchange or os.environ.get("VQA_GRAD_EXCHANGE", "allreduce")
-        if self.exchange not in EXCHANGES:
-            raise ValueError("exchange must be one of %s, got %r" % (", ".join(EXCHANGES), self.exchange))
+        if self.exchange not in TRAINING_EXCHANGES:
+            # ("none" would train on unreduced gradients without a word: it exists for bench.py's compute-only leg and
+            #  is reachable through reset() only)
+            raise ValueError("exchange must be one of %s, got %r" % (", ".join(TRAINING_EXCHANGES), self.exchange))
+        self.fallback_reason = None                    # set when exchange="p2p" could not be set up and all-reduce took over
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.world = dist.get_world_size(group)
         self.buckets: List[_Bucket] | None = None      # built after the first backward
@@ -151,11 +157,35 @@ class GradReducer:
                 self._where[p] = (bi, pi)
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         if self.exchange == "p2p":
-            self._p2p_setup()
+            self._p2p_setup_or_fall_back()
 
     # -- p2p exchange: peer-mapped buckets ------------------------------------------------------
+    def _p2p_setup_or_fall_back(self):
+        """exchange="p2p" has only ever run with ranks sharing one GPU.  If mapping a peer or
+        switching peer access on fails on ANY rank, every rank drops to RCCL's all-reduce -- the decision is itself
+        all-reduced, so the ranks cannot disagree -- and says why once, instead of raising in the middle of a run."""
+        err = None
+        try:
+            self._p2p_setup()
+        except Exception as e:                         # noqa: BLE001 -- whatever the mapping raised, the step must go on
+            err = "%s: %s" % (type(e).__name__, e)
+        bad = torch.tensor([1 if err else 0], dtype=torch.int32, device=self.buckets[0].flat.device)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.group)
+        if int(bad.item()) == 0:
+            self._tok = torch.zeros(1, device=self._dev)
+            self._p2p_sync()
+            return
+        for b in self.buckets:
+            b.peers, b.peer_ptrs = None, None
+        self.fallback_reason = err or "a peer rank could not map this rank's buckets"
+        self.exchange = "allreduce"                    # (the buckets' padding is harmless for the all-reduce)
+        if dist.get_rank(self.group) == 0 or err:
+            log.warning("GradReducer: exchange='p2p' unavailable (%s); using RCCL all-reduce", self.fallback_reason)
+
     def _p2p_setup(self):
-        """Map every peer's buckets into this process (once per bucket layout)."""
+        """Map every peer's buckets into this process (once per bucket layout).  Exactly one collective
+        (all_gather_object), which every rank reaches whether or not its own part failed -- a rank that raises afterwards
+        leaves no peer waiting (the caller's consensus all-reduce comes next on every rank)."""
         import ctypes as C
         from torch.multiprocessing.reductions import reduce_tensor
         from . import _lib
@@ -164,10 +194,17 @@ class GradReducer:
         for b in self.buckets:
             if b.flat.dtype != torch.float32 or not b.flat.is_cuda:
                 raise RuntimeError("exchange='p2p' takes fp32 gradients on a GPU")
-        torch.cuda.synchronize()
-        mine = [reduce_tensor(b.flat) for b in self.buckets]           # (rebuild function, IPC handle + offset) per bucket
+        self._dev = self.buckets[0].flat.device
+        torch.cuda.synchronize(self._dev)
+        try:
+            mine = [reduce_tensor(b.flat) for b in self.buckets]       # (rebuild function, IPC handle + offset) per bucket
+        except Exception as e:                                         # noqa: BLE001
+            mine = "%s: %s" % (type(e).__name__, e)
         every = [None] * self.world
         dist.all_gather_object(every, mine, group=self.group)
+        for r, m in enumerate(every):
+            if isinstance(m, str):
+                raise RuntimeError("rank %d could not export its buckets (%s)" % (r, m))
         for bi, b in enumerate(self.buckets):
             b.peers = [b.flat if r == self.rank else every[r][bi][0](*every[r][bi][1]) for r in range(self.world)]
             for r, t in enumerate(b.peers):
@@ -180,15 +217,14 @@ class GradReducer:
                         _lib.check(self._lib.coattn_p2p_enable_peer(t.device.index), "coattn_p2p_enable_peer")
                     b.flat.new_empty(4).copy_(t[:4])
             b.peer_ptrs = (C.c_void_p * self.world)(*[t.data_ptr() for t in b.peers])
-        self._tok = torch.zeros(1, device=self.buckets[0].flat.device)
-        self._p2p_sync()
 
     def _p2p_sync(self):
         """Every rank's work enqueued so far is done before any rank's later work starts."""
         if dist.get_backend(self.group) == "nccl":
-            dist.all_reduce(self._tok, group=self.group)              # on the stream: the host does not block
+            with torch.cuda.device(self._dev):
+                dist.all_reduce(self._tok, group=self.group)          # on the stream: the host does not block
         else:
-            torch.cuda.synchronize()
+            torch.cuda.synchronize(self._dev)
             dist.barrier(group=self.group)
 
     def _p2p_release(self):
@@ -197,20 +233,23 @@ class GradReducer:
         self._p2p_sync()
         for b in self.buckets:
             b.peers, b.peer_ptrs = None, None                          # unmap before the owners free
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(self._dev)
         dist.barrier(group=self.group)
 
     def _p2p_finish(self):
         from . import _lib
-        stream = torch.cuda.current_stream().cuda_stream
+        # (the buckets' own device and its current stream, whatever device the caller has selected: as head.py / loss.py)
+        stream = torch.cuda.current_stream(self._dev).cuda_stream
         self._p2p_sync()                                               # every rank's buckets are packed
-        for b in self.buckets:
-            _lib.check(self._lib.coattn_p2p_reduce_scatter(b.peer_ptrs, self.world, self.rank, b.flat.numel() // self.world,
-                                                           1.0 / self.world, stream), "coattn_p2p_reduce_scatter")
+        with torch.cuda.device(self._dev):
+            for b in self.buckets:
+                _lib.check(self._lib.coattn_p2p_reduce_scatter(b.peer_ptrs, self.world, self.rank, b.flat.numel() // self.world,
+                                                               1.0 / self.world, stream), "coattn_p2p_reduce_scatter")
         self._p2p_sync()                                               # every shard is reduced
-        for b in self.buckets:
-            _lib.check(self._lib.coattn_p2p_all_gather(b.peer_ptrs, self.world, self.rank, b.flat.numel() // self.world,
-                                                       stream), "coattn_p2p_all_gather")
+        with torch.cuda.device(self._dev):
+            for b in self.buckets:
+                _lib.check(self._lib.coattn_p2p_all_gather(b.peer_ptrs, self.world, self.rank, b.flat.numel() // self.world,
+                                                           stream), "coattn_p2p_all_gather")
         self._p2p_sync()                                               # nobody still reads a bucket that is packed next
 
     def _launch(self, b):

@@ -67,8 +67,10 @@ def parse():
     ap.add_argument("--no-runahead", dest="runahead", action="store_false",
                     help="run the frozen image encoder in series with the rest of the step (default: one step "
                          "ahead on its own HIP stream)")
-    ap.add_argument("--model", default="attention", choices=["attention", "attention_resnet"],
-                    help="developer switch: attention_resnet + --opt-lvl 1 --num-cls 3000 is BASELINE config 4")
+    ap.add_argument("--model", default="attention", choices=["attention", "attention_resnet", "attention_bert"],
+                    help="attention (BASELINE config 2 / 3, the headline); attention_resnet + --opt-lvl 1 --num-cls 3000 is "
+                         "BASELINE config 4; attention_bert is BASELINE config 5 (frozen BERT-base token embeddings, 768-d, as "
+                         "the word level; run it with --gpus 4)")
     ap.add_argument("--opt-lvl", type=int, default=0, help="developer switch: >0 = bf16 autocast (not the headline)")
     ap.add_argument("--stock-graph", action="store_true",
                     help="run the frozen encoder's Sequential as is (default: ReLU/MaxPool swap and conv bias folded "
@@ -689,6 +691,8 @@ def main():
     device = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(device)
     torch.manual_seed(0)
+    if args.model == "attention_bert":               # token ids are BERT's own WordPiece ids
+        args.vocab = T.BERT_VOCAB
     model = T.build_model(args.model, args.vocab, args.num_cls).to(device)
     if args.channels_last:
         model.image_encoder.to(memory_format=torch.channels_last)
@@ -724,7 +728,10 @@ def main():
                                       args.image_size, args.image_size, n_grid, model.co_attention.hidden_dim,
                                       args.seq_len, args.vocab,
                                       "fp32" if args.opt_lvl == 0 else "bf16 autocast",
-                                      "VGG11-bn" if args.model == "attention" else "ResNet-152 (hidden 2048)",
+                                      {"attention": "VGG11-bn", "attention_resnet": "ResNet-152 (hidden 2048)",
+                                       "attention_bert": "VGG11-bn; word level = Linear(768 -> 512) over frozen random-init "
+                                                         "BERT-base token embeddings (BertEmbeddings, vocab 30,522) in place of the "
+                                                         "learned embedding (BASELINE config 5)"}[args.model],
                                       "channels_last" if args.channels_last else "NCHW",
                                       (", encoder one step ahead on its own stream" if trainer.runahead else "")
                                       + ("" if args.stock_graph else ", ReLU after MaxPool, conv bias folded into BN running mean")),
@@ -767,9 +774,22 @@ def main():
                                "backend": torch.distributed.get_backend(),
                                "note": "headline value = the allreduce run; 'none' keeps gradients local (timing only)"}
     if world > 1:
-        if rank == 0 and trainer.reducer is not None:
-            out["allreduce_payload_mb"] = round(trainer.reducer.payload_bytes() / 1e6, 2)
-            out["allreduce_buckets"] = len(trainer.reducer.buckets or [])
+        # self-verifying scaling line: what the communicator itself reports, and which physical GPU every rank ran on
+        # (N distinct UUIDs = N GPUs; ranks sharing a device would show here)
+        props = torch.cuda.get_device_properties(device)
+        mine = {"rank": rank, "local_device": device.index, "gpu": props.name, "uuid": str(getattr(props, "uuid", "unknown")),
+                "host": os.uname().nodename}
+        every = [None] * world
+        torch.distributed.all_gather_object(every, mine)
+        if rank == 0:
+            out["rccl_world_size"] = torch.distributed.get_world_size()
+            out["dist_backend"] = torch.distributed.get_backend()
+            out["ranks"] = every
+            out["distinct_gpus"] = len({e["uuid"] for e in every})
+            if trainer.reducer is not None:
+                out["allreduce_payload_mb"] = round(trainer.reducer.payload_bytes() / 1e6, 2)
+                out["allreduce_buckets"] = len(trainer.reducer.buckets or [])
+                out["grad_exchange_fallback"] = trainer.reducer.fallback_reason
         vdist.shutdown()
     if rank == 0 and not args.no_extras:
         del trainer, model, batch

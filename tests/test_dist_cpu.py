@@ -263,3 +263,82 @@ def test_world8_direct_exchange_at_the_real_payload():
             assert o["payload"] == res[0][1][ex]["payload"] and 48e6 < o["payload"] < 49.5e6, o["payload"]
             assert 3 <= o["buckets"] <= 4
         assert out["direct"]["final"] == "direct" and out["p2p"]["final"] == "allreduce"
+
+
+def _worker_bert(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from vqa_amd import dist as vdist
+    vdist.init_from_env("gloo")
+    model, batch = _bert_model_and_batch()
+    sl = slice(rank * 4 // world, (rank + 1) * 4 // world)
+    red = vdist.GradReducer(model, bucket_mb=0.05)
+    crit = torch.nn.CrossEntropyLoss()
+    for step in range(2):
+        model.zero_grad(set_to_none=True)
+        red.prepare()
+        crit(model(batch[0][sl], batch[1][sl], batch[2][sl]), batch[3][sl]).backward()
+        red.finish()
+    bucketed = sorted(n for b in red.buckets for p in b.params for n, pp in model.named_parameters() if pp is p)
+    q.put((rank, red.unused, bucketed, red.payload_bytes(),
+           {n: p.grad.numpy().copy() for n, p in model.named_parameters() if p.grad is not None}))
+    vdist.shutdown()
+
+
+def _bert_model_and_batch():
+    """BASELINE config 5's trainable subgraph on the CPU: QuestionBertCoAttentionEncoder (frozen BERT token embeddings ->
+    Linear(768 -> d) word level, phrase and sentence levels on top) -> co-attention -> MLP, image features fixed."""
+    from oracle.coattn_oracle import OracleMLPClassifier, OracleParallelCoAttention
+    from vqa_amd import train as T
+    from vqa_amd.modules import QuestionBertCoAttentionEncoder
+    d, K, B, N, Tq = 32, 7, 4, 9, 6
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.question_encoder = QuestionBertCoAttentionEncoder(**T.bert_question_params(hidden_dim=d, vocab_size=50, bert_dim=16))
+            self.co_attention = OracleParallelCoAttention(d, as_executed=False)
+            self.mlp_classify = OracleMLPClassifier(d, 2 * d, K)
+
+        def forward(self, x_img, tok, lens):
+            return self.mlp_classify(*self.co_attention(x_img, list(self.question_encoder(tok, lens))))
+    torch.manual_seed(0)
+    net = Net()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, N, d, generator=g).clamp_min(0)
+    lens = torch.tensor([Tq, Tq, Tq, Tq])                # equal lengths: every shard packs the same way
+    tok = torch.randint(2, 50, (B, Tq), generator=g)
+    return net, (x, tok, lens, torch.arange(B) % K)
+
+
+@pytest.mark.timeout(300)
+def test_config5_bert_word_level_world2():
+    """BASELINE config 5 over two gloo ranks: the frozen BERT embeddings never enter a bucket (they need no gradient),
+    W_b is discovered as unused, and the averaged half-batch gradients are the full-batch gradients."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bert, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    model, batch = _bert_model_and_batch()
+    torch.nn.CrossEntropyLoss()(model(*batch[:3]), batch[3]).backward()
+    full = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    live = sum(p.numel() for n, p in model.named_parameters() if p.requires_grad and "W_b" not in n)
+    for _, unused, bucketed, payload, grads in res:
+        assert unused == ["co_attention.W_b.weight", "co_attention.W_b.bias"]
+        assert not any("bert" in n for n in bucketed) and any("word_proj" in n for n in bucketed)
+        assert payload == 4 * live
+        for n, g in full.items():
+            if n.endswith("w_v.bias") or n.endswith("w_q.bias"):
+                continue                                 # analytically zero (softmax shift invariance): rounding noise
+            assert torch.allclose(torch.from_numpy(grads[n]), g, atol=2e-6, rtol=1e-4), n
+    for n in res[0][4]:
+        assert (res[0][4][n] == res[1][4][n]).all(), n

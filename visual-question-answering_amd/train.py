@@ -50,11 +50,25 @@ def int_min_two(k):
     return k
 
 
-def setup_model_configs(model_name: str, vocab_size: int, vgg_train: bool = False, vgg_wts_path=None) -> dict:
-    """--model -> class, image size and encoder parameters (main.py:388-418).  The 'attention'
-    entry's ``mlp_dim`` key is carried but never forwarded by the reference (main.py:164), so the
+def setup_model_configs(args, vocab_size: int, vgg_train: bool = False, vgg_wts_path=None) -> dict:
+    """--model -> class, image size and encoder parameters (main.py:388-418).  Called as the reference calls it,
+    ``setup_model_configs(args, vocab_size)`` with the parsed command line (main.py:388: ``args.model``,
+    ``args.vgg_train``, ``args.vgg_wts_path`` are read), or with the model name and the two VGG settings spelled out.
+    The 'attention' entry's ``mlp_dim`` key is carried but never forwarded by the reference (main.py:164), so the
     model's own default (1024, model.py:160) applies; both are 1024."""
+    if isinstance(args, str):
+        model_name = args
+    else:                                            # the reference's argparse namespace
+        model_name = args.model
+        vgg_train = getattr(args, "vgg_train", vgg_train)
+        vgg_wts_path = getattr(args, "vgg_wts_path", vgg_wts_path)
     img = dict(is_trainable=vgg_train, weights_path=vgg_wts_path or PATH_VGG_WEIGHTS)
+    if model_name == "attention_bert":
+        # BASELINE config 5 (extension; the reference lists BERT as a TODO, README.md:137-141): the attention model with
+        # frozen BERT-base token embeddings (768-d, WordPiece vocabulary of 30,522; built from the config -- random init,
+        # there is no network for checkpoints) projected to the hidden size as the word level.  `vocab_size` is BERT's own.
+        return dict(model=HierarchicalCoAttentionNet, image_size=(448, 448), image_params=img,
+                    question_params=bert_question_params(hidden_dim=512), mlp_dim=1024, vocab_size=BERT_VOCAB)
     registry = {
         "baseline": dict(model=VQABaselineNet, image_size=(224, 224), image_params=img,
                          question_params=dict(vocab_size=vocab_size, word_emb_dim=300, hidden_dim=1024)),
@@ -71,7 +85,10 @@ def setup_model_configs(model_name: str, vocab_size: int, vgg_train: bool = Fals
     return registry[model_name]      # 'bert' is accepted by the reference's argparse but has no entry: KeyError
 
 
-def bert_question_params(hidden_dim: int = 512, vocab_size: int = 30522, bert_dim: int = 768) -> dict:
+BERT_VOCAB = 30522                   # bert-base-uncased's WordPiece vocabulary
+
+
+def bert_question_params(hidden_dim: int = 512, vocab_size: int = BERT_VOCAB, bert_dim: int = 768) -> dict:
     """Question-encoder parameters for BASELINE config 5: frozen BERT-base token embeddings (random
     init -- no network for checkpoints) in place of the learned word embedding."""
     from transformers import BertConfig
@@ -341,7 +358,7 @@ class Trainer:
 def main(argv=None):
     ap = argparse.ArgumentParser(description="Visual Question Answering (MI355X co-attention path)")
     ap.add_argument("--mode", default="train", choices=["train", "test"])
-    ap.add_argument("--model", default="attention", choices=["baseline", "attention", "bert", "attention_resnet"])
+    ap.add_argument("--model", default="attention", choices=["baseline", "attention", "bert", "attention_resnet", "attention_bert"])
     ap.add_argument("--num_cls", "-K", type=int_min_two, default=1000)
     ap.add_argument("--batch_size", "-bs", type=int, default=8)
     ap.add_argument("--num_steps", type=int, default=20)
@@ -376,9 +393,9 @@ def main(argv=None):
         # one thread per logical CPU oversubscribes a containerised rank (measured: 39.7 vs 26.3 ms/step)
         torch.set_num_threads(max(1, min(4, usable_cpus())))
     torch.manual_seed(0)                                        # identical weights on every rank
-    cfg = setup_model_configs(args.model, args.vocab_size, args.vgg_train, args.vgg_wts_path)
-    model = build_model(args.model, args.vocab_size, args.num_cls, vgg_train=args.vgg_train,
-                        vgg_wts_path=args.vgg_wts_path)
+    cfg = setup_model_configs(args, args.vocab_size)             # (as main.py:388)
+    args.vocab_size = cfg.get("vocab_size", args.vocab_size)     # attention_bert: token ids are BERT's
+    model = cfg["model"](cfg["question_params"], cfg["image_params"], K=args.num_cls + 1)
     if args.model_ckpt:
         model.load_state_dict(torch.load(args.model_ckpt, map_location="cpu"))
     model.to(device)

@@ -6,6 +6,7 @@
 //   attend_v_kernel : v_l = a_{v,l}^T V for all levels with ONE more pass over a channel-major V [d][N]
 //   (the location-major twin is attend_v_lm_kernel in coattn_fwd32.hip).
 #include "fused.h"
+#include <stdlib.h>
 
 
 namespace {
@@ -69,12 +70,19 @@ int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, c
   a.wv = (const float*)p->w_v; a.cv = (const float*)p->c_v; a.wq = (const float*)p->w_q; a.cq = (const float*)p->c_q;
   a.C = saved + so.C; a.av = saved + so.av; a.aq = saved + so.aq; a.Hq = saved + so.Hq;
   a.q_out = q_out;
+  // Small grids (the 7 x 7 grid of 224 x 224 images: N = 49) on location-major features: the attended image feature
+  // v_l = a_v^T V is computed by the affinity kernel's own workgroup -- its 100 KB of V come from L2, where phase 1 left
+  // them, in less time than a second launch costs.  (At N = 196 the separate pass over V stays: DESIGN.md section 3.1.)
+  static const int fuse_v_env = [] { const char* e = getenv("COATTN_FUSE_V"); return e ? atoi(e) : 1; }();   // developer switch
+  const bool fuse_v = lm && N <= 64 && d % 512 == 0 && fuse_v_env;
+  a.v_out = fuse_v ? v_out : nullptr;
   a.stamps = COATTN_STAMPS ? reinterpret_cast<unsigned long long*>(ws) : nullptr;
   a.B = B; a.N = N; a.T = T; a.d = d; a.L = L;
   a.bf16 = bf16;
   a.np = (np == 2 && !bf16) ? 2 : 3;
   CA_TRY(fused32_forward(a, s));
   prof_mark(s, "coattn_fwd32");
+  if (fuse_v) return 0;
   if (lm) {
     CA_TRY(launch_attend_v_lm(V, vl.sB, a.av, v_out, B, N, d, L, s));
     prof_mark(s, "attend_v");

@@ -64,8 +64,10 @@ __device__ __forceinline__ void vmcnt_wait(int n) {
 // NP = 1 (SP, single product): the reduced-precision mode (COATTN_FLAG_BF16_PROJ) -- every operand of BOTH phases rounded once
 // to bf16, ONE MFMA per product (the hi x hi term of the split; the mid / lo pieces are neither computed, stored in the
 // LDS image nor read back).
-template <int NT, int NW, bool LM, int NP>
+// FV: the kernel also attends the image features, v_l = a_v^T V (model.py:391) -- location-major V, NT = 2, four waves.
+template <int NT, int NW, bool LM, int NP, bool FV = false>
 __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs a) {
+  static_assert(!FV || (LM && NT == 2 && NW == 4), "the fused v pass: location-major features, N <= 64, 256 threads");
   constexpr bool SP = NP == 1;
   constexpr int NPAD = 32 * NT;
   constexpr int SLD = 36;                            // row stride of the f32 reduction slots [n][t = 32]: 16-byte accesses
@@ -78,7 +80,8 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
   float* svpart = slot0;                             // [NW * 4][NPAD]   (aliases slot0 from phase 2 on)
   float* sqpart = slot0 + NW * 4 * NPAD;             // [NW * 2][32]
   float* aqs = sqpart + NW * 2 * 32;                 // 32
-  static_assert(NW * 4 * NPAD + NW * 2 * 32 + 32 <= SLOT_FLOATS, "phase-2 scratch must fit the slot");
+  float* avs = aqs + 32;                             // [NPAD]  a_v for the fused v pass (FV)
+  static_assert(NW * 4 * NPAD + NW * 2 * 32 + 32 + NPAD <= SLOT_FLOATS, "phase-2 scratch must fit the slot");
   static_assert(SLOT_FLOATS * 4 <= 3 * PIECE * 2, "slot 1 must fit inside the image region");
 
   int b, l;
@@ -657,6 +660,18 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
 #pragma unroll
     for (int t = 0; t < kTRows; ++t)
       xq[i][t] = buf_load1(rs_q, (t * d + tid + i * NW * 64) * 4, 0);   // sweeps past d: rows past T or junk, unused
+  // FV: v = sum_n a_v[n] V[n][:] by this workgroup.  A thread takes four consecutive channels (128 threads cover d = 512;
+  // wider d: sweeps of 512) and every other location row (tid >> 7 picks the parity): 16-byte loads, a wave reads two whole
+  // 1 KB row segments per instruction.  The rows of the first sweep's first half (locations < 32) are requested here, before
+  // the softmaxes; rows >= N lie outside the sample's buffer and read 0.  V was streamed by phase 1: it comes from L2.
+  constexpr int VB = 16;                             // rows per thread and batch (two batches cover 64 locations)
+  const int v_c4 = tid & 127, v_par = tid >> 7;
+  const int v_voff = (v_par * d + 4 * v_c4) * 4;
+  f32x4 xv0[FV ? VB : 1], xv1[FV ? VB : 1];
+  if constexpr (FV) {
+#pragma unroll
+    for (int i = 0; i < VB; ++i) xv0[i] = buf_load4(rs_v, v_voff, 2 * i * d * 4);
+  }
   lds_barrier();                                     // every wave's score partials are in LDS
   CA_STAMP(4);
   if (w == 0) {
@@ -691,6 +706,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
     for (int k = 0; k < PER; ++k) {
       const int n = lane + 64 * k;
       if (n < N) avg[n] = sc[k] * inv;
+      if (FV) avs[n] = sc[k] * inv;                  // (zeros beyond N)
     }
   }
   if (w == 1) {
@@ -728,6 +744,26 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
 #pragma unroll
     for (int t = 0; t < kTRows; ++t) acc = fmaf(aqr[t], x[t], acc);
     a.q_out[pair * (size_t)d + dd] = acc;
+  }
+  if constexpr (FV) {
+    f32x4* vpart = reinterpret_cast<f32x4*>(Cimg);   // [128] the odd rows' partial sums (the image is dead by now)
+    for (int c0 = 0; c0 < d; c0 += 512) {            // sweeps of 512 channels (one at d = 512)
+      if (c0 > 0) {
+#pragma unroll
+        for (int i = 0; i < VB; ++i) xv0[i] = buf_load4(rs_v, v_voff, (2 * i * d + c0) * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < VB; ++i) xv1[i] = buf_load4(rs_v, v_voff, (2 * (VB + i) * d + c0) * 4);
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < VB; ++i) acc += xv0[i] * avs[v_par + 2 * i];
+#pragma unroll
+      for (int i = 0; i < VB; ++i) acc += xv1[i] * avs[v_par + 2 * (VB + i)];
+      if (c0 > 0) lds_barrier();                     // the previous sweep's partial sums have been read
+      if (v_par) vpart[v_c4] = acc;
+      lds_barrier();
+      if (!v_par) *reinterpret_cast<f32x4*>(a.v_out + pair * (size_t)d + c0 + 4 * v_c4) = acc + vpart[v_c4];
+    }
   }
   CA_STAMP(5);
 }
@@ -791,7 +827,7 @@ __global__ __launch_bounds__(256) void attend_v_lm_kernel(const float* V, long v
   }
 }
 
-template <int NT, int NW, bool LM, int NP>
+template <int NT, int NW, bool LM, int NP, bool FV = false>
 int launch_fwd32(const FwdArgs& a, hipStream_t s) {
   constexpr int NPAD = 32 * NT;
   constexpr int RING_SLOTS = (NT + 1) * ((NT + 1 >= 6) ? 1 : 2);
@@ -799,12 +835,12 @@ int launch_fwd32(const FwdArgs& a, hipStream_t s) {
   const size_t lds = lds_p2 > lds_p1 ? lds_p2 : lds_p1;
   static DeviceOnce once;                            // the attribute is per device
   CA_TRY(once.run([&] {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(coattn_fwd32_kernel<NT, NW, LM, NP>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(coattn_fwd32_kernel<NT, NW, LM, NP, FV>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }, "coattn_fwd32"));
   const int groups = (a.B + 7) / 8;
   dim3 grid(groups * a.L * 8), block(NW * 64);
-  hipLaunchKernelGGL((coattn_fwd32_kernel<NT, NW, LM, NP>), grid, block, lds, s, a);
+  hipLaunchKernelGGL((coattn_fwd32_kernel<NT, NW, LM, NP, FV>), grid, block, lds, s, a);
   CA_CHECK_LAUNCH("coattn_fwd32");
   return 0;
 }
@@ -814,6 +850,12 @@ int dispatch_fwd32(const FwdArgs& a, hipStream_t s) {
   const bool small_n = a.N <= 64;
   const bool w2 = a.np == 2;                         // phase 2 on two pieces
   if (a.d % 512 == 0) {
+    if constexpr (LM) {
+      if (small_n && a.v_out) {                      // the kernel attends the image features too (FwdArgs::v_out)
+        if (a.bf16) return launch_fwd32<2, 4, true, 1, true>(a, s);
+        return w2 ? launch_fwd32<2, 4, true, 2, true>(a, s) : launch_fwd32<2, 4, true, 3, true>(a, s);
+      }
+    }
     if (a.bf16) return small_n ? launch_fwd32<2, 4, LM, 1>(a, s) : launch_fwd32<7, 4, LM, 1>(a, s);
     if (w2) return small_n ? launch_fwd32<2, 4, LM, 2>(a, s) : launch_fwd32<7, 4, LM, 2>(a, s);
     return small_n ? launch_fwd32<2, 4, LM, 3>(a, s) : launch_fwd32<7, 4, LM, 3>(a, s);
@@ -824,7 +866,10 @@ int dispatch_fwd32(const FwdArgs& a, hipStream_t s) {
 
 }  // namespace
 
-int fused32_forward(const FwdArgs& a, hipStream_t s) { return a.lm ? dispatch_fwd32<true>(a, s) : dispatch_fwd32<false>(a, s); }
+int fused32_forward(const FwdArgs& a, hipStream_t s) {
+  CA_CHECK_ARG(!a.v_out || (a.lm && a.N <= 64 && a.d % 512 == 0), "fused forward: the in-kernel v pass needs location-major features, N <= 64, d %% 512 == 0");
+  return a.lm ? dispatch_fwd32<true>(a, s) : dispatch_fwd32<false>(a, s);
+}
 
 int launch_attend_v_lm(const float* V, long v_sB, const float* av, float* v_out, int B, int N, int d, int L, hipStream_t s) {
   CA_CHECK_ARG(N <= 256 && L <= 3 && d % 128 == 0, "attend_v (location-major): unsupported shape");

@@ -274,6 +274,8 @@ struct FwdArgs {
   float* aq;             // [L][B][T]
   float* Hq;             // [L][B][T][d]
   float* q_out;          // [L][B][d]
+  float* v_out;          // [L][B][d]: written by the kernel itself when it also attends the image features (location-major
+                         // features on N <= 64 locations; otherwise NULL and attend_v(_lm)_kernel follows)
   unsigned long long* stamps;   // diagnostic builds only
   int B, N, T, d, L;
   int bf16;              // reduced-precision mode: operands rounded to bf16, one MFMA per product (d % 512 == 0)

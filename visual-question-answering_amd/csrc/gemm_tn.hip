@@ -24,10 +24,9 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 16;
 constexpr int LDT = BM + 32;                   // [k][row] image row stride (elements): conflict-free writes + transposed reads
 constexpr int IMG = BK * LDT;                  // one piece image
-constexpr int OPER = 3 * IMG;                  // the three pieces of one operand
 // BCM (B contiguous along the contraction index: channel-major image features): [col][k] images, 48-byte rows
 // (conflict-free ds_read_b128 fragments)
-constexpr int LDRB = 24, IMGB = BN * LDRB, OPERB = 3 * IMGB;
+constexpr int LDRB = 24, IMGB = BN * LDRB;
 
 struct TnArgs {
   const float* A; long a_sl; int a_ld;         // level l at A + l * a_sl
@@ -61,6 +60,8 @@ template <bool SUM3, bool BCM, int NP>
 __device__ __forceinline__ void gemm_tn_body(const TnArgs& g, const int bid, const int nblk, short* const lds) {
   static_assert(NP >= 1 && NP <= 3, "pieces per operand");
   constexpr bool P1 = NP == 1;
+  // (only the pieces of the width are staged: two pieces -> 41 KB of LDS per workgroup)
+  constexpr int OPER = NP * IMG, OPERB = NP * IMGB;
   constexpr int BUF = OPER + (BCM ? OPERB : OPER);                         // elements of one LDS buffer
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
@@ -260,8 +261,8 @@ __device__ __forceinline__ void gemm_tn_body(const TnArgs& g, const int bid, con
 // SUM3 / BCM describe job 0; job 1 is always plain.  The backward's whole GEMM work is ONE launch of this kernel:
 // [small reductions][dW_v parts][dW_q parts][tiles of dQ = dP_q W_q on the gemm_w body].
 template <bool SUM3, bool BCM, int NP>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnJobs jobs) {
-  extern __shared__ __attribute__((aligned(16))) short lds_dyn[];          // 2 buffers: 61,440 B (BCM: 67,584 B)
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnJobs jobs) {   // (three workgroups per CU at two pieces -- 168 VGPRs -- spill: 135 -> 163 us)
+  extern __shared__ __attribute__((aligned(16))) short lds_dyn[];          // 2 buffers: 61,440 B at three pieces (BCM: 67,584 B)
   const int id = (int)blockIdx.x - jobs.nred, ngemm = (int)gridDim.x - jobs.nred - jobs.nw;
   if (id >= ngemm) {                                 // (61,440 B of the dynamic LDS)
     gw::gemm_w_body<false, NP>(jobs.wj, id - ngemm, lds_dyn);
@@ -351,8 +352,11 @@ int launch_gemm_tn(const TnGemm* d, const int* ksplit, const int* S, int n, hipS
   CA_CHECK_ARG(n == 1 || (d[1].a_term == 0 && d[1].b_kdiv == 0), "gemm_tn: only the first job may sum three A terms or have a k-contiguous B");
   const bool sum3 = d[0].a_term != 0, bcm = d[0].b_kdiv != 0;
   const dim3 grid((unsigned)(jobs.nred + nb[0] + nb[1] + jobs.nw));
-  const size_t lds = (size_t)2 * (OPER + (bcm ? OPERB : OPER)) * sizeof(short);
   const int np = d[0].bf16 ? 1 : (d[0].np == 2 ? 2 : 3);
+  // two buffers of the staged pieces; the dQ projection's tiles (gemm_w_body) need 2 * np * 10,240 B of it
+  size_t lds = (size_t)2 * np * (IMG + (bcm ? IMGB : IMG)) * sizeof(short);
+  if (wextra && lds < (size_t)2 * np * gw::BM * gw::LDR * sizeof(short)) lds = (size_t)2 * np * gw::BM * gw::LDR * sizeof(short);
+  const size_t lds_max = (size_t)2 * 3 * (IMG + IMGB) * sizeof(short);     // (three pieces, BCM: 67,584 B)
   auto np_of = [](int bf16, int npf) { return bf16 ? 1 : (npf == 2 ? 2 : 3); };
   CA_CHECK_ARG((n == 1 || np_of(d[1].bf16, d[1].np) == np) && (!wextra || np_of(wextra->bf16, wextra->np) == np),
                "gemm_tn: the jobs of a launch share the precision mode");
@@ -363,7 +367,7 @@ int launch_gemm_tn(const TnGemm* d, const int* ksplit, const int* S, int n, hipS
       const void* fns[6] = {reinterpret_cast<const void*>(gemm_tn_kernel<true, true, 3>), reinterpret_cast<const void*>(gemm_tn_kernel<false, true, 3>),
                             reinterpret_cast<const void*>(gemm_tn_kernel<true, true, 2>), reinterpret_cast<const void*>(gemm_tn_kernel<false, true, 2>),
                             reinterpret_cast<const void*>(gemm_tn_kernel<true, true, 1>), reinterpret_cast<const void*>(gemm_tn_kernel<false, true, 1>)};
-      for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
       return e;
     }, "gemm_tn"));
   }

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void wsplit_kernel(const SplitArgs a) {
 // the first one's last, partial round of workgroups would leave idle.  AM0: layout of job 0's A operand.
 template <bool AM0, int NP, int NW = 4>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_w_kernel(const WJobs jobs) {
-  __shared__ __attribute__((aligned(16))) short smem[2 * 3 * BM * LDR];  // 61,440 B: two workgroups of 256 threads per CU
+  __shared__ __attribute__((aligned(16))) short smem[2 * NP * BM * LDR];  // three pieces: 61,440 B; two workgroups of 256 threads per CU
   static_assert(BM * LDR == BK * LDT, "both image layouts have the same size");
   if ((int)blockIdx.x < jobs.first1) gemm_w_body<AM0, NP, NW>(jobs.job[0], (int)blockIdx.x, smem);
   else gemm_w_body<false, NP, NW>(jobs.job[1], (int)blockIdx.x - jobs.first1, smem);

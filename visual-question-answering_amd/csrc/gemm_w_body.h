@@ -223,7 +223,7 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
 #pragma unroll
   for (int k = 0; k < 6; ++k) { load_b(0, k, 0); load_b(1, k, 1); }
   short* const img0 = smem;
-  short* const img1 = smem + 3 * IMG;
+  short* const img1 = smem + NP * IMG;               // (only the pieces of the width are staged)
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
 #pragma unroll

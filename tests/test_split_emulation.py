@@ -17,7 +17,8 @@ from . import _golden as G
 # products (operands truncated to 16 significand bits, mid*mid dropped: ~2^-16 relative per product)
 WIDTHS = {
     "affinity": 3,      # A = Q V^T                                   coattn_fwd32 phase 1
-    "proj": 3,          # P_v = V W_v^T, P_q = Q W_q^T                gemm_w   (two pieces: H_q off by 2e-4, see below)
+    "proj": 3,          # P_v = V W_v^T                               gemm_w   (two pieces: H_q off by 2e-4, see below)
+    "proj_q": 2,        # P_q = Q W_q^T                               gemm_w   (reaches H_v summed over T <= 28 tokens only)
     "h": 2,             # C^T P_q, C P_v                              coattn_fwd32 phase 2
     "bwd": 2,           # recomputed C^T P_q, C dZ_v, C^T dZ_q, dC    bwd_nat32 / bwd_dc32
     "dq": 2,            # dA V                                        bwd_dq32(x)
@@ -71,7 +72,7 @@ def emulate(V_phys, Qs, P, gv, gq, W):
     dQs = []
     for l, Q in enumerate(Qs):
         Q = Q.double()
-        Pq = f32(mm(Q, Wq.T, W["proj"]) + bq)
+        Pq = f32(mm(Q, Wq.T, W.get("proj_q", W["proj"])) + bq)
         C = f32(torch.tanh(mm(Q, V_phys, W["affinity"])))
         Ct = C.transpose(1, 2)
         H_v = torch.tanh(Pv + mm(Ct, Pq, W["h"]))
@@ -156,6 +157,7 @@ if __name__ == "__main__":
         tables["only_" + k] = dict(EXACT, **{k: 2})
     tables["no_proj"] = dict(WIDTHS, proj=3)
     tables["no_proj_h"] = dict(WIDTHS, proj=3, h=3)
+    tables["projq2"] = dict(WIDTHS, proj_q=2)
     tables["fp16_fwd"] = dict(WIDTHS, proj="2h", h="2h")
     tables["fp16_fwd_only"] = dict(EXACT, proj="2h", h="2h")
     tables["fp16_all"] = {k: "2h" for k in WIDTHS}

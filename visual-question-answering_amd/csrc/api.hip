@@ -220,6 +220,7 @@ struct Ctx {
   hipStream_t s;
   VLayout vl;                 // element strides of x_img[B,N,d]
   bool bf16_proj = false;     // COATTN_FLAG_BF16_PROJ: the projections and their gradients on the bf16 MFMA
+  int np_pq = 3;              // width of the P_q projection in the fp32 mode (3 | 2)
   float pscale = 1.f;         // factor on P_v, P_q as stored (fused path: kPScale, fused.h)
 };
 
@@ -287,6 +288,10 @@ static int np_bwd(int flags) {
   static const int split = env_int("COATTN_SPLIT", 2);
   return ((flags & COATTN_FLAG_EXACT3) || split == 3) ? 3 : 2;
 }
+static int np_projq(int flags) {                    // P_q = Q W_q^T: its error reaches H_v summed over T <= 28 tokens only
+  static const int split = env_int("COATTN_SPLIT", 2), pq = env_int("COATTN_SPLIT_PQ", 2);
+  return ((flags & COATTN_FLAG_EXACT3) || split == 3) ? 3 : (pq == 2 ? 2 : 3);
+}
 static int np_fwd(int flags) {
   static const int split = env_int("COATTN_SPLIT", 2), fwd = env_int("COATTN_SPLIT_FWD", 2);
   return ((flags & COATTN_FLAG_EXACT3) || split == 3) ? 3 : (fwd == 2 ? 2 : 3);
@@ -312,6 +317,7 @@ int general_projections(const Ctx& c, const float* V, const float* const* Q, con
   wq.a_sm = c.d; wq.Wf = wimg + wsplit_bytes(c.d, c.d); wq.C = sv + sp.Pq; wq.c_sz = (long)BTd; wq.c_sm = c.d;
   wq.bias_n = (const float*)p->b_q; wq.out_scale = c.pscale; wq.M = c.B * c.T; wq.N = c.d; wq.K = c.d; wq.batch = c.L;
   wv.bf16 = wq.bf16 = c.bf16_proj ? 1 : 0;          // reduced precision: the same kernels, hi pieces only, one MFMA per product
+  wv.np = 3; wq.np = c.np_pq;                        // fp32 mode: P_v on the exact split, P_q on two pieces (tests/test_split_emulation.py)
   const bool w_ok = gemm_w_enabled();
   bool v_w = false;
   if (w_ok && c.vl.sD == 1 && c.vl.sB == (long)c.N * c.vl.sN && c.vl.sN < (1L << 24)) {
@@ -564,6 +570,7 @@ static int forward_impl(const void* V, const VLayout& vl, const void* const* Q, 
   float* tail = (float*)ws + sp.total;
   Ctx c{B, N, T, d, L, (hipStream_t)stream, vl};
   c.bf16_proj = (flags & COATTN_FLAG_BF16_PROJ) != 0;
+  c.np_pq = fused ? np_projq(flags) : 3;              // (the general-shape path stays exact throughout)
   c.pscale = fused ? kPScale : 1.f;
   if (do_proj)
     CA_TRY(general_projections(c, (const float*)V, (const float* const*)Q, p, sv,

@@ -65,13 +65,16 @@ __device__ __forceinline__ void gemm_tn_body(const TnArgs& g, const int bid, con
   constexpr int BUF = OPER + (BCM ? OPERB : OPER);                         // elements of one LDS buffer
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
-  // the tiles of one part share an XCD (ids equal mod 8): they read the same rows of A and B
+  // XCD-aware order (workgroup i runs on XCD i % 8): the (part, tile) pairs in part-major order are cut into eight runs,
+  // one per XCD -- the tiles of one part (they read the same rows of A and B) then share an XCD's L2 and run side by
+  // side, whatever the number of parts (before: only for the first parts & ~7 of them; 23 parts left 7 spread over all
+  // eight XCDs, their operands fetched once per XCD)
   const int ntn = g.N / BN, ntiles = (g.M / BM) * ntn;
   int z, t;
   {
-    const int id = bid, nz8 = (nblk / ntiles) & ~7;                        // parts covered by the XCD-grouped range
-    if (id < nz8 * ntiles) { z = (id & 7) + 8 * (id / (8 * ntiles)); t = (id >> 3) % ntiles; }
-    else { const int r = id - nz8 * ntiles; z = nz8 + r / ntiles; t = r % ntiles; }
+    int lin = bid;
+    if ((nblk & 7) == 0) lin = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    z = lin / ntiles; t = lin % ntiles;
   }
   if (g.mask_blk > 0 && !((g.tile_mask >> (((t / ntn) / g.mask_blk) * 3 + (t % ntn) / g.mask_blk)) & 1u)) return;
   const int m0 = (t / ntn) * BM, n0 = (t % ntn) * BN;

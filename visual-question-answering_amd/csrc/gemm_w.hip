@@ -61,13 +61,14 @@ __global__ __launch_bounds__(256) void wsplit_kernel(const SplitArgs a) {
 }
 
 // Up to two independent GEMMs per launch (P_v and P_q of the forward): the second one's workgroups fill the slots
-// the first one's last, partial round of workgroups would leave idle.  AM0: layout of job 0's A operand.
-template <bool AM0, int NP, int NW = 4>
+// the first one's last, partial round of workgroups would leave idle.  AM0: layout of job 0's A operand; NP / NP1: the
+// widths of job 0 / job 1 (the forward runs P_v on three pieces and P_q on two in one launch).
+template <bool AM0, int NP, int NW = 4, int NP1 = NP>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_w_kernel(const WJobs jobs) {
-  __shared__ __attribute__((aligned(16))) short smem[2 * NP * BM * LDR];  // three pieces: 61,440 B; two workgroups of 256 threads per CU
+  __shared__ __attribute__((aligned(16))) short smem[2 * (NP > NP1 ? NP : NP1) * BM * LDR];  // three pieces: 61,440 B; two workgroups of 256 threads per CU
   static_assert(BM * LDR == BK * LDT, "both image layouts have the same size");
   if ((int)blockIdx.x < jobs.first1) gemm_w_body<AM0, NP, NW>(jobs.job[0], (int)blockIdx.x, smem);
-  else gemm_w_body<false, NP, NW>(jobs.job[1], (int)blockIdx.x - jobs.first1, smem);
+  else gemm_w_body<false, NP1, NW>(jobs.job[1], (int)blockIdx.x - jobs.first1, smem);
 }
 
 }  // namespace
@@ -141,7 +142,8 @@ int launch_gemm_w(const WGemm* d, int n, hipStream_t s) {
   CA_CHECK_ARG(nb[0] + nb[1] < 2147483647L, "gemm_w: grid too large");
   jobs.first1 = (int)nb[0];
   CA_CHECK_ARG(n == 1 || d[1].a_sk == 0, "gemm_w: only the first job may have an m-contiguous A operand");
-  CA_CHECK_ARG(n == 1 || (d[1].bf16 == d[0].bf16 && (d[1].np == 2) == (d[0].np == 2)), "gemm_w: the jobs of a launch share the precision mode");
+  CA_CHECK_ARG(n == 1 || d[1].bf16 == d[0].bf16, "gemm_w: the jobs of a launch share the precision mode");
+  const bool two0 = d[0].np == 2, two1 = n == 2 ? d[1].np == 2 : two0;      // fp32 mode: the width of each job
   const dim3 grid((unsigned)(nb[0] + nb[1]));
   if (wide) {
     if (d[0].a_sk) hipLaunchKernelGGL((gemm_w_kernel<true, 1, 8>), grid, dim3(512), 0, s, jobs);
@@ -149,9 +151,15 @@ int launch_gemm_w(const WGemm* d, int n, hipStream_t s) {
   } else if (d[0].bf16) {
     if (d[0].a_sk) hipLaunchKernelGGL((gemm_w_kernel<true, 1>), grid, dim3(256), 0, s, jobs);
     else hipLaunchKernelGGL((gemm_w_kernel<false, 1>), grid, dim3(256), 0, s, jobs);
-  } else if (d[0].np == 2) {
+  } else if (two0 && two1) {
     if (d[0].a_sk) hipLaunchKernelGGL((gemm_w_kernel<true, 2>), grid, dim3(256), 0, s, jobs);
     else hipLaunchKernelGGL((gemm_w_kernel<false, 2>), grid, dim3(256), 0, s, jobs);
+  } else if (two1) {                                  // P_v exact, P_q on two pieces
+    if (d[0].a_sk) hipLaunchKernelGGL((gemm_w_kernel<true, 3, 4, 2>), grid, dim3(256), 0, s, jobs);
+    else hipLaunchKernelGGL((gemm_w_kernel<false, 3, 4, 2>), grid, dim3(256), 0, s, jobs);
+  } else if (two0) {
+    if (d[0].a_sk) hipLaunchKernelGGL((gemm_w_kernel<true, 2, 4, 3>), grid, dim3(256), 0, s, jobs);
+    else hipLaunchKernelGGL((gemm_w_kernel<false, 2, 4, 3>), grid, dim3(256), 0, s, jobs);
   } else {
     if (d[0].a_sk) hipLaunchKernelGGL((gemm_w_kernel<true, 3>), grid, dim3(256), 0, s, jobs);
     else hipLaunchKernelGGL((gemm_w_kernel<false, 3>), grid, dim3(256), 0, s, jobs);

@@ -79,11 +79,15 @@ def test_graphed_function_matches_the_autograd_path():
     for a, b in zip(ref, grads()):
         # (3 * g: one rounding apart; the biases of w_v / w_q have analytically zero gradients: rounding noise ~1e-8)
         assert (a - b).abs().max() <= 1e-6 * a.abs().max().item() + 1e-7
-    # inputs at other addresses: a second graph pair is captured; a non-contiguous layout goes through the static inputs
+    # inputs at other addresses: a second graph pair is captured; a layout the kernels do not run on (channel-major rows
+    # of 49 floats) is re-laid once, as on the eager path, and read from that buffer: one more address set
     x2 = x.clone()
     _, l3 = hp(x2, [q.detach().clone() for q in Qs], lab)
     _, l4 = hp(x.permute(0, 2, 1).contiguous().permute(0, 2, 1), [q.detach() for q in Qs], lab)
-    assert torch.equal(l3, lref) and torch.equal(l4, lref) and len(hp._pairs) == 3
+    assert torch.equal(l3, lref) and torch.equal(l4, lref) and len(hp._pairs) == 4
+    # float64 question features cannot be read in place: they go through the static inputs (no new pair)
+    _, l5 = hp(x, [q.detach().double() for q in Qs], lab)
+    assert torch.equal(l5, lref) and len(hp._pairs) == 4
     assert co.W_b.weight.grad is None
 
 

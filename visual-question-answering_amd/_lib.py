@@ -145,6 +145,25 @@ def check(rc: int, what: str) -> None:
         raise RuntimeError("%s failed (%d): %s" % (what, rc, load().coattn_last_error().decode()))
 
 
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def on_device(dev):
+    """Context manager that makes `dev` the current device for the C-ABI call inside (per-device one-time kernel
+    attributes are keyed by it) -- a no-op object when it already is: ``torch.cuda.device`` costs ~10 us of host time per
+    entry, the hot path enters it four times per step."""
+    import torch
+    return _NO_GUARD if dev.index is None or dev.index == torch.cuda.current_device() else torch.cuda.device(dev)
+
+
 _ws_cache = {}
 
 

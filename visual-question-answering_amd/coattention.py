@@ -88,7 +88,7 @@ class _CoAttentionFn(torch.autograd.Function):
         ws = _lib.scratch(fb, dev, stream)            # per-stream scratch, reused from call to call
         qptr = (C.c_void_p * L)(*[q.data_ptr() for q in Qs])
         p = _lib.Params(*[t.data_ptr() for t in params])
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(lib.coattn_forward(_ptr(V), *_strides(V), qptr, C.byref(p), _ptr(out_v), _ptr(out_q), _ptr(saved),
                                           _ptr(ws), B, N, T, d, L, _lib.F32, impl, C.c_void_p(stream)),
                        "coattn_forward")
@@ -121,7 +121,7 @@ class _CoAttentionFn(torch.autograd.Function):
         p = _lib.Params(*[t.data_ptr() for t in params])
         qptr = (C.c_void_p * L)(*[q.data_ptr() for q in Qs])
         dqptr = (C.c_void_p * L)(*[q.data_ptr() for q in dQs])
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(lib.coattn_backward(_ptr(V), *_strides(V), qptr, C.byref(p), _ptr(saved), _ptr(g_v), _ptr(g_q),
                                            _ptr(dV), *(_strides(dV) if need_dv else (0, 0, 0)), dqptr, C.byref(pg), 0,
                                            _ptr(ws), B, N, T, d, L, _lib.F32, impl, C.c_void_p(stream)),

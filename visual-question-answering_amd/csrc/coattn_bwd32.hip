@@ -106,8 +106,10 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
       if (NP >= 2) *reinterpret_cast<u32x2*>(Cimg + PIECE + off) = u32x2{mm[0], mm[1]};
       if (NP == 3) *reinterpret_cast<u32x2*>(Cimg + 2 * PIECE + off) = u32x2{ll[0], ll[1]};
     }
-    const float* dg = a.dsv + pair * (size_t)N;
-    for (int e = tid; e < NPAD; e += NTHR) dsvs[e] = e < N ? dg[e] : 0.f;
+    if (w == NW - 1) {                               // ds_v of this (sample, level); its sum is the dc_v partial
+      const float tot = softmax_bwd_v(a, b, l, lane, dsvs, NPAD);
+      if (lane == 0) a.dcs_part[pair] = tot;
+    }
   }
   lds_barrier();
 
@@ -365,8 +367,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc32_kernel(const BwdArgs a) {
       if (NP >= 2) *reinterpret_cast<u32x2*>(Cimg + PIECE + off) = u32x2{mm[0], mm[1]};
       if (NP == 3) *reinterpret_cast<u32x2*>(Cimg + 2 * PIECE + off) = u32x2{ll[0], ll[1]};
     }
-    const float* dg = a.dsv + pair * (size_t)N;
-    for (int e = tid; e < NPAD; e += NTHR) dsvs[e] = e < N ? dg[e] : 0.f;
+    if (w == NW - 1) softmax_bwd_v(a, b, l, lane, dsvs, NPAD);   // ds_v of this (sample, level), as bwd_nat32_kernel computes it
   }
   lds_barrier();
   const int ntiles = (N + 31) >> 5;

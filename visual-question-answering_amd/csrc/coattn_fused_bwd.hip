@@ -4,8 +4,9 @@
 //
 // H_v [N,d] is never stored: both big kernels recompute it from P_v, P_q and C (saved).
 //
-//   bwd_pre_kernel  (per sample, all levels)  one pass over V: da_v = V gv -> softmax backward
-//                   ds_v; da_q = Q gq -> ds_q; dZ_q = ds_q (x) w_q (.) (1 - H_q^2); dw_q / dc partials.
+//   bwd_pre_kernel  (per sample, all levels)  one pass over V: da_v = V gv partials (the image side's softmax backward
+//                   ds_v is finished in the prologues of the two big kernels); da_q = Q gq -> ds_q;
+//                   dZ_q = ds_q (x) w_q (.) (1 - H_q^2); dw_q / dc_q partials.
 //   bwd_dc32_kernel (coattn_bwd32.hip; per sample x level, orientation [d][n], bf16 MFMA with the exact 3-way
 //                   split): H_v^T tile = P_v^T + P_q^T C -> dZ_v^T, and dC += P_q dZ_v^T + dZ_q P_v^T with the
 //                   dZ_v^T / P_v^T fragments as MFMA B operands (contraction over d); cross-wave sum through
@@ -92,39 +93,6 @@ struct PreArgs {
   float* dcs_part;                       // [2][L*B]
   int B, N, T, d, L;
 };
-
-// Image side, one wave per (sample, level): da_v = sum of the channel-chunk partials; ds_v = a_v (da_v - <a_v, da_v>);
-// dc_v partial.  (A launch of its own behind bwd_pre_kernel, whose extra blocks produce the partials.)
-__global__ __launch_bounds__(64) void bwd_prev_kernel(const PreArgs a) {
-  const int N = a.N, B = a.B;
-  const int pairi = blockIdx.x, l = pairi / B, b = pairi - l * B, lane = threadIdx.x;
-  const size_t pair = (size_t)pairi;
-  const int nkc = a.nkc;
-  const float* pp = a.dav_part + (size_t)b * nkc * 3 * N + (size_t)l * N;
-  const float* avp = a.av + pair * N;
-  float da[4], avv[4];
-  float dot = 0.f, tot_v = 0.f;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int n = lane + 64 * k;
-    float sacc = 0.f;
-    if (n < N)
-      for (int kc = 0; kc < nkc; ++kc) sacc += pp[(size_t)kc * 3 * N + n];
-    da[k] = sacc;
-    avv[k] = (n < N) ? avp[n] : 0.f;
-    dot = fmaf(avv[k], sacc, dot);
-  }
-  dot = wave_sum(dot);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int n = lane + 64 * k;
-    const float v = avv[k] * (da[k] - dot);
-    if (n < N) a.dsv[pair * N + n] = v;
-    tot_v += v;
-  }
-  tot_v = wave_sum(tot_v);
-  if (lane == 0) a.dcs_part[pair] = tot_v;          // [2][L*B]
-}
 
 // Blocks [0, L*B): one workgroup (256 threads) per (sample, level), question side -- softmax backward of a_q
 // (da_q = Q gq), dZ_q = ds_q (x) w_q (.) (1 - H_q^2), dw_q / dc_q partials.  Blocks past L*B: the da_v partials
@@ -316,8 +284,8 @@ int launch_pre(const PreArgs& a, hipStream_t s) {
   const size_t lds = (size_t)(64 + a.d) * sizeof(float);           // (>= the 768 B of a channel-major da_v block)
   hipLaunchKernelGGL(bwd_pre_kernel, dim3(a.L * a.B + a.dav_gx * a.B), dim3(256), lds, s, a);
   CA_CHECK_LAUNCH("bwd_pre");
-  hipLaunchKernelGGL(bwd_prev_kernel, dim3(a.L * a.B), dim3(64), 0, s, a);
-  CA_CHECK_LAUNCH("bwd_prev");
+  // (the image side's softmax backward -- ds_v from these partials -- happens in the prologues of bwd_dc32_kernel and
+  //  bwd_nat32_kernel: fused.h softmax_bwd_v)
   return 0;
 }
 
@@ -359,7 +327,8 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   prof_mark(s, "bwd_pre");
   // 2. the two recompute kernels
   BwdArgs ba;
-  ba.Pv = saved + so.Pv; ba.Pq = saved + so.Pq; ba.C = saved + so.C; ba.dsv = ws + wo.dsv; ba.dZq = ws + wo.dZq;
+  ba.Pv = saved + so.Pv; ba.Pq = saved + so.Pq; ba.C = saved + so.C; ba.dZq = ws + wo.dZq;
+  ba.dav_part = ws + wo.part; ba.nkc = pa.nkc; ba.av = saved + so.av; ba.dcs_part = ws + wo.dcs_part;
   ba.wv = (const float*)p->w_v;
   ba.dPv = ws + wo.dPv; ba.dPq = ws + wo.dPq; ba.dA = ws + wo.dA; ba.dwv_part = ws + wo.dwv_part;
   ba.dbv_part = ws + wo.dbv_part; ba.dbq_part = ws + wo.dbq_part;

@@ -83,6 +83,9 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
   float* avs = aqs + 32;                             // [NPAD]  a_v for the fused v pass (FV)
   static_assert(NW * 4 * NPAD + NW * 2 * 32 + 32 + NPAD <= SLOT_FLOATS, "phase-2 scratch must fit the slot");
   static_assert(SLOT_FLOATS * 4 <= 3 * PIECE * 2, "slot 1 must fit inside the image region");
+  // Small grids (NT = 2): every wave has a slot of its own (4 x 9 KB inside the dead rings), the image pass adds the four
+  // -- one barrier and the add / put round of waves 0 and 2 less; same order of additions ((w0 + w1) + (w2 + w3)).
+  constexpr bool SLOT4 = NT == 2 && NW == 4;
 
   int b, l;
   if (!block_to_pair(blockIdx.x, a.B, a.L, b, l)) return;
@@ -370,7 +373,10 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
         }
     };
     // (w0 + w1) -> slot 0, (w2 + w3) -> slot 1; the image pass adds the two
-    if constexpr (NW == 4) {
+    if constexpr (SLOT4) {
+      put(slot0 + w * SLOT_FLOATS);
+      __syncthreads();
+    } else if constexpr (NW == 4) {
       if (w == 1) put(slot0);
       if (w == 3) put(slot1);
       __syncthreads();
@@ -402,9 +408,14 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
     for (int k = 0; k < PER; ++k) {
       const int e = tid + k * NW * 64, tq = e / NPAD, n = e - tq * NPAD;
       sum[k] = *reinterpret_cast<const f32x4*>(&slot0[n * SLD + 4 * tq]);
-      if constexpr (NW == 4) sum[k] += *reinterpret_cast<const f32x4*>(&slot1[n * SLD + 4 * tq]);
+      if constexpr (SLOT4) {
+        sum[k] += *reinterpret_cast<const f32x4*>(&slot0[SLOT_FLOATS + n * SLD + 4 * tq]);
+        f32x4 s23 = *reinterpret_cast<const f32x4*>(&slot0[2 * SLOT_FLOATS + n * SLD + 4 * tq]);
+        s23 += *reinterpret_cast<const f32x4*>(&slot0[3 * SLOT_FLOATS + n * SLD + 4 * tq]);
+        sum[k] += s23;
+      } else if constexpr (NW == 4) sum[k] += *reinterpret_cast<const f32x4*>(&slot1[n * SLD + 4 * tq]);
     }
-    if constexpr (NW == 4) lds_barrier();            // every read of slot 1 is done: the image may overwrite it
+    if constexpr (NW == 4) lds_barrier();            // every read of slots 1 .. is done: the image may overwrite them
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
       const int e = tid + k * NW * 64, tq = e / NPAD, n = e - tq * NPAD;

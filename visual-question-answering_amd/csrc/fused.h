@@ -287,7 +287,10 @@ struct BwdArgs {
   const float* Pv;        // [B][N][d]
   const float* Pq;        // [L][B][T][d]
   const float* C;         // [L][B][T][N]
-  const float* dsv;       // [L][B][N]
+  const float* dav_part;  // [B][nkc][3][N] channel-chunk partials of da_v = V gv (bwd_pre_kernel's extra blocks)
+  int nkc;
+  const float* av;        // saved a_v [L][B][N]
+  float* dcs_part;        // [2][L*B]: dc_v partials (written by bwd_nat32_kernel)
   const float* dZq;       // [L][B][T][d]
   const float* wv;
   float* dPv;             // [L][B][N][d]
@@ -301,6 +304,37 @@ struct BwdArgs {
   int np;                 // (bf16 = 0) width of the contractions: 3 or 2 pieces
   int dp_bf16;            // (with bf16, bwd_nat32_kernel) dPv / dPq are bf16 arrays of the same index order
 };
+
+// Image-side softmax backward of one (sample, level) by ONE wave: da_v = the sum of the channel-chunk partials,
+// ds_v = a_v (da_v - <a_v, da_v>) into the LDS array dsvs[0 .. npad) (zeros beyond N); returns sum_n ds_v (the dc_v partial,
+// valid in every lane).  Both big backward kernels run it in their prologue (same arithmetic, same values) -- it used to
+// be a launch of its own (one wave per pair, 5 us of launch latency).  N <= 256.
+__device__ __forceinline__ float softmax_bwd_v(const BwdArgs& a, int b, int l, int lane, float* dsvs, int npad) {
+  const int N = a.N, nkc = a.nkc;
+  const float* pp = a.dav_part + (size_t)b * nkc * 3 * N + (size_t)l * N;
+  const float* avp = a.av + ((size_t)l * a.B + b) * N;
+  float da[4], avv[4];
+  float dot = 0.f, tot = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int n = lane + 64 * k;
+    float sacc = 0.f;
+    if (n < N)
+      for (int kc = 0; kc < nkc; ++kc) sacc += pp[(size_t)kc * 3 * N + n];
+    da[k] = sacc;
+    avv[k] = (n < N) ? avp[n] : 0.f;
+    dot = fmaf(avv[k], sacc, dot);
+  }
+  dot = wave_sum(dot);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int n = lane + 64 * k;
+    const float v = avv[k] * (da[k] - dot);
+    if (n < npad) dsvs[n] = v;                       // (exact zeros beyond N: a_v reads as 0 there)
+    tot += v;
+  }
+  return wave_sum(tot);
+}
 
 // dP_q on the bf16 MFMA 32x32x16 with the exact 3-way split (coattn_bwd32.hip); same shapes as the fused forward
 int launch_bwd_nat32(const BwdArgs& a, hipStream_t s);

@@ -166,9 +166,12 @@ class _HotPathFn(torch.autograd.Function):
             raise RuntimeError("HotPathGraph: labels must be integer class indices (int64 [B]), got %s" % labels.dtype)
         if ctx.needs_input_grad[1] and hp.dV is None:
             raise RuntimeError("HotPathGraph: built with need_dv=False but the image features require a gradient")
-        ins = (x_img, Qw, Qp, Qs, labels)
+        # (features in a layout the kernels do not run on -- e.g. the channel-major view at N = 49, whose rows are not
+        #  16-byte multiples -- are re-laid once, as on the eager path; the allocator hands that buffer's block back step
+        #  after step, so it is one more address set, not a copy into the static input on top)
+        ins = (_native_layout(x_img), Qw, Qp, Qs, labels)
         pair = hp.pair(ins) if hp.usable_in_place(ins) else None
-        if pair is None:                                         # other layout / too many address sets: static inputs
+        if pair is None:                                         # other dtype / too many address sets: static inputs
             hp.V.copy_(x_img)
             torch._foreach_copy_(hp.Q, [Qw, Qp, Qs])
             hp.labels.copy_(labels)

@@ -76,7 +76,7 @@ class _HeadFn(torch.autograd.Function):
         lab = labels.contiguous() if labels is not None else None
         p = _lib.HeadParams(*[t.data_ptr() for t in ps])
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(lib.coattn_head_forward(_rows(v), _rows(q), C.byref(p), _ptr(lab), _ptr(logits), _ptr(loss),
                                                _ptr(saved), B, d, mlp, K, _lib.F32, ctx.flags, stream), "coattn_head_forward")
         if labels is not None:
@@ -109,7 +109,7 @@ class _HeadFn(torch.autograd.Function):
         grads = [torch.empty_like(t) for t in ps]
         p = _lib.HeadParams(*[t.data_ptr() for t in ps])
         pg = _lib.HeadParamGrads(*[t.data_ptr() for t in grads])
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(lib.coattn_head_backward(_rows(v), _rows(q), C.byref(p), _ptr(saved), _ptr(g_loss), _ptr(g_logits),
                                                 _rows(dx) if need_in else None, None, C.byref(pg), 0, _ptr(ws),
                                                 B, d, mlp, K, _lib.F32, ctx.flags, C.c_void_p(stream)), "coattn_head_backward")
@@ -124,7 +124,7 @@ def check_labels() -> None:
         return
     saved, B, d, mlp, K, dev = _last
     lib = _lib.load()
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = lib.coattn_head_status(_ptr(saved), B, d, mlp, K, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     if rc == -2:
         raise IndexError(lib.coattn_last_error().decode())

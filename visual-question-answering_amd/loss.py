@@ -41,7 +41,7 @@ class _CrossEntropyFn(torch.autograd.Function):
         need = ctx.needs_input_grad[0]
         dz = torch.empty_like(z) if need else None
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(lib.coattn_ce_forward(_ptr(z), _ptr(lab), _ptr(loss), _ptr(dz), _ptr(ws), B, K, _lib.F32,
                                              stream), "coattn_ce_forward")
         global _last
@@ -65,7 +65,7 @@ def check_labels() -> None:
         return
     ws, B, dev = _last
     lib = _lib.load()
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = lib.coattn_ce_status(_ptr(ws), B, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     if rc == -2:
         raise IndexError(lib.coattn_last_error().decode())

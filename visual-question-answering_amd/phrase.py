@@ -46,7 +46,7 @@ class _PhraseConvPoolFn(torch.autograd.Function):
         ws = torch.empty(fb, dtype=torch.uint8, device=x.device)
         p = _lib.PhraseParams(*[t.data_ptr() for t in ps])
         stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(lib.coattn_phrase_forward(_ptr(X), C.byref(p), _ptr(out), _ptr(saved), _ptr(ws), B, T, E,
                                                  _lib.F32, flags, stream), "coattn_phrase_forward")
         if need_grad:
@@ -68,7 +68,7 @@ class _PhraseConvPoolFn(torch.autograd.Function):
         p = _lib.PhraseParams(*[t.data_ptr() for t in ps])
         pg = _lib.PhraseParamGrads(*[t.data_ptr() for t in grads])
         stream = C.c_void_p(torch.cuda.current_stream(X.device).cuda_stream)
-        with torch.cuda.device(X.device):
+        with _lib.on_device(X.device):
             _lib.check(lib.coattn_phrase_backward(_ptr(X), C.byref(p), _ptr(out), _ptr(saved), _ptr(g), _ptr(dX),
                                                   C.byref(pg), 0, _ptr(ws), B, T, E, _lib.F32, ctx.flags, stream),
                        "coattn_phrase_backward")

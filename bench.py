@@ -27,9 +27,11 @@ contract fields it carries
                 TFLOP/s against the dense bf16 MFMA peak / 6 (six bf16 products per fp32 product);
                 roofline_weight_grad: the same for its weight gradient dW_v (gemm_tn_kernel + reduce)
   hot_path      isolated co-attention (+MLP+CE) fwd+bwd rates on device-resident features, N=196
-                and N=49, both feature layouts; the HIP op's fwd+bwd device time (pipelined calls) and the
-                wall time of single synchronised calls; host_enqueue_ms = host time to queue one step; graph_*: the same
-                step replayed from one captured HIP graph (vqa_amd/graph.py).
+                and N=49, both feature layouts, as train.Trainer.step runs it (one autograd node over static buffers,
+                C-ABI calls issued eagerly); host_enqueue_ms = host time to queue one step; modules_*: the same step
+                module by module (ParallelCoAttention -> MLPClassifier.forward_loss); graph_*: replayed from captured
+                HIP graphs (vqa_amd/graph.py); the HIP op's fwd+bwd device time (pipelined calls) and the wall time
+                of single synchronised calls.
 """
 from __future__ import annotations
 
@@ -143,7 +145,7 @@ def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20, b
     label = (torch.arange(B, device=device) * 7) % (K + 1)
     params = [p for p in list(co.parameters()) + list(mlp.parameters())]
 
-    def step():                                      # as Trainer.step: logits and loss out of the answer head's one call
+    def mstep():                                     # module by module: ParallelCoAttention -> MLPClassifier.forward_loss
         for p in params:
             p.grad = None
         _, loss = mlp.forward_loss(*co(x_img, Qs), label)
@@ -161,20 +163,26 @@ def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20, b
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / iters, (t1 - t0) / iters
 
-    dt, host = timed(step)
-    # the same step replayed from ONE captured HIP graph (graph.py: co-attention + head + loss, forward and backward)
+    mdt, mhost = timed(mstep)
+    # as train.Trainer.step runs it by default: the hot path as ONE autograd node over static buffers, its four C-ABI calls
+    # issued eagerly, the static gradient buffers assigned to param.grad (graph.py, capture=False, direct_grads=True) ...
     from vqa_amd.graph import HotPathGraph
-    hp = HotPathGraph(co, mlp, B, N, T, flags=_lib_flag(bf16))
+    hs = HotPathGraph(co, mlp, B, N, T, flags=_lib_flag(bf16), capture=False, direct_grads=True)
+    # ... and replayed from captured HIP graphs (Trainer(graph=True))
+    hp = HotPathGraph(co, mlp, B, N, T, flags=_lib_flag(bf16), direct_grads=True)
 
-    def gstep():
-        for p in params:
-            p.grad = None
-        for q in Qs:
-            q.grad = None
-        _, loss = hp(x_img, Qs, label)
-        loss.backward()
+    def make_step(h):
+        def f():
+            for p in params:
+                p.grad = None
+            for q in Qs:
+                q.grad = None
+            _, loss = h(x_img, Qs, label)
+            loss.backward()
+        return f
 
-    gdt, ghost = timed(gstep)
+    dt, host = timed(make_step(hs))
+    gdt, ghost = timed(make_step(hp))
     # forward + backward of the HIP op alone (C-ABI calls through the autograd function):
     #  (a) device time of a pipelined run (HIP events around `iters` back-to-back fwd+bwd calls: what the train
     #      loop sees, the host runs ahead of the GPU);
@@ -218,6 +226,8 @@ def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20, b
     flop = 3.0 * B * (2 * N * d * d + 3 * 2 * T * d * d + 3 * (3 * 2 * T * N * d + 4 * (N + T) * d))
     return {"N": N, "d": d, "K": K, "layout": layout, "mode": "reduced precision (every product ONE bf16 MFMA, fp32 accumulation; dP_v / dP_q stored as bf16)" if bf16 else "fp32",
             "pairs_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "host_enqueue_ms": round(host * 1e3, 3),
+            "step_path": "train.Trainer's default: one autograd node over static buffers, C-ABI calls issued eagerly",
+            "modules_ms_per_step": round(mdt * 1e3, 3), "modules_host_enqueue_ms": round(mhost * 1e3, 3),
             "graph_ms_per_step": round(gdt * 1e3, 3), "graph_host_enqueue_ms": round(ghost * 1e3, 3),
             "graph_pairs_per_s": round(B / gdt, 1),
             "coattn_fwd_bwd_ms": round(t_dev * 1e3, 4), "coattn_fwd_bwd_tflops": round(flop / t_dev / 1e12, 2),

@@ -190,3 +190,77 @@ def test_capture_while_another_thread_allocates():
     finally:
         stop.set()
         th.join()
+
+
+def test_eager_static_mode_and_direct_grads():
+    """HotPathGraph(capture=False): the same node issued eagerly -- bit for bit the captured replay and the module path;
+    direct_grads=True: the static gradient buffers become param.grad (no AccumulateGrad clones), accumulate onto an
+    existing .grad, and survive zero_grad(set_to_none=False)."""
+    from vqa_amd.graph import HotPathGraph
+    B, N, T, d, mlp, K = 12, 49, 26, 256, 128, 19
+    co, head = _modules(d, mlp, K, seed=11)
+    x = torch.randn(B, N, d, device="cuda").clamp_min_(0)
+    Qs = [(torch.randn(B, T, d, device="cuda") * 0.2).requires_grad_(True) for _ in range(3)]
+    lab = torch.arange(B, device="cuda") % K
+    params = [p for p in list(co.parameters()) + list(head.parameters())]
+    live = [p for p in params if p is not co.W_b.weight and p is not co.W_b.bias]
+
+    def clear():
+        for t in Qs + params:
+            t.grad = None
+
+    _, loss = head.forward_loss(*co(x, Qs), lab)
+    loss.backward()
+    ref = [t.grad.clone() for t in Qs + live]
+    clear()
+    he = HotPathGraph(co, head, B, N, T, capture=False, direct_grads=True)
+    _, l1 = he(x, Qs, lab)
+    l1.backward()
+    assert torch.equal(l1, loss.detach())
+    for a, t in zip(ref, Qs + live):
+        assert torch.equal(a, t.grad)
+    assert co.W_v.weight.grad is he.co_grads[0] and co.W_b.weight.grad is None      # the static buffer itself
+    # a second backward without clearing: the buffers hold the new gradient in place (as after zero_grad(set_to_none=False))
+    for p in live:
+        p.grad.zero_()
+    for q in Qs:
+        q.grad = None
+    _, l2 = he(x, Qs, lab)
+    l2.backward()
+    for a, t in zip(ref, Qs + live):
+        assert torch.equal(a, t.grad)
+    # gradients held elsewhere are accumulated onto
+    clear()
+    for p in live:
+        p.grad = torch.ones_like(p)
+    _, l3 = he(x, Qs, lab)
+    l3.backward()
+    for a, t in zip(ref[3:], live):
+        assert torch.allclose(t.grad, a + 1.0, rtol=0, atol=1e-6)
+    # the captured replay gives the same values
+    clear()
+    hg = HotPathGraph(co, head, B, N, T, direct_grads=True)
+    _, l4 = hg(x, Qs, lab)
+    l4.backward()
+    assert torch.equal(l4, loss.detach())
+    for a, t in zip(ref, Qs + live):
+        assert torch.equal(a, t.grad)
+
+
+def test_trainer_default_path_matches_the_module_path(monkeypatch):
+    """Three Adam steps: Trainer's default (static hot path, direct gradients) against VQA_HOT_PATH=modules."""
+    from vqa_amd import train as T
+    dev = torch.device("cuda:0")
+    losses = {}
+    for mode in ("modules", "static"):
+        monkeypatch.setenv("VQA_HOT_PATH", mode)
+        torch.manual_seed(0)
+        model = T.build_model("attention", 100, 10).to(dev)
+        tr = T.Trainer(model, 1e-4, dev)
+        assert model.hot_path_static == (mode == "static")
+        b = T.synthetic_batch(8, (64, 64), 26, 100, 11, seed=1)
+        im, qu, la, ln = T.sort_batch(b["image"], b["question"], b["label"], b["ques_len"])
+        im, qu, la = im.to(dev), qu.to(dev), la.to(dev)
+        losses[mode] = [float(tr.step(im, qu, ln, la, next_image=im).detach()) for _ in range(3)]
+    for a, b in zip(losses["modules"], losses["static"]):
+        assert abs(a - b) <= 1e-5 * abs(a)

@@ -14,6 +14,14 @@ C-ABI's strides, without a copy.  The upstream gradient of the loss is a device 
 
     hp = HotPathGraph(co_attention, mlp_classify, B, N, T)          # modules of HierarchicalCoAttentionNet
     logits, loss = hp(x_img, [Q_w, Q_p, Q_s], labels)               # autograd-aware; shapes fixed
+
+``capture=False`` keeps everything above -- static buffers, one autograd node for the whole hot path, argument blocks
+built once per address set -- but issues the four C-ABI calls EAGERLY on the current stream instead of replaying
+captured graphs: no capture, no graph-node gaps on the device, and a host cost per step close to the replay's (what is
+left is the ~25 kernel launches).  It is what ``train.Trainer`` uses by default.  ``direct_grads=True`` (the Trainer sets
+it when it owns the step: gradients are consumed by the optimiser before the next backward, and no gradient hooks need
+to fire) assigns the static gradient buffers to ``param.grad`` instead of handing them to autograd, whose AccumulateGrad
+would clone each of the 16 (it cannot steal a buffer somebody else still holds): 16 copy kernels per step less.
 """
 from __future__ import annotations
 
@@ -35,8 +43,10 @@ def _ptr(t):
 class HotPathGraph:
     MAX_KEYS = 8
 
-    def __init__(self, co_attention, mlp_classify, B: int, N: int, T: int, need_dv: bool = False, flags: int = 0):
+    def __init__(self, co_attention, mlp_classify, B: int, N: int, T: int, need_dv: bool = False, flags: int = 0,
+                 capture: bool = True, direct_grads: bool = False):
         self.co, self.mlp = co_attention, mlp_classify
+        self.capture, self.direct_grads = capture, direct_grads
         d = co_attention.hidden_dim
         mlp, K = mlp_classify.W_s.weight.shape[0], mlp_classify.W_h.weight.shape[0]
         self.dims = (B, N, T, d, mlp, K)
@@ -70,16 +80,27 @@ class HotPathGraph:
         self.hsaved = torch.empty(hsb // 4, **f32); self.hws = torch.empty(hwb // 4, **f32)
         self.g_loss = torch.ones(1, **f32)                           # upstream gradient of the loss (device scalar)
         self._pairs = {}                                             # input addresses -> (forward graph, backward graph)
+        self._plans = {}                                             # input addresses -> argument blocks of the four calls
         self._warm = False
         self._static = (self.V, self.Q[0], self.Q[1], self.Q[2], self.labels)
+        self._lib = _lib.load()
         self.pair(self._static)
 
-    # the C-ABI calls on `stream`, reading the inputs `ins` = (V [B,N,d] in a native layout, Q_w, Q_p, Q_s, labels)
-    def _enqueue(self, ins, stream, fwd=True, bwd=True):
-        lib = _lib.load()
+    def _key(self, ins):
+        return tuple(t.data_ptr() for t in ins) + tuple(ins[0].stride())
+
+    def _plan(self, ins):
+        """Argument blocks of the four C-ABI calls for the inputs `ins` = (V [B,N,d] in a native layout, Q_w, Q_p, Q_s,
+        labels), built once per address set (everything but the stream).  Parameters are read where they lie (the
+        optimiser updates them in place); the ctypes blocks are kept alive by the plan."""
+        key = self._key(ins)
+        plan = self._plans.get(key)
+        if plan is not None:
+            return plan
+        if len(self._plans) >= 8 * self.MAX_KEYS:                # (eager mode has no graph to keep: drop the oldest)
+            self._plans.pop(next(iter(self._plans)))
         B, N, T, d, mlp, K = self.dims
         V, Qs, labels = ins[0], ins[1:4], ins[4]
-        st = C.c_void_p(stream)
         qptr = (C.c_void_p * 3)(*[t.data_ptr() for t in Qs])
         dqptr = (C.c_void_p * 3)(*[t.data_ptr() for t in self.dQ])
         rows = lambda t: (C.c_void_p * 3)(*[t[l].data_ptr() for l in range(3)])   # noqa: E731
@@ -87,21 +108,34 @@ class HotPathGraph:
         pg = _lib.ParamGrads(*[t.data_ptr() for t in self.co_grads])
         hp = _lib.HeadParams(*[t.data_ptr() for t in self.head_params])
         hg = _lib.HeadParamGrads(*[t.data_ptr() for t in self.head_grads])
+        rv, rq, rdx = rows(self.v), rows(self.q), rows(self.dx)
         vs = _strides(V)
-        dvs = (N * d, d, 1)                                  # the static dV buffer is location-major
+        dvs = (N * d, d, 1) if self.dV is not None else (0, 0, 0)   # the static dV buffer is location-major
+        plan = {
+            "keep": (qptr, dqptr, p, pg, hp, hg, rv, rq, rdx),
+            "co_fwd": (_ptr(V), *vs, qptr, C.byref(p), _ptr(self.v), _ptr(self.q), _ptr(self.saved), _ptr(self.ws),
+                       B, N, T, d, 3, _lib.F32, self.flags),
+            "head_fwd": (rv, rq, C.byref(hp), _ptr(labels), _ptr(self.logits), _ptr(self.loss), _ptr(self.hsaved),
+                         B, d, mlp, K, _lib.F32, self.head_flags),
+            "head_bwd": (rv, rq, C.byref(hp), _ptr(self.hsaved), _ptr(self.g_loss), None, rdx, None, C.byref(hg), 0,
+                         _ptr(self.hws), B, d, mlp, K, _lib.F32, self.head_flags),
+            "co_bwd": (_ptr(V), *vs, qptr, C.byref(p), _ptr(self.saved), _ptr(self.dx), _ptr(self.dx), _ptr(self.dV), *dvs,
+                       dqptr, C.byref(pg), 0, _ptr(self.ws), B, N, T, d, 3, _lib.F32, self.flags),
+        }
+        self._plans[key] = plan
+        return plan
+
+    # the C-ABI calls on `stream`, reading the inputs `ins` = (V [B,N,d] in a native layout, Q_w, Q_p, Q_s, labels)
+    def _enqueue(self, ins, stream, fwd=True, bwd=True):
+        lib = self._lib
+        plan = self._plan(ins)
+        st = C.c_void_p(stream)
         if fwd:
-            _lib.check(lib.coattn_forward(_ptr(V), *vs, qptr, C.byref(p), _ptr(self.v), _ptr(self.q), _ptr(self.saved),
-                                          _ptr(self.ws), B, N, T, d, 3, _lib.F32, self.flags, st), "coattn_forward")
-            _lib.check(lib.coattn_head_forward(rows(self.v), rows(self.q), C.byref(hp), _ptr(labels), _ptr(self.logits),
-                                               _ptr(self.loss), _ptr(self.hsaved), B, d, mlp, K, _lib.F32, self.head_flags, st),
-                       "coattn_head_forward")
+            _lib.check(lib.coattn_forward(*plan["co_fwd"], st), "coattn_forward")
+            _lib.check(lib.coattn_head_forward(*plan["head_fwd"], st), "coattn_head_forward")
         if bwd:
-            _lib.check(lib.coattn_head_backward(rows(self.v), rows(self.q), C.byref(hp), _ptr(self.hsaved), _ptr(self.g_loss),
-                                                None, rows(self.dx), None, C.byref(hg), 0, _ptr(self.hws), B, d, mlp, K,
-                                                _lib.F32, self.head_flags, st), "coattn_head_backward")
-            _lib.check(lib.coattn_backward(_ptr(V), *vs, qptr, C.byref(p), _ptr(self.saved), _ptr(self.dx), _ptr(self.dx),
-                                           _ptr(self.dV), *(dvs if self.dV is not None else (0, 0, 0)), dqptr, C.byref(pg),
-                                           0, _ptr(self.ws), B, N, T, d, 3, _lib.F32, self.flags, st), "coattn_backward")
+            _lib.check(lib.coattn_head_backward(*plan["head_bwd"], st), "coattn_head_backward")
+            _lib.check(lib.coattn_backward(*plan["co_bwd"], st), "coattn_backward")
 
     def usable_in_place(self, ins) -> bool:
         B, N, T, d, _, _ = self.dims
@@ -116,10 +150,12 @@ class HotPathGraph:
     def pair(self, ins):
         """(forward graph, backward graph) reading the inputs at the addresses of `ins`; captured on first use, or
         None when MAX_KEYS address sets are already held (the caller then copies into the static inputs)."""
-        key = tuple(t.data_ptr() for t in ins) + tuple(ins[0].stride())
+        key = self._key(ins)
         hit = self._pairs.get(key)
         if hit is not None:
             return hit
+        if not self.capture:                                     # eager mode: nothing to capture (run() issues the calls)
+            return _EAGER
         if len(self._pairs) >= self.MAX_KEYS:
             return None
         with torch.cuda.device(self.device):
@@ -146,13 +182,25 @@ class HotPathGraph:
         """The same calls without the graphs (tests compare the two bit for bit)."""
         self._enqueue(ins or self._static, torch.cuda.current_stream(self.device).cuda_stream)
 
+    def run(self, pair, ins, fwd: bool):
+        """One direction of the hot path: replay the captured graph, or (eager mode) issue its two C-ABI calls."""
+        if pair is _EAGER:
+            with _lib.on_device(self.device):
+                self._enqueue(ins, torch.cuda.current_stream(self.device).cuda_stream, fwd, not fwd)
+        else:
+            pair[0 if fwd else 1].replay()
+
     def replay(self, ins=None):
-        gf, gb = self.pair(ins or self._static)
-        gf.replay()
-        gb.replay()
+        ins = ins or self._static
+        pair = self.pair(ins)
+        self.run(pair, ins, True)
+        self.run(pair, ins, False)
 
     def __call__(self, x_img: torch.Tensor, x_ques: Sequence[torch.Tensor], labels: torch.Tensor):
         return _HotPathFn.apply(self, x_img, labels, *x_ques, *self.co_params, *self.head_params)
+
+
+_EAGER = ("eager", "eager")        # what pair() returns in eager mode (capture=False)
 
 
 class _HotPathFn(torch.autograd.Function):
@@ -177,7 +225,7 @@ class _HotPathFn(torch.autograd.Function):
             hp.labels.copy_(labels)
             ins = hp._static
             pair = hp.pair(ins)
-        pair[0].replay()
+        hp.run(pair, ins, True)
         # (as head.answer_head after a forward with labels: Trainer.check_labels() reads this step's status word)
         _head._last = (hp.hsaved, B, d, mlp, K, hp.device)
         ctx.hp, ctx.pair = hp, pair
@@ -190,7 +238,17 @@ class _HotPathFn(torch.autograd.Function):
     def backward(ctx, g_logits, g_loss):
         hp = ctx.hp
         hp.g_loss.copy_(g_loss.reshape(1))
-        ctx.pair[1].replay()
+        hp.run(ctx.pair, ctx.keep, False)
+        if hp.direct_grads:
+            # the owner of the step (train.Trainer) consumes the gradients before the next backward and needs no gradient
+            # hooks: the static buffers BECOME param.grad (autograd's AccumulateGrad would clone each one -- it cannot
+            # steal a buffer this object still holds: 16 copy kernels per step)
+            for p, g in zip(hp.co_params + hp.head_params, hp.co_grads + hp.head_grads):
+                if p.grad is None or p.grad is g:
+                    p.grad = g
+                else:
+                    p.grad.add_(g)
+            return (None, hp.dV, None, *hp.dQ) + (None,) * 16
         # (the static gradient buffers are handed out as they are: autograd accumulates / the optimiser consumes them
         #  before the next step's backward overwrites them)
         return (None, hp.dV, None, *hp.dQ, *hp.co_grads, *hp.head_grads)

@@ -319,6 +319,10 @@ class HierarchicalCoAttentionNet(nn.Module):
         self.co_attention = ParallelCoAttention(self.hidden_dim)
         self.mlp_classify = MLPClassifier(self.hidden_dim, mlp_dim, K)
         self.hot_path_graph = False                   # opt-in: replay the hot path from a captured HIP graph (graph.py)
+        # train.Trainer's default on CUDA: the hot path as ONE autograd node over static buffers, its C-ABI calls issued
+        # eagerly (graph.HotPathGraph(capture=False)); hot_path_direct_grads: the static gradient buffers become param.grad
+        self.hot_path_static = False
+        self.hot_path_direct_grads = False
         self._graphs = {}
 
     def forward(self, x_img, x_ques, x_ques_lens):
@@ -332,7 +336,8 @@ class HierarchicalCoAttentionNet(nn.Module):
         x_ques_features = list(self.question_encoder(x_ques, x_ques_lens))
         if callable(x_img_features):            # resolved only now: the question side is queued first
             x_img_features = x_img_features()
-        if labels is not None and self.hot_path_graph and x_img_features.is_cuda and torch.is_grad_enabled():
+        if (labels is not None and (self.hot_path_graph or self.hot_path_static) and x_img_features.is_cuda
+                and torch.is_grad_enabled()):
             return self._graphed(x_img_features, x_ques_features, labels)
         x_img_attn, x_ques_attn = self.co_attention(x_img_features, x_ques_features)
         if labels is not None:
@@ -340,18 +345,21 @@ class HierarchicalCoAttentionNet(nn.Module):
         return self.mlp_classify(x_img_attn, x_ques_attn)
 
     def _graphed(self, x_img_features, x_ques_features, labels):
-        """co-attention + answer head + loss, forward AND backward, as one replay of a captured HIP graph (graph.py);
-        captured per (B, N, T) on first use.  Opt-in: ``net.hot_path_graph = True`` (``Trainer(graph=True)``)."""
+        """co-attention + answer head + loss, forward AND backward, as one autograd node over static buffers (graph.py),
+        built per (B, N, T) on first use: replayed from captured HIP graphs (``net.hot_path_graph = True``,
+        ``Trainer(graph=True)``) or with its four C-ABI calls issued eagerly (``net.hot_path_static``, the Trainer's
+        default)."""
         from . import _lib
         from .graph import HotPathGraph
         B, N, _ = x_img_features.shape
         T = x_ques_features[0].shape[1]
         key = (B, N, T, bool(x_img_features.requires_grad), bool(self.co_attention.bf16_projections),
-               bool(self.mlp_classify.bf16_products))
+               bool(self.mlp_classify.bf16_products), bool(self.hot_path_graph), bool(self.hot_path_direct_grads))
         hp = self._graphs.get(key)
         if hp is None:
             hp = self._graphs[key] = HotPathGraph(self.co_attention, self.mlp_classify, B, N, T, need_dv=key[3],
-                                                  flags=_lib.FLAG_BF16_PROJ if key[4] else 0)
+                                                  flags=_lib.FLAG_BF16_PROJ if key[4] else 0, capture=key[6],
+                                                  direct_grads=key[7])
         return hp(x_img_features, x_ques_features, labels)
 
 

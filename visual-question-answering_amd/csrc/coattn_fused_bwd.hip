@@ -18,6 +18,7 @@
 //   then MFMA GEMMs: dQ = a_q (x) gq + dA V^T + dP_q W_q;  dV = sum_l (a_v (x) gv + Q^T dA) +
 //   (sum_l dP_v) W_v (skipped when the image features need no gradient);  dW_v, dW_q, biases.
 #include "fused.h"
+#include <stdlib.h>
 
 
 
@@ -527,9 +528,11 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     // both weight gradients in one launch: 32 split-K parts (x 16 tiles = the 512 workgroup slots) shared in
     // proportion to the contraction lengths, so that all workgroups run about equally long
     const double kv = (double)B * N, kq = (double)L * B * T;
-    int pv = (int)(32.0 * kv / (kv + kq) + 0.5);
-    pv = pv < 1 ? 1 : (pv > 31 ? 31 : pv);
-    const int pq = (32 - pv) / L > 0 ? (32 - pv) / L * L : L;
+    static const int budget_env = [] { const char* e = getenv("COATTN_TN_PARTS"); return e ? atoi(e) : 0; }();   // developer switch
+    const int budget = budget_env > 0 ? budget_env : 32;
+    int pv = (int)((double)budget * kv / (kv + kq) + 0.5);
+    pv = pv < 1 ? 1 : (pv > budget - 1 ? budget - 1 : pv);
+    const int pq = (budget - pv) / L > 0 ? (budget - pv) / L * L : L;
     int ks[2], S[2];
     const int parts_v = gemm_tn_plan(tnv, pv, &ks[0], &S[0]);
     tnq.C = part + (size_t)parts_v * d * d;

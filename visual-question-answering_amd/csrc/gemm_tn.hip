@@ -19,6 +19,17 @@
 #include "gemm_w_body.h"
 #include <type_traits>
 
+// Developer switches (tools/ab_gemmtn.sh, never in the shipped library; wrong results): GEMMTN_KO bit 0 no MFMAs, 1 no global
+// loads past the prologue, 2 no split arithmetic, 3 no LDS writes, 4 no fragment reads past the prologue, 5 no barrier.
+// Measured at cfg 2, two-piece width (N = 196: 135 us for the whole backward launch): no MFMAs -1 us (hidden), no loads
+// -47 (with them gone the split is loop-invariant and leaves too), no split -31, no LDS writes -36 (the split feeding them
+// is dead code then), no fragment reads -3, no barrier 0; everything but the dQ tiles and the epilogues off: 51 us.  The
+// split arithmetic of operands that every one of the four tiles sharing them repeats is the largest single item.
+// Requesting the rows two steps ahead instead of one (two register sets): 142 us, no gain -- it is not latency.
+#ifndef GEMMTN_KO
+#define GEMMTN_KO 0
+#endif
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 16;
@@ -127,6 +138,7 @@ __device__ __forceinline__ void gemm_tn_body(const TnArgs& g, const int bid, con
   constexpr int PA[6] = {2, 0, 1, 1, 0, 0};      // smallest terms first (gemm.hip's order)
   constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
   auto load_raw = [&](int x, int s) {            // x: 0,1 = A halves, 2,3 = B halves; step s of this part
+    if ((GEMMTN_KO & 2) && s >= 2) return;
     // (the step goes into the VECTOR offset: the resource's range check does not see the scalar offset)
     if (x < 2) {
       raw[x] = buf_load4(rs_a, a_voff + (x & 1) * a_half + s * a_step, 0);
@@ -143,6 +155,10 @@ __device__ __forceinline__ void gemm_tn_body(const TnArgs& g, const int bid, con
     } else raw[x] = buf_load4(rs_b, b_voff + (x & 1) * b_half + s * b_step, 0);
   };
   auto stage = [&](int x, int e, int st) {       // split of raw[x], pair e, in three stages of 5, 5 and 1 VALU
+    if (GEMMTN_KO & 4) {
+      if (st == 0) ph[e] = pm[e] = pl[e] = __builtin_bit_cast(unsigned, raw[x][2 * e]);
+      return;
+    }
     if (st == 0) {
       if (SUM3 && x < 2) {                       // (level order 0 + 1 + 2, as the separate summing pass adds them)
         raw[x][2 * e] = (raw[x][2 * e] + rawt[x][0][2 * e]) + rawt[x][1][2 * e];
@@ -164,6 +180,7 @@ __device__ __forceinline__ void gemm_tn_body(const TnArgs& g, const int bid, con
   };
   auto write_piece = [&](short* buf, int x, int q) {
     if (q >= NP) return;
+    if ((GEMMTN_KO & 8) && buf != lds) return;       // (the prologue's image is still written)
     const u32x2 v = q == 0 ? u32x2{ph[0], ph[1]} : (q == 1 ? u32x2{pm[0], pm[1]} : u32x2{pl[0], pl[1]});
     if (BCM && x >= 2) *reinterpret_cast<u32x2*>(&buf[q * IMGB + (x & 1) * 64 * LDRB + bc_st]) = v;
     else *reinterpret_cast<u32x2*>(&buf[(x >> 1) * OPER + q * IMG + (x & 1) * 8 * LDT + st_off]) = v;
@@ -174,6 +191,7 @@ __device__ __forceinline__ void gemm_tn_body(const TnArgs& g, const int bid, con
     constexpr int QA[3] = {2, 0, 1}, QB[3] = {0, 2, 1};
     const int grp = r >> 2, isb = grp & 1, q = isb ? QB[grp >> 1] : QA[grp >> 1], tile = (r >> 1) & 1, hi = r & 1;
     if (q >= NP) return;
+    if ((GEMMTN_KO & 16) && buf != lds) return;
     if (BCM && isb) {                            // one 16-byte read per fragment (issued with its first half)
       if (hi == 0) {
         const bf16x8 v = *reinterpret_cast<const bf16x8*>(buf + q * IMGB + b_rd + tile * 32 * LDRB);
@@ -198,7 +216,8 @@ __device__ __forceinline__ void gemm_tn_body(const TnArgs& g, const int bid, con
       const int mi = NP == 2 ? n >> 1 : n;
       const bool mf = NP == 3 || (NP == 2 && (n & 1)) || (NP == 1 && n >= 20);
       const int tt = NP == 2 ? 3 + (mi >> 2) : n >> 2, i = (mi >> 1) & 1, j = mi & 1;
-      if (mf)
+      if (mf && (GEMMTN_KO & 1)) acc[i][j][n & 15] += __builtin_bit_cast(float, (int)fa[SET][PA[tt]][i][0][0] ^ (int)fb[SET][PB[tt]][j][0][0]);
+      if (mf && !(GEMMTN_KO & 1))
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(fa[SET][PA[tt]][i]), frag(fb[SET][PB[tt]][j]), acc[i][j], 0, 0, 0);
       // raw[x]: pair 0 stages in slots 4x, 4x+1, 4x+2; pair 1 in 4x+1, 4x+2, 4x+3; pieces written in 4x+3 .. 4x+5
       if (n < 16) {
@@ -211,7 +230,7 @@ __device__ __forceinline__ void gemm_tn_body(const TnArgs& g, const int bid, con
         const int w = n - 3, x = w >> 2, q = w & 3;
         if (q < 3) write_piece(nxt, x, q);
       }
-      if (n == 18) lds_barrier();
+      if (n == 18 && !(GEMMTN_KO & 32)) lds_barrier();
       if (n >= 18) {
 #pragma unroll
         for (int r = 4 * (n - 18); r < 4 * (n - 17); ++r) read_frag(OTHER{}, nxt, r);

@@ -22,6 +22,7 @@
 #include "fused.h"
 #include "gemm_w_body.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
@@ -136,7 +137,8 @@ int launch_gemm_w(const WGemm* d, int n, hipStream_t s) {
   WJobs jobs = {};
   long nb[2] = {0, 0};
   // single-product mode with wide outputs: 128 x 256 tiles on 512 threads (the A rows are staged once for twice the columns)
-  bool wide = d[0].bf16 != 0;
+  static const int wide2 = [] { const char* e = getenv("COATTN_GEMMW_WIDE2"); return e ? atoi(e) : 0; }();   // developer switch
+  bool wide = d[0].bf16 != 0 || (wide2 && d[0].np == 2 && (n == 1 || d[1].np == 2));
   for (int i = 0; i < n; ++i) wide = wide && d[i].N % 256 == 0 && (d[i].kband_n == 0 || d[i].kband_n % 256 == 0);
   for (int i = 0; i < n; ++i) CA_TRY(gemm_w_fill_job(d[i], jobs.job[i], &nb[i], wide ? 256 : BN));
   CA_CHECK_ARG(nb[0] + nb[1] < 2147483647L, "gemm_w: grid too large");
@@ -145,7 +147,10 @@ int launch_gemm_w(const WGemm* d, int n, hipStream_t s) {
   CA_CHECK_ARG(n == 1 || d[1].bf16 == d[0].bf16, "gemm_w: the jobs of a launch share the precision mode");
   const bool two0 = d[0].np == 2, two1 = n == 2 ? d[1].np == 2 : two0;      // fp32 mode: the width of each job
   const dim3 grid((unsigned)(nb[0] + nb[1]));
-  if (wide) {
+  if (wide && !d[0].bf16) {
+    if (d[0].a_sk) hipLaunchKernelGGL((gemm_w_kernel<true, 2, 8>), grid, dim3(512), 0, s, jobs);
+    else hipLaunchKernelGGL((gemm_w_kernel<false, 2, 8>), grid, dim3(512), 0, s, jobs);
+  } else if (wide) {
     if (d[0].a_sk) hipLaunchKernelGGL((gemm_w_kernel<true, 1, 8>), grid, dim3(512), 0, s, jobs);
     else hipLaunchKernelGGL((gemm_w_kernel<false, 1, 8>), grid, dim3(512), 0, s, jobs);
   } else if (d[0].bf16) {

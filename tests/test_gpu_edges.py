@@ -386,3 +386,46 @@ def test_question_features_not_16_byte_aligned():
     for u, w in zip(a, b):
         assert torch.isfinite(u).all()
         assert (u - w).abs().max().item() <= 2e-5 * max(1e-3, w.abs().max().item())
+
+
+def test_profile_marks_of_forward_and_backward():
+    """coattn_profile_begin / _end (bench.py's per-kernel legs): one mark per launch group of the calls in between, positive
+    times that add up to about the span of the calls; without a begin the end call is an error, not a crash."""
+    import ctypes as C
+    import torch
+    from oracle import coattn_oracle as O
+    from vqa_amd import _lib
+    lib = _lib.load()
+    us = (C.c_float * 48)()
+    names = C.create_string_buffer(1024)
+    assert lib.coattn_profile_end(us, names, 1024, 48) == -1 and b"coattn_profile_begin" in lib.coattn_last_error()
+    B, N, T, d, L = 8, 49, 26, 512, 3
+    P = O.make_params(d, 5)
+    V, Qs = O.make_inputs(B, N, T, d, 5, lens=[T] * B, scale_q=(2.0 / d) ** 0.5)
+    dev = torch.device("cuda:0")
+    Vb = V.permute(0, 2, 1).contiguous().to(dev)
+    Qd = [q.to(dev) for q in Qs]
+    keys = ("W_v.weight", "W_v.bias", "W_q.weight", "W_q.bias", "w_v.weight", "w_v.bias", "w_q.weight", "w_q.bias")
+    ps = [P[k].to(dev).contiguous() for k in keys]
+    sb, fb, bb = _lib.workspace_bytes(B, N, T, d, L)
+    saved = torch.empty(sb // 4, device=dev); ws = torch.empty(max(fb, bb) // 4, device=dev)
+    v = torch.empty(L, B, d, device=dev); q = torch.empty(L, B, d, device=dev)
+    g = torch.ones(L, B, d, device=dev)
+    dQ = [torch.empty_like(t) for t in Qd]; grads = [torch.empty_like(t) for t in ps]
+    qptr = (C.c_void_p * L)(*[t.data_ptr() for t in Qd]); dqptr = (C.c_void_p * L)(*[t.data_ptr() for t in dQ])
+    p = _lib.Params(*[t.data_ptr() for t in ps]); pg = _lib.ParamGrads(*[t.data_ptr() for t in grads])
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    vs = (N * d, d, 1)
+    for _ in range(2):                                       # (the first call pays the one-time kernel attributes)
+        _lib.check(lib.coattn_profile_begin(st), "coattn_profile_begin")
+        _lib.check(lib.coattn_forward(Vb.data_ptr(), *vs, qptr, C.byref(p), v.data_ptr(), q.data_ptr(), saved.data_ptr(),
+                                      ws.data_ptr(), B, N, T, d, L, _lib.F32, 0, st), "coattn_forward")
+        _lib.check(lib.coattn_backward(Vb.data_ptr(), *vs, qptr, C.byref(p), saved.data_ptr(), g.data_ptr(), g.data_ptr(), None,
+                                       0, 0, 0, dqptr, C.byref(pg), 0, ws.data_ptr(), B, N, T, d, L, _lib.F32, 0, st),
+                   "coattn_backward")
+        n = lib.coattn_profile_end(us, names, 1024, 48)
+    marks = names.value.decode().split("\n")
+    assert n == len(marks) and n >= 8, (n, marks)
+    assert marks[:3] == ["wsplit", "projections", "coattn_fwd32"] and "bwd_nat32" in marks and marks[-1] == "reduce_partials"
+    assert all(us[i] > 0 for i in range(n)) and sum(us[i] for i in range(n)) < 5e4
+    assert torch.isfinite(v).all() and all(torch.isfinite(t).all() for t in grads)

@@ -23,7 +23,9 @@ def _shapes():
            (2, 32, 5, 512, 3), (2, 33, 26, 512, 1), (1, 65, 3, 512, 2), (2, 97, 26, 512, 3), (1, 129, 7, 256, 3),
            (2, 161, 26, 512, 2), (1, 193, 28, 512, 3),
            # the widest hidden sizes the fused kernels take (4 and 8 channel slices per wave)
-           (1, 196, 26, 2048, 3), (1, 64, 28, 4096, 1)]
+           (1, 196, 26, 2048, 3), (1, 64, 28, 4096, 1),
+           # small grids on location-major features: the forward kernel attends the image features itself (two channel sweeps)
+           (2, 50, 26, 1024, 3), (3, 37, 9, 512, 2)]
     for _ in range(14):
         d = rng.choice([4, 20, 36, 64, 100, 256, 512])
         out.append((rng.randint(1, 5), rng.randint(1, 210), rng.randint(1, 30), d, rng.randint(1, 3)))

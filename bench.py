@@ -376,6 +376,14 @@ def backward_legs(device, B=160, N=196, T=26, d=512, L=3, iters=60, layout="lm",
                "bwd_gemm_dw": "gemm_tn_kernel / gemm_bf_tn_kernel (dW_v + dW_q)", "bwd_gemm_dq_projection": "gemm_w_kernel / gemm_bf_kernel (dQ = dP_q W_q)",
                "reduce_partials": "reduce_partials4_kernel"}
     np_prod = 1 if bf16 else (6 if os.environ.get("COATTN_SPLIT") == "3" else 3)
+    traffic = {}                                       # HBM-side bytes per launch from the committed rocprofv3 PMC passes
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic_backward.json")) as fh:
+            for e in json.load(fh)["entries"]:
+                if e.get("shape") == {"B": B, "N": N, "T": T, "d": d, "L": L} and e.get("layout") == layout and not bf16:
+                    traffic = {k: v["hbm_bytes_per_launch"] for k, v in e["kernels"].items()}
+    except (OSError, ValueError, KeyError):
+        pass
     out = []
     total = sum(tot.values()) / iters
     for nm in order:
@@ -384,7 +392,7 @@ def backward_legs(device, B=160, N=196, T=26, d=512, L=3, iters=60, layout="lm",
         if nm in alg:
             ach = alg[nm] / t / 1e9
             e.update({"bound": "hbm", "algorithmic_bytes": alg[nm], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                      "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None})
+                      "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(nm)})
         elif nm.startswith("bwd_gemm"):
             fl = {"bwd_gemm": 2.0 * d * d * (B * N + 2 * L * B * T), "bwd_gemm_dw": 2.0 * d * d * (B * N + L * B * T),
                   "bwd_gemm_dq_projection": 2.0 * d * d * L * B * T}[nm]
@@ -395,10 +403,12 @@ def backward_legs(device, B=160, N=196, T=26, d=512, L=3, iters=60, layout="lm",
                       "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                       "peak_note": "dense bf16 MFMA peak 2500 TFLOP/s / %d partial product(s) per product" % np_prod,
                       "frac_of_fp32_matrix_peak": round(ach / 157.3, 4),
-                      "hbm_bytes": hbm, "hbm_frac_at_this_time": round(hbm / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": None})
+                      "hbm_bytes": hbm, "hbm_frac_at_this_time": round(hbm / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic.get(nm)})
         out.append(e)
     return {"shape": {"B": B, "N": N, "T": T, "d": d, "L": L}, "v_layout": layout, "calls": iters,
             "total_us": round(total, 1), "kernels": out,
+            "traffic_source": "profiles/pmc_traffic_backward.json (rocprofv3 PMC passes of tools/probe_hot.py at this shape, committed; "
+                              "not measured by this run)" if traffic else None,
             "note": "time between HIP events the library records after each launch group of coattn_backward "
                     "(coattn_profile_begin / _end); dV not requested (frozen image encoder)"}
 

@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "refresh")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 
 def one(pattern):
@@ -27,9 +27,13 @@ line = [l for l in open(os.path.join(SRC, "bench.json")) if l.startswith("{")][-
 json.loads(line)
 open(os.path.join(DST, "%s_bench.json" % tag), "w").write(line)
 for leg, name in (("roofline", "roofline"), ("hot", "hot_path"), ("step", "full_step"), ("bench_stats", "bench"),
-                  ("headline", "headline")):
+                  ("headline", "headline"), ("headline196", "reference_grid"), ("fb_49", "fwd_bwd_n49"), ("fb_196", "fwd_bwd_n196")):
     shutil.copy(one("%s/**/*kernel_stats.csv" % leg), os.path.join(DST, "%s_%s_kernel_stats.csv" % (tag, name)))
 shutil.copy(os.path.join(SRC, "pmc_traffic.json"), os.path.join(DST, "pmc_traffic.json"))
+shutil.copy(os.path.join(SRC, "pmc_traffic_backward.json"), os.path.join(DST, "pmc_traffic_backward.json"))
+c5 = [l for l in open(os.path.join(SRC, "cfg5_bench.json")) if l.startswith("{")][-1]
+json.loads(c5)
+open(os.path.join(DST, "%s_cfg5_bench.json" % tag), "w").write(c5)
 # config 4's bench line and hot-path kernels, the answer head's kernels and its unprofiled timing
 c4 = [l for l in open(os.path.join(SRC, "cfg4_bench.json")) if l.startswith("{")][-1]
 json.loads(c4)
@@ -63,7 +67,8 @@ if vals:
     json.dump(out, open(os.path.join(DST, "%s_pmc_mfma.json" % tag), "w"), indent=1)
 # the same counters over the whole isolated hot path (bench.py --only hot): one entry per kernel of the HIP library;
 # pmc_cfg4_hot: config 4's hot path (the reduced-precision instantiations)
-for src_dir, out_name in (("pmc_hot", "pmc_hot_path_kernels"), ("pmc_cfg4_hot", "pmc_cfg4_hot_path_kernels")):
+for src_dir, out_name in (("pmc_hot", "pmc_hot_path_kernels"), ("pmc_cfg4_hot", "pmc_cfg4_hot_path_kernels"),
+                          ("pmc_fb_49", "pmc_fwd_bwd_n49_kernels"), ("pmc_fb_196", "pmc_fwd_bwd_n196_kernels")):
     hot = {}
     for f in newest("%s/**/*counter_collection.csv" % src_dir):
         for r in csv.DictReader(open(f)):

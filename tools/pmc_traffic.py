@@ -27,13 +27,16 @@ for dd in dirs:
                 vals.setdefault((kern, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
 mean = {k: sum(v) / len(v) for k, v in vals.items()}
 known_attend_read = 4.0 * (B * d * N + L * B * N)              # V once + a_v
-calib = known_attend_read / (mean[("attend_v", "FETCH_SIZE")] * 1024.0)
-fetch = (mean[("fwd", "FETCH_SIZE")] + mean[("attend_v", "FETCH_SIZE")]) * 1024.0 * 2.0
-write = (mean[("fwd", "WRITE_SIZE")] + mean[("attend_v", "WRITE_SIZE")]) * 1024.0
+# (small grids on location-major features: the forward kernel attends the image features itself, no attend_v launch)
+has_attend = ("attend_v", "FETCH_SIZE") in mean
+calib = known_attend_read / (mean[("attend_v", "FETCH_SIZE")] * 1024.0) if has_attend else None
+fetch = (mean[("fwd", "FETCH_SIZE")] + mean.get(("attend_v", "FETCH_SIZE"), 0.0)) * 1024.0 * 2.0
+write = (mean[("fwd", "WRITE_SIZE")] + mean.get(("attend_v", "WRITE_SIZE"), 0.0)) * 1024.0
 out = {"shape": {"B": B, "N": N, "T": T, "d": d, "L": L}, "layout": layout,
        "hbm_bytes_per_launch": int(fetch + write),
        "fetch_bytes_corrected_x2": int(fetch), "write_bytes": int(write),
-       "fetch_calibration_factor_on_attend_v": round(calib, 3),
+       "fetch_calibration_factor_on_attend_v": round(calib, 3) if calib else None,
+       "kernels": "coattn_fwd32_kernel" + (" + attend_v kernel" if has_attend else " (attends the image features itself)"),
        "raw_kib": {"%s.%s" % k: round(v, 1) for k, v in mean.items()},
        "note": "FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950 halves coalesced-read bytes); calibration on "
                "the attend_v kernel's exactly known read volume; counters from separate --pmc passes"}

@@ -41,6 +41,9 @@ def _pieces(x64, n, dt=torch.bfloat16):
 
 def mm(a, b, n):
     """a @ b as the n-piece kernels compute it (fp32 accumulation not modelled: float64 sums)."""
+    if n == "2x3":                                  # a on two pieces, b (the weight) on three: ah bh + am bh + ah bm + ah bl
+        pa, pb = _pieces(a, 2), _pieces(b, 3)
+        return (pa[0] + pa[1]) @ pb[0] + pa[0] @ (pb[1] + pb[2])
     if n == "2h":                                   # two fp16 pieces (hi + lo: 22 significand bits, fp16's range)
         pa, pb = _pieces(a, 2, torch.float16), _pieces(b, 2, torch.float16)
         return (pa[0] + pa[1]) @ pb[0] + pa[0] @ pb[1]
@@ -158,6 +161,8 @@ if __name__ == "__main__":
     tables["no_proj"] = dict(WIDTHS, proj=3)
     tables["no_proj_h"] = dict(WIDTHS, proj=3, h=3)
     tables["projq2"] = dict(WIDTHS, proj_q=2)
+    tables["projv2x3"] = dict(WIDTHS, proj="2x3")
+    tables["projv2x3_only"] = dict(EXACT, proj="2x3", proj_q=3)
     tables["fp16_fwd"] = dict(WIDTHS, proj="2h", h="2h")
     tables["fp16_fwd_only"] = dict(EXACT, proj="2h", h="2h")
     tables["fp16_all"] = {k: "2h" for k in WIDTHS}

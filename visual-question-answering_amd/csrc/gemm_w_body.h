@@ -130,7 +130,12 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
   constexpr int PB[6] = {0, 2, 1, 0, 1, 0};      // (gemm.hip's order)
   constexpr int RQ[3] = {2, 0, 1};               // fragment read order = order of first use
   constexpr int IMG = BM * LDR;                  // elements of one piece image
-  auto load_a = [&](int i, int s) { if (i < AP) raw[i] = buf_load4(rs_a, a_voff[i], (s + s0) * a_kstep); };
+  auto load_a = [&](int i, int s) {
+#ifdef GEMMW_NOA
+    if (s >= 2) return;                          // developer switch: no A reloads past the prologue
+#endif
+    if (i < AP) raw[i] = buf_load4(rs_a, a_voff[i], (s + s0) * a_kstep);
+  };
   auto load_b = [&](int ring, int k, int half) {
     const int j = k / 3, q = k % 3;
     if (q >= NP) return;
@@ -272,6 +277,9 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
       const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (row >= g.M) continue;
       float* crow = Cb + (long)row * g.c_sm;
+#ifdef GEMMW_NOSTORE
+      if (acc[i][0][r] != 12345.678f) continue;  // developer switch: no C stores
+#endif
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         if (col[j] < g.N) crow[col[j]] = (acc[i][j][r] + bn[j]) * g.oscale;

@@ -201,12 +201,15 @@ int coattn_ce_status(const void* ws, int B, void* stream);
  * (overwritten; the gradient of q_l + v_l goes to both; dq may be NULL or equal dv: stored once; dv NULL: no input
  * gradients).  pg: the eight parameter gradients (accumulate = 0 overwrites, 1 adds).  ws: scratch of `ws_bwd` bytes. */
 /* flags bit 0 of coattn_head_forward / coattn_head_backward: the layers of a direction as phases of ONE launch separated by
- * grid-wide barriers instead of one launch per layer (same tiles, same values; measured slower or equal: opt-in). */
+ * grid-wide barriers instead of one launch per layer (same tiles, same values; measured slower or equal: opt-in).  The
+ * barriers' spins are bounded: should one time out (the grid not resident), the call's first output element -- logits[0][0],
+ * and with it the loss; the first gradient element -- is NaN rather than silently stale. */
 #define COATTN_HEAD_PERSISTENT 1
 /* flags bit 2 (COATTN_FLAG_BF16_PROJ) of both: the reduced-precision mode -- the operands of the four products and of their
  * gradients rounded to bf16 while they are fed to the matrix pipe (ONE v_mfma_f32_32x32x16_bf16 where the exact head issues
  * eight v_mfma_f32_32x32x2_f32), fp32 accumulation, biases, tanh, cross entropy and bias gradients; bf16 tolerance.  Pass the
- * same flag to the forward and the backward of a step.  (The one-launch form is exact only: bit 0 wins.) */
+ * same flag to the forward and the backward of a step.  (The one-launch form is exact only: bits 0 and 2 together are an
+ * argument error, -1.) */
 typedef struct coattn_head_params {
   const void* W_w; const void* b_w;   /* model.py:409 */
   const void* W_p; const void* b_p;   /* model.py:410 */
@@ -262,7 +265,11 @@ int coattn_gemm_f32(const coattn_gemm_desc* g, void* stream);
  * The weight is split once into its three bf16 pieces in MFMA-fragment order (`wimg`, device scratch of
  * coattn_linear_workspace_bytes(N, K) bytes) and the GEMM reads the fragments in place (gemm_w.hip) -- the
  * kernel pair coattn_forward uses for both projections.  flags bit 0: `wimg` already holds the image of this
- * W (skip the split); flags bit 2 (COATTN_FLAG_BF16_PROJ): operands rounded to bf16, one MFMA per product.  K % 32 == 0, M >= 128, x 16-byte aligned with ld_x % 4 == 0; other shapes: error -1
+ * W (skip the split) -- WRITTEN BY A CALL WITH THE SAME N, K, precision flags (bits 2, 3) AND ON THE SAME KERNEL: the image's
+ * format belongs to the kernel that reads it (three-piece fragments for gemm_w.hip, hi-only 1 KB chunks for gemm_bf.hip), and
+ * which kernel runs depends on M (>= 256 and a multiple of 256 for gemm_bf.hip), ld_x and the alignment of x as well.  Reuse
+ * an image only across calls of one shape class -- e.g. the steps of a loop over equal batches; a last partial batch with
+ * another M must split again.  The library cannot check this (the image carries no tag).  flags bit 2 (COATTN_FLAG_BF16_PROJ): operands rounded to bf16, one MFMA per product.  K % 32 == 0, M >= 128, x 16-byte aligned with ld_x % 4 == 0; other shapes: error -1
  * (use coattn_gemm_f32).  bias may be NULL; out_scale 0 means 1.
  * flags bit 3 (COATTN_FLAG_BF16_IN, with bit 2): x holds bf16 elements (ld_x in elements, % 8 == 0) -- the activations of
  * an autocast encoder, or the fused backward's own bf16 gradients -- read as they are by the wide-shape kernel

@@ -120,6 +120,15 @@ def test_one_launch_form_gives_the_same_bits(shape):
                 assert torch.equal(a[k], b[k]), k
 
 
+def test_one_launch_form_refuses_the_reduced_precision_flag():
+    """The one-launch kernels exist for the exact tiles only: together with COATTN_FLAG_BF16_PROJ the call is an error, not a
+    silently exact result."""
+    from vqa_amd import _lib
+    ref, v, q, labels = _case(8, 64, 64, 12, seed=3)
+    with pytest.raises(RuntimeError, match="COATTN_HEAD_PERSISTENT has no reduced-precision form"):
+        _call(v, q, ref.state_dict(), labels, g_loss=1.0, flags=1 | _lib.FLAG_BF16_PROJ)
+
+
 @pytest.mark.parametrize("shape", [(160, 2048, 1024, 3001), (160, 512, 1024, 1001), (3, 20, 12, 5), (70, 96, 160, 33)],
                          ids=lambda s: "B%d_d%d_mlp%d_K%d" % s)
 def test_head_reduced_precision_mode(shape):

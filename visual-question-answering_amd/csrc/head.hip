@@ -448,7 +448,11 @@ __global__ __launch_bounds__(kThreads) void head_bwd_kernel(const BwdLayer L) {
 // (VERDICT r2 asked for this form first).  Placement-independent protocol (cdna_hip_programming.md Guideline 16): every
 // wave drains its stores, workgroup barrier, one lane's agent-scope release, a monotonic arrival counter (zeroed by a
 // memset node in front of the launch), relaxed polling with s_sleep, one agent-scope acquire, workgroup barrier.  The
-// grid is at most one workgroup per CU, so every workgroup is resident; the spin is bounded (a time-out raises bar[1]).
+// grid is at most one workgroup per CU, so every workgroup is resident; the spin is bounded: a time-out raises bar[1], every
+// workgroup then leaves its barriers with stale data, and workgroup 0 -- which owns element [0][0] of the last phase's
+// output -- writes NaN over it when the kernel ends (nobody read bar[1] before): the forward's logits[0][0]
+// turns the loss of that call into NaN, the backward's first gradient element is NaN.  Not the default, and not combined
+// with the reduced-precision flag (the one-launch kernels exist for the exact tiles only).
 // Measured against the per-layer launches in DESIGN.md 3.5; the launches are the default.
 __device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned target) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave
@@ -468,7 +472,14 @@ __device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned target) {
   __syncthreads();
 }
 
-struct FwdAll { FwdLayer L[4]; unsigned* bar; };
+struct FwdAll { FwdLayer L[4]; unsigned* bar; float* poison; };
+// after the last phase: make a barrier time-out visible in the values (see above)
+__device__ __forceinline__ void poison_on_timeout(unsigned* bar, float* poison) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this workgroup's own stores of the last phase are out
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0 && __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+    *poison = __builtin_nanf("");
+}
 template <bool VEC>
 __global__ __launch_bounds__(kThreads) void head_fwd_persistent_kernel(const FwdAll a) {
   __shared__ __attribute__((aligned(16))) float smem[kWaves * 2 * 32 * LDR];
@@ -484,9 +495,10 @@ __global__ __launch_bounds__(kThreads) void head_fwd_persistent_kernel(const Fwd
     }
     if (l < 3) grid_barrier(a.bar, (unsigned)(l + 1) * gridDim.x);
   }
+  poison_on_timeout(a.bar, a.poison);
 }
 
-struct BwdAll { BwdLayer L[4]; unsigned* bar; bool vec0; };
+struct BwdAll { BwdLayer L[4]; unsigned* bar; float* poison; bool vec0; };
 template <bool VEC>
 __global__ __launch_bounds__(kThreads) void head_bwd_persistent_kernel(const BwdAll a) {
   __shared__ __attribute__((aligned(16))) float smem[kWaves * 2 * 32 * LDR];
@@ -506,6 +518,7 @@ __global__ __launch_bounds__(kThreads) void head_bwd_persistent_kernel(const Bwd
     }
     if (l < 3) grid_barrier(a.bar, (unsigned)(l + 1) * gridDim.x);
   }
+  poison_on_timeout(a.bar, a.poison);
 }
 
 inline size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
@@ -609,8 +622,11 @@ extern "C" int coattn_head_forward(const void* const* v, const void* const* q, c
   Ls[3].A = Comp{nullptr, nullptr, sv + hs.hs, 0, 0, mlp};
   Ls[3].W = (const float*)p->W_h; Ls[3].bias = (const float*)p->b_h; Ls[3].C = (float*)logits; Ls[3].ldc = K; Ls[3].act = 0; Ls[3].N = K; Ls[3].K = mlp;
   for (int l = 0; l < 4; ++l) Ls[l].M = B;
+  CA_CHECK_ARG(!((flags & COATTN_HEAD_PERSISTENT) && (flags & COATTN_FLAG_BF16_PROJ)),
+               "head_forward: COATTN_HEAD_PERSISTENT has no reduced-precision form (drop one of the two flags)");
   if (flags & COATTN_HEAD_PERSISTENT) {
     FwdAll all = {};
+    all.poison = (float*)logits;
     int most = 0;
     for (int l = 0; l < 4; ++l) { all.L[l] = Ls[l]; const int t = ((B + 31) / 32) * ((Ls[l].N + 31) / 32); most = t > most ? t : most; }
     all.bar = reinterpret_cast<unsigned*>(sv + hs.st) + 8;          // (behind the cross entropy's status word)
@@ -692,8 +708,11 @@ extern "C" int coattn_head_backward(const void* const* v, const void* const* q, 
     L.dW = (float*)pg->dW_w; L.db = (float*)pg->db_w; L.N = d; L.Kin = d;
   }
   for (int l = 0; l < 4; ++l) { Ls[l].M = B; Ls[l].accumulate = accumulate; }
+  CA_CHECK_ARG(!((flags & COATTN_HEAD_PERSISTENT) && (flags & COATTN_FLAG_BF16_PROJ)),
+               "head_backward: COATTN_HEAD_PERSISTENT has no reduced-precision form (drop one of the two flags)");
   if (flags & COATTN_HEAD_PERSISTENT) {
     BwdAll all = {};
+    all.poison = dv ? (float*)dv[0] : (float*)pg->dW_w;          // element [0][0] of the last phase's first tile: workgroup 0 owns it
     for (int l = 0; l < 4; ++l) {
       all.L[l] = Ls[l];
       all.L[l].nx = (l < 3 || dv) ? ((B + 31) / 32) * ((Ls[l].Kin + 31) / 32) : 0;

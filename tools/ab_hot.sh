@@ -8,6 +8,7 @@ mkdir -p $O
 for setting in "$@"; do
   tag=$(echo "$setting" | tr ' =' '__')
   for N in 196 49; do
+    find gpurun_out/ab_hot -name "*_stats.csv" -delete 2>/dev/null       # (a directory is reused from run to run: kstats.py takes the first file)
     ( [ "$setting" != "-" ] && export $setting; rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_$N -- python3 tools/probe_hot.py $N ${LAYOUT:-lm} 200 > $O/${tag}_$N.log 2>&1 )
     rm -f $O/${tag}_$N/*/*kernel_trace.csv
     echo "== $setting N=$N: $(tail -1 $O/${tag}_$N.log)"

@@ -534,12 +534,16 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     pv = pv < 1 ? 1 : (pv > budget - 1 ? budget - 1 : pv);
     const int pq = (budget - pv) / L > 0 ? (budget - pv) / L * L : L;
     int ks[2], S[2];
-    const int parts_v = gemm_tn_plan(tnv, pv, &ks[0], &S[0]);
+    // two-piece width: 128 x 256 tiles on 512-thread workgroups (gemm_tn_wide.hip) -- the same split-K partition, pieces and
+    // order of products, so the same bits as the 128 x 128 kernel
+    const bool wide = gemm_tn_wide_supported(tnv) && gemm_tn_wide_supported(tnq) && (!combine || (wdq.N % 256 == 0 && wdq.np == 2));
+    const int parts_v = wide ? gemm_tn_wide_plan(tnv, pv, &ks[0], &S[0]) : gemm_tn_plan(tnv, pv, &ks[0], &S[0]);
     tnq.C = part + (size_t)parts_v * d * d;
-    const int parts_q = gemm_tn_plan(tnq, pq, &ks[1], &S[1]);
+    const int parts_q = wide ? gemm_tn_wide_plan(tnq, pq, &ks[1], &S[1]) : gemm_tn_plan(tnq, pq, &ks[1], &S[1]);
     CA_CHECK_ARG(parts_v + parts_q <= kMaxParts, "fused backward: %d split-K parts exceed the workspace", parts_v + parts_q);
     const TnGemm both[2] = {tnv, tnq};
-    CA_TRY(launch_gemm_tn(both, ks, S, 2, s, &small, combine ? &wdq : nullptr));
+    if (wide) CA_TRY(launch_gemm_tn_wide(both, ks, S, 2, s, &small, combine ? &wdq : nullptr));
+    else CA_TRY(launch_gemm_tn(both, ks, S, 2, s, &small, combine ? &wdq : nullptr));
     prof_mark(s, combine ? "bwd_gemm" : "bwd_gemm_dw");
     if (combine) CA_TRY(run_dq());
     CA_TRY(launch_reduce_partials2(part, (float*)pg->dW_v, parts_v, tnq.C, (float*)pg->dW_q, parts_q, (int64_t)d * d,

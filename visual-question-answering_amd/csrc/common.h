@@ -92,17 +92,20 @@ struct ReduceJobs {
   long sum_n;
   long ld;                                           // row stride of the partial buffers (0: n)
 };
+// (`active`: workgroups of more than 256 threads -- gemm_tn_wide_kernel -- pass threadIdx.x < 256: the other threads only
+//  keep the barriers company)
 __device__ __forceinline__ void reduce_jobs_block(const ReduceJobs& jobs, int nparts, long n, int accumulate, int bx,
-                                                  int by, float (*red)[64]) {
+                                                  int by, float (*red)[64], bool active = true) {
   // the four waves take interleaved parts and are combined in a fixed order
   if (by >= jobs.njobs) {                            // whole-array sum (fixed order: as sum_all_kernel)
     if (bx) return;
     const float* x = jobs.sum_x[by - jobs.njobs];
     float* out = jobs.sum_out[by - jobs.njobs];
     float acc = 0.f;
-    for (long i = threadIdx.x; i < jobs.sum_n; i += 256) acc += x[i];
+    if (active)
+      for (long i = threadIdx.x; i < jobs.sum_n; i += 256) acc += x[i];
     acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = acc;
+    if (active && (threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
       const float t = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
@@ -115,7 +118,7 @@ __device__ __forceinline__ void reduce_jobs_block(const ReduceJobs& jobs, int np
   const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const long j = (long)bx * 64 + col, ld = jobs.ld ? jobs.ld : n;
   float acc = 0.f;
-  if (j < n) {
+  if (active && j < n) {
     int c = grp;
     for (; c + 28 < nparts; c += 32) {               // 8 loads in flight per thread
       float v[8];
@@ -126,7 +129,7 @@ __device__ __forceinline__ void reduce_jobs_block(const ReduceJobs& jobs, int np
     }
     for (; c < nparts; c += 4) acc += part[(long)c * ld + j];
   }
-  red[grp][col] = acc;
+  if (active) red[grp][col] = acc;
   __syncthreads();
   if (grp == 0 && j < n) {
     const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);

@@ -235,6 +235,12 @@ struct TnReduce {                                                    // launch_r
 int launch_gemm_tn(const TnGemm* d, const int* ksplit, const int* S, int n, hipStream_t s, const TnReduce* red = nullptr,
                    const WGemm* wextra = nullptr);
 
+// the same launch on 128 x 256 tiles / 512-thread workgroups, for the two-piece width (gemm_tn_wide.hip)
+int gemm_tn_wide_supported(const TnGemm& d);
+int gemm_tn_wide_plan(const TnGemm& d, int max_parts, int* ksplit, int* S);
+int launch_gemm_tn_wide(const TnGemm* d, const int* ksplit, const int* S, int n, hipStream_t s, const TnReduce* red = nullptr,
+                        const WGemm* wextra = nullptr);
+
 // XCD-aware block -> (b, l): blocks i and i+8 share an XCD (round-robin dispatch), so give the
 // L levels of one sample consecutive slots on one XCD.  Speed only; any mapping is correct.
 __device__ __forceinline__ bool block_to_pair(int bid, int B, int L, int& b, int& l) {

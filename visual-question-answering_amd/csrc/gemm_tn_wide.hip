@@ -1,0 +1,291 @@
+// Weight-gradient GEMM  C = A^T B  on 128 x 256 tiles and 512-thread workgroups (gfx950) -- the backward's one GEMM
+// launch at the two-piece width.
+//
+// gemm_tn.hip's 128 x 128 tile was laid out for six partial products per fp32 product: its fillers hide under 24 MFMAs
+// per step.  At the two-piece width (three products) the knock-outs of that kernel (tools/ab_gemmtn.sh) show
+// the MFMAs hidden completely and the launch carried by what every tile repeats: the split of its operand blocks
+// (each block is split by all four tiles that share it; under SUM3 the A operand costs 10 VALU per pair) and their loads
+// (32 KB per step and workgroup under SUM3: the CU's vector-memory path at the MFMA-bound step rate).  Here a workgroup
+// owns a 128 x 256 tile -- eight waves as 2 x 4, each still 64 x 64 (2 x 2 MFMA tiles, the same 12 MFMAs per step): the A
+// rows (the SUM3 operand) are loaded, summed, split and staged ONCE for twice the columns, a thread stages one A float4 and
+// two B float4 per step instead of two and two.  Per MFMA: 5 loads instead of 8, 44 split VALU instead of 64, 6 LDS writes
+// instead of 8.  One workgroup per CU (8 waves = the two waves per SIMD of the four-wave kernel's two workgroups), 57 KB
+// of LDS at two pieces; 32 split-K parts x 8 tiles = the 256 CUs.  Same numerics as gemm_tn.hip (same pieces, same order
+// of the partial products, same split-K partition when the part count is the same); the dQ projection's tiles ride along on
+// gemm_w_body's 128 x 256 / 512-thread form, the small reductions as workgroups whose first 256 threads work.
+//
+// Shapes: M % 128 == 0, N % 256 == 0, both operands row-major over the contraction rows (the channel-major B operand and
+// the masked phrase-level products stay on gemm_tn.hip).
+#include "common.h"
+#include "fused.h"
+#include "gemm_w_body.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+constexpr int BM = 128, BN = 256, BK = 16, NTHR = 512;
+constexpr int LDTA = BM + 32, LDTB = BN + 32;      // [k][col] image row strides (elements): conflict-free writes + transposed reads
+constexpr int IMGA = BK * LDTA, IMGB = BK * LDTB;  // one piece image of each operand
+
+struct TwArgs {
+  const float* A; long a_sl; int a_ld; long a_term;
+  const float* B; const float* b_ptrs[8]; long b_sl; int b_ld;
+  float* C;
+  int M, N, K, ksplit, S;
+};
+struct TwJobs {
+  TwArgs job[2]; int first1; ReduceJobs red; int nred, red_bx, red_nparts, red_acc; long red_n;
+  gw::WArgs wj; int nw;
+};
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <bool SUM3, int NP>
+__device__ __forceinline__ void gemm_tn_wide_body(const TwArgs& g, const int bid, const int nblk, short* const lds) {
+  static_assert(NP == 2 || NP == 3, "pieces per operand");
+  constexpr int OPERA = NP * IMGA, OPERB = NP * IMGB, BUF = OPERA + OPERB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3, li = lane & 31, lh = lane >> 5;
+  // XCD-run order (gemm_tn.hip): the tiles of a part share an XCD's L2
+  const int ntn = g.N / BN, ntiles = (g.M / BM) * ntn;
+  int lin = bid;
+  if ((nblk & 7) == 0) lin = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  const int z = lin / ntiles, t = lin % ntiles;
+  const int m0 = (t / ntn) * BM, n0 = (t % ntn) * BN;
+  const int lvl = z / g.S, p = z % g.S;
+  const int kbeg = p * g.ksplit, kend = min(g.K, kbeg + g.ksplit);
+  const int steps = (kend - kbeg + BK - 1) / BK;
+  const float* Ab = g.A + (long)lvl * g.a_sl;
+  const float* Bb = g.b_ptrs[0] ? g.b_ptrs[lvl & 7] : g.B + (long)lvl * g.b_sl;
+  // rows past K read 0 (resource bound); rows past kend belong to the next part: ksplit % 16 == 0, so a step never straddles
+  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(Ab, (unsigned)((long)g.K * g.a_ld * 4));
+  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(Bb, (unsigned)((long)g.K * g.b_ld * 4));
+  const unsigned tbytes = (SUM3 && g.a_term) ? (unsigned)((long)g.K * g.a_ld * 4) : 0u;
+  const __amdgpu_buffer_rsrc_t rs_a1 = make_rsrc(Ab + (SUM3 ? g.a_term : 0), tbytes);
+  const __amdgpu_buffer_rsrc_t rs_a2 = make_rsrc(Ab + (SUM3 ? 2 * g.a_term : 0), tbytes);
+
+  // staging per step: A one float4 per thread (16 k-rows x 128 columns), B two (8 k-rows x 256 columns, twice)
+  const int ska = tid >> 5, sma = (tid & 31) * 4, skb = tid >> 6, smb = (tid & 63) * 4;
+  const int a_voff = ((kbeg + ska) * g.a_ld + m0 + sma) * 4, b_voff = ((kbeg + skb) * g.b_ld + n0 + smb) * 4;
+  const int a_step = BK * g.a_ld * 4, b_step = BK * g.b_ld * 4, b_half = 8 * g.b_ld * 4;
+  const int sta = ska * LDTA + sma, stb = OPERA + skb * LDTB + smb;          // (+ 8 * LDTB for the second B float4)
+  // transposed fragment read: each 16-lane group fetches a 4 (k) x 16 (rows) block; lane 4q+p of the group supplies
+  // the address of block row q, columns 4p..4p+3, and receives the 4 k of row (lane & 15)
+  const int trq = 8 * lh + ((lane & 15) >> 2), trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const int a_rd = trq * LDTA + trc + wr * 64, b_rd = OPERA + trq * LDTB + trc + wc * 64;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 raw[3];                                  // A, B k 0..7, B k 8..15 of the step being staged
+  f32x4 rawt[2];                                 // SUM3: the other two terms of raw[0]
+  bf16x4 fa[2][3][2][2], fb[2][3][2][2];         // [set][piece][tile][k half]: fragment = {lo, hi}
+  unsigned ph[2], pm[2], pl[2];
+  float ra[2], rb[2];
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0};      // smallest terms first (gemm.hip's order)
+  constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+  auto load_raw = [&](int x, int s) {            // (the step goes into the VECTOR offset: the range check does not see the scalar one)
+    if (x == 0) {
+      raw[0] = buf_load4(rs_a, a_voff + s * a_step, 0);
+      if (SUM3) {
+        rawt[0] = buf_load4(rs_a1, a_voff + s * a_step, 0);
+        rawt[1] = buf_load4(rs_a2, a_voff + s * a_step, 0);
+      }
+    } else raw[x] = buf_load4(rs_b, b_voff + (x - 1) * b_half + s * b_step, 0);
+  };
+  auto stage = [&](int x, int e, int st) {       // split of raw[x], pair e, in three stages of 5, 5 and 1 VALU
+    if (st == 0) {
+      if (SUM3 && x == 0) {                      // (level order 0 + 1 + 2, as the separate summing pass adds them)
+        raw[0][2 * e] = (raw[0][2 * e] + rawt[0][2 * e]) + rawt[1][2 * e];
+        raw[0][2 * e + 1] = (raw[0][2 * e + 1] + rawt[0][2 * e + 1]) + rawt[1][2 * e + 1];
+      }
+      ph[e] = cvt_pk_bf16(raw[x][2 * e], raw[x][2 * e + 1]);
+      ra[e] = sub1(raw[x][2 * e], __builtin_bit_cast(float, ph[e] << 16));
+      rb[e] = sub1(raw[x][2 * e + 1], __builtin_bit_cast(float, ph[e] & 0xffff0000u));
+    } else if (st == 1) {
+      pm[e] = cvt_pk_bf16(ra[e], rb[e]);
+      if (NP == 2) return;
+      ra[e] = sub1(ra[e], __builtin_bit_cast(float, pm[e] << 16));
+      rb[e] = sub1(rb[e], __builtin_bit_cast(float, pm[e] & 0xffff0000u));
+    } else if (NP == 3) {
+      pl[e] = cvt_pk_bf16(ra[e], rb[e]);
+    }
+  };
+  auto write_piece = [&](short* buf, int x, int q) {
+    if (q >= NP) return;
+    const u32x2 v = q == 0 ? u32x2{ph[0], ph[1]} : (q == 1 ? u32x2{pm[0], pm[1]} : u32x2{pl[0], pl[1]});
+    if (x == 0) *reinterpret_cast<u32x2*>(&buf[q * IMGA + sta]) = v;
+    else *reinterpret_cast<u32x2*>(&buf[q * IMGB + (x - 1) * 8 * LDTB + stb]) = v;
+  };
+  // fragment reads in the order of first use: a2, b0, a0, b2, a1, b1 (tile 0, tile 1; lo, hi): r = 0..23
+  auto read_frag = [&](auto SETc, const short* buf, int r) {
+    constexpr int SET = decltype(SETc)::value;
+    constexpr int QA[3] = {2, 0, 1}, QB[3] = {0, 2, 1};
+    const int grp = r >> 2, isb = grp & 1, q = isb ? QB[grp >> 1] : QA[grp >> 1], tile = (r >> 1) & 1, hi = r & 1;
+    if (q >= NP) return;
+    if (isb) fb[SET][q][tile][hi] = lds_tr16(buf + q * IMGB + b_rd + tile * 32 + hi * 4 * LDTB);
+    else fa[SET][q][tile][hi] = lds_tr16(buf + q * IMGA + a_rd + tile * 32 + hi * 4 * LDTA);
+  };
+  auto frag = [&](const bf16x4 (&f)[2]) { return bf16x8{f[0][0], f[0][1], f[0][2], f[0][3], f[1][0], f[1][1], f[1][2], f[1][3]}; };
+  // one 16-k step: MFMAs on fragment set SET; raw (step s + 1) is split into image `nxt`, re-requested for step
+  // s + 2, and after the barrier the fragments of step s + 1 are read into the other set
+  auto step = [&](auto SETc, int s, short* nxt) {
+    constexpr int SET = decltype(SETc)::value;
+    using OTHER = std::integral_constant<int, SET ^ 1>;
+#pragma unroll
+    for (int n = 0; n < 24; ++n) {
+      // the MFMA of slot n: all 24 (NP = 3), every other slot (NP = 2: products 3 .. 5)
+      const int mi = NP == 2 ? n >> 1 : n;
+      const bool mf = NP == 3 || (n & 1);
+      const int tt = NP == 2 ? 3 + (mi >> 2) : n >> 2, i = (mi >> 1) & 1, j = mi & 1;
+      if (mf)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(fa[SET][PA[tt]][i]), frag(fb[SET][PB[tt]][j]), acc[i][j], 0, 0, 0);
+      // raw[x]: pair 0 stages in slots 4x, 4x+1, 4x+2; pair 1 in 4x+1, 4x+2, 4x+3; pieces written in 4x+3 .. 4x+5
+      if (n < 12) {
+        const int x = n >> 2, u = n & 3;
+        if (u <= 2) stage(x, 0, u);
+        if (u >= 1) stage(x, 1, u - 1);
+        if (u == 3) load_raw(x, s + 2);
+      }
+      if (n >= 3 && n < 14) {
+        const int w = n - 3, x = w >> 2, q = w & 3;
+        if (q < 3) write_piece(nxt, x, q);
+      }
+      if (n == 18) lds_barrier();
+      if (n >= 18) {
+#pragma unroll
+        for (int r = 4 * (n - 18); r < 4 * (n - 17); ++r) read_frag(OTHER{}, nxt, r);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  short* const img0 = lds;
+  short* const img1 = lds + BUF;
+  // prologue: step 0 into image 0, raw = step 1, fragments of step 0 in set 0
+#pragma unroll
+  for (int x = 0; x < 3; ++x) load_raw(x, 0);
+#pragma unroll
+  for (int x = 0; x < 3; ++x) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int st = 0; st < 3; ++st) stage(x, e, st);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) write_piece(img0, x, q);
+    load_raw(x, 1);
+  }
+  lds_barrier();
+#pragma unroll
+  for (int r = 0; r < 24; ++r) read_frag(I0{}, img0, r);
+  // (loads past the part's last step read rows of the next part or 0; they are split into the idle image and never used)
+  int s = 0;
+  for (; s + 2 <= steps; s += 2) {               // (one loop exit: the accumulators stay in place)
+    step(I0{}, s, img1);
+    step(I1{}, s + 1, img0);
+  }
+  if (s < steps) step(I0{}, s, img1);
+
+  float* Cb = g.C + (long)z * g.M * g.N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      float* crow = Cb + (long)row * g.N + n0 + wc * 64 + li;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) crow[j * 32] = acc[i][j][r];
+    }
+}
+
+// [small reductions][job 0 parts][job 1 parts][tiles of the dQ projection on gemm_w_body<.., 8>]
+template <bool SUM3, int NP>
+__global__ __launch_bounds__(NTHR, 2) void gemm_tn_wide_kernel(const TwJobs jobs) {
+  extern __shared__ __attribute__((aligned(16))) short lds_dyn[];
+  const int id = (int)blockIdx.x - jobs.nred, ngemm = (int)gridDim.x - jobs.nred - jobs.nw;
+  if (id >= ngemm) {
+    gw::gemm_w_body<false, NP, 8>(jobs.wj, id - ngemm, lds_dyn);
+    return;
+  }
+  if (id < 0) {
+    reduce_jobs_block(jobs.red, jobs.red_nparts, jobs.red_n, jobs.red_acc, (int)blockIdx.x % jobs.red_bx,
+                      (int)blockIdx.x / jobs.red_bx, reinterpret_cast<float(*)[64]>(lds_dyn), threadIdx.x < 256);
+    return;
+  }
+  if (id < jobs.first1) gemm_tn_wide_body<SUM3, NP>(jobs.job[0], id, jobs.first1, lds_dyn);
+  else gemm_tn_wide_body<false, NP>(jobs.job[1], id - jobs.first1, ngemm - jobs.first1, lds_dyn);
+}
+
+}  // namespace
+
+int gemm_tn_wide_supported(const TnGemm& d) {
+  static const int on = [] { const char* e = getenv("COATTN_TN_WIDE"); return e ? atoi(e) : 1; }();   // developer switch
+  return on && gemm_tn_supported(d) && !d.bf16 && d.np == 2 && !d.b_kdiv && d.mask_blk == 0 && (d.M % BM) == 0 && (d.N % BN) == 0;
+}
+
+// split-K plan for `max_parts` parts (32 parts x 8 tiles of 128 x 256 = one workgroup per CU at d = 512)
+int gemm_tn_wide_plan(const TnGemm& d, int max_parts, int* ksplit, int* S) {
+  int want = max_parts / d.levels;                 // (the caller shares its budget of parts between the jobs of a launch)
+  if (want < 1) want = 1;
+  int ks = (d.K + want - 1) / want;
+  ks = (ks + BK - 1) / BK * BK;
+  *ksplit = ks;
+  *S = (d.K + ks - 1) / ks;
+  return d.levels * *S;
+}
+
+int launch_gemm_tn_wide(const TnGemm* d, const int* ksplit, const int* S, int n, hipStream_t s, const TnReduce* red,
+                        const WGemm* wextra) {
+  CA_CHECK_ARG(n == 1 || n == 2, "gemm_tn_wide: 1 or 2 jobs per launch");
+  TwJobs jobs = {};
+  if (wextra) {
+    long nbw = 0;
+    CA_CHECK_ARG(wextra->a_sk == 0 && wextra->np == 2 && !wextra->bf16 && wextra->N % 256 == 0 && wextra->kband_n == 0,
+                 "gemm_tn_wide: the extra GEMM must be a row-major two-piece product with N %% 256 == 0");
+    CA_TRY(gemm_w_fill_job(*wextra, jobs.wj, &nbw, 256));
+    jobs.nw = (int)nbw;
+  }
+  if (red) {
+    CA_CHECK_ARG(red->njobs >= 1 && red->njobs <= 4 && red->n > 0, "gemm_tn_wide: bad reduction jobs");
+    for (int i = 0; i < red->njobs; ++i) { jobs.red.src[i] = red->src[i]; jobs.red.dst[i] = red->dst[i]; }
+    jobs.red.njobs = red->njobs;
+    const int nsum = red->sum_x[0] ? 2 : 0;
+    for (int i = 0; i < nsum; ++i) { jobs.red.sum_x[i] = red->sum_x[i]; jobs.red.sum_out[i] = red->sum_out[i]; }
+    jobs.red.sum_n = red->sum_n; jobs.red.ld = red->ld;
+    jobs.red_bx = (int)((red->n + 63) / 64);
+    jobs.nred = jobs.red_bx * (red->njobs + nsum);
+    jobs.red_nparts = red->nparts; jobs.red_n = red->n; jobs.red_acc = red->accumulate;
+  }
+  long nb[2] = {0, 0};
+  for (int i = 0; i < n; ++i) {
+    CA_CHECK_ARG(gemm_tn_wide_supported(d[i]), "gemm_tn_wide: unsupported shape M=%d N=%d K=%d", d[i].M, d[i].N, d[i].K);
+    CA_CHECK_ARG(d[i].A && (d[i].B || d[i].b_ptrs[0]) && d[i].C && ksplit[i] > 0 && (ksplit[i] % BK) == 0 && (long)S[i] * ksplit[i] >= d[i].K,
+                 "gemm_tn_wide: bad arguments");
+    CA_CHECK_ARG(i == 0 || d[i].a_term == 0, "gemm_tn_wide: only the first job may sum three A terms");
+    TwArgs& g = jobs.job[i];
+    g = TwArgs{};
+    g.A = d[i].A; g.a_sl = d[i].a_sl; g.a_ld = d[i].a_ld; g.a_term = d[i].a_term;
+    g.B = d[i].B; g.b_sl = d[i].b_sl; g.b_ld = d[i].b_ld;
+    for (int t = 0; t < 8; ++t) g.b_ptrs[t] = d[i].b_ptrs[t];
+    g.C = d[i].C; g.M = d[i].M; g.N = d[i].N; g.K = d[i].K; g.ksplit = ksplit[i]; g.S = S[i];
+    nb[i] = (long)(d[i].M / BM) * (d[i].N / BN) * d[i].levels * S[i];
+  }
+  CA_CHECK_ARG(nb[0] + nb[1] < 2147483647L, "gemm_tn_wide: grid too large");
+  jobs.first1 = (int)nb[0];
+  const bool sum3 = d[0].a_term != 0;
+  const dim3 grid((unsigned)(jobs.nred + nb[0] + nb[1] + jobs.nw));
+  size_t lds = (size_t)2 * 2 * (IMGA + IMGB) * sizeof(short);              // two buffers of two pieces: 57,344 B
+  if (wextra && lds < (size_t)2 * 2 * gw::BM * gw::LDR * sizeof(short)) lds = (size_t)2 * 2 * gw::BM * gw::LDR * sizeof(short);
+  if (sum3) hipLaunchKernelGGL((gemm_tn_wide_kernel<true, 2>), grid, dim3(NTHR), lds, s, jobs);
+  else hipLaunchKernelGGL((gemm_tn_wide_kernel<false, 2>), grid, dim3(NTHR), lds, s, jobs);
+  CA_CHECK_LAUNCH("gemm_tn_wide");
+  return 0;
+}

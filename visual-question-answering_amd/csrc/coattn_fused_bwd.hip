@@ -98,6 +98,9 @@ struct PreArgs {
 // Blocks [0, L*B): one workgroup (256 threads) per (sample, level), question side -- softmax backward of a_q
 // (da_q = Q gq), dZ_q = ds_q (x) w_q (.) (1 - H_q^2), dw_q / dc_q partials.  Blocks past L*B: the da_v partials
 // (one pass over V for all levels, independent of the question side: they fill the idle half of the chip).
+// (Round 4, measured and not kept: requesting a wave's rows together -- all 7 Q rows of the da_q dot products, all 14 / 2 x 7
+//  H_q rows of the dZ_q sweep, the 4 V rows of a da_v wave -- costs registers the da_v blocks of the same launch pay for
+//  with occupancy: 60 -> 102 / 128 VGPRs, 27.7 -> 32.6 / 37.3 us at N = 196, 22.7 -> 22.3 / 21.6 at N = 49.)
 __global__ __launch_bounds__(256) void bwd_pre_kernel(const PreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int d = a.d, T = a.T, B = a.B;
@@ -369,7 +372,8 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   wdq.bf16 = bf16_proj; wdq.np = np;
   const bool wdq_ok = wgemm && q_al && gemm_w_supported(wdq);
   // (a dQ projection on gemm_bf.hip -- 512-thread workgroups -- cannot ride in the weight-gradient launch)
-  const bool combine = dq32 && wdq_ok && tn_v && tn_q && !gemm_bf_supported(wdq);
+  static const int no_combine = [] { const char* e = getenv("COATTN_NO_COMBINE"); return e ? atoi(e) : 0; }();   // developer switch
+  const bool combine = dq32 && wdq_ok && tn_v && tn_q && !gemm_bf_supported(wdq) && !no_combine;
   // Reduced-precision mode with a frozen image encoder (no dV) and all three consumers of dP_v / dP_q on gemm_bf.hip:
   // bwd_nat32 stores both as bf16 -- the GEMMs would round them on their way in anyway -- halving what it writes and
   // what they fetch.

@@ -138,7 +138,9 @@ int launch_gemm_w(const WGemm* d, int n, hipStream_t s) {
   long nb[2] = {0, 0};
   // single-product mode with wide outputs: 128 x 256 tiles on 512 threads (the A rows are staged once for twice the columns)
   static const int wide2 = [] { const char* e = getenv("COATTN_GEMMW_WIDE2"); return e ? atoi(e) : 0; }();   // developer switch
-  bool wide = d[0].bf16 != 0 || (wide2 && d[0].np == 2 && (n == 1 || d[1].np == 2));
+  static const int wide32 = [] { const char* e = getenv("COATTN_GEMMW_WIDE32"); return e ? atoi(e) : 0; }();  // developer switch: the forward's (3, 2) launch
+  const bool mixed32 = wide32 && !d[0].bf16 && n == 2 && d[0].np != 2 && d[1].np == 2;
+  bool wide = d[0].bf16 != 0 || (wide2 && d[0].np == 2 && (n == 1 || d[1].np == 2)) || mixed32;
   for (int i = 0; i < n; ++i) wide = wide && d[i].N % 256 == 0 && (d[i].kband_n == 0 || d[i].kband_n % 256 == 0);
   for (int i = 0; i < n; ++i) CA_TRY(gemm_w_fill_job(d[i], jobs.job[i], &nb[i], wide ? 256 : BN));
   CA_CHECK_ARG(nb[0] + nb[1] < 2147483647L, "gemm_w: grid too large");
@@ -147,7 +149,10 @@ int launch_gemm_w(const WGemm* d, int n, hipStream_t s) {
   CA_CHECK_ARG(n == 1 || d[1].bf16 == d[0].bf16, "gemm_w: the jobs of a launch share the precision mode");
   const bool two0 = d[0].np == 2, two1 = n == 2 ? d[1].np == 2 : two0;      // fp32 mode: the width of each job
   const dim3 grid((unsigned)(nb[0] + nb[1]));
-  if (wide && !d[0].bf16) {
+  if (wide && mixed32) {
+    if (d[0].a_sk) hipLaunchKernelGGL((gemm_w_kernel<true, 3, 8, 2>), grid, dim3(512), 0, s, jobs);
+    else hipLaunchKernelGGL((gemm_w_kernel<false, 3, 8, 2>), grid, dim3(512), 0, s, jobs);
+  } else if (wide && !d[0].bf16) {
     if (d[0].a_sk) hipLaunchKernelGGL((gemm_w_kernel<true, 2, 8>), grid, dim3(512), 0, s, jobs);
     else hipLaunchKernelGGL((gemm_w_kernel<false, 2, 8>), grid, dim3(512), 0, s, jobs);
   } else if (wide) {

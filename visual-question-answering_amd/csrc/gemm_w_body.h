@@ -4,6 +4,14 @@
 #include "common.h"
 #include "fused.h"
 
+// Developer switch: non-temporal stores for the result.  By itself the GEMM gains (the fp32 output leaves in one burst when
+// the workgroups of a round finish together: P_v-shaped 58.3 -> 54.7 us at two pieces, dQ-shaped 28.5 -> 26.4, width 3
+// 86.7 -> 85.3), but the kernels that read the result next lose what the stores no longer leave in the caches: whole
+// forward + backward 550 -> 560 us at N = 196, 271 -> 270 at N = 49 (tools/ab_libs.sh, same box, twice).  Off.
+#ifndef GEMMW_NTSTORE
+#define GEMMW_NTSTORE 0
+#endif
+
 namespace gw {
 
 constexpr int BM = 128, BN = 128, BK = 32;    // (BN: the four-wave tile; gemm_w_body<.., 8> takes 256 columns)
@@ -282,7 +290,11 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
 #endif
 #pragma unroll
       for (int j = 0; j < 2; ++j)
+#if GEMMW_NTSTORE
+        if (col[j] < g.N) __builtin_nontemporal_store((acc[i][j][r] + bn[j]) * g.oscale, &crow[col[j]]);
+#else
         if (col[j] < g.N) crow[col[j]] = (acc[i][j][r] + bn[j]) * g.oscale;
+#endif
     }
 }
 

@@ -264,3 +264,23 @@ def test_trainer_default_path_matches_the_module_path(monkeypatch):
         losses[mode] = [float(tr.step(im, qu, ln, la, next_image=im).detach()) for _ in range(3)]
     for a, b in zip(losses["modules"], losses["static"]):
         assert abs(a - b) <= 1e-5 * abs(a)
+
+
+def test_hot_path_node_is_rebuilt_when_the_module_moves():
+    """The node reads the parameters where they lie; moving the module (new storages) must not leave it reading the old ones."""
+    from vqa_amd import train as T
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = T.build_model("attention", 100, 10).to(dev)
+    tr = T.Trainer(model, 1e-4, dev)
+    b = T.synthetic_batch(4, (64, 64), 26, 100, 11, seed=1)
+    im, qu, la, ln = T.sort_batch(b["image"], b["question"], b["label"], b["ques_len"])
+    im, qu, la = im.to(dev), qu.to(dev), la.to(dev)
+    tr.step(im, qu, ln, la)
+    first = next(iter(model._graphs.values()))
+    model.float().cpu().to(dev)                              # round trip: every parameter gets new storage
+    tr.optimizer = torch.optim.Adam(model.parameters(), 1e-4)
+    loss = tr.step(im, qu, ln, la)
+    assert torch.isfinite(loss)
+    second = next(iter(model._graphs.values()))
+    assert second is not first and second.co_params[0] is model.co_attention.W_v.weight

@@ -72,6 +72,7 @@ class HotPathGraph:
         for p in self.co_params + self.head_params:
             if not p.is_contiguous() or p.dtype != torch.float32:
                 raise RuntimeError("HotPathGraph: parameters must be contiguous fp32")
+        self.param_ptr0 = self.co_params[0].data_ptr()                # (modules.HierarchicalCoAttentionNet checks it: the module may move)
         self.co_grads = [torch.empty_like(p) for p in self.co_params]
         self.head_grads = [torch.empty_like(p) for p in self.head_params]
         sb, fb, bb = _lib.workspace_bytes(B, N, T, d, 3, flags)

@@ -356,6 +356,11 @@ class HierarchicalCoAttentionNet(nn.Module):
         key = (B, N, T, bool(x_img_features.requires_grad), bool(self.co_attention.bf16_projections),
                bool(self.mlp_classify.bf16_products), bool(self.hot_path_graph), bool(self.hot_path_direct_grads))
         hp = self._graphs.get(key)
+        # (the node reads the parameters where they lie: one built before the module was moved -- .to(), .cuda(), new
+        #  Parameter objects -- would read the old storage)
+        if hp is not None and (hp.co_params[0] is not self.co_attention.W_v.weight or hp.head_params[6] is not self.mlp_classify.W_h.weight
+                               or hp.co_params[0].data_ptr() != hp.param_ptr0):
+            hp = None
         if hp is None:
             hp = self._graphs[key] = HotPathGraph(self.co_attention, self.mlp_classify, B, N, T, need_dv=key[3],
                                                   flags=_lib.FLAG_BF16_PROJ if key[4] else 0, capture=key[6],

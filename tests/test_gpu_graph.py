@@ -278,7 +278,9 @@ def test_hot_path_node_is_rebuilt_when_the_module_moves():
     im, qu, la = im.to(dev), qu.to(dev), la.to(dev)
     tr.step(im, qu, ln, la)
     first = next(iter(model._graphs.values()))
+    keep = [p.data for p in model.parameters()]              # (held: the allocator must not hand the same blocks back)
     model.float().cpu().to(dev)                              # round trip: every parameter gets new storage
+    assert keep[0].data_ptr() != next(model.parameters()).data_ptr()
     tr.optimizer = torch.optim.Adam(model.parameters(), 1e-4)
     loss = tr.step(im, qu, ln, la)
     assert torch.isfinite(loss)

@@ -211,7 +211,9 @@ def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20, b
         fb()
     e1.record()
     torch.cuda.synchronize()
-    t_dev = e0.elapsed_time(e1) * 1e-3 / (3 * iters)
+    t_autograd = e0.elapsed_time(e1) * 1e-3 / (3 * iters)      # (through the autograd function: host-paced on a slow host)
+    # the two C-ABI calls themselves, back to back from pre-built argument blocks: device-paced whatever the host
+    t_dev = coattn_device_time(device, B=B, N=N, T=T, d=d, layout=layout, bf16=bf16)
     fwd = bwd = 0.0
     for it in range(iters + 3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -231,6 +233,9 @@ def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20, b
             "graph_ms_per_step": round(gdt * 1e3, 3), "graph_host_enqueue_ms": round(ghost * 1e3, 3),
             "graph_pairs_per_s": round(B / gdt, 1),
             "coattn_fwd_bwd_ms": round(t_dev * 1e3, 4), "coattn_fwd_bwd_tflops": round(flop / t_dev / 1e12, 2),
+            "coattn_fwd_bwd_note": "device time of coattn_forward + coattn_backward (C-ABI calls back to back, HIP events); "
+                                   "coattn_fwd_bwd_autograd_ms: the same through the autograd function (host-paced on a slow host)",
+            "coattn_fwd_bwd_autograd_ms": round(t_autograd * 1e3, 4),
             "coattn_fwd_wall_ms": round(fwd / iters * 1e3, 4), "coattn_bwd_wall_ms": round(bwd / iters * 1e3, 4),
             "coattn_fwd_bwd_wall_tflops": round(flop / ((fwd + bwd) / iters) / 1e12, 2)}
 
@@ -301,18 +306,9 @@ def roofline_leg(device, B=160, N=196, T=26, d=512, L=3, iters=100, layout="lm")
             "algorithmic_bytes": alg}
 
 
-def backward_legs(device, B=160, N=196, T=26, d=512, L=3, iters=60, layout="lm", bf16=False):
-    """Every launch group of coattn_backward (frozen image encoder: no dV, the train step's case), timed by the HIP
-    events the library records between its launches (coattn_profile_begin / coattn_profile_end) -- averaged over `iters`
-    calls after a clock warm-up.  Algorithmic bytes per launch (DESIGN.md section 3.3; fp32, per (pair, level) unless
-    stated): what each kernel must read and write once --
-      bwd_pre    V once per pair (da_v for the three levels) + per level Q, H_q read, dZ_q written
-      bwd_dc32   P_v, P_q, dZ_q, C read, dA written
-      bwd_nat32  P_v, P_q, dZ_q, C read, dP_v, dP_q written
-      bwd_dq     V, dA read, dQ read and written
-      bwd_gemm   MFMA-bound: 2 (B N d^2 + 2 L B T d^2) flops (dW_v, dW_q, dQ = dP_q W_q) against the dense bf16 peak /
-                 partial products per fp32 product (3 at the two-piece width, 6 at the exact split); its HBM bytes beside
-    against 8 TB/s."""
+def coattn_c_calls(device, B, N, T, d, L, layout, bf16):
+    """coattn_forward / coattn_backward (frozen image encoder: no dV) as closures over pre-built argument blocks on synthetic
+    features: (lib, stream, fwd, bwd).  A call costs the host one ctypes crossing, so loops over them are device-paced."""
     import ctypes as C
     import vqa_amd
     from vqa_amd import _lib
@@ -340,11 +336,52 @@ def backward_legs(device, B=160, N=196, T=26, d=512, L=3, iters=60, layout="lm",
     _lib.check(lib.coattn_forward(V.data_ptr(), *vstr, qptr, C.byref(p), v.data_ptr(), q.data_ptr(), saved.data_ptr(),
                                   ws.data_ptr(), B, N, T, d, L, _lib.F32, flags, stream), "coattn_forward")
 
+    def fwd():
+        return lib.coattn_forward(V.data_ptr(), *vstr, qptr, C.byref(p), v.data_ptr(), q.data_ptr(), saved.data_ptr(),
+                                  ws.data_ptr(), B, N, T, d, L, _lib.F32, flags, stream)
+
     def bwd():
         return lib.coattn_backward(V.data_ptr(), *vstr, qptr, C.byref(p), saved.data_ptr(), gv.data_ptr(), gq.data_ptr(),
                                    None, 0, 0, 0, dqptr, C.byref(pg), 0, ws.data_ptr(), B, N, T, d, L, _lib.F32, flags, stream)
 
     _lib.check(bwd(), "coattn_backward")
+    fwd.keep = bwd.keep = (V, Qs, ps, saved, ws, v, q, gv, gq, dQs, grads, qptr, dqptr, p, pg)   # (the closures' buffers)
+    return lib, stream, fwd, bwd
+
+
+def coattn_device_time(device, B=160, N=196, T=26, d=512, L=3, layout="lm", bf16=False, iters=50):
+    """Device time of one coattn_forward + coattn_backward (HIP events around `iters` back-to-back pairs of C-ABI calls, the
+    median of three windows after a clock warm-up)."""
+    lib, stream, fwd, bwd = coattn_c_calls(device, B, N, T, d, L, layout, bf16)
+    for _ in range(2 * iters):
+        fwd(); bwd()
+    ts = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fwd(); bwd()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e-3 / iters)
+    return sorted(ts)[1]
+
+
+def backward_legs(device, B=160, N=196, T=26, d=512, L=3, iters=60, layout="lm", bf16=False):
+    """Every launch group of coattn_backward (frozen image encoder: no dV, the train step's case), timed by the HIP
+    events the library records between its launches (coattn_profile_begin / coattn_profile_end) -- averaged over `iters`
+    calls after a clock warm-up.  Algorithmic bytes per launch (DESIGN.md section 3.3; fp32, per (pair, level) unless
+    stated): what each kernel must read and write once --
+      bwd_pre    V once per pair (da_v for the three levels) + per level Q, H_q read, dZ_q written
+      bwd_dc32   P_v, P_q, dZ_q, C read, dA written
+      bwd_nat32  P_v, P_q, dZ_q, C read, dP_v, dP_q written
+      bwd_dq     V, dA read, dQ read and written
+      bwd_gemm   MFMA-bound: 2 (B N d^2 + 2 L B T d^2) flops (dW_v, dW_q, dQ = dP_q W_q) against the dense bf16 peak /
+                 partial products per fp32 product (3 at the two-piece width, 6 at the exact split); its HBM bytes beside
+    against 8 TB/s."""
+    import ctypes as C
+    from vqa_amd import _lib
+    lib, stream, _fwd, bwd = coattn_c_calls(device, B, N, T, d, L, layout, bf16)
     for _ in range(2 * iters):                         # clock warm-up (see roofline_leg)
         bwd()
     us = (C.c_float * 48)()

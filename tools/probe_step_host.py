@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer probe: where the HOST time of one isolated hot-path step (co-attention + answer head + loss, forward and
 backward; bench.py hot_path_leg) goes -- cProfile over pipelined steps, eager and graph-replayed.
-usage: tools/probe_step_host.py [N=49] [eager|graph]"""
+usage: tools/probe_step_host.py [N=49] [eager|static|graph]   (eager: module by module; static: one node, calls issued eagerly)"""
 import cProfile, os, pstats, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,7 +20,8 @@ x_img = torch.randn(B, N, d, device=dev).clamp_min_(0)
 Qs = [torch.randn(B, T, d, device=dev).requires_grad_(True) for _ in range(3)]
 label = (torch.arange(B, device=dev) * 7) % (K + 1)
 params = list(co.parameters()) + list(mlp.parameters())
-hp = HotPathGraph(co, mlp, B, N, T) if mode == "graph" else None
+hp = (HotPathGraph(co, mlp, B, N, T, direct_grads=True) if mode == "graph" else
+      HotPathGraph(co, mlp, B, N, T, capture=False, direct_grads=True) if mode == "static" else None)
 
 def step():
     for p in params:

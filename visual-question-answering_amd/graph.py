@@ -88,13 +88,14 @@ class HotPathGraph:
         self.pair(self._static)
 
     def _key(self, ins):
-        return tuple(t.data_ptr() for t in ins) + tuple(ins[0].stride())
+        V = ins[0]
+        return (V.data_ptr(), ins[1].data_ptr(), ins[2].data_ptr(), ins[3].data_ptr(), ins[4].data_ptr(), V.stride(0), V.stride(1), V.stride(2))
 
-    def _plan(self, ins):
+    def _plan(self, ins, key=None):
         """Argument blocks of the four C-ABI calls for the inputs `ins` = (V [B,N,d] in a native layout, Q_w, Q_p, Q_s,
         labels), built once per address set (everything but the stream).  Parameters are read where they lie (the
         optimiser updates them in place); the ctypes blocks are kept alive by the plan."""
-        key = self._key(ins)
+        key = key or self._key(ins)
         plan = self._plans.get(key)
         if plan is not None:
             return plan
@@ -148,15 +149,15 @@ class HotPathGraph:
                 and all(q.is_contiguous() and q.dtype == torch.float32 and q.data_ptr() % 16 == 0 and q.device == self.device
                         for q in ins[1:4]))
 
-    def pair(self, ins):
+    def pair(self, ins, key=None):
         """(forward graph, backward graph) reading the inputs at the addresses of `ins`; captured on first use, or
         None when MAX_KEYS address sets are already held (the caller then copies into the static inputs)."""
-        key = self._key(ins)
+        if not self.capture:                                     # eager mode: nothing to capture (run() issues the calls)
+            return _EAGER
+        key = key or self._key(ins)
         hit = self._pairs.get(key)
         if hit is not None:
             return hit
-        if not self.capture:                                     # eager mode: nothing to capture (run() issues the calls)
-            return _EAGER
         if len(self._pairs) >= self.MAX_KEYS:
             return None
         with torch.cuda.device(self.device):
@@ -183,11 +184,20 @@ class HotPathGraph:
         """The same calls without the graphs (tests compare the two bit for bit)."""
         self._enqueue(ins or self._static, torch.cuda.current_stream(self.device).cuda_stream)
 
-    def run(self, pair, ins, fwd: bool):
-        """One direction of the hot path: replay the captured graph, or (eager mode) issue its two C-ABI calls."""
+    def run(self, pair, ins, fwd: bool, plan=None):
+        """One direction of the hot path: replay the captured graph, or (eager mode) issue its two C-ABI calls (`plan`: the
+        argument blocks of `ins`, if the caller has them already)."""
         if pair is _EAGER:
+            plan = plan or self._plan(ins)
+            lib = self._lib
+            st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
             with _lib.on_device(self.device):
-                self._enqueue(ins, torch.cuda.current_stream(self.device).cuda_stream, fwd, not fwd)
+                if fwd:
+                    _lib.check(lib.coattn_forward(*plan["co_fwd"], st), "coattn_forward")
+                    _lib.check(lib.coattn_head_forward(*plan["head_fwd"], st), "coattn_head_forward")
+                else:
+                    _lib.check(lib.coattn_head_backward(*plan["head_bwd"], st), "coattn_head_backward")
+                    _lib.check(lib.coattn_backward(*plan["co_bwd"], st), "coattn_backward")
         else:
             pair[0 if fwd else 1].replay()
 
@@ -198,6 +208,11 @@ class HotPathGraph:
         self.run(pair, ins, False)
 
     def __call__(self, x_img: torch.Tensor, x_ques: Sequence[torch.Tensor], labels: torch.Tensor):
+        # With direct gradients the parameters need not be inputs of the autograd node (their gradients do not travel through
+        # autograd) as long as some input keeps the node alive -- the question levels of a trainable question encoder do;
+        # 6 arguments instead of 22 through the Function machinery on every step.
+        if self.direct_grads and (x_ques[0].requires_grad or x_ques[1].requires_grad or x_ques[2].requires_grad or x_img.requires_grad):
+            return _HotPathFn.apply(self, x_img, labels, *x_ques)
         return _HotPathFn.apply(self, x_img, labels, *x_ques, *self.co_params, *self.head_params)
 
 
@@ -219,14 +234,18 @@ class _HotPathFn(torch.autograd.Function):
         #  16-byte multiples -- are re-laid once, as on the eager path; the allocator hands that buffer's block back step
         #  after step, so it is one more address set, not a copy into the static input on top)
         ins = (_native_layout(x_img), Qw, Qp, Qs, labels)
-        pair = hp.pair(ins) if hp.usable_in_place(ins) else None
+        key = hp._key(ins)
+        pair = hp.pair(ins, key) if hp.usable_in_place(ins) else None
         if pair is None:                                         # other dtype / too many address sets: static inputs
             hp.V.copy_(x_img)
             torch._foreach_copy_(hp.Q, [Qw, Qp, Qs])
             hp.labels.copy_(labels)
             ins = hp._static
-            pair = hp.pair(ins)
-        hp.run(pair, ins, True)
+            key = hp._key(ins)
+            pair = hp.pair(ins, key)
+        plan = hp._plan(ins, key) if pair is _EAGER else None   # (built once per address set; the backward reuses it)
+        hp.run(pair, ins, True, plan)
+        ctx.plan = plan
         # (as head.answer_head after a forward with labels: Trainer.check_labels() reads this step's status word)
         _head._last = (hp.hsaved, B, d, mlp, K, hp.device)
         ctx.hp, ctx.pair = hp, pair
@@ -239,7 +258,7 @@ class _HotPathFn(torch.autograd.Function):
     def backward(ctx, g_logits, g_loss):
         hp = ctx.hp
         hp.g_loss.copy_(g_loss.reshape(1))
-        hp.run(ctx.pair, ctx.keep, False)
+        hp.run(ctx.pair, ctx.keep, False, ctx.plan)
         if hp.direct_grads:
             # the owner of the step (train.Trainer) consumes the gradients before the next backward and needs no gradient
             # hooks: the static buffers BECOME param.grad (autograd's AccumulateGrad would clone each one -- it cannot
@@ -249,7 +268,7 @@ class _HotPathFn(torch.autograd.Function):
                     p.grad = g
                 else:
                     p.grad.add_(g)
-            return (None, hp.dV, None, *hp.dQ) + (None,) * 16
+            return (None, hp.dV, None, *hp.dQ) + (None,) * (len(ctx.needs_input_grad) - 6)
         # (the static gradient buffers are handed out as they are: autograd accumulates / the optimiser consumes them
         #  before the next step's backward overwrites them)
         return (None, hp.dV, None, *hp.dQ, *hp.co_grads, *hp.head_grads)

@@ -17,7 +17,7 @@ fd, wd = sys.argv[1:3]
 B, N, T, d, L = [int(x) for x in sys.argv[3:8]]
 layout = sys.argv[8]
 MARKS = {"bwd_pre_kernel": "bwd_pre", "bwd_dc32_kernel": "bwd_dc32", "bwd_nat32_kernel": "bwd_nat32", "bwd_dq32x_kernel": "bwd_dq",
-         "bwd_dq32_kernel": "bwd_dq", "gemm_tn_kernel": "bwd_gemm", "reduce_partials4_kernel": "reduce_partials"}
+         "bwd_dq32_kernel": "bwd_dq", "gemm_tn_kernel": "bwd_gemm", "gemm_tn_wide_kernel": "bwd_gemm", "reduce_partials4_kernel": "reduce_partials"}
 vals = {}
 for dd, ctr in ((fd, "FETCH_SIZE"), (wd, "WRITE_SIZE")):
     for f in glob.glob(os.path.join(dd, "**", "*counter_collection.csv"), recursive=True):

@@ -213,7 +213,9 @@ def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20, b
     torch.cuda.synchronize()
     t_autograd = e0.elapsed_time(e1) * 1e-3 / (3 * iters)      # (through the autograd function: host-paced on a slow host)
     # the two C-ABI calls themselves, back to back from pre-built argument blocks: device-paced whatever the host
-    t_dev = coattn_device_time(device, B=B, N=N, T=T, d=d, layout=layout, bf16=bf16)
+    # (channel-major rows that are not 16-byte multiples -- N = 49 -- are re-laid once by the module before the call: the
+    #  calls themselves then see location-major features)
+    t_dev = coattn_device_time(device, B=B, N=N, T=T, d=d, layout=layout if (layout == "lm" or N % 4 == 0) else "lm", bf16=bf16)
     fwd = bwd = 0.0
     for it in range(iters + 3):
         torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -374,9 +374,9 @@ def backward_legs(device, B=160, N=196, T=26, d=512, L=3, iters=60, layout="lm",
     events the library records between its launches (coattn_profile_begin / coattn_profile_end) -- averaged over `iters`
     calls after a clock warm-up.  Algorithmic bytes per launch (fp32, per (pair, level) unless
     stated): what each kernel must read and write once --
-      bwd_pre    V once per pair (da_v for the three levels) + per level Q, H_q read, dZ_q written
-      bwd_dc32   P_v, P_q, dZ_q, C read, dA written
-      bwd_nat32  P_v, P_q, dZ_q, C read, dP_v, dP_q written
+      bwd_pre    V once per pair (da_v for the three levels) + per level Q read
+      bwd_dc32   P_v, P_q, H_q, C read, dA written            (dZ_q is formed from H_q where it is used, never stored)
+      bwd_nat32  P_v, P_q, H_q, C read, dP_v, dP_q written
       bwd_dq     V, dA read, dQ read and written
       bwd_gemm   MFMA-bound: 2 (B N d^2 + 2 L B T d^2) flops (dW_v, dW_q, dQ = dP_q W_q) against the dense bf16 peak /
                  partial products per fp32 product (3 at the two-piece width, 6 at the exact split); its HBM bytes beside
@@ -407,11 +407,11 @@ def backward_legs(device, B=160, N=196, T=26, d=512, L=3, iters=60, layout="lm",
         "bwd_dq": f4 * (N * d + T * N + 2 * T * d),
     }
     alg = {k: B * L * b for k, b in per_level.items()}
-    alg["bwd_pre"] = B * f4 * (N * d + L * 3 * T * d)
+    alg["bwd_pre"] = B * f4 * (N * d + L * T * d)
     # kernels behind a mark (the names rocprofv3 shows): for matching against profiles/*_kernel_stats.csv
-    kernels = {"bwd_pre": "bwd_pre_kernel + bwd_prev_kernel", "bwd_dc32": "bwd_dc32_kernel", "bwd_nat32": "bwd_nat32_kernel",
+    kernels = {"bwd_pre": "bwd_pre_kernel", "bwd_dc32": "bwd_dc32_kernel", "bwd_nat32": "bwd_nat32_kernel",
                "bwd_dq": "bwd_dq32x_kernel" if N <= 64 else "bwd_dq32_kernel",
-               "bwd_gemm": "gemm_tn_kernel (dW_v + dW_q split-K parts, dQ = dP_q W_q tiles, small reductions)",
+               "bwd_gemm": "gemm_tn_wide_kernel / gemm_tn_kernel (dW_v + dW_q split-K parts, dQ = dP_q W_q tiles, small reductions)",
                "bwd_gemm_dw": "gemm_tn_kernel / gemm_bf_tn_kernel (dW_v + dW_q)", "bwd_gemm_dq_projection": "gemm_w_kernel / gemm_bf_kernel (dQ = dP_q W_q)",
                "reduce_partials": "reduce_partials4_kernel"}
     np_prod = 1 if bf16 else (6 if os.environ.get("COATTN_SPLIT") == "3" else 3)

@@ -16,7 +16,9 @@
 //     dZ_v = ds_v w_v (1 - H_v^2) = 4 ds_v w_v r (1 - r), r = 1 / (1 + e^{2 H}), happen in place; split, the dZ_v
 //     fragment is the B operand of dP_q += C dZ_v (contraction over the fragment's row index = locations), and then
 //     the accumulator of dP_v, stored as it lies (whole 128-byte row segments);
-//   * the dP_q accumulators start from dZ_q; dw_v, db_v, db_q partials are in-lane sums over the accumulator rows.
+//   * the dP_q accumulators start from dZ_q; dw_v, db_v, db_q partials are in-lane sums over the accumulator rows;
+//   * dZ_q = ds_q (x) w_q (.) (1 - H_q^2) is formed from the saved H_q as it is loaded (both kernels; ds_q comes from
+//     bwd_pre_kernel), and bwd_nat32_kernel sums the dw_q partial sum_t ds_q[t] H_q[t][:] on the way.
 // H_v is never stored.  Rows t >= T / n >= N fall outside the per-sample buffer descriptors (loads 0, stores dropped).
 #include "fused.h"
 #include <stdlib.h>
@@ -41,6 +43,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   short* Cimg = reinterpret_cast<short*>(smem);
   float* dsvs = reinterpret_cast<float*>(smem + 3 * PIECE * 2);   // [NPAD] ds_v, zero padded
+  float* dsqs = dsvs + NPAD;                                      // [32] ds_q, zeros for t >= T
   int b, l;
   if (!block_to_pair(blockIdx.x, a.B, a.L, b, l)) return;
   const int N = a.N, T = a.T, d = a.d;
@@ -50,7 +53,9 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
   const size_t pair = (size_t)l * a.B + b;
   const __amdgpu_buffer_rsrc_t rs_pv = make_rsrc(a.Pv + (size_t)b * N * d, (unsigned)N * d * 4u);
   const __amdgpu_buffer_rsrc_t rs_pq = make_rsrc(a.Pq + pair * (size_t)T * d, (unsigned)T * d * 4u);
-  const __amdgpu_buffer_rsrc_t rs_dzq = make_rsrc(a.dZq + pair * (size_t)T * d, (unsigned)T * d * 4u);
+  const __amdgpu_buffer_rsrc_t rs_hq = make_rsrc(a.Hq + pair * (size_t)T * d, (unsigned)T * d * 4u);
+  const __amdgpu_buffer_rsrc_t rs_wq = make_rsrc(a.wq, (unsigned)d * 4u);
+  const __amdgpu_buffer_rsrc_t rs_dwq = make_rsrc(a.dwq_part + pair * (size_t)d, (unsigned)d * 4u);
   constexpr int ES = DPB ? 2 : 4;                    // bytes of a stored dP element
   const __amdgpu_buffer_rsrc_t rs_dpq = make_rsrc(reinterpret_cast<const char*>(a.dPq) + pair * (size_t)T * d * ES, (unsigned)T * d * ES);
   const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(a.C + pair * (size_t)T * N, (unsigned)T * N * 4u);
@@ -69,8 +74,9 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
     }
   };
   // B operands of a pass (32 channels c0 .. c0 + 31, lane r <-> channel c0 + r): P_q in the k order of the C^T rows
-  // (t = 16 ks + 8 h + i), raw; dZ_q accumulator-shaped (rows crow(g, h)), which is also the start of the dP_q
-  // accumulators -- its B-operand order comes from one v_permlane32_swap per register pair (coattn_fwd32.hip).
+  // (t = 16 ks + 8 h + i), raw; H_q accumulator-shaped (rows crow(g, h)): at the top of its pass it becomes dZ_q, which
+  // is also the start of the dP_q accumulators -- its B-operand order comes from one v_permlane32_swap per register
+  // pair (coattn_fwd32.hip).
   auto load_pass = [&](int c0, f32x8 (&praw)[2], f32x16& zf) {
     int bn = (8 * h * d + r) * 4, bc = (4 * h * d + r) * 4;
     asm volatile("" : "+v"(bn));
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
 #pragma unroll
       for (int i = 0; i < 8; ++i) praw[ks][i] = buf_load1(rs_pq, bn, (c0 + (16 * ks + i) * d) * 4);
 #pragma unroll
-    for (int g = 0; g < 16; ++g) zf[g] = buf_load1(rs_dzq, bc, (c0 + ((g & 3) + 8 * (g >> 2)) * d) * 4);
+    for (int g = 0; g < 16; ++g) zf[g] = buf_load1(rs_hq, bc, (c0 + ((g & 3) + 8 * (g >> 2)) * d) * 4);
   };
   f32x8 pq_raw[2];
   f32x16 zq_frag;
@@ -110,6 +116,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
       const float tot = softmax_bwd_v(a, b, l, lane, dsvs, NPAD);
       if (lane == 0) a.dcs_part[pair] = tot;
     }
+    if (w == 0 && lane < 32) dsqs[lane] = a.dsq[pair * 32 + lane];
   }
   lds_barrier();
 
@@ -139,6 +146,24 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
     const int c0n = (((pi + 1) >> 2) * NW + w) * 128 + 32 * ((pi + 1) & 3);
     const float wv4 = 4.0f * a.wv[c0 + r];
     bf16x8 pqB[2][3], zqB[2][3];
+    {
+      float dwq = 0.f;                               // this lane's sum_t ds_q[t] H_q[t][c0 + r] over its rows
+      int ho = h;                                    // (opaque: the lane constants below are rebuilt per pass instead of
+      asm volatile("" : "+v"(ho));                   //  living in registers through the unit loop, which has none to spare)
+      const float wqc = buf_load1(rs_wq, (lane - 32 * ho) * 4, c0 * 4);
+#pragma unroll
+      for (int gg = 0; gg < 4; ++gg) {
+        const f32x4 sq = *reinterpret_cast<const f32x4*>(&dsqs[8 * gg + 4 * ho]);   // rows crow(4 gg + i, h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float hq = zq_frag[4 * gg + i];
+          dwq = fmaf(sq[i], hq, dwq);
+          zq_frag[4 * gg + i] = sq[i] * wqc * (1.0f - hq * hq);
+        }
+      }
+      dwq += __shfl_xor(dwq, 32, 64);                // (stored here: nothing of it lives through the pass)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dwq), rs_dwq, ho == 0 ? lane * 4 : 0x40000000, c0 * 4, 0);
+    }
     f32x16 accq = zq_frag;                           // dP_q = dZ_q + C dZ_v
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -344,8 +369,9 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc32_kernel(const BwdArgs a) {
   const size_t pair = (size_t)l * a.B + b;
   const __amdgpu_buffer_rsrc_t rs_pv = make_rsrc(a.Pv + (size_t)b * N * d, (unsigned)N * d * 4u);
   const __amdgpu_buffer_rsrc_t rs_pq = make_rsrc(a.Pq + pair * (size_t)T * d, (unsigned)T * d * 4u);
-  const __amdgpu_buffer_rsrc_t rs_dzq = make_rsrc(a.dZq + pair * (size_t)T * d, (unsigned)T * d * 4u);
+  const __amdgpu_buffer_rsrc_t rs_hq = make_rsrc(a.Hq + pair * (size_t)T * d, (unsigned)T * d * 4u);
   const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(a.C + pair * (size_t)T * N, (unsigned)T * N * 4u);
+  const float dsq_r = a.dsq[pair * 32 + r];          // ds_q of this lane's token (0 for t >= T)
   const __amdgpu_buffer_rsrc_t rs_da = make_rsrc(a.dA + pair * (size_t)T * N, (unsigned)T * N * 4u);
   const int nsl = d / (128 * NW);
   // ---- the image of C (as in bwd_nat32_kernel) and ds_v
@@ -409,14 +435,15 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc32_kernel(const BwdArgs a) {
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
           for (int i = 0; i < 8; ++i) raw[ks][i] = buf_load1(rs_pq, (8 * h * d + r) * 4, (k0 + (16 * ks + i) * d) * 4);
-        f32x4 qa[2][2], za[2][2], wa[2][2];          // lane = token r: channels k0 + 16 ks + 4 h + {0..3}, + 8
+        f32x4 qa[2][2], za[2][2], wa[2][2], wz[2][2];   // lane = token r: channels k0 + 16 ks + 4 h + {0..3}, + 8
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             qa[ks][u] = buf_load4(rs_pq, (r * d + 4 * h) * 4, (k0 + 16 * ks + 8 * u) * 4);
-            za[ks][u] = buf_load4(rs_dzq, (r * d + 4 * h) * 4, (k0 + 16 * ks + 8 * u) * 4);
+            za[ks][u] = buf_load4(rs_hq, (r * d + 4 * h) * 4, (k0 + 16 * ks + 8 * u) * 4);
             wa[ks][u] = *reinterpret_cast<const f32x4*>(a.wv + k0 + 16 * ks + 8 * u + 4 * h);
+            wz[ks][u] = *reinterpret_cast<const f32x4*>(a.wq + k0 + 16 * ks + 8 * u + 4 * h);
           }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -425,7 +452,8 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc32_kernel(const BwdArgs a) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             x[i] = qa[ks][i >> 2][i & 3] * kInv * wa[ks][i >> 2][i & 3];
-            z[i] = za[ks][i >> 2][i & 3] * kInv;
+            const float hq = za[ks][i >> 2][i & 3];                   // dZ_q = ds_q w_q (1 - H_q^2), as bwd_nat32_kernel forms it
+            z[i] = dsq_r * wz[ks][i >> 2][i & 3] * (1.0f - hq * hq) * kInv;
           }
           splitn<NP>(x, pqA[ks]);
           splitn<NP>(z, zqA[ks]);
@@ -743,7 +771,7 @@ int launch_dq32(const DqArgs& a, hipStream_t s) {
 template <int NT, int NW, int NP, bool DPB>
 int launch_nat32(const BwdArgs& a, hipStream_t s) {
   constexpr int NPAD = 32 * NT;
-  const size_t lds = (size_t)3 * NPAD * 32 * 2 + (size_t)NPAD * 4;
+  const size_t lds = (size_t)3 * NPAD * 32 * 2 + (size_t)NPAD * 4 + 32 * 4;
   const int groups = (a.B + 7) / 8;
   hipLaunchKernelGGL((bwd_nat32_kernel<NT, NW, NP, DPB>), dim3(groups * a.L * 8), dim3(NW * 64), lds, s, a);
   CA_CHECK_LAUNCH("bwd_nat32");

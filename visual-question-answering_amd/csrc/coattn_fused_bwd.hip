@@ -5,8 +5,10 @@
 // H_v [N,d] is never stored: both big kernels recompute it from P_v, P_q and C (saved).
 //
 //   bwd_pre_kernel  (per sample, all levels)  one pass over V: da_v = V gv partials (the image side's softmax backward
-//                   ds_v is finished in the prologues of the two big kernels); da_q = Q gq -> ds_q;
-//                   dZ_q = ds_q (x) w_q (.) (1 - H_q^2); dw_q / dc_q partials.
+//                   ds_v is finished in the prologues of the two big kernels); da_q = Q gq -> ds_q, dc_q partials.
+//                   (dZ_q = ds_q (x) w_q (.) (1 - H_q^2) is not stored: the two big kernels form it from the saved H_q
+//                   where they used to read it -- the same bytes for them, one read of H_q and one write of dZ_q
+//                   less for this kernel -- and bwd_nat32_kernel sums the dw_q partial.)
 //   bwd_dc32_kernel (coattn_bwd32.hip; per sample x level, orientation [d][n], bf16 MFMA with the exact 3-way
 //                   split): H_v^T tile = P_v^T + P_q^T C -> dZ_v^T, and dC += P_q dZ_v^T + dZ_q P_v^T with the
 //                   dZ_v^T / P_v^T fragments as MFMA B operands (contraction over d); cross-wave sum through
@@ -84,23 +86,20 @@ struct PreArgs {
   const float* Q[8];
   const float* gq;                       // [L][B][d]
   const float* av; const float* aq;      // saved
-  const float* Hq;                       // saved [L][B][T][d]
-  const float* wq;
   // the da_v blocks ride along in the same launch (blocks past L*B): dav_gx blocks per sample
   const float* V; long v_sB; const float* gv; float* dav_out; int dav_lm, dav_gx;
-  float* dsv;                            // [L][B][N]
-  float* dZq;                            // [L][B][T][d]
-  float* dwq_part;                       // [L*B][d]
+  float* dsq;                            // [L*B][32] ds_q, zeros for t >= T
   float* dcs_part;                       // [2][L*B]
   int B, N, T, d, L;
 };
 
 // Blocks [0, L*B): one workgroup (256 threads) per (sample, level), question side -- softmax backward of a_q
-// (da_q = Q gq), dZ_q = ds_q (x) w_q (.) (1 - H_q^2), dw_q / dc_q partials.  Blocks past L*B: the da_v partials
-// (one pass over V for all levels, independent of the question side: they fill the idle half of the chip).
-// (Round 4, measured and not kept: requesting a wave's rows together -- all 7 Q rows of the da_q dot products, all 14 / 2 x 7
-//  H_q rows of the dZ_q sweep, the 4 V rows of a da_v wave -- costs registers the da_v blocks of the same launch pay for
-//  with occupancy: 60 -> 102 / 128 VGPRs, 27.7 -> 32.6 / 37.3 us at N = 196, 22.7 -> 22.3 / 21.6 at N = 49.)
+// (da_q = Q gq -> ds_q, dc_q partial).  Blocks past L*B: the da_v partials (one pass over V for all levels, independent
+// of the question side: they fill the idle half of the chip).
+// (Round 4, measured and not kept while this kernel also swept H_q into dZ_q: requesting a wave's rows together -- all 7 Q
+//  rows of the da_q dot products, all 14 / 2 x 7 H_q rows of the sweep, the 4 V rows of a da_v wave -- costs registers the
+//  da_v blocks of the same launch pay for with occupancy: 60 -> 102 / 128 VGPRs, 27.7 -> 32.6 / 37.3 us at N = 196,
+//  22.7 -> 22.3 / 21.6 at N = 49.)
 __global__ __launch_bounds__(256) void bwd_pre_kernel(const PreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int d = a.d, T = a.T, B = a.B;
@@ -112,8 +111,6 @@ __global__ __launch_bounds__(256) void bwd_pre_kernel(const PreArgs a) {
     return;
   }
   float* daq = lds;                       // 32
-  float* dsq = daq + 32;                  // 32
-  float* dwr = dsq + 32;                  // d   (second row group's dw_q partial)
   const int pairi = blockIdx.x, l = pairi / B, b = pairi - l * B;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const size_t pair = (size_t)pairi;
@@ -136,40 +133,9 @@ __global__ __launch_bounds__(256) void bwd_pre_kernel(const PreArgs a) {
     const float x = (lane < T) ? daq[lane] : 0.f;
     const float dq = wave_sum(aqv * x);
     const float sq = aqv * (x - dq);
-    if (lane < 32) dsq[lane] = sq;
+    if (lane < 32) a.dsq[pair * 32 + lane] = sq;                     // (lanes >= T: zeros)
     const float tot_q = wave_sum(sq);
     if (lane == 0) a.dcs_part[(size_t)a.L * B + pair] = tot_q;       // [2][L*B]
-  }
-  __syncthreads();
-  // ---- dZ_q rows and the dw_q partial: 128 threads x float4 cover d = 512; two row groups
-  const int grp = tid >> 7, c4 = (tid & 127) * 4;
-  const float* Hp = a.Hq + pair * (size_t)T * d;
-  float* Zp = a.dZq + pair * (size_t)T * d;
-  for (int base = 0; base < d; base += 512) {      // uniform trip count: barriers inside
-    const int c0 = base + c4;
-    const bool act = c0 < d;
-    f32x4 dw = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (act) {
-      const f32x4 wq4 = *reinterpret_cast<const f32x4*>(a.wq + c0);
-      for (int t = grp; t < T; t += 2) {
-        const f32x4 h = *reinterpret_cast<const f32x4*>(Hp + (size_t)t * d + c0);
-        const float sv = dsq[t];
-        f32x4 z;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          dw[e] = fmaf(sv, h[e], dw[e]);
-          z[e] = sv * wq4[e] * (1.0f - h[e] * h[e]);
-        }
-        *reinterpret_cast<f32x4*>(Zp + (size_t)t * d + c0) = z;
-      }
-      if (grp == 1) *reinterpret_cast<f32x4*>(dwr + c0) = dw;
-    }
-    __syncthreads();
-    if (act && grp == 0) {
-      const f32x4 o = *reinterpret_cast<const f32x4*>(dwr + c0);
-      *reinterpret_cast<f32x4*>(a.dwq_part + pair * (size_t)d + c0) = dw + o;
-    }
-    __syncthreads();
   }
 }
 
@@ -285,7 +251,7 @@ hipError_t set_lds(K kern, size_t bytes) {
 }
 
 int launch_pre(const PreArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)(64 + a.d) * sizeof(float);           // (>= the 768 B of a channel-major da_v block)
+  const size_t lds = 768;                                           // the 3 x 64 g values of a channel-major da_v block; 32 da_q
   hipLaunchKernelGGL(bwd_pre_kernel, dim3(a.L * a.B + a.dav_gx * a.B), dim3(256), lds, s, a);
   CA_CHECK_LAUNCH("bwd_pre");
   // (the image side's softmax backward -- ds_v from these partials -- happens in the prologues of bwd_dc32_kernel and
@@ -323,15 +289,15 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   pa.dav_part = ws + wo.part;
   pa.nkc = lm ? 1 : d / 64;
   for (int l = 0; l < 8; ++l) pa.Q[l] = l < L ? Q[l] : nullptr;
-  pa.gq = gq; pa.av = saved + so.av; pa.aq = saved + so.aq; pa.Hq = saved + so.Hq;
-  pa.wq = (const float*)p->w_q;
-  pa.dsv = ws + wo.dsv; pa.dZq = ws + wo.dZq; pa.dwq_part = ws + wo.dwq_part; pa.dcs_part = ws + wo.dcs_part;
+  pa.gq = gq; pa.av = saved + so.av; pa.aq = saved + so.aq;
+  pa.dsq = ws + wo.dsq; pa.dcs_part = ws + wo.dcs_part;
   pa.B = B; pa.N = N; pa.T = T; pa.d = d; pa.L = L;
   CA_TRY(launch_pre(pa, s));
   prof_mark(s, "bwd_pre");
   // 2. the two recompute kernels
   BwdArgs ba;
-  ba.Pv = saved + so.Pv; ba.Pq = saved + so.Pq; ba.C = saved + so.C; ba.dZq = ws + wo.dZq;
+  ba.Pv = saved + so.Pv; ba.Pq = saved + so.Pq; ba.C = saved + so.C;
+  ba.Hq = saved + so.Hq; ba.dsq = ws + wo.dsq; ba.wq = (const float*)p->w_q; ba.dwq_part = ws + wo.dwq_part;
   ba.dav_part = ws + wo.part; ba.nkc = pa.nkc; ba.av = saved + so.av; ba.dcs_part = ws + wo.dcs_part;
   ba.wv = (const float*)p->w_v;
   ba.dPv = ws + wo.dPv; ba.dPq = ws + wo.dPq; ba.dA = ws + wo.dA; ba.dwv_part = ws + wo.dwv_part;

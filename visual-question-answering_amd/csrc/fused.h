@@ -297,7 +297,9 @@ struct BwdArgs {
   int nkc;
   const float* av;        // saved a_v [L][B][N]
   float* dcs_part;        // [2][L*B]: dc_v partials (written by bwd_nat32_kernel)
-  const float* dZq;       // [L][B][T][d]
+  const float* Hq;        // saved H_q [L][B][T][d]: dZ_q = ds_q (x) w_q (.) (1 - H_q^2) is formed where it is used
+  const float* dsq;       // [L*B][32] ds_q (bwd_pre_kernel; zeros for t >= T)
+  const float* wq;
   const float* wv;
   float* dPv;             // [L][B][N][d]
   float* dPq;             // [L][B][T][d]
@@ -305,6 +307,7 @@ struct BwdArgs {
   float* dwv_part;        // [L*B][d]
   float* dbv_part;        // [L*B][d]   sum_n dP_v[n][:]
   float* dbq_part;        // [L*B][d]   sum_t dP_q[t][:]
+  float* dwq_part;        // [L*B][d]   sum_t ds_q[t] H_q[t][:]   (bwd_nat32_kernel)
   int B, N, T, d, L;
   int bf16;               // reduced-precision mode: one MFMA per product (d % 512 == 0)
   int np;                 // (bf16 = 0) width of the contractions: 3 or 2 pieces
@@ -387,14 +390,14 @@ inline SavedOff saved_off(int B, int N, int T, int d, int L) {   // the one layo
 
 // workspace of the fused backward (floats)
 struct FusedBwdOff {
-  size_t dsv, dZq, dPq, dPv, dA, dwv_part, dbv_part, dbq_part, dwq_part, dcs_part, part, total;
+  size_t dsv, dsq, dPq, dPv, dA, dwv_part, dbv_part, dbq_part, dwq_part, dcs_part, part, total;
 };
 constexpr int kMaxParts = 40;   // split-K parts of the weight-gradient GEMMs (32 shared by dW_v and dW_q, rounded up per level)
 inline FusedBwdOff fused_bwd_off(int B, int N, int T, int d, int L) {
   FusedBwdOff p;
   size_t o = 0;
   p.dsv = o; o += fal64((size_t)L * B * N);
-  p.dZq = o; o += fal64((size_t)L * B * T * d);
+  p.dsq = o; o += fal64((size_t)L * B * 32);
   p.dPq = o; o += fal64((size_t)L * B * T * d);
   p.dPv = o; o += fal64((size_t)L * B * N * d);
   p.dA = o;  o += fal64((size_t)L * B * T * N);

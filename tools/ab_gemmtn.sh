@@ -2,17 +2,20 @@
 # Knock-out timing of the backward's GEMM launch (gemm_tn_kernel inside coattn_backward): builds variants of the library
 # with -DGEMMTN_KO=<mask> HERE (cross-compile), then `tools/ab_gemmtn.sh run` ON THE GPU BOX times them (wrong results).
 #   tools/ab_gemmtn.sh build 1 2 4 8 16 32 ...      tools/ab_gemmtn.sh run 1 2 4 8 16 32 ...
+# FILE=gemm_tn_wide MACRO=GEMMTNW_KO: the same for gemm_tn_wide_kernel (run with COATTN_NO_COMBINE=1 to time the weight
+# gradients without the dQ projection's tiles)
+FILE=${FILE:-gemm_tn}; MACRO=${MACRO:-GEMMTN_KO}
 mode=$1; shift
 if [ "$mode" = build ]; then
   cd "$(dirname "$0")/../visual-question-answering_amd/csrc"
   for ko in "$@"; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -fno-slp-vectorize -mllvm -pragma-unroll-threshold=1000000 \
-      -DGEMMTN_KO=$ko ${EXTRA:-} -c gemm_tn.hip -o /tmp/gemm_tn_ko$ko.o &
+      -D$MACRO=$ko ${EXTRA:-} -c $FILE.hip -o /tmp/${FILE}_ko$ko.o &
   done
   wait
   for ko in "$@"; do
-    objs=$(ls *.o | grep -v "^gemm_tn.o$" | tr "\n" " ")
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/ab/libcoattn_tnko$ko.so $objs /tmp/gemm_tn_ko$ko.o -Wl,-rpath,/opt/rocm/lib
+    objs=$(ls *.o | grep -v "^$FILE.o$" | tr "\n" " ")
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/ab/libcoattn_tnko$ko.so $objs /tmp/${FILE}_ko$ko.o -Wl,-rpath,/opt/rocm/lib
   done
   exit 0
 fi

@@ -14,6 +14,16 @@
 // of the partial products, same split-K partition when the part count is the same); the dQ projection's tiles ride along on
 // gemm_w_body's 128 x 256 / 512-thread form, the small reductions as workgroups whose first 256 threads work.
 //
+// What bounds it (round 4, measured on the weight gradients alone, COATTN_NO_COMBINE=1; 88 us at N = 196, 39 at N = 49):
+// not the schedule.  Knock-outs (GEMMTNW_KO below): without MFMAs 88 us, without the requests 61.5, without split / image
+// writes / fragment reads 56.5, MFMAs alone 50.  Two forms of this body that take the staging chain off the MFMA waves'
+// critical path measured THE SAME time: requests two steps ahead (a second staging register set: 121 vs 122 us for the
+// whole launch), and specialised waves -- four waves (one per SIMD) that only request / sum / split / write, four that
+// only read fragments and multiply 64 x 128 each, one barrier per step, same bits -- 120.4 vs 121.8 us at N = 196, 63.2 vs
+// 62.0 at N = 49.  The launch moves its 338 MB at 3.8 TB/s whatever the waves do in between: the rate at which a CU's
+// 40 KB per step (512-byte and 1-KB row segments of 2-KB rows) come back, not their latency and not the issue slots.
+// Neither form was kept.
+//
 // Shapes: M % 128 == 0, N % 256 == 0, both operands row-major over the contraction rows (the channel-major B operand and
 // the masked phrase-level products stay on gemm_tn.hip).
 #include "common.h"
@@ -21,6 +31,13 @@
 #include "gemm_w_body.h"
 #include <stdlib.h>
 #include <type_traits>
+
+// Developer switches (tools/ab_gemmtn.sh with FILE=gemm_tn_wide MACRO=GEMMTNW_KO, never in the shipped library; wrong
+// results): GEMMTNW_KO bit 0 no MFMAs, 1 no global loads after the prologue's, 2 no split arithmetic, 3 no LDS writes,
+// 4 no fragment reads, 5 no barrier.
+#ifndef GEMMTNW_KO
+#define GEMMTNW_KO 0
+#endif
 
 namespace {
 
@@ -91,6 +108,7 @@ __device__ __forceinline__ void gemm_tn_wide_body(const TwArgs& g, const int bid
   constexpr int PA[6] = {2, 0, 1, 1, 0, 0};      // smallest terms first (gemm.hip's order)
   constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
   auto load_raw = [&](int x, int s) {            // (the step goes into the VECTOR offset: the range check does not see the scalar one)
+    if ((GEMMTNW_KO & 2) && s >= 2) return;
     if (x == 0) {
       raw[0] = buf_load4(rs_a, a_voff + s * a_step, 0);
       if (SUM3) {
@@ -100,6 +118,10 @@ __device__ __forceinline__ void gemm_tn_wide_body(const TwArgs& g, const int bid
     } else raw[x] = buf_load4(rs_b, b_voff + (x - 1) * b_half + s * b_step, 0);
   };
   auto stage = [&](int x, int e, int st) {       // split of raw[x], pair e, in three stages of 5, 5 and 1 VALU
+    if (GEMMTNW_KO & 4) {
+      if (st == 0) ph[e] = pm[e] = pl[e] = __builtin_bit_cast(unsigned, raw[x][2 * e]);
+      return;
+    }
     if (st == 0) {
       if (SUM3 && x == 0) {                      // (level order 0 + 1 + 2, as the separate summing pass adds them)
         raw[0][2 * e] = (raw[0][2 * e] + rawt[0][2 * e]) + rawt[1][2 * e];
@@ -119,6 +141,7 @@ __device__ __forceinline__ void gemm_tn_wide_body(const TwArgs& g, const int bid
   };
   auto write_piece = [&](short* buf, int x, int q) {
     if (q >= NP) return;
+    if ((GEMMTNW_KO & 8) && buf != lds) return;      // (the prologue's image is still written)
     const u32x2 v = q == 0 ? u32x2{ph[0], ph[1]} : (q == 1 ? u32x2{pm[0], pm[1]} : u32x2{pl[0], pl[1]});
     if (x == 0) *reinterpret_cast<u32x2*>(&buf[q * IMGA + sta]) = v;
     else *reinterpret_cast<u32x2*>(&buf[q * IMGB + (x - 1) * 8 * LDTB + stb]) = v;
@@ -129,6 +152,7 @@ __device__ __forceinline__ void gemm_tn_wide_body(const TwArgs& g, const int bid
     constexpr int QA[3] = {2, 0, 1}, QB[3] = {0, 2, 1};
     const int grp = r >> 2, isb = grp & 1, q = isb ? QB[grp >> 1] : QA[grp >> 1], tile = (r >> 1) & 1, hi = r & 1;
     if (q >= NP) return;
+    if ((GEMMTNW_KO & 16) && buf != lds) return;
     if (isb) fb[SET][q][tile][hi] = lds_tr16(buf + q * IMGB + b_rd + tile * 32 + hi * 4 * LDTB);
     else fa[SET][q][tile][hi] = lds_tr16(buf + q * IMGA + a_rd + tile * 32 + hi * 4 * LDTA);
   };
@@ -144,7 +168,8 @@ __device__ __forceinline__ void gemm_tn_wide_body(const TwArgs& g, const int bid
       const int mi = NP == 2 ? n >> 1 : n;
       const bool mf = NP == 3 || (n & 1);
       const int tt = NP == 2 ? 3 + (mi >> 2) : n >> 2, i = (mi >> 1) & 1, j = mi & 1;
-      if (mf)
+      if (mf && (GEMMTNW_KO & 1)) acc[i][j][n & 15] += __builtin_bit_cast(float, (int)fa[SET][PA[tt]][i][0][0] ^ (int)fb[SET][PB[tt]][j][0][0]);
+      if (mf && !(GEMMTNW_KO & 1))
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(fa[SET][PA[tt]][i]), frag(fb[SET][PB[tt]][j]), acc[i][j], 0, 0, 0);
       // raw[x]: pair 0 stages in slots 4x, 4x+1, 4x+2; pair 1 in 4x+1, 4x+2, 4x+3; pieces written in 4x+3 .. 4x+5
       if (n < 12) {
@@ -157,7 +182,7 @@ __device__ __forceinline__ void gemm_tn_wide_body(const TwArgs& g, const int bid
         const int w = n - 3, x = w >> 2, q = w & 3;
         if (q < 3) write_piece(nxt, x, q);
       }
-      if (n == 18) lds_barrier();
+      if (n == 18 && !(GEMMTNW_KO & 32)) lds_barrier();
       if (n >= 18) {
 #pragma unroll
         for (int r = 4 * (n - 18); r < 4 * (n - 17); ++r) read_frag(OTHER{}, nxt, r);

@@ -44,6 +44,7 @@ extern "C" {
 #endif
 
 #define COATTN_F32 0
+#define COATTN_BF16 1   /* storage type of an INPUT where an entry point says so (coattn_features_native); the math stays fp32 */
 
 /* impl selector (flags & 3): 0 = auto (fused kernels when the shape allows, else general),
  * 1 = general-shape kernels (MFMA GEMM composition), 2 = fused kernels (error if unsupported). */
@@ -97,6 +98,18 @@ const char* coattn_last_error(void);
  * `names` = the n mark names joined by '\n' (truncated to names_bytes).  Not for use under graph capture. */
 int coattn_profile_begin(void* stream);
 int coattn_profile_end(float* us, char* names, int names_bytes, int max_marks);
+
+/* Image features as the encoder leaves them -> the layout the kernels run on (the boundary on the image side: what
+ * HierarchicalCoAttentionNet does between image_encoder and co_attention, model.py:215-217 view + permute, under AMP
+ * main.py:73, :185 with bf16 activations).
+ *   x   : element (b, n, c) at x[b sB + n sN + c sD], x_dtype COATTN_F32 or COATTN_BF16, any non-negative strides -- e.g.
+ *         the permuted NCHW view (sB >= d N, sN = 1, sD = N) at N = 49, whose 196-byte (98-byte) rows the kernels do not
+ *         take in place;
+ *   out : fp32 [B, N, d] contiguous (location-major), the V of coattn_forward / coattn_backward with strides (N d, d, 1).
+ * One pass at the memory rate (read along n, written along c through an LDS tile).  Features that are already fp32 and
+ * location-major, or channel-major with N % 4 == 0, need no call: coattn_forward takes them where they lie. */
+int coattn_features_native(const void* x, int x_dtype, int64_t sB, int64_t sN, int64_t sD, void* out, int B, int N, int d,
+                           void* stream);
 
 /* 1 if a fused-kernel configuration exists for this shape (for channel-major or location-major V), else 0 */
 int coattn_fused_supported(int B, int N, int T, int d, int L, int dtype);

@@ -18,9 +18,10 @@ EXPORTS = ("coattn_version", "coattn_last_error", "coattn_fused_supported", "coa
            "coattn_linear_wgrad_workspace_bytes", "coattn_linear_weight_grad",
            "coattn_head_workspace_bytes", "coattn_head_forward", "coattn_head_backward", "coattn_head_status",
            "coattn_ce_status", "coattn_p2p_enable_peer", "coattn_p2p_reduce_scatter", "coattn_p2p_all_gather",
-           "coattn_profile_begin", "coattn_profile_end")
+           "coattn_profile_begin", "coattn_profile_end", "coattn_features_native")
 
 F32 = 0
+BF16 = 1                  # storage type of coattn_features_native's input
 IMPL_AUTO, IMPL_GENERAL, IMPL_FUSED = 0, 1, 2
 FLAG_BF16_PROJ = 4
 FLAG_BF16_IN = 8          # linear entry points: x (dy) stored as bf16
@@ -128,6 +129,8 @@ def load() -> C.CDLL:
     lib.coattn_p2p_all_gather.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int64, C.c_void_p]
     lib.coattn_profile_begin.argtypes = [C.c_void_p]
     lib.coattn_profile_end.argtypes = [C.POINTER(C.c_float), C.c_char_p, C.c_int, C.c_int]
+    lib.coattn_features_native.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+                                           C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.coattn_head_status.argtypes = [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
     lib.coattn_head_workspace_bytes.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_size_t)] * 2
     lib.coattn_head_forward.argtypes = ([C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(HeadParams)]

@@ -28,20 +28,65 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-def _native_layout(x_img: torch.Tensor) -> torch.Tensor:
-    """The module input x_img[B,N,d] as the kernels take it: by pointer + element strides, no copy, when it is
-    location-major (a channels_last encoder: contiguous [B,N,d]) or channel-major (the permuted view of an NCHW
-    encoder, model.py:215-217: strides (d N, 1, N)) with rows that are 16-byte multiples (N % 4 == 0: N = 196);
-    anything else is made contiguous -- location-major -- once.  That includes channel-major features at N = 49: their
-    196-byte rows push the projection GEMMs onto dword loads (2 x 80 us per step), a 16 MB re-layout costs 8 us."""
+def _is_native(x_img: torch.Tensor) -> bool:
     B, N, d = x_img.shape
     sB, sN, sD = _strides(x_img)
     ext = (N - 1) * sN + (d - 1) * sD
     lm = sD == 1 and sN == d
     cm = sN == 1 and sD == N and N % 4 == 0
-    if (lm or cm) and sB > ext and x_img.data_ptr() % 16 == 0:
+    return bool((lm or cm) and sB > ext and x_img.data_ptr() % 16 == 0)
+
+
+def _native_layout(x_img: torch.Tensor) -> torch.Tensor:
+    """The fp32 module input x_img[B,N,d] as the kernels take it: by pointer + element strides, no copy, when it is
+    location-major (a channels_last encoder: contiguous [B,N,d]) or channel-major (the permuted view of an NCHW
+    encoder, model.py:215-217: strides (d N, 1, N)) with rows that are 16-byte multiples (N % 4 == 0: N = 196);
+    anything else is made contiguous -- location-major -- once.  That includes channel-major features at N = 49: their
+    196-byte rows push the projection GEMMs onto dword loads (2 x 80 us per step), a 16 MB re-layout costs 8 us.
+    (Inside autograd, where the copy must stay differentiable; features that need no gradient come through
+    `native_features`, whose copy is the library's one-pass kernel.)"""
+    if _is_native(x_img):
         return x_img
     return x_img.contiguous()
+
+
+def native_features(x_img: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """Image features that need NO gradient (the frozen encoder of every BASELINE config, model.py:239-241), as the
+    encoder left them -- fp32 or bf16 (an autocast encoder, main.py:73, :185), any strides -- in a layout the kernels
+    run on: the tensor itself when it is fp32 and native already (see `_native_layout`), else ONE pass of
+    coattn_features_native into fp32 [B,N,d] (`out`, if given: a contiguous fp32 buffer of that shape).  What torch
+    makes of the same input is an up-cast and a strided copy: two passes, the second at a quarter of the memory rate."""
+    if x_img.requires_grad and torch.is_grad_enabled():
+        raise RuntimeError("native_features is for features without a gradient (use the module: its copy is differentiable)")
+    if not x_img.is_cuda or x_img.dtype not in (torch.float32, torch.bfloat16):
+        x = x_img.detach().to(torch.float32)
+        x = _native_layout(x)
+        if out is None:
+            return x
+        out.copy_(x)
+        return out
+    if out is None and x_img.dtype == torch.float32 and _is_native(x_img):
+        return x_img
+    B, N, d = x_img.shape
+    if _strides(x_img)[2] == 1:                      # rows along the channels already: a plain (vectorised) up-cast / copy
+        if out is None:
+            return _native_layout(x_img.to(torch.float32))
+        out.copy_(x_img)
+        return out
+    if out is None:
+        out = torch.empty((B, N, d), device=x_img.device, dtype=torch.float32)
+    elif (tuple(out.shape) != (B, N, d) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x_img.device):
+        raise RuntimeError("native_features: `out` must be a contiguous fp32 [B,N,d] tensor on the features' device")
+    lib = _lib.load()
+    sB, sN, sD = _strides(x_img)
+    if min(sB, sN, sD) < 0:
+        raise RuntimeError("native_features: negative strides")
+    with _lib.on_device(x_img.device):
+        _lib.check(lib.coattn_features_native(_ptr(x_img), _lib.BF16 if x_img.dtype == torch.bfloat16 else _lib.F32,
+                                              sB, sN, sD, _ptr(out), B, N, d,
+                                              C.c_void_p(torch.cuda.current_stream(x_img.device).cuda_stream)),
+                   "coattn_features_native")
+    return out
 
 
 def _strides(x: torch.Tensor):
@@ -160,6 +205,8 @@ class ParallelCoAttention(nn.Module):
     def forward(self, x_img: torch.Tensor, x_ques_hierarchy: Sequence[torch.Tensor]) -> Tuple[List, List]:
         """x_img [B,N,d]; x_ques_hierarchy: list of [B,T,d] -> (list of v_l [B,d], list of q_l [B,d])."""
         impl = _impl_flag() | (_lib.FLAG_BF16_PROJ if self.bf16_projections else 0)
+        if x_img.is_cuda and not (x_img.requires_grad and torch.is_grad_enabled()):
+            x_img = native_features(x_img)           # frozen encoder: bf16 / non-native strides in one library pass
         v, q = coattention(x_img, list(x_ques_hierarchy), self.W_v.weight, self.W_v.bias, self.W_q.weight,
                            self.W_q.bias, self.w_v.weight, self.w_v.bias, self.w_q.weight, self.w_q.bias, impl=impl)
         n = v.shape[0]

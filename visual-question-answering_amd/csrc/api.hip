@@ -16,7 +16,7 @@ void coattn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int coattn_version(void) { return 500; }   // 0.5.0: widths of the fp32 mode (COATTN_FLAG_EXACT3 / _SPLIT2), coattn_profile_*
+extern "C" int coattn_version(void) { return 510; }   // 0.5.1: coattn_features_native; 0.5.0: widths of the fp32 mode (COATTN_FLAG_EXACT3 / _SPLIT2), coattn_profile_*
 
 // ---------------------------------------------------------------------------------------
 // per-kernel timing (bench.py's backward roofline legs): HIP events recorded between the launches of the calls made

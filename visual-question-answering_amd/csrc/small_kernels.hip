@@ -363,3 +363,73 @@ int launch_rank1(const float* a, const float* g, float* out, int Z, int I, int J
   CA_CHECK_LAUNCH("rank1");
   return 0;
 }
+
+// ---- image features -> the layout the kernels run on ------------------------------------------------------------------
+// out[b][n][c] (fp32, contiguous [B, N, d]) = x[b sB + n sN + c sD]  (fp32 or bf16, any strides).  The case it exists
+// for: the permuted view of an NCHW encoder output (model.py:215-217: strides (d N, 1, N)) whose rows are not 16-byte
+// multiples (N = 49: the 7 x 7 grids of BASELINE configs 2 - 5 at 224 x 224) or which an autocast encoder left in bf16
+// (config 4, main.py:73, :185) -- one pass, read along n, written along c, instead of the up-cast and the strided copy
+// the host framework would make of it (two passes, the second at a quarter of the memory rate).
+namespace {
+template <typename TIn>
+__device__ __forceinline__ float feat_load(const TIn* p);
+template <>
+__device__ __forceinline__ float feat_load<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float feat_load<unsigned short>(const unsigned short* p) {
+  return __builtin_bit_cast(float, (unsigned)(*p) << 16);
+}
+
+// TR: the input is contiguous along n (sN == 1): 64 (c) x 64 (n) tiles through LDS.  Else: lanes along c, no LDS.
+// grid (ceil(N / 64), ceil(d / 64), B), 256 threads.
+template <typename TIn, bool TR>
+__global__ __launch_bounds__(256) void features_native_kernel(const TIn* __restrict__ x, long sB, long sN, long sD,
+                                                              float* __restrict__ out, int N, int d) {
+  __shared__ float tile[64][65];
+  const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const TIn* xb = x + (long)blockIdx.z * sB;
+  float* ob = out + (long)blockIdx.z * N * d;
+  if (TR) {
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {               // all the requests first
+      const int c = c0 + w + 4 * i, n = n0 + lane;
+      v[i] = (c < d && n < N) ? feat_load<TIn>(xb + (long)n * sN + (long)c * sD) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tile[w + 4 * i][lane] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int n = n0 + w + 4 * i, c = c0 + lane;
+      if (n < N && c < d) ob[(long)n * d + c] = tile[lane][w + 4 * i];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int n = n0 + w + 4 * i, c = c0 + lane;
+      if (n < N && c < d) ob[(long)n * d + c] = feat_load<TIn>(xb + (long)n * sN + (long)c * sD);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int coattn_features_native(const void* x, int x_dtype, int64_t sB, int64_t sN, int64_t sD, void* out, int B,
+                                      int N, int d, void* stream) {
+  CA_CHECK_ARG(x_dtype == COATTN_F32 || x_dtype == COATTN_BF16, "features_native: dtype %d (COATTN_F32 or COATTN_BF16)", x_dtype);
+  CA_CHECK_ARG(x && out && B > 0 && N > 0 && d > 0 && B <= 65535, "features_native: bad argument (B=%d N=%d d=%d)", B, N, d);
+  CA_CHECK_ARG(sB >= 0 && sN >= 0 && sD >= 0, "features_native: negative strides");
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((d + 63) / 64), (unsigned)B);
+  const bool tr = sN == 1 && sD != 1;
+  float* o = (float*)out;
+  if (x_dtype == COATTN_F32) {
+    if (tr) hipLaunchKernelGGL((features_native_kernel<float, true>), grid, dim3(256), 0, s, (const float*)x, (long)sB, (long)sN, (long)sD, o, N, d);
+    else hipLaunchKernelGGL((features_native_kernel<float, false>), grid, dim3(256), 0, s, (const float*)x, (long)sB, (long)sN, (long)sD, o, N, d);
+  } else {
+    if (tr) hipLaunchKernelGGL((features_native_kernel<unsigned short, true>), grid, dim3(256), 0, s, (const unsigned short*)x, (long)sB, (long)sN, (long)sD, o, N, d);
+    else hipLaunchKernelGGL((features_native_kernel<unsigned short, false>), grid, dim3(256), 0, s, (const unsigned short*)x, (long)sB, (long)sN, (long)sD, o, N, d);
+  }
+  CA_CHECK_LAUNCH("features_native");
+  return 0;
+}

@@ -32,7 +32,7 @@ import torch
 
 from . import _lib
 from . import head as _head
-from .coattention import _native_layout, _strides
+from .coattention import _is_native, _native_layout, _strides, native_features
 from .head import _workspace_bytes as _head_ws
 
 
@@ -211,6 +211,13 @@ class HotPathGraph:
         # With direct gradients the parameters need not be inputs of the autograd node (their gradients do not travel through
         # autograd) as long as some input keeps the node alive -- the question levels of a trainable question encoder do;
         # 6 arguments instead of 22 through the Function machinery on every step.
+        # Features of a frozen encoder that the kernels do not take where they lie (bf16 from an autocast encoder; the
+        # channel-major view at N = 49) go through the library's one-pass conversion into the node's static fp32 buffer --
+        # one address set for the plans / graphs, and neither autocast's up-cast nor torch's strided copy on top of it.
+        if (x_img.is_cuda and not (x_img.requires_grad and torch.is_grad_enabled()) and x_img.data_ptr() != self.V.data_ptr()
+                and x_img.dtype in (torch.float32, torch.bfloat16) and tuple(x_img.shape) == tuple(self.V.shape)
+                and x_img.device == self.device and (x_img.dtype != torch.float32 or not _is_native(x_img))):
+            x_img = native_features(x_img, out=self.V)
         if self.direct_grads and (x_ques[0].requires_grad or x_ques[1].requires_grad or x_ques[2].requires_grad or x_img.requires_grad):
             return _HotPathFn.apply(self, x_img, labels, *x_ques)
         return _HotPathFn.apply(self, x_img, labels, *x_ques, *self.co_params, *self.head_params)
@@ -237,7 +244,8 @@ class _HotPathFn(torch.autograd.Function):
         key = hp._key(ins)
         pair = hp.pair(ins, key) if hp.usable_in_place(ins) else None
         if pair is None:                                         # other dtype / too many address sets: static inputs
-            hp.V.copy_(x_img)
+            if x_img.data_ptr() != hp.V.data_ptr():
+                hp.V.copy_(x_img)
             torch._foreach_copy_(hp.Q, [Qw, Qp, Qs])
             hp.labels.copy_(labels)
             ins = hp._static

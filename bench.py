@@ -24,7 +24,8 @@ contract fields it carries
                 host cores on a bounded sample (rank 0, N=1 only); cpu_baseline_hot_path: the oracle
                 port of the isolated hot path (co-attention + MLP + CE fwd+bwd) at N=196 and N=49
   roofline_projection  the MFMA-bound P_v projection GEMM (gemm_w_kernel), timed the same way: fp32-equivalent
-                TFLOP/s against the dense bf16 MFMA peak / 6 (six bf16 products per fp32 product);
+                TFLOP/s against the dense 16-bit MFMA peak / 3 (two FP16 pieces per operand: three partial products per
+                fp32 product, the form coattn_forward runs it in; the exact bf16 split -- six products -- beside it);
                 roofline_weight_grad: the same for its weight gradient dW_v (gemm_tn_kernel + reduce)
   hot_path      isolated co-attention (+MLP+CE) fwd+bwd rates on device-resident features, N=196
                 and N=49, both feature layouts, as train.Trainer.step runs it (one autograd node over static buffers,
@@ -457,10 +458,11 @@ def projection_leg(device, B=160, N=196, d=512, iters=50, bf16=False):
     location-major features, through coattn_linear_forward -- the weight split once into MFMA-fragment order, then
     gemm_w_kernel (the pair coattn_forward launches; the timed region re-uses the weight image, so it is the GEMM
     kernel alone; the split is timed beside it).  Algorithmic flops 2 B N d^2 / average launch time
-    (HIP events on the launch stream).  Every fp32 product is computed as six bf16 x bf16 partial products of an
-    exact 3-way split on the bf16 MFMA (fp32-accurate): the roofline is the dense bf16 MFMA peak divided by those
-    six products (416.7 TFLOP/s fp32-equivalent); the fraction of the fp32 matrix peak (157.3 TFLOP/s, a pipe the
-    kernel does not use) is reported beside it."""
+    (HIP events on the launch stream).  In the form coattn_forward runs it (COATTN_FLAG_F16PAIR) every fp32 product is
+    three fp16 x fp16 partial products of two FP16 pieces per operand (22 significand bits; include/coattn.h): the
+    roofline is the dense 16-bit MFMA peak divided by those three products (833.3 TFLOP/s fp32-equivalent); the
+    exact bf16 split (six products, COATTN_FLAG_EXACT3's form) is timed beside it, and the fraction of the fp32 matrix
+    peak (157.3 TFLOP/s, a pipe the kernel does not use) is reported too."""
     import ctypes as C
     from vqa_amd import _lib
     lib = _lib.load()
@@ -472,7 +474,7 @@ def projection_leg(device, B=160, N=196, d=512, iters=50, bf16=False):
     wimg = torch.empty(lib.coattn_linear_workspace_bytes(d, d) // 4, device=device)
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    mode = _lib.FLAG_BF16_PROJ if bf16 else 0
+    mode = _lib.FLAG_BF16_PROJ if bf16 else _lib.FLAG_F16PAIR
 
     def call(flags):
         return lib.coattn_linear_forward(V.data_ptr(), d, W.data_ptr(), bias.data_ptr(), Pv.data_ptr(), wimg.data_ptr(),
@@ -499,19 +501,28 @@ def projection_leg(device, B=160, N=196, d=512, iters=50, bf16=False):
     t_with_split = window(0)
     flop = 2.0 * B * N * d * d
     ach = flop / t / 1e12
-    # the bound that applies: dense bf16 MFMA peak -- divided by the six products per fp32 product in fp32 mode
-    peak = 2500.0 if bf16 else 2500.0 / 6.0
+    exact = None
+    if not bf16:                                   # the exact bf16 split (six products) of the same product, beside it
+        mode = 0
+        _lib.check(call(0), "coattn_linear_forward")
+        for _ in range(iters):
+            call(1)
+        t6 = sorted(window(1) for _ in range(3))[1]
+        exact = {"avg_launch_us": round(t6 * 1e6, 2), "achieved": round(flop / t6 / 1e12, 1), "peak": round(2500.0 / 6.0, 1),
+                 "frac": round(flop / t6 / 1e12 / (2500.0 / 6.0), 4), "note": "three bf16 pieces per operand, six partial products (COATTN_FLAG_EXACT3)"}
+    # the bound that applies: dense 16-bit MFMA peak -- divided by the three products per fp32 product in fp32 mode
+    peak = 2500.0 if bf16 else 2500.0 / 3.0
     return {"bound": "mfma", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "peak_note": ("dense bf16 MFMA peak (operands rounded to bf16, one MFMA per product, fp32 accumulation)" if bf16 else
-                          "fp32-equivalent: dense bf16 MFMA peak 2500 TFLOP/s / 6 partial products per fp32 product"),
-            "frac_of_fp32_matrix_peak": round(ach / 157.3, 4),
+                          "fp32-equivalent: dense 16-bit MFMA peak 2500 TFLOP/s / 3 partial products per fp32 product (two FP16 pieces per operand)"),
+            "frac_of_fp32_matrix_peak": round(ach / 157.3, 4), "exact_bf16_split": exact,
             "traffic": None,
             "kernel": ("P_v projection GEMM (gemm_bf_kernel at N % 256 == 0, K % 64 == 0, else gemm_w_kernel's single-piece mode: "
                        "weight pre-rounded into a hi-only fragment image, one MFMA per product)" if bf16 else
-                       "P_v projection GEMM (gemm_w_kernel: pre-split weight, 3-way bf16 split)"),
+                       "P_v projection GEMM (gemm_w_kernel: weight pre-split into two FP16 pieces, A split while staged)"),
             "shape": {"M": B * N, "N": d, "K": d}, "avg_launch_us": round(t * 1e6, 2),
             "windows_us": [round(x * 1e6, 2) for x in ts], "calls_per_window": iters, "algorithmic_flops": flop,
-            "bf16_mfma_frac": round((1.0 if bf16 else 6.0) * ach / 2500.0, 4),
+            "bf16_mfma_frac": round((1.0 if bf16 else 3.0) * ach / 2500.0, 4),
             "weight_split_us": round(max(t_with_split - t, 0.0) * 1e6, 2)}
 
 

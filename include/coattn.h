@@ -62,17 +62,24 @@ extern "C" {
  * The same bit selects the bf16 MFMA for the three contractions of coattn_phrase_forward/backward. */
 #define COATTN_FLAG_BF16_PROJ 4
 #define COATTN_FLAG_BF16_IN 8     /* coattn_linear_forward / coattn_linear_weight_grad, with COATTN_FLAG_BF16_PROJ: x (dy) is STORED as bf16 */
-/* Widths of the fp32 mode.  An fp32 product runs on the bf16 MFMA as partial products of bf16 PIECES of its operands:
- * three pieces each (hi + mid + lo = the value exactly, six partial products: fp32-accurate) or two (hi + mid: 16
- * significand bits, three partial products, ~2^-16 relative per product, random in sign).  By default the affinity
- * A = Q V^T (model.py:377 -- the one contraction whose error the saturating tanh amplifies) and the projections
- * (model.py:380-384 -- their error reaches H_q summed over the N locations) keep three pieces; C^T P_q, C P_v of the forward
- * and the gradient contractions of coattn_backward run on two.  On the golden cases: v, q within 1e-6, attention maps
- * within 4e-7, gradients within 3e-5 of max|.| (the contract: 1e-4); tests/test_split_emulation.py has the budget row by row.
- * flags bit 4 (coattn_forward / coattn_backward): every contraction on three pieces. */
+/* Widths of the fp32 mode.  An fp32 product runs on the 16-bit MFMAs as partial products of 16-bit PIECES of its operands:
+ *   - three bf16 pieces each (hi + mid + lo = the value exactly, six partial products: fp32-accurate, fp32's range);
+ *   - two bf16 pieces (hi + mid: 16 significand bits, three partial products, ~2^-16 relative per product, random in sign,
+ *     fp32's range) -- the gradient contractions of coattn_backward, whose operands are gradients of any magnitude;
+ *   - two FP16 pieces (hi + lo: 22 significand bits, three partial products on v_mfma_f32_32x32x16_f16, ~2^-22 relative) --
+ *     the forward-side contractions, whose operands are features, projections and tanh values: the affinity A = Q V^T
+ *     (model.py:377), the projections (model.py:380-384; the weight image holds 256 W, divided out), C^T P_q and C P_v.
+ *     Range: exact pieces for |x| <= 65,504 (values below 2^-14 keep 2^-24 absolute); conversions saturate, so magnitudes
+ *     up to 131,008 are still carried (with fewer bits) and larger ones clamp there -- finite for any finite input.
+ * On the golden cases: v, q within 1e-6, attention maps within 4e-7, H_q within 2e-5, gradients within 1.5e-5 of max|.|
+ * (the contract: 1e-4); tests/test_split_emulation.py has the budget row by row.
+ * flags bit 4 (coattn_forward / coattn_backward): every contraction on three bf16 pieces (fp32's range throughout). */
 #define COATTN_FLAG_EXACT3 16
 /* flags bit 5 (coattn_linear_forward; `accumulate` of coattn_linear_weight_grad): the two-piece width for this product. */
 #define COATTN_FLAG_SPLIT2 32
+/* flags bit 6 (coattn_linear_forward): two FP16 pieces for this product (the form coattn_forward runs its projections in);
+ * the weight image written under this flag is read under this flag only. */
+#define COATTN_FLAG_F16PAIR 64
 typedef struct coattn_params {
   const void* W_v; const void* b_v;   /* model.py:350 */
   const void* W_q; const void* b_q;   /* model.py:351 */

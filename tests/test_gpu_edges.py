@@ -429,3 +429,19 @@ def test_profile_marks_of_forward_and_backward():
     assert marks[:3] == ["wsplit", "projections", "coattn_fwd32"] and "bwd_nat32" in marks and marks[-1] == "reduce_partials"
     assert all(us[i] > 0 for i in range(n)) and sum(us[i] for i in range(n)) < 5e4
     assert torch.isfinite(v).all() and all(torch.isfinite(t).all() for t in grads)
+
+
+def test_large_feature_magnitudes_stay_finite():
+    """The forward-side contractions run on two FP16 pieces (include/coattn.h): features far beyond fp16's range must not
+    turn into inf - inf = NaN -- the conversions saturate; with COATTN_FLAG_EXACT3 the values are carried exactly."""
+    from tests._hip import run_hip
+    from tests import _golden as G
+    torch.manual_seed(77)
+    V, Qs, P, gv, gq = G.build_case("g3_n49_ragged", torch.float32)
+    V = V.clone()
+    V[:, :, 0] *= 1.0e5                                   # one location of every sample, all channels: up to ~1e6
+    V[0, 3, :] = 1.0e30
+    for exact in (False, True):
+        r = run_hip(V, Qs, P, gv, gq, impl="fused", layout="lm", exact3=exact)
+        for k, t in r.items():
+            assert torch.isfinite(t).all(), (exact, k)

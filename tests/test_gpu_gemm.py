@@ -224,6 +224,44 @@ def test_linear_strided_rows_scale_and_image_reuse():
     assert _rel(y2, 2.5 * (x2[:, :K].double() @ W.double().t())) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(31360, 512, 512), (4160, 512, 512), (777, 256, 96), (130, 96, 64)])
+def test_linear_two_fp16_pieces(M, N, K):
+    """COATTN_FLAG_F16PAIR (the form coattn_forward runs its projections in): two FP16 pieces per operand, the weight image
+    scaled by 256 -- 22 significand bits; values of ordinary magnitude, and a weight image reused under the same flag."""
+    from vqa_amd import _lib
+    torch.manual_seed(13)
+    x = torch.randn(M, K, device="cuda").clamp_min_(0) * 3.0          # post-ReLU-like features
+    W = torch.randn(N, K, device="cuda") / K ** 0.5
+    b = torch.randn(N, device="cuda")
+    rc, y, wimg = _linear(x, K, W, b, M, N, K, flags=_lib.FLAG_F16PAIR)
+    _lib.check(rc, "coattn_linear_forward")
+    ref = x.double() @ W.double().t() + b.double()
+    assert _rel(y, ref) < 4e-6
+    rc, y2, _ = _linear(x, K, torch.zeros_like(W), b, M, N, K, flags=_lib.FLAG_F16PAIR | 1, wimg=wimg)
+    _lib.check(rc, "coattn_linear_forward")
+    assert torch.equal(y, y2)
+
+
+def test_linear_two_fp16_pieces_range():
+    """Beyond fp16's range the conversions saturate (MODE.FP16_OVFL): hi + lo carries magnitudes up to 131,008, larger ones
+    clamp there -- finite results for any finite input; tiny values keep 2^-24 absolute."""
+    from vqa_amd import _lib
+    torch.manual_seed(14)
+    M, N, K = 256, 128, 64
+    W = torch.randn(N, K, device="cuda") / K ** 0.5
+    x = torch.randn(M, K, device="cuda")
+    x[0, :] = 60000.0; x[1, :] = 1.0e5; x[2, :] = 1.0e9; x[3, :] = -3.0e38; x[4, :] = 1.0e-6; x[5, :] = 3.0e-8
+    rc, y, _ = _linear(x, K, W, None, M, N, K, flags=_lib.FLAG_F16PAIR)
+    _lib.check(rc, "coattn_linear_forward")
+    assert torch.isfinite(y).all()
+    ref = x.double() @ W.double().t()
+    assert _rel(y[0:1], ref[0:1]) < 4e-6 and _rel(y[6:], ref[6:]) < 4e-6          # inside the range: 22 bits
+    assert _rel(y[1:2], ref[1:2]) < 1e-3                                           # 65,504 .. 131,008: fewer bits
+    clamped = torch.full((1, K), 131008.0, device="cuda").double() @ W.double().t()
+    assert _rel(y[2:3], clamped) < 1e-3 and _rel(y[3:4], -clamped) < 1e-3          # beyond: clamped, finite
+    assert (y[4:6].double() - ref[4:6]).abs().max() < 1e-6                          # tiny values: absolute 2^-24 per element
+
+
 def test_linear_rejects_unsupported_shapes():
     from vqa_amd import _lib
     x = torch.randn(64, 48, device="cuda"); W = torch.randn(32, 48, device="cuda")

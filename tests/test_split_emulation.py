@@ -13,13 +13,15 @@ import torch
 
 from . import _golden as G
 
-# contraction -> pieces per operand.  3: six partial products (error ~2^-24 per product), 2: three partial
-# products (operands truncated to 16 significand bits, mid*mid dropped: ~2^-16 relative per product)
+# contraction -> pieces per operand.  3: six partial products of bf16 pieces (error ~2^-24 per product), 2: three partial
+# products (operands truncated to 16 significand bits, mid*mid dropped: ~2^-16 relative per product), "2h": two FP16
+# pieces (22 significand bits, three partial products, ~2^-22; fp16's range), "2hs": the same with the weight operand
+# scaled by 256 (fused.h kF16WScale: the lo pieces of ~0.04-sized weights would be subnormal otherwise)
 WIDTHS = {
-    "affinity": 3,      # A = Q V^T                                   coattn_fwd32 phase 1
-    "proj": 3,          # P_v = V W_v^T                               gemm_w   (two pieces: H_q off by 2e-4, see below)
-    "proj_q": 2,        # P_q = Q W_q^T                               gemm_w   (reaches H_v summed over T <= 28 tokens only)
-    "h": 2,             # C^T P_q, C P_v                              coattn_fwd32 phase 2
+    "affinity": "2h",   # A = Q V^T                                   coattn_fwd32 phase 1
+    "proj": "2hs",      # P_v = V W_v^T                               gemm_w   (two BF16 pieces: H_q off by 2e-4, see below)
+    "proj_q": "2hs",    # P_q = Q W_q^T                               gemm_w
+    "h": "2h",          # C^T P_q, C P_v                              coattn_fwd32 phase 2
     "bwd": 2,           # recomputed C^T P_q, C dZ_v, C^T dZ_q, dC    bwd_nat32 / bwd_dc32
     "dq": 2,            # dA V                                        bwd_dq32(x)
     "gemm_bwd": 2,      # dP_q W_q, dW_v, dW_q                        gemm_tn launch
@@ -44,9 +46,10 @@ def mm(a, b, n):
     if n == "2x3":                                  # a on two pieces, b (the weight) on three: ah bh + am bh + ah bm + ah bl
         pa, pb = _pieces(a, 2), _pieces(b, 3)
         return (pa[0] + pa[1]) @ pb[0] + pa[0] @ (pb[1] + pb[2])
-    if n == "2h":                                   # two fp16 pieces (hi + lo: 22 significand bits, fp16's range)
-        pa, pb = _pieces(a, 2, torch.float16), _pieces(b, 2, torch.float16)
-        return (pa[0] + pa[1]) @ pb[0] + pa[0] @ pb[1]
+    if n in ("2h", "2hs"):                          # two fp16 pieces (hi + lo: 22 significand bits, fp16's range)
+        sc = 256.0 if n == "2hs" else 1.0           # ("2hs": b is the weight, held as 256 W)
+        pa, pb = _pieces(a, 2, torch.float16), _pieces(b * sc, 2, torch.float16)
+        return ((pa[0] + pa[1]) @ pb[0] + pa[0] @ pb[1]) / sc
     pa, pb = _pieces(a, n), _pieces(b, n)
     if n == 1:
         return pa[0] @ pb[0]
@@ -139,18 +142,38 @@ def test_exact_split_is_at_fp32_level():
     assert max(ef.values()) < 5e-6 and max(eg.values()) < 5e-6, (ef, eg)
 
 
-def test_projections_need_three_pieces():
-    """Why the forward projections keep the exact split: their error reaches H_q = tanh(P_q + C P_v) amplified by the
-    sum over the N locations (two pieces: 2e-4 on the saturated case, past the contract)."""
-    ef, _ = run_case("g2_cfg2_natural", dict(WIDTHS, proj=2))
+# the widths of rounds 3 / 4 before the FP16 pieces: the exact bf16 split where two bf16 pieces do not hold
+BF16_WIDTHS = dict(WIDTHS, affinity=3, proj=3, proj_q=2, h=2)
+
+
+def test_projections_do_not_hold_on_two_bf16_pieces():
+    """Why the forward projections are not on two BF16 pieces: their error reaches H_q = tanh(P_q + C P_v) amplified by
+    the sum over the N locations (2e-4 on the saturated case, past the contract) -- 16 significand bits are too few."""
+    ef, _ = run_case("g2_cfg2_natural", dict(BF16_WIDTHS, proj=2))
     assert max(ef.values()) > 1e-4, ef
 
 
-def test_affinity_needs_three_pieces():
-    """Why phase 1 keeps the exact split: two pieces in A = Q V^T break the gradient contract on the saturated case."""
-    W = dict(WIDTHS, affinity=2)
-    _, eg = run_case("g2_cfg2_natural", W)
+def test_affinity_does_not_hold_on_two_bf16_pieces():
+    """The same for phase 1: two bf16 pieces in A = Q V^T break the gradient contract on the saturated case."""
+    _, eg = run_case("g2_cfg2_natural", dict(BF16_WIDTHS, affinity=2))
     assert max(eg.values()) > 1e-4, eg
+
+
+def test_fp16_pieces_beat_the_bf16_widths_they_replace():
+    """Two FP16 pieces for the forward-side contractions (22 bits, half the MFMAs of the exact bf16 split): less error than
+    exact affinity / P_v next to two-bf16-piece P_q / phase 2."""
+    ef_h, eg_h = run_case("g2_cfg2_natural", WIDTHS)
+    ef_b, eg_b = run_case("g2_cfg2_natural", BF16_WIDTHS)
+    assert max(ef_h.values()) < 0.5 * max(ef_b.values()), (ef_h, ef_b)
+    assert max(eg_h.values()) < max(eg_b.values()), (eg_h, eg_b)
+
+
+def test_weight_scale_matters_for_fp16_pieces():
+    """Without the factor 256 on the weight image the lo pieces of the weights are fp16 subnormals (2^-24 absolute): the
+    projections then carry the largest error of the forward."""
+    ef, _ = run_case("g2_cfg2_natural", dict(WIDTHS, proj="2h", proj_q="2h"))
+    ef_s, _ = run_case("g2_cfg2_natural", WIDTHS)
+    assert max(ef.values()) > 2 * max(ef_s.values()), (ef, ef_s)
 
 
 if __name__ == "__main__":

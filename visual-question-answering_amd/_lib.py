@@ -27,6 +27,7 @@ FLAG_BF16_PROJ = 4
 FLAG_BF16_IN = 8          # linear entry points: x (dy) stored as bf16
 FLAG_EXACT3 = 16          # coattn_forward / coattn_backward: every contraction on the exact three-piece split
 FLAG_SPLIT2 = 32          # linear entry points: the two-piece width (hi + mid, three partial products)
+FLAG_F16PAIR = 64        # coattn_linear_forward: two FP16 pieces (the form the forward runs its projections in)
 
 
 class Params(C.Structure):

@@ -16,7 +16,7 @@ void coattn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int coattn_version(void) { return 510; }   // 0.5.1: coattn_features_native; 0.5.0: widths of the fp32 mode (COATTN_FLAG_EXACT3 / _SPLIT2), coattn_profile_*
+extern "C" int coattn_version(void) { return 520; }   // 0.5.2: forward-side contractions on two FP16 pieces (COATTN_FLAG_F16PAIR); 0.5.1: coattn_features_native; 0.5.0: widths of the fp32 mode (COATTN_FLAG_EXACT3 / _SPLIT2), coattn_profile_*
 
 // ---------------------------------------------------------------------------------------
 // per-kernel timing (bench.py's backward roofline legs): HIP events recorded between the launches of the calls made
@@ -158,6 +158,7 @@ extern "C" int coattn_linear_forward(const void* x, int64_t ld_x, const void* W,
   g.out_scale = out_scale; g.M = M; g.N = N; g.K = K; g.batch = 1;
   g.bf16 = (flags & COATTN_FLAG_BF16_PROJ) ? 1 : 0;
   g.np = (flags & COATTN_FLAG_SPLIT2) ? 2 : 3;
+  if ((flags & COATTN_FLAG_F16PAIR) && !g.bf16) { g.np = 2; g.f16 = 1; }
   g.a_bf16 = (flags & COATTN_FLAG_BF16_IN) ? 1 : 0;
   CA_CHECK_ARG(!g.a_bf16 || g.bf16, "linear: COATTN_FLAG_BF16_IN needs COATTN_FLAG_BF16_PROJ");
   CA_CHECK_ARG(g.a_bf16 ? gemm_bf_supported(g) : gemm_w_supported(g), "linear: shape M=%d N=%d K=%d ld=%ld not supported (see coattn.h)", M, N, K, (long)ld_x);
@@ -221,6 +222,7 @@ struct Ctx {
   VLayout vl;                 // element strides of x_img[B,N,d]
   bool bf16_proj = false;     // COATTN_FLAG_BF16_PROJ: the projections and their gradients on the bf16 MFMA
   int np_pq = 3;              // width of the P_q projection in the fp32 mode (3 | 2)
+  bool f16_proj = false;      // fp32 mode: both projections on two FP16 pieces (fused.h kF16WScale)
   float pscale = 1.f;         // factor on P_v, P_q as stored (fused path: kPScale, fused.h)
 };
 
@@ -292,9 +294,18 @@ static int np_projq(int flags) {                    // P_q = Q W_q^T: its error 
   static const int split = env_int("COATTN_SPLIT", 2), pq = env_int("COATTN_SPLIT_PQ", 2);
   return ((flags & COATTN_FLAG_EXACT3) || split == 3) ? 3 : (pq == 2 ? 2 : 3);
 }
-static int np_fwd(int flags) {
-  static const int split = env_int("COATTN_SPLIT", 2), fwd = env_int("COATTN_SPLIT_FWD", 2);
-  return ((flags & COATTN_FLAG_EXACT3) || split == 3) ? 3 : (fwd == 2 ? 2 : 3);
+// The forward's projections P_v, P_q on two FP16 pieces (fused.h; tests/test_split_emulation.py: less error than the exact
+// split of P_v next to two bf16 pieces of P_q, at half the MFMAs of the former).  COATTN_FWD_F16=0 (developer switch),
+// COATTN_FLAG_EXACT3 or COATTN_SPLIT=3: the bf16 widths.
+static bool f16_fwd(int flags) {
+  static const int split = env_int("COATTN_SPLIT", 2), on = env_int("COATTN_FWD_F16", 1);
+  return !(flags & COATTN_FLAG_EXACT3) && split != 3 && on != 0;
+}
+static int np_fwd(int flags) {                      // 4: both phases of the forward kernel on two FP16 pieces (coattn_fwd32.hip)
+  static const int split = env_int("COATTN_SPLIT", 2), fwd = env_int("COATTN_SPLIT_FWD", 2), hk = env_int("COATTN_FWD_F16_KERNEL", 1);
+  if ((flags & COATTN_FLAG_EXACT3) || split == 3) return 3;
+  if (f16_fwd(flags) && hk != 0 && fwd == 2) return 4;
+  return fwd == 2 ? 2 : 3;
 }
 
 // COATTN_GEMM_W=0 (developer switch): the projections through gemm.hip instead of the pre-split-weight kernel
@@ -318,6 +329,7 @@ int general_projections(const Ctx& c, const float* V, const float* const* Q, con
   wq.bias_n = (const float*)p->b_q; wq.out_scale = c.pscale; wq.M = c.B * c.T; wq.N = c.d; wq.K = c.d; wq.batch = c.L;
   wv.bf16 = wq.bf16 = c.bf16_proj ? 1 : 0;          // reduced precision: the same kernels, hi pieces only, one MFMA per product
   wv.np = 3; wq.np = c.np_pq;                        // fp32 mode: P_v on the exact split, P_q on two pieces (tests/test_split_emulation.py)
+  if (c.f16_proj && !c.bf16_proj) { wv.np = wq.np = 2; wv.f16 = wq.f16 = 1; }   // ... or both on two FP16 pieces
   const bool w_ok = gemm_w_enabled();
   bool v_w = false;
   if (w_ok && c.vl.sD == 1 && c.vl.sB == (long)c.N * c.vl.sN && c.vl.sN < (1L << 24)) {
@@ -334,7 +346,9 @@ int general_projections(const Ctx& c, const float* V, const float* const* Q, con
     //  precision mode, so it runs on the same kernel as P_q and wants the same image format)
     if (v_w) jobs[nj++] = WSplit{(const float*)p->W_v, const_cast<void*>(wv.Wf), c.d, c.d, 0, c.d, wimg_pieces(wv)};
     if (q_w) jobs[nj++] = WSplit{(const float*)p->W_q, const_cast<void*>(wq.Wf), c.d, c.d, 0, c.d, wimg_pieces(wq)};
-    if (q_w && keep_wqT) jobs[nj++] = WSplit{(const float*)p->W_q, sv + sp.wqT, c.d, c.d, 1, c.d, wimg_pieces(wq)};
+    WGemm wqb = wq;                                   // (the backward's operands are gradients: bf16 pieces, fused.h)
+    wqb.f16 = 0;
+    if (q_w && keep_wqT) jobs[nj++] = WSplit{(const float*)p->W_q, sv + sp.wqT, c.d, c.d, 1, c.d, wimg_pieces(wqb)};
     CA_TRY(launch_wsplit(jobs, nj, c.s));
     prof_mark(c.s, "wsplit");
   }
@@ -571,6 +585,7 @@ static int forward_impl(const void* V, const VLayout& vl, const void* const* Q, 
   Ctx c{B, N, T, d, L, (hipStream_t)stream, vl};
   c.bf16_proj = (flags & COATTN_FLAG_BF16_PROJ) != 0;
   c.np_pq = fused ? np_projq(flags) : 3;              // (the general-shape path stays exact throughout)
+  c.f16_proj = fused && f16_fwd(flags);
   c.pscale = fused ? kPScale : 1.f;
   if (do_proj)
     CA_TRY(general_projections(c, (const float*)V, (const float* const*)Q, p, sv,

@@ -79,7 +79,7 @@ int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, c
   a.stamps = COATTN_STAMPS ? reinterpret_cast<unsigned long long*>(ws) : nullptr;
   a.B = B; a.N = N; a.T = T; a.d = d; a.L = L;
   a.bf16 = bf16;
-  a.np = (np == 2 && !bf16) ? 2 : 3;
+  a.np = ((np == 2 || np == 4) && !bf16) ? np : 3;      // 4: both phases on two FP16 pieces (coattn_fwd32.hip)
   CA_TRY(fused32_forward(a, s));
   prof_mark(s, "coattn_fwd32");
   if (fuse_v) return 0;

@@ -64,10 +64,16 @@ __device__ __forceinline__ void vmcnt_wait(int n) {
 // NP = 1 (SP, single product): the reduced-precision mode (COATTN_FLAG_BF16_PROJ) -- every operand of BOTH phases rounded once
 // to bf16, ONE MFMA per product (the hi x hi term of the split; the mid / lo pieces are neither computed, stored in the
 // LDS image nor read back).
+// NP_ = 4 (HF, the default of the fp32 mode): BOTH phases on two FP16 pieces per operand (fused.h: 22 significand bits, the
+// three products lo*hi, hi*lo, hi*hi on v_mfma_f32_32x32x16_f16) -- every operand here is of ordinary magnitude (features,
+// projections, tanh values); less error than the exact bf16 split of phase 1 next to two bf16 pieces in phase 2
+// (tests/test_split_emulation.py), at half the MFMAs and 6 instead of 11 split instructions per pair in phase 1.
 // FV: the kernel also attends the image features, v_l = a_v^T V (model.py:391) -- location-major V, NT = 2, four waves.
-template <int NT, int NW, bool LM, int NP, bool FV = false>
+template <int NT, int NW, bool LM, int NP_, bool FV = false>
 __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs a) {
   static_assert(!FV || (LM && NT == 2 && NW == 4), "the fused v pass: location-major features, N <= 64, 256 threads");
+  constexpr bool HF = NP_ == 4;
+  constexpr int NP = HF ? 2 : NP_;                   // pieces per operand in phase 2 (and, with HF, in phase 1)
   constexpr bool SP = NP == 1;
   constexpr int NPAD = 32 * NT;
   constexpr int SLD = 36;                            // row stride of the f32 reduction slots [n][t = 32]: 16-byte accesses
@@ -89,6 +95,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
 
   int b, l;
   if (!block_to_pair(blockIdx.x, a.B, a.L, b, l)) return;
+  if (HF) f16_saturating_conversions();
   CA_STAMP(0);
   const int N = a.N, T = a.T, d = a.d;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -199,12 +206,12 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
             continue;
           }
           if (j == 0) {                              // Q unit: split it, and the first tile's fragment
-            split3(f32x8{cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6], cur[7]}, qa[0]);
-            split3(f32x8{cur[8], cur[9], cur[10], cur[11], cur[12], cur[13], cur[14], cur[15]}, qa[1]);
+            splitn_x<HF ? 2 : 3, HF>(f32x8{cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6], cur[7]}, qa[0]);
+            splitn_x<HF ? 2 : 3, HF>(f32x8{cur[8], cur[9], cur[10], cur[11], cur[12], cur[13], cur[14], cur[15]}, qa[1]);
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-              unsigned hh, mm, ll;
-              split3_pair(nxt[2 * m], nxt[2 * m + 1], hh, mm, ll);
+              unsigned hh = 0, mm = 0, ll = 0;
+              split_pair_x<HF ? 2 : 3, HF>(nxt[2 * m], nxt[2 * m + 1], hh, mm, ll);
               vh[m >> 2][m & 3] = hh; vm[m >> 2][m & 3] = mm; vl[m >> 2][m & 3] = ll;
             }
           } else {
@@ -214,11 +221,12 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
 #pragma unroll
             for (int m = 0; m < 12; ++m) {
               const int ks = m / 6, i = m % 6;
-              if (!SP || i == 5) acc[j - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks][PA[i]], b3[ks][PB[i]], acc[j - 1], 0, 0, 0);
+              // (HF: the products of pieces 0 / 1 are the last three of the six, in the same order)
+              if (SP ? i == 5 : (!HF || i >= 3)) acc[j - 1] = mfma32_16<HF>(qa[ks][PA[i]], b3[ks][PB[i]], acc[j - 1]);
               if (jn != 0 && m >= 2 && m < 10) {     // the next unit is a V tile: split it under these MFMAs
                 const int pr = m - 2;
-                unsigned hh, mm, ll;
-                split3_pair(nxt[2 * pr], nxt[2 * pr + 1], hh, mm, ll);
+                unsigned hh = 0, mm = 0, ll = 0;
+                split_pair_x<HF ? 2 : 3, HF>(nxt[2 * pr], nxt[2 * pr + 1], hh, mm, ll);
                 nh[pr >> 2][pr & 3] = hh; nm[pr >> 2][pr & 3] = mm; nl[pr >> 2][pr & 3] = ll;
               }
               __builtin_amdgcn_sched_barrier(0);
@@ -292,8 +300,8 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
       bf16x8 qa[3];
       u32x4 vh, vm, vl;                                // split pieces of the current bf16 unit's V fragment
       auto split_pair_v = [&](const f32x8& x, const int pr) {
-        unsigned hh, mm, ll;
-        split3_pair(x[2 * pr], x[2 * pr + 1], hh, mm, ll);
+        unsigned hh = 0, mm = 0, ll = 0;
+        split_pair_x<HF ? 2 : 3, HF>(x[2 * pr], x[2 * pr + 1], hh, mm, ll);
         vh[pr] = hh; vm[pr] = mm; vl[pr] = ll;
       };
       // prologue: units 0 .. R-2 in flight, unit 0 (the first Q fragment) read back
@@ -319,7 +327,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
           const bool next_bf = jn >= 1 && (jn - 1) < NB;    // the next unit is a V tile on the bf16 path: split it here
           if (j == 0) {                                // Q fragment of this k-step: split it, and the first tile's fragment
             qraw = cur;
-            if (NB > 0) split3(qraw, qa);
+            if (NB > 0) splitn_x<HF ? 2 : 3, HF>(qraw, qa);
             if (next_bf) {
   #pragma unroll
               for (int pr = 0; pr < 4; ++pr) split_pair_v(nxt, pr);
@@ -329,10 +337,10 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
             u32x4 nh, nm, nl;
   #pragma unroll
             for (int m = 0; m < 6; ++m) {
-              if (!SP || m == 5) acc[j - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[PA[m]], b3[PB[m]], acc[j - 1], 0, 0, 0);
+              if (SP ? m == 5 : (!HF || m >= 3)) acc[j - 1] = mfma32_16<HF>(qa[PA[m]], b3[PB[m]], acc[j - 1]);
               if (next_bf && m < 4) {
-                unsigned hh, mm, ll;
-                split3_pair(nxt[2 * m], nxt[2 * m + 1], hh, mm, ll);
+                unsigned hh = 0, mm = 0, ll = 0;
+                split_pair_x<HF ? 2 : 3, HF>(nxt[2 * m], nxt[2 * m + 1], hh, mm, ll);
                 nh[m] = hh; nm[m] = mm; nl[m] = ll;
               }
               __builtin_amdgcn_sched_barrier(0);
@@ -429,8 +437,8 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, th), rs_c, cvoff, i * N * 4, 0);
       }
       unsigned hh[2] = {0, 0}, mm[2] = {0, 0}, ll[2] = {0, 0};
-      split_pair<NP>(c[0], c[1], hh[0], mm[0], ll[0]);
-      split_pair<NP>(c[2], c[3], hh[1], mm[1], ll[1]);
+      split_pair_x<NP, HF>(c[0], c[1], hh[0], mm[0], ll[0]);
+      split_pair_x<NP, HF>(c[2], c[3], hh[1], mm[1], ll[1]);
       const int off = n * 32 + 8 * ((tq >> 1) ^ ((n >> 2) & 3)) + 4 * (tq & 1);
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
       *reinterpret_cast<u32x2*>(Cimg + off) = u32x2{hh[0], hh[1]};
@@ -473,7 +481,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
           x[k] = lo;
           x[4 + k] = hi;
         }
-        splitn<NP>(x, pqB[ct][ks]);
+        splitn_x<NP, HF>(x, pqB[ct][ks]);
       }
     }
   };
@@ -510,7 +518,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
       auto split_half = [&](const f32x16& pv, const int s2, bf16x8 (&pb)[3]) {
         const f32x8 x = f32x8{pv[8 * s2], pv[8 * s2 + 1], pv[8 * s2 + 2], pv[8 * s2 + 3],
                               pv[8 * s2 + 4], pv[8 * s2 + 5], pv[8 * s2 + 6], pv[8 * s2 + 7]};
-        splitn<NP>(x, pb);
+        splitn_x<NP, HF>(x, pb);
       };
       auto read_cq = [&](const short* img, const int s2, bf16x8 (&cq)[3]) {     // A = C (tokens x locations)
 #pragma unroll
@@ -548,14 +556,14 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
           // ---- the MFMA
           // (slot m % 6 of a group of six: every slot at width 3, every other one at width 2, the last at width 1)
           const int kp = slot_product<NP>(m % 6), grp = kp < 0 ? -1 : m / 6, pa = piece_a<NP>(kp < 0 ? 0 : kp), pb = piece_b<NP>(kp < 0 ? 0 : kp);
-          if (grp == 0) accq[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cq0[pa], pb0[pb], accq[ct], 0, 0, 0);
+          if (grp == 0) accq[ct] = mfma32_16<HF>(cq0[pa], pb0[pb], accq[ct]);
           if (grp == 1) {
             const bf16x8 b = pb == 0 ? __builtin_bit_cast(bf16x8, h1) : pb == 1 ? __builtin_bit_cast(bf16x8, m1)
                                                                                 : __builtin_bit_cast(bf16x8, l1);
-            accq[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cq1[pa], b, accq[ct], 0, 0, 0);
+            accq[ct] = mfma32_16<HF>(cq1[pa], b, accq[ct]);
           }
-          if (grp == 2) cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca0[pa], pqB[ct][0][pb], cur, 0, 0, 0);
-          if (grp == 3) cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca1[pa], pqB[ct][1][pb], cur, 0, 0, 0);
+          if (grp == 2) cur = mfma32_16<HF>(ca0[pa], pqB[ct][0][pb], cur);
+          if (grp == 3) cur = mfma32_16<HF>(ca1[pa], pqB[ct][1][pb], cur);
           // ---- the next group's A operands
           if (m == 1) read_cq(img, 1, cq1);
           if (m == 7) read_ca(img, 0, ca0);
@@ -563,7 +571,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
           // ---- its VALU chunk
           if (m < 4) {                               // split pair m of this unit's second k-step (registers 8 .. 15)
             unsigned hh = 0, mm = 0, ll = 0;
-            split_pair<NP>(cur[8 + 2 * m], cur[8 + 2 * m + 1], hh, mm, ll);
+            split_pair_x<NP, HF>(cur[8 + 2 * m], cur[8 + 2 * m + 1], hh, mm, ll);
             h1[m] = hh; m1[m] = mm; l1[m] = ll;
           }
           if (m >= 4 && m < 20) {                    // register g = m - 4 of unit u-1: its score term
@@ -581,7 +589,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
           }
           if (m >= 20) {                             // split pair m - 20 of the next unit's first k-step
             unsigned hh = 0, mm = 0, ll = 0;
-            split_pair<NP>(next[2 * (m - 20)], next[2 * (m - 20) + 1], hh, mm, ll);
+            split_pair_x<NP, HF>(next[2 * (m - 20)], next[2 * (m - 20) + 1], hh, mm, ll);
             h0[m - 20] = hh; m0[m - 20] = mm; l0[m - 20] = ll;
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -859,18 +867,22 @@ int launch_fwd32(const FwdArgs& a, hipStream_t s) {
 template <bool LM>
 int dispatch_fwd32(const FwdArgs& a, hipStream_t s) {
   const bool small_n = a.N <= 64;
-  const bool w2 = a.np == 2;                         // phase 2 on two pieces
+  const bool w2 = a.np == 2;                         // phase 2 on two bf16 pieces
+  const bool hf = a.np == 4;                         // both phases on two FP16 pieces (the default)
   if (a.d % 512 == 0) {
     if constexpr (LM) {
       if (small_n && a.v_out) {                      // the kernel attends the image features too (FwdArgs::v_out)
         if (a.bf16) return launch_fwd32<2, 4, true, 1, true>(a, s);
+        if (hf) return launch_fwd32<2, 4, true, 4, true>(a, s);
         return w2 ? launch_fwd32<2, 4, true, 2, true>(a, s) : launch_fwd32<2, 4, true, 3, true>(a, s);
       }
     }
     if (a.bf16) return small_n ? launch_fwd32<2, 4, LM, 1>(a, s) : launch_fwd32<7, 4, LM, 1>(a, s);
+    if (hf) return small_n ? launch_fwd32<2, 4, LM, 4>(a, s) : launch_fwd32<7, 4, LM, 4>(a, s);
     if (w2) return small_n ? launch_fwd32<2, 4, LM, 2>(a, s) : launch_fwd32<7, 4, LM, 2>(a, s);
     return small_n ? launch_fwd32<2, 4, LM, 3>(a, s) : launch_fwd32<7, 4, LM, 3>(a, s);
   }
+  if (hf) return small_n ? launch_fwd32<2, 2, LM, 4>(a, s) : launch_fwd32<7, 2, LM, 4>(a, s);
   if (w2) return small_n ? launch_fwd32<2, 2, LM, 2>(a, s) : launch_fwd32<7, 2, LM, 2>(a, s);
   return small_n ? launch_fwd32<2, 2, LM, 3>(a, s) : launch_fwd32<7, 2, LM, 3>(a, s);   // (the fp32 mode at these widths)
 }

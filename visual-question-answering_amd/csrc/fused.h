@@ -75,6 +75,16 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {      // one 
 // cycles beside MFMAs than two plain subtractions): the kernels are compiled with -fno-slp-vectorize; an inline-asm
 // v_sub_f32 would do the same but costs a wait state after every statement.
 __device__ __forceinline__ float sub1(float a, float b) { return a - b; }
+// two FP16 pieces of a pair (6 VALU: v_cvt_pk_f16_f32, two v_cvt_f32_f16, two v_sub_f32, v_cvt_pk_f16_f32; round to nearest even)
+typedef _Float16 hfv2 __attribute__((ext_vector_type(2)));
+typedef _Float16 hfv8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split_pair_h(float a, float b, unsigned& h, unsigned& m) {
+  const hfv2 hh = __builtin_convertvector((f32x2{a, b}), hfv2);
+  h = __builtin_bit_cast(unsigned, hh);
+  const float ra = sub1(a, (float)hh[0]);
+  const float rb = sub1(b, (float)hh[1]);
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{ra, rb}), hfv2));
+}
 // one pair of fp32 values -> the three packed bf16 pairs (11 VALU ops)
 __device__ __forceinline__ void split3_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
   h = cvt_pk_bf16(a, b);
@@ -128,6 +138,38 @@ __device__ __forceinline__ void splitn(const f32x8& v, bf16x8 (&p)[3]) {
   if constexpr (NP >= 2) p[1] = __builtin_bit_cast(bf16x8, m);
   if constexpr (NP == 3) p[2] = __builtin_bit_cast(bf16x8, l);
 }
+// the same with the pieces' format as a parameter: H = two FP16 pieces (NP = 2), else NP bf16 pieces
+template <int NP, bool H>
+__device__ __forceinline__ void split_pair_x(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+  if constexpr (H) {
+    static_assert(NP == 2, "FP16 pieces: two per operand");
+    split_pair_h(a, b, h, m);
+  } else {
+    split_pair<NP>(a, b, h, m, l);
+  }
+}
+template <int NP, bool H>
+__device__ __forceinline__ void splitn_x(const f32x8& v, bf16x8 (&p)[3]) {
+  if constexpr (H) {
+    u32x4 h, m;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned hh, mm;
+      split_pair_h(v[2 * i], v[2 * i + 1], hh, mm);
+      h[i] = hh; m[i] = mm;
+    }
+    p[0] = __builtin_bit_cast(bf16x8, h);
+    p[1] = __builtin_bit_cast(bf16x8, m);
+  } else {
+    splitn<NP>(v, p);
+  }
+}
+// one 32x32x16 MFMA on 16-bit operand registers of either format
+template <bool H>
+__device__ __forceinline__ f32x16 mfma32_16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+  if constexpr (H) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hfv8, a), __builtin_bit_cast(hfv8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 // partial products of a width in the order they are issued (smallest first)
 template <int NP> __device__ __forceinline__ constexpr int n_products() { return NP == 3 ? 6 : NP == 2 ? 3 : 1; }
 template <int NP> __device__ __forceinline__ constexpr int piece_a(int k) {      // A-operand piece of product k
@@ -172,7 +214,20 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, int voff, i
 }
 
 // ---- GEMM against a pre-split weight (gemm_w.hip) ---------------------------------------------------------------
-struct WSplit { const float* W; void* out; int N, K, trans, ld; int pieces; };   // Bw(k,n) = trans ? W[k*ld+n] : W[n*ld+k]; pieces: 3 (0 = 3), 1 = hi piece only (gemm_bf.hip)
+struct WSplit { const float* W; void* out; int N, K, trans, ld; int pieces; };   // Bw(k,n) = trans ? W[k*ld+n] : W[n*ld+k]; pieces: 3 (0 = 3), 1 = hi piece only (gemm_bf.hip),
+                                                                                 // 16 = two FP16 pieces of kF16WScale * W (WGemm.f16)
+// Forward-side contractions on two FP16 pieces (x = hi + lo, 22 significand bits; the three products lo*hi, hi*lo, hi*hi on
+// v_mfma_f32_32x32x16_f16): the cost of the two-piece bf16 width with 64 x less error -- for operands of ordinary magnitude
+// only: features, projections, tanh values (|x| < 65,504; gfx950 keeps fp16 subnormals in conversions and in the MFMA, so
+// small values lose precision only below 2^-24 absolute).  Gradients stay on bf16 pieces (fp32's range).  The weight image
+// holds kF16WScale * W so that the lo pieces of ~0.04-sized weights are normal numbers; the GEMM divides it out.
+constexpr float kF16WScale = 256.f;
+// Kernels that split into FP16 pieces set MODE.FP16_OVFL first: a conversion that overflows fp16 then saturates at
+// +-65,504 instead of becoming inf, so hi + lo represents magnitudes up to 131,008 (with fewer bits above 65,504) and larger
+// ones clamp there -- finite results for any finite input, never inf - inf = NaN (probed on gfx950, tools/ab/probe_f16_ovfl.hip).
+__device__ __forceinline__ void f16_saturating_conversions() {
+  __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);   // hwreg(HW_REG_MODE, offset 23, size 1) = FP16_OVFL
+}
 struct WGemm {
   const float* A; const float* a_ptrs[8]; long a_sz; int a_sm;       // A[z][m][k], k contiguous; z from the table or a_sz
   int a_sk, a_mdiv; long a_sdiv;                                     // a_sk != 0: A contiguous along m instead, element
@@ -184,6 +239,7 @@ struct WGemm {
   int M, N, K, batch;
   int bf16;                                                          // 1: operands rounded to bf16, ONE MFMA per product (COATTN_FLAG_BF16_PROJ)
   int np;                                                            // (bf16 = 0) bf16 pieces per operand: 0 / 3 = the exact split (six products), 2 = hi + mid (three products)
+  int f16;                                                           // (np = 2) the two pieces are FP16 (Wf: a pieces = 16 image)
   int a_bf16;                                                        // (gemm_bf_kernel) A is STORED as bf16; a_sm, a_sz stay in elements
 };
 size_t wsplit_bytes(int N, int K);
@@ -193,7 +249,7 @@ int launch_gemm_w(const WGemm* d, int n, hipStream_t s);          // n = 1 or 2 
 // single-product bf16 GEMM for wide shapes (gemm_bf.hip): reads a hi-piece-only weight image (WSplit.pieces = 1)
 int gemm_bf_supported(const WGemm& d);
 int launch_gemm_bf(const WGemm* d, int n, hipStream_t s);
-inline int wimg_pieces(const WGemm& d) { return gemm_bf_supported(d) ? 1 : 3; }
+inline int wimg_pieces(const WGemm& d) { return gemm_bf_supported(d) ? 1 : (d.f16 && d.np == 2 && !d.bf16 ? 16 : 3); }
 // the kernel a pre-split-weight GEMM runs on: gemm_bf when it takes the shape, else gemm_w
 inline int launch_gemm_wx(const WGemm* d, int n, hipStream_t s) {
   if (n == 2 && gemm_bf_supported(d[0]) != gemm_bf_supported(d[1])) {   // one job on each kernel: two launches

@@ -38,6 +38,7 @@ struct SplitArgs { SplitJob job[3]; int njobs; };
 // trans = 0: Bw(k, n) = W[n][k] (y = x W^T); trans = 1: Bw(k, n) = W[k][n] (dx = dy W).
 __global__ __launch_bounds__(256) void wsplit_kernel(const SplitArgs a) {
   const SplitJob j = a.job[blockIdx.y];
+  f16_saturating_conversions();                      // (only the pieces = 16 jobs convert to fp16)
   const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
   const int ks16 = (j.K + 15) / 16, nt32 = (j.N + 31) / 32;
   const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -49,6 +50,19 @@ __global__ __launch_bounds__(256) void wsplit_kernel(const SplitArgs a) {
   for (int e = 0; e < 8; ++e) {
     const int k = k0 + e;
     v[e] = (n < j.N && k < j.K) ? (j.trans ? j.W[(size_t)k * j.ld + n] : j.W[(size_t)n * j.ld + k]) : 0.f;
+  }
+  if (j.pieces == 16) {                              // two FP16 pieces of kF16WScale * W (fused.h), in the slots of pieces 0 and 1
+    u32x4 h, m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned hh, mm;
+      split_pair_h(v[2 * e] * kF16WScale, v[2 * e + 1] * kF16WScale, hh, mm);
+      h[e] = hh; m[e] = mm;
+    }
+    char* out = (char*)j.out + (size_t)chunk * kChunkBytes + lane * 16;
+    *reinterpret_cast<u32x4*>(out) = h;
+    *reinterpret_cast<u32x4*>(out + kFragBytes) = m;
+    return;
   }
   bf16x8 p[3];
   split3(v, p);
@@ -64,12 +78,13 @@ __global__ __launch_bounds__(256) void wsplit_kernel(const SplitArgs a) {
 // Up to two independent GEMMs per launch (P_v and P_q of the forward): the second one's workgroups fill the slots
 // the first one's last, partial round of workgroups would leave idle.  AM0: layout of job 0's A operand; NP / NP1: the
 // widths of job 0 / job 1 (the forward runs P_v on three pieces and P_q on two in one launch).
-template <bool AM0, int NP, int NW = 4, int NP1 = NP>
+template <bool AM0, int NP, int NW = 4, int NP1 = NP, bool H = false>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_w_kernel(const WJobs jobs) {
   __shared__ __attribute__((aligned(16))) short smem[2 * (NP > NP1 ? NP : NP1) * BM * LDR];  // three pieces: 61,440 B; two workgroups of 256 threads per CU
   static_assert(BM * LDR == BK * LDT, "both image layouts have the same size");
-  if ((int)blockIdx.x < jobs.first1) gemm_w_body<AM0, NP, NW>(jobs.job[0], (int)blockIdx.x, smem);
-  else gemm_w_body<false, NP1, NW>(jobs.job[1], (int)blockIdx.x - jobs.first1, smem);
+  if (H) f16_saturating_conversions();
+  if ((int)blockIdx.x < jobs.first1) gemm_w_body<AM0, NP, NW, H>(jobs.job[0], (int)blockIdx.x, smem);
+  else gemm_w_body<false, NP1, NW, H>(jobs.job[1], (int)blockIdx.x - jobs.first1, smem);
 }
 
 }  // namespace
@@ -83,7 +98,8 @@ int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s) {
   int chunks = 0;
   for (int i = 0; i < njobs; ++i) {
     CA_CHECK_ARG(jobs[i].W && jobs[i].out && jobs[i].N > 0 && jobs[i].K > 0, "wsplit: bad job");
-    a.job[i] = SplitJob{jobs[i].W, jobs[i].out, jobs[i].N, jobs[i].K, jobs[i].trans, jobs[i].ld, jobs[i].pieces == 1 ? 1 : 3};
+    a.job[i] = SplitJob{jobs[i].W, jobs[i].out, jobs[i].N, jobs[i].K, jobs[i].trans, jobs[i].ld,
+                        jobs[i].pieces == 1 ? 1 : (jobs[i].pieces == 16 ? 16 : 3)};
     const int c = ((jobs[i].N + 31) / 32) * ((jobs[i].K + 15) / 16);
     chunks = c > chunks ? c : chunks;
   }
@@ -124,6 +140,7 @@ int gemm_w_fill_job(const WGemm& d, gw::WArgs& g, long* nblk, int bn) {
   g.C = d.C; g.c_sz = d.c_sz; g.c_sm = d.c_sm;
   for (int t = 0; t < 8; ++t) { g.a_ptrs[t] = d.a_ptrs[t]; g.c_ptrs[t] = d.c_ptrs[t]; }
   g.bias_n = d.bias_n; g.oscale = d.out_scale != 0.f ? d.out_scale : 1.f;
+  g.ascale = (d.f16 && d.np == 2 && !d.bf16) ? 1.0f / kF16WScale : 1.0f;
   g.M = d.M; g.N = d.N; g.K = d.K;
   const long ntn = (d.N + bn - 1) / bn, ntm = (d.M + BM - 1) / BM;
   g.xcd_group = ntm >= 32 ? 1 : 0;
@@ -149,7 +166,13 @@ int launch_gemm_w(const WGemm* d, int n, hipStream_t s) {
   CA_CHECK_ARG(n == 1 || d[1].bf16 == d[0].bf16, "gemm_w: the jobs of a launch share the precision mode");
   const bool two0 = d[0].np == 2, two1 = n == 2 ? d[1].np == 2 : two0;      // fp32 mode: the width of each job
   const dim3 grid((unsigned)(nb[0] + nb[1]));
-  if (wide && mixed32) {
+  const bool h0 = d[0].f16 && two0 && !d[0].bf16, h1 = n == 2 ? (d[1].f16 && two1 && !d[1].bf16) : h0;
+  CA_CHECK_ARG(h0 == h1, "gemm_w: the jobs of a launch share the piece format");
+  if (h0) {                                           // two FP16 pieces (the forward's projections)
+    CA_CHECK_ARG(!wide, "gemm_w: FP16 pieces run on the four-wave tile");
+    if (d[0].a_sk) hipLaunchKernelGGL((gemm_w_kernel<true, 2, 4, 2, true>), grid, dim3(256), 0, s, jobs);
+    else hipLaunchKernelGGL((gemm_w_kernel<false, 2, 4, 2, true>), grid, dim3(256), 0, s, jobs);
+  } else if (wide && mixed32) {
     if (d[0].a_sk) hipLaunchKernelGGL((gemm_w_kernel<true, 3, 8, 2>), grid, dim3(512), 0, s, jobs);
     else hipLaunchKernelGGL((gemm_w_kernel<false, 3, 8, 2>), grid, dim3(512), 0, s, jobs);
   } else if (wide && !d[0].bf16) {

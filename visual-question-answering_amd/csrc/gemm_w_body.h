@@ -26,6 +26,7 @@ struct WArgs {
   const void* Wf; unsigned wf_bytes;
   float* C; float* c_ptrs[8]; long c_sz; int c_sm;
   const float* bias_n; float oscale;
+  float ascale;                                // on the accumulators (1, or 1 / kF16WScale for an FP16 weight image)
   int M, N, K, xcd_group;
 };
 
@@ -46,9 +47,11 @@ constexpr int LDT = BM + 32;                   // AM: [k][row] image row stride 
 // NW = 8    : 512-thread workgroups, tile 128 x 256 (the eight waves as 2 x 4): the A rows staged once serve twice the
 //             columns -- for the single-product mode at d = 2048, where the L2 -> CU traffic of A re-read by every
 //             column tile is the bound, not the MFMAs.
-template <bool AM, int NP = 3, int NW = 4>
+// H (NP = 2)  : the two pieces are FP16 (fused.h: split_pair_h, v_mfma_f32_32x32x16_f16) -- the forward's projections.
+template <bool AM, int NP = 3, int NW = 4, bool H = false>
 __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short* const smem) {
   static_assert(NP >= 1 && NP <= 3, "pieces per operand");
+  static_assert(!H || NP == 2, "FP16 pieces: two per operand");
   constexpr bool P1 = NP == 1;
   constexpr int WCN = NW / 2, BN = 64 * WCN, NT = 64 * NW, AP = 1024 / NT;   // waves per tile row, tile width, threads, A float4 per thread and step
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -170,6 +173,17 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
 #ifdef GEMMW_NOSPLIT
     if (st == 0) ph[e] = pm[e] = pl[e] = cvt_pk_bf16(raw[i][2 * e], raw[i][2 * e + 1]);
 #else
+    if (H) {
+      if (st == 0) {
+        const hfv2 hh = __builtin_convertvector((f32x2{raw[i][2 * e], raw[i][2 * e + 1]}), hfv2);
+        ph[e] = __builtin_bit_cast(unsigned, hh);
+        ra[e] = sub1(raw[i][2 * e], (float)hh[0]);
+        rb[e] = sub1(raw[i][2 * e + 1], (float)hh[1]);
+      } else if (st == 1) {
+        pm[e] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{ra[e], rb[e]}), hfv2));
+      }
+      return;
+    }
     if (st == 0) {
       ph[e] = cvt_pk_bf16(raw[i][2 * e], raw[i][2 * e + 1]);
       ra[e] = sub1(raw[i][2 * e], __builtin_bit_cast(float, ph[e] << 16));
@@ -200,7 +214,8 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
       const bool mf = NP == 3 || (NP == 2 && (n & 1)) || (NP == 1 && n >= 20);
       const int t = NP == 2 ? 3 + (mi >> 2) : n >> 2, i = (mi >> 1) & 1, j = mi & 1;
 #ifndef GEMMW_NOMFMA
-      if (mf) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[HH][PA[t]][i], bq[BU][j][PB[t]], acc[i][j], 0, 0, 0);
+      if (mf && H) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hfv8, af[HH][PA[t]][i]), __builtin_bit_cast(hfv8, bq[BU][j][PB[t]]), acc[i][j], 0, 0, 0);
+      if (mf && !H) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[HH][PA[t]][i], bq[BU][j][PB[t]], acc[i][j], 0, 0, 0);
 #else
       if (n < 4) acc[i][j][0] += __builtin_bit_cast(float, (int)af[HH][PA[t]][i][0] ^ (int)bq[BU][j][PB[t]][0]);
 #endif
@@ -293,7 +308,7 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
 #if GEMMW_NTSTORE
         if (col[j] < g.N) __builtin_nontemporal_store((acc[i][j][r] + bn[j]) * g.oscale, &crow[col[j]]);
 #else
-        if (col[j] < g.N) crow[col[j]] = (acc[i][j][r] + bn[j]) * g.oscale;
+        if (col[j] < g.N) crow[col[j]] = H ? fmaf(acc[i][j][r], g.ascale, bn[j]) * g.oscale : (acc[i][j][r] + bn[j]) * g.oscale;
 #endif
     }
 }

@@ -168,8 +168,11 @@ int launch_gemm_w(const WGemm* d, int n, hipStream_t s) {
   const dim3 grid((unsigned)(nb[0] + nb[1]));
   const bool h0 = d[0].f16 && two0 && !d[0].bf16, h1 = n == 2 ? (d[1].f16 && two1 && !d[1].bf16) : h0;
   CA_CHECK_ARG(h0 == h1, "gemm_w: the jobs of a launch share the piece format");
-  if (h0) {                                           // two FP16 pieces (the forward's projections)
-    CA_CHECK_ARG(!wide, "gemm_w: FP16 pieces run on the four-wave tile");
+  if (h0 && wide) {                                   // (developer switch COATTN_GEMMW_WIDE2: 128 x 256 tiles, eight waves --
+                                                      //  the forward's launch 96.8 -> 93.9 us at N = 196, 48.8 -> 52.8 at N = 49: off)
+    if (d[0].a_sk) hipLaunchKernelGGL((gemm_w_kernel<true, 2, 8, 2, true>), grid, dim3(512), 0, s, jobs);
+    else hipLaunchKernelGGL((gemm_w_kernel<false, 2, 8, 2, true>), grid, dim3(512), 0, s, jobs);
+  } else if (h0) {                                    // two FP16 pieces (the forward's projections)
     if (d[0].a_sk) hipLaunchKernelGGL((gemm_w_kernel<true, 2, 4, 2, true>), grid, dim3(256), 0, s, jobs);
     else hipLaunchKernelGGL((gemm_w_kernel<false, 2, 4, 2, true>), grid, dim3(256), 0, s, jobs);
   } else if (wide && mixed32) {

@@ -224,7 +224,7 @@ struct WSplit { const float* W; void* out; int N, K, trans, ld; int pieces; };  
 constexpr float kF16WScale = 256.f;
 // Kernels that split into FP16 pieces set MODE.FP16_OVFL first: a conversion that overflows fp16 then saturates at
 // +-65,504 instead of becoming inf, so hi + lo represents magnitudes up to 131,008 (with fewer bits above 65,504) and larger
-// ones clamp there -- finite results for any finite input, never inf - inf = NaN (probed on gfx950, tools/ab/probe_f16_ovfl.hip).
+// ones clamp there -- finite results for any finite input, never inf - inf = NaN (probed on gfx950, tools/probe_f16_ovfl.hip).
 __device__ __forceinline__ void f16_saturating_conversions() {
   __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);   // hwreg(HW_REG_MODE, offset 23, size 1) = FP16_OVFL
 }

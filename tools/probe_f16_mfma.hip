@@ -28,3 +28,4 @@ int main() {
     printf("a=%g b=%g: mfma %g (exact %g), cvt(a)=%g\n", t[0], t[1], h, t[0] * t[1], c);
   }
   return 0;
+}

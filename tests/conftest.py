@@ -32,3 +32,14 @@ def pytest_report_header(config):
         return "gpu: none visible"
     p = torch.cuda.get_device_properties(0)
     return "gpu: %s uuid %s (%d CUs)" % (p.name, getattr(p, "uuid", "unknown"), p.multi_processor_count)
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """The same line at the END of the run: `-q` drops the header, and a failure that comes and goes between boxes of the
+    pool is only worth anything with the device it happened on."""
+    import torch
+
+    if torch.cuda.is_available():
+        p = torch.cuda.get_device_properties(0)
+        terminalreporter.write_line("gpu: %s uuid %s (%d CUs), exit status %s" % (p.name, getattr(p, "uuid", "unknown"),
+                                                                                   p.multi_processor_count, int(exitstatus)))

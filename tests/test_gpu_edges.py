@@ -312,11 +312,14 @@ def test_large_batch_backward_workspace():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(23, 196, 26, 512, "lm"), (9, 49, 26, 512, "cm"), (3, 100, 17, 1024, "lm")])
+@pytest.mark.parametrize("shape", [(23, 196, 26, 512, "lm"), (9, 49, 26, 512, "cm"), (3, 100, 17, 1024, "lm"),
+                                   (640, 196, 26, 512, "cm"), (640, 196, 26, 512, "lm"), (320, 49, 26, 512, "cm")])
 def test_repeated_runs_are_bitwise_identical(shape):
     """no float atomics, fixed summation orders -- forward outputs and every gradient (image features
     included) of repeated runs on the same inputs are bit-for-bit the same (also a check on the LDS-only barriers and
-    counted waits of the fused kernels: a race would show here)."""
+    counted waits of the fused kernels: a race would show here).  The large batches are there because a race needs a busy
+    chip: the missing order between a ring slot's read-back and its refill in the channel-major phase 1 (round 4) showed in
+    one launch out of eight at B = 640 and in one out of seventy at B = 160."""
     import vqa_amd
     B, N, T, d, lay = shape
     torch.manual_seed(7)
@@ -327,7 +330,7 @@ def test_repeated_runs_are_bitwise_identical(shape):
     x.requires_grad_(True)
     Qs = [(torch.randn(B, T, d, device="cuda") * 0.5).requires_grad_(True) for _ in range(3)]
     ref = None
-    for _ in range(12):
+    for _ in range(12 if B < 100 else 30):
         for t in [x] + Qs + list(co.parameters()):
             t.grad = None
         v, q = co(x, Qs)

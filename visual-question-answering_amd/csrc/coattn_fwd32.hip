@@ -315,7 +315,14 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
         for (int p = 0; p < R; ++p) {                  // unit p of the body: k-step g0 + p / UPK, position p % UPK
           const int j = p % UPK, pn = (p + 1) % R, jn = (p + 1) % UPK;
           cur = nxt;
-          // refill the slot of the previous unit (its read-back has completed), then read back the next unit
+          // Refill the slot of the previous unit, then read back the next one.  The wait is the ordering between that
+          // slot's read-back and its refill: the values read from it were consumed one iteration ago IN THE SOURCE, but
+          // nothing ties the DMA issue to the instructions that consume them, and hipcc hoists it above them -- the
+          // two-fp16-piece build issued the refill of the Q slot before the wait for the Q fragment's second
+          // ds_read_b128, and on a busy LDS the refill (an L2 hit) now and then overtook the read: eight token rows of one
+          // pair's affinity wrong in one launch out of eight at B = 640 (tools/probe_repeat.py found it; the three-piece
+          // builds never showed it in thousands of soak rounds, but carried the same missing order).
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           dma_unit(g0 + (p + R - 1) / UPK, (p + R - 1) % UPK, (p + R - 1) % R);
           vmcnt_wait(pending_after(pn));
           nxt = read_unit(jn, pn);

@@ -11,6 +11,8 @@ One process, ITERS rounds.  Every round runs, interleaved,
   cfg2      coattention forward + backward at B=160, N=49, lm        -- test_gpu_parity.py::test_full_size_cfg2_properties[fused-lm-49]
   gemm_bf   the reduced-precision GEMMs of gemm_bf.hip (LDS-DMA weight image, counted waits) at config 4's size,
             M = 7,840, N = K = 2,048: coattn_linear_forward / coattn_linear_weight_grad with COATTN_FLAG_BF16_PROJ
+  big_cm    the module's forward + backward at B = 640, N = 196, channel-major features (a busy chip: round 4's race of the
+            forward kernel showed there) -- every 4th round, bitwise against round 0
   cfg4      the module's forward + backward in the reduced-precision mode at config 4's full size (B=160, N=49, d=2048,
             frozen image encoder): single-product fused kernels, gemm_bf.hip with bf16-stored gradients -- every 4th round,
             bf16 tolerance against float64, bitwise against round 0
@@ -191,6 +193,9 @@ class CoCase:
 cases = [CoCase(23, 196, 26, 512, "lm", 7, 0.5), CoCase(9, 49, 26, 512, "cm", 8, 0.5), CoCase(3, 100, 17, 1024, "lm", 9, 0.5),
          CoCase(160, 49, 26, 512, "lm", 10, (2.0 / 512) ** 0.5 * 4)]
 bf_case = CoCase(160, 49, 26, 2048, "lm", 11, (2.0 / 2048) ** 0.5 * 4, bf16=True)     # config 4's size, every 4th round
+# a busy chip, channel-major features: where round 4's race of the forward kernel's phase 1 showed (one launch in eight at
+# this size, one in seventy at B = 160) -- every 4th round
+big_cm_case = CoCase(640, 196, 26, 512, "cm", 12, (2.0 / 512) ** 0.5 * 4)
 OUT_NAMES = ["v0", "v1", "v2", "q0", "q1", "q2", "dV", "dQ0", "dQ1", "dQ2", "dW_v", "db_v", "dW_q", "db_q", "dw_v", "dc_v",
              "dw_q", "dc_q"]
 
@@ -242,7 +247,7 @@ for it in range(args.iters):
         report("gemm_bf_tn", it, dW, bt_ref, 2e-5, first.get("bt"))
         first.setdefault("bt", dW.clone())
     # fused co-attention forward + backward
-    for c in cases + ([bf_case] if it % 4 == 0 else []):
+    for c in cases + ([bf_case, big_cm_case] if it % 4 == 0 else []):
         outs = c.run()
         for nm, o, r in zip(OUT_NAMES, outs, c.ref):
             if o is None:                                            # (no dV in the frozen-encoder case)

@@ -69,8 +69,9 @@ extern "C" {
  *   - two FP16 pieces (hi + lo: 22 significand bits, three partial products on v_mfma_f32_32x32x16_f16, ~2^-22 relative) --
  *     the forward-side contractions, whose operands are features, projections and tanh values: the affinity A = Q V^T
  *     (model.py:377), the projections (model.py:380-384; the weight image holds 256 W, divided out), C^T P_q and C P_v.
- *     Range: exact pieces for |x| <= 65,504 (values below 2^-14 keep 2^-24 absolute); conversions saturate, so magnitudes
- *     up to 131,008 are still carried (with fewer bits) and larger ones clamp there -- finite for any finite input.
+ *     Range: exact pieces for |x| <= 65,504 (values below 2^-14 keep 2^-24 absolute; for the projection weights, whose
+ *     image is scaled, |W| <= 255); conversions saturate, so magnitudes up to 131,008 (weights: 511) are still carried
+ *     (with fewer bits) and larger ones clamp there -- finite for any finite input.
  * On the golden cases: v, q within 1e-6, attention maps within 4e-7, H_q within 2e-5, gradients within 1.5e-5 of max|.|
  * (the contract: 1e-4); tests/test_split_emulation.py has the budget row by row.
  * flags bit 4 (coattn_forward / coattn_backward): every contraction on three bf16 pieces (fp32's range throughout). */

@@ -2,7 +2,7 @@
 """Developer tool: coattn_forward + coattn_backward through the C-ABI, R times on the same inputs into fresh NaN-filled
 buffers; every region of `saved` and of the backward workspace is compared with the first run bit for bit -- names the first
 intermediate that is not repeatable (a race shows as a region that differs between runs).
-usage: tools/probe_repeat.py [B N T d layout repeats]"""
+usage: tools/probe_repeat.py [B N T d layout repeats [flags: fused|general|bf16|exact3 ...]]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,7 +20,11 @@ ps = [torch.randn(d, d, device=dev) / d ** 0.5, torch.randn(d, device=dev) * 0.1
       torch.randn(d, device=dev) * 0.1, torch.randn(1, d, device=dev) / d ** 0.5, torch.randn(1, device=dev),
       torch.randn(1, d, device=dev) / d ** 0.5, torch.randn(1, device=dev)]
 gv = torch.randn(L, B, d, device=dev); gq = torch.randn(L, B, d, device=dev)
-flag = _lib.IMPL_FUSED
+opts = sys.argv[7:]
+flag = _lib.IMPL_GENERAL if "general" in opts else _lib.IMPL_FUSED
+if "bf16" in opts: flag |= _lib.FLAG_BF16_PROJ
+if "exact3" in opts: flag |= _lib.FLAG_EXACT3
+need_dv = "dv" in opts
 sb, fb, bb = _lib.workspace_bytes(B, N, T, d, L, flag)
 al = lambda n: (n + 63) & ~63
 def regions(names_sizes):
@@ -33,7 +37,7 @@ WS = regions([("dsv", L*B*N), ("dsq", L*B*32), ("dPq", L*B*T*d), ("dPv", L*B*N*d
               ("dbv_part", L*B*d), ("dbq_part", L*B*d), ("dwq_part", L*B*d), ("dcs_part", L*B*2)])
 qptr = (C.c_void_p * L)(*[t.data_ptr() for t in Qs]); p = _lib.Params(*[t.data_ptr() for t in ps])
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-print("gpu uuid", getattr(torch.cuda.get_device_properties(0), "uuid", "?"), "B N T d", B, N, T, d, layout)
+print("gpu uuid", getattr(torch.cuda.get_device_properties(0), "uuid", "?"), "B N T d", B, N, T, d, layout, opts)
 ref = None
 nbad = 0
 for it in range(R):
@@ -44,13 +48,16 @@ for it in range(R):
     pg = _lib.ParamGrads(*[t.data_ptr() for t in grads]); dqptr = (C.c_void_p * L)(*[t.data_ptr() for t in dQs])
     _lib.check(lib.coattn_forward(Vbuf.data_ptr(), *vstr, qptr, C.byref(p), v.data_ptr(), q.data_ptr(), saved.data_ptr(),
                                   ws.data_ptr(), B, N, T, d, L, _lib.F32, flag, st), "fwd")
+    dV = torch.full_like(Vbuf, float("nan")) if need_dv else None
     _lib.check(lib.coattn_backward(Vbuf.data_ptr(), *vstr, qptr, C.byref(p), saved.data_ptr(), gv.data_ptr(), gq.data_ptr(),
-                                   None, *vstr, dqptr, C.byref(pg), 0, ws2.data_ptr(), B, N, T, d, L, _lib.F32, flag, st), "bwd")
+                                   dV.data_ptr() if need_dv else None, *vstr, dqptr, C.byref(pg), 0, ws2.data_ptr(), B, N, T, d, L, _lib.F32, flag, st), "bwd")
     torch.cuda.synchronize()
     cur = {"v": v, "q": q, "dQ": torch.stack(dQs)}
+    if need_dv: cur["dV"] = dV
     cur.update({"grad%d" % i: g for i, g in enumerate(grads)})
     cur.update({"saved." + n: saved[o:o + s] for n, (o, s) in SV.items()})
-    cur.update({"ws." + n: ws2[o:o + s] for n, (o, s) in WS.items() if n != "dsv"})
+    if flag & 3 == _lib.IMPL_FUSED and not (flag & _lib.FLAG_BF16_PROJ):      # (the fp32 fused backward's workspace layout)
+        cur.update({"ws." + n: ws2[o:o + s] for n, (o, s) in WS.items() if n != "dsv"})
     if ref is None:
         ref = {k: t.clone() for k, t in cur.items()}
         print("run 0: nonfinite per tensor:", {k: int((~torch.isfinite(t)).sum()) for k, t in cur.items() if (~torch.isfinite(t)).any()})

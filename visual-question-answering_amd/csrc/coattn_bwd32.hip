@@ -284,7 +284,8 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
     }
     // the next pass' operands fly under the tail and the epilogue (beyond the last pass: channel offsets >= d,
     // the values are never used)
-    load_pass(c0n, pq_raw, zq_frag);
+    // (three pieces: the registers are all taken across the tail -- the request waits until it is done)
+    if constexpr (NP != 3) load_pass(c0n, pq_raw, zq_frag);
     // the last unit's dZ_v: split, dP_q and dP_v contributions, dP_v out
     auto finish = [&](f32x16& dz) {
       const int lu = ntiles - 1;
@@ -314,6 +315,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
       case 2: finish(ring[2]); break;
       default: finish(ring[3]); break;
     }
+    if constexpr (NP == 3) load_pass(c0n, pq_raw, zq_frag);
     // epilogue: dP_q out; db_q = sum_t dP_q[t][:] (rows t >= T are exact zeros), dw_v, db_v partials of this
     // (sample, level): in-lane sums over the accumulator rows, then the two lane halves
     {

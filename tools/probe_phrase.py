@@ -23,12 +23,12 @@ for impl in ("hip", "stock"):
         x.grad = None
         mod(x).backward(g)
     for name, fn, fl in (("fwd", fwd, flop_fwd), ("fwd+bwd", fb, 3 * flop_fwd)):
-        for _ in range(5):
+        for _ in range(40):
             fn()
         torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(20):
+        for _ in range(100):
             fn()
         e1.record(); torch.cuda.synchronize()
-        t = e0.elapsed_time(e1) / 20
+        t = e0.elapsed_time(e1) / 100
         print("%-6s %-8s %8.3f ms  (%5.1f TFLOP/s on the %.1f GFLOP of live taps)" % (impl, name, t, fl / t / 1e9, fl / 1e9), flush=True)

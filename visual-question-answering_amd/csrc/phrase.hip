@@ -164,6 +164,20 @@ __global__ __launch_bounds__(256) void phrase_wsplit_kernel(const float* __restr
     const int cc = (trans ? k0 + e : n) % E, i = (trans ? n : k0 + e) % E;
     v[e] = g == 0 ? W1[(long)cc * E + i] : (g == 1 ? W2[((long)cc * E + i) * 2 + jb] : W3[((long)cc * E + i) * 3 + jb]);
   }
+  if (pieces == 16) {                                // two FP16 pieces of kF16WScale * W (fused.h), as gemm_w.hip's wsplit_kernel
+    f16_saturating_conversions();
+    u32x4 h, m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned hh, mm;
+      split_pair_h(v[2 * e] * kF16WScale, v[2 * e + 1] * kF16WScale, hh, mm);
+      h[e] = hh; m[e] = mm;
+    }
+    char* out = img + (size_t)chunk * gw::kChunkBytes + lane * 16;
+    *reinterpret_cast<u32x4*>(out) = h;
+    *reinterpret_cast<u32x4*>(out + gw::kFragBytes) = m;
+    return;
+  }
   bf16x8 pz[3];
   split3(v, pz);
   if (pieces == 1) {                                 // hi piece only, 1 KB chunks: the image gemm_bf.hip reads
@@ -278,6 +292,10 @@ extern "C" int coattn_phrase_forward(const void* X, const coattn_phrase_params* 
   wg.C = reinterpret_cast<float*>(w + pl.z); wg.c_sm = 3 * E; wg.bias_n = reinterpret_cast<const float*>(w + pl.bcat);
   wg.M = B * T; wg.N = 3 * E; wg.K = 3 * E; wg.batch = 1;
   wg.bf16 = bf16 ? 1 : 0;                                // reduced precision: one MFMA per product (gemm_bf.hip / gemm_w.hip)
+  // fp32 mode: the forward product Z = Xcat Wcat^T on two FP16 pieces per operand, as the co-attention's projections
+  // (fused.h; its operands are word features and conv weights) -- COATTN_FLAG_EXACT3 / COATTN_FWD_F16=0: the exact bf16 split
+  static const int f16_env = [] { const char* e = getenv("COATTN_FWD_F16"); return e ? atoi(e) : 1; }();
+  if (!bf16 && !(flags & COATTN_FLAG_EXACT3) && f16_env) { wg.np = 2; wg.f16 = 1; }
   if (E % 128 == 0) {                                    // (k bands first: the kernel and its weight-image format depend on them)
     wg.kband_n = E;
     wg.kband_lo[0] = E; wg.kband_hi[0] = 2 * E;
@@ -329,6 +347,11 @@ extern "C" int coattn_phrase_backward(const void* X, const coattn_phrase_params*
   wdx.A = dZ; wdx.a_sm = 3 * E; wdx.Wf = w + pl.wimg; wdx.C = reinterpret_cast<float*>(w + pl.xcat); wdx.c_sm = 3 * E;
   wdx.M = (int)bt; wdx.N = 3 * E; wdx.K = 3 * E; wdx.batch = 1;
   wdx.bf16 = bf16 ? 1 : 0;
+  // fp32 mode: the two gradient products (dXcat = dZ Wcat, dWcat = dZ^T Xcat) on two bf16 pieces per operand, as the
+  // co-attention's backward (fused.h "Widths": gradients keep bf16's range) -- COATTN_FLAG_EXACT3 / COATTN_SPLIT=3: three
+  static const int split_env = [] { const char* e = getenv("COATTN_SPLIT"); return e ? atoi(e) : 2; }();
+  const int np_b = (!bf16 && !(flags & COATTN_FLAG_EXACT3) && split_env != 3) ? 2 : 3;
+  wdx.np = np_b;
   if (E % 128 == 0) {                                    // tap block j of dXcat receives only the n-grams that have that tap
     wdx.kband_n = E;
     wdx.kband_lo[0] = E; wdx.kband_hi[0] = 3 * E;        // x[t-1]: bi, tri
@@ -355,6 +378,7 @@ extern "C" int coattn_phrase_backward(const void* X, const coattn_phrase_params*
   tn.mask_blk = E / 128;                             // rows: n-gram (uni, bi, tri); columns: tap x[t-1], x[t], x[t+1]
   tn.tile_mask = (1u << 1) | (3u << 3) | (7u << 6);
   tn.bf16 = bf16 ? 1 : 0;
+  tn.np = np_b;
   const bool tn_ok = hand_gemms() && E % 128 == 0 && gemm_tn_supported(tn);
   if (tn_ok && gemm_bf_tn_supported(tn)) {
     // reduced-precision mode at wide shapes: the single-product 256 x 256 kernel of gemm_bf.hip (same mask, same part layout)

@@ -4,7 +4,7 @@ for lib in base new; do
   if [ $lib = base ]; then export COATTN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/libcoattn_base.so; else unset COATTN_LIB_PATH; fi
   for N in 196 49; do
     find gpurun_out/abl -name "*_stats.csv" -delete 2>/dev/null
-    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abl -- python3 tools/probe_hot.py $N lm 200 > gpurun_out/abl.log 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/abl -- python3 tools/probe_hot.py $N ${LAYOUT:-lm} 200 > gpurun_out/abl.log 2>&1
     python3 - $lib $N <<'PY'
 import csv,glob,sys,re
 f=sorted(glob.glob("gpurun_out/abl/**/*kernel_stats.csv", recursive=True))[0]

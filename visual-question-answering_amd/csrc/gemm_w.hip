@@ -78,8 +78,11 @@ __global__ __launch_bounds__(256) void wsplit_kernel(const SplitArgs a) {
 // Up to two independent GEMMs per launch (P_v and P_q of the forward): the second one's workgroups fill the slots
 // the first one's last, partial round of workgroups would leave idle.  AM0: layout of job 0's A operand; NP / NP1: the
 // widths of job 0 / job 1 (the forward runs P_v on three pieces and P_q on two in one launch).
+#ifndef GEMMW_OCC2           // workgroups per CU of the two-piece four-wave kernels (gemm_w_body.h: two-set B ring)
+#define GEMMW_OCC2 3
+#endif
 template <bool AM0, int NP, int NW = 4, int NP1 = NP, bool H = false>
-__global__ __launch_bounds__(64 * NW, 2) void gemm_w_kernel(const WJobs jobs) {
+__global__ __launch_bounds__(64 * NW, (NP == 2 && NP1 == 2 && NW == 4) ? GEMMW_OCC2 : 2) void gemm_w_kernel(const WJobs jobs) {
   __shared__ __attribute__((aligned(16))) short smem[2 * (NP > NP1 ? NP : NP1) * BM * LDR];  // three pieces: 61,440 B; two workgroups of 256 threads per CU
   static_assert(BM * LDR == BK * LDT, "both image layouts have the same size");
   if (H) f16_saturating_conversions();

@@ -133,7 +133,17 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
   //                after it the A fragments of the next step's first half are read
   //   A fragments: af[h] for half h; those of half 1 are read during half 0
   f32x4 raw[AP];
-  bf16x8 bq[3][2][3];                            // [ring][tile j][piece]
+  // B ring: three half-step register sets (loads two half steps ahead).  The two-piece four-wave kernels keep two sets
+  // (one half step ahead): with the 16 registers that frees they fit THREE workgroups on a CU (<= 170 VGPRs, 3 x 40 KB of
+  // LDS), and a third wave per SIMD hides more than the deeper ring did -- the forward's projection launch 91.2 -> 84.3 us at
+  // N = 196 (1,376 tiles: 1.8 rounds instead of 2.7), 46.3 -> 42.3 at N = 49 (644 tiles: one round instead of 1.26).
+  // -DGEMMW_RB3 (developer switch, with -DGEMMW_OCC2=2): the three-set ring at two workgroups per CU.
+#ifdef GEMMW_RB3
+  constexpr int RB = 3;
+#else
+  constexpr int RB = (NP == 2 && NW == 4) ? 2 : 3;
+#endif
+  bf16x8 bq[RB][2][3];                           // [ring][tile j][piece]
   bf16x8 af[2][3][2];                            // [half][piece][tile i]
   unsigned ph[2], pm[2], pl[2];                  // packed pieces of the raw[i] being split (its two pairs)
   float ra[2], rb[2];
@@ -220,7 +230,7 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
       if (n < 4) acc[i][j][0] += __builtin_bit_cast(float, (int)af[HH][PA[t]][i][0] ^ (int)bq[BU][j][PB[t]][0]);
 #endif
 #ifndef GEMMW_NOB
-      if (n < 6) load_b(BL, n, 2 * s + HH + 2);
+      if (n < 6) load_b(BL, n, 2 * s + HH + RB - 1);
 #endif
       if (HH == 0) {
         if (n < 6) read_a(cur, 1, n);
@@ -249,7 +259,7 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
 #pragma unroll
   for (int i = 0; i < AP; ++i) load_a(i, 0);
 #pragma unroll
-  for (int k = 0; k < 6; ++k) { load_b(0, k, 0); load_b(1, k, 1); }
+  for (int k = 0; k < 6; ++k) { load_b(0, k, 0); if (RB == 3) load_b(1, k, 1); }
   short* const img0 = smem;
   short* const img1 = smem + NP * IMG;               // (only the pieces of the width are staged)
 #pragma unroll
@@ -275,14 +285,18 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
     half(I1{}, U1, U0, s, cur, nxt);
   };
   int s = 0;
-  for (; s + 3 <= KS; s += 3) {                            // (one loop exit: the accumulators stay in place)
-    step(I0{}, I1{}, I2{}, s);
-    step(I2{}, I0{}, I1{}, s + 1);
-    step(I1{}, I2{}, I0{}, s + 2);
-  }
-  if (s < KS) {
-    step(I0{}, I1{}, I2{}, s);
-    if (s + 1 < KS) step(I2{}, I0{}, I1{}, s + 1);
+  if constexpr (RB == 3) {
+    for (; s + 3 <= KS; s += 3) {                          // (one loop exit: the accumulators stay in place)
+      step(I0{}, I1{}, I2{}, s);
+      step(I2{}, I0{}, I1{}, s + 1);
+      step(I1{}, I2{}, I0{}, s + 2);
+    }
+    if (s < KS) {
+      step(I0{}, I1{}, I2{}, s);
+      if (s + 1 < KS) step(I2{}, I0{}, I1{}, s + 1);
+    }
+  } else {                                                 // two sets: half 0 uses set 0 and loads set 1, half 1 the reverse
+    for (; s < KS; ++s) step(I0{}, I1{}, I1{}, s);
   }
 
   float* Cb = g.c_ptrs[0] ? g.c_ptrs[z & 7] : g.C + (long)z * g.c_sz;

@@ -378,7 +378,8 @@ def backward_legs(device, B=160, N=196, T=26, d=512, L=3, iters=60, layout="lm",
       bwd_pre    V once per pair (da_v for the three levels) + per level Q read
       bwd_dc32   P_v, P_q, H_q, C read, dA written            (dZ_q is formed from H_q where it is used, never stored)
       bwd_nat32  P_v, P_q, H_q, C read, dP_v, dP_q written
-      bwd_dq     V, dA read, dQ read and written
+      bwd_dq     V, dA read, dQ read and written; + the weight gradients' split-K partials read and their sums written (the
+                 reduction rides in this launch)
       bwd_gemm   MFMA-bound: 2 (B N d^2 + 2 L B T d^2) flops (dW_v, dW_q, dQ = dP_q W_q) against the dense bf16 peak /
                  partial products per fp32 product (3 at the two-piece width, 6 at the exact split); its HBM bytes beside
     against 8 TB/s."""
@@ -409,6 +410,8 @@ def backward_legs(device, B=160, N=196, T=26, d=512, L=3, iters=60, layout="lm",
     }
     alg = {k: B * L * b for k, b in per_level.items()}
     alg["bwd_pre"] = B * f4 * (N * d + L * T * d)
+    if not bf16:                                       # the 32 split-K partials of dW_v, dW_q read, the two sums written
+        alg["bwd_dq"] += (32 + 2) * d * d * f4
     # kernels behind a mark (the names rocprofv3 shows): for matching against profiles/*_kernel_stats.csv
     kernels = {"bwd_pre": "bwd_pre_kernel", "bwd_dc32": "bwd_dc32_kernel", "bwd_nat32": "bwd_nat32_kernel",
                "bwd_dq": "bwd_dq32x_kernel" if N <= 64 else "bwd_dq32_kernel",

@@ -428,8 +428,9 @@ def test_profile_marks_of_forward_and_backward():
                    "coattn_backward")
         n = lib.coattn_profile_end(us, names, 1024, 48)
     marks = names.value.decode().split("\n")
-    assert n == len(marks) and n >= 8, (n, marks)
-    assert marks[:3] == ["wsplit", "projections", "coattn_fwd32"] and "bwd_nat32" in marks and marks[-1] == "reduce_partials"
+    assert n == len(marks) and n >= 7, (n, marks)
+    # (the partial sums of the weight gradients ride in the dQ kernel's launch: bwd_dq is the last mark)
+    assert marks[:3] == ["wsplit", "projections", "coattn_fwd32"] and "bwd_nat32" in marks and marks[-1] == "bwd_dq"
     assert all(us[i] > 0 for i in range(n)) and sum(us[i] for i in range(n)) < 5e4
     assert torch.isfinite(v).all() and all(torch.isfinite(t).all() for t in grads)
 

@@ -551,6 +551,10 @@ __global__ __launch_bounds__(256) void bwd_dq32_kernel(const DqArgs a) {
   float* aqs = reinterpret_cast<float*>(smem + 3 * PIECE * 2 + 4 * LDR * 2);
   // blocks i and i + 8 share an XCD (round-robin dispatch): the L levels of one (sample, channel slice) take
   // consecutive slots of one XCD, so that V comes from HBM once and from that XCD's L2 for the other levels
+  {
+    const int main_blocks = ((a.B * (a.d / 128) + 7) / 8) * a.L * 8;
+    if ((int)blockIdx.x >= main_blocks) { reduce_partials4_block(a, (int)blockIdx.x - main_blocks); return; }
+  }
   int item, l;
   if (!block_to_pair(blockIdx.x, a.B * (a.d / 128), a.L, item, l)) return;
   const int nslice = a.d / 128, b = item / nslice, slice = item - b * nslice;
@@ -658,6 +662,7 @@ __global__ __launch_bounds__(256) void bwd_dq32x_kernel(const DqArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   short* img = reinterpret_cast<short*>(smem);
   float* aqs = reinterpret_cast<float*>(smem + ML * LEVEL * 2);
+  if ((int)blockIdx.x >= a.B * (a.d / 128)) { reduce_partials4_block(a, (int)blockIdx.x - a.B * (a.d / 128)); return; }
   const int nslice = a.d / 128, item = blockIdx.x, b = item / nslice, slice = item - b * nslice;
   const int N = a.N, T = a.T, d = a.d, L = a.L;
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -755,7 +760,7 @@ template <int NT, bool LM, int NP>
 int launch_dq32x(const DqArgs& a, hipStream_t s) {
   constexpr int NPAD = 32 * NT;
   const size_t lds = (size_t)3 * ((3 * kTRows + 4) * (NPAD + 8) * 2) + 3 * 32 * 4;
-  hipLaunchKernelGGL((bwd_dq32x_kernel<NT, LM, NP>), dim3(a.B * (a.d / 128)), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((bwd_dq32x_kernel<NT, LM, NP>), dim3(a.B * (a.d / 128) + a.red_jobs * a.red_blocks), dim3(256), lds, s, a);
   CA_CHECK_LAUNCH("bwd_dq32x");
   return 0;
 }
@@ -765,7 +770,7 @@ int launch_dq32(const DqArgs& a, hipStream_t s) {
   constexpr int NPAD = 32 * NT;
   const size_t lds = (size_t)(3 * kTRows + 4) * (NPAD + 8) * 2 + 32 * 4;   // + 4 rows: what lanes 28 .. 31 of the last piece read
   const int items = a.B * (a.d / 128);
-  hipLaunchKernelGGL((bwd_dq32_kernel<NT, LM, NP>), dim3(((items + 7) / 8) * a.L * 8), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((bwd_dq32_kernel<NT, LM, NP>), dim3(((items + 7) / 8) * a.L * 8 + a.red_jobs * a.red_blocks), dim3(256), lds, s, a);
   CA_CHECK_LAUNCH("bwd_dq32");
   return 0;
 }

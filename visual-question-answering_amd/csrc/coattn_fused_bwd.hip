@@ -396,9 +396,16 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     CA_TRY(dq_projection(false));
     prof_mark(s, "bwd_gemm_dq_projection");
   }
+  // (red: the two weight gradients' partial sums, handed to the dQ kernel's launch when it is the bf16-MFMA one)
+  struct RedJob { const float* part[2]; float* out[2]; int np[2]; long n; int acc; bool on; } red = {};
+  static const int red_in_dq = [] { const char* e = getenv("COATTN_RED_IN_DQ"); return e ? atoi(e) : 1; }();   // developer switch
   auto run_dq = [&]() -> int {
-    DqArgs da;
+    DqArgs da = {};
     da.accumulate = dq32 ? 1 : 0;
+    if (red.on && dq32) {
+      for (int i = 0; i < 2; ++i) { da.red_part[i] = red.part[i]; da.red_out[i] = red.out[i]; da.red_np[i] = red.np[i]; }
+      da.red_n = red.n; da.red_acc = red.acc; da.red_jobs = 2; da.red_blocks = (int)((red.n / 4 + 255) / 256);
+    }
     da.V = V; da.v_sB = vl.sB; da.dA = ws + wo.dA; da.aq = saved + so.aq; da.gq = gq;
     for (int l = 0; l < 8; ++l) da.dQ[l] = l < L ? dQ[l] : nullptr;
     da.B = B; da.N = N; da.T = T; da.d = d; da.L = L;
@@ -515,6 +522,13 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     if (wide) CA_TRY(launch_gemm_tn_wide(both, ks, S, 2, s, &small, combine ? &wdq : nullptr));
     else CA_TRY(launch_gemm_tn(both, ks, S, 2, s, &small, combine ? &wdq : nullptr));
     prof_mark(s, combine ? "bwd_gemm" : "bwd_gemm_dw");
+    const bool red_al = (((int64_t)d * d) & 3) == 0 && ((((uintptr_t)part) | ((uintptr_t)pg->dW_v) | ((uintptr_t)tnq.C) | ((uintptr_t)pg->dW_q)) & 15) == 0;
+    if (combine && dq32 && red_in_dq && red_al) {       // the partial sums ride in the dQ kernel's launch
+      red.part[0] = part; red.out[0] = (float*)pg->dW_v; red.np[0] = parts_v;
+      red.part[1] = tnq.C; red.out[1] = (float*)pg->dW_q; red.np[1] = parts_q;
+      red.n = (long)d * d; red.acc = accumulate; red.on = true;
+      return run_dq();
+    }
     if (combine) CA_TRY(run_dq());
     CA_TRY(launch_reduce_partials2(part, (float*)pg->dW_v, parts_v, tnq.C, (float*)pg->dW_q, parts_q, (int64_t)d * d,
                                    accumulate, s));

@@ -414,7 +414,31 @@ struct DqArgs {
   int accumulate;        // bwd_dq32_kernel: add onto dQ (which then already holds dP_q W_q) instead of overwriting it
   int bf16;              // reduced-precision mode: one MFMA per product
   int np;                // (bf16 = 0) width of the contraction: 3 or 2 pieces
+  // bwd_dq32(x)_kernel: the sum of the weight gradients' split-K partials rides along as the launch's last workgroups
+  // (red_blocks of them per job, red_jobs jobs: out[j] (+)= sum_c part[c][j], four floats per thread) -- nothing of it
+  // depends on dQ, and a launch of its own cost a launch gap and 7 us during which nothing else ran
+  const float* red_part[2]; float* red_out[2]; int red_np[2]; long red_n; int red_acc, red_blocks, red_jobs;
 };
+__device__ __forceinline__ void reduce_partials4_block(const DqArgs& a, int id) {   // (as small_kernels.hip reduce_partials4_kernel)
+  const int job = id / a.red_blocks, bx = id - job * a.red_blocks;
+  const float* part = a.red_part[job];
+  float* out = a.red_out[job];
+  const int nparts = a.red_np[job];
+  const long n = a.red_n, j = ((long)bx * 256 + threadIdx.x) * 4;
+  if (j >= n) return;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  int c = 0;
+  for (; c + 8 <= nparts; c += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(part + (long)(c + u) * n + j);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  for (; c < nparts; ++c) acc += *reinterpret_cast<const f32x4*>(part + (long)c * n + j);
+  f32x4* o = reinterpret_cast<f32x4*>(out + j);
+  *o = a.red_acc ? *o + acc : acc;
+}
 // dQ_l = a_q (x) gq + dA_l V on the bf16 MFMA with the exact 3-way split: location-major V (lm), or channel-major V
 // whose rows are 16-byte multiples (N % 4 == 0)
 int launch_bwd_dq32(const DqArgs& a, int lm, hipStream_t s);

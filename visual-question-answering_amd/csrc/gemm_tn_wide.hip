@@ -24,8 +24,8 @@
 // 40 KB per step (512-byte and 1-KB row segments of 2-KB rows) come back, not their latency and not the issue slots.
 // Neither form was kept.
 //
-// Shapes: M % 128 == 0, N % 256 == 0, both operands row-major over the contraction rows (the channel-major B operand and
-// the masked phrase-level products stay on gemm_tn.hip).
+// Shapes: M % 128 == 0, N % 256 == 0; B row-major over the contraction rows, or (first job, BCM) contiguous along them in
+// groups -- channel-major image features; the masked phrase-level products stay on gemm_tn.hip.
 #include "common.h"
 #include "fused.h"
 #include "gemm_w_body.h"
@@ -44,10 +44,12 @@ namespace {
 constexpr int BM = 128, BN = 256, BK = 16, NTHR = 512;
 constexpr int LDTA = BM + 32, LDTB = BN + 32;      // [k][col] image row strides (elements): conflict-free writes + transposed reads
 constexpr int IMGA = BK * LDTA, IMGB = BK * LDTB;  // one piece image of each operand
+constexpr int LDRB = 24, IMGBC = BN * LDRB;        // BCM: the B image is [column][k] (16 k + 8 pad), one ds_read_b128 per fragment
 
 struct TwArgs {
   const float* A; long a_sl; int a_ld; long a_term;
   const float* B; const float* b_ptrs[8]; long b_sl; int b_ld;
+  int b_kdiv; long b_sdiv; unsigned b_bytes;     // BCM (gemm_tn.hip): k = (group, row inside the group of b_kdiv rows)
   float* C;
   int M, N, K, ksplit, S;
 };
@@ -58,10 +60,12 @@ struct TwJobs {
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-template <bool SUM3, int NP>
+// BCM: the B operand is contiguous along k inside groups of b_kdiv rows (channel-major image features [B, d, N]: k =
+// (sample, location), n = channel), as in gemm_tn.hip: float4 = 4 consecutive k of one column, [column][k] images.
+template <bool SUM3, int NP, bool BCM = false>
 __device__ __forceinline__ void gemm_tn_wide_body(const TwArgs& g, const int bid, const int nblk, short* const lds) {
   static_assert(NP == 2 || NP == 3, "pieces per operand");
-  constexpr int OPERA = NP * IMGA, OPERB = NP * IMGB, BUF = OPERA + OPERB;
+  constexpr int OPERA = NP * IMGA, OPERB = NP * (BCM ? IMGBC : IMGB), BUF = OPERA + OPERB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3, li = lane & 31, lh = lane >> 5;
   // XCD-run order (gemm_tn.hip): the tiles of a part share an XCD's L2
@@ -77,7 +81,7 @@ __device__ __forceinline__ void gemm_tn_wide_body(const TwArgs& g, const int bid
   const float* Bb = g.b_ptrs[0] ? g.b_ptrs[lvl & 7] : g.B + (long)lvl * g.b_sl;
   // rows past K read 0 (resource bound); rows past kend belong to the next part: ksplit % 16 == 0, so a step never straddles
   const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(Ab, (unsigned)((long)g.K * g.a_ld * 4));
-  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(Bb, (unsigned)((long)g.K * g.b_ld * 4));
+  const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(Bb, BCM ? g.b_bytes : (unsigned)((long)g.K * g.b_ld * 4));
   const unsigned tbytes = (SUM3 && g.a_term) ? (unsigned)((long)g.K * g.a_ld * 4) : 0u;
   const __amdgpu_buffer_rsrc_t rs_a1 = make_rsrc(Ab + (SUM3 ? g.a_term : 0), tbytes);
   const __amdgpu_buffer_rsrc_t rs_a2 = make_rsrc(Ab + (SUM3 ? 2 * g.a_term : 0), tbytes);
@@ -90,7 +94,18 @@ __device__ __forceinline__ void gemm_tn_wide_body(const TwArgs& g, const int bid
   // transposed fragment read: each 16-lane group fetches a 4 (k) x 16 (rows) block; lane 4q+p of the group supplies
   // the address of block row q, columns 4p..4p+3, and receives the 4 k of row (lane & 15)
   const int trq = 8 * lh + ((lane & 15) >> 2), trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-  const int a_rd = trq * LDTA + trc + wr * 64, b_rd = OPERA + trq * LDTB + trc + wc * 64;
+  const int a_rd = trq * LDTA + trc + wr * 64;
+  const int b_rd = BCM ? OPERA + (wc * 64 + li) * LDRB + 8 * lh : OPERA + trq * LDTB + trc + wc * 64;
+  // BCM staging: 4 lanes cover the 16 k (64 B) of one column, 128 columns per load of the workgroup; the second float4
+  // is column + 128.  The (group, row) position of the thread's 4-k group is tracked step by step (no division in the loop).
+  const int bc_col = tid >> 2, bc_kq = tid & 3;
+  int bc_n = 0, bc_voff = 0;
+  if (BCM) {
+    const int kg = kbeg + 4 * bc_kq;
+    bc_n = kg % g.b_kdiv;
+    bc_voff = (int)(((long)(kg / g.b_kdiv) * g.b_sdiv + bc_n + (long)(n0 + bc_col) * g.b_ld) * 4);
+  }
+  const int bc_st = OPERA + bc_col * LDRB + 4 * bc_kq;                     // + 128 * LDRB for the second float4
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -114,6 +129,12 @@ __device__ __forceinline__ void gemm_tn_wide_body(const TwArgs& g, const int bid
       if (SUM3) {
         rawt[0] = buf_load4(rs_a1, a_voff + s * a_step, 0);
         rawt[1] = buf_load4(rs_a2, a_voff + s * a_step, 0);
+      }
+    } else if (BCM) {
+      raw[x] = buf_load4(rs_b, bc_voff + (x - 1) * 128 * g.b_ld * 4, 0);
+      if (x == 2) {                              // both column halves of this step requested: on to the next 16 k
+        bc_n += BK; bc_voff += BK * 4;
+        if (bc_n >= g.b_kdiv) { bc_n -= g.b_kdiv; bc_voff += (int)((g.b_sdiv - g.b_kdiv) * 4); }
       }
     } else raw[x] = buf_load4(rs_b, b_voff + (x - 1) * b_half + s * b_step, 0);
   };
@@ -144,6 +165,7 @@ __device__ __forceinline__ void gemm_tn_wide_body(const TwArgs& g, const int bid
     if ((GEMMTNW_KO & 8) && buf != lds) return;      // (the prologue's image is still written)
     const u32x2 v = q == 0 ? u32x2{ph[0], ph[1]} : (q == 1 ? u32x2{pm[0], pm[1]} : u32x2{pl[0], pl[1]});
     if (x == 0) *reinterpret_cast<u32x2*>(&buf[q * IMGA + sta]) = v;
+    else if (BCM) *reinterpret_cast<u32x2*>(&buf[q * IMGBC + (x - 1) * 128 * LDRB + bc_st]) = v;
     else *reinterpret_cast<u32x2*>(&buf[q * IMGB + (x - 1) * 8 * LDTB + stb]) = v;
   };
   // fragment reads in the order of first use: a2, b0, a0, b2, a1, b1 (tile 0, tile 1; lo, hi): r = 0..23
@@ -153,6 +175,14 @@ __device__ __forceinline__ void gemm_tn_wide_body(const TwArgs& g, const int bid
     const int grp = r >> 2, isb = grp & 1, q = isb ? QB[grp >> 1] : QA[grp >> 1], tile = (r >> 1) & 1, hi = r & 1;
     if (q >= NP) return;
     if ((GEMMTNW_KO & 16) && buf != lds) return;
+    if (BCM && isb) {                            // one 16-byte read per fragment (issued with its first half)
+      if (hi == 0) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(buf + q * IMGBC + b_rd + tile * 32 * LDRB);
+        fb[SET][q][tile][0] = bf16x4{v[0], v[1], v[2], v[3]};
+        fb[SET][q][tile][1] = bf16x4{v[4], v[5], v[6], v[7]};
+      }
+      return;
+    }
     if (isb) fb[SET][q][tile][hi] = lds_tr16(buf + q * IMGB + b_rd + tile * 32 + hi * 4 * LDTB);
     else fa[SET][q][tile][hi] = lds_tr16(buf + q * IMGA + a_rd + tile * 32 + hi * 4 * LDTA);
   };
@@ -232,7 +262,7 @@ __device__ __forceinline__ void gemm_tn_wide_body(const TwArgs& g, const int bid
 }
 
 // [small reductions][job 0 parts][job 1 parts][tiles of the dQ projection on gemm_w_body<.., 8>]
-template <bool SUM3, int NP>
+template <bool SUM3, int NP, bool BCM = false>
 __global__ __launch_bounds__(NTHR, 2) void gemm_tn_wide_kernel(const TwJobs jobs) {
   extern __shared__ __attribute__((aligned(16))) short lds_dyn[];
   const int id = (int)blockIdx.x - jobs.nred, ngemm = (int)gridDim.x - jobs.nred - jobs.nw;
@@ -245,7 +275,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_tn_wide_kernel(const TwJobs jobs
                       (int)blockIdx.x / jobs.red_bx, reinterpret_cast<float(*)[64]>(lds_dyn), threadIdx.x < 256);
     return;
   }
-  if (id < jobs.first1) gemm_tn_wide_body<SUM3, NP>(jobs.job[0], id, jobs.first1, lds_dyn);
+  if (id < jobs.first1) gemm_tn_wide_body<SUM3, NP, BCM>(jobs.job[0], id, jobs.first1, lds_dyn);
   else gemm_tn_wide_body<false, NP>(jobs.job[1], id - jobs.first1, ngemm - jobs.first1, lds_dyn);
 }
 
@@ -253,7 +283,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_tn_wide_kernel(const TwJobs jobs
 
 int gemm_tn_wide_supported(const TnGemm& d) {
   static const int on = [] { const char* e = getenv("COATTN_TN_WIDE"); return e ? atoi(e) : 1; }();   // developer switch
-  return on && gemm_tn_supported(d) && !d.bf16 && d.np == 2 && !d.b_kdiv && d.mask_blk == 0 && (d.M % BM) == 0 && (d.N % BN) == 0;
+  return on && gemm_tn_supported(d) && !d.bf16 && d.np == 2 && d.mask_blk == 0 && (d.M % BM) == 0 && (d.N % BN) == 0;
 }
 
 // split-K plan for `max_parts` parts (32 parts x 8 tiles of 128 x 256 = one workgroup per CU at d = 512)
@@ -294,22 +324,34 @@ int launch_gemm_tn_wide(const TnGemm* d, const int* ksplit, const int* S, int n,
     CA_CHECK_ARG(gemm_tn_wide_supported(d[i]), "gemm_tn_wide: unsupported shape M=%d N=%d K=%d", d[i].M, d[i].N, d[i].K);
     CA_CHECK_ARG(d[i].A && (d[i].B || d[i].b_ptrs[0]) && d[i].C && ksplit[i] > 0 && (ksplit[i] % BK) == 0 && (long)S[i] * ksplit[i] >= d[i].K,
                  "gemm_tn_wide: bad arguments");
-    CA_CHECK_ARG(i == 0 || d[i].a_term == 0, "gemm_tn_wide: only the first job may sum three A terms");
+    CA_CHECK_ARG(i == 0 || (d[i].a_term == 0 && d[i].b_kdiv == 0), "gemm_tn_wide: only the first job may sum three A terms or have a k-contiguous B");
     TwArgs& g = jobs.job[i];
     g = TwArgs{};
     g.A = d[i].A; g.a_sl = d[i].a_sl; g.a_ld = d[i].a_ld; g.a_term = d[i].a_term;
     g.B = d[i].B; g.b_sl = d[i].b_sl; g.b_ld = d[i].b_ld;
+    g.b_kdiv = d[i].b_kdiv; g.b_sdiv = d[i].b_sdiv; g.b_bytes = d[i].b_kdiv ? (unsigned)((long)(d[i].K / d[i].b_kdiv) * d[i].b_sdiv * 4) : 0u;
     for (int t = 0; t < 8; ++t) g.b_ptrs[t] = d[i].b_ptrs[t];
     g.C = d[i].C; g.M = d[i].M; g.N = d[i].N; g.K = d[i].K; g.ksplit = ksplit[i]; g.S = S[i];
     nb[i] = (long)(d[i].M / BM) * (d[i].N / BN) * d[i].levels * S[i];
   }
   CA_CHECK_ARG(nb[0] + nb[1] < 2147483647L, "gemm_tn_wide: grid too large");
   jobs.first1 = (int)nb[0];
-  const bool sum3 = d[0].a_term != 0;
+  const bool sum3 = d[0].a_term != 0, bcm = d[0].b_kdiv != 0;
   const dim3 grid((unsigned)(jobs.nred + nb[0] + nb[1] + jobs.nw));
-  size_t lds = (size_t)2 * 2 * (IMGA + IMGB) * sizeof(short);              // two buffers of two pieces: 57,344 B
+  // two buffers of two pieces: 57,344 B; with the [column][k] image of a BCM first job 69,632 B (above the 64 KB default)
+  size_t lds = (size_t)2 * 2 * (IMGA + (bcm ? IMGBC : IMGB)) * sizeof(short);
   if (wextra && lds < (size_t)2 * 2 * gw::BM * gw::LDR * sizeof(short)) lds = (size_t)2 * 2 * gw::BM * gw::LDR * sizeof(short);
-  if (sum3) hipLaunchKernelGGL((gemm_tn_wide_kernel<true, 2>), grid, dim3(NTHR), lds, s, jobs);
+  if (bcm) {
+    static DeviceOnce once;
+    CA_TRY(once.run([&] {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_wide_kernel<true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_wide_kernel<false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      return e;
+    }, "gemm_tn_wide"));
+  }
+  if (sum3 && bcm) hipLaunchKernelGGL((gemm_tn_wide_kernel<true, 2, true>), grid, dim3(NTHR), lds, s, jobs);
+  else if (bcm) hipLaunchKernelGGL((gemm_tn_wide_kernel<false, 2, true>), grid, dim3(NTHR), lds, s, jobs);
+  else if (sum3) hipLaunchKernelGGL((gemm_tn_wide_kernel<true, 2>), grid, dim3(NTHR), lds, s, jobs);
   else hipLaunchKernelGGL((gemm_tn_wide_kernel<false, 2>), grid, dim3(NTHR), lds, s, jobs);
   CA_CHECK_LAUNCH("gemm_tn_wide");
   return 0;

@@ -131,8 +131,13 @@ def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20, b
     """Isolated hot path (co-attention + MLPClassifier + CE, fwd+bwd) on resident features.
     layout: "lm" = x_img contiguous [B,N,d] (what the channels_last encoder of the train step hands over),
     "cm" = the permuted view of a channel-major [B,d,N] buffer (the reference's NCHW encoder, model.py:215-217)."""
+    import gc
     import vqa_amd
     from vqa_amd.modules import MLPClassifier
+    # (the previous leg's captured graphs and their memory pools die in a garbage-collection pass -- reference cycles through
+    #  the autograd nodes -- and destroying them takes milliseconds: not inside this leg's timed loops)
+    gc.collect()
+    torch.cuda.synchronize()
     torch.manual_seed(0)
     co = vqa_amd.ParallelCoAttention(d).to(device)
     co.bf16_projections = bf16                       # the reduced-precision mode of --opt_lvl >= 1 (config 4)

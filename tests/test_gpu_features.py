@@ -62,7 +62,15 @@ def test_native_features_helper():
     lm = torch.randn(2, 49, 512, device=DEV)
     assert native_features(lm) is lm                                      # fp32 location-major: where it lies
     cm196 = torch.randn(2, 512, 196, device=DEV).permute(0, 2, 1)
-    assert native_features(cm196) is cm196                                # channel-major, 16-byte rows: where it lies
+    y = native_features(cm196)                                            # frozen channel-major features: converted (faster kernels)
+    assert y.is_contiguous() and torch.equal(y, cm196.contiguous())
+    import sys
+    ca = sys.modules["vqa_amd.coattention"]                               # (the package attribute of that name is the function)
+    old, ca.CM_FEATURES = ca.CM_FEATURES, "inplace"
+    try:
+        assert native_features(cm196) is cm196                            # ... or read where they lie (16-byte rows)
+    finally:
+        ca.CM_FEATURES = old
     cm49 = torch.randn(2, 512, 49, device=DEV).permute(0, 2, 1)
     y = native_features(cm49)
     assert y.is_contiguous() and torch.equal(y, cm49.contiguous())

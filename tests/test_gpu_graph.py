@@ -109,10 +109,14 @@ def test_trainer_graph_mode_matches_eager_training():
         assert abs(a - b) <= 1e-5 * abs(a)
 
 
-def test_channel_major_features_are_captured_in_place():
+def test_channel_major_features_are_captured_in_place(monkeypatch):
     """The reference's layout -- x_img = the permuted view of a [B,d,N] buffer (model.py:215-217) -- is read where it
-    lies through the C-ABI's strides (no copy into the static input), bit for bit the eager module path."""
+    lies through the C-ABI's strides (no copy into the static input), bit for bit the eager module path.  (With
+    VQA_CM_FEATURES=inplace: by default the host converts frozen channel-major features, the next test.)"""
     from vqa_amd.graph import HotPathGraph
+    import sys
+    ca = sys.modules["vqa_amd.coattention"]                   # (the package attribute of that name is the function)
+    monkeypatch.setattr(ca, "CM_FEATURES", "inplace")
     B, N, T, d, mlp, K = 16, 196, 26, 512, 256, 37
     co, head = _modules(d, mlp, K, seed=5)
     buf = torch.randn(B, d, N, device="cuda").clamp_min_(0)
@@ -133,6 +137,33 @@ def test_channel_major_features_are_captured_in_place():
     assert torch.equal(loss2, loss.detach())
     for a, b in zip(ref, [q.grad for q in Qs] + [p.grad for p in params if p.grad is not None]):
         assert torch.equal(a, b)
+
+
+def test_frozen_channel_major_features_are_converted_by_default():
+    """Frozen channel-major features go through the library's one-pass conversion into the node's static input and run on
+    the location-major kernels (faster by more than the pass costs): bit for bit the run on location-major features."""
+    from vqa_amd.graph import HotPathGraph
+    B, N, T, d, mlp, K = 16, 196, 26, 512, 256, 37
+    co, head = _modules(d, mlp, K, seed=6)
+    buf = torch.randn(B, d, N, device="cuda").clamp_min_(0)
+    lab = torch.arange(B, device="cuda") % K
+    params = list(co.parameters()) + list(head.parameters())
+    out = []
+    for x in (buf.permute(0, 2, 1), buf.permute(0, 2, 1).contiguous()):
+        for p in params:
+            p.grad = None
+        Qs = [(torch.randn(B, T, d, device="cuda", generator=torch.Generator("cuda").manual_seed(3 + l)) * 0.2).requires_grad_(True)
+              for l in range(3)]
+        hp = HotPathGraph(co, head, B, N, T, capture=False)
+        _, loss = hp(x, Qs, lab)
+        loss.backward()
+        out.append([loss.detach().clone()] + [q.grad.clone() for q in Qs] + [p.grad.clone() for p in params if p.grad is not None])
+        if x.stride(2) != 1:
+            assert torch.equal(hp.V, x.contiguous())
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    _, qs = co(buf.permute(0, 2, 1), [torch.zeros(B, T, d, device="cuda") for _ in range(3)])   # the module path converts too
+    assert all(torch.isfinite(t).all() for t in qs)
 
 
 def test_graph_path_label_checks():

@@ -28,13 +28,20 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-def _is_native(x_img: torch.Tensor) -> bool:
+def _is_native(x_img: torch.Tensor, lm_only: bool = False) -> bool:
     B, N, d = x_img.shape
     sB, sN, sD = _strides(x_img)
     ext = (N - 1) * sN + (d - 1) * sD
     lm = sD == 1 and sN == d
-    cm = sN == 1 and sD == N and N % 4 == 0
+    cm = sN == 1 and sD == N and N % 4 == 0 and not lm_only
     return bool((lm or cm) and sB > ext and x_img.data_ptr() % 16 == 0)
+
+
+# Frozen channel-major features (the reference's NCHW view at N = 196): the kernels read them in place through the C-ABI's
+# strides, but the location-major kernels are faster by more than the library's one-pass conversion costs (cfg 2, N = 196: the
+# isolated hot path 0.71 ms in place, 0.64 location-major, the conversion 28 us) -- so the host converts.  "inplace" keeps
+# them where they lie (VQA_CM_FEATURES=inplace, or set this attribute).
+CM_FEATURES = os.environ.get("VQA_CM_FEATURES", "convert")
 
 
 def _native_layout(x_img: torch.Tensor) -> torch.Tensor:
@@ -65,7 +72,7 @@ def native_features(x_img: torch.Tensor, out: torch.Tensor = None) -> torch.Tens
             return x
         out.copy_(x)
         return out
-    if out is None and x_img.dtype == torch.float32 and _is_native(x_img):
+    if out is None and x_img.dtype == torch.float32 and _is_native(x_img, lm_only=CM_FEATURES != "inplace"):
         return x_img
     B, N, d = x_img.shape
     if _strides(x_img)[2] == 1:                      # rows along the channels already: a plain (vectorised) up-cast / copy

@@ -26,6 +26,7 @@ would clone each of the 16 (it cannot steal a buffer somebody else still holds):
 from __future__ import annotations
 
 import ctypes as C
+import sys
 from typing import Sequence
 
 import torch
@@ -33,6 +34,8 @@ import torch
 from . import _lib
 from . import head as _head
 from .coattention import _is_native, _native_layout, _strides, native_features
+# (the package exports a FUNCTION named `coattention`, which shadows the submodule as an attribute: take the module itself)
+_coattention = sys.modules[_is_native.__module__]
 from .head import _workspace_bytes as _head_ws
 
 
@@ -216,7 +219,8 @@ class HotPathGraph:
         # one address set for the plans / graphs, and neither autocast's up-cast nor torch's strided copy on top of it.
         if (x_img.is_cuda and not (x_img.requires_grad and torch.is_grad_enabled()) and x_img.data_ptr() != self.V.data_ptr()
                 and x_img.dtype in (torch.float32, torch.bfloat16) and tuple(x_img.shape) == tuple(self.V.shape)
-                and x_img.device == self.device and (x_img.dtype != torch.float32 or not _is_native(x_img))):
+                and x_img.device == self.device
+                and (x_img.dtype != torch.float32 or not _is_native(x_img, lm_only=_coattention.CM_FEATURES != "inplace"))):
             x_img = native_features(x_img, out=self.V)
         if self.direct_grads and (x_ques[0].requires_grad or x_ques[1].requires_grad or x_ques[2].requires_grad or x_img.requires_grad):
             return _HotPathFn.apply(self, x_img, labels, *x_ques)

@@ -17,7 +17,8 @@
  *     stream), re-entrant and thread-agnostic (backward runs on the autograd thread);
  *   - return 0 on success, < 0 on error (never throws); coattn_last_error() returns the
  *     calling thread's last message;
- *   - math is fp32 (dtype = COATTN_F32), row-vector convention Linear(x) = x W^T + b.
+ *   - math is fp32 (dtype = COATTN_F32: fp32 storage and accumulation; products fp32-accurate by default, see
+ *     "Widths of the fp32 mode" below), row-vector convention Linear(x) = x W^T + b.
  *
  * Layouts
  *   V      : the image features x_img[B,N,d] (model.py:215-217), given as a base pointer plus the element
@@ -62,25 +63,35 @@ extern "C" {
  * The same bit selects the bf16 MFMA for the three contractions of coattn_phrase_forward/backward. */
 #define COATTN_FLAG_BF16_PROJ 4
 #define COATTN_FLAG_BF16_IN 8     /* coattn_linear_forward / coattn_linear_weight_grad, with COATTN_FLAG_BF16_PROJ: x (dy) is STORED as bf16 */
-/* Widths of the fp32 mode.  An fp32 product runs on the 16-bit MFMAs as partial products of 16-bit PIECES of its operands:
- *   - three bf16 pieces each (hi + mid + lo = the value exactly, six partial products: fp32-accurate, fp32's range);
- *   - two bf16 pieces (hi + mid: 16 significand bits, three partial products, ~2^-16 relative per product, random in sign,
- *     fp32's range) -- the gradient contractions of coattn_backward, whose operands are gradients of any magnitude;
- *   - two FP16 pieces (hi + lo: 22 significand bits, three partial products on v_mfma_f32_32x32x16_f16, ~2^-22 relative) --
- *     the forward-side contractions, whose operands are features, projections and tanh values: the affinity A = Q V^T
- *     (model.py:377), the projections (model.py:380-384; the weight image holds 256 W, divided out), C^T P_q and C P_v.
- *     Range: exact pieces for |x| <= 65,504 (values below 2^-14 keep 2^-24 absolute; for the projection weights, whose
- *     image is scaled, |W| <= 255); conversions saturate, so magnitudes up to 131,008 (weights: 511) are still carried
- *     (with fewer bits) and larger ones clamp there -- finite for any finite input.
- * On the golden cases: v, q within 1e-6, attention maps within 4e-7, H_q within 2e-5, gradients within 1.5e-5 of max|.|
- * (the contract: 1e-4); tests/test_split_emulation.py has the budget row by row.
- * flags bit 4 (coattn_forward / coattn_backward): every contraction on three bf16 pieces (fp32's range throughout). */
+/* Widths of the fp32 mode (dtype COATTN_F32).  An fp32 product runs on the 16-bit MFMAs as partial products of 16-bit
+ * PIECES of its operands.
+ *   flags = 0 -- the DEFAULT, "exact": three bf16 pieces per operand (hi + mid + lo = the value exactly, six partial
+ *     products down to relative order 2^-16, each exact in the fp32 accumulator): every contraction of coattn_forward /
+ *     coattn_backward / coattn_phrase_* is fp32-accurate (one fp32 rounding per product) over fp32's whole range, as the
+ *     reference's fp32 bmm / Linear (model.py:377-392).  inf / NaN inputs give inf / NaN outputs.
+ *   COATTN_FLAG_FAST16 (flags bit 7) -- the "tolerance" mode a caller opts into (train.Trainer does): fewer partial
+ *     products, inside the north star's 1e-4 contract on operands of ordinary magnitude:
+ *       - forward-side contractions on two FP16 pieces (hi + lo: 22 significand bits, three partial products on
+ *         v_mfma_f32_32x32x16_f16, ~2^-22 relative): the affinity A = Q V^T (model.py:377), the projections (model.py:380-384;
+ *         the weight image holds 256 W, divided out), C^T P_q and C P_v.  RANGE: exact pieces for |x| <= 65,504 (values below
+ *         2^-14 keep 2^-24 absolute; projection weights |W| <= 255); the conversions SATURATE (MODE.FP16_OVFL), so magnitudes
+ *         up to 131,008 are still carried with fewer bits and larger ones -- +-inf included -- clamp there.  That event is not
+ *         silent: the projection launch records the largest magnitude it converted, and coattn_status() reports it
+ *         (-4 = an operand left the exact-piece range in the last coattn_forward on this `saved`);
+ *       - gradient contractions of coattn_backward on two bf16 pieces (hi + mid: 16 significand bits, three partial products,
+ *         ~2^-16 relative per product, random in sign, fp32's range) -- their operands are gradients of any magnitude.
+ *     On the golden cases: v, q within 1e-6, attention maps within 4e-7, H_q within 2e-5, gradients within 1.5e-5 of max|.|
+ *     (tests assert 5e-5; the contract is 1e-4); tests/test_split_emulation.py has the budget row by row.
+ *     Shapes the hand-scheduled projection kernels do not take (the general-shape path; B N < 128 rows) stay exact.
+ *   COATTN_FLAG_EXACT3 (flags bit 4) -- spells the default out (it wins over COATTN_FLAG_FAST16); kept from v0.5.x, where
+ *     the tolerance mode was the default of flags = 0. */
 #define COATTN_FLAG_EXACT3 16
-/* flags bit 5 (coattn_linear_forward; `accumulate` of coattn_linear_weight_grad): the two-piece width for this product. */
+/* flags bit 5 (coattn_linear_forward; `accumulate` of coattn_linear_weight_grad): the two-bf16-piece width for this product. */
 #define COATTN_FLAG_SPLIT2 32
-/* flags bit 6 (coattn_linear_forward): two FP16 pieces for this product (the form coattn_forward runs its projections in);
- * the weight image written under this flag is read under this flag only. */
+/* flags bit 6 (coattn_linear_forward): two FP16 pieces for this product (the form COATTN_FLAG_FAST16 runs the projections
+ * in; no range report: that is coattn_forward's); the weight image written under this flag is read under this flag only. */
 #define COATTN_FLAG_F16PAIR 64
+#define COATTN_FLAG_FAST16 128
 typedef struct coattn_params {
   const void* W_v; const void* b_v;   /* model.py:350 */
   const void* W_q; const void* b_q;   /* model.py:351 */
@@ -159,6 +170,18 @@ int coattn_backward(const void* V, int64_t v_sB, int64_t v_sN, int64_t v_sD, con
                     const coattn_param_grads* pg, int accumulate,
                     void* ws, int B, int N, int T, int d, int L, int dtype, int flags, void* stream);
 
+/* Range report of the tolerance mode (COATTN_FLAG_FAST16).  SYNCHRONISES `stream`, reads the status words the last
+ * coattn_forward left in `saved` (or in `ws`, when that call was given saved = NULL) and returns
+ *    0  every operand converted to FP16 pieces lay inside the exact-piece range (or the call did not use FP16 pieces:
+ *       exact mode, reduced-precision mode, general-shape path);
+ *   -4  some operand did not: an activation (image / question feature, stored projection) beyond 65,504 or a projection
+ *       weight beyond 255.87 in magnitude, +-inf included -- its pieces were clamped (see COATTN_FLAG_FAST16) and the
+ *       results of that call are not within tolerance of the reference; coattn_last_error() names the operand class and
+ *       the magnitude.  Re-run with flags = 0 (exact), which computes the reference's value over fp32's whole range.
+ * amax (host, may be NULL): [0] = largest |activation| beyond the range seen by the projection launch (0 if none),
+ * [1] = largest |256 W| over both projection weights.  Call it where the host synchronises anyway (reading the loss). */
+int coattn_status(const void* saved, int B, int N, int T, int d, int L, int dtype, void* stream, float* amax);
+
 /* ---- PhraseConvPool: the question hierarchy's phrase level ----------------
  * Replaces reference model.py:301-334 (`PhraseConvPool.forward`: 1/2/3-gram Conv1d + Tanh with
  * ConstantPad1d (0,0) / (1,0) / (1,1), concatenated along channels, then MaxPool2d((1,3)) over
@@ -174,7 +197,9 @@ typedef struct coattn_phrase_param_grads {
   void* dW1; void* db1; void* dW2; void* db2; void* dW3; void* db3;
 } coattn_phrase_param_grads;
 
-/* saved: forward -> backward state (argmax index per output element); ws_*: scratch. */
+/* saved: forward -> backward state (argmax index per output element, then the status words of coattn_phrase_status);
+ * ws_*: scratch.  flags: COATTN_FLAG_BF16_PROJ, COATTN_FLAG_FAST16 (see "Widths of the fp32 mode"); pass the same flags to the
+ * forward and the backward of a step. */
 int coattn_phrase_workspace_bytes(int B, int T, int E, int dtype, size_t* saved, size_t* ws_fwd, size_t* ws_bwd);
 
 /* X [B,T,E] (rows past a question's length are zeros, as the embedding delivers them) -> out [B,T,E].
@@ -187,6 +212,11 @@ int coattn_phrase_forward(const void* X, const coattn_phrase_params* p, void* ou
 int coattn_phrase_backward(const void* X, const coattn_phrase_params* p, const void* out, const void* saved,
                            const void* g_out, void* dX, const coattn_phrase_param_grads* pg, int accumulate,
                            void* ws, int B, int T, int E, int dtype, int flags, void* stream);
+
+/* Range report of coattn_phrase_forward under COATTN_FLAG_FAST16 (its product Z = Xcat Wcat^T then runs on two FP16
+ * pieces, like the co-attention's projections): as coattn_status -- synchronises, 0 / -4 -- on the status words behind the
+ * argmax bytes of `saved` (saved must have been given to the forward call). */
+int coattn_phrase_status(const void* saved, int B, int T, int E, void* stream, float* amax);
 
 /* ---- cross entropy of the train step ------------------------------------------------
  * coattn_ce_forward replaces `nn.CrossEntropyLoss()(logits, label)` (main.py:94, :214; mean over the batch)

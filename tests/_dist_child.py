@@ -113,6 +113,8 @@ def main():
             out["p." + n] = p.detach().cpu().numpy()
         if red is not None:
             out["n_buckets"] = np.asarray([len(red.buckets)])
+            out["exchange_used"] = np.asarray([red.exchange])
+            out["fallback"] = np.asarray([red.fallback_reason or ""])
             red.reset("none")                                          # (p2p: unmaps the peers' buckets, in step)
     np.savez(a.out, **out)
     if a.exchange != "none":

@@ -29,6 +29,7 @@ def saved_views(saved, B, N, T, d, L):
     return out
 
 
+last_status = None
 LAYOUTS = ("cm", "lm")      # channel-major [B,d,N] (the reference's NCHW encoder) / location-major [B,N,d] (channels_last)
 
 
@@ -53,7 +54,8 @@ def run_hip(V, Qs, P, gv=None, gq=None, impl="general", need_dv=True, accumulate
     assert gv is None or gv.shape[0] == len(Qs)
     T = Qs[0].shape[1]
     L = len(Qs)
-    flag = IMPL[impl] | (_lib.FLAG_BF16_PROJ if bf16_proj else 0) | (_lib.FLAG_EXACT3 if exact3 else 0)
+    # (the tolerance mode -- what train.Trainer runs -- unless exact3: flags = 0, the C-ABI's default, fp32-accurate products)
+    flag = IMPL[impl] | (_lib.FLAG_BF16_PROJ if bf16_proj else 0) | (0 if (exact3 or bf16_proj) else _lib.FLAG_FAST16)
     sb, fb, bb = _lib.workspace_bytes(B, N, T, d, L, flag)
     v = torch.full((L, B, d), float("nan"), device=dev)
     q = torch.full((L, B, d), float("nan"), device=dev)
@@ -66,6 +68,9 @@ def run_hip(V, Qs, P, gv=None, gq=None, impl="general", need_dv=True, accumulate
                                   ws.data_ptr(), B, N, T, d, L, _lib.F32, flag, C.c_void_p(stream)), "coattn_forward")
     torch.cuda.synchronize()
     out = {"v": v, "q": q}
+    amax = (C.c_float * 2)()
+    global last_status                      # (rc, largest out-of-range |activation|, largest |256 W|) of this forward call
+    last_status = (lib.coattn_status(saved.data_ptr(), B, N, T, d, L, _lib.F32, C.c_void_p(stream), amax), amax[0], amax[1])
     out.update(saved_views(saved, B, N, T, d, L))
     if gv is None:
         return out

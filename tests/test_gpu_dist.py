@@ -25,16 +25,20 @@ def _free_port():
     return p
 
 
-def _run_ranks(tmp_path, mode, world, exchange, tag, extra=()):
+def _run_ranks(tmp_path, mode, world, exchange, tag, extra=(), env=None):
     port = _free_port()
     outs = [str(tmp_path / ("%s_%s_%d.npz" % (tag, exchange, r))) for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_child.py"), "--mode", mode, "--world", str(world),
                                "--rank", str(r), "--port", str(port), "--exchange", exchange, "--out", outs[r], *extra],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                              env=dict(os.environ, **(env or {}))) for r in range(world)]
     logs = [p.communicate(timeout=600)[0] for p in procs]
     for r, p in enumerate(procs):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, logs[r][-4000:])
     return [dict(np.load(o)) for o in outs]
+
+
+GLOO_ONE_GPU = ("--backend", "gloo", "--same-gpu")
 
 
 @pytest.mark.timeout(900)
@@ -88,6 +92,31 @@ def test_p2p_exchange_ranks_sharing_one_gpu(tmp_path, world):
     equal the single-process full-batch gradients, identical on every rank, three Adam steps in lockstep."""
     full = _run_ranks(tmp_path, "sub", 1, "none", "full")[0]
     ranks = _run_ranks(tmp_path, "sub", world, "p2p", "p2p%d" % world, extra=("--backend", "gloo", "--same-gpu"))
+    _check_against_full_batch(full, ranks)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("exchange", ["allreduce", "direct"])
+def test_world2_ranks_sharing_one_gpu_equal_full_batch(tmp_path, exchange):
+    """The gloo twins of the nccl world-2 cases above, which have never had two GPUs to run on: two ranks on
+    this ONE GPU, CUDA buckets -- the hooked bucket path, the all-reduce and the one-shot "direct" exchange (its collectives on
+    a host copy of the bucket: gloo has no all-to-all on CUDA tensors; same shard arithmetic, same order of the sums) give
+    averaged gradients equal to the single-process full-batch gradients, identical on both ranks, three Adam steps in lockstep."""
+    full = _run_ranks(tmp_path, "sub", 1, "none", "full")[0]
+    ranks = _run_ranks(tmp_path, "sub", 2, exchange, "g2", extra=GLOO_ONE_GPU)
+    assert all(str(r["exchange_used"][0]) == exchange for r in ranks)
+    _check_against_full_batch(full, ranks)
+
+
+@pytest.mark.timeout(900)
+def test_p2p_falls_back_to_all_reduce_by_consensus(tmp_path):
+    """exchange="p2p" when ONE rank cannot export its buckets (injected: VQA_P2P_FAIL_RANK=1): every rank reaches the one
+    collective of the set-up, the decision is all-reduced, BOTH ranks continue on the all-reduce and say why -- the
+    gradients are still the full-batch gradients (nobody hangs, nobody trains on unreduced gradients)."""
+    full = _run_ranks(tmp_path, "sub", 1, "none", "full")[0]
+    ranks = _run_ranks(tmp_path, "sub", 2, "p2p", "fb", extra=GLOO_ONE_GPU, env={"VQA_P2P_FAIL_RANK": "1"})
+    for r in ranks:
+        assert str(r["exchange_used"][0]) == "allreduce" and "export" in str(r["fallback"][0]), (r["exchange_used"], r["fallback"])
     _check_against_full_batch(full, ranks)
 
 

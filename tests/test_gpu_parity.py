@@ -13,6 +13,11 @@ pytestmark = pytest.mark.gpu
 
 FWD_TOL = 1e-4
 GRAD_TOL = 1e-4
+# On the reference's goldens the asserts are tighter than the contract, so that green itself certifies margin:
+# the tolerance mode (COATTN_FLAG_FAST16: what train.Trainer runs, and what run_hip passes unless exact3) is held to 5e-5
+# (observed: H_q 2.0e-5, gradients 1.5e-5 of max|.|), the exact mode (flags = 0) to 1e-5.
+GOLDEN_TOL_FAST = 5e-5
+GOLDEN_TOL_EXACT = 1e-5
 
 
 def _impls(name):
@@ -39,22 +44,26 @@ def test_forward_backward_vs_reference_golden(name):
             ge = G.grad_errors(r, gold, "64")
             print(name, impl, layout, "fwd", {k: "%.1e" % v for k, v in fe.items()},
                   "grad", {k: "%.1e" % v for k, v in ge.items()})
-            assert max(fe.values()) < FWD_TOL, (impl, layout, fe)
-            assert max(ge.values()) < GRAD_TOL, (impl, layout, ge)
+            assert max(fe.values()) < GOLDEN_TOL_FAST, (impl, layout, fe)
+            assert max(ge.values()) < GOLDEN_TOL_FAST, (impl, layout, ge)
+            from tests import _hip
+            assert _hip.last_status[0] == 0, _hip.last_status        # no operand left the FP16-piece range
 
 
 @pytest.mark.parametrize("name", sorted(G.CASES))
 def test_exact_split_flag_vs_reference_golden(name):
-    """COATTN_FLAG_EXACT3: every contraction on the three-piece split -- the goldens hold at fp32 rounding level."""
+    """flags = 0, the C-ABI's default (= COATTN_FLAG_EXACT3): every contraction on the three-piece split -- the goldens hold
+    at fp32 rounding level, in both physical layouts."""
     from tests._hip import run_hip
     if "fused" not in _impls(name):
         pytest.skip("general-shape path: always exact")
     gold = G.load(name)
     V, Qs, P, gv, gq = G.build_case(name, torch.float32)
-    r = run_hip(V, Qs, P, gv, gq, impl="fused", layout="lm", exact3=True)
-    fe, ge = G.fwd_errors(r, gold, "64"), G.grad_errors(r, gold, "64")
-    print(name, "exact3 fwd %.1e grad %.1e" % (max(fe.values()), max(ge.values())))
-    assert max(fe.values()) < 1e-5 and max(ge.values()) < 1e-5, (fe, ge)
+    for layout in ("cm", "lm"):
+        r = run_hip(V, Qs, P, gv, gq, impl="fused", layout=layout, exact3=True)
+        fe, ge = G.fwd_errors(r, gold, "64"), G.grad_errors(r, gold, "64")
+        print(name, layout, "exact fwd %.1e grad %.1e" % (max(fe.values()), max(ge.values())))
+        assert max(fe.values()) < GOLDEN_TOL_EXACT and max(ge.values()) < GOLDEN_TOL_EXACT, (layout, fe, ge)
     # the default widths differ from it only inside their budget (tests/test_split_emulation.py)
     r2 = run_hip(V, Qs, P, gv, gq, impl="fused", layout="lm")
     for k in ("dQ", "dW_v.weight", "dW_q.weight"):
@@ -129,6 +138,19 @@ def test_frozen_image_features_and_accumulate(impl):
         assert (cacc["d" + k] - (a["d" + k] + 1.0)).abs().max() < 1e-4 * max(1.0, a["d" + k].abs().max().item()), k
 
 
+_FULL64 = {}
+
+
+def _full_batch_grads_float64(N, V, Qs, P, gv, gq):
+    """Parameter gradients of the FULL batch from the oracle run in float64 on the fp32 inputs (cached per grid: the six
+    parametrisations below share two sets of inputs)."""
+    if N not in _FULL64:
+        d64 = lambda t: t.double()                                    # noqa: E731
+        g = O.coattn_backward(d64(V), [d64(q) for q in Qs], {k: d64(v) for k, v in P.items()}, d64(gv), d64(gq))
+        _FULL64[N] = {k: g["d" + k] for k in O.PARAM_KEYS}
+    return _FULL64[N]
+
+
 @pytest.mark.parametrize("impl,layout,N", [("general", "cm", 196), ("fused", "cm", 196), ("fused", "lm", 196),
                                            ("general", "lm", 49), ("fused", "cm", 49), ("fused", "lm", 49)])
 def test_full_size_cfg2_properties(impl, layout, N):
@@ -163,10 +185,14 @@ def test_full_size_cfg2_properties(impl, layout, N):
     r2 = run_hip(V, Qs, P, 2 * gv, 2 * gq, impl=impl, layout=layout)
     for k in ("dV_phys", "dQ", "dW_v.weight", "dW_q.weight", "dw_v.weight"):
         assert (r2[k] - 2 * r[k]).abs().max() <= 2e-5 * max(1e-3, r[k].abs().max().item()), k
-    # full-batch parameter gradients vs the oracle (CPU, ~10 s)
-    gf = O.coattn_backward(V, Qs, P, gv, gq)
+    # full-batch parameter gradients (sums over 160 x N x 3 rows) vs the oracle in FLOAT64 at the contract's 1e-4 -- the
+    # tolerance mode at BASELINE's own size (this used to be 2e-4 against an fp32 CPU oracle)
+    gf = _full_batch_grads_float64(N, V, Qs, P, gv, gq)
+    worst = {}
     for k in O.PARAM_KEYS:
         if k.endswith("w_v.bias") or k.endswith("w_q.bias"):
             continue
-        ref = gf["d" + k]
-        assert (r["d" + k].cpu() - ref).abs().max() / ref.abs().max() < 2e-4, k
+        ref = gf[k]
+        worst[k] = float((r["d" + k].cpu().double() - ref).abs().max() / ref.abs().max())
+    print("full batch N=%d %s %s: parameter-gradient errors vs float64" % (N, impl, layout), {k: "%.1e" % e for k, e in worst.items()})
+    assert max(worst.values()) < GRAD_TOL, worst

@@ -26,11 +26,16 @@ def _case(B, T, E, seed):
 
 # (12, 26, 512) and (40, 13, 384): >= 128 rows and 128-aligned channels -> the hand-scheduled GEMMs (k bands with 4 / 3
 # column tiles per band, masked split-K weight gradient); (4, 26, 512): weight gradient only; the rest: general GEMM
+@pytest.mark.parametrize("fast", [True, False], ids=["tolerance_mode", "exact_mode"])
 @pytest.mark.parametrize("shape", [(3, 26, 64), (2, 5, 20), (1, 1, 4), (4, 26, 512), (2, 7, 36), (12, 26, 512), (40, 13, 384)],
                          ids=lambda s: "B%d_T%d_E%d" % s)
-def test_phrase_conv_pool_vs_oracle(shape):
+def test_phrase_conv_pool_vs_oracle(shape, fast):
+    """fast: the tolerance mode train.Trainer sets (Z = Xcat Wcat^T on two FP16 pieces, the gradient products on two bf16
+    pieces; include/coattn.h COATTN_FLAG_FAST16), held to 5e-5; else the module's default, fp32-accurate products, 1e-5."""
     B, T, E = shape
     mod, ref, x, g = _case(B, T, E, 11 + E)
+    mod.fast_products = fast
+    tol = 5e-5 if fast else 1e-5
     assert list(mod.state_dict().keys()) == list(ref.state_dict().keys())
     xr = x.double().requires_grad_(True)
     yr = ref(xr)
@@ -41,13 +46,39 @@ def test_phrase_conv_pool_vs_oracle(shape):
     y.backward(g.cuda())
     assert y.shape == (B, T, E)
     err = (y.detach().cpu().double() - yr.detach()).abs().max().item()
-    assert err < 1e-4, err
+    assert err < tol, err
     def rel(a, b):
         return (a.cpu().double() - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
-    assert rel(xg.grad, xr.grad) < 1e-4
+    worst = {"dx": rel(xg.grad, xr.grad)}
     for (k, p), (_, pr) in zip(mod.named_parameters(), ref.named_parameters()):
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
-        assert rel(p.grad, pr.grad) < 1e-4, (k, rel(p.grad, pr.grad))
+        worst[k] = rel(p.grad, pr.grad)
+    print("phrase", shape, "fast" if fast else "exact", "fwd %.1e" % err, {k: "%.1e" % e for k, e in worst.items()})
+    assert max(worst.values()) < tol, worst
+    import vqa_amd
+    vqa_amd.check_range()                                     # (tolerance mode: nothing left the FP16-piece range)
+
+
+def test_phrase_range_report():
+    """A conv weight beyond the scaled FP16 weight image's range (|W| > 255.87): the tolerance mode reports it
+    (vqa_amd.check_range raises RangeError); the exact mode computes the reference's value."""
+    import vqa_amd
+    mod, ref, x, g = _case(12, 26, 512, 77)
+    with torch.no_grad():
+        mod.conv_bigram[1].weight[5, 9, 1] = 400.0
+    ref.load_state_dict({k: v.double() for k, v in mod.state_dict().items()})
+    yr = ref(x.double())
+    mod = mod.cuda()
+    mod.fast_products = True
+    xg = x.cuda().requires_grad_(True)
+    mod(xg)
+    with pytest.raises(vqa_amd.RangeError):
+        vqa_amd.check_range()
+    vqa_amd._lib._last_status["phrase"] = None
+    mod.fast_products = False
+    y = mod(xg)
+    vqa_amd.check_range()
+    assert (y.detach().cpu().double() - yr).abs().max().item() < 1e-5
 
 
 def test_phrase_matches_stock_modules_on_gpu_and_inference(monkeypatch):

@@ -19,6 +19,7 @@ if [ "$mode" = build ]; then
   done
   exit 0
 fi
+export VQA_PRECISION=fast   # developer tools time the tolerance mode train.Trainer runs (modules default to exact)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for N in ${NS:-196 49}; do
 for ko in base "$@"; do

@@ -1,4 +1,5 @@
 # per-variant P_v / P_q kernel time by rocprofv3 kernel trace (developer script)
+export VQA_PRECISION=fast   # developer tools time the tolerance mode train.Trainer runs (modules default to exact)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for v in base "$@"; do
   if [ $v = base ]; then unset COATTN_LIB_PATH; else export COATTN_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab/libcoattn_stamps_$v.so; fi

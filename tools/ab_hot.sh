@@ -1,6 +1,7 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: per-kernel times of the co-attention forward + backward at N = 196 and 49, for each setting of
 # the environment given as arguments ("COATTN_SPLIT=3" "COATTN_SPLIT_FWD=2" ...; "-" = defaults).
+export VQA_PRECISION=fast   # developer tools time the tolerance mode train.Trainer runs (modules default to exact)
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/ab_hot

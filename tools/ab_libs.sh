@@ -1,3 +1,4 @@
+export VQA_PRECISION=fast   # developer tools time the tolerance mode train.Trainer runs (modules default to exact)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for rep in 1 2; do
 for lib in base new; do

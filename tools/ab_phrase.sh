@@ -1,6 +1,7 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: kernel-time sum of the phrase level's forward + backward (tools/probe_phrase.py, HIP path) per setting of
 # the environment given as arguments ("COATTN_SPLIT=3" ...; "-" = defaults): the probe's wall time is host-paced.
+export VQA_PRECISION=fast   # developer tools time the tolerance mode train.Trainer runs (modules default to exact)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for setting in "$@"; do
   rm -rf gpurun_out/abp; mkdir -p gpurun_out/abp

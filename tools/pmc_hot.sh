@@ -1,5 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: counter passes over the co-attention forward + backward at one shape (tools/probe_hot.py).
+export VQA_PRECISION=fast   # developer tools time the tolerance mode train.Trainer runs (modules default to exact)
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 N=${1:-196}

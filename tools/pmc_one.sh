@@ -1,5 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: one counter pass over tools/probe_hot.py: pmc_one.sh N "COUNTER ..." [kernel-name filter]
+export VQA_PRECISION=fast   # developer tools time the tolerance mode train.Trainer runs (modules default to exact)
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 N=$1; O=gpurun_out/pmc_one

@@ -23,7 +23,7 @@ gv = torch.randn(L, B, d, device=dev); gq = torch.randn(L, B, d, device=dev)
 opts = sys.argv[7:]
 flag = _lib.IMPL_GENERAL if "general" in opts else _lib.IMPL_FUSED
 if "bf16" in opts: flag |= _lib.FLAG_BF16_PROJ
-if "exact3" in opts: flag |= _lib.FLAG_EXACT3
+if "exact3" not in opts and "bf16" not in opts: flag |= _lib.FLAG_FAST16    # (default: the tolerance mode train.Trainer runs)
 need_dv = "dv" in opts
 sb, fb, bb = _lib.workspace_bytes(B, N, T, d, L, flag)
 al = lambda n: (n + 63) & ~63

@@ -39,7 +39,7 @@ vstr = (d * N, 1, N)
 if os.environ.get("LAYOUT", "lm") == "lm":
     V, vstr = V.permute(0, 2, 1).contiguous(), (N * d, d, 1)
 args = (V.data_ptr(), *vstr, qptr, C.byref(p), v.data_ptr(), q.data_ptr(), saved.data_ptr(), ws.data_ptr(),
-        B, N, T, d, L, _lib.F32, 0, stream)
+        B, N, T, d, L, _lib.F32, _lib.FLAG_FAST16, stream)
 _lib.check(lib.coattn_forward(*args), "coattn_forward")
 for _ in range(int(os.environ.get("WARM", "300"))):        # clocks ramp over the first ~30 ms of load: read the stamps warm
     _lib.check(lib.coattn_attention_forward(*args), "coattn_attention_forward")

@@ -1,3 +1,4 @@
+export VQA_PRECISION=fast   # developer tools time the tolerance mode train.Trainer runs (modules default to exact)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/refresh; mkdir -p gpurun_out/refresh
 for N in 49 196; do

@@ -2,6 +2,7 @@
 # Runs ON THE GPU BOX (through gpurun): regenerates everything profiles/ is built from into
 # gpurun_out/refresh/.  tools/collect_profiles.py then copies the summaries into profiles/.
 set -u
+export VQA_PRECISION=fast   # developer tools time the tolerance mode train.Trainer runs (modules default to exact)
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/refresh

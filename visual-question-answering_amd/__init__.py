@@ -7,8 +7,10 @@ There is no CPU fallback: using the co-attention op without the HIP library or o
 tensors raises.
 """
 from . import _lib  # noqa: F401
+from ._lib import RangeError, check_range  # noqa: F401
 from .coattention import ParallelCoAttention, coattention, native_features  # noqa: F401
 from .loss import CrossEntropyLoss, cross_entropy  # noqa: F401
 from .head import answer_head  # noqa: F401
 
-__all__ = ["ParallelCoAttention", "coattention", "native_features", "answer_head", "cross_entropy", "CrossEntropyLoss", "_lib"]
+__all__ = ["ParallelCoAttention", "coattention", "native_features", "answer_head", "cross_entropy", "CrossEntropyLoss", "_lib",
+           "check_range", "RangeError"]

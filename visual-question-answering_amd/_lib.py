@@ -18,16 +18,29 @@ EXPORTS = ("coattn_version", "coattn_last_error", "coattn_fused_supported", "coa
            "coattn_linear_wgrad_workspace_bytes", "coattn_linear_weight_grad",
            "coattn_head_workspace_bytes", "coattn_head_forward", "coattn_head_backward", "coattn_head_status",
            "coattn_ce_status", "coattn_p2p_enable_peer", "coattn_p2p_reduce_scatter", "coattn_p2p_all_gather",
-           "coattn_profile_begin", "coattn_profile_end", "coattn_features_native")
+           "coattn_profile_begin", "coattn_profile_end", "coattn_features_native", "coattn_status",
+           "coattn_phrase_status")
 
 F32 = 0
 BF16 = 1                  # storage type of coattn_features_native's input
 IMPL_AUTO, IMPL_GENERAL, IMPL_FUSED = 0, 1, 2
 FLAG_BF16_PROJ = 4
 FLAG_BF16_IN = 8          # linear entry points: x (dy) stored as bf16
-FLAG_EXACT3 = 16          # coattn_forward / coattn_backward: every contraction on the exact three-piece split
+FLAG_EXACT3 = 16          # coattn_forward / coattn_backward: every contraction on the exact three-piece split (= flags 0: the default)
 FLAG_SPLIT2 = 32          # linear entry points: the two-piece width (hi + mid, three partial products)
-FLAG_F16PAIR = 64        # coattn_linear_forward: two FP16 pieces (the form the forward runs its projections in)
+FLAG_F16PAIR = 64        # coattn_linear_forward: two FP16 pieces (the form the tolerance mode runs its projections in)
+FLAG_FAST16 = 128        # coattn_forward / coattn_backward / coattn_phrase_*: the tolerance mode (forward products on two FP16
+                         # pieces = 22 bits, backward on two bf16 pieces = 16 bits; range report: coattn_status)
+
+
+def precision_flag(fast: bool) -> int:
+    return FLAG_FAST16 if fast else 0
+
+
+def default_fast() -> bool:
+    """The modules' default precision: exact fp32 products (the reference's arithmetic) unless VQA_PRECISION=fast;
+    train.Trainer opts into the tolerance mode itself (precision="fast")."""
+    return os.environ.get("VQA_PRECISION", "exact") == "fast"
 
 
 class Params(C.Structure):
@@ -125,6 +138,8 @@ def load() -> C.CDLL:
     lib.coattn_linear_weight_grad.argtypes = ([C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
                                               + [C.c_int] * 4 + [C.c_void_p])
     lib.coattn_ce_status.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.coattn_status.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.POINTER(C.c_float)]
+    lib.coattn_phrase_status.argtypes = [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p, C.POINTER(C.c_float)]
     lib.coattn_p2p_enable_peer.argtypes = [C.c_int]
     lib.coattn_p2p_reduce_scatter.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int64, C.c_float, C.c_void_p]
     lib.coattn_p2p_all_gather.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int64, C.c_void_p]
@@ -142,6 +157,39 @@ def load() -> C.CDLL:
                                          + [C.c_int] * 6 + [C.c_void_p])
     _lib = lib
     return lib
+
+
+class RangeError(FloatingPointError):
+    """An operand of the tolerance mode (FLAG_FAST16) left the exact range of its two FP16 pieces: the call's results are
+    clamped, not within tolerance of the reference.  Use the exact mode (the modules' default; Trainer(precision="exact"))."""
+
+
+# (tensor holding the status words, dims) of the last tolerance-mode calls on this thread's modules: check_range() reads them
+_last_status = {"coattn": None, "phrase": None}
+
+
+def check_range(stream=None) -> None:
+    """Raise RangeError if the last tolerance-mode co-attention / phrase forward met an operand outside the FP16-piece
+    range (include/coattn.h, coattn_status).  Synchronises the current stream -- call it where the host reads the loss."""
+    import torch
+    lib = load()
+    amax = (C.c_float * 2)()
+    for kind in ("coattn", "phrase"):
+        last = _last_status[kind]
+        if last is None:
+            continue
+        buf, dims, dev = last
+        _last_status[kind] = None                       # (one report per forward call)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream if stream is None else stream)
+        with on_device(dev):
+            if kind == "coattn":
+                rc = lib.coattn_status(C.c_void_p(buf.data_ptr()), *dims, F32, st, amax)
+            else:
+                rc = lib.coattn_phrase_status(C.c_void_p(buf.data_ptr()), *dims, st, amax)
+        if rc == -4:
+            raise RangeError("%s (largest activation beyond the range %.4g, largest 256*|W| %.4g)"
+                             % (lib.coattn_last_error().decode(), amax[0], amax[1]))
+        check(rc, "coattn_status" if kind == "coattn" else "coattn_phrase_status")
 
 
 def check(rc: int, what: str) -> None:

@@ -144,6 +144,8 @@ class _CoAttentionFn(torch.autograd.Function):
             _lib.check(lib.coattn_forward(_ptr(V), *_strides(V), qptr, C.byref(p), _ptr(out_v), _ptr(out_q), _ptr(saved),
                                           _ptr(ws), B, N, T, d, L, _lib.F32, impl, C.c_void_p(stream)),
                        "coattn_forward")
+        if impl & _lib.FLAG_FAST16:                   # tolerance mode: where _lib.check_range() finds this call's status words
+            _lib._last_status["coattn"] = (saved if saved is not None else ws, (B, N, T, d, L), dev)
         if need_grad:
             ctx.save_for_backward(V, saved, *params, *Qs)
             ctx.dims = (B, N, T, d, L, impl)
@@ -208,10 +210,15 @@ class ParallelCoAttention(nn.Module):
         self.w_q = nn.Linear(hidden_dim, 1)
         # reduced-precision mode (apex O1 analogue, main.py:185): projections on the bf16 MFMA
         self.bf16_projections = False
+        # Precision of the fp32 mode (include/coattn.h "Widths of the fp32 mode").  False -- the default, as the reference:
+        # every product fp32-accurate over fp32's range.  True -- the tolerance mode (forward products on two FP16 pieces =
+        # 22 significand bits, backward on two bf16 pieces = 16; inside the 1e-4 contract for operands below 65,504 in
+        # magnitude; `vqa_amd.check_range()` reports an operand that was not): what train.Trainer(precision="fast") sets.
+        self.fast_products = _lib.default_fast()
 
     def forward(self, x_img: torch.Tensor, x_ques_hierarchy: Sequence[torch.Tensor]) -> Tuple[List, List]:
         """x_img [B,N,d]; x_ques_hierarchy: list of [B,T,d] -> (list of v_l [B,d], list of q_l [B,d])."""
-        impl = _impl_flag() | (_lib.FLAG_BF16_PROJ if self.bf16_projections else 0)
+        impl = _impl_flag() | (_lib.FLAG_BF16_PROJ if self.bf16_projections else 0) | _lib.precision_flag(self.fast_products)
         if x_img.is_cuda and not (x_img.requires_grad and torch.is_grad_enabled()):
             x_img = native_features(x_img)           # frozen encoder: bf16 / non-native strides in one library pass
         v, q = coattention(x_img, list(x_ques_hierarchy), self.W_v.weight, self.W_v.bias, self.W_q.weight,

@@ -16,7 +16,7 @@ void coattn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int coattn_version(void) { return 520; }   // 0.5.2: forward-side contractions on two FP16 pieces (COATTN_FLAG_F16PAIR); 0.5.1: coattn_features_native; 0.5.0: widths of the fp32 mode (COATTN_FLAG_EXACT3 / _SPLIT2), coattn_profile_*
+extern "C" int coattn_version(void) { return 600; }   // 0.6.0: flags = 0 is the exact mode, COATTN_FLAG_FAST16 the tolerance mode, coattn_status / coattn_phrase_status; 0.5.2: forward-side contractions on two FP16 pieces (COATTN_FLAG_F16PAIR); 0.5.1: coattn_features_native; 0.5.0: widths of the fp32 mode (COATTN_FLAG_EXACT3 / _SPLIT2), coattn_profile_*
 
 // ---------------------------------------------------------------------------------------
 // per-kernel timing (bench.py's backward roofline legs): HIP events recorded between the launches of the calls made
@@ -163,7 +163,7 @@ extern "C" int coattn_linear_forward(const void* x, int64_t ld_x, const void* W,
   CA_CHECK_ARG(!g.a_bf16 || g.bf16, "linear: COATTN_FLAG_BF16_IN needs COATTN_FLAG_BF16_PROJ");
   CA_CHECK_ARG(g.a_bf16 ? gemm_bf_supported(g) : gemm_w_supported(g), "linear: shape M=%d N=%d K=%d ld=%ld not supported (see coattn.h)", M, N, K, (long)ld_x);
   if (!(flags & 1)) {
-    const WSplit job{(const float*)W, wimg, N, K, 0, K, wimg_pieces(g)};
+    const WSplit job{(const float*)W, wimg, N, K, 0, K, wimg_pieces(g), nullptr};
     CA_TRY(launch_wsplit(&job, 1, (hipStream_t)stream));
   }
   return launch_gemm_wx(&g, 1, (hipStream_t)stream);
@@ -205,12 +205,49 @@ extern "C" int coattn_gemm_bf16(const coattn_gemm_desc* g, void* stream) {
   return launch_gemm_bf16in(*g, (hipStream_t)stream);
 }
 
+// Range report of the tolerance mode (include/coattn.h): header + per-chunk weight maxima from the status words.
+int read_status_words(const float* status, int n_words, hipStream_t s, float* amax, const char* what) {
+  if (hipStreamSynchronize(s) != hipSuccess) { coattn_set_error("%s: hipStreamSynchronize failed", what); return -3; }
+  float hdr[2] = {0.f, 0.f};
+  if (hipMemcpy(hdr, status, sizeof(hdr), hipMemcpyDeviceToHost) != hipSuccess) { coattn_set_error("%s: reading the status words failed", what); return -3; }
+  if (amax) amax[0] = amax[1] = 0.f;
+  if (hdr[1] != 1.f) return 0;                       // the call converted nothing to FP16 pieces
+  float wmax = 0.f;
+  {
+    const int n = n_words - kStatusHdr;
+    float* w = (float*)malloc((size_t)n * sizeof(float));
+    CA_CHECK_ARG(w != nullptr, "%s: out of host memory", what);
+    const hipError_t e = hipMemcpy(w, status + kStatusHdr, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+    for (int i = 0; e == hipSuccess && i < n; ++i) wmax = (w[i] > wmax || w[i] != w[i]) ? w[i] : wmax;
+    free(w);
+    if (e != hipSuccess) { coattn_set_error("%s: reading the status words failed", what); return -3; }
+  }
+  if (amax) { amax[0] = hdr[0]; amax[1] = wmax; }
+  const bool act = !(hdr[0] <= kF16Exact), wgt = !(wmax <= kF16Exact);
+  if (act || wgt) {
+    coattn_set_error("%s: FP16-piece range exceeded in the last forward (COATTN_FLAG_FAST16): %s%s%s -- pieces were clamped; "
+                     "re-run with flags = 0 (exact)", what,
+                     act ? "an activation (feature or stored projection) of magnitude > 65504" : "", act && wgt ? " and " : "",
+                     wgt ? "a projection weight of magnitude > 255.87" : "");
+    if (amax) { /* magnitudes are in amax */ }
+    return -4;
+  }
+  return 0;
+}
+
+extern "C" int coattn_status(const void* saved, int B, int N, int T, int d, int L, int dtype, void* stream, float* amax) {
+  CA_TRY(check_shape(B, N, T, d, L, dtype));
+  CA_CHECK_ARG(saved != nullptr, "status: null `saved`");
+  const SavedPlan sp = plan_saved(B, N, T, d, L);
+  return read_status_words((const float*)saved + sp.status, (int)status_floats(d, d, 2), (hipStream_t)stream, amax, "coattn_status");
+}
+
 // ---------------------------------------------------------------------------------------
 // general-shape implementation: MFMA GEMM composition
 // ---------------------------------------------------------------------------------------
 // COATTN_BF_TN_ROUNDS (developer switch): rounds of workgroups the split-K parts of gemm_bf.hip's weight-gradient kernel fill
 int bf_tn_rounds() {
-  static const int r = [] { const char* e = getenv("COATTN_BF_TN_ROUNDS"); return e ? atoi(e) : 1; }();   // (measured: 1 round 101 us, 2: 128, 3: 152 -- the partial results' round trip)
+  static const int r = dev_env_int("COATTN_BF_TN_ROUNDS", 1);   // (measured: 1 round 101 us, 2: 128, 3: 152 -- the partial results' round trip)
   return r < 1 ? 1 : r;
 }
 
@@ -281,37 +318,72 @@ int c_times(const Ctx& c, const float* C, const float* Y, const float* X, float*
   return launch_gemm_f32(g, c.s);
 }
 
-// Width of the fp32 mode's contractions (fused.h).  Default: the mixed widths of DESIGN.md section 3 -- the affinity and
-// the projections on the exact split, phase 2 of the forward kernel (C^T P_q, C P_v) and the backward's contractions on
-// two pieces.  COATTN_FLAG_EXACT3 (or the developer switch COATTN_SPLIT=3) puts every contraction on the exact split;
-// COATTN_SPLIT_FWD=3 (developer switch) only the forward kernel's phase 2.
-static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-static int np_bwd(int flags) {
+// Width of the fp32 mode's contractions (fused.h, include/coattn.h "Widths of the fp32 mode").  flags = 0: every
+// contraction on the exact three-piece split.  COATTN_FLAG_FAST16: the forward-side contractions on two FP16 pieces, the
+// backward's on two bf16 pieces.  Developer switches (builds with -DCOATTN_DEV_SWITCHES only): COATTN_SPLIT=3 forces the exact
+// split, COATTN_FWD_F16=0 / COATTN_FWD_F16_KERNEL=0 / COATTN_SPLIT_FWD=3 / COATTN_SPLIT_PQ=3 the bf16 widths of round 4's A/B runs.
+static int env_int(const char* name, int dflt) { return dev_env_int(name, dflt); }
+static bool fast16(int flags) {
   static const int split = env_int("COATTN_SPLIT", 2);
-  return ((flags & COATTN_FLAG_EXACT3) || split == 3) ? 3 : 2;
+  return (flags & COATTN_FLAG_FAST16) && !(flags & COATTN_FLAG_EXACT3) && split != 3;
 }
+static int np_bwd(int flags) { return fast16(flags) ? 2 : 3; }
 static int np_projq(int flags) {                    // P_q = Q W_q^T: its error reaches H_v summed over T <= 28 tokens only
-  static const int split = env_int("COATTN_SPLIT", 2), pq = env_int("COATTN_SPLIT_PQ", 2);
-  return ((flags & COATTN_FLAG_EXACT3) || split == 3) ? 3 : (pq == 2 ? 2 : 3);
+  static const int pq = env_int("COATTN_SPLIT_PQ", 2);
+  return fast16(flags) ? (pq == 2 ? 2 : 3) : 3;
 }
 // The forward's projections P_v, P_q on two FP16 pieces (fused.h; tests/test_split_emulation.py: less error than the exact
-// split of P_v next to two bf16 pieces of P_q, at half the MFMAs of the former).  COATTN_FWD_F16=0 (developer switch),
-// COATTN_FLAG_EXACT3 or COATTN_SPLIT=3: the bf16 widths.
+// split of P_v next to two bf16 pieces of P_q, at half the MFMAs of the former).
 static bool f16_fwd(int flags) {
-  static const int split = env_int("COATTN_SPLIT", 2), on = env_int("COATTN_FWD_F16", 1);
-  return !(flags & COATTN_FLAG_EXACT3) && split != 3 && on != 0;
+  static const int on = env_int("COATTN_FWD_F16", 1);
+  return fast16(flags) && on != 0;
 }
-static int np_fwd(int flags) {                      // 4: both phases of the forward kernel on two FP16 pieces (coattn_fwd32.hip)
-  static const int split = env_int("COATTN_SPLIT", 2), fwd = env_int("COATTN_SPLIT_FWD", 2), hk = env_int("COATTN_FWD_F16_KERNEL", 1);
-  if ((flags & COATTN_FLAG_EXACT3) || split == 3) return 3;
-  if (f16_fwd(flags) && hk != 0 && fwd == 2) return 4;
-  return fwd == 2 ? 2 : 3;
+static int np_fwd(int flags, bool f16) {            // 4: both phases of the forward kernel on two FP16 pieces (coattn_fwd32.hip)
+  static const int fwd = env_int("COATTN_SPLIT_FWD", 2), hk = env_int("COATTN_FWD_F16_KERNEL", 1);
+  if (!fast16(flags)) return 3;
+  if (f16) return (hk != 0 && fwd == 2) ? 4 : (fwd == 2 ? 2 : 3);
+  return f16_fwd(flags) ? 3 : (fwd == 2 ? 2 : 3);   // FP16 pieces wanted but not available for this shape: exact
 }
 
 // COATTN_GEMM_W=0 (developer switch): the projections through gemm.hip instead of the pre-split-weight kernel
 static bool gemm_w_enabled() {
-  static const int on = [] { const char* e = getenv("COATTN_GEMM_W"); return e ? atoi(e) : 1; }();
+  static const int on = dev_env_int("COATTN_GEMM_W", 1);
   return on != 0;
+}
+
+// The two projection jobs of a forward call on the pre-split-weight kernel (gemm_w.hip): P_v from the image features in
+// either layout, P_q of all levels from the pointer table.  Returns through v_w / q_w which of them that kernel takes.
+void projection_jobs(const Ctx& c, const float* V, const float* const* Q, const coattn_params* p, float* sv, char* wimg,
+                     WGemm& wv, WGemm& wq, bool& v_w, bool& q_w) {
+  const SavedPlan sp = plan_saved(c.B, c.N, c.T, c.d, c.L);
+  const size_t BTd = (size_t)c.B * c.T * c.d;
+  wv = WGemm{}; wq = WGemm{};
+  wv.A = V; wv.a_sm = (int)c.vl.sN; wv.Wf = wimg; wv.C = sv + sp.Pv; wv.c_sm = c.d;
+  wv.bias_n = p ? (const float*)p->b_v : nullptr; wv.out_scale = c.pscale; wv.M = c.B * c.N; wv.N = c.d; wv.K = c.d; wv.batch = 1;
+  for (int l = 0; l < c.L; ++l) wq.a_ptrs[l] = Q[l];
+  wq.a_sm = c.d; wq.Wf = wimg + wsplit_bytes(c.d, c.d); wq.C = sv + sp.Pq; wq.c_sz = (long)BTd; wq.c_sm = c.d;
+  wq.bias_n = p ? (const float*)p->b_q : nullptr; wq.out_scale = c.pscale; wq.M = c.B * c.T; wq.N = c.d; wq.K = c.d; wq.batch = c.L;
+  wv.bf16 = wq.bf16 = c.bf16_proj ? 1 : 0;          // reduced precision: the same kernels, hi pieces only, one MFMA per product
+  wv.np = 3; wq.np = c.np_pq;
+  const bool w_ok = gemm_w_enabled();
+  v_w = false;
+  if (w_ok && c.vl.sD == 1 && c.vl.sB == (long)c.N * c.vl.sN && c.vl.sN < (1L << 24)) {
+    v_w = gemm_w_supported(wv) != 0;                 // location-major rows, samples abutting
+  } else if (w_ok && c.vl.sN == 1 && c.vl.sD < (1L << 24)) {
+    wv.a_sm = 0; wv.a_sk = (int)c.vl.sD; wv.a_mdiv = c.N; wv.a_sdiv = c.vl.sB;   // channel-major, read in place
+    v_w = gemm_w_supported(wv) != 0;
+  }
+  q_w = w_ok && gemm_w_supported(wq);
+}
+// Tolerance mode: FP16 pieces are used only when BOTH projections run on the pre-split-weight kernel -- it is that launch
+// which range-checks the image and question features and the stored projections for the fused kernel behind it
+// (coattn_status); any other shape computes exactly.
+bool f16_path(const Ctx& c, const float* V, const float* const* Q, int flags, int fused) {
+  if (!fused || c.bf16_proj || !f16_fwd(flags)) return false;
+  WGemm wv, wq;
+  bool v_w, q_w;
+  projection_jobs(c, V, Q, nullptr, nullptr, nullptr, wv, wq, v_w, q_w);
+  return v_w && q_w;
 }
 
 // wimg: room for two pre-split weight images (wsplit_bytes(d, d) each) at the end of the forward workspace
@@ -321,36 +393,27 @@ int general_projections(const Ctx& c, const float* V, const float* const* Q, con
   const SavedPlan sp = plan_saved(c.B, c.N, c.T, c.d, c.L);
   const size_t BTd = (size_t)c.B * c.T * c.d;
   // fp32 projections of row-major activations: the weight is split once, the GEMM reads it as MFMA fragments
-  WGemm wv = {}, wq = {};
-  wv.A = V; wv.a_sm = (int)c.vl.sN; wv.Wf = wimg; wv.C = sv + sp.Pv; wv.c_sm = c.d;
-  wv.bias_n = (const float*)p->b_v; wv.out_scale = c.pscale; wv.M = c.B * c.N; wv.N = c.d; wv.K = c.d; wv.batch = 1;
-  for (int l = 0; l < c.L; ++l) wq.a_ptrs[l] = Q[l];
-  wq.a_sm = c.d; wq.Wf = wimg + wsplit_bytes(c.d, c.d); wq.C = sv + sp.Pq; wq.c_sz = (long)BTd; wq.c_sm = c.d;
-  wq.bias_n = (const float*)p->b_q; wq.out_scale = c.pscale; wq.M = c.B * c.T; wq.N = c.d; wq.K = c.d; wq.batch = c.L;
-  wv.bf16 = wq.bf16 = c.bf16_proj ? 1 : 0;          // reduced precision: the same kernels, hi pieces only, one MFMA per product
-  wv.np = 3; wq.np = c.np_pq;                        // fp32 mode: P_v on the exact split, P_q on two pieces (tests/test_split_emulation.py)
-  if (c.f16_proj && !c.bf16_proj) { wv.np = wq.np = 2; wv.f16 = wq.f16 = 1; }   // ... or both on two FP16 pieces
-  const bool w_ok = gemm_w_enabled();
-  bool v_w = false;
-  if (w_ok && c.vl.sD == 1 && c.vl.sB == (long)c.N * c.vl.sN && c.vl.sN < (1L << 24)) {
-    v_w = gemm_w_supported(wv) != 0;                 // location-major rows, samples abutting
-  } else if (w_ok && c.vl.sN == 1 && c.vl.sD < (1L << 24)) {
-    wv.a_sm = 0; wv.a_sk = (int)c.vl.sD; wv.a_mdiv = c.N; wv.a_sdiv = c.vl.sB;   // channel-major, read in place
-    v_w = gemm_w_supported(wv) != 0;
-  }
-  const bool q_w = w_ok && gemm_w_supported(wq);
+  WGemm wv, wq;
+  bool v_w, q_w;
+  projection_jobs(c, V, Q, p, sv, wimg, wv, wq, v_w, q_w);
+  float* status = sv + sp.status;
+  const bool f16 = c.f16_proj && !c.bf16_proj;        // (forward_impl: only when v_w && q_w)
+  if (f16) { wv.np = wq.np = 2; wv.f16 = wq.f16 = 1; wv.status = wq.status = status; }   // both on two FP16 pieces
   if (v_w || q_w) {
     WSplit jobs[3];
     int nj = 0;
     // (the image of W_q^T is read by the backward's dQ projection: a GEMM of P_q's shape with row-major A in the same
     //  precision mode, so it runs on the same kernel as P_q and wants the same image format)
-    if (v_w) jobs[nj++] = WSplit{(const float*)p->W_v, const_cast<void*>(wv.Wf), c.d, c.d, 0, c.d, wimg_pieces(wv)};
-    if (q_w) jobs[nj++] = WSplit{(const float*)p->W_q, const_cast<void*>(wq.Wf), c.d, c.d, 0, c.d, wimg_pieces(wq)};
+    const int chunks = ((c.d + 31) / 32) * ((c.d + 15) / 16);
+    if (v_w) jobs[nj++] = WSplit{(const float*)p->W_v, const_cast<void*>(wv.Wf), c.d, c.d, 0, c.d, wimg_pieces(wv), status + kStatusHdr};
+    if (q_w) jobs[nj++] = WSplit{(const float*)p->W_q, const_cast<void*>(wq.Wf), c.d, c.d, 0, c.d, wimg_pieces(wq), status + kStatusHdr + chunks};
     WGemm wqb = wq;                                   // (the backward's operands are gradients: bf16 pieces, fused.h)
     wqb.f16 = 0;
-    if (q_w && keep_wqT) jobs[nj++] = WSplit{(const float*)p->W_q, sv + sp.wqT, c.d, c.d, 1, c.d, wimg_pieces(wqb)};
-    CA_TRY(launch_wsplit(jobs, nj, c.s));
+    if (q_w && keep_wqT) jobs[nj++] = WSplit{(const float*)p->W_q, sv + sp.wqT, c.d, c.d, 1, c.d, wimg_pieces(wqb), nullptr};
+    CA_TRY(launch_wsplit(jobs, nj, c.s, status, f16 ? 1 : 0));   // (also writes the header of the call's status words)
     prof_mark(c.s, "wsplit");
+  } else {                                            // no weight-split launch on this path: header = "no FP16 pieces"
+    if (hipMemsetAsync(status, 0, 2 * sizeof(float), c.s) != hipSuccess) { coattn_set_error("forward: hipMemsetAsync failed"); return -3; }
   }
   if (v_w && q_w) {                                   // both projections in one launch
     const WGemm both[2] = {wv, wq};
@@ -584,8 +647,10 @@ static int forward_impl(const void* V, const VLayout& vl, const void* const* Q, 
   float* tail = (float*)ws + sp.total;
   Ctx c{B, N, T, d, L, (hipStream_t)stream, vl};
   c.bf16_proj = (flags & COATTN_FLAG_BF16_PROJ) != 0;
-  c.np_pq = fused ? np_projq(flags) : 3;              // (the general-shape path stays exact throughout)
-  c.f16_proj = fused && f16_fwd(flags);
+  c.f16_proj = f16_path(c, (const float*)V, (const float* const*)Q, flags, fused);
+  // (the general-shape path stays exact throughout; a fused shape without the FP16 path too -- unless the developer switch
+  //  COATTN_FWD_F16=0 asks for round 4's bf16 widths)
+  c.np_pq = (fused && fast16(flags) && !f16_fwd(flags)) ? np_projq(flags) : 3;
   c.pscale = fused ? kPScale : 1.f;
   if (do_proj)
     CA_TRY(general_projections(c, (const float*)V, (const float* const*)Q, p, sv,
@@ -593,7 +658,7 @@ static int forward_impl(const void* V, const VLayout& vl, const void* const* Q, 
   if (!do_attn) return 0;
   if (fused)
     return fused_attention_forward(B, N, T, d, L, (const float*)V, vl, (const float* const*)Q, p, (float*)v_out,
-                                   (float*)q_out, sv, tail, c.s, c.bf16_proj ? 1 : 0, np_fwd(flags));
+                                   (float*)q_out, sv, tail, c.s, c.bf16_proj ? 1 : 0, np_fwd(flags, c.f16_proj));
   return general_attention(c, (const float*)V, (const float* const*)Q, p, (float*)v_out, (float*)q_out, sv, tail);
 }
 

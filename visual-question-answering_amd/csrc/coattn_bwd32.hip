@@ -804,7 +804,7 @@ int launch_bwd_nat32(const BwdArgs& a, hipStream_t s) {
 }
 
 int launch_bwd_dq32(const DqArgs& a, int lm, hipStream_t s) {
-  static const int shared = [] { const char* e = getenv("COATTN_DQ32X"); return e ? atoi(e) : 1; }();   // developer switch
+  static const int shared = dev_env_int("COATTN_DQ32X", 1);   // developer switch
   const int np = a.bf16 ? 1 : (a.np == 2 ? 2 : 3);
   auto go = [&](auto NPc) -> int {
     constexpr int NP = decltype(NPc)::value;

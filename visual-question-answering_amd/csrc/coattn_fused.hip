@@ -73,7 +73,7 @@ int fused_attention_forward(int B, int N, int T, int d, int L, const float* V, c
   // Small grids (the 7 x 7 grid of 224 x 224 images: N = 49) on location-major features: the attended image feature
   // v_l = a_v^T V is computed by the affinity kernel's own workgroup -- its 100 KB of V come from L2, where phase 1 left
   // them, in less time than a second launch costs.  (At N = 196 the separate pass over V stays: DESIGN.md section 3.1.)
-  static const int fuse_v_env = [] { const char* e = getenv("COATTN_FUSE_V"); return e ? atoi(e) : 1; }();   // developer switch
+  static const int fuse_v_env = dev_env_int("COATTN_FUSE_V", 1);   // developer switch
   const bool fuse_v = lm && N <= 64 && d % 512 == 0 && fuse_v_env;
   a.v_out = fuse_v ? v_out : nullptr;
   a.stamps = COATTN_STAMPS ? reinterpret_cast<unsigned long long*>(ws) : nullptr;

@@ -338,7 +338,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   wdq.bf16 = bf16_proj; wdq.np = np;
   const bool wdq_ok = wgemm && q_al && gemm_w_supported(wdq);
   // (a dQ projection on gemm_bf.hip -- 512-thread workgroups -- cannot ride in the weight-gradient launch)
-  static const int no_combine = [] { const char* e = getenv("COATTN_NO_COMBINE"); return e ? atoi(e) : 0; }();   // developer switch
+  static const int no_combine = dev_env_int("COATTN_NO_COMBINE", 0);   // developer switch
   const bool combine = dq32 && wdq_ok && tn_v && tn_q && !gemm_bf_supported(wdq) && !no_combine;
   // Reduced-precision mode with a frozen image encoder (no dV) and all three consumers of dP_v / dP_q on gemm_bf.hip:
   // bwd_nat32 stores both as bf16 -- the GEMMs would round them on their way in anyway -- halving what it writes and
@@ -348,7 +348,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     WGemm wq = wdq;
     tv.a_bf16 = tq.a_bf16 = wq.a_bf16 = 1;
     tv.a_term = L == 3 ? (long)BNd : 0;
-    static const int off = [] { const char* e = getenv("COATTN_DP_BF16"); return e && atoi(e) == 0; }();   // developer switch
+    static const int off = (dev_env_int("COATTN_DP_BF16", 1) == 0);   // developer switch
     if (!off && bf16_proj && !dV && L == 3 && d % 512 == 0 && dq32 && wdq_ok && tn_v && tn_q && gemm_bf_tn_supported(tv) &&
         gemm_bf_tn_supported(tq) && gemm_bf_supported(wq)) {
       ba.dp_bf16 = 1;
@@ -398,7 +398,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   }
   // (red: the two weight gradients' partial sums, handed to the dQ kernel's launch when it is the bf16-MFMA one)
   struct RedJob { const float* part[2]; float* out[2]; int np[2]; long n; int acc; bool on; } red = {};
-  static const int red_in_dq = [] { const char* e = getenv("COATTN_RED_IN_DQ"); return e ? atoi(e) : 1; }();   // developer switch
+  static const int red_in_dq = dev_env_int("COATTN_RED_IN_DQ", 1);   // developer switch
   auto run_dq = [&]() -> int {
     DqArgs da = {};
     da.accumulate = dq32 ? 1 : 0;
@@ -505,7 +505,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     // both weight gradients in one launch: 32 split-K parts (x 16 tiles = the 512 workgroup slots) shared in
     // proportion to the contraction lengths, so that all workgroups run about equally long
     const double kv = (double)B * N, kq = (double)L * B * T;
-    static const int budget_env = [] { const char* e = getenv("COATTN_TN_PARTS"); return e ? atoi(e) : 0; }();   // developer switch
+    static const int budget_env = dev_env_int("COATTN_TN_PARTS", 0);   // developer switch
     const int budget = budget_env > 0 ? budget_env : 32;
     int pv = (int)((double)budget * kv / (kv + kq) + 0.5);
     pv = pv < 1 ? 1 : (pv > budget - 1 ? budget - 1 : pv);

@@ -62,6 +62,20 @@ struct DeviceOnce {
   }
 };
 
+// ---- developer switches --------------------------------------------------------------------------------------------
+// Environment variables that select kernels / widths for A/B timing (tools/ab_*.sh) exist only in builds made with
+// -DCOATTN_DEV_SWITCHES; the shipped library ignores the environment (numerics must not depend on it).
+#include <stdlib.h>
+static inline int dev_env_int(const char* name, int dflt) {
+#ifdef COATTN_DEV_SWITCHES
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+#else
+  (void)name;
+  return dflt;
+#endif
+}
+
 // ---- per-kernel timing marks (coattn_profile_begin / _end, api.hip) ----------------------------------------------
 // Between coattn_profile_begin and coattn_profile_end on the calling thread, prof_mark(s, name) records a HIP event on `s`:
 // the time since the previous mark is attributed to `name` (the launches issued in between).  Off (one thread-local

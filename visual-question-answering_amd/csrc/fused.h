@@ -214,8 +214,20 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, int voff, i
 }
 
 // ---- GEMM against a pre-split weight (gemm_w.hip) ---------------------------------------------------------------
-struct WSplit { const float* W; void* out; int N, K, trans, ld; int pieces; };   // Bw(k,n) = trans ? W[k*ld+n] : W[n*ld+k]; pieces: 3 (0 = 3), 1 = hi piece only (gemm_bf.hip),
-                                                                                 // 16 = two FP16 pieces of kF16WScale * W (WGemm.f16)
+struct WSplit { const float* W; void* out; int N, K, trans, ld; int pieces; float* amax; };   // Bw(k,n) = trans ? W[k*ld+n] : W[n*ld+k]; pieces: 3 (0 = 3), 1 = hi piece only (gemm_bf.hip),
+                                                                                 // 16 = two FP16 pieces of kF16WScale * W (WGemm.f16);
+                                                                                 // amax (pieces = 16; may be NULL): one word per wave
+                                                                                 // = per (32-column tile, 16-k step) chunk, max |256 W|
+// Status words of the tolerance mode (COATTN_FLAG_FAST16; coattn_status / coattn_phrase_status), floats:
+//   [0]  written 0 by the weight-split launch, then raised (atomicMax on the bit pattern) by any wave of the projection launch
+//        that converted an activation beyond kF16Exact to FP16 pieces: the largest such |x|;
+//   [1]  1.0 if the call that wrote the words used FP16 pieces, else 0 (written by the weight-split launch);
+//   [kStatusHdr + job * chunks + chunk]  max |kF16WScale * W| per chunk of weight-split job 0 / 1 (FP16 images only).
+constexpr int kStatusHdr = 64;
+constexpr float kF16Exact = 65504.f;
+// synchronises `s`, reads the words back: 0, or -4 with the error message set (api.hip); amax (host, may be NULL): [0] activations, [1] weights
+int read_status_words(const float* status, int n_words, hipStream_t s, float* amax, const char* what);
+inline size_t status_floats(int N, int K, int nweights) { return kStatusHdr + (size_t)nweights * ((N + 31) / 32) * ((K + 15) / 16); }
 // Forward-side contractions on two FP16 pieces (x = hi + lo, 22 significand bits; the three products lo*hi, hi*lo, hi*hi on
 // v_mfma_f32_32x32x16_f16): the cost of the two-piece bf16 width with 64 x less error -- for operands of ordinary magnitude
 // only: features, projections, tanh values (|x| < 65,504; gfx950 keeps fp16 subnormals in conversions and in the MFMA, so
@@ -241,9 +253,11 @@ struct WGemm {
   int np;                                                            // (bf16 = 0) bf16 pieces per operand: 0 / 3 = the exact split (six products), 2 = hi + mid (three products)
   int f16;                                                           // (np = 2) the two pieces are FP16 (Wf: a pieces = 16 image)
   int a_bf16;                                                        // (gemm_bf_kernel) A is STORED as bf16; a_sm, a_sz stay in elements
+  float* status;                                                     // (f16) status word [0] of the call (see kStatusHdr), or NULL
 };
 size_t wsplit_bytes(int N, int K);
-int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s);
+// status_hdr (may be NULL): the launch's first thread writes [0] = 0 and [1] = f16 ? 1 : 0 (the status words' header)
+int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s, float* status_hdr = nullptr, int f16 = 0);
 int gemm_w_supported(const WGemm& d);
 int launch_gemm_w(const WGemm* d, int n, hipStream_t s);          // n = 1 or 2 GEMMs in one launch
 // single-product bf16 GEMM for wide shapes (gemm_bf.hip): reads a hi-piece-only weight image (WSplit.pieces = 1)
@@ -450,7 +464,7 @@ int launch_attend_v_lm(const float* V, long v_sB, const float* av, float* v_out,
 inline size_t fal64(size_t n) { return (n + 63) & ~(size_t)63; }
 
 struct SavedOff {
-  size_t Pv, Pq, C, av, aq, Hq, wqT, total;
+  size_t Pv, Pq, C, av, aq, Hq, wqT, status, total;
 };
 inline SavedOff saved_off(int B, int N, int T, int d, int L) {   // the one layout of `saved`
   SavedOff p;
@@ -464,6 +478,7 @@ inline SavedOff saved_off(int B, int N, int T, int d, int L) {   // the one layo
   // W_q split for the backward's dQ projection (gemm_w.hip, wsplit_bytes(d, d)): written by the forward's weight-split
   // launch, so that the backward has no split launch of its own
   p.wqT = o; o += fal64((size_t)((d + 31) / 32) * ((d + 15) / 16) * 768);
+  p.status = o; o += fal64(status_floats(d, d, 2));   // range report of the tolerance mode (W_v, W_q images)
   p.total = o;
   return p;
 }

@@ -817,7 +817,7 @@ static int launch_gemm_impl(const coattn_gemm_desc& d, hipStream_t s, int bf16) 
     // (192-row tiles were also tried for that case and measured slower: 279 vs 235 us.)
     const long ntn = (d.N + 127) / 128;
     const long wg128 = ntn * ((d.M + 127) / 128) * d.batch;
-    static const int force_bm = [] { const char* e = getenv("COATTN_GEMM_BM"); return e ? atoi(e) : 0; }();   // developer switch
+    static const int force_bm = dev_env_int("COATTN_GEMM_BM", 0);   // developer switch
     const bool small_tiles = force_bm ? force_bm == 64 : (wg128 > 768 && wg128 < 3 * 768);
     const int bm = small_tiles ? 64 : 128;
     const long ntm = (d.M + bm - 1) / bm;
@@ -856,7 +856,7 @@ static int launch_gemm_impl(const coattn_gemm_desc& d, hipStream_t s, int bf16) 
 // split is the faster mode on all layouts of the path (P_v 188 -> 128 us, dW_v 172 -> 124, dQ projection
 // 87 -> 60, dW_q 73 -> 57, P_q 87 -> 62); before that it lost on transposing operands (P_v 203 vs 182 us).
 int launch_gemm_f32(const coattn_gemm_desc& d, hipStream_t s) {
-  static const int x3 = [] { const char* e = getenv("COATTN_GEMM_X3"); return e ? atoi(e) : 1; }();
+  static const int x3 = dev_env_int("COATTN_GEMM_X3", 1);
   if (x3 >= 1) {
     const int rc = launch_gemm_impl(d, s, 2);            // 0 launched, < 0 error, 1 not eligible
     if (rc <= 0) return rc;

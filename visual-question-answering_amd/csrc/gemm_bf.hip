@@ -454,7 +454,7 @@ namespace {
 
 // COATTN_GEMM_BF=0 (developer switch): gemm_w's single-piece mode instead
 int gemm_bf_enabled() {
-  static const int on = [] { const char* e = getenv("COATTN_GEMM_BF"); return e ? atoi(e) : 1; }();
+  static const int on = dev_env_int("COATTN_GEMM_BF", 1);
   return on;
 }
 

@@ -382,7 +382,7 @@ int launch_gemm_tn(const TnGemm* d, const int* ksplit, const int* S, int n, hipS
   // workgroup per CU -- which the hardware then grants -- costs the weight-gradient parts more in L2 than it hides
   // (channel-major cfg 2 at N = 196: 176 us against 165).  The LDS request is what holds it at two (3 x 54 KB > 160 KB);
   // developer switch COATTN_TN_LDS=<bytes> (0: as computed).
-  static const int lds_env = [] { const char* e = getenv("COATTN_TN_LDS"); return e ? atoi(e) : 55296; }();
+  static const int lds_env = dev_env_int("COATTN_TN_LDS", 55296);
   const size_t lds_max = (size_t)2 * 3 * (IMG + IMGB) * sizeof(short);     // (three pieces, BCM: 67,584 B)
   if (np == 2 && lds_env > 0 && (size_t)lds_env > lds && (size_t)lds_env <= (bcm ? lds_max : (size_t)65536)) lds = (size_t)lds_env;
   auto np_of = [](int bf16, int npf) { return bf16 ? 1 : (npf == 2 ? 2 : 3); };

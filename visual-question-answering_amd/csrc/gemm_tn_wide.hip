@@ -282,7 +282,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_tn_wide_kernel(const TwJobs jobs
 }  // namespace
 
 int gemm_tn_wide_supported(const TnGemm& d) {
-  static const int on = [] { const char* e = getenv("COATTN_TN_WIDE"); return e ? atoi(e) : 1; }();   // developer switch
+  static const int on = dev_env_int("COATTN_TN_WIDE", 1);   // developer switch
   return on && gemm_tn_supported(d) && !d.bf16 && d.np == 2 && d.mask_blk == 0 && (d.M % BM) == 0 && (d.N % BN) == 0;
 }
 

@@ -30,8 +30,8 @@ using namespace gw;
 
 struct WJobs { WArgs job[2]; int first1; };   // blocks [0, first1) work on job 0, the rest on job 1
 
-struct SplitJob { const float* W; void* out; int N, K, trans, ld, pieces; };
-struct SplitArgs { SplitJob job[3]; int njobs; };
+struct SplitJob { const float* W; void* out; int N, K, trans, ld, pieces; float* amax; };
+struct SplitArgs { SplitJob job[3]; int njobs; float* status_hdr; float f16; };
 
 // One wave per (32-column tile nt, 16-k step ks): lane (li = lane & 31, lh = lane >> 5) holds
 // Bw(k = 16 ks + 8 lh + e, n = 32 nt + li), e = 0..7 -- the B operand layout of v_mfma_f32_32x32x16_bf16.
@@ -39,6 +39,8 @@ struct SplitArgs { SplitJob job[3]; int njobs; };
 __global__ __launch_bounds__(256) void wsplit_kernel(const SplitArgs a) {
   const SplitJob j = a.job[blockIdx.y];
   f16_saturating_conversions();                      // (only the pieces = 16 jobs convert to fp16)
+  // header of the call's status words (fused.h kStatusHdr): the projection launch behind this one raises [0]
+  if (a.status_hdr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.status_hdr[0] = 0.f; a.status_hdr[1] = a.f16; }
   const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
   const int ks16 = (j.K + 15) / 16, nt32 = (j.N + 31) / 32;
   const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -53,11 +55,18 @@ __global__ __launch_bounds__(256) void wsplit_kernel(const SplitArgs a) {
   }
   if (j.pieces == 16) {                              // two FP16 pieces of kF16WScale * W (fused.h), in the slots of pieces 0 and 1
     u32x4 h, m;
+    float amax = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       unsigned hh, mm;
-      split_pair_h(v[2 * e] * kF16WScale, v[2 * e + 1] * kF16WScale, hh, mm);
+      const float w0 = v[2 * e] * kF16WScale, w1 = v[2 * e + 1] * kF16WScale;
+      amax = fmaxf(amax, fmaxf(fabsf(w0), fabsf(w1)));
+      split_pair_h(w0, w1, hh, mm);
       h[e] = hh; m[e] = mm;
+    }
+    if (j.amax) {                                    // range report (coattn_status): one word per wave, no atomics, no zeroing
+      amax = wave_max(amax);
+      if (lane == 0) j.amax[chunk] = amax;
     }
     char* out = (char*)j.out + (size_t)chunk * kChunkBytes + lane * 16;
     *reinterpret_cast<u32x4*>(out) = h;
@@ -94,15 +103,16 @@ __global__ __launch_bounds__(64 * NW, (NP == 2 && NP1 == 2 && NW == 4) ? GEMMW_O
 
 size_t wsplit_bytes(int N, int K) { return (size_t)((N + 31) / 32) * ((K + 15) / 16) * kChunkBytes; }
 
-int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s) {
+int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s, float* status_hdr, int f16) {
   CA_CHECK_ARG(njobs >= 1 && njobs <= 3, "wsplit: 1 to 3 jobs per launch");
   SplitArgs a = {};
   a.njobs = njobs;
+  a.status_hdr = status_hdr; a.f16 = f16 ? 1.f : 0.f;
   int chunks = 0;
   for (int i = 0; i < njobs; ++i) {
     CA_CHECK_ARG(jobs[i].W && jobs[i].out && jobs[i].N > 0 && jobs[i].K > 0, "wsplit: bad job");
     a.job[i] = SplitJob{jobs[i].W, jobs[i].out, jobs[i].N, jobs[i].K, jobs[i].trans, jobs[i].ld,
-                        jobs[i].pieces == 1 ? 1 : (jobs[i].pieces == 16 ? 16 : 3)};
+                        jobs[i].pieces == 1 ? 1 : (jobs[i].pieces == 16 ? 16 : 3), jobs[i].pieces == 16 ? jobs[i].amax : nullptr};
     const int c = ((jobs[i].N + 31) / 32) * ((jobs[i].K + 15) / 16);
     chunks = c > chunks ? c : chunks;
   }
@@ -144,6 +154,7 @@ int gemm_w_fill_job(const WGemm& d, gw::WArgs& g, long* nblk, int bn) {
   for (int t = 0; t < 8; ++t) { g.a_ptrs[t] = d.a_ptrs[t]; g.c_ptrs[t] = d.c_ptrs[t]; }
   g.bias_n = d.bias_n; g.oscale = d.out_scale != 0.f ? d.out_scale : 1.f;
   g.ascale = (d.f16 && d.np == 2 && !d.bf16) ? 1.0f / kF16WScale : 1.0f;
+  g.status = g.ascale != 1.0f ? d.status : nullptr;
   g.M = d.M; g.N = d.N; g.K = d.K;
   const long ntn = (d.N + bn - 1) / bn, ntm = (d.M + BM - 1) / BM;
   g.xcd_group = ntm >= 32 ? 1 : 0;
@@ -157,8 +168,8 @@ int launch_gemm_w(const WGemm* d, int n, hipStream_t s) {
   WJobs jobs = {};
   long nb[2] = {0, 0};
   // single-product mode with wide outputs: 128 x 256 tiles on 512 threads (the A rows are staged once for twice the columns)
-  static const int wide2 = [] { const char* e = getenv("COATTN_GEMMW_WIDE2"); return e ? atoi(e) : 0; }();   // developer switch
-  static const int wide32 = [] { const char* e = getenv("COATTN_GEMMW_WIDE32"); return e ? atoi(e) : 0; }();  // developer switch: the forward's (3, 2) launch
+  static const int wide2 = dev_env_int("COATTN_GEMMW_WIDE2", 0);   // developer switch
+  static const int wide32 = dev_env_int("COATTN_GEMMW_WIDE32", 0);  // developer switch: the forward's (3, 2) launch
   const bool mixed32 = wide32 && !d[0].bf16 && n == 2 && d[0].np != 2 && d[1].np == 2;
   bool wide = d[0].bf16 != 0 || (wide2 && d[0].np == 2 && (n == 1 || d[1].np == 2)) || mixed32;
   for (int i = 0; i < n; ++i) wide = wide && d[i].N % 256 == 0 && (d[i].kband_n == 0 || d[i].kband_n % 256 == 0);

@@ -28,6 +28,7 @@ struct WArgs {
   const float* bias_n; float oscale;
   float ascale;                                // on the accumulators (1, or 1 / kF16WScale for an FP16 weight image)
   int M, N, K, xcd_group;
+  float* status;                               // (H) word [0] of the call's status words (fused.h kStatusHdr), or NULL
 };
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -147,6 +148,7 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
   bf16x8 af[2][3][2];                            // [half][piece][tile i]
   unsigned ph[2], pm[2], pl[2];                  // packed pieces of the raw[i] being split (its two pairs)
   float ra[2], rb[2];
+  float amax = 0.f;                              // (H) largest |value| this thread converted to FP16 pieces or stored (range report)
   constexpr int PA[6] = {2, 0, 1, 1, 0, 0};      // smallest terms first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
   constexpr int PB[6] = {0, 2, 1, 0, 1, 0};      // (gemm.hip's order)
   constexpr int RQ[3] = {2, 0, 1};               // fragment read order = order of first use
@@ -185,6 +187,7 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
 #else
     if (H) {
       if (st == 0) {
+        amax = fmaxf(amax, fmaxf(fabsf(raw[i][2 * e]), fabsf(raw[i][2 * e + 1])));   // one v_max3_f32 with |.| modifiers
         const hfv2 hh = __builtin_convertvector((f32x2{raw[i][2 * e], raw[i][2 * e + 1]}), hfv2);
         ph[e] = __builtin_bit_cast(unsigned, hh);
         ra[e] = sub1(raw[i][2 * e], (float)hh[0]);
@@ -322,9 +325,19 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
 #if GEMMW_NTSTORE
         if (col[j] < g.N) __builtin_nontemporal_store((acc[i][j][r] + bn[j]) * g.oscale, &crow[col[j]]);
 #else
-        if (col[j] < g.N) crow[col[j]] = H ? fmaf(acc[i][j][r], g.ascale, bn[j]) * g.oscale : (acc[i][j][r] + bn[j]) * g.oscale;
+        if (col[j] < g.N) {
+          const float y = H ? fmaf(acc[i][j][r], g.ascale, bn[j]) * g.oscale : (acc[i][j][r] + bn[j]) * g.oscale;
+          if (H) amax = fmaxf(amax, fabsf(y));   // (the stored projection is an FP16-piece operand of the fused kernels)
+          crow[col[j]] = y;
+        }
 #endif
     }
+  // Range report of the tolerance mode: a wave that met a magnitude beyond the exact-piece range raises the call's status
+  // word (positive floats order like their bit patterns) -- the rare case; every other wave pays one compare.
+  if (H && g.status && __builtin_amdgcn_ballot_w64(!(amax <= kF16Exact)) != 0) {
+    amax = wave_max(amax);
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(g.status), __builtin_bit_cast(unsigned, amax));
+  }
 }
 
 }  // namespace gw

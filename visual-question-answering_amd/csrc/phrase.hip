@@ -146,8 +146,9 @@ __global__ __launch_bounds__(256) void phrase_wsplit_kernel(const float* __restr
                                                             const float* __restrict__ W3, const float* __restrict__ b1,
                                                             const float* __restrict__ b2, const float* __restrict__ b3,
                                                             char* __restrict__ img, float* __restrict__ bcat, int E,
-                                                            int trans, int pieces) {
+                                                            int trans, int pieces, float* __restrict__ status) {
   const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (status && gid == 0) { status[0] = 0.f; status[1] = pieces == 16 ? 1.f : 0.f; }   // header of the status words (fused.h kStatusHdr)
   if (bcat && gid < 3 * E) bcat[gid] = gid < E ? b1[gid] : (gid < 2 * E ? b2[gid - E] : b3[gid - 2 * E]);
   const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
   const int ks16 = 3 * E / 16, chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -157,7 +158,10 @@ __global__ __launch_bounds__(256) void phrase_wsplit_kernel(const float* __restr
   // (c, col) = (output channel of cat(uni, bi, tri), column of Xcat); a chunk lies inside one E x E block (E % 32 == 0)
   const int c = trans ? k0 : n, col0 = trans ? n : k0;
   const int g = c / E, jb = col0 / E;
-  if ((g == 0 && jb != 1) || (g == 1 && jb == 2)) return;
+  if ((g == 0 && jb != 1) || (g == 1 && jb == 2)) {
+    if (status && pieces == 16 && lane == 0) status[kStatusHdr + chunk] = 0.f;
+    return;
+  }
   f32x8 v;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -167,11 +171,18 @@ __global__ __launch_bounds__(256) void phrase_wsplit_kernel(const float* __restr
   if (pieces == 16) {                                // two FP16 pieces of kF16WScale * W (fused.h), as gemm_w.hip's wsplit_kernel
     f16_saturating_conversions();
     u32x4 h, m;
+    float amax = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       unsigned hh, mm;
-      split_pair_h(v[2 * e] * kF16WScale, v[2 * e + 1] * kF16WScale, hh, mm);
+      const float w0 = v[2 * e] * kF16WScale, w1 = v[2 * e + 1] * kF16WScale;
+      amax = fmaxf(amax, fmaxf(fabsf(w0), fabsf(w1)));
+      split_pair_h(w0, w1, hh, mm);
       h[e] = hh; m[e] = mm;
+    }
+    if (status) {                                    // range report (coattn_phrase_status): one word per wave
+      amax = wave_max(amax);
+      if (lane == 0) status[kStatusHdr + chunk] = amax;
     }
     char* out = img + (size_t)chunk * gw::kChunkBytes + lane * 16;
     *reinterpret_cast<u32x4*>(out) = h;
@@ -222,7 +233,7 @@ PhrasePlan plan_phrase(int B, int T, int E) {
 
 // COATTN_GEMM_W=0 (developer switch): the general GEMM of gemm.hip instead of the hand-scheduled kernels
 bool hand_gemms() {
-  static const int on = [] { const char* e = getenv("COATTN_GEMM_W"); return e ? atoi(e) : 1; }();
+  static const int on = dev_env_int("COATTN_GEMM_W", 1);
   return on != 0;
 }
 
@@ -237,7 +248,7 @@ int check_phrase(const void* X, const coattn_phrase_params* p, int B, int T, int
 // wimg_trans < 0: Wcat and bcat as fp32 arrays (general GEMM); 0 / 1: the weight image of gemm_w for the forward /
 // the dXcat product instead (+ bcat)
 int build_operands(const float* X, const coattn_phrase_params* p, char* ws, const PhrasePlan& pl, int B, int T, int E,
-                   hipStream_t s, int wimg_trans = -1, int pieces = 3) {
+                   hipStream_t s, int wimg_trans = -1, int pieces = 3, float* status = nullptr) {
   const long bt = (long)B * T;
   float* Xcat = reinterpret_cast<float*>(ws + pl.xcat);
   if ((E & 3) == 0 && ((((uintptr_t)X) | ((uintptr_t)Xcat)) & 15) == 0) {
@@ -252,9 +263,13 @@ int build_operands(const float* X, const coattn_phrase_params* p, char* ws, cons
     const int chunks = (3 * E / 16) * (3 * E / 32);
     hipLaunchKernelGGL(phrase_wsplit_kernel, dim3((unsigned)((chunks + 3) / 4)), dim3(256), 0, s, (const float*)p->W1,
                        (const float*)p->W2, (const float*)p->W3, (const float*)p->b1, (const float*)p->b2,
-                       (const float*)p->b3, ws + pl.wimg, reinterpret_cast<float*>(ws + pl.bcat), E, wimg_trans, pieces);
+                       (const float*)p->b3, ws + pl.wimg, reinterpret_cast<float*>(ws + pl.bcat), E, wimg_trans, pieces, status);
     CA_CHECK_LAUNCH("phrase_wsplit");
     return 0;
+  }
+  if (status && hipMemsetAsync(status, 0, 2 * sizeof(float), s) != hipSuccess) {   // (no weight-split launch: header = "no FP16 pieces")
+    coattn_set_error("phrase: hipMemsetAsync failed");
+    return -3;
   }
   const long nw = 9L * E * E;
   hipLaunchKernelGGL(phrase_pack_w_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s,
@@ -272,7 +287,8 @@ extern "C" int coattn_phrase_workspace_bytes(int B, int T, int E, int dtype, siz
   CA_CHECK_ARG(dtype == COATTN_F32, "phrase: only COATTN_F32 is implemented");
   CA_CHECK_ARG(B >= 1 && T >= 1 && E >= 1, "phrase: B, T, E must be >= 1 (got %d, %d, %d)", B, T, E);
   const PhrasePlan pl = plan_phrase(B, T, E);
-  if (saved) *saved = al256((size_t)B * T * E);             // argmax index per output element, 1 byte each
+  // argmax index per output element, 1 byte each; then the status words of coattn_phrase_status
+  if (saved) *saved = al256((size_t)B * T * E) + al256(status_floats(3 * E, 3 * E, 1) * sizeof(float));
   if (ws_fwd) *ws_fwd = pl.total_fwd;
   if (ws_bwd) *ws_bwd = pl.total_bwd;
   return 0;
@@ -292,10 +308,13 @@ extern "C" int coattn_phrase_forward(const void* X, const coattn_phrase_params* 
   wg.C = reinterpret_cast<float*>(w + pl.z); wg.c_sm = 3 * E; wg.bias_n = reinterpret_cast<const float*>(w + pl.bcat);
   wg.M = B * T; wg.N = 3 * E; wg.K = 3 * E; wg.batch = 1;
   wg.bf16 = bf16 ? 1 : 0;                                // reduced precision: one MFMA per product (gemm_bf.hip / gemm_w.hip)
-  // fp32 mode: the forward product Z = Xcat Wcat^T on two FP16 pieces per operand, as the co-attention's projections
-  // (fused.h; its operands are word features and conv weights) -- COATTN_FLAG_EXACT3 / COATTN_FWD_F16=0: the exact bf16 split
-  static const int f16_env = [] { const char* e = getenv("COATTN_FWD_F16"); return e ? atoi(e) : 1; }();
-  if (!bf16 && !(flags & COATTN_FLAG_EXACT3) && f16_env) { wg.np = 2; wg.f16 = 1; }
+  // fp32 mode, COATTN_FLAG_FAST16: the forward product Z = Xcat Wcat^T on two FP16 pieces per operand, as the co-attention's
+  // projections (fused.h; its operands are word features and conv weights; range report: coattn_phrase_status, which needs
+  // `saved`) -- default: the exact bf16 split
+  static const int f16_env = dev_env_int("COATTN_FWD_F16", 1), split_env = dev_env_int("COATTN_SPLIT", 2);
+  const bool fast = (flags & COATTN_FLAG_FAST16) && !(flags & COATTN_FLAG_EXACT3) && split_env != 3;
+  float* status = saved ? reinterpret_cast<float*>(static_cast<char*>(saved) + al256((size_t)B * T * E)) : nullptr;
+  if (!bf16 && fast && f16_env && status) { wg.np = 2; wg.f16 = 1; wg.status = status; }
   if (E % 128 == 0) {                                    // (k bands first: the kernel and its weight-image format depend on them)
     wg.kband_n = E;
     wg.kband_lo[0] = E; wg.kband_hi[0] = 2 * E;
@@ -303,7 +322,8 @@ extern "C" int coattn_phrase_forward(const void* X, const coattn_phrase_params* 
     wg.kband_lo[2] = 0; wg.kband_hi[2] = 3 * E;
   }
   const bool hand = hand_gemms() && E % 128 == 0 && gemm_w_supported(wg);
-  CA_TRY(build_operands((const float*)X, p, w, pl, B, T, E, s, hand ? 0 : -1, wimg_pieces(wg)));
+  if (!hand) { wg.np = 0; wg.f16 = 0; wg.status = nullptr; }   // general GEMM: exact
+  CA_TRY(build_operands((const float*)X, p, w, pl, B, T, E, s, hand ? 0 : -1, wimg_pieces(wg), status));
   coattn_gemm_desc g = {};
   g.A = w + pl.xcat; g.B = w + pl.wcat; g.C = w + pl.z; g.bias_n = w + pl.bcat;
   g.M = B * T; g.N = 3 * E; g.K = 3 * E; g.batch = 1; g.inner = 1;
@@ -328,6 +348,12 @@ extern "C" int coattn_phrase_forward(const void* X, const coattn_phrase_params* 
   return 0;
 }
 
+extern "C" int coattn_phrase_status(const void* saved, int B, int T, int E, void* stream, float* amax) {
+  CA_CHECK_ARG(saved != nullptr && B >= 1 && T >= 1 && E >= 1, "phrase_status: bad argument");
+  const float* status = reinterpret_cast<const float*>(static_cast<const char*>(saved) + al256((size_t)B * T * E));
+  return read_status_words(status, (int)status_floats(3 * E, 3 * E, 1), (hipStream_t)stream, amax, "coattn_phrase_status");
+}
+
 extern "C" int coattn_phrase_backward(const void* X, const coattn_phrase_params* p, const void* out, const void* saved,
                                       const void* g_out, void* dX, const coattn_phrase_param_grads* pg, int accumulate,
                                       void* ws, int B, int T, int E, int dtype, int flags, void* stream) {
@@ -347,10 +373,10 @@ extern "C" int coattn_phrase_backward(const void* X, const coattn_phrase_params*
   wdx.A = dZ; wdx.a_sm = 3 * E; wdx.Wf = w + pl.wimg; wdx.C = reinterpret_cast<float*>(w + pl.xcat); wdx.c_sm = 3 * E;
   wdx.M = (int)bt; wdx.N = 3 * E; wdx.K = 3 * E; wdx.batch = 1;
   wdx.bf16 = bf16 ? 1 : 0;
-  // fp32 mode: the two gradient products (dXcat = dZ Wcat, dWcat = dZ^T Xcat) on two bf16 pieces per operand, as the
-  // co-attention's backward (fused.h "Widths": gradients keep bf16's range) -- COATTN_FLAG_EXACT3 / COATTN_SPLIT=3: three
-  static const int split_env = [] { const char* e = getenv("COATTN_SPLIT"); return e ? atoi(e) : 2; }();
-  const int np_b = (!bf16 && !(flags & COATTN_FLAG_EXACT3) && split_env != 3) ? 2 : 3;
+  // fp32 mode, COATTN_FLAG_FAST16: the two gradient products (dXcat = dZ Wcat, dWcat = dZ^T Xcat) on two bf16 pieces per
+  // operand, as the co-attention's backward (fused.h "Widths": gradients keep bf16's range) -- default: three
+  static const int split_env = dev_env_int("COATTN_SPLIT", 2);
+  const int np_b = (!bf16 && (flags & COATTN_FLAG_FAST16) && !(flags & COATTN_FLAG_EXACT3) && split_env != 3) ? 2 : 3;
   wdx.np = np_b;
   if (E % 128 == 0) {                                    // tap block j of dXcat receives only the n-grams that have that tap
     wdx.kband_n = E;

@@ -59,11 +59,15 @@ def init_from_env(backend: str | None = None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = os.environ.get("VQA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        import datetime
+        # (VQA_DIST_TIMEOUT_S: a rank that never arrives ends the others with an error after this long, not after the
+        #  backend's own default)
+        tmo = datetime.timedelta(seconds=int(os.environ.get("VQA_DIST_TIMEOUT_S", "600")))
         if backend == "nccl":
             torch.cuda.set_device(local)
-            dist.init_process_group(backend, rank=rk, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group(backend, rank=rk, world_size=world, device_id=torch.device("cuda", local), timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rk, world_size=world)
+            dist.init_process_group(backend, rank=rk, world_size=world, timeout=tmo)
     return rk, world, local
 
 
@@ -93,6 +97,7 @@ class _Bucket:
             o += p.numel()
         self.pending = len(params)
         self.work = None
+        self.host = None                                  # direct exchange under gloo with CUDA buckets: host copy of the bucket
 
 
 class GradReducer:
@@ -184,22 +189,29 @@ class GradReducer:
 
     def _p2p_setup(self):
         """Map every peer's buckets into this process (once per bucket layout).  Exactly one collective
-        (all_gather_object), which every rank reaches whether or not its own part failed -- a rank that raises afterwards
-        leaves no peer waiting (the caller's consensus all-reduce comes next on every rank)."""
+        (all_gather_object), which every rank reaches whether or not its own part failed: EVERYTHING that can fail before it
+        -- loading the library, the dtype / device checks, the synchronisation, exporting the IPC handles -- runs inside the
+        try block whose outcome is what the rank contributes (a rank that raised before the collective left the
+        others waiting in it).  A rank that raises afterwards leaves no peer waiting (the caller's consensus all-reduce
+        comes next on every rank)."""
         import ctypes as C
-        from torch.multiprocessing.reductions import reduce_tensor
-        from . import _lib
-        self._lib = _lib.load()
+        mine = None
         self.rank = dist.get_rank(self.group)
-        for b in self.buckets:
-            if b.flat.dtype != torch.float32 or not b.flat.is_cuda:
-                raise RuntimeError("exchange='p2p' takes fp32 gradients on a GPU")
-        self._dev = self.buckets[0].flat.device
-        torch.cuda.synchronize(self._dev)
         try:
-            mine = [reduce_tensor(b.flat) for b in self.buckets]       # (rebuild function, IPC handle + offset) per bucket
-        except Exception as e:                                         # noqa: BLE001
+            from torch.multiprocessing.reductions import reduce_tensor
+            from . import _lib
+            self._lib = _lib.load()
+            for b in self.buckets:
+                if b.flat.dtype != torch.float32 or not b.flat.is_cuda:
+                    raise RuntimeError("exchange='p2p' takes fp32 gradients on a GPU")
+            self._dev = self.buckets[0].flat.device
+            torch.cuda.synchronize(self._dev)
+            if os.environ.get("VQA_P2P_FAIL_RANK") == str(self.rank):       # test hook: this rank cannot export
+                raise RuntimeError("export failure injected by VQA_P2P_FAIL_RANK")
+            mine = [reduce_tensor(b.flat) for b in self.buckets]           # (rebuild function, IPC handle + offset) per bucket
+        except Exception as e:                                             # noqa: BLE001
             mine = "%s: %s" % (type(e).__name__, e)
+            self._dev = self.buckets[0].flat.device
         every = [None] * self.world
         dist.all_gather_object(every, mine, group=self.group)
         for r, m in enumerate(every):
@@ -214,6 +226,7 @@ class GradReducer:
                     # peer access from this rank's device to the bucket's (an error here, not a faulting kernel later),
                     # then one small copy through torch as a check of the mapping
                     with torch.cuda.device(b.flat.device):
+                        from . import _lib
                         _lib.check(self._lib.coattn_p2p_enable_peer(t.device.index), "coattn_p2p_enable_peer")
                     b.flat.new_empty(4).copy_(t[:4])
             b.peer_ptrs = (C.c_void_p * self.world)(*[t.data_ptr() for t in b.peers])
@@ -259,11 +272,20 @@ class GradReducer:
             b.work = False                              # packed; p2p: the exchange runs in finish(), "none": nothing sent
         elif self.exchange == "direct":
             # stage 1: shard j of this rank's bucket goes straight to rank j (stage 2 in finish())
-            if b.recv is None:
-                b.recv = torch.empty_like(b.flat)
-            b.work = dist.all_to_all_single(b.recv, b.flat, group=self.group, async_op=True)
+            # (gloo has no all-to-all / all-gather on CUDA tensors: there -- ranks rehearsing on one GPU -- the same
+            #  collectives run on a host copy of the bucket; the shard arithmetic and the order of the sums are the same)
+            src = b.flat
+            if self._host_staged(b):
+                b.host = b.flat.cpu()
+                src = b.host
+            if b.recv is None or b.recv.device != src.device:
+                b.recv = torch.empty_like(src)
+            b.work = dist.all_to_all_single(b.recv, src, group=self.group, async_op=True)
         else:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _host_staged(self, b) -> bool:
+        return b.flat.is_cuda and dist.get_backend(self.group) == "gloo"
 
     def _on_grad(self, p):
         bi, _ = self._where[p]
@@ -299,9 +321,13 @@ class GradReducer:
                 for r in range(1, self.world):
                     shard.add_(pieces[r])
                 shard.div_(self.world)
-                gathers.append((dist.all_gather_into_tensor(b.flat, shard, group=self.group, async_op=True), shard))
+                dst = b.host if self._host_staged(b) else b.flat
+                gathers.append((dist.all_gather_into_tensor(dst, shard, group=self.group, async_op=True), shard))
             for work, _ in gathers:
                 work.wait()
+            for b in self.buckets:
+                if self._host_staged(b):
+                    b.flat.copy_(b.host)
         for b in self.buckets:
             if self.exchange == "allreduce":
                 b.work.wait()

@@ -22,6 +22,14 @@ left is the ~25 kernel launches).  It is what ``train.Trainer`` uses by default.
 it when it owns the step: gradients are consumed by the optimiser before the next backward, and no gradient hooks need
 to fire) assigns the static gradient buffers to ``param.grad`` instead of handing them to autograd, whose AccumulateGrad
 would clone each of the 16 (it cannot steal a buffer somebody else still holds): 16 copy kernels per step less.
+Contract of ``direct_grads``: ``param.grad`` ALIASES a static buffer that the next backward rewrites -- whoever keeps a
+reference to it across steps (a gradient logger, an EMA of gradients) must clone it.  A second backward without a
+``zero_grad(set_to_none=True)`` in between (micro-batch accumulation) is supported in eager mode: the kernels then ADD into
+the buffers (C-ABI ``accumulate = 1``); with captured graphs, or when only some of the 16 parameters still hold the static
+buffer, it raises instead of dropping the earlier gradient.
+
+``logits`` is returned as a fresh tensor (``alias_outputs=True``: the static buffer itself, overwritten by the next
+step).  A gradient arriving for ``logits`` is added by the head's backward in eager mode; under graph capture it raises.
 """
 from __future__ import annotations
 
@@ -47,9 +55,9 @@ class HotPathGraph:
     MAX_KEYS = 8
 
     def __init__(self, co_attention, mlp_classify, B: int, N: int, T: int, need_dv: bool = False, flags: int = 0,
-                 capture: bool = True, direct_grads: bool = False):
+                 capture: bool = True, direct_grads: bool = False, alias_outputs: bool = False):
         self.co, self.mlp = co_attention, mlp_classify
-        self.capture, self.direct_grads = capture, direct_grads
+        self.capture, self.direct_grads, self.alias_outputs = capture, direct_grads, alias_outputs
         d = co_attention.hidden_dim
         mlp, K = mlp_classify.W_s.weight.shape[0], mlp_classify.W_h.weight.shape[0]
         self.dims = (B, N, T, d, mlp, K)
@@ -68,14 +76,14 @@ class HotPathGraph:
         self.dx = torch.empty((3, B, d), **f32)                      # d(q_l + v_l): upstream gradient of both v and q
         self.dV = torch.empty((B, N, d), **f32) if need_dv else None
         self.dQ = [torch.empty((B, T, d), **f32) for _ in range(3)]
-        self.co_params = [co_attention.W_v.weight, co_attention.W_v.bias, co_attention.W_q.weight, co_attention.W_q.bias,
-                          co_attention.w_v.weight, co_attention.w_v.bias, co_attention.w_q.weight, co_attention.w_q.bias]
-        self.head_params = [mlp_classify.W_w.weight, mlp_classify.W_w.bias, mlp_classify.W_p.weight, mlp_classify.W_p.bias,
-                            mlp_classify.W_s.weight, mlp_classify.W_s.bias, mlp_classify.W_h.weight, mlp_classify.W_h.bias]
+        self.co_params, self.head_params = self._param_lists(co_attention, mlp_classify)
         for p in self.co_params + self.head_params:
             if not p.is_contiguous() or p.dtype != torch.float32:
                 raise RuntimeError("HotPathGraph: parameters must be contiguous fp32")
-        self.param_ptr0 = self.co_params[0].data_ptr()                # (modules.HierarchicalCoAttentionNet checks it: the module may move)
+        # (modules.HierarchicalCoAttentionNet checks them: the plans / graphs hold raw addresses of all 16 parameters, and
+        #  .to(), p.data = ..., load_state_dict(assign=True) re-point storage without touching the Parameter objects)
+        self.param_ptrs = tuple(p.data_ptr() for p in self.co_params + self.head_params)
+        self.param_ptr0 = self.param_ptrs[0]
         self.co_grads = [torch.empty_like(p) for p in self.co_params]
         self.head_grads = [torch.empty_like(p) for p in self.head_params]
         sb, fb, bb = _lib.workspace_bytes(B, N, T, d, 3, flags)
@@ -89,6 +97,19 @@ class HotPathGraph:
         self._static = (self.V, self.Q[0], self.Q[1], self.Q[2], self.labels)
         self._lib = _lib.load()
         self.pair(self._static)
+
+    @staticmethod
+    def _param_lists(co, mlp):
+        return ([co.W_v.weight, co.W_v.bias, co.W_q.weight, co.W_q.bias, co.w_v.weight, co.w_v.bias, co.w_q.weight, co.w_q.bias],
+                [mlp.W_w.weight, mlp.W_w.bias, mlp.W_p.weight, mlp.W_p.bias, mlp.W_s.weight, mlp.W_s.bias, mlp.W_h.weight, mlp.W_h.bias])
+
+    def stale(self) -> bool:
+        """True if any of the 16 parameters this node reads by raw address is no longer the module's Parameter object, or
+        has had its storage re-pointed (.to(), p.data = ..., load_state_dict(assign=True)): the node must be rebuilt."""
+        co, head = self._param_lists(self.co, self.mlp)
+        now = co + head
+        mine = self.co_params + self.head_params
+        return any(a is not b for a, b in zip(now, mine)) or tuple(p.data_ptr() for p in now) != self.param_ptrs
 
     def _key(self, ins):
         V = ins[0]
@@ -127,6 +148,11 @@ class HotPathGraph:
             "co_bwd": (_ptr(V), *vs, qptr, C.byref(p), _ptr(self.saved), _ptr(self.dx), _ptr(self.dx), _ptr(self.dV), *dvs,
                        dqptr, C.byref(pg), 0, _ptr(self.ws), B, N, T, d, 3, _lib.F32, self.flags),
         }
+        # (variants of the two backward calls: a gradient arriving for the logits; accumulate = 1 for a second backward
+        #  onto the same static gradient buffers)
+        plan["head_bwd_args"] = lambda g_logits, acc: plan["head_bwd"][:5] + (_ptr(g_logits),) + plan["head_bwd"][6:9] + (acc,) + plan["head_bwd"][10:]   # noqa: E731
+        plan["co_bwd_args"] = lambda acc: plan["co_bwd"][:15] + (acc,) + plan["co_bwd"][16:]   # noqa: E731
+        assert plan["head_bwd"][9] == 0 and plan["head_bwd"][5] is None and plan["co_bwd"][15] == 0
         self._plans[key] = plan
         return plan
 
@@ -187,9 +213,20 @@ class HotPathGraph:
         """The same calls without the graphs (tests compare the two bit for bit)."""
         self._enqueue(ins or self._static, torch.cuda.current_stream(self.device).cuda_stream)
 
-    def run(self, pair, ins, fwd: bool, plan=None):
+    def run(self, pair, ins, fwd: bool, plan=None, g_logits=None, accumulate: int = 0):
         """One direction of the hot path: replay the captured graph, or (eager mode) issue its two C-ABI calls (`plan`: the
-        argument blocks of `ins`, if the caller has them already)."""
+        argument blocks of `ins`, if the caller has them already).  g_logits / accumulate (backward, eager mode only): an
+        upstream gradient of the logits to add; add into the parameter-gradient buffers instead of overwriting them."""
+        if pair is not _EAGER and (g_logits is not None or accumulate):
+            raise RuntimeError("HotPathGraph: a gradient for `logits` / a second backward onto the same gradient buffers "
+                               "cannot be replayed from the captured graph (use capture=False, or the module path)")
+        if pair is _EAGER and not fwd and (g_logits is not None or accumulate):
+            plan = plan or self._plan(ins)
+            st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            with _lib.on_device(self.device):
+                _lib.check(self._lib.coattn_head_backward(*plan["head_bwd_args"](g_logits, accumulate), st), "coattn_head_backward")
+                _lib.check(self._lib.coattn_backward(*plan["co_bwd_args"](accumulate), st), "coattn_backward")
+            return
         if pair is _EAGER:
             plan = plan or self._plan(ins)
             lib = self._lib
@@ -260,17 +297,38 @@ class _HotPathFn(torch.autograd.Function):
         ctx.plan = plan
         # (as head.answer_head after a forward with labels: Trainer.check_labels() reads this step's status word)
         _head._last = (hp.hsaved, B, d, mlp, K, hp.device)
+        if hp.flags & _lib.FLAG_FAST16:                          # tolerance mode: this step's status words (_lib.check_range())
+            _lib._last_status["coattn"] = (hp.saved, (B, N, T, d, 3), hp.device)
         ctx.hp, ctx.pair = hp, pair
         ctx.keep = ins                                           # the graphs read these addresses again in backward
-        ctx.mark_non_differentiable(hp.logits)
-        return hp.logits, hp.loss.clone()
+        ctx.set_materialize_grads(False)                         # (an unused output arrives as None, not as zeros)
+        # logits: a fresh tensor by default -- the static buffer is overwritten by the next step
+        return (hp.logits if hp.alias_outputs else hp.logits.clone()), hp.loss.clone()
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g_logits, g_loss):
         hp = ctx.hp
-        hp.g_loss.copy_(g_loss.reshape(1))
-        hp.run(ctx.pair, ctx.keep, False, ctx.plan)
+        if g_loss is None and g_logits is None:
+            return (None,) * len(ctx.needs_input_grad)
+        if g_loss is None:
+            hp.g_loss.zero_()
+        else:
+            hp.g_loss.copy_(g_loss.reshape(1))
+        if g_logits is not None:
+            g_logits = g_logits.contiguous().float()
+        acc = 0
+        if hp.direct_grads:
+            # A second backward with the static buffers still in place as param.grad (no zero_grad(set_to_none=True) in
+            # between: micro-batch accumulation, retain_graph): the kernels must ADD, or the earlier gradient is lost
+            held = [p.grad is g for p, g in zip(hp.co_params + hp.head_params, hp.co_grads + hp.head_grads)]
+            if all(held):
+                acc = 1
+            elif any(held):
+                raise RuntimeError("HotPathGraph(direct_grads=True): some parameters still hold the static gradient buffer "
+                                   "from the previous backward and others do not -- call zero_grad(set_to_none=True) on all of "
+                                   "them before every backward, or on none")
+        hp.run(ctx.pair, ctx.keep, False, ctx.plan, g_logits=g_logits, accumulate=acc)
         if hp.direct_grads:
             # the owner of the step (train.Trainer) consumes the gradients before the next backward and needs no gradient
             # hooks: the static buffers BECOME param.grad (autograd's AccumulateGrad would clone each one -- it cannot

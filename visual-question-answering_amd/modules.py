@@ -186,13 +186,15 @@ class PhraseConvPool(nn.Module):
         self.conv_bigram = nn.Sequential(nn.ConstantPad1d((1, 0), 0), nn.Conv1d(emb_dim, emb_dim, 2, 1), nn.Tanh())
         self.conv_trigram = nn.Sequential(nn.ConstantPad1d((1, 1), 0), nn.Conv1d(emb_dim, emb_dim, 3, 1), nn.Tanh())
         self.max_pool = nn.MaxPool2d(kernel_size=(1, 3))
+        self.fast_products = False     # tolerance mode of the HIP path's fp32 products (train.Trainer(precision="fast") sets it)
 
     def forward(self, x_question):
         if x_question.is_cuda and os.environ.get("VQA_PHRASE_IMPL", "hip") != "stock":
             # MI355X path (csrc/phrase.hip): same parameters, same values; stock modules below on CPU
             from .phrase import phrase_conv_pool
             u, b, t = self.conv_unigram[1], self.conv_bigram[1], self.conv_trigram[1]
-            return phrase_conv_pool(x_question, u.weight, u.bias, b.weight, b.bias, t.weight, t.bias)
+            return phrase_conv_pool(x_question, u.weight, u.bias, b.weight, b.bias, t.weight, t.bias,
+                                    fast=self.fast_products)
         B, T, E = x_question.shape
         x = x_question.permute(0, 2, 1)                                          # [B, E, T]
         grams = torch.cat([self.conv_unigram(x), self.conv_bigram(x), self.conv_trigram(x)], dim=1)
@@ -354,17 +356,17 @@ class HierarchicalCoAttentionNet(nn.Module):
         B, N, _ = x_img_features.shape
         T = x_ques_features[0].shape[1]
         key = (B, N, T, bool(x_img_features.requires_grad), bool(self.co_attention.bf16_projections),
-               bool(self.mlp_classify.bf16_products), bool(self.hot_path_graph), bool(self.hot_path_direct_grads))
+               bool(self.mlp_classify.bf16_products), bool(self.hot_path_graph), bool(self.hot_path_direct_grads),
+               bool(self.co_attention.fast_products))
         hp = self._graphs.get(key)
         # (the node reads the parameters where they lie: one built before the module was moved -- .to(), .cuda(), new
         #  Parameter objects -- would read the old storage)
-        if hp is not None and (hp.co_params[0] is not self.co_attention.W_v.weight or hp.head_params[6] is not self.mlp_classify.W_h.weight
-                               or hp.co_params[0].data_ptr() != hp.param_ptr0):
+        if hp is not None and hp.stale():          # (all 16 parameters: any of them may have been replaced or re-pointed -- ADVICE r4)
             hp = None
         if hp is None:
             hp = self._graphs[key] = HotPathGraph(self.co_attention, self.mlp_classify, B, N, T, need_dv=key[3],
-                                                  flags=_lib.FLAG_BF16_PROJ if key[4] else 0, capture=key[6],
-                                                  direct_grads=key[7])
+                                                  flags=(_lib.FLAG_BF16_PROJ if key[4] else 0) | _lib.precision_flag(key[8] and not key[4]),
+                                                  capture=key[6], direct_grads=key[7])
         return hp(x_img_features, x_ques_features, labels)
 
 

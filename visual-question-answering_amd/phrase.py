@@ -49,6 +49,8 @@ class _PhraseConvPoolFn(torch.autograd.Function):
         with _lib.on_device(x.device):
             _lib.check(lib.coattn_phrase_forward(_ptr(X), C.byref(p), _ptr(out), _ptr(saved), _ptr(ws), B, T, E,
                                                  _lib.F32, flags, stream), "coattn_phrase_forward")
+        if (flags & _lib.FLAG_FAST16) and saved is not None:   # tolerance mode: this call's status words, for _lib.check_range()
+            _lib._last_status["phrase"] = (saved, (B, T, E), x.device)
         if need_grad:
             ctx.flags = flags
             ctx.save_for_backward(X, out, saved, *ps)
@@ -75,10 +77,12 @@ class _PhraseConvPoolFn(torch.autograd.Function):
         return (dX, *grads, None)
 
 
-def phrase_conv_pool(x, W1, b1, W2, b2, W3, b3, bf16=None):
+def phrase_conv_pool(x, W1, b1, W2, b2, W3, b3, bf16=None, fast=False):
     """x [B,T,E] -> [B,T,E]; weights in torch Conv1d layout ([E,E,k]) of the unigram / bigram / trigram convs.
     bf16: contract on the bf16 MFMA (fp32 storage / accumulation); default: when CUDA autocast is on --
-    the stock Conv1d modules would run in reduced precision there too."""
+    the stock Conv1d modules would run in reduced precision there too.  fast: the tolerance mode of the fp32 products
+    (include/coattn.h COATTN_FLAG_FAST16; default: fp32-accurate products)."""
     if bf16 is None:
         bf16 = x.is_cuda and torch.is_autocast_enabled("cuda")
-    return _PhraseConvPoolFn.apply(x, W1, b1, W2, b2, W3, b3, _lib.FLAG_BF16_PROJ if bf16 else 0)
+    return _PhraseConvPoolFn.apply(x, W1, b1, W2, b2, W3, b3,
+                                   (_lib.FLAG_BF16_PROJ if bf16 else 0) | _lib.precision_flag(fast and not bf16))

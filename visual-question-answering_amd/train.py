@@ -19,6 +19,7 @@ from typing import Dict
 
 import torch
 import torch.nn as nn
+import torch.utils.data
 
 from . import dist as vdist
 from .loss import CrossEntropyLoss
@@ -236,9 +237,17 @@ class Trainer:
     stream."""
 
     def __init__(self, model: nn.Module, lr: float = 1e-4, device=None, opt_lvl: int = 0,
-                 bucket_mb: float = 16.0, encoder_runahead: bool = True, graph: bool = False, static_hot_path: bool = True):
+                 bucket_mb: float = 16.0, encoder_runahead: bool = True, graph: bool = False, static_hot_path: bool = True,
+                 precision: str = "fast"):
         self.device = device or next(model.parameters()).device
         self.model = model
+        # Precision of the HIP path's fp32 products (include/coattn.h "Widths of the fp32 mode"): "fast" -- this trainer's
+        # default -- is the tolerance mode (forward products on two FP16 pieces = 22 significand bits, backward on two bf16
+        # pieces = 16; inside the reference contract of 1e-4 for operands below 65,504 in magnitude, and check_range()
+        # reports and falls back when one is not); "exact": fp32-accurate products over fp32's range, the modules' own default.
+        if precision not in ("fast", "exact"):
+            raise ValueError("precision must be 'fast' or 'exact'")
+        self.set_precision(precision)
         self.criterion = CrossEntropyLoss()      # nn.CrossEntropyLoss() semantics (main.py:94); fused HIP kernel on CUDA
         self.optimizer = torch.optim.Adam(model.parameters(), lr)
         self.opt_lvl = opt_lvl
@@ -336,6 +345,32 @@ class Trainer:
         self.optimizer.step()
         return loss
 
+    def set_precision(self, precision: str) -> None:
+        self.precision = precision
+        fast = precision == "fast"
+        co = getattr(self.model, "co_attention", None)
+        if co is not None and hasattr(co, "fast_products"):
+            co.fast_products = fast
+        for m in self.model.modules():
+            if m is not co and hasattr(m, "fast_products"):
+                m.fast_products = fast
+
+    def check_range(self) -> bool:
+        """Tolerance mode only: True if every operand of the last step's forward lay inside the FP16-piece range.  If one
+        did not (its pieces were clamped: that step's values are off), warn, switch this trainer to the exact mode for the
+        following steps and return False.  Synchronises -- call it where the loss is read on the host."""
+        if self.device.type != "cuda" or self.precision != "fast" or self.opt_lvl > 0:
+            return True
+        from . import _lib
+        try:
+            _lib.check_range()
+        except _lib.RangeError as e:
+            import warnings
+            warnings.warn("vqa_amd.Trainer: %s -- continuing in the exact mode" % e)
+            self.set_precision("exact")
+            return False
+        return True
+
     def check_labels(self) -> None:
         """Raise IndexError if a label of the last step lay outside [0, K) (the asynchronous HIP loss only sets a status
         word where nn.CrossEntropyLoss raises); synchronises -- call it where the loss is read on the host."""
@@ -364,18 +399,69 @@ class Trainer:
         return {"accuracy": 100.0 * n_ok / max(n, 1), "loss": loss / max(len(batches), 1)}
 
 
-def main(argv=None):
+class SyntheticVQADataset(torch.utils.data.Dataset):
+    """Samples shaped like VQADataset's (dataloader.py:72: {'image','question','ques_len','label'}) drawn from a seed per
+    index: images N(0,1), token ids U{2..vocab-1} zero-padded to max_seq_len, lengths U{3..max}, labels U{0..K}.  Stands
+    in for the dataset files this environment does not have; feeds the same DataLoader(batch_size, shuffle, drop_last,
+    num_workers) as main.py:129-130."""
+
+    def __init__(self, n_samples, image_size, max_seq_len, vocab_size, num_classes, seed):
+        self.n, self.size, self.T, self.vocab, self.K, self.seed = n_samples, image_size, max_seq_len, vocab_size, num_classes, seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 1000003 + i)
+        n = int(torch.randint(min(3, self.T), self.T + 1, (1,), generator=g))
+        q = torch.randint(2, self.vocab, (self.T,), generator=g) * (torch.arange(self.T) < n)
+        return {"image": torch.randn(3, *self.size, generator=g), "question": q, "ques_len": torch.tensor(n),
+                "label": torch.randint(0, self.K, (), generator=g)}
+
+
+def build_parser():
+    """The reference's command line (main.py:34-78; same names, types and meanings) plus what it lacks here: synthetic
+    data, precision, data-parallel launch through the environment.  The dataset / vocabulary flags are accepted so that
+    a reference command line parses; only --synthetic data exists in this environment."""
     ap = argparse.ArgumentParser(description="Visual Question Answering (MI355X co-attention path)")
+    # Experiment params (main.py:37-41; not `required` here: synthetic runs need no directory)
     ap.add_argument("--mode", default="train", choices=["train", "test"])
+    ap.add_argument("--expt_dir", type=str, default=None, help="root directory to save model & summaries")
+    ap.add_argument("--expt_name", type=str, default="expt")
+    ap.add_argument("--run_name", type=str, default="run")
     ap.add_argument("--model", default="attention", choices=["baseline", "attention", "bert", "attention_resnet", "attention_bert"])
+    # Data params (main.py:44-48)
+    ap.add_argument("--train_img", type=str, default=None)
+    ap.add_argument("--train_file", type=str, default=None)
+    ap.add_argument("--val_img", type=str, default=None)
+    ap.add_argument("--val_file", type=str, default=None)
     ap.add_argument("--num_cls", "-K", type=int_min_two, default=1000)
+    ap.add_argument("--vocab_file", type=str, default=None)
+    # Training params (main.py:54-59)
     ap.add_argument("--batch_size", "-bs", type=int, default=8)
-    ap.add_argument("--num_steps", type=int, default=20)
+    ap.add_argument("--num_epochs", "-ep", type=int, default=1,
+                    help="number of epochs (the reference's default is 50; an epoch here is --num_steps synthetic batches)")
     ap.add_argument("--learning_rate", "-lr", type=float, default=1e-4)
-    ap.add_argument("--log_interval", type=int, default=10)
+    ap.add_argument("--log_interval", type=int, default=10, help="interval size for logging training summaries")
+    ap.add_argument("--save_interval", type=int, default=3000, help="save model after `n` weight update steps (main.py:260-263)")
+    ap.add_argument("--val_size", type=int, default=0,
+                    help="validation set size for evaluating accuracy (samples; the reference's default is 10000; 0 = no "
+                         "validation: there is no --val_file here, the samples are synthetic)")
+    ap.add_argument("--K_eval", type=int, default=1000)
+    # Model params (main.py:65-67)
+    ap.add_argument("--model_ckpt", type=str, default=None, help="resume training; e.g. model_1000.pth (inside the log directory, or a path)")
     ap.add_argument("--vgg_wts_path", type=str, default=None)
     ap.add_argument("--vgg_train", type=str2bool, default="false")
-    ap.add_argument("--opt_lvl", type=int, default=0, choices=[0, 1, 2, 3])
+    # GPU params (main.py:72-73)
+    ap.add_argument("--gpu_id", type=int, default=0, help="cuda:gpu_id of a single-process run (under a launcher LOCAL_RANK decides)")
+    ap.add_argument("--opt_lvl", type=int, default=0, choices=[0, 1, 2, 3],
+                    help="0 = fp32 (the parity mode; the reference's default is apex O1, which is CUDA-only); >= 1: bf16 autocast")
+    # Misc params (main.py:76)
+    ap.add_argument("--num_workers", type=int, default=0, help="number of worker processes of the DataLoader")
+    # --- this build ---
+    ap.add_argument("--num_steps", type=int, default=20, help="synthetic batches per epoch")
+    ap.add_argument("--precision", default="fast", choices=["fast", "exact"],
+                    help="fp32 products of the HIP path: tolerance mode (default) or fp32-accurate (include/coattn.h)")
     ap.add_argument("--synthetic", type=str2bool, default="true", help="synthetic data (the only source here)")
     ap.add_argument("--vocab_size", type=int, default=10000)
     ap.add_argument("--max_seq_length", type=int, default=26)
@@ -383,19 +469,24 @@ def main(argv=None):
     ap.add_argument("--channels_last", type=str2bool, default="true",
                     help="run the stock image encoder in channels_last (MIOpen NHWC kernels)")
     ap.add_argument("--val_interval", type=int, default=0,
-                    help="every this many steps: accuracy / loss under eval() on --val_batches synthetic batches "
-                         "(main.py:242-257, :290-351); 0 = off")
-    ap.add_argument("--val_batches", type=int, default=2)
-    ap.add_argument("--model_ckpt", type=str, default=None)
-    ap.add_argument("--save_path", type=str, default=None)
-    args = ap.parse_args(argv)
+                    help="validate every this many steps (0: at --log_interval, as main.py:225-246, when --val_size > 0)")
+    ap.add_argument("--val_batches", type=int, default=0, help="validation batches (overrides --val_size // --batch_size)")
+    ap.add_argument("--save_path", type=str, default=None, help="also save the final state_dict here")
+    return ap
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
     if args.mode == "test":
         raise NotImplementedError("TODO: test mode")          # as the reference, main.py:286-287
     if not args.synthetic:
         raise SystemExit("only --synthetic true is available: the VQA dataset is not present in this environment")
 
     rank, world, local = vdist.init_from_env()
-    device = torch.device("cuda", local) if torch.cuda.is_available() else torch.device("cpu")
+    if torch.cuda.is_available():
+        device = torch.device("cuda", local if "LOCAL_RANK" in os.environ else args.gpu_id)   # (main.py:80)
+    else:
+        device = torch.device("cpu")
     if device.type == "cuda":
         torch.cuda.set_device(device)
         # the step is GPU work; the host side only launches kernels and stages batches.  ATen's default of
@@ -405,48 +496,68 @@ def main(argv=None):
     cfg = setup_model_configs(args, args.vocab_size)             # (as main.py:388)
     args.vocab_size = cfg.get("vocab_size", args.vocab_size)     # attention_bert: token ids are BERT's
     model = cfg["model"](cfg["question_params"], cfg["image_params"], K=args.num_cls + 1)
+    # log directory expt_dir/expt_name/run_name (main.py:110-114): checkpoints model_{step}.pth live there (main.py:260-263)
+    log_dir = os.path.join(args.expt_dir, args.expt_name, args.run_name) if args.expt_dir else None
+    if log_dir and rank == 0:
+        os.makedirs(log_dir, exist_ok=True)
     if args.model_ckpt:
-        model.load_state_dict(torch.load(args.model_ckpt, map_location="cpu"))
+        ckpt = args.model_ckpt
+        if log_dir and not os.path.isabs(ckpt) and os.path.exists(os.path.join(log_dir, ckpt)):
+            ckpt = os.path.join(log_dir, ckpt)                   # (main.py:169)
+        model.load_state_dict(torch.load(ckpt, map_location="cpu"))
     model.to(device)
     cl = args.channels_last and device.type == "cuda" and args.model.startswith("attention")
     if cl:
         model.image_encoder.to(memory_format=torch.channels_last)
-    trainer = Trainer(model, args.learning_rate, device, args.opt_lvl)
+    trainer = Trainer(model, args.learning_rate, device, args.opt_lvl, precision=args.precision)
     size = (args.image_size, args.image_size) if args.image_size else cfg["image_size"]
-    def host_batches():
-        for step in range(args.num_steps):
-            b = synthetic_batch(args.batch_size, size, args.max_seq_length, args.vocab_size, args.num_cls + 1,
-                                seed=1234 + rank + 1000 * step)
-            image, question, label, ques_len = sort_batch(b["image"], b["question"], b["label"], b["ques_len"])
-            yield image, question, ques_len, label
+    n_cls = args.num_cls + 1
 
+    def loader(n_samples, seed):
+        ds = SyntheticVQADataset(n_samples, size, args.max_seq_length, args.vocab_size, n_cls, seed)
+        return torch.utils.data.DataLoader(ds, args.batch_size, shuffle=True, drop_last=True, num_workers=args.num_workers,
+                                           generator=torch.Generator().manual_seed(seed))
+
+    def sorted_host(batch):                                      # main.py:196-202
+        image, question, label, ques_len = sort_batch(batch["image"], batch["question"], batch["label"], batch["ques_len"])
+        return image, question, ques_len, label
+
+    train_loader = loader(args.num_steps * args.batch_size, 1234 + rank)
+    steps_per_epoch = len(train_loader)
     val = []
-    if args.val_interval > 0:
-        for i in range(args.val_batches):
-            b = synthetic_batch(args.batch_size, size, args.max_seq_length, args.vocab_size, args.num_cls + 1,
-                                seed=987654 + rank + 1000 * i)
-            image, question, label, ques_len = sort_batch(b["image"], b["question"], b["label"], b["ques_len"])
+    n_val = args.val_batches or args.val_size // args.batch_size
+    if n_val > 0:
+        for b in loader(n_val * args.batch_size, 987654 + rank):
+            image, question, ques_len, label = sorted_host(b)
             image = image.to(device)
             if cl:
                 image = image.contiguous(memory_format=torch.channels_last)
             val.append((image, question.to(device), ques_len, label.to(device)))
+    val_every = args.val_interval or (args.log_interval if val else 0)
 
     t0 = time.time()
-    batches = DevicePrefetcher(host_batches(), device, cl)
-    for step, (image, question, ques_len, label) in enumerate(batches):
-        validate_now = bool(val) and (step + 1) % args.val_interval == 0
-        # no encoder run-ahead across a validation: its BatchNorm statistics must be those of this step
-        nxt, ready = (None, None) if validate_now else batches.peek_image()
-        loss = trainer.step(image, question, ques_len, label, next_image=nxt, next_ready=ready)
-        if (step + 1) % args.log_interval == 0:
-            trainer.check_labels()                               # (the host synchronises here anyway to read the loss)
-        if (step + 1) % args.log_interval == 0 and rank == 0:
-            print(json.dumps({"step": step + 1, "loss": round(float(loss), 5),
-                              "pairs_per_s": round(world * args.batch_size * (step + 1) / (time.time() - t0), 2)}))
-        if validate_now:
-            m = trainer.validate(val)
-            if rank == 0:
-                print(json.dumps({"step": step + 1, "val_accuracy": round(m["accuracy"], 3), "val_loss": round(m["loss"], 5)}))
+    step = 0
+    for epoch in range(args.num_epochs):
+        batches = DevicePrefetcher((sorted_host(b) for b in train_loader), device, cl)
+        for image, question, ques_len, label in batches:
+            validate_now = bool(val) and val_every > 0 and (step + 1) % val_every == 0
+            # no encoder run-ahead across a validation: its BatchNorm statistics must be those of this step
+            nxt, ready = (None, None) if validate_now else batches.peek_image()
+            loss = trainer.step(image, question, ques_len, label, next_image=nxt, next_ready=ready)
+            if (step + 1) % args.log_interval == 0:
+                trainer.check_labels()                           # (the host synchronises here anyway to read the loss)
+                trainer.check_range()
+                if rank == 0:
+                    print(json.dumps({"epoch": epoch + 1, "step": step + 1, "steps_per_epoch": steps_per_epoch,
+                                      "loss": round(float(loss), 5), "precision": trainer.precision,
+                                      "pairs_per_s": round(world * args.batch_size * (step + 1) / (time.time() - t0), 2)}))
+            if validate_now:
+                m = trainer.validate(val)
+                if rank == 0:
+                    print(json.dumps({"step": step + 1, "val_accuracy": round(m["accuracy"], 3), "val_loss": round(m["loss"], 5)}))
+            if (step + 1) % args.save_interval == 0 and log_dir and rank == 0:   # main.py:260-263
+                torch.save(model.state_dict(), os.path.join(log_dir, "model_%d.pth" % (step + 1)))
+            step += 1
     if args.save_path and rank == 0:
         torch.save(model.state_dict(), args.save_path)
     vdist.shutdown()

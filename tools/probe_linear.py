@@ -12,7 +12,8 @@ d = 512
 for M in (31360, 12480, 7840):
     x = torch.randn(M, d, device=dev); W = torch.randn(d, d, device=dev) / d ** 0.5
     y = torch.empty(M, d, device=dev); wimg = torch.empty(lib.coattn_linear_workspace_bytes(d, d) // 4, device=dev)
-    for name, fl in (("exact", 0), ("two-piece", _lib.FLAG_SPLIT2), ("two-fp16", _lib.FLAG_F16PAIR)):
+    widths = (("exact", 0), ("two-piece", _lib.FLAG_SPLIT2), ("two-fp16", _lib.FLAG_F16PAIR))
+    for name, fl in (widths[2:] if os.environ.get("H2ONLY") else widths):
         call = lambda f: lib.coattn_linear_forward(x.data_ptr(), d, W.data_ptr(), None, y.data_ptr(), wimg.data_ptr(), M, d, d, 0.0, f | fl, st)
         _lib.check(call(0), "linear")
         for _ in range(200): call(1)

@@ -354,7 +354,7 @@ static bool gemm_w_enabled() {
 // The two projection jobs of a forward call on the pre-split-weight kernel (gemm_w.hip): P_v from the image features in
 // either layout, P_q of all levels from the pointer table.  Returns through v_w / q_w which of them that kernel takes.
 void projection_jobs(const Ctx& c, const float* V, const float* const* Q, const coattn_params* p, float* sv, char* wimg,
-                     WGemm& wv, WGemm& wq, bool& v_w, bool& q_w) {
+                     WGemm& wv, WGemm& wq, bool& v_w, bool& q_w, bool want_f16) {
   const SavedPlan sp = plan_saved(c.B, c.N, c.T, c.d, c.L);
   const size_t BTd = (size_t)c.B * c.T * c.d;
   wv = WGemm{}; wq = WGemm{};
@@ -365,6 +365,7 @@ void projection_jobs(const Ctx& c, const float* V, const float* const* Q, const 
   wq.bias_n = p ? (const float*)p->b_q : nullptr; wq.out_scale = c.pscale; wq.M = c.B * c.T; wq.N = c.d; wq.K = c.d; wq.batch = c.L;
   wv.bf16 = wq.bf16 = c.bf16_proj ? 1 : 0;          // reduced precision: the same kernels, hi pieces only, one MFMA per product
   wv.np = 3; wq.np = c.np_pq;
+  if (want_f16 && !c.bf16_proj) { wv.np = wq.np = 2; wv.f16 = wq.f16 = 1; }   // two FP16 pieces (any M runs on gemm_w then)
   const bool w_ok = gemm_w_enabled();
   v_w = false;
   if (w_ok && c.vl.sD == 1 && c.vl.sB == (long)c.N * c.vl.sN && c.vl.sN < (1L << 24)) {
@@ -382,7 +383,7 @@ bool f16_path(const Ctx& c, const float* V, const float* const* Q, int flags, in
   if (!fused || c.bf16_proj || !f16_fwd(flags)) return false;
   WGemm wv, wq;
   bool v_w, q_w;
-  projection_jobs(c, V, Q, nullptr, nullptr, nullptr, wv, wq, v_w, q_w);
+  projection_jobs(c, V, Q, nullptr, nullptr, nullptr, wv, wq, v_w, q_w, true);
   return v_w && q_w;
 }
 
@@ -395,10 +396,10 @@ int general_projections(const Ctx& c, const float* V, const float* const* Q, con
   // fp32 projections of row-major activations: the weight is split once, the GEMM reads it as MFMA fragments
   WGemm wv, wq;
   bool v_w, q_w;
-  projection_jobs(c, V, Q, p, sv, wimg, wv, wq, v_w, q_w);
+  const bool f16 = c.f16_proj && !c.bf16_proj;        // (forward_impl: only when both projections run on gemm_w)
+  projection_jobs(c, V, Q, p, sv, wimg, wv, wq, v_w, q_w, f16);
   float* status = sv + sp.status;
-  const bool f16 = c.f16_proj && !c.bf16_proj;        // (forward_impl: only when v_w && q_w)
-  if (f16) { wv.np = wq.np = 2; wv.f16 = wq.f16 = 1; wv.status = wq.status = status; }   // both on two FP16 pieces
+  if (f16) wv.status = wq.status = status;            // both on two FP16 pieces, range-checked
   if (v_w || q_w) {
     WSplit jobs[3];
     int nj = 0;

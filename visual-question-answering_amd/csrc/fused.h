@@ -264,13 +264,18 @@ int launch_gemm_w(const WGemm* d, int n, hipStream_t s);          // n = 1 or 2 
 int gemm_bf_supported(const WGemm& d);
 int launch_gemm_bf(const WGemm* d, int n, hipStream_t s);
 inline int wimg_pieces(const WGemm& d) { return gemm_bf_supported(d) ? 1 : (d.f16 && d.np == 2 && !d.bf16 ? 16 : 3); }
-// the kernel a pre-split-weight GEMM runs on: gemm_bf when it takes the shape, else gemm_w
+// two FP16 pieces per operand on 128 x 256 tiles with the weight through LDS (gemm_h2.hip): the tolerance mode's projections
+int gemm_h2_supported(const WGemm& d);
+int launch_gemm_h2(const WGemm* d, int n, hipStream_t s);
+// the kernel a pre-split-weight GEMM runs on: gemm_bf / gemm_h2 when they take the shape and mode, else gemm_w
+inline int gemm_wx_kernel(const WGemm& d) { return gemm_bf_supported(d) ? 1 : (gemm_h2_supported(d) ? 2 : 0); }
 inline int launch_gemm_wx(const WGemm* d, int n, hipStream_t s) {
-  if (n == 2 && gemm_bf_supported(d[0]) != gemm_bf_supported(d[1])) {   // one job on each kernel: two launches
+  if (n == 2 && gemm_wx_kernel(d[0]) != gemm_wx_kernel(d[1])) {   // one job on each kernel: two launches
     const int rc = launch_gemm_wx(&d[0], 1, s);
     return rc ? rc : launch_gemm_wx(&d[1], 1, s);
   }
-  return gemm_bf_supported(d[0]) ? launch_gemm_bf(d, n, s) : launch_gemm_w(d, n, s);
+  const int k = gemm_wx_kernel(d[0]);
+  return k == 1 ? launch_gemm_bf(d, n, s) : (k == 2 ? launch_gemm_h2(d, n, s) : launch_gemm_w(d, n, s));
 }
 
 // ---- weight-gradient GEMM C = A^T B with split-K parts (gemm_tn.hip) ---------------------------------------------

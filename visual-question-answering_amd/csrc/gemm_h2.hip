@@ -1,0 +1,315 @@
+// The forward's projections in the tolerance mode (COATTN_FLAG_FAST16): fp32 activations x nn.Linear weight on two FP16
+// pieces per operand (fused.h: 22 significand bits, three partial products on v_mfma_f32_32x32x16_f16), gfx950:
+//
+//   C[z][m][n] = ((sum_k A[z][m][k] * Bw(k, n)) / kF16WScale + bias_n[n]) * out_scale        A rows contiguous along k
+//
+// P_v = V W_v^T + b_v from location-major image features and P_q = Q W_q^T + b_q of the three levels (model.py:380-384).
+//
+// Why its own kernel (round 5).  gemm_w.hip's 128 x 128 tile feeds every wave its own B fragments from L2 and re-reads the
+// A rows once per column tile: 48 KB through the CU's vector-memory path per 32-k step for 96 MFMAs = 512 B per MFMA.  With
+// three MFMAs per product instead of six that path (64 B/clk per CU) is what binds: at the full matrix rate the tile would
+// need 64 B/clk -- the kernel sat at 0.31-0.33 of its bound with the matrix pipe idle two thirds of the time (DESIGN.md
+// section 3.2: knock-outs additive).  Here:
+//   * tile 128 x 256 per 512-thread workgroup (8 waves as 2 x 4, 64 x 64 = 2 x 2 MFMA tiles each), 32 k per step:
+//     A 16 KB + B 32 KB per step for 192 MFMAs = 256 B per MFMA, half of gemm_w's;
+//   * B: the pre-split FP16 weight image (wsplit, pieces = 16: 1 KB per (32-column tile, 16-k step, piece), lane-major) goes
+//     global -> LDS by LDS-DMA (no registers, no VALU), ONCE per workgroup, into a ring of three 32 KB buffers, two steps ahead;
+//     the two waves that share a column read the fragments back lane-linear (conflict-free ds_read_b128);
+//   * A: fp32 rows in whole 128-byte lines -> registers -> two FP16 pieces (6 VALU per pair, range tracked for coattn_status)
+//     -> LDS [128][32 + 8] per piece, double-buffered, requested one step ahead;
+//   * one barrier per step, inside the MFMA stream; every MFMA is followed by its share of the other work and a scheduling
+//     fence (left alone hipcc clusters the staging behind the MFMAs, where both waves of a SIMD do it at the same time).
+// LDS: 2 x 20 KB (A) + 3 x 32 KB (B) = 136 KB: one workgroup per CU, two waves per SIMD.
+// Shapes: N % 256 == 0, K % 32 == 0, A rows 16-byte aligned, no k bands; everything else stays on gemm_w.hip.
+// Ordering of the LDS-DMA ring (DESIGN.md "LDS-DMA rings"): a buffer is refilled two barriers after its last read (WAR), and
+// read one barrier after the counted s_waitcnt vmcnt(6) that retires its DMA in the issuing wave (RAW).
+#include "common.h"
+#include "fused.h"
+#include "gemm_w_body.h"
+#include <type_traits>
+
+#ifndef GEMMH2_KO
+#define GEMMH2_KO 0        // developer knock-outs (wrong results): 1 no A reloads, 2 no weight DMA, 4 no MFMAs, 8 no split / LDS writes, 16 no C stores
+#endif
+
+namespace {
+
+constexpr int HM = 128, HN = 256, HK = 32;
+constexpr int LDA = HK + 8;                       // halfs per staged A row (80 B: conflict-free ds_read_b128, gemm_w_body.h)
+constexpr int A_IMG = HM * LDA;                   // halfs of one piece image (10,240 B)
+constexpr int A_BUF = 2 * A_IMG;                  // both pieces
+constexpr int B_BUF = (HN / 32) * 2 * 2 * 512;    // halfs: 8 column tiles x 2 k-steps of 16 x 2 pieces x 1 KB
+constexpr int kLds = (2 * A_BUF + 3 * B_BUF) * 2; // bytes: 139,264
+constexpr int kChunk3 = 3 * 1024;                 // the weight image keeps gemm_w's 3 KB chunk stride (the third KB is unused)
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+struct H2Jobs { gw::WArgs job[2]; int first1; };
+
+__device__ __forceinline__ void gemm_h2_body(const gw::WArgs& g, const int id, short* const smem) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3, li = lane & 31, lh = lane >> 5;
+  // XCD-aware order: the column tiles of a row tile run on one XCD, one after the other (they re-read the same A rows)
+  const int ntm = (g.M + HM - 1) / HM, ntn = g.N / HN;
+  const int x = id & 7, slot = id >> 3, per = ntn * ((ntm + 7) / 8);
+  const int z = slot / per, t = slot % per, mt = (t / ntn) * 8 + x;
+  if (mt >= ntm) return;
+  const int m0 = mt * HM, n0 = (t % ntn) * HN;
+  const float* Ab = g.a_ptrs[0] ? g.a_ptrs[z & 7] : g.A + (long)z * g.a_sz;
+  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(Ab, (unsigned)(((long)(g.M - 1) * g.a_sm + g.K) * 4));
+  const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(g.Wf, g.wf_bytes);
+  const int KS = g.K / HK;
+
+  short* const abuf0 = smem;
+  short* const abuf1 = smem + A_BUF;
+  short* const bbase = smem + 2 * A_BUF;
+
+  // A staging: 2 float4 per thread and step; a wave's load covers 8 rows x 128 B (whole lines)
+  const int a_row = tid >> 3, a_k = (tid & 7) * 4;
+  int a_voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) a_voff[i] = (m0 + a_row + 64 * i) < g.M ? ((m0 + a_row + 64 * i) * g.a_sm + a_k) * 4 : 0x40000000;   // rows past M read 0
+  const int a_wr = a_row * LDA + a_k;             // + 64 i rows
+  const int a_rd = (wr * 64 + li) * LDA + 8 * lh; // + 32 i rows, + 16 h
+  // B: wave w moves column tile w of a step: its (k-step of 16, piece) chunks, 1 KB each, lane-linear
+  const int b_src = (n0 / 32 + wave) * (g.K / 16) * kChunk3;          // + (2 s + h) * 3 KB + q * 1 KB; lane part in the vector offset
+  const int b_dst = wave * 4 * 512;                                    // halfs inside a B buffer: ((ct * 2 + h) * 2 + q) * 512
+  const int b_rd = (wc * 2) * 4 * 512 + lane * 8;                      // + ((j * 2 + h) * 2 + q) * 512
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 raw[2];
+  bf16x8 af[2][2][2], bq[2][2][2];                // [fragment set][piece][tile]
+  unsigned ph[2], pm[2];
+  float ra[2], rb[2];
+  float amax = 0.f;                               // largest |value| converted to FP16 pieces or stored (coattn_status)
+
+  auto load_a = [&](int i, int s) {
+    if ((GEMMH2_KO & 1) && s >= 2) return;
+    raw[i] = buf_load4(rs_a, a_voff[i], s * HK * 4);
+  };
+  auto dma_b = [&](int c, int s, short* bbuf) {   // chunk c = h * 2 + q of step s -> the ring buffer `bbuf` (= s % 3)
+    if (GEMMH2_KO & 2) return;
+    short* dst = bbuf + b_dst + c * 512;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)dst, 16, lane * 16, b_src + (2 * s + (c >> 1)) * kChunk3 + (c & 1) * 1024, 0, 0);
+  };
+  // split of raw[i], pair e, in two stages (5 + 1 VALU, + the range maximum)
+  auto stage = [&](int i, int e, int st) {
+    if (GEMMH2_KO & 8) { if (st == 0) ph[e] = pm[e] = __builtin_bit_cast(unsigned, raw[i][2 * e]); return; }
+    if (st == 0) {
+      amax = fmaxf(amax, fmaxf(fabsf(raw[i][2 * e]), fabsf(raw[i][2 * e + 1])));
+      const hfv2 hh = __builtin_convertvector((f32x2{raw[i][2 * e], raw[i][2 * e + 1]}), hfv2);
+      ph[e] = __builtin_bit_cast(unsigned, hh);
+      ra[e] = sub1(raw[i][2 * e], (float)hh[0]);
+      rb[e] = sub1(raw[i][2 * e + 1], (float)hh[1]);
+    } else {
+      pm[e] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{ra[e], rb[e]}), hfv2));
+    }
+  };
+  auto write_a = [&](short* img, int i, int q) {
+    if (GEMMH2_KO & 8) return;
+    *reinterpret_cast<u32x2*>(&img[q * A_IMG + 64 * i * LDA + a_wr]) = q == 0 ? u32x2{ph[0], ph[1]} : u32x2{pm[0], pm[1]};
+  };
+  auto read_af = [&](auto SETc, const short* img, int h, int k) {      // k = q * 2 + i
+    constexpr int SET = decltype(SETc)::value;
+    const int q = k >> 1, i = k & 1;
+    af[SET][q][i] = *reinterpret_cast<const bf16x8*>(&img[q * A_IMG + a_rd + i * 32 * LDA + 16 * h]);
+  };
+  auto read_bq = [&](auto SETc, const short* bb, int h, int k) {       // k = q * 2 + j
+    constexpr int SET = decltype(SETc)::value;
+    const int q = k >> 1, j = k & 1;
+    bq[SET][q][j] = *reinterpret_cast<const bf16x8*>(&bb[b_rd + ((j * 2 + h) * 2 + q) * 512]);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  // the twelve MFMAs of a half step (smallest partial product first: lo * hi, hi * lo, hi * hi), each followed by fillers
+  auto mfma_slot = [&](auto SETc, int n) {
+    constexpr int SET = decltype(SETc)::value;
+    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+    const int tp = n >> 2, i = (n >> 1) & 1, j = n & 1;
+    if (!(GEMMH2_KO & 4))
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hfv8, af[SET][PA[tp]][i]), __builtin_bit_cast(hfv8, bq[SET][PB[tp]][j]), acc[i][j], 0, 0, 0);
+    else if (n == 0) acc[i][j][0] += __builtin_bit_cast(float, (int)af[SET][0][i][0] ^ (int)bq[SET][0][j][0]);
+  };
+
+  // ---- prologue: steps 0 and 1 of B in flight, step 0 of A split into image 0, step 1 of A requested -------------------
+  load_a(0, 0); load_a(1, 0);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) dma_b(c, 0, bbase);
+  if (KS > 1) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dma_b(c, 1, bbase + B_BUF);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { stage(i, e, 0); stage(i, e, 1); }
+    write_a(abuf0, i, 0); write_a(abuf0, i, 1);
+  }
+  if (KS > 1) { load_a(0, 1); load_a(1, 1); }
+  // (every DMA above is older than the two row loads just issued: all but the two youngest operations retired)
+  if (KS > 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { read_af(I0{}, abuf0, 0, k); read_bq(I0{}, bbase, 0, k); }
+
+  // One step; W1 / W2: steps s + 1 / s + 2 exist (compile-time: the last two steps are peeled, the loop body has no branches).
+  // acur / anxt: the A images of this and the next step; bcur / bnxt / bdma: the B ring buffers of steps s, s + 1, s + 2.
+  auto step = [&](auto W1c, auto W2c, int s, const short* acur, short* anxt, const short* bcur, const short* bnxt, short* bdma) {
+    constexpr bool w1 = decltype(W1c)::value, w2 = decltype(W2c)::value;
+    // half 0: MFMAs on fragment set 0; the fragments of half 1 are read; the rows of step s + 1 (requested one step ago) are
+    // split and written to the other A image
+#pragma unroll
+    for (int n = 0; n < 12; ++n) {
+      mfma_slot(I0{}, n);
+      if (n < 4) read_af(I1{}, acur, 1, n);
+      if (n >= 4 && n < 8) read_bq(I1{}, bcur, 1, n - 4);
+      if (w1) {
+        if (n == 4) stage(0, 0, 0);
+        if (n == 5) { stage(0, 0, 1); stage(0, 1, 0); }
+        if (n == 6) { stage(0, 1, 1); write_a(anxt, 0, 0); }
+        if (n == 7) { write_a(anxt, 0, 1); stage(1, 0, 0); }
+        if (n == 8) { stage(1, 0, 1); stage(1, 1, 0); }
+        if (n == 9) { stage(1, 1, 1); write_a(anxt, 1, 0); }
+        if (n == 10) write_a(anxt, 1, 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // half 1: MFMAs on fragment set 1; the weight chunks of step s + 2 go out (their ring buffer was last read in step s - 1,
+    // two barriers ago), then the rows of step s + 2; the barrier; the fragments of step s + 1's first half
+#pragma unroll
+    for (int n = 0; n < 12; ++n) {
+      mfma_slot(I1{}, n);
+      if (n < 4 && w2) dma_b(n, s + 2, bdma);
+      if (n == 4 && w2) load_a(0, s + 2);
+      if (n == 5 && w2) load_a(1, s + 2);
+      if (n == 7 && w1) {
+        // Everything this wave wrote for step s + 1 has landed -- its A pieces (lgkmcnt) and its share of the weight chunks
+        // of step s + 1, issued one step ago: all but the six youngest vector-memory operations (the four DMAs and two row
+        // loads of THIS half step; none in the step before the last) have retired -- then all waves meet.  The reads come
+        // after the barrier, never before it.
+        if (w2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      if (n >= 8 && n < 10 && w1) {
+        read_af(I0{}, anxt, 0, 2 * (n - 8)); read_af(I0{}, anxt, 0, 2 * (n - 8) + 1);
+      }
+      if (n >= 10 && w1) {
+        read_bq(I0{}, bnxt, 0, 2 * (n - 10)); read_bq(I0{}, bnxt, 0, 2 * (n - 10) + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  using TT = std::true_type;
+  using FF = std::false_type;
+  short* a0 = abuf0; short* a1 = abuf1;
+  short* b0 = bbase; short* b1 = bbase + B_BUF; short* b2 = bbase + 2 * B_BUF;
+  int s = 0;
+  for (; s + 2 < KS; ++s) {
+    step(TT{}, TT{}, s, a0, a1, b0, b1, b2);
+    short* ta = a0; a0 = a1; a1 = ta;
+    short* tb = b0; b0 = b1; b1 = b2; b2 = tb;
+  }
+  if (s + 1 < KS) {
+    step(TT{}, FF{}, s, a0, a1, b0, b1, b2);
+    short* ta = a0; a0 = a1; a1 = ta;
+    b0 = b1;
+    ++s;
+  }
+  step(FF{}, FF{}, s, a0, a1, b0, b1, b2);
+
+  float* Cb = g.c_ptrs[0] ? g.c_ptrs[z & 7] : g.C + (long)z * g.c_sz;
+  float bn[2];
+  int col[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    col[j] = n0 + wc * 64 + j * 32 + li;
+    bn[j] = g.bias_n ? g.bias_n[col[j]] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row >= g.M) continue;
+      if ((GEMMH2_KO & 16) && acc[i][0][r] != 12345.678f) continue;
+      float* crow = Cb + (long)row * g.c_sm;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float y = fmaf(acc[i][j][r], g.ascale, bn[j]) * g.oscale;
+        amax = fmaxf(amax, fabsf(y));             // (the stored projection is an FP16-piece operand of the fused kernels)
+        crow[col[j]] = y;
+      }
+    }
+  // range report of the tolerance mode (as gemm_w_body.h): the rare wave that met a magnitude beyond the exact-piece range
+  if (g.status && __builtin_amdgcn_ballot_w64(!(amax <= kF16Exact)) != 0) {
+    amax = wave_max(amax);
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(g.status), __builtin_bit_cast(unsigned, amax));
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const H2Jobs jobs) {
+  extern __shared__ __attribute__((aligned(16))) short h2_smem[];
+  f16_saturating_conversions();
+  if ((int)blockIdx.x < jobs.first1) gemm_h2_body(jobs.job[0], (int)blockIdx.x, h2_smem);
+  else gemm_h2_body(jobs.job[1], (int)blockIdx.x - jobs.first1, h2_smem);
+}
+
+}  // namespace
+
+// COATTN_GEMM_H2=0 (developer switch): gemm_w's two-FP16-piece mode instead
+static int gemm_h2_enabled() {
+  static const int on = dev_env_int("COATTN_GEMM_H2", 1);
+  return on;
+}
+
+int gemm_h2_supported(const WGemm& d) {
+  auto pal = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+  bool ok = gemm_h2_enabled() && d.f16 && d.np == 2 && !d.bf16 && !d.a_bf16 && !d.a_sk && d.kband_n == 0 && d.M >= 1 && d.N >= HN &&
+            (d.N % HN) == 0 && d.K >= HK && (d.K % HK) == 0 && (d.a_sm & 3) == 0 && (d.a_sz & 3) == 0 && d.batch >= 1 && d.batch <= 8 &&
+            (d.a_ptrs[0] ? true : pal(d.A)) && ((long)d.M * d.a_sm + d.K) * 4 < 0x40000000L && wsplit_bytes(d.N, d.K) < 0x40000000UL;
+  for (int t = 0; t < 8; ++t) ok = ok && pal(d.a_ptrs[t]);
+  return ok ? 1 : 0;
+}
+
+int launch_gemm_h2(const WGemm* d, int n, hipStream_t s) {
+  CA_CHECK_ARG(n == 1 || n == 2, "gemm_h2: 1 or 2 jobs per launch");
+  H2Jobs jobs = {};
+  long nb[2] = {0, 0};
+  for (int i = 0; i < n; ++i) {
+    CA_CHECK_ARG(gemm_h2_supported(d[i]), "gemm_h2: unsupported shape M=%d N=%d K=%d", d[i].M, d[i].N, d[i].K);
+    CA_CHECK_ARG((d[i].A || d[i].a_ptrs[0]) && d[i].Wf && (d[i].C || d[i].c_ptrs[0]), "gemm_h2: null operand");
+    gw::WArgs& g = jobs.job[i];
+    g = gw::WArgs{};
+    g.A = d[i].A; g.a_sz = d[i].a_sz; g.a_sm = d[i].a_sm;
+    g.Wf = d[i].Wf; g.wf_bytes = (unsigned)wsplit_bytes(d[i].N, d[i].K);
+    g.C = d[i].C; g.c_sz = d[i].c_sz; g.c_sm = d[i].c_sm;
+    for (int t = 0; t < 8; ++t) { g.a_ptrs[t] = d[i].a_ptrs[t]; g.c_ptrs[t] = d[i].c_ptrs[t]; }
+    g.bias_n = d[i].bias_n; g.oscale = d[i].out_scale != 0.f ? d[i].out_scale : 1.f;
+    g.ascale = 1.0f / kF16WScale;
+    g.status = d[i].status;
+    g.M = d[i].M; g.N = d[i].N; g.K = d[i].K;
+    const long ntm = (d[i].M + HM - 1) / HM, ntn = d[i].N / HN;
+    nb[i] = (long)d[i].batch * ntn * ((ntm + 7) / 8) * 8;
+  }
+  CA_CHECK_ARG(nb[0] + nb[1] < 2147483647L, "gemm_h2: grid too large");
+  jobs.first1 = (int)nb[0];
+  static DeviceOnce once;
+  CA_TRY(once.run([&] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+  }, "gemm_h2"));
+  hipLaunchKernelGGL(gemm_h2_kernel, dim3((unsigned)(nb[0] + nb[1])), dim3(512), kLds, s, jobs);
+  CA_CHECK_LAUNCH("gemm_h2");
+  return 0;
+}

@@ -123,7 +123,9 @@ int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s, float* status_hd
 
 int gemm_w_supported(const WGemm& d) {
   auto pal = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
-  bool ok = !d.a_bf16 && d.M >= 128 && d.N > 0 && d.K >= BK && (d.K % BK) == 0 && (d.a_sz & 3) == 0 && d.batch >= 1 && d.batch <= 8 &&
+  // (M >= 128: smaller products are better off on gemm.hip -- except the two-FP16-piece mode, whose range report lives in this
+  //  kernel: there any M runs here, a lone partial tile, so that the tolerance mode covers small batches too)
+  bool ok = !d.a_bf16 && d.M >= ((d.f16 && d.np == 2 && !d.bf16) ? 1 : 128) && d.N > 0 && d.K >= BK && (d.K % BK) == 0 && (d.a_sz & 3) == 0 && d.batch >= 1 && d.batch <= 8 &&
             wsplit_bytes(d.N, d.K) < 0x40000000UL && (d.a_ptrs[0] ? true : pal(d.A));
   if (d.a_sk) {      // A contiguous along m, rows split by a_mdiv
     ok = ok && d.a_mdiv > 0 && (d.a_mdiv & 3) == 0 && (d.a_sk & 3) == 0 && (d.a_sdiv & 3) == 0 && (d.M & 3) == 0 &&

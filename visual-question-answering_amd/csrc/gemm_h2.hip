@@ -266,6 +266,301 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_kernel(const H2Jobs jobs) {
   else gemm_h2_body(jobs.job[1], (int)blockIdx.x - jobs.first1, h2_smem);
 }
 
+
+// ---- the same tiles as ONE software pipeline per CU: persistent workgroups (K % 512 == 0) ----------------------------------
+// Knock-outs of the kernel above at the P_v shape (tools/ab_gemmh2.sh; 56 us on that box) came out ADDITIVE: MFMAs 22.5 us,
+// result stores 10.8, split + LDS writes 6.8, row loads 3.6, weight DMA 3.8, everything off 9.4 -- with one workgroup per CU
+// and every CU in the same phase, the chip loads (prologue), computes, and writes its 32 MB of results (epilogue) one after the
+// other.  Here a workgroup walks its tiles (id, id + grid, ...) as one uninterrupted stream of K-steps:
+//   * the loads run AHEAD of the tile boundary -- steps 14 and 15 of a tile request the first rows and weight chunks of the
+//     NEXT tile: no prologue after the first tile;
+//   * the result of a tile is stored DURING the next tile's steps -- two accumulator sets alternate, four stores per step of
+//     the set that was finished (64 per thread = 16 steps): the writes are spread over the whole kernel instead of arriving in
+//     bursts, and nothing waits for them (vmcnt retires in order: a store is older than the rows requested in the same step,
+//     which are consumed a step later).  Stores go through a buffer descriptor of the tile's rows: rows past M are dropped.
+// The 16 steps of a 512-deep pass are unrolled (the deferred stores name their registers), the LDS rings rotate at run time.
+struct H2Load {                                    // a tile's loader side: its A rows and its weight column tiles
+  __amdgpu_buffer_rsrc_t rs_a, rs_w;
+  int a_voff[2];                                   // per thread: byte offset of its two staged rows' first float4 (or out of range)
+  int b_src;                                       // byte offset of this wave's column tile in the weight image
+};
+struct H2Store {                                   // a tile's store side
+  __amdgpu_buffer_rsrc_t rs_c;
+  int c_voff, c_sm4;                               // per thread: byte offset of its first result element; row stride in bytes
+  float bn0, bn1, oscale;
+};
+
+// Tile `id` of the launch -> (job, batch index z, first row m0, first column n0); false for the padding ids of the XCD-aware
+// order (no such row tile).  The job table is read through the kernel-argument segment's address (a dynamic index into the
+// by-value argument would be copied to scratch memory).
+__device__ __forceinline__ bool h2_decode(const H2Jobs* kj, int id, const gw::WArgs*& g, int& z, int& m0, int& n0) {
+  const int j1 = id >= kj->first1 ? 1 : 0;
+  g = &kj->job[j1];
+  if (j1) id -= kj->first1;
+  const int ntm = (g->M + HM - 1) / HM, ntn = g->N / HN;
+  const int x = id & 7, slot = id >> 3, per = ntn * ((ntm + 7) / 8);
+  z = slot / per;
+  const int tt = slot % per, mt = (tt / ntn) * 8 + x;
+  m0 = mt * HM; n0 = (tt % ntn) * HN;
+  return mt < ntm;
+}
+__device__ __forceinline__ void h2_load_side(const gw::WArgs* g, int z, int m0, int n0, int wave, int tid, H2Load& l) {
+  const float* Ab = g->a_ptrs[0] ? g->a_ptrs[z & 7] : g->A + (long)z * g->a_sz;
+  l.rs_a = make_rsrc(Ab, (unsigned)(((long)(g->M - 1) * g->a_sm + g->K) * 4));
+  l.rs_w = make_rsrc(g->Wf, g->wf_bytes);
+  const int a_row = tid >> 3, a_k = (tid & 7) * 4;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) l.a_voff[i] = (m0 + a_row + 64 * i) < g->M ? ((m0 + a_row + 64 * i) * g->a_sm + a_k) * 4 : 0x40000000;
+  l.b_src = (n0 / 32 + wave) * (g->K / 16) * kChunk3;
+}
+__device__ __forceinline__ void h2_store_side(const gw::WArgs* g, int z, int m0, int n0, int wave, int lane, H2Store& c) {
+  const int wr = wave >> 2, wc = wave & 3, li = lane & 31, lh = lane >> 5;
+  float* Cb = g->c_ptrs[0] ? g->c_ptrs[z & 7] : g->C + (long)z * g->c_sz;
+  // (rows past M lie beyond the descriptor's records -- the row stride covers the columns, c_sm >= N: their stores are dropped)
+  c.rs_c = make_rsrc(Cb, (unsigned)(((long)(g->M - 1) * g->c_sm + g->N) * 4));
+  c.c_voff = ((m0 + wr * 64 + 4 * lh) * g->c_sm + n0 + wc * 64 + li) * 4;
+  c.c_sm4 = g->c_sm * 4;
+  c.bn0 = g->bias_n ? g->bias_n[n0 + wc * 64 + li] : 0.f;
+  c.bn1 = g->bias_n ? g->bias_n[n0 + wc * 64 + 32 + li] : 0.f;
+  c.oscale = g->oscale;
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_h2p_kernel(const H2Jobs jobs_by_value, const int total, float* const status) {
+  extern __shared__ __attribute__((aligned(16))) short h2_smem[];
+  (void)jobs_by_value;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const H2Jobs* const kj = (const H2Jobs*)__builtin_amdgcn_kernarg_segment_ptr();   // (the first kernel argument, by address)
+#else
+  const H2Jobs* const kj = &jobs_by_value;
+#endif
+  f16_saturating_conversions();
+  short* const smem = h2_smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3, li = lane & 31, lh = lane >> 5;
+  const int G = gridDim.x;
+  short* const abuf0 = smem;
+  short* const abuf1 = smem + A_BUF;
+  short* const bbase = smem + 2 * A_BUF;
+  const int a_wr = (tid >> 3) * LDA + (tid & 7) * 4;
+  const int a_rd = (wr * 64 + li) * LDA + 8 * lh;
+  const int b_dst = wave * 4 * 512;
+  const int b_rd = (wc * 2) * 4 * 512 + lane * 8;
+  const __amdgpu_buffer_rsrc_t rs_null = make_rsrc(smem, 0u);          // no records: loads read 0, stores are dropped
+
+  // L: what the loader requests (the tile being computed, or -- from step 14 of its last pass on -- the next tile);
+  // ps: the store side of the finished tile whose result is going out during the current tile's steps
+  H2Load L;
+  H2Store ps;
+  const gw::WArgs* cg;                                                 // the tile being computed
+  int cz, cm0, cn0;
+  int cid = blockIdx.x;
+  while (cid < total && !h2_decode(kj, cid, cg, cz, cm0, cn0)) cid += G;
+  if (cid >= total) return;
+  h2_load_side(cg, cz, cm0, cn0, wave, tid, L);
+  ps.rs_c = rs_null; ps.c_voff = 0; ps.c_sm4 = 0; ps.bn0 = ps.bn1 = 0.f; ps.oscale = 1.f;
+  int lk = 0;                                                          // the loader requests k-step lk + (static step) + 2
+
+  f32x16 acc[2][2][2];                                                 // [set][i][j]
+  // (set 1 is "stored" during the first tile -- into a descriptor without records -- and its values enter the range maximum)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[1][i][j][r] = 0.f;
+  f32x4 raw[2];
+  bf16x8 af[2][2][2], bq[2][2][2];
+  unsigned ph[2], pm[2];
+  float ra[2], rb[2];
+  float amax = 0.f;
+  const float ascale = 1.0f / kF16WScale;
+
+  auto load_a = [&](int i, int ks) { raw[i] = buf_load4(L.rs_a, L.a_voff[i], ks * HK * 4); };
+  auto dma_b = [&](int c, int ks, short* bbuf) {
+    if (GEMMH2_KO & 2) return;
+    short* dst = bbuf + b_dst + c * 512;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(L.rs_w, (lds_ptr)dst, 16, lane * 16, L.b_src + (2 * ks + (c >> 1)) * kChunk3 + (c & 1) * 1024, 0, 0);
+  };
+  auto stage = [&](int i, int e, int st) {
+    if (GEMMH2_KO & 8) { if (st == 0) ph[e] = pm[e] = __builtin_bit_cast(unsigned, raw[i][2 * e]); return; }
+    if (st == 0) {
+      amax = fmaxf(amax, fmaxf(fabsf(raw[i][2 * e]), fabsf(raw[i][2 * e + 1])));
+      const hfv2 hh = __builtin_convertvector((f32x2{raw[i][2 * e], raw[i][2 * e + 1]}), hfv2);
+      ph[e] = __builtin_bit_cast(unsigned, hh);
+      ra[e] = sub1(raw[i][2 * e], (float)hh[0]);
+      rb[e] = sub1(raw[i][2 * e + 1], (float)hh[1]);
+    } else {
+      pm[e] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{ra[e], rb[e]}), hfv2));
+    }
+  };
+  auto write_a = [&](short* img, int i, int q) {
+    if (GEMMH2_KO & 8) return;
+    *reinterpret_cast<u32x2*>(&img[q * A_IMG + 64 * i * LDA + a_wr]) = q == 0 ? u32x2{ph[0], ph[1]} : u32x2{pm[0], pm[1]};
+  };
+  // fragment (piece q, tile i / j) of half step h into fragment set SET
+  auto read_af = [&](auto SETc, const short* img, int h, int q, int i) {
+    constexpr int SET = decltype(SETc)::value;
+    if (GEMMH2_KO & 32) return;
+    af[SET][q][i] = *reinterpret_cast<const bf16x8*>(&img[q * A_IMG + a_rd + i * 32 * LDA + 16 * h]);
+  };
+  auto read_bq = [&](auto SETc, const short* bb, int h, int q, int j) {
+    constexpr int SET = decltype(SETc)::value;
+    if (GEMMH2_KO & 128) return;
+    bq[SET][q][j] = *reinterpret_cast<const bf16x8*>(&bb[b_rd + ((j * 2 + h) * 2 + q) * 512]);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  // ---- prologue (once): steps 0 and 1 of the first tile ----------------------------------------------------------------
+  load_a(0, 0); load_a(1, 0);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) dma_b(c, 0, bbase);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) dma_b(c, 1, bbase + B_BUF);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { stage(i, e, 0); stage(i, e, 1); }
+    write_a(abuf0, i, 0); write_a(abuf0, i, 1);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  load_a(0, 1); load_a(1, 1);
+  asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");           // every DMA above is older than the two row loads
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { read_af(I0{}, abuf0, 0, k >> 1, k & 1); read_bq(I0{}, bbase, 0, k >> 1, k & 1); }
+
+  short* a0 = abuf0; short* a1 = abuf1;                                // A images of this / the next step
+  short* b0 = bbase; short* b1 = bbase + B_BUF; short* b2 = bbase + 2 * B_BUF;   // B ring: this step, the next, the DMA's target
+  int nid = cid;                                                       // the tile after the one being computed (set at step 14)
+  bool more = true;
+
+  // The twelve MFMAs of a half step on fragment set FS, smallest partial product first: n = 0..3 lo(A) x hi(B), 4..7 hi x lo,
+  // 8..11 hi x hi.  The fragments of the OTHER set are read as their registers' previous contents die: lo(A) of this set
+  // is dead after n = 3, lo(B) after n = 7 -- so the next half step's lo pieces are requested at n = 4, 5 and n = 8, 9 (the
+  // allocator can give them those registers), its hi pieces, which need registers of their own, at n = 0..3.
+  // 16 steps of the current tile into accumulator set S; PS = the set being stored (four of its 64 values per step).
+  // last: this is the tile's last pass -- from step 14 on the loader works on the next tile.
+  auto pass16 = [&](auto Sc, const __amdgpu_buffer_rsrc_t prs, const bool last) __attribute__((always_inline)) {
+    constexpr int S = decltype(Sc)::value, PS = S ^ 1;
+    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      if (s == 14 && last) {                                           // steps 14, 15 request steps 0, 1 of the next tile
+        const gw::WArgs* ng; int nz, nm0, nn0;
+        nid = cid + G;
+        while (nid < total && !h2_decode(kj, nid, ng, nz, nm0, nn0)) nid += G;
+        more = nid < total;
+        if (more) h2_load_side(ng, nz, nm0, nn0, wave, tid, L);
+        else { L.rs_a = rs_null; L.rs_w = rs_null; }
+        lk = -16;
+      }
+      // half 0: MFMAs on fragment set 0; fragments of half 1; split of the rows requested a step ago; deferred stores
+#pragma unroll
+      for (int n = 0; n < 12; ++n) {
+        const int tp = n >> 2, i = (n >> 1) & 1, j = n & 1;
+        if (!(GEMMH2_KO & 4)) acc[S][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hfv8, af[0][PA[tp]][i]), __builtin_bit_cast(hfv8, bq[0][PB[tp]][j]), acc[S][i][j], 0, 0, 0);
+        else if (n == 0) acc[S][i][j][0] += __builtin_bit_cast(float, (int)af[0][0][i][0] ^ (int)bq[0][0][j][0]);
+        if (n == 0) read_af(I1{}, a0, 1, 0, 0);
+        if (n == 1) read_af(I1{}, a0, 1, 0, 1);
+        if (n == 2) read_bq(I1{}, b0, 1, 0, 0);
+        if (n == 3) read_bq(I1{}, b0, 1, 0, 1);
+        if (n == 4) { read_af(I1{}, a0, 1, 1, 0); stage(0, 0, 0); }
+        if (n == 5) { read_af(I1{}, a0, 1, 1, 1); stage(0, 0, 1); stage(0, 1, 0); }
+        if (n == 6) { stage(0, 1, 1); write_a(a1, 0, 0); }
+        if (n == 7) { write_a(a1, 0, 1); stage(1, 0, 0); }
+        if (n == 8) { read_bq(I1{}, b0, 1, 1, 0); stage(1, 0, 1); stage(1, 1, 0); }
+        if (n == 9) { read_bq(I1{}, b0, 1, 1, 1); stage(1, 1, 1); write_a(a1, 1, 0); }
+        if (n == 10) write_a(a1, 1, 1);
+        if (n >= 8 && !(GEMMH2_KO & 16)) {                             // element e = 4 s + (n - 8): (i, r, j) = (e >> 5, (e >> 1) & 15, e & 1)
+          const int e = 4 * s + (n - 8), pi = e >> 5, pr = (e >> 1) & 15, pj = e & 1;
+          const float y = fmaf(acc[PS][pi][pj][pr], ascale, pj ? ps.bn1 : ps.bn0) * ps.oscale;
+          amax = fmaxf(amax, fabsf(y));
+          asm volatile("" : "+v"(amax));                               // (here and now: left alone hipcc defers the 64 maxima to the end and spills every y until then)
+          const int row = pi * 32 + (pr & 3) + 8 * (pr >> 2);
+          int sm4 = ps.c_sm4;
+          asm volatile("" : "+s"(sm4));                                // (computed where it is used: 32 hoisted products would not fit the SGPRs)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), prs, ps.c_voff + pj * 128, row * sm4, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // half 1: MFMAs on fragment set 1.  First the barrier (this wave's A pieces of the next step were written in half 0; its
+      // share of the next step's weight chunks was requested one step ago), then the fragments of the next step's first half
+      // -- in the order of their first use, so that the last one is read five slots before it is needed --, the loader's
+      // next weight chunks and rows
+#pragma unroll
+      for (int n = 0; n < 12; ++n) {
+        const int tp = n >> 2, i = (n >> 1) & 1, j = n & 1;
+        if (!(GEMMH2_KO & 4)) acc[S][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hfv8, af[1][PA[tp]][i]), __builtin_bit_cast(hfv8, bq[1][PB[tp]][j]), acc[S][i][j], 0, 0, 0);
+        else if (n == 0) acc[S][i][j][0] += __builtin_bit_cast(float, (int)af[1][0][i][0] ^ (int)bq[1][0][j][0]);
+        if (n == 0) {
+          // All but the SIX youngest vector-memory operations have retired -- the youngest are the previous step's two row
+          // loads and this step's four stores; the weight DMAs of the previous step are older -- and this wave's LDS writes
+          // have landed.  Then all waves meet; the reads come after the barrier.
+          if (GEMMH2_KO & 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          else if (GEMMH2_KO & 16) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+          if (!(GEMMH2_KO & 64)) __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          read_af(I0{}, a1, 0, 1, 0);                                  // lo(A): first operand of the next half step
+        }
+        if (n == 1) { read_af(I0{}, a1, 0, 1, 1); dma_b(0, lk + s + 2, b2); }
+        if (n == 2) { read_bq(I0{}, b1, 0, 0, 0); dma_b(1, lk + s + 2, b2); }
+        if (n == 3) { read_bq(I0{}, b1, 0, 0, 1); dma_b(2, lk + s + 2, b2); }
+        if (n == 4) { read_af(I0{}, a1, 0, 0, 0); dma_b(3, lk + s + 2, b2); }
+        if (n == 5) { read_af(I0{}, a1, 0, 0, 1); if (!(GEMMH2_KO & 1)) load_a(0, lk + s + 2); }
+        if (n == 6) { read_bq(I0{}, b1, 0, 1, 0); if (!(GEMMH2_KO & 1)) load_a(1, lk + s + 2); }
+        if (n == 7) read_bq(I0{}, b1, 0, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      { short* ta = a0; a0 = a1; a1 = ta; }
+      { short* tb = b0; b0 = b1; b1 = b2; b2 = tb; }
+    }
+  };
+  // one tile into set S; returns whether another tile follows
+  auto run_tile = [&](auto Sc) __attribute__((always_inline)) {
+    constexpr int S = decltype(Sc)::value;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[S][i][j][r] = 0.f;
+    lk = 0;
+    pass16(Sc, ps.rs_c, true);                                          // (K == 512: one pass of 16 steps per tile)
+    // this tile is the finished one now: its store side; the next tile (found at step 14) becomes the one being computed
+    h2_store_side(cg, cz, cm0, cn0, wave, lane, ps);
+    cid = nid;
+    if (more) (void)h2_decode(kj, cid, cg, cz, cm0, cn0);
+    return more;
+  };
+  auto flush = [&](auto PSc) __attribute__((always_inline)) {          // the last tile's result
+    constexpr int PS = decltype(PSc)::value;
+    if (GEMMH2_KO & 16) { if (acc[PS][0][0][0] != 12345.678f) return; }
+#pragma unroll
+    for (int e = 0; e < 64; ++e) {
+      const int pi = e >> 5, pr = (e >> 1) & 15, pj = e & 1;
+      const float y = fmaf(acc[PS][pi][pj][pr], ascale, pj ? ps.bn1 : ps.bn0) * ps.oscale;
+      amax = fmaxf(amax, fabsf(y));
+      asm volatile("" : "+v"(amax));
+      const int row = pi * 32 + (pr & 3) + 8 * (pr >> 2);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), ps.rs_c, ps.c_voff + pj * 128, row * ps.c_sm4, 0);
+    }
+  };
+  for (;;) {
+    if (!run_tile(I0{})) { flush(I0{}); break; }
+    if (!run_tile(I1{})) { flush(I1{}); break; }
+  }
+  // the loader ran two steps past the last tile (reads without records: zeros): nothing of it is in flight past this point
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (status && __builtin_amdgcn_ballot_w64(!(amax <= kF16Exact)) != 0) {
+    amax = wave_max(amax);
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(status), __builtin_bit_cast(unsigned, amax));
+  }
+}
+
 }  // namespace
 
 // COATTN_GEMM_H2=0 (developer switch): gemm_w's two-FP16-piece mode instead
@@ -306,9 +601,33 @@ int launch_gemm_h2(const WGemm* d, int n, hipStream_t s) {
   CA_CHECK_ARG(nb[0] + nb[1] < 2147483647L, "gemm_h2: grid too large");
   jobs.first1 = (int)nb[0];
   static DeviceOnce once;
+  static int n_cu[DeviceOnce::kMaxDev];
   CA_TRY(once.run([&] {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    int dev = 0, cus = 256;
+    if (e == hipSuccess) e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e == hipSuccess && dev >= 0 && dev < DeviceOnce::kMaxDev) n_cu[dev] = cus;
+    return e;
   }, "gemm_h2"));
+  // persistent form (one workgroup per CU walks its tiles as one pipeline): 512-deep passes, both jobs; COATTN_GEMM_H2P=0
+  // (developer switch): one workgroup per tile
+  static const int persistent = dev_env_int("COATTN_GEMM_H2P", 1);
+  bool pk = persistent != 0;
+  for (int i = 0; i < n; ++i) pk = pk && d[i].K == 512 && d[i].c_sm >= d[i].N;
+  // (the status word of a launch is shared by its jobs)
+  float* status = d[0].status ? d[0].status : (n == 2 ? d[1].status : nullptr);
+  if (pk) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int cus = (dev >= 0 && dev < DeviceOnce::kMaxDev && n_cu[dev] > 0) ? n_cu[dev] : 256;
+    const long total = nb[0] + nb[1];
+    const unsigned grid = (unsigned)(total < cus ? total : cus);
+    hipLaunchKernelGGL(gemm_h2p_kernel, dim3(grid), dim3(512), kLds, s, jobs, (int)total, status);
+    CA_CHECK_LAUNCH("gemm_h2p");
+    return 0;
+  }
   hipLaunchKernelGGL(gemm_h2_kernel, dim3((unsigned)(nb[0] + nb[1])), dim3(512), kLds, s, jobs);
   CA_CHECK_LAUNCH("gemm_h2");
   return 0;

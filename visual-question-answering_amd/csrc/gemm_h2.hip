@@ -28,6 +28,9 @@
 #include "gemm_w_body.h"
 #include <type_traits>
 
+#ifndef GEMMH2_STAMPS
+#define GEMMH2_STAMPS 0    // diagnostic build (tools/probe_h2_stamps.py): wave 0 writes the shader clock at every half step of the
+#endif                     // persistent kernel into the unused third KB of weight-image chunk blockIdx.x (128 stamps per workgroup)
 #ifndef GEMMH2_KO
 #define GEMMH2_KO 0        // developer knock-outs (wrong results): 1 no A reloads, 2 no weight DMA, 4 no MFMAs, 8 no split / LDS writes, 16 no C stores
 #endif
@@ -40,6 +43,7 @@ constexpr int A_IMG = HM * LDA;                   // halfs of one piece image (1
 constexpr int A_BUF = 2 * A_IMG;                  // both pieces
 constexpr int B_BUF = (HN / 32) * 2 * 2 * 512;    // halfs: 8 column tiles x 2 k-steps of 16 x 2 pieces x 1 KB
 constexpr int kLds = (2 * A_BUF + 3 * B_BUF) * 2; // bytes: 139,264
+constexpr int kLdsP = 2 * A_BUF * 2;              // the persistent kernel keeps only the A images in LDS: 40,960 B
 constexpr int kChunk3 = 3 * 1024;                 // the weight image keeps gemm_w's 3 KB chunk stride (the third KB is unused)
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -327,7 +331,6 @@ __device__ __forceinline__ void h2_store_side(const gw::WArgs* g, int z, int m0,
 
 __global__ __launch_bounds__(512, 2) void gemm_h2p_kernel(const H2Jobs jobs_by_value, const int total, float* const status) {
   extern __shared__ __attribute__((aligned(16))) short h2_smem[];
-  (void)jobs_by_value;
 #if defined(__HIP_DEVICE_COMPILE__)
   const H2Jobs* const kj = (const H2Jobs*)__builtin_amdgcn_kernarg_segment_ptr();   // (the first kernel argument, by address)
 #else
@@ -340,14 +343,12 @@ __global__ __launch_bounds__(512, 2) void gemm_h2p_kernel(const H2Jobs jobs_by_v
   const int G = gridDim.x;
   short* const abuf0 = smem;
   short* const abuf1 = smem + A_BUF;
-  short* const bbase = smem + 2 * A_BUF;
   const int a_wr = (tid >> 3) * LDA + (tid & 7) * 4;
   const int a_rd = (wr * 64 + li) * LDA + 8 * lh;
-  const int b_dst = wave * 4 * 512;
-  const int b_rd = (wc * 2) * 4 * 512 + lane * 8;
   const __amdgpu_buffer_rsrc_t rs_null = make_rsrc(smem, 0u);          // no records: loads read 0, stores are dropped
 
-  // L: what the loader requests (the tile being computed, or -- from step 14 of its last pass on -- the next tile);
+  // L: what the loader requests (the tile being computed, or -- towards the end of its last pass -- the next tile): the A rows
+  // two steps ahead (they cross into the next tile at step 14), the weight fragments two half steps ahead (at step 15);
   // ps: the store side of the finished tile whose result is going out during the current tile's steps
   H2Load L;
   H2Store ps;
@@ -357,8 +358,12 @@ __global__ __launch_bounds__(512, 2) void gemm_h2p_kernel(const H2Jobs jobs_by_v
   while (cid < total && !h2_decode(kj, cid, cg, cz, cm0, cn0)) cid += G;
   if (cid >= total) return;
   h2_load_side(cg, cz, cm0, cn0, wave, tid, L);
+  __amdgpu_buffer_rsrc_t b_rs = L.rs_w, nb_rs = L.rs_w;               // weight image the fragment loads read / of the next tile
+  int b_src = L.b_src + (wc * 2 - wave) * (cg->K / 16) * kChunk3 + lane * 16, nb_src = b_src;   // this wave's first column tile, lane part included
+  int b_tile = (cg->K / 16) * kChunk3, nb_tile = b_tile;               // bytes between column tiles of the image
   ps.rs_c = rs_null; ps.c_voff = 0; ps.c_sm4 = 0; ps.bn0 = ps.bn1 = 0.f; ps.oscale = 1.f;
-  int lk = 0;                                                          // the loader requests k-step lk + (static step) + 2
+  int lk = 0;                                                          // the A loader requests k-step lk + (static step) + 2
+  int lkb = 0;                                                         // the B loader requests half step lkb + (static half) + 2
 
   f32x16 acc[2][2][2];                                                 // [set][i][j]
   // (set 1 is "stored" during the first tile -- into a descriptor without records -- and its values enter the range maximum)
@@ -369,24 +374,29 @@ __global__ __launch_bounds__(512, 2) void gemm_h2p_kernel(const H2Jobs jobs_by_v
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[1][i][j][r] = 0.f;
   f32x4 raw[2];
-  bf16x8 af[2][2][2], bq[2][2][2];
+  bf16x8 af[2][2][2];                                                  // [fragment set][piece][tile i]: from LDS, one half step ahead
+  bf16x8 bq[3][2][2];                                                  // [ring][piece][tile j]: from the weight image (L2), two half steps ahead
   unsigned ph[2], pm[2];
   float ra[2], rb[2];
   float amax = 0.f;
   const float ascale = 1.0f / kF16WScale;
 
   auto load_a = [&](int i, int ks) { raw[i] = buf_load4(L.rs_a, L.a_voff[i], ks * HK * 4); };
-  auto dma_b = [&](int c, int ks, short* bbuf) {
+  // weight fragments of half step `hs` (16 k): (piece q, tile j) of this wave's two column tiles, 1 KB per wave each
+  auto load_b = [&](auto Rc, int hs, int q, int j) {
+    constexpr int R = decltype(Rc)::value;
     if (GEMMH2_KO & 2) return;
-    short* dst = bbuf + b_dst + c * 512;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(L.rs_w, (lds_ptr)dst, 16, lane * 16, L.b_src + (2 * ks + (c >> 1)) * kChunk3 + (c & 1) * 1024, 0, 0);
+    bq[R][q][j] = __builtin_bit_cast(bf16x8, buf_load4(b_rs, b_src + j * b_tile + q * 1024, hs * kChunk3));
   };
+  // split of pair e of raw[i] in three sub-stages of 2, 4 and 1 VALU operations (the range maximum rides in the first)
   auto stage = [&](int i, int e, int st) {
     if (GEMMH2_KO & 8) { if (st == 0) ph[e] = pm[e] = __builtin_bit_cast(unsigned, raw[i][2 * e]); return; }
     if (st == 0) {
-      amax = fmaxf(amax, fmaxf(fabsf(raw[i][2 * e]), fabsf(raw[i][2 * e + 1])));
-      const hfv2 hh = __builtin_convertvector((f32x2{raw[i][2 * e], raw[i][2 * e + 1]}), hfv2);
-      ph[e] = __builtin_bit_cast(unsigned, hh);
+      // (one v_max3_f32 with |.| modifiers: fmaxf() costs a canonicalising v_max per operand on top)
+      asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(raw[i][2 * e]), "v"(raw[i][2 * e + 1]));
+      ph[e] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{raw[i][2 * e], raw[i][2 * e + 1]}), hfv2));
+    } else if (st == 1) {
+      const hfv2 hh = __builtin_bit_cast(hfv2, ph[e]);
       ra[e] = sub1(raw[i][2 * e], (float)hh[0]);
       rb[e] = sub1(raw[i][2 * e + 1], (float)hh[1]);
     } else {
@@ -397,127 +407,140 @@ __global__ __launch_bounds__(512, 2) void gemm_h2p_kernel(const H2Jobs jobs_by_v
     if (GEMMH2_KO & 8) return;
     *reinterpret_cast<u32x2*>(&img[q * A_IMG + 64 * i * LDA + a_wr]) = q == 0 ? u32x2{ph[0], ph[1]} : u32x2{pm[0], pm[1]};
   };
-  // fragment (piece q, tile i / j) of half step h into fragment set SET
+  // fragment (piece q, tile i) of half step h into fragment set SET
   auto read_af = [&](auto SETc, const short* img, int h, int q, int i) {
     constexpr int SET = decltype(SETc)::value;
     if (GEMMH2_KO & 32) return;
     af[SET][q][i] = *reinterpret_cast<const bf16x8*>(&img[q * A_IMG + a_rd + i * 32 * LDA + 16 * h]);
   };
-  auto read_bq = [&](auto SETc, const short* bb, int h, int q, int j) {
-    constexpr int SET = decltype(SETc)::value;
-    if (GEMMH2_KO & 128) return;
-    bq[SET][q][j] = *reinterpret_cast<const bf16x8*>(&bb[b_rd + ((j * 2 + h) * 2 + q) * 512]);
-  };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
 
-  // ---- prologue (once): steps 0 and 1 of the first tile ----------------------------------------------------------------
+  // ---- prologue (once): step 0 of the first tile split into image 0, step 1 requested, weight fragments of half steps 0, 1 --
   load_a(0, 0); load_a(1, 0);
 #pragma unroll
-  for (int c = 0; c < 4; ++c) dma_b(c, 0, bbase);
-#pragma unroll
-  for (int c = 0; c < 4; ++c) dma_b(c, 1, bbase + B_BUF);
-  __builtin_amdgcn_sched_barrier(0);
+  for (int k = 0; k < 4; ++k) { load_b(I0{}, 0, k >> 1, k & 1); load_b(I1{}, 1, k >> 1, k & 1); }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
-    for (int e = 0; e < 2; ++e) { stage(i, e, 0); stage(i, e, 1); }
+    for (int e = 0; e < 2; ++e) { stage(i, e, 0); stage(i, e, 1); stage(i, e, 2); }
     write_a(abuf0, i, 0); write_a(abuf0, i, 1);
   }
-  __builtin_amdgcn_sched_barrier(0);
   load_a(0, 1); load_a(1, 1);
-  asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");           // every DMA above is older than the two row loads
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
+  lds_barrier();
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { read_af(I0{}, abuf0, 0, k >> 1, k & 1); read_bq(I0{}, bbase, 0, k >> 1, k & 1); }
+  for (int k = 0; k < 4; ++k) read_af(I0{}, abuf0, 0, k >> 1, k & 1);
 
   short* a0 = abuf0; short* a1 = abuf1;                                // A images of this / the next step
-  short* b0 = bbase; short* b1 = bbase + B_BUF; short* b2 = bbase + 2 * B_BUF;   // B ring: this step, the next, the DMA's target
   int nid = cid;                                                       // the tile after the one being computed (set at step 14)
   bool more = true;
+  int stamp_n = 1;
+  unsigned long long* const stamp_p = reinterpret_cast<unsigned long long*>(const_cast<char*>(static_cast<const char*>(cg->Wf)) + (size_t)blockIdx.x * kChunk3 + 2048);
+  if (GEMMH2_STAMPS && tid == 0) { stamp_p[0] = __builtin_amdgcn_s_memtime(); stamp_p[127] = __builtin_amdgcn_s_memrealtime(); }
 
-  // The twelve MFMAs of a half step on fragment set FS, smallest partial product first: n = 0..3 lo(A) x hi(B), 4..7 hi x lo,
-  // 8..11 hi x hi.  The fragments of the OTHER set are read as their registers' previous contents die: lo(A) of this set
-  // is dead after n = 3, lo(B) after n = 7 -- so the next half step's lo pieces are requested at n = 4, 5 and n = 8, 9 (the
-  // allocator can give them those registers), its hi pieces, which need registers of their own, at n = 0..3.
+  // The twelve MFMAs of a half step, smallest partial product first: n = 0..3 lo(A) x hi(B), 4..7 hi x lo, 8..11 hi x hi, on
+  // A fragment set FS (LDS, read one half step ahead in the order of first use) and weight ring set RS (registers, loaded two
+  // half steps ahead: ring set (g + 2) % 3 = (g - 1) % 3 was last used in the previous half step).
   // 16 steps of the current tile into accumulator set S; PS = the set being stored (four of its 64 values per step).
-  // last: this is the tile's last pass -- from step 14 on the loader works on the next tile.
+  // last: this is the tile's last pass -- towards its end the loaders work on the next tile.
   auto pass16 = [&](auto Sc, const __amdgpu_buffer_rsrc_t prs, const bool last) __attribute__((always_inline)) {
     constexpr int S = decltype(Sc)::value, PS = S ^ 1;
     constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      if (s == 14 && last) {                                           // steps 14, 15 request steps 0, 1 of the next tile
+      if (s == 14 && last) {                                           // A rows: steps 14, 15 request steps 0, 1 of the next tile
         const gw::WArgs* ng; int nz, nm0, nn0;
         nid = cid + G;
         while (nid < total && !h2_decode(kj, nid, ng, nz, nm0, nn0)) nid += G;
         more = nid < total;
-        if (more) h2_load_side(ng, nz, nm0, nn0, wave, tid, L);
-        else { L.rs_a = rs_null; L.rs_w = rs_null; }
+        if (more) {
+          h2_load_side(ng, nz, nm0, nn0, wave, tid, L);
+          nb_rs = L.rs_w; nb_tile = (ng->K / 16) * kChunk3;
+          nb_src = L.b_src + (wc * 2 - wave) * nb_tile + lane * 16;
+        } else { L.rs_a = rs_null; nb_rs = rs_null; }
         lk = -16;
       }
-      // half 0: MFMAs on fragment set 0; fragments of half 1; split of the rows requested a step ago; deferred stores
+      if (s == 15 && last) { b_rs = nb_rs; b_src = nb_src; b_tile = nb_tile; lkb = -32; }   // weight fragments: step 15 requests half steps 0, 1 of the next tile
 #pragma unroll
-      for (int n = 0; n < 12; ++n) {
-        const int tp = n >> 2, i = (n >> 1) & 1, j = n & 1;
-        if (!(GEMMH2_KO & 4)) acc[S][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hfv8, af[0][PA[tp]][i]), __builtin_bit_cast(hfv8, bq[0][PB[tp]][j]), acc[S][i][j], 0, 0, 0);
-        else if (n == 0) acc[S][i][j][0] += __builtin_bit_cast(float, (int)af[0][0][i][0] ^ (int)bq[0][0][j][0]);
-        if (n == 0) read_af(I1{}, a0, 1, 0, 0);
-        if (n == 1) read_af(I1{}, a0, 1, 0, 1);
-        if (n == 2) read_bq(I1{}, b0, 1, 0, 0);
-        if (n == 3) read_bq(I1{}, b0, 1, 0, 1);
-        if (n == 4) { read_af(I1{}, a0, 1, 1, 0); stage(0, 0, 0); }
-        if (n == 5) { read_af(I1{}, a0, 1, 1, 1); stage(0, 0, 1); stage(0, 1, 0); }
-        if (n == 6) { stage(0, 1, 1); write_a(a1, 0, 0); }
-        if (n == 7) { write_a(a1, 0, 1); stage(1, 0, 0); }
-        if (n == 8) { read_bq(I1{}, b0, 1, 1, 0); stage(1, 0, 1); stage(1, 1, 0); }
-        if (n == 9) { read_bq(I1{}, b0, 1, 1, 1); stage(1, 1, 1); write_a(a1, 1, 0); }
-        if (n == 10) write_a(a1, 1, 1);
-        if (n >= 8 && !(GEMMH2_KO & 16)) {                             // element e = 4 s + (n - 8): (i, r, j) = (e >> 5, (e >> 1) & 15, e & 1)
-          const int e = 4 * s + (n - 8), pi = e >> 5, pr = (e >> 1) & 15, pj = e & 1;
-          const float y = fmaf(acc[PS][pi][pj][pr], ascale, pj ? ps.bn1 : ps.bn0) * ps.oscale;
-          amax = fmaxf(amax, fabsf(y));
-          asm volatile("" : "+v"(amax));                               // (here and now: left alone hipcc defers the 64 maxima to the end and spills every y until then)
-          const int row = pi * 32 + (pr & 3) + 8 * (pr >> 2);
-          int sm4 = ps.c_sm4;
-          asm volatile("" : "+s"(sm4));                                // (computed where it is used: 32 hoisted products would not fit the SGPRs)
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), prs, ps.c_voff + pj * 128, row * sm4, 0);
+      for (int h = 0; h < 2; ++h) {
+        if (GEMMH2_STAMPS == 1 && tid == 0 && stamp_n < 126) {
+          stamp_p[stamp_n] = __builtin_amdgcn_s_memtime();
+          stamp_p[126] = __builtin_amdgcn_s_memrealtime();
+          ++stamp_n;
         }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // half 1: MFMAs on fragment set 1.  First the barrier (this wave's A pieces of the next step were written in half 0; its
-      // share of the next step's weight chunks was requested one step ago), then the fragments of the next step's first half
-      // -- in the order of their first use, so that the last one is read five slots before it is needed --, the loader's
-      // next weight chunks and rows
 #pragma unroll
-      for (int n = 0; n < 12; ++n) {
-        const int tp = n >> 2, i = (n >> 1) & 1, j = n & 1;
-        if (!(GEMMH2_KO & 4)) acc[S][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hfv8, af[1][PA[tp]][i]), __builtin_bit_cast(hfv8, bq[1][PB[tp]][j]), acc[S][i][j], 0, 0, 0);
-        else if (n == 0) acc[S][i][j][0] += __builtin_bit_cast(float, (int)af[1][0][i][0] ^ (int)bq[1][0][j][0]);
-        if (n == 0) {
-          // All but the SIX youngest vector-memory operations have retired -- the youngest are the previous step's two row
-          // loads and this step's four stores; the weight DMAs of the previous step are older -- and this wave's LDS writes
-          // have landed.  Then all waves meet; the reads come after the barrier.
-          if (GEMMH2_KO & 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-          else if (GEMMH2_KO & 16) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-          if (!(GEMMH2_KO & 64)) __builtin_amdgcn_s_barrier();
-          asm volatile("" ::: "memory");
-          read_af(I0{}, a1, 0, 1, 0);                                  // lo(A): first operand of the next half step
+        for (int n = 0; n < 12; ++n) {
+          const int tp = n >> 2, i = (n >> 1) & 1, j = n & 1;
+          const int g = 2 * s + h;                                     // half step of the pass: A set g & 1, weight ring set g % 3
+          auto mf = [&](auto FSc, auto RSc) __attribute__((always_inline)) {
+            constexpr int FS = decltype(FSc)::value, RS = decltype(RSc)::value;
+            if (!(GEMMH2_KO & 4)) acc[S][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hfv8, af[FS][PA[tp]][i]), __builtin_bit_cast(hfv8, bq[RS][PB[tp]][j]), acc[S][i][j], 0, 0, 0);
+            else if (n == 0) acc[S][i][j][0] += __builtin_bit_cast(float, (int)af[FS][0][i][0] ^ (int)bq[RS][0][j][0]);
+          };
+          auto ldb = [&](int q, int jj) __attribute__((always_inline)) {   // into ring set (g + 2) % 3
+            if ((g + 2) % 3 == 0) load_b(I0{}, lkb + g + 2, q, jj);
+            else if ((g + 2) % 3 == 1) load_b(I1{}, lkb + g + 2, q, jj);
+            else load_b(I2{}, lkb + g + 2, q, jj);
+          };
+          if (GEMMH2_STAMPS == 2 && (s == 4 || s == 5) && tid == 0 && stamp_n < 126) { stamp_p[stamp_n] = __builtin_amdgcn_s_memtime(); ++stamp_n; }
+          if (h == 0) {
+            if (g % 3 == 0) mf(I0{}, I0{}); else if (g % 3 == 1) mf(I0{}, I1{}); else mf(I0{}, I2{});
+          } else {
+            if (g % 3 == 0) mf(I1{}, I0{}); else if (g % 3 == 1) mf(I1{}, I1{}); else mf(I1{}, I2{});
+          }
+          // weight fragments of half step g + 2: hi pieces first (first use: n = 0)
+          if (n == 0) ldb(0, 0);
+          if (n == 1) ldb(0, 1);
+          if (n == 2) ldb(1, 0);
+          if (n == 3) ldb(1, 1);
+          if (h == 0) {
+            // A fragments of half 1 (this step's image), lo pieces first.  The split of the rows requested a step ago, spread
+            // over the twelve slots (pair p = n / 3 of the four, sub-stage n % 3: 2, 4, 1 VALU operations); each row register
+            // set is re-requested (step s + 2) as soon as its last pair has been read; pieces of raw[0] written at n = 6, 7.
+            if (n == 0) read_af(I1{}, a0, 1, 1, 0);
+            if (n == 1) read_af(I1{}, a0, 1, 1, 1);
+            if (n == 2) read_af(I1{}, a0, 1, 0, 0);
+            if (n == 3) read_af(I1{}, a0, 1, 0, 1);
+            if (n == 6) write_a(a1, 0, 0);
+            if (n == 7) write_a(a1, 0, 1);
+            stage(n / 6, (n / 3) & 1, n % 3);
+            if (n == 5 && !(GEMMH2_KO & 1)) load_a(0, lk + s + 2);
+            if (n == 11 && !(GEMMH2_KO & 1)) load_a(1, lk + s + 2);
+          } else {
+            // pieces of raw[1]; then the barrier -- this wave's A pieces of the next step have landed (lgkmcnt), all waves meet,
+            // the reads come after it --; the A fragments of the next step's first half (lo pieces first); the deferred stores
+            if (n == 0) write_a(a1, 1, 0);
+            if (n == 1) write_a(a1, 1, 1);
+            if (n == 2) {
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              if (!(GEMMH2_KO & 64)) __builtin_amdgcn_s_barrier();
+              asm volatile("" ::: "memory");
+              read_af(I0{}, a1, 0, 1, 0);
+            }
+            if (n == 3) read_af(I0{}, a1, 0, 1, 1);
+            if (n == 4) read_af(I0{}, a1, 0, 0, 0);
+            if (n == 5) read_af(I0{}, a1, 0, 0, 1);
+            if (n >= 6 && n < 10 && !(GEMMH2_KO & 16)) {               // element e = 4 s + (n - 6): (i, r, j) = (e >> 5, (e >> 1) & 15, e & 1)
+              const int e = 4 * s + (n - 6), pi = e >> 5, pr = (e >> 1) & 15, pj = e & 1;
+              const float y = fmaf(acc[PS][pi][pj][pr], ascale, pj ? ps.bn1 : ps.bn0) * ps.oscale;
+              asm volatile("v_max_f32 %0, %0, |%1|" : "+v"(amax) : "v"(y));   // (here and now: left alone hipcc defers the 64 maxima to the end and spills every y until then)
+              const int row = pi * 32 + (pr & 3) + 8 * (pr >> 2);
+              int sm4 = ps.c_sm4;
+              asm volatile("" : "+s"(sm4));                            // (computed where it is used: 32 hoisted products would not fit the SGPRs)
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), prs, ps.c_voff + pj * 128, row * sm4, 0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        if (n == 1) { read_af(I0{}, a1, 0, 1, 1); dma_b(0, lk + s + 2, b2); }
-        if (n == 2) { read_bq(I0{}, b1, 0, 0, 0); dma_b(1, lk + s + 2, b2); }
-        if (n == 3) { read_bq(I0{}, b1, 0, 0, 1); dma_b(2, lk + s + 2, b2); }
-        if (n == 4) { read_af(I0{}, a1, 0, 0, 0); dma_b(3, lk + s + 2, b2); }
-        if (n == 5) { read_af(I0{}, a1, 0, 0, 1); if (!(GEMMH2_KO & 1)) load_a(0, lk + s + 2); }
-        if (n == 6) { read_bq(I0{}, b1, 0, 1, 0); if (!(GEMMH2_KO & 1)) load_a(1, lk + s + 2); }
-        if (n == 7) read_bq(I0{}, b1, 0, 1, 1);
-        __builtin_amdgcn_sched_barrier(0);
       }
       { short* ta = a0; a0 = a1; a1 = ta; }
-      { short* tb = b0; b0 = b1; b1 = b2; b2 = tb; }
     }
+    // 32 half steps = 2 (mod 3): rotate the weight ring's two live sets (half steps 32, 33 -> ring sets 2, 0) back to sets 0, 1
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { const bf16x8 t0 = bq[0][q][j]; bq[0][q][j] = bq[2][q][j]; bq[1][q][j] = t0; }
   };
   // one tile into set S; returns whether another tile follows
   auto run_tile = [&](auto Sc) __attribute__((always_inline)) {
@@ -528,7 +551,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2p_kernel(const H2Jobs jobs_by_v
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[S][i][j][r] = 0.f;
-    lk = 0;
+    lk = 0; lkb = 0;
     pass16(Sc, ps.rs_c, true);                                          // (K == 512: one pass of 16 steps per tile)
     // this tile is the finished one now: its store side; the next tile (found at step 14) becomes the one being computed
     h2_store_side(cg, cz, cm0, cn0, wave, lane, ps);
@@ -543,8 +566,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2p_kernel(const H2Jobs jobs_by_v
     for (int e = 0; e < 64; ++e) {
       const int pi = e >> 5, pr = (e >> 1) & 15, pj = e & 1;
       const float y = fmaf(acc[PS][pi][pj][pr], ascale, pj ? ps.bn1 : ps.bn0) * ps.oscale;
-      amax = fmaxf(amax, fabsf(y));
-      asm volatile("" : "+v"(amax));
+      asm volatile("v_max_f32 %0, %0, |%1|" : "+v"(amax) : "v"(y));
       const int row = pi * 32 + (pr & 3) + 8 * (pr >> 2);
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), ps.rs_c, ps.c_voff + pj * 128, row * ps.c_sm4, 0);
     }
@@ -553,8 +575,6 @@ __global__ __launch_bounds__(512, 2) void gemm_h2p_kernel(const H2Jobs jobs_by_v
     if (!run_tile(I0{})) { flush(I0{}); break; }
     if (!run_tile(I1{})) { flush(I1{}); break; }
   }
-  // the loader ran two steps past the last tile (reads without records: zeros): nothing of it is in flight past this point
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   if (status && __builtin_amdgcn_ballot_w64(!(amax <= kF16Exact)) != 0) {
     amax = wave_max(amax);
     if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(status), __builtin_bit_cast(unsigned, amax));
@@ -624,7 +644,7 @@ int launch_gemm_h2(const WGemm* d, int n, hipStream_t s) {
     const int cus = (dev >= 0 && dev < DeviceOnce::kMaxDev && n_cu[dev] > 0) ? n_cu[dev] : 256;
     const long total = nb[0] + nb[1];
     const unsigned grid = (unsigned)(total < cus ? total : cus);
-    hipLaunchKernelGGL(gemm_h2p_kernel, dim3(grid), dim3(512), kLds, s, jobs, (int)total, status);
+    hipLaunchKernelGGL(gemm_h2p_kernel, dim3(grid), dim3(512), kLdsP, s, jobs, (int)total, status);
     CA_CHECK_LAUNCH("gemm_h2p");
     return 0;
   }

@@ -263,6 +263,8 @@ __device__ __forceinline__ void gemm_tn_wide_body(const TwArgs& g, const int bid
 
 // [small reductions][job 0 parts][job 1 parts][tiles of the dQ projection on gemm_w_body<.., 8>]
 template <bool SUM3, int NP, bool BCM = false>
+// (__launch_bounds__' second argument is the minimum number of waves per SIMD: 2 = ONE 512-thread workgroup per CU, 256
+//  registers per lane -- the design; 169 used, no scratch: tools/regs.py gemm_tn_wide)
 __global__ __launch_bounds__(NTHR, 2) void gemm_tn_wide_kernel(const TwJobs jobs) {
   extern __shared__ __attribute__((aligned(16))) short lds_dyn[];
   const int id = (int)blockIdx.x - jobs.nred, ngemm = (int)gridDim.x - jobs.nred - jobs.nw;
@@ -342,10 +344,14 @@ int launch_gemm_tn_wide(const TnGemm* d, const int* ksplit, const int* S, int n,
   size_t lds = (size_t)2 * 2 * (IMGA + (bcm ? IMGBC : IMGB)) * sizeof(short);
   if (wextra && lds < (size_t)2 * 2 * gw::BM * gw::LDR * sizeof(short)) lds = (size_t)2 * 2 * gw::BM * gw::LDR * sizeof(short);
   if (bcm) {
+    // (set once per device to the LARGEST request any call can make -- the [column][k] form, or the dQ tiles' images if they
+    //  ever outgrow it -- not to the first call's value: ADVICE r4)
+    constexpr size_t kLdsMax = (size_t)2 * 2 * (IMGA + IMGBC) * sizeof(short) > (size_t)2 * 2 * gw::BM * gw::LDR * sizeof(short)
+                                   ? (size_t)2 * 2 * (IMGA + IMGBC) * sizeof(short) : (size_t)2 * 2 * gw::BM * gw::LDR * sizeof(short);
     static DeviceOnce once;
     CA_TRY(once.run([&] {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_wide_kernel<true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_wide_kernel<false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_wide_kernel<true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_wide_kernel<false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
       return e;
     }, "gemm_tn_wide"));
   }

@@ -242,6 +242,38 @@ def test_linear_two_fp16_pieces(M, N, K):
     assert torch.equal(y, y2)
 
 
+@pytest.mark.parametrize("name,M,N,K,flag", [
+    ("gemm_bf: LDS-DMA weight ring, config 4's P_v shape", 7840, 2048, 2048, "BF16_PROJ"),
+    ("gemm_h2: LDS-DMA weight ring of three buffers (K not 512: one workgroup per tile)", 31360, 512, 1024, "F16PAIR"),
+    ("gemm_h2p: persistent pipeline, deferred stores, register weight ring (config 2's P_v shape)", 31360, 512, 512, "F16PAIR"),
+    ("gemm_h2p at the step's own grid (7 x 7: two tiles per workgroup for some, one for others)", 7840, 512, 512, "F16PAIR")],
+    ids=["gemm_bf_cfg4", "gemm_h2_dma", "gemm_h2p_n196", "gemm_h2p_n49"])
+def test_ring_kernels_are_repeatable_and_right(name, M, N, K, flag):
+    """The kernels whose operand rings are ordered by hand-counted waits (LDS-DMA refills behind read-backs, deferred stores
+    in the vmcnt queue; DESIGN.md "LDS-DMA rings"): 25 launches on the same inputs into NaN-filled outputs, every one
+    bit-identical to the first, and the first right against the float64 product (a race shows as a rare different tile --
+    round 4 met one in the forward kernel's ring only at B = 640; VERDICT r4 asks for the sweep over gemm_bf as well)."""
+    from vqa_amd import _lib
+    torch.manual_seed(21)
+    x = torch.randn(M, K, device="cuda")
+    W = torch.randn(N, K, device="cuda") / K ** 0.5
+    b = torch.randn(N, device="cuda")
+    fl = _lib.FLAG_BF16_PROJ if flag == "BF16_PROJ" else _lib.FLAG_F16PAIR
+    rc, y0, wimg = _linear(x, K, W, b, M, N, K, flags=fl)
+    _lib.check(rc, "coattn_linear_forward")
+    rows = torch.arange(0, M, max(1, M // 997), device="cuda")
+    if flag == "BF16_PROJ":
+        ref = x[rows].bfloat16().double() @ W.bfloat16().double().t() + b.double()
+        assert _rel(y0[rows], ref) < 1e-5, name
+    else:
+        ref = x[rows].double() @ W.double().t() + b.double()
+        assert _rel(y0[rows], ref) < 4e-6, name
+    for rep in range(25):
+        rc, y, _ = _linear(x, K, W, b, M, N, K, flags=fl | (rep & 1), wimg=wimg)     # (every other call reuses the weight image)
+        _lib.check(rc, "coattn_linear_forward")
+        assert torch.equal(y, y0), (name, rep, int((y != y0).sum()))
+
+
 def test_linear_two_fp16_pieces_range():
     """Beyond fp16's range the conversions saturate (MODE.FP16_OVFL): hi + lo carries magnitudes up to 131,008, larger ones
     clamp there -- finite results for any finite input; tiny values keep 2^-24 absolute."""

@@ -1,5 +1,7 @@
-// Fused co-attention forward for gfx950, every contraction on the bf16 MFMA 32x32x16 with the exact 3-way
-// split (fp32-accurate: x = hi + mid + lo in bf16 pieces, six partial products, fp32 accumulation).
+// Fused co-attention forward for gfx950, every contraction on the 16-bit MFMAs 32x32x16 through a split of the fp32
+// operands into 16-bit pieces (fused.h): the exact 3-way bf16 split (x = hi + mid + lo, six partial products: fp32-accurate,
+// the default, flags = 0), two FP16 pieces in BOTH phases (22 significand bits, three products: COATTN_FLAG_FAST16, template
+// value NP_ = 4), or one bf16 piece (COATTN_FLAG_BF16_PROJ); fp32 accumulation throughout.
 //
 // "affinity + softmax + reduce" (model.py:377-392 after the projections), one workgroup per (sample b, level l),
 // NW = d/128 waves (4 at d = 512), two workgroups per CU:
@@ -59,8 +61,9 @@ __device__ __forceinline__ void vmcnt_wait(int n) {
 }
 
 
-// NP: width of the phase-2 contractions C^T P_q, C P_v (fused.h: 3 = the exact split, 2 = hi + mid).  The affinity of
-// phase 1 always keeps the exact split in the fp32 mode: it is the one contraction whose error the tanh amplifies.
+// NP: width of the phase-2 contractions C^T P_q, C P_v (fused.h: 3 = the exact split, 2 = hi + mid bf16 pieces -- the latter
+// only behind a developer switch: with bf16 pieces the affinity of phase 1 keeps the exact split, it is the one contraction
+// whose error the tanh amplifies; the tolerance mode the library ships is NP_ = 4 below).
 // NP = 1 (SP, single product): the reduced-precision mode (COATTN_FLAG_BF16_PROJ) -- every operand of BOTH phases rounded once
 // to bf16, ONE MFMA per product (the hi x hi term of the split; the mid / lo pieces are neither computed, stored in the
 // LDS image nor read back).

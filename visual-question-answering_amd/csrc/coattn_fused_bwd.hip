@@ -339,7 +339,14 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   const bool wdq_ok = wgemm && q_al && gemm_w_supported(wdq);
   // (a dQ projection on gemm_bf.hip -- 512-thread workgroups -- cannot ride in the weight-gradient launch)
   static const int no_combine = dev_env_int("COATTN_NO_COMBINE", 0);   // developer switch
-  const bool combine = dq32 && wdq_ok && tn_v && tn_q && !gemm_bf_supported(wdq) && !no_combine;
+  // COATTN_OWN_DQ=1 (developer switch; round 5, measured and NOT kept): the dQ projection as a launch of its own on the
+  // persistent pipeline of gemm_h2.hip (bf16 pieces) between the weight gradients and the dA V kernel -- 98.9 + 28.5 us against
+  // 123.2 combined at N = 196, 41.8 + 26.6 against 63.7 at N = 49: inside the weight-gradient launch its tiles fill the CUs
+  // the last parts leave, which is worth as much as the faster kernel.
+  static const int own_dq_env = dev_env_int("COATTN_OWN_DQ", 0);
+  const bool own_dq = own_dq_env && dq32 && wdq_ok && tn_v && tn_q && !gemm_bf_supported(wdq) && gemm_h2_supported(wdq) && !no_combine;
+  const bool combine = dq32 && wdq_ok && tn_v && tn_q && !gemm_bf_supported(wdq) && !no_combine && !own_dq;
+  const bool late_dq = combine || own_dq;           // the dA V kernel (and, before it, the projection) run after the weight gradients
   // Reduced-precision mode with a frozen image encoder (no dV) and all three consumers of dP_v / dP_q on gemm_bf.hip:
   // bwd_nat32 stores both as bf16 -- the GEMMs would round them on their way in anyway -- halving what it writes and
   // what they fetch.
@@ -392,7 +399,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   //    accumulate input); channel-major features with unaligned rows (N % 4 != 0): the exact-f32 kernel first, then
   //    the projection onto it.
   //    When the projection shares the weight-gradient launch (step 5), the dA V kernel runs after that launch.
-  if (dq32 && !combine) {
+  if (dq32 && !late_dq) {
     CA_TRY(dq_projection(false));
     prof_mark(s, "bwd_gemm_dq_projection");
   }
@@ -439,7 +446,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     prof_mark(s, "bwd_dq");
     return 0;
   };
-  if (!combine) CA_TRY(run_dq());
+  if (!late_dq) CA_TRY(run_dq());
   if (dV) {
     for (int l = 0; l < L; ++l) {
       const float* dA = ws + wo.dA + l * BTN;
@@ -522,14 +529,18 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     if (wide) CA_TRY(launch_gemm_tn_wide(both, ks, S, 2, s, &small, combine ? &wdq : nullptr));
     else CA_TRY(launch_gemm_tn(both, ks, S, 2, s, &small, combine ? &wdq : nullptr));
     prof_mark(s, combine ? "bwd_gemm" : "bwd_gemm_dw");
+    if (own_dq) {
+      CA_TRY(dq_projection(false));
+      prof_mark(s, "bwd_gemm_dq_projection");
+    }
     const bool red_al = (((int64_t)d * d) & 3) == 0 && ((((uintptr_t)part) | ((uintptr_t)pg->dW_v) | ((uintptr_t)tnq.C) | ((uintptr_t)pg->dW_q)) & 15) == 0;
-    if (combine && dq32 && red_in_dq && red_al) {       // the partial sums ride in the dQ kernel's launch
+    if (late_dq && dq32 && red_in_dq && red_al) {       // the partial sums ride in the dQ kernel's launch
       red.part[0] = part; red.out[0] = (float*)pg->dW_v; red.np[0] = parts_v;
       red.part[1] = tnq.C; red.out[1] = (float*)pg->dW_q; red.np[1] = parts_q;
       red.n = (long)d * d; red.acc = accumulate; red.on = true;
       return run_dq();
     }
-    if (combine) CA_TRY(run_dq());
+    if (late_dq) CA_TRY(run_dq());
     CA_TRY(launch_reduce_partials2(part, (float*)pg->dW_v, parts_v, tnq.C, (float*)pg->dW_q, parts_q, (int64_t)d * d,
                                    accumulate, s));
     prof_mark(s, "reduce_partials");

@@ -329,6 +329,9 @@ __device__ __forceinline__ void h2_store_side(const gw::WArgs* g, int z, int m0,
   c.oscale = g->oscale;
 }
 
+// H: the two pieces are FP16 (the forward's projections; range-tracked) -- else bf16 hi + mid (the backward's dQ = dP_q W_q:
+// gradients keep fp32's range; the weight image is the three-piece bf16 one, whose first two pieces are read)
+template <bool H>
 __global__ __launch_bounds__(512, 2) void gemm_h2p_kernel(const H2Jobs jobs_by_value, const int total, float* const status) {
   extern __shared__ __attribute__((aligned(16))) short h2_smem[];
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2p_kernel(const H2Jobs jobs_by_v
 #else
   const H2Jobs* const kj = &jobs_by_value;
 #endif
-  f16_saturating_conversions();
+  if (H) f16_saturating_conversions();
   short* const smem = h2_smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3, li = lane & 31, lh = lane >> 5;
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2p_kernel(const H2Jobs jobs_by_v
   unsigned ph[2], pm[2];
   float ra[2], rb[2];
   float amax = 0.f;
-  const float ascale = 1.0f / kF16WScale;
+  const float ascale = H ? 1.0f / kF16WScale : 1.0f;
 
   auto load_a = [&](int i, int ks) { raw[i] = buf_load4(L.rs_a, L.a_voff[i], ks * HK * 4); };
   // weight fragments of half step `hs` (16 k): (piece q, tile j) of this wave's two column tiles, 1 KB per wave each
@@ -391,6 +394,14 @@ __global__ __launch_bounds__(512, 2) void gemm_h2p_kernel(const H2Jobs jobs_by_v
   // split of pair e of raw[i] in three sub-stages of 2, 4 and 1 VALU operations (the range maximum rides in the first)
   auto stage = [&](int i, int e, int st) {
     if (GEMMH2_KO & 8) { if (st == 0) ph[e] = pm[e] = __builtin_bit_cast(unsigned, raw[i][2 * e]); return; }
+    if (!H) {                                                          // bf16 hi + mid (fused.h split_pair<2>)
+      if (st == 0) ph[e] = cvt_pk_bf16(raw[i][2 * e], raw[i][2 * e + 1]);
+      else if (st == 1) {
+        ra[e] = sub1(raw[i][2 * e], __builtin_bit_cast(float, ph[e] << 16));
+        rb[e] = sub1(raw[i][2 * e + 1], __builtin_bit_cast(float, ph[e] & 0xffff0000u));
+      } else pm[e] = cvt_pk_bf16(ra[e], rb[e]);
+      return;
+    }
     if (st == 0) {
       // (one v_max3_f32 with |.| modifiers: fmaxf() costs a canonicalising v_max per operand on top)
       asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(raw[i][2 * e]), "v"(raw[i][2 * e + 1]));
@@ -475,7 +486,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2p_kernel(const H2Jobs jobs_by_v
           const int g = 2 * s + h;                                     // half step of the pass: A set g & 1, weight ring set g % 3
           auto mf = [&](auto FSc, auto RSc) __attribute__((always_inline)) {
             constexpr int FS = decltype(FSc)::value, RS = decltype(RSc)::value;
-            if (!(GEMMH2_KO & 4)) acc[S][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hfv8, af[FS][PA[tp]][i]), __builtin_bit_cast(hfv8, bq[RS][PB[tp]][j]), acc[S][i][j], 0, 0, 0);
+            if (!(GEMMH2_KO & 4)) acc[S][i][j] = mfma32_16<H>(af[FS][PA[tp]][i], bq[RS][PB[tp]][j], acc[S][i][j]);
             else if (n == 0) acc[S][i][j][0] += __builtin_bit_cast(float, (int)af[FS][0][i][0] ^ (int)bq[RS][0][j][0]);
           };
           auto ldb = [&](int q, int jj) __attribute__((always_inline)) {   // into ring set (g + 2) % 3
@@ -524,7 +535,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2p_kernel(const H2Jobs jobs_by_v
             if (n >= 6 && n < 10 && !(GEMMH2_KO & 16)) {               // element e = 4 s + (n - 6): (i, r, j) = (e >> 5, (e >> 1) & 15, e & 1)
               const int e = 4 * s + (n - 6), pi = e >> 5, pr = (e >> 1) & 15, pj = e & 1;
               const float y = fmaf(acc[PS][pi][pj][pr], ascale, pj ? ps.bn1 : ps.bn0) * ps.oscale;
-              asm volatile("v_max_f32 %0, %0, |%1|" : "+v"(amax) : "v"(y));   // (here and now: left alone hipcc defers the 64 maxima to the end and spills every y until then)
+              if (H) asm volatile("v_max_f32 %0, %0, |%1|" : "+v"(amax) : "v"(y));   // (here and now: left alone hipcc defers the 64 maxima to the end and spills every y until then)
               const int row = pi * 32 + (pr & 3) + 8 * (pr >> 2);
               int sm4 = ps.c_sm4;
               asm volatile("" : "+s"(sm4));                            // (computed where it is used: 32 hoisted products would not fit the SGPRs)
@@ -566,7 +577,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2p_kernel(const H2Jobs jobs_by_v
     for (int e = 0; e < 64; ++e) {
       const int pi = e >> 5, pr = (e >> 1) & 15, pj = e & 1;
       const float y = fmaf(acc[PS][pi][pj][pr], ascale, pj ? ps.bn1 : ps.bn0) * ps.oscale;
-      asm volatile("v_max_f32 %0, %0, |%1|" : "+v"(amax) : "v"(y));
+      if (H) asm volatile("v_max_f32 %0, %0, |%1|" : "+v"(amax) : "v"(y));
       const int row = pi * 32 + (pr & 3) + 8 * (pr >> 2);
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), ps.rs_c, ps.c_voff + pj * 128, row * ps.c_sm4, 0);
     }
@@ -575,7 +586,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2p_kernel(const H2Jobs jobs_by_v
     if (!run_tile(I0{})) { flush(I0{}); break; }
     if (!run_tile(I1{})) { flush(I1{}); break; }
   }
-  if (status && __builtin_amdgcn_ballot_w64(!(amax <= kF16Exact)) != 0) {
+  if (H && status && __builtin_amdgcn_ballot_w64(!(amax <= kF16Exact)) != 0) {
     amax = wave_max(amax);
     if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(status), __builtin_bit_cast(unsigned, amax));
   }
@@ -591,7 +602,11 @@ static int gemm_h2_enabled() {
 
 int gemm_h2_supported(const WGemm& d) {
   auto pal = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
-  bool ok = gemm_h2_enabled() && d.f16 && d.np == 2 && !d.bf16 && !d.a_bf16 && !d.a_sk && d.kband_n == 0 && d.M >= 1 && d.N >= HN &&
+  // two FP16 pieces (the forward): any K % 32 == 0; two bf16 pieces (the backward's dQ projection, behind the developer switch
+  // COATTN_OWN_DQ of coattn_fused_bwd.hip -- by default those tiles ride in the weight-gradient launch on gemm_w_body): the
+  // persistent kernel only
+  static const int bf_pieces = dev_env_int("COATTN_OWN_DQ", 0);
+  bool ok = gemm_h2_enabled() && d.np == 2 && (d.f16 || (bf_pieces && d.K == 512 && d.c_sm >= d.N && d.M >= 128)) && !d.bf16 && !d.a_bf16 && !d.a_sk && d.kband_n == 0 && d.M >= 1 && d.N >= HN &&
             (d.N % HN) == 0 && d.K >= HK && (d.K % HK) == 0 && (d.a_sm & 3) == 0 && (d.a_sz & 3) == 0 && d.batch >= 1 && d.batch <= 8 &&
             (d.a_ptrs[0] ? true : pal(d.A)) && ((long)d.M * d.a_sm + d.K) * 4 < 0x40000000L && wsplit_bytes(d.N, d.K) < 0x40000000UL;
   for (int t = 0; t < 8; ++t) ok = ok && pal(d.a_ptrs[t]);
@@ -612,8 +627,8 @@ int launch_gemm_h2(const WGemm* d, int n, hipStream_t s) {
     g.C = d[i].C; g.c_sz = d[i].c_sz; g.c_sm = d[i].c_sm;
     for (int t = 0; t < 8; ++t) { g.a_ptrs[t] = d[i].a_ptrs[t]; g.c_ptrs[t] = d[i].c_ptrs[t]; }
     g.bias_n = d[i].bias_n; g.oscale = d[i].out_scale != 0.f ? d[i].out_scale : 1.f;
-    g.ascale = 1.0f / kF16WScale;
-    g.status = d[i].status;
+    g.ascale = d[i].f16 ? 1.0f / kF16WScale : 1.0f;
+    g.status = d[i].f16 ? d[i].status : nullptr;
     g.M = d[i].M; g.N = d[i].N; g.K = d[i].K;
     const long ntm = (d[i].M + HM - 1) / HM, ntn = d[i].N / HN;
     nb[i] = (long)d[i].batch * ntn * ((ntm + 7) / 8) * 8;
@@ -624,7 +639,8 @@ int launch_gemm_h2(const WGemm* d, int n, hipStream_t s) {
   static int n_cu[DeviceOnce::kMaxDev];
   CA_TRY(once.run([&] {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2p_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_h2p_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     int dev = 0, cus = 256;
     if (e == hipSuccess) e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -634,8 +650,9 @@ int launch_gemm_h2(const WGemm* d, int n, hipStream_t s) {
   // persistent form (one workgroup per CU walks its tiles as one pipeline): 512-deep passes, both jobs; COATTN_GEMM_H2P=0
   // (developer switch): one workgroup per tile
   static const int persistent = dev_env_int("COATTN_GEMM_H2P", 1);
-  bool pk = persistent != 0;
+  bool pk = persistent != 0 || !d[0].f16;
   for (int i = 0; i < n; ++i) pk = pk && d[i].K == 512 && d[i].c_sm >= d[i].N;
+  CA_CHECK_ARG(n == 1 || (d[0].f16 != 0) == (d[1].f16 != 0), "gemm_h2: the jobs of a launch share the piece format");
   // (the status word of a launch is shared by its jobs)
   float* status = d[0].status ? d[0].status : (n == 2 ? d[1].status : nullptr);
   if (pk) {
@@ -644,10 +661,12 @@ int launch_gemm_h2(const WGemm* d, int n, hipStream_t s) {
     const int cus = (dev >= 0 && dev < DeviceOnce::kMaxDev && n_cu[dev] > 0) ? n_cu[dev] : 256;
     const long total = nb[0] + nb[1];
     const unsigned grid = (unsigned)(total < cus ? total : cus);
-    hipLaunchKernelGGL(gemm_h2p_kernel, dim3(grid), dim3(512), kLdsP, s, jobs, (int)total, status);
+    if (d[0].f16) hipLaunchKernelGGL(gemm_h2p_kernel<true>, dim3(grid), dim3(512), kLdsP, s, jobs, (int)total, status);
+    else hipLaunchKernelGGL(gemm_h2p_kernel<false>, dim3(grid), dim3(512), kLdsP, s, jobs, (int)total, status);
     CA_CHECK_LAUNCH("gemm_h2p");
     return 0;
   }
+  CA_CHECK_ARG(d[0].f16, "gemm_h2: the bf16-piece form exists as the persistent kernel only");
   hipLaunchKernelGGL(gemm_h2_kernel, dim3((unsigned)(nb[0] + nb[1])), dim3(512), kLds, s, jobs);
   CA_CHECK_LAUNCH("gemm_h2");
   return 0;

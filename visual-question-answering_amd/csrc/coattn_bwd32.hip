@@ -354,6 +354,9 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
 //     dC += (P_q w_v) dZ_v^T.
 // The saved P_v, P_q carry the factor kPScale (fused.h): right for the exponential, divided out of the two dC operands.
 // Cross-wave sum per location tile through LDS in a fixed order; rows t >= T / n >= N: loads 0, stores dropped.
+#ifndef DC32_KO
+#define DC32_KO 0   // developer knock-outs of bwd_dc32_kernel (wrong results; tools/ab_dc32.sh): 1 the tanh' arithmetic (one VALU
+#endif              // operation per element instead of five), 2 the operand splits (one conversion per pair), 4 the MFMAs, 8 the P_v fragment loads
 template <int NT, int NW, int NP>
 __global__ __launch_bounds__(NW * 64, 2) void bwd_dc32_kernel(const BwdArgs a) {
   constexpr int NPAD = 32 * NT, PIECE = NPAD * 32, NTHR = NW * 64, SLD = 36;
@@ -406,30 +409,50 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc32_kernel(const BwdArgs a) {
       ca[p] = *reinterpret_cast<const bf16x8*>(img + p * PIECE + r * 32 + 8 * ((2 * ks + h) ^ rk));
   };
   auto split16 = [&](const f32x16& x, bf16x8 (&p0)[3], bf16x8 (&p1)[3]) {
+    if (DC32_KO & 2) {                                // knock-out: one conversion per pair, every piece the same
+      bf16x8 q0[3], q1[3];
+      splitn<1>(f32x8{x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]}, q0);
+      splitn<1>(f32x8{x[8], x[9], x[10], x[11], x[12], x[13], x[14], x[15]}, q1);
+      for (int p = 0; p < 3; ++p) { p0[p] = q0[0]; p1[p] = q1[0]; }
+      return;
+    }
     splitn<NP>(f32x8{x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]}, p0);
     splitn<NP>(f32x8{x[8], x[9], x[10], x[11], x[12], x[13], x[14], x[15]}, p1);
   };
   // the transposed fragment of tile nt, channels k0 ..: register 4 c + j <-> channel k0 + 8 c + 4 h + j = k0 + crow
-  auto load_frag = [&](int nt, int k0, f32x16& x) {
+  auto load_frag = [&](int nt, int k0, bool live, f32x16& x) {   // !live: out-of-range addresses (zeros, no traffic)
+    if ((DC32_KO & 8) && nt > 0) return;              // knock-out: the first tile's fragment stands for all
+    const int vo = live ? (r * d + 4 * h) * 4 : 0x40000000;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const f32x4 v = buf_load4(rs_pv, (r * d + 4 * h) * 4, (32 * nt * d + k0 + 8 * c) * 4);
+      const f32x4 v = buf_load4(rs_pv, vo, (32 * nt * d + k0 + 8 * c) * 4);
       x[4 * c] = v[0]; x[4 * c + 1] = v[1]; x[4 * c + 2] = v[2]; x[4 * c + 3] = v[3];
     }
   };
   constexpr float kInv = 1.0f / kPScale;
 
-#pragma unroll 1
-  for (int t0 = 0; t0 < ntiles; t0 += GT) {          // groups of location tiles
-    const int gt = ntiles - t0 < GT ? ntiles - t0 : GT;
-    f32x16 dC[GT];
+  // A group of gt location tiles from tile t0 on.  gt is a compile-time value: the unit's tiles are then ONE basic block,
+  // and the P_v fragments really run two tiles ahead, across unit boundaries too (behind a runtime `break` per tile the
+  // compiler sank every fragment load to its first use: a full memory latency per tile with two waves per SIMD).
+  auto group = [&](const int t0, auto gtc) __attribute__((always_inline)) {
+    constexpr int gt = decltype(gtc)::value;
+    const int ncu = 4 * nsl;
+    auto unit_k0 = [&](int cu) { return ((cu >> 2) * NW + w) * 128 + 32 * (cu & 3); };
+    auto flat_frag = [&](int f, f32x16& x) {         // fragment f of the group's (unit, tile) sequence; past its end: no traffic
+      const int cu2 = f / gt;
+      load_frag(t0 + (f - cu2 * gt), unit_k0(cu2), cu2 < ncu, x);
+    };
+    f32x16 dC[gt];
 #pragma unroll
-    for (int ti = 0; ti < GT; ++ti)
+    for (int ti = 0; ti < gt; ++ti)
 #pragma unroll
       for (int g = 0; g < 16; ++g) dC[ti][g] = 0.f;
+    f32x16 cur, nxt, nx2;
+    flat_frag(0, nxt);
+    flat_frag(1, nx2);
 #pragma unroll 1
-    for (int cu = 0; cu < 4 * nsl; ++cu) {           // this wave's channel units of 32
-      const int k0 = ((cu >> 2) * NW + w) * 128 + 32 * (cu & 3);
+    for (int cu = 0; cu < ncu; ++cu) {               // this wave's channel units of 32
+      const int k0 = unit_k0(cu);
       bf16x8 pqB[2][3], pqA[2][3], zqA[2][3];
       {
         f32x8 raw[2];
@@ -461,40 +484,47 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc32_kernel(const BwdArgs a) {
           splitn<NP>(z, zqA[ks]);
         }
       }
-      f32x16 cur, nxt, nx2;                          // two fragments in flight: nothing else hides their latency
-      load_frag(t0, k0, nxt);
-      load_frag(t0 + 1, k0, nx2);
 #pragma unroll
-      for (int ti = 0; ti < GT; ++ti) {
-        if (ti >= gt) break;
+      for (int ti = 0; ti < gt; ++ti) {
         const int nt = t0 + ti;
         cur = nxt;
         nxt = nx2;
-        if (ti + 2 < GT) load_frag(nt + 2, k0, nx2);  // (past the group's last tile: a harmless extra request)
+        flat_frag(cu * gt + ti + 2, nx2);
+        __builtin_amdgcn_sched_barrier(0);           // (the request stays HERE, two tiles ahead of its use)
         const short* img = Cimg + 32 * nt * 32;
         bf16x8 F0[3], F1[3], Z0[3], Z1[3], ca[3];
         split16(cur, F0, F1);
         read_ca(img, 0, ca);
-        cur = mfma32_xn<NP>(pqB[0], ca, cur);
+        if (!(DC32_KO & 4)) cur = mfma32_xn<NP>(pqB[0], ca, cur);
         read_ca(img, 1, ca);
-        cur = mfma32_xn<NP>(pqB[1], ca, cur);
+        if (!(DC32_KO & 4)) cur = mfma32_xn<NP>(pqB[1], ca, cur);
         const float ds4 = 4.0f * dsvs[32 * nt + r];
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
+          if (DC32_KO & 1) { cur[g] = cur[g] * ds4; continue; }
           const float rr = sig2_scaled(cur[g]);
           cur[g] = fmaf(-rr, rr, rr) * ds4;
         }
         split16(cur, Z0, Z1);
-        dC[ti] = mfma32_xn<NP>(pqA[0], Z0, dC[ti]);
-        dC[ti] = mfma32_xn<NP>(pqA[1], Z1, dC[ti]);
-        dC[ti] = mfma32_xn<NP>(zqA[0], F0, dC[ti]);
-        dC[ti] = mfma32_xn<NP>(zqA[1], F1, dC[ti]);
+        if (!(DC32_KO & 4)) {
+          dC[ti] = mfma32_xn<NP>(pqA[0], Z0, dC[ti]);
+          dC[ti] = mfma32_xn<NP>(pqA[1], Z1, dC[ti]);
+          dC[ti] = mfma32_xn<NP>(zqA[0], F0, dC[ti]);
+          dC[ti] = mfma32_xn<NP>(zqA[1], F1, dC[ti]);
+        } else {                                     // knock-out: every operand still has to exist
+#pragma unroll
+          for (int p = 0; p < NP; ++p)
+            asm volatile("" ::"v"(Z0[p]), "v"(Z1[p]), "v"(F0[p]), "v"(F1[p]), "v"(ca[p]));
+#pragma unroll
+          for (int p = 0; p < NP; ++p)
+            asm volatile("" ::"v"(pqA[0][p]), "v"(pqA[1][p]), "v"(zqA[0][p]), "v"(zqA[1][p]), "v"(pqB[0][p]), "v"(pqB[1][p]));
+          dC[ti][0] += cur[0];
+        }
       }
     }
     // ---- the group's tiles: cross-wave sum in a fixed order, dA = dC (1 - C^2)
 #pragma unroll
-    for (int ti = 0; ti < GT; ++ti) {
-      if (ti >= gt) break;
+    for (int ti = 0; ti < gt; ++ti) {
       const int nt = t0 + ti;
       float* mine = slots + w * 32 * SLD;
 #pragma unroll
@@ -513,16 +543,26 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_dc32_kernel(const BwdArgs a) {
         }
         const int col = 32 * nt + n;
         const int voff = col < N ? (4 * tq * N + col) * 4 : 0x40000000;
+        float c[4];                                  // (all four requested before the first store: the compiler
+#pragma unroll                                       //  orders a load after a store it cannot tell apart from it)
+        for (int i = 0; i < 4; ++i) c[i] = buf_load1(rs_c, voff, i * N * 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float c = buf_load1(rs_c, voff, i * N * 4);
-          const float v = s[i] * (1.0f - c * c);
+          const float v = s[i] * (1.0f - c[i] * c[i]);
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_da, voff, i * N * 4, 0);
         }
       }
       lds_barrier();
     }
-  }
+  };
+  static_assert(GT <= 4, "remainder groups of up to three tiles");
+  int t0 = 0;
+#pragma unroll 1
+  for (; t0 + GT <= ntiles; t0 += GT) group(t0, std::integral_constant<int, GT>());
+  const int rest = ntiles - t0;
+  if (GT > 1 && rest == 1) group(t0, std::integral_constant<int, 1>());
+  if (GT > 2 && rest == 2) group(t0, std::integral_constant<int, 2>());
+  if (GT > 3 && rest == 3) group(t0, std::integral_constant<int, 3>());
 }
 
 template <int NT, int NW, int NP>

@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "refresh")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 
 
 def one(pattern):
@@ -31,6 +31,10 @@ for leg, name in (("roofline", "roofline"), ("hot", "hot_path"), ("step", "full_
     shutil.copy(one("%s/**/*kernel_stats.csv" % leg), os.path.join(DST, "%s_%s_kernel_stats.csv" % (tag, name)))
 shutil.copy(os.path.join(SRC, "pmc_traffic.json"), os.path.join(DST, "pmc_traffic.json"))
 shutil.copy(os.path.join(SRC, "pmc_traffic_backward.json"), os.path.join(DST, "pmc_traffic_backward.json"))
+s448 = [l for l in open(os.path.join(SRC, "step448.json")) if l.startswith("{")][-1]
+json.loads(s448)
+open(os.path.join(DST, "%s_step448_bench.json" % tag), "w").write(s448)
+shutil.copy(one("step448/**/*kernel_stats.csv"), os.path.join(DST, "%s_step448_kernel_stats.csv" % tag))
 c5 = [l for l in open(os.path.join(SRC, "cfg5_bench.json")) if l.startswith("{")][-1]
 json.loads(c5)
 open(os.path.join(DST, "%s_cfg5_bench.json" % tag), "w").write(c5)

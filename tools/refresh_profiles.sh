@@ -24,6 +24,9 @@ for N in 49 196; do
   $R --kernel-trace --stats --output-format csv -d $O/fb_$N -- python3 tools/probe_hot.py $N lm 200 > $O/fb_$N.log 2>&1
 done
 $R --kernel-trace --stats --output-format csv -d $O/step -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/step.log 2>&1
+# the full step at the reference's 448 x 448 images (N = 196): its line and its kernels
+timeout 400 python3 bench.py --image-size 448 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/step448.json 2> $O/step448.err
+$R --kernel-trace --stats --output-format csv -d $O/step448 -- python3 bench.py --image-size 448 --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/step448.log 2>&1
 drop_traces
 tail -c 300 $O/bench.json
 fi

@@ -1,12 +1,12 @@
 # developer script (runs on the GPU box): knock-out builds of gemm_bf.hip timed against the shipped kernel
 # usage (local): tools/ab_gemmbf.sh build   -> tools/ab/libcoattn_bf_<ko>.so ; then gpurun -- bash tools/ab_gemmbf.sh run
 set -u
-KOS="1 2 3 4 8 16 31"
+KOS=${KOS:-"1 2 3 4 8 16 31"}    # knock-out masks, or NAME=VALUE defines (KOS="BF_EARLY=0" tools/ab_gemmbf.sh build)
 if [ "${1:-run}" = build ]; then
   mkdir -p tools/ab
   cd visual-question-answering_amd/csrc
   for k in $KOS; do
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DGEMMBF_KO=$k -c gemm_bf.hip -o ../../tools/ab/gemm_bf_$k.o
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $(case $k in *=*) echo -D$k;; *) echo -DGEMMBF_KO=$k;; esac) -c gemm_bf.hip -o ../../tools/ab/gemm_bf_$k.o
     OBJS=$(ls *.o | grep -v gemm_bf.o)
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/ab/libcoattn_bf_$k.so $OBJS ../../tools/ab/gemm_bf_$k.o -Wl,-rpath,/opt/rocm/lib
   done

@@ -1,7 +1,7 @@
 // Cross entropy of the train step on gfx950 (reference main.py:94 / :214: nn.CrossEntropyLoss() on the logits of
 // MLPClassifier, mean over the batch) together with its gradient: one workgroup per row -- log-sum-exp, loss and
-// d logits = (softmax - onehot) / B in one pass -- and a fixed-order sum of the row losses.  Deterministic: no
-// atomics.  (SURVEY.md section 8f-1.  The MLPClassifier itself stays on the stock PyTorch-ROCm modules: a
+// d logits = (softmax - onehot) / B in one pass -- and a fixed-order sum of the row losses by the workgroup that finishes
+// last (an integer ticket; no float atomics: deterministic).  (SURVEY.md section 8f-1.  The MLPClassifier itself stays on the stock PyTorch-ROCm modules: a
 // composition of this library's GEMM for its four B-row products was built and measured in round 1 -- 30 launches,
 // 0.53 ms against ~0.2 ms for the stock head -- and was removed again in round 2; see DESIGN.md.)
 #include "common.h"
@@ -28,10 +28,14 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 // row_loss[i] = (logsumexp(z_i) - z_i[label_i]) * inv_b ; dlogits = (softmax(z_i) - onehot(label_i)) * inv_b.
 // A label outside [0, K) makes the row's loss NaN and raises the status word (nn.CrossEntropyLoss raises there:
 // coattn_ce_status reports it at the caller's next synchronisation point).
+// The mean rides in the same launch: the workgroup that finishes LAST (a ticket from status[1], which it leaves at 0 for the
+// next call) adds the B row losses in sum_all_kernel's fixed order -- whichever workgroup that is, the same bits.  status[0]
+// and status[1] are 0 when the launch starts (the caller's memset, or the answer head's last layer: head.hip).
 __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
-                                                      float* __restrict__ row_loss, float* __restrict__ dlogits, int K,
-                                                      float inv_b, int* __restrict__ status, int ldd) {
+                                                      float* row_loss, float* __restrict__ dlogits, int K,
+                                                      float inv_b, int* status, int ldd, float* __restrict__ loss, int B) {
   __shared__ float sh[4];
+  __shared__ unsigned ticket;
   const int i = blockIdx.x;
   const float* z = logits + (long)i * K;
   float m = -INFINITY;
@@ -42,14 +46,28 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
   s = block_sum(s, sh);
   const long long lab = labels[i];
   const bool ok = lab >= 0 && lab < K;
-  if (threadIdx.x == 0) {
-    row_loss[i] = ok ? (logf(s) + m - z[lab]) * inv_b : NAN;
-    if (!ok) status[0] = i + 1;                       // (any offending row: the writers race benignly)
-  }
   if (dlogits) {
     const float inv = inv_b / s;
     for (int k = threadIdx.x; k < ldd; k += 256)     // rows ldd >= K floats apart, the padding zeroed
       dlogits[(long)i * ldd + k] = k < K ? expf(z[k] - m) * inv - ((ok && k == lab) ? inv_b : 0.f) : 0.f;
+  }
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&row_loss[i], ok ? (logf(s) + m - z[lab]) * inv_b : NAN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!ok) status[0] = i + 1;                       // (any offending row: the writers race benignly)
+    __threadfence();                                  // the row loss is visible device-wide before the ticket is taken
+    ticket = atomicAdd(reinterpret_cast<unsigned*>(status) + 1, 1u);
+  }
+  __syncthreads();
+  if (ticket != (unsigned)(B - 1)) return;
+  __threadfence();
+  float acc = 0.f;                                    // (sum_all_kernel's order: strided per thread, wave sums, (0 + 1) + (2 + 3))
+  for (int r = threadIdx.x; r < B; r += 256) acc += __hip_atomic_load(&row_loss[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    loss[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    reinterpret_cast<unsigned*>(status)[1] = 0u;
   }
 }
 
@@ -57,17 +75,18 @@ inline size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
 
 }  // namespace
 
-// rows + mean for the answer head (head.hip): row_loss [B] scratch, dlogits [B][ldd] (ldd = 0: K) or NULL
+// rows + mean for the answer head (head.hip): row_loss [B] scratch, dlogits [B][ldd] (ldd = 0: K) or NULL.
+// zeroed: status[0] and status[1] have been cleared by an earlier launch on this stream (head.hip's logits layer)
 int launch_ce_rows(const float* logits, const void* labels, float* row_loss, float* dlogits, float* loss, int B, int K,
-                   int* status, hipStream_t s, int ldd) {
-  if (hipMemsetAsync(status, 0, 16, s) != hipSuccess) {       // (a memset node under graph capture)
+                   int* status, hipStream_t s, int ldd, bool zeroed) {
+  if (!zeroed && hipMemsetAsync(status, 0, 16, s) != hipSuccess) {       // (a memset node under graph capture)
     coattn_set_error("ce: clearing the status word failed");
     return -3;
   }
   hipLaunchKernelGGL(ce_rows_kernel, dim3(B), dim3(256), 0, s, logits, (const long long*)labels, row_loss, dlogits, K,
-                     1.0f / (float)B, status, ldd > 0 ? ldd : K);
+                     1.0f / (float)B, status, ldd > 0 ? ldd : K, loss, B);
   CA_CHECK_LAUNCH("ce_rows");
-  return launch_sum_all(row_loss, loss, B, 0, s);
+  return 0;
 }
 
 extern "C" int coattn_ce_workspace_bytes(int B, int K, int dtype, size_t* ws) {
@@ -106,5 +125,5 @@ extern "C" int coattn_ce_forward(const void* logits, const void* labels, void* l
   CA_CHECK_ARG(logits && labels && loss && ws, "ce_forward: null argument");                   // dlogits may be NULL
   hipStream_t s = (hipStream_t)stream;
   return launch_ce_rows((const float*)logits, labels, (float*)ws, (float*)dlogits, (float*)loss, B, K,
-                        reinterpret_cast<int*>((float*)ws + al64((size_t)B)), s, 0);
+                        reinterpret_cast<int*>((float*)ws + al64((size_t)B)), s, 0, false);
 }

@@ -23,6 +23,9 @@
 #include "gemm_w_body.h"
 #include <type_traits>
 
+#ifndef BF_EARLY
+#define BF_EARLY 1
+#endif
 #ifndef GEMMBF_KO
 #define GEMMBF_KO 0        // developer knock-outs (wrong results), tools/ab_gemmbf.sh: 1 no A reloads, 2 no weight DMA, 4 no MFMAs, 8 no A LDS writes, 16 no fragment re-reads
 #endif
@@ -128,12 +131,18 @@ __device__ __forceinline__ void gemm_bf_body(const gw::WArgs& g, const int id, s
   //  rows are consumed in the FIRST half of a step, while no DMA is in flight, and the DMA of step s + 1 and the reloads
   //  for step s + 2 are issued in the second half, in this order -- the barrier's vmcnt(8) counts on it)
   auto reload_one = [&](int i, int s) { raw[i] = buf_load4(rs_a, a_voff[i], (k_lo + (s + 2) * TK) * ES); };
+  short* const buf0 = smem;
+  short* const buf1 = smem + BUF;
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
   using I3 = std::integral_constant<int, 3>;
-  auto group = [&](auto SETc, const short* cur, short* nxt, int s, auto KSc, bool write, bool reload) {
+  // (BF_EARLY: the rows of step s + 2 are re-requested right behind the LDS write that frees their registers -- a whole step
+  //  ahead of their use.  In the second half of the step, behind the weight DMA, the youngest request was two MFMA slots old
+  //  when the compiler's vmcnt(0) in front of the next step's first write waited for it: a memory latency per step.)
+  auto group = [&](auto SETc, const short* cur, short* nxt, int s, auto KSc, auto Wc, auto Rc) {
     constexpr int SET = decltype(SETc)::value, ks = decltype(KSc)::value;
+    constexpr bool write = decltype(Wc)::value, reload = decltype(Rc)::value;
     using OTHER = std::integral_constant<int, SET ^ 1>;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -141,17 +150,21 @@ __device__ __forceinline__ void gemm_bf_body(const gw::WArgs& g, const int id, s
       if (!(GEMMBF_KO & 4)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[SET][i], bf[SET][j], acc[i][j], 0, 0, 0);
       else if (m == 0) acc[i][j][0] += __builtin_bit_cast(float, (int)af[SET][i][0] ^ (int)bf[SET][j][0]);
       if (m == 0 && ks < 3 && !(GEMMBF_KO & 16)) read_frags(OTHER{}, cur, ks + 1);
-      if (ks < 2 && (m & 1) && 4 * ks + (m >> 1) < NA && write && !(GEMMBF_KO & 8)) write_one(4 * ks + (m >> 1), nxt);   // groups 0, 1: the staged registers
+      if (ks < 2 && (m & 1) && 4 * ks + (m >> 1) < NA) {                                                // groups 0, 1: the staged registers
+        if (write && !(GEMMBF_KO & 8)) write_one(4 * ks + (m >> 1), nxt);
+        if (BF_EARLY && reload && !(GEMMBF_KO & 1)) reload_one(4 * ks + (m >> 1), s);                   // ... and the rows of step s + 2 into them
+      }
       if (ks == 2 && m == 0 && write && !(GEMMBF_KO & 2)) dma_b(s + 1, nxt);                           // group 2: the weight chunks of step s + 1
-      if (ks >= 2 && (m & 1) && 4 * (ks - 2) + (m >> 1) < NA && reload && !(GEMMBF_KO & 1)) reload_one(4 * (ks - 2) + (m >> 1), s);   // groups 2, 3: rows of step s + 2
+      if (!BF_EARLY && ks >= 2 && (m & 1) && 4 * (ks - 2) + (m >> 1) < NA && reload && !(GEMMBF_KO & 1)) reload_one(4 * (ks - 2) + (m >> 1), s);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
   // Every wave's LDS-DMA and LDS writes have landed, then all waves meet (the DMA is ordered only by the issuing wave's
-  // vmcnt: the wait comes BEFORE the barrier, the reads after it).  vmcnt counts in issue order, so with the next-but-one
-  // step's NA A loads issued BEHIND the DMA, "all but the NA youngest" retires the DMA and leaves those loads flying.
+  // vmcnt: the wait comes BEFORE the barrier, the reads after it).  vmcnt counts in issue order: with the A requests issued
+  // BEHIND the DMA (!BF_EARLY), "all but the NA youngest" retires the DMA and leaves those loads flying; with them in front
+  // of it the wait is for everything (the requests are half a step to a step old by then).
   auto step_barrier = [&](bool a_in_flight) {
-    if (a_in_flight && !(GEMMBF_KO & 1)) {
+    if (!BF_EARLY && a_in_flight && !(GEMMBF_KO & 1)) {
       if constexpr (ABF) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     }
@@ -159,25 +172,29 @@ __device__ __forceinline__ void gemm_bf_body(const gw::WArgs& g, const int id, s
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
-  short* const buf0 = smem;
-  short* const buf1 = smem + BUF;
+  using TT = std::true_type;
+  using FF = std::false_type;
+  auto step = [&](int s, auto Wc, auto Rc) __attribute__((always_inline)) {
+    short* cur = (s & 1) ? buf1 : buf0;             // (nxt was last read in step s - 1: every wave is past that barrier)
+    short* nxt = (s & 1) ? buf0 : buf1;
+    read_frags(I0{}, cur, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    group(I0{}, cur, nxt, s, I0{}, Wc, Rc);
+    group(I1{}, cur, nxt, s, I1{}, Wc, Rc);
+    group(I0{}, cur, nxt, s, I2{}, Wc, Rc);
+    group(I1{}, cur, nxt, s, I3{}, Wc, Rc);
+    step_barrier(decltype(Rc)::value);
+  };
   load_a(0);
   dma_b(0, buf0);
   write_a(buf0);
   if (KS > 1) load_a(1);
   step_barrier(KS > 1);
-  for (int s = 0; s < KS; ++s) {
-    short* cur = (s & 1) ? buf1 : buf0;
-    short* nxt = (s & 1) ? buf0 : buf1;
-    const bool write = s + 1 < KS, reload = s + 2 < KS;   // (nxt was last read in step s - 1: every wave is past that barrier)
-    read_frags(I0{}, cur, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    group(I0{}, cur, nxt, s, I0{}, write, reload);
-    group(I1{}, cur, nxt, s, I1{}, write, reload);
-    group(I0{}, cur, nxt, s, I2{}, write, reload);
-    group(I1{}, cur, nxt, s, I3{}, write, reload);
-    step_barrier(reload);
-  }
+  int s = 0;
+#pragma unroll 1
+  for (; s + 2 < KS; ++s) step(s, TT{}, TT{});      // write = s + 1 < KS, reload = s + 2 < KS: compile-time in the main loop
+  if (s + 1 < KS) { step(s, TT{}, FF{}); ++s; }
+  step(s, FF{}, FF{});
 
   float* Cb = g.c_ptrs[0] ? g.c_ptrs[z & 7] : g.C + (long)z * g.c_sz;
   float bn[2];

@@ -14,7 +14,7 @@
 // are folded into the A-operand addressing, bias + tanh into the epilogue, tanh' of the backward into the epilogue of the
 // product that yields d h; every backward launch carries the dX tiles of a layer (the dependent chain) AND the tiles of
 // that layer's weight gradient dW = dY^T X (+ the bias gradient), which depend on nothing the launch itself produces and
-// fill the CUs the chain leaves idle.  Forward: 4 launches + cross entropy (2); backward: 4 launches.
+// fill the CUs the chain leaves idle.  Forward: 4 launches + cross entropy (1: ce.hip); backward: 4 launches.
 //
 // Arithmetic: exact fp32 on v_mfma_f32_32x32x2_f32 (one rounding per product, as an fmaf chain).  The products are too
 // small for the bf16 3-way split of the big GEMMs to pay: every operand element is used by one 32 x 32 tile only, so the
@@ -406,6 +406,7 @@ __device__ __forceinline__ void dw_tile(const DY& Y, const Comp& X, float* __res
 struct FwdLayer {
   Comp A; const float* W; const float* bias; float* C; int ldc, act;
   int M, N, K;
+  int* zero2;                     // two words workgroup 0 clears (the cross entropy's status word and ticket: ce.hip), or NULL
 };
 
 template <bool VEC, bool BF>
@@ -415,6 +416,7 @@ __global__ __launch_bounds__(kThreads) void head_fwd_kernel(const FwdLayer L) {
   const int mt = blockIdx.x / ntn, nt = blockIdx.x % ntn;
   TileOut o = {};
   o.C = L.C; o.ldc = L.ldc; o.bias = L.bias; o.act = L.act; o.hsplit = 0x7fffffff;
+  if (L.zero2 && blockIdx.x == 0 && threadIdx.x == 0) { L.zero2[0] = 0; L.zero2[1] = 0; }
   fwd_tile<VEC, BF>(L.A, L.W, L.K, o, L.M, L.N, L.K, 32 * mt, 32 * nt, smem);
 }
 
@@ -584,7 +586,7 @@ int launch_bwd(BwdLayer& L, bool want_dx, bool vec, bool bf, hipStream_t s) {
 }  // namespace
 
 // cross entropy rows + mean (ce.hip)
-int launch_ce_rows(const float* logits, const void* labels, float* row_loss, float* dlogits, float* loss, int B, int K, int* status, hipStream_t s, int ldd);
+int launch_ce_rows(const float* logits, const void* labels, float* row_loss, float* dlogits, float* loss, int B, int K, int* status, hipStream_t s, int ldd, bool zeroed);
 int head_status_check(const int* status_dev, void* stream);
 
 extern "C" int coattn_head_workspace_bytes(int B, int d, int mlp, int K, int dtype, size_t* saved, size_t* ws_bwd) {
@@ -624,6 +626,7 @@ extern "C" int coattn_head_forward(const void* const* v, const void* const* q, c
   for (int l = 0; l < 4; ++l) Ls[l].M = B;
   CA_CHECK_ARG(!((flags & COATTN_HEAD_PERSISTENT) && (flags & COATTN_FLAG_BF16_PROJ)),
                "head_forward: COATTN_HEAD_PERSISTENT has no reduced-precision form (drop one of the two flags)");
+  bool ce_zeroed = false;
   if (flags & COATTN_HEAD_PERSISTENT) {
     FwdAll all = {};
     all.poison = (float*)logits;
@@ -637,9 +640,10 @@ extern "C" int coattn_head_forward(const void* const* v, const void* const* q, c
     CA_CHECK_LAUNCH("head_fwd_persistent");
   } else {
     const bool bf = (flags & COATTN_FLAG_BF16_PROJ) != 0;
+    if (labels) { Ls[3].zero2 = reinterpret_cast<int*>(sv + hs.st); ce_zeroed = true; }   // (the logits layer clears the loss's two words)
     for (int l = 0; l < 4; ++l) CA_TRY(launch_fwd(Ls[l], vec, bf, s));
   }
-  if (labels) CA_TRY(launch_ce_rows((const float*)logits, labels, sv + hs.rl, sv + hs.dl, (float*)loss, B, K, reinterpret_cast<int*>(sv + hs.st), s, kpad(K)));
+  if (labels) CA_TRY(launch_ce_rows((const float*)logits, labels, sv + hs.rl, sv + hs.dl, (float*)loss, B, K, reinterpret_cast<int*>(sv + hs.st), s, kpad(K), ce_zeroed));
   return 0;
 }
 

@@ -72,7 +72,9 @@ class HotPathGraph:
         self.labels = torch.zeros((B,), device=dev, dtype=torch.int64)
         # static outputs
         self.v = torch.empty((3, B, d), **f32); self.q = torch.empty((3, B, d), **f32)
-        self.logits = torch.empty((B, K), **f32); self.loss = torch.empty((), **f32)
+        # logits and loss share one buffer: a step hands out ONE copy of it (two views), not two
+        self.out = torch.empty(B * K + 4, **f32)
+        self.logits = self.out[:B * K].view(B, K); self.loss = self.out[B * K]
         self.dx = torch.empty((3, B, d), **f32)                      # d(q_l + v_l): upstream gradient of both v and q
         self.dV = torch.empty((B, N, d), **f32) if need_dv else None
         self.dQ = [torch.empty((B, T, d), **f32) for _ in range(3)]
@@ -149,8 +151,9 @@ class HotPathGraph:
                        dqptr, C.byref(pg), 0, _ptr(self.ws), B, N, T, d, 3, _lib.F32, self.flags),
         }
         # (variants of the two backward calls: a gradient arriving for the logits; accumulate = 1 for a second backward
-        #  onto the same static gradient buffers)
-        plan["head_bwd_args"] = lambda g_logits, acc: plan["head_bwd"][:5] + (_ptr(g_logits),) + plan["head_bwd"][6:9] + (acc,) + plan["head_bwd"][10:]   # noqa: E731
+        #  onto the same static gradient buffers; the loss's upstream gradient read where autograd left it)
+        plan["head_bwd_args"] = lambda g_logits, acc, g_loss=None: (plan["head_bwd"][:4] + (_ptr(self.g_loss if g_loss is None else g_loss), _ptr(g_logits))   # noqa: E731
+                                                                    + plan["head_bwd"][6:9] + (acc,) + plan["head_bwd"][10:])
         plan["co_bwd_args"] = lambda acc: plan["co_bwd"][:15] + (acc,) + plan["co_bwd"][16:]   # noqa: E731
         assert plan["head_bwd"][9] == 0 and plan["head_bwd"][5] is None and plan["co_bwd"][15] == 0
         self._plans[key] = plan
@@ -213,18 +216,18 @@ class HotPathGraph:
         """The same calls without the graphs (tests compare the two bit for bit)."""
         self._enqueue(ins or self._static, torch.cuda.current_stream(self.device).cuda_stream)
 
-    def run(self, pair, ins, fwd: bool, plan=None, g_logits=None, accumulate: int = 0):
+    def run(self, pair, ins, fwd: bool, plan=None, g_logits=None, accumulate: int = 0, g_loss=None):
         """One direction of the hot path: replay the captured graph, or (eager mode) issue its two C-ABI calls (`plan`: the
         argument blocks of `ins`, if the caller has them already).  g_logits / accumulate (backward, eager mode only): an
         upstream gradient of the logits to add; add into the parameter-gradient buffers instead of overwriting them."""
         if pair is not _EAGER and (g_logits is not None or accumulate):
             raise RuntimeError("HotPathGraph: a gradient for `logits` / a second backward onto the same gradient buffers "
                                "cannot be replayed from the captured graph (use capture=False, or the module path)")
-        if pair is _EAGER and not fwd and (g_logits is not None or accumulate):
+        if pair is _EAGER and not fwd and (g_logits is not None or accumulate or g_loss is not None):
             plan = plan or self._plan(ins)
             st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
             with _lib.on_device(self.device):
-                _lib.check(self._lib.coattn_head_backward(*plan["head_bwd_args"](g_logits, accumulate), st), "coattn_head_backward")
+                _lib.check(self._lib.coattn_head_backward(*plan["head_bwd_args"](g_logits, accumulate, g_loss), st), "coattn_head_backward")
                 _lib.check(self._lib.coattn_backward(*plan["co_bwd_args"](accumulate), st), "coattn_backward")
             return
         if pair is _EAGER:
@@ -303,7 +306,10 @@ class _HotPathFn(torch.autograd.Function):
         ctx.keep = ins                                           # the graphs read these addresses again in backward
         ctx.set_materialize_grads(False)                         # (an unused output arrives as None, not as zeros)
         # logits: a fresh tensor by default -- the static buffer is overwritten by the next step
-        return (hp.logits if hp.alias_outputs else hp.logits.clone()), hp.loss.clone()
+        if hp.alias_outputs:
+            return hp.logits, hp.loss.clone()
+        out = hp.out.clone()                                      # (one copy kernel for both)
+        return out[:B * K].view(B, K), out[B * K]
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
@@ -311,10 +317,14 @@ class _HotPathFn(torch.autograd.Function):
         hp = ctx.hp
         if g_loss is None and g_logits is None:
             return (None,) * len(ctx.needs_input_grad)
+        direct = None
         if g_loss is None:
             hp.g_loss.zero_()
+        elif (ctx.pair is _EAGER and g_loss.dtype == torch.float32 and g_loss.device == hp.device and g_loss.numel() == 1
+              and g_loss.data_ptr() % 4 == 0):
+            direct = g_loss                                      # eager calls read it where autograd left it: no copy kernel
         else:
-            hp.g_loss.copy_(g_loss.reshape(1))
+            hp.g_loss.copy_(g_loss.reshape(1))                   # (the captured graph reads the static scalar)
         if g_logits is not None:
             g_logits = g_logits.contiguous().float()
         acc = 0
@@ -328,7 +338,7 @@ class _HotPathFn(torch.autograd.Function):
                 raise RuntimeError("HotPathGraph(direct_grads=True): some parameters still hold the static gradient buffer "
                                    "from the previous backward and others do not -- call zero_grad(set_to_none=True) on all of "
                                    "them before every backward, or on none")
-        hp.run(ctx.pair, ctx.keep, False, ctx.plan, g_logits=g_logits, accumulate=acc)
+        hp.run(ctx.pair, ctx.keep, False, ctx.plan, g_logits=g_logits, accumulate=acc, g_loss=direct)
         if hp.direct_grads:
             # the owner of the step (train.Trainer) consumes the gradients before the next backward and needs no gradient
             # hooks: the static buffers BECOME param.grad (autograd's AccumulateGrad would clone each one -- it cannot

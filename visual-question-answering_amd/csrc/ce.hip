@@ -46,16 +46,16 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
   s = block_sum(s, sh);
   const long long lab = labels[i];
   const bool ok = lab >= 0 && lab < K;
-  if (dlogits) {
-    const float inv = inv_b / s;
-    for (int k = threadIdx.x; k < ldd; k += 256)     // rows ldd >= K floats apart, the padding zeroed
-      dlogits[(long)i * ldd + k] = k < K ? expf(z[k] - m) * inv - ((ok && k == lab) ? inv_b : 0.f) : 0.f;
-  }
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0) {                             // (before the gradient row is stored: the fence has nothing of it to wait for)
     __hip_atomic_store(&row_loss[i], ok ? (logf(s) + m - z[lab]) * inv_b : NAN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!ok) status[0] = i + 1;                       // (any offending row: the writers race benignly)
     __threadfence();                                  // the row loss is visible device-wide before the ticket is taken
     ticket = atomicAdd(reinterpret_cast<unsigned*>(status) + 1, 1u);
+  }
+  if (dlogits) {
+    const float inv = inv_b / s;
+    for (int k = threadIdx.x; k < ldd; k += 256)     // rows ldd >= K floats apart, the padding zeroed
+      dlogits[(long)i * ldd + k] = k < K ? expf(z[k] - m) * inv - ((ok && k == lab) ? inv_b : 0.f) : 0.f;
   }
   __syncthreads();
   if (ticket != (unsigned)(B - 1)) return;

@@ -56,6 +56,7 @@ struct TwArgs {
 struct TwJobs {
   TwArgs job[2]; int first1; ReduceJobs red; int nred, red_bx, red_nparts, red_acc; long red_n;
   gw::WArgs wj; int nw;
+  int wfirst;                     // > 0: the dQ tiles come FIRST, in this many block slots (nw rounded up to the XCD count), the split-K parts behind them
 };
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -267,8 +268,15 @@ template <bool SUM3, int NP, bool BCM = false>
 //  registers per lane -- the design; 169 used, no scratch: tools/regs.py gemm_tn_wide)
 __global__ __launch_bounds__(NTHR, 2) void gemm_tn_wide_kernel(const TwJobs jobs) {
   extern __shared__ __attribute__((aligned(16))) short lds_dyn[];
-  const int id = (int)blockIdx.x - jobs.nred, ngemm = (int)gridDim.x - jobs.nred - jobs.nw;
-  if (id >= ngemm) {
+  int id = (int)blockIdx.x - jobs.nred;
+  const int ngemm = (int)gridDim.x - jobs.nred - (jobs.wfirst ? jobs.wfirst : jobs.nw);
+  if (jobs.wfirst && id >= 0) {
+    if (id < jobs.wfirst) {
+      if (id < jobs.nw) gw::gemm_w_body<false, NP, 8>(jobs.wj, id, lds_dyn);
+      return;
+    }
+    id -= jobs.wfirst;
+  } else if (id >= ngemm) {
     gw::gemm_w_body<false, NP, 8>(jobs.wj, id - ngemm, lds_dyn);
     return;
   }
@@ -309,6 +317,8 @@ int launch_gemm_tn_wide(const TnGemm* d, const int* ksplit, const int* S, int n,
                  "gemm_tn_wide: the extra GEMM must be a row-major two-piece product with N %% 256 == 0");
     CA_TRY(gemm_w_fill_job(*wextra, jobs.wj, &nbw, 256));
     jobs.nw = (int)nbw;
+    static const int first = dev_env_int("COATTN_DQ_FIRST", 0);   // developer switch
+    if (first) jobs.wfirst = (jobs.nw + 7) / 8 * 8;
   }
   if (red) {
     CA_CHECK_ARG(red->njobs >= 1 && red->njobs <= 4 && red->n > 0, "gemm_tn_wide: bad reduction jobs");
@@ -339,7 +349,7 @@ int launch_gemm_tn_wide(const TnGemm* d, const int* ksplit, const int* S, int n,
   CA_CHECK_ARG(nb[0] + nb[1] < 2147483647L, "gemm_tn_wide: grid too large");
   jobs.first1 = (int)nb[0];
   const bool sum3 = d[0].a_term != 0, bcm = d[0].b_kdiv != 0;
-  const dim3 grid((unsigned)(jobs.nred + nb[0] + nb[1] + jobs.nw));
+  const dim3 grid((unsigned)(jobs.nred + nb[0] + nb[1] + (jobs.wfirst ? jobs.wfirst : jobs.nw)));
   // two buffers of two pieces: 57,344 B; with the [column][k] image of a BCM first job 69,632 B (above the 64 KB default)
   size_t lds = (size_t)2 * 2 * (IMGA + (bcm ? IMGBC : IMGB)) * sizeof(short);
   if (wextra && lds < (size_t)2 * 2 * gw::BM * gw::LDR * sizeof(short)) lds = (size_t)2 * 2 * gw::BM * gw::LDR * sizeof(short);

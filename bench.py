@@ -172,16 +172,20 @@ def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20, b
         loss.backward()
 
     def timed(fn):
-        """(wall per step, host time to ENQUEUE a step) over `iters` pipelined steps."""
+        """(wall per step, host time to ENQUEUE a step) over `iters` pipelined steps: the median of three windows (one host
+        hiccup -- an allocator trim, a page fault in a fresh buffer -- used to own a whole leg's number)."""
         for _ in range(5):
             fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            fn()
-        t1 = time.perf_counter()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / iters, (t1 - t0) / iters
+        wins = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                fn()
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            wins.append(((time.perf_counter() - t0) / iters, (t1 - t0) / iters))
+        return sorted(wins)[1]
 
     mdt, mhost = timed(mstep)
     # as train.Trainer.step runs it by default: the hot path as ONE autograd node over static buffers, its four C-ABI calls

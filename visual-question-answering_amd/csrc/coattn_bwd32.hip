@@ -161,7 +161,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
           zq_frag[4 * gg + i] = sq[i] * wqc * (1.0f - hq * hq);
         }
       }
-      dwq += __shfl_xor(dwq, 32, 64);                // (stored here: nothing of it lives through the pass)
+      dwq = half_sum(dwq);                // (stored here: nothing of it lives through the pass)
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dwq), rs_dwq, ho == 0 ? lane * 4 : 0x40000000, c0 * 4, 0);
     }
     f32x16 accq = zq_frag;                           // dP_q = dZ_q + C dZ_v
@@ -331,9 +331,9 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
         store_dp(rs_dpq, v, hrow + ((g & 3) + 8 * (g >> 2)) * d, c0);
         s += v;
       }
-      s += __shfl_xor(s, 32, 64);
-      dwacc += __shfl_xor(dwacc, 32, 64);
-      dbacc += __shfl_xor(dbacc, 32, 64);
+      s = half_sum(s);
+      dwacc = half_sum(dwacc);
+      dbacc = half_sum(dbacc);
       if (h == 0) {
         a.dbq_part[pair * (size_t)d + c0 + r] = s;
         a.dwv_part[pair * (size_t)d + c0 + r] = dwacc;

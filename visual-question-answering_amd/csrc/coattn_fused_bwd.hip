@@ -52,30 +52,44 @@ __device__ __forceinline__ void dav_cm_block(const float* V, long v_sB, const fl
 
 // location-major V [N][d]: da_v[l][n] = V[n][:] . gv[l][:], whole rows -> part[b][0][l][n] (one "chunk").
 // grid (ceil(N / 16), B); a wave takes 4 rows, lanes along the channels (float4), three wave sums per row.
-__device__ __forceinline__ void dav_lm_block(const float* V, long v_sB, const float* gv, float* part, int B, int N, int d,
-                                             int L, int bx, int b) {
+__device__ __forceinline__ void dav_lm_block(const float* __restrict__ V, long v_sB, const float* __restrict__ gv, float* __restrict__ part,
+                                             int B, int N, int d, int L, int bx, int b) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float* Vb = V + (size_t)b * v_sB;
-  for (int i = 0; i < 4; ++i) {
-    const int n = bx * 16 + 4 * w + i;
-    if (n >= N) break;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (int k = 4 * lane; k < d; k += 256) {
-      const f32x4 x = *reinterpret_cast<const f32x4*>(Vb + (size_t)n * d + k);
-      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gv + ((size_t)0 * B + b) * d + k);
-      const f32x4 g1 = L > 1 ? *reinterpret_cast<const f32x4*>(gv + ((size_t)1 * B + b) * d + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-      const f32x4 g2 = L > 2 ? *reinterpret_cast<const f32x4*>(gv + ((size_t)2 * B + b) * d + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const int n0 = bx * 16 + 4 * w;
+  if (n0 >= N) return;
+  // the wave's four rows are requested together (rows past N: row N - 1 again, its sums dropped), the level vectors are
+  // read once per 256-channel sweep, the twelve wave sums run as independent chains
+  float a[4][3] = {};
+  const float* rowp[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rowp[i] = Vb + (size_t)min(n0 + i, N - 1) * d;
+  for (int k = 4 * lane; k < d; k += 256) {
+    f32x4 x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = *reinterpret_cast<const f32x4*>(rowp[i] + k);
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gv + ((size_t)0 * B + b) * d + k);
+    const f32x4 g1 = L > 1 ? *reinterpret_cast<const f32x4*>(gv + ((size_t)1 * B + b) * d + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 g2 = L > 2 ? *reinterpret_cast<const f32x4*>(gv + ((size_t)2 * B + b) * d + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        a0 = fmaf(x[e], g0[e], a0);
-        a1 = fmaf(x[e], g1[e], a1);
-        a2 = fmaf(x[e], g2[e], a2);
+        a[i][0] = fmaf(x[i][e], g0[e], a[i][0]);
+        a[i][1] = fmaf(x[i][e], g1[e], a[i][1]);
+        a[i][2] = fmaf(x[i][e], g2[e], a[i][2]);
       }
-    }
-    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2);
-    if (lane == 0) {
-      float* o = part + (size_t)b * 3 * N + n;
-      o[0] = a0; o[N] = a1; o[2 * (size_t)N] = a2;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int l = 0; l < 3; ++l) a[i][l] = wave_sum(a[i][l]);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (n0 + i >= N) break;
+      float* o = part + (size_t)b * 3 * N + n0 + i;
+      o[0] = a[i][0]; o[N] = a[i][1]; o[2 * (size_t)N] = a[i][2];
     }
   }
 }
@@ -117,15 +131,23 @@ __global__ __launch_bounds__(256) void bwd_pre_kernel(const PreArgs a) {
   // ---- question side: da_q[t] = Q[t] . gq, one wave per row
   const float* Qp = a.Q[l] + (size_t)b * T * d;
   const float* gqp = a.gq + pair * d;
-  for (int t = w; t < T; t += 4) {
-    float acc = 0.f;
+  for (int t0 = w; t0 < T; t0 += 16) {               // four of the wave's rows (t0, t0 + 4, ...) at a time, requested together
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int k = 4 * lane; k < d; k += 256) {
-      const f32x4 x = *reinterpret_cast<const f32x4*>(Qp + (size_t)t * d + k);
+      f32x4 x[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) x[i] = *reinterpret_cast<const f32x4*>(Qp + (size_t)min(t0 + 4 * i, T - 1) * d + k);
       const f32x4 g = *reinterpret_cast<const f32x4*>(gqp + k);
-      acc += x[0] * g[0] + x[1] * g[1] + x[2] * g[2] + x[3] * g[3];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] += x[i][0] * g[0] + x[i][1] * g[1] + x[i][2] * g[2] + x[i][3] * g[3];
     }
-    acc = wave_sum(acc);
-    if (lane == 0) daq[t] = acc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = wave_sum(acc[i]);
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (t0 + 4 * i < T) daq[t0 + 4 * i] = acc[i];
+    }
   }
   __syncthreads();
   if (w == 0) {

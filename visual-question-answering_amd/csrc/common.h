@@ -83,16 +83,37 @@ static inline int dev_env_int(const char* name, int dflt) {
 void prof_mark(hipStream_t s, const char* name);
 
 // ---- wave64 reductions ------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// All-reduce butterflies without the LDS crossbar (__shfl_xor compiles to ds_bpermute_b32: a ~100-cycle round trip and an
+// lgkmcnt wait per step): halves and 16-lane rows meet through gfx950's lane-swap instructions (after the swap the two
+// registers hold [lo, lo] and [hi, hi]), the rest through DPP operands of the add itself -- row_ror:8 (= xor 8), row_half_mirror
+// (lane i <-> i ^ 7), quad_perm xor 2, xor 1: masks 8, 7, 2, 1 span the row, so every lane ends with the whole sum, in one fixed order.
+// (the swaps are inline asm: with the same value as both operands hipcc 7.2 adds the first result to itself)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+#define CA_WAVE_REDUCE(OP)                                                                    \
+  float a = v, b = v;                                                                         \
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));                 \
+  v = OP(a, b);                                                                               \
+  a = v; b = v;                                                                               \
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));                 \
+  v = OP(a, b);                                                                               \
+  v = OP(v, dpp_f32<0x128>(v));   /* row_ror:8 */                                             \
+  v = OP(v, dpp_f32<0x141>(v));   /* row_half_mirror */                                       \
+  v = OP(v, dpp_f32<0x4E>(v));    /* quad_perm [2,3,0,1] */                                   \
+  v = OP(v, dpp_f32<0xB1>(v));    /* quad_perm [1,0,3,2] */                                   \
   return v;
+__device__ __forceinline__ float ca_addf(float x, float y) { return x + y; }
+// v(lane) + v(lane ^ 32): the two 32-lane halves of the wave, in every lane
+__device__ __forceinline__ float half_sum(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
 }
+__device__ __forceinline__ float wave_sum(float v) { CA_WAVE_REDUCE(ca_addf) }
+__device__ __forceinline__ float wave_max(float v) { CA_WAVE_REDUCE(fmaxf) }
+#undef CA_WAVE_REDUCE
 
 // ---- small reductions shared by reduce_jobs_kernel (small_kernels.hip) and gemm_tn_kernel (extra workgroups) ----
 // up to 4 independent reductions of [nparts][n] partial buffers (row `by` = job, 64 columns per block `bx`)

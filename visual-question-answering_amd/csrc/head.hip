@@ -398,7 +398,7 @@ __device__ __forceinline__ void dw_tile(const DY& Y, const Comp& X, float* __res
     }
   }
   if (db && k0 == 0) {
-    colsum += __shfl_xor(colsum, 32, 64);
+    colsum = half_sum(colsum);
     if (lh == 0 && a_ok) db[n0 + li] = accumulate ? db[n0 + li] + colsum : colsum;
   }
 }

@@ -817,9 +817,12 @@ __global__ __launch_bounds__(256) void attend_v_lm_kernel(const float* V, long v
     for (int k = 0; k < 8; ++k) x[k] = buf_load4(rs_v, voff, (8 * batch + k) * rstep);
   };
   load8(0, x0);
-  for (int i = tid; i < 3 * 256; i += 256) {
-    const int l = i >> 8, n = i & 255;
-    aw[l][n] = (l < L && n < N) ? av[((size_t)l * B + b) * N + n] : 0.f;
+  {                                                    // the three levels' weights of location tid: clamped addresses, requested together
+    float w3[3];                                       // (a guarded load is a branch and a wait of its own: three latencies in a row)
+#pragma unroll
+    for (int l = 0; l < 3; ++l) w3[l] = av[((size_t)min(l, L - 1) * B + b) * N + min(tid, N - 1)];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) aw[l][tid] = (l < L && tid < N) ? w3[l] : 0.f;
   }
   __syncthreads();
   f32x4 acc[3];

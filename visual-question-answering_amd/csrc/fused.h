@@ -397,17 +397,28 @@ __device__ __forceinline__ float softmax_bwd_v(const BwdArgs& a, int b, int l, i
   const int N = a.N, nkc = a.nkc;
   const float* pp = a.dav_part + (size_t)b * nkc * 3 * N + (size_t)l * N;
   const float* avp = a.av + ((size_t)l * a.B + b) * N;
-  float da[4], avv[4];
+  // the lane's four locations are requested TOGETHER, from clamped addresses (a guarded load is a branch and a wait of its own:
+  // four memory latencies in a row at the head of both big kernels); per location the chunks add up in the same order as before
+  float da[4] = {0.f, 0.f, 0.f, 0.f}, avv[4];
+  int idx[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) idx[k] = min(lane + 64 * k, N - 1);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) avv[k] = avp[idx[k]];
+  for (int kc = 0; kc < nkc; ++kc) {
+    float t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = pp[(size_t)kc * 3 * N + idx[k]];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) da[k] += t[k];
+  }
   float dot = 0.f, tot = 0.f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int n = lane + 64 * k;
-    float sacc = 0.f;
-    if (n < N)
-      for (int kc = 0; kc < nkc; ++kc) sacc += pp[(size_t)kc * 3 * N + n];
-    da[k] = sacc;
-    avv[k] = (n < N) ? avp[n] : 0.f;
-    dot = fmaf(avv[k], sacc, dot);
+    const bool in = lane + 64 * k < N;
+    da[k] = in ? da[k] : 0.f;
+    avv[k] = in ? avv[k] : 0.f;
+    dot = fmaf(avv[k], da[k], dot);
   }
   dot = wave_sum(dot);
 #pragma unroll

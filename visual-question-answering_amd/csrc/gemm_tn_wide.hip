@@ -38,6 +38,9 @@
 #ifndef GEMMTNW_KO
 #define GEMMTNW_KO 0
 #endif
+#ifndef TNW_INTERLEAVE
+#define TNW_INTERLEAVE 0
+#endif
 
 namespace {
 
@@ -76,8 +79,12 @@ __device__ __forceinline__ void gemm_tn_wide_body(const TwArgs& g, const int bid
   const int z = lin / ntiles, t = lin % ntiles;
   const int m0 = (t / ntn) * BM, n0 = (t % ntn) * BN;
   const int lvl = z / g.S, p = z % g.S;
-  const int kbeg = p * g.ksplit, kend = min(g.K, kbeg + g.ksplit);
-  const int steps = (kend - kbeg + BK - 1) / BK;
+  // TNW_INTERLEAVE (developer build, location-major B only): part p takes the 16-row blocks p, p + S, p + 2 S, ... instead of a
+  // contiguous range -- all workgroups then read one neighbourhood of rows at a time
+  const bool il = TNW_INTERLEAVE && !BCM;
+  const int nblk16 = (g.K + BK - 1) / BK;
+  const int kbeg = il ? p * BK : p * g.ksplit, kend = min(g.K, kbeg + g.ksplit);
+  const int steps = il ? (nblk16 > p ? (nblk16 - p + g.S - 1) / g.S : 0) : (kend - kbeg + BK - 1) / BK;
   const float* Ab = g.A + (long)lvl * g.a_sl;
   const float* Bb = g.b_ptrs[0] ? g.b_ptrs[lvl & 7] : g.B + (long)lvl * g.b_sl;
   // rows past K read 0 (resource bound); rows past kend belong to the next part: ksplit % 16 == 0, so a step never straddles
@@ -90,7 +97,7 @@ __device__ __forceinline__ void gemm_tn_wide_body(const TwArgs& g, const int bid
   // staging per step: A one float4 per thread (16 k-rows x 128 columns), B two (8 k-rows x 256 columns, twice)
   const int ska = tid >> 5, sma = (tid & 31) * 4, skb = tid >> 6, smb = (tid & 63) * 4;
   const int a_voff = ((kbeg + ska) * g.a_ld + m0 + sma) * 4, b_voff = ((kbeg + skb) * g.b_ld + n0 + smb) * 4;
-  const int a_step = BK * g.a_ld * 4, b_step = BK * g.b_ld * 4, b_half = 8 * g.b_ld * 4;
+  const int a_step = (il ? g.S : 1) * BK * g.a_ld * 4, b_step = (il ? g.S : 1) * BK * g.b_ld * 4, b_half = 8 * g.b_ld * 4;
   const int sta = ska * LDTA + sma, stb = OPERA + skb * LDTB + smb;          // (+ 8 * LDTB for the second B float4)
   // transposed fragment read: each 16-lane group fetches a 4 (k) x 16 (rows) block; lane 4q+p of the group supplies
   // the address of block row q, columns 4p..4p+3, and receives the 4 k of row (lane & 15)

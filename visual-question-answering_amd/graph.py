@@ -323,6 +323,9 @@ class _HotPathFn(torch.autograd.Function):
         elif (ctx.pair is _EAGER and g_loss.dtype == torch.float32 and g_loss.device == hp.device and g_loss.numel() == 1
               and g_loss.data_ptr() % 4 == 0):
             direct = g_loss                                      # eager calls read it where autograd left it: no copy kernel
+            # (the kernel reads it after this function has returned and autograd has dropped it: tell the allocator which
+            #  stream still uses the block, in case it was allocated on another one)
+            g_loss.record_stream(torch.cuda.current_stream(hp.device))
         else:
             hp.g_loss.copy_(g_loss.reshape(1))                   # (the captured graph reads the static scalar)
         if g_logits is not None:

@@ -78,6 +78,36 @@ def test_cross_entropy_semantics():
     assert torch.isfinite(cross_entropy(z2, lab))
 
 
+@pytest.mark.parametrize("B", [1, 2, 63, 160, 257, 1000])
+def test_cross_entropy_mean_is_one_launch_and_order_independent(B):
+    """The mean is added by whichever workgroup finishes last (ce.hip: an integer ticket): the value must not depend on which
+    one that is -- repeated calls bit for bit, equal to the fixed-order sum of the row losses (strided per thread of 256,
+    wave sums, (0 + 1) + (2 + 3)) within fp32 rounding of the float64 mean -- and the ticket word must be back at 0."""
+    from vqa_amd import _lib
+    from vqa_amd.loss import cross_entropy
+    K = 1001
+    z = torch.from_numpy(O.hash_normal((B, K), 11, 2.0)).float().cuda()
+    lab = torch.from_numpy((O.hash_uniform(B, 12) * K).astype("int64")).clamp_(0, K - 1).cuda()
+    ref = torch.nn.functional.cross_entropy(z.double(), lab).item()
+    first = cross_entropy(z, lab)
+    assert abs(first.item() - ref) < 2e-6 * max(1.0, abs(ref))
+    for _ in range(20):
+        assert torch.equal(cross_entropy(z, lab), first)
+    # through the C-ABI: the workspace's ticket word is 0 again after every call
+    lib = _lib.load()
+    n = C.c_size_t()
+    assert lib.coattn_ce_workspace_bytes(B, K, _lib.F32, C.byref(n)) == 0
+    ws = torch.full((n.value // 4,), float("nan"), device="cuda")          # (uninitialised by contract: the call clears its words)
+    loss = torch.empty((), device="cuda"); dz = torch.empty(B, K, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        assert lib.coattn_ce_forward(z.data_ptr(), lab.data_ptr(), loss.data_ptr(), dz.data_ptr(), ws.data_ptr(), B, K, _lib.F32, st) == 0
+        assert torch.equal(loss, first)
+    words = ws.view(torch.int32)[(B + 63) // 64 * 64:][:2].tolist()
+    assert words == [0, 0], words
+    assert lib.coattn_ce_status(ws.data_ptr(), B, st) == 0
+
+
 def test_c_abi_errors():
     """Loud argument errors of the cross-entropy entry points."""
     from vqa_amd import _lib

@@ -4,7 +4,10 @@ M mfma, BL1/BL4 buffer loads, GL global loads, D LDS, ST stores, W(..) waits, BA
 usage: tools/isa_trace.py file.s <substring of the mangled kernel name>"""
 import re, sys
 txt = open(sys.argv[1]).read().split('\n')
-start = next(i for i, l in enumerate(txt) if l.startswith('_Z') and sys.argv[2] in l and l.rstrip().split(':')[0].endswith('BwdArgs') or (l.startswith('_Z') and sys.argv[2] in l and ':' in l))
+cands = [i for i, l in enumerate(txt) if l.startswith('_Z') and sys.argv[2] in l.split(':')[0] and ':' in l]
+if not cands:
+    raise SystemExit("no kernel whose mangled name contains %r (kernels: grep '^_Z.*:' %s)" % (sys.argv[2], sys.argv[1]))
+start = cands[0]
 out = []
 valu = 0
 def flush():

@@ -181,6 +181,15 @@ int coattn_backward(const void* V, int64_t v_sB, int64_t v_sN, int64_t v_sD, con
  * amax (host, may be NULL): [0] = largest |activation| beyond the range seen by the projection launch (0 if none),
  * [1] = largest |256 W| over both projection weights.  Call it where the host synchronises anyway (reading the loss). */
 int coattn_status(const void* saved, int B, int N, int T, int d, int L, int dtype, void* stream, float* amax);
+/* The same report made STICKY across calls without a synchronisation (v0.6.1): every coattn_forward rewrites the status words
+ * of its `saved`, so a caller that reads them only now and then (a training loop that reads the loss every log_interval
+ * steps) would miss the steps in between.  ASYNCHRONOUS on `stream`: folds the status words the last coattn_forward left in
+ * `saved` into `acc`, two floats in DEVICE memory the caller owns and zeroes: acc[0] = max(acc[0], largest out-of-range
+ * |activation| of that call), acc[1] = max(acc[1], largest |256 W|) -- maxima on the bit patterns, so a NaN wins.  A call
+ * that used no FP16 pieces leaves acc alone.  The caller reads acc where it synchronises anyway: the tolerance mode held
+ * for every folded call iff acc[0] <= 65504 and acc[1] <= 65504 (both 0 when nothing was out of range / no weights seen).
+ * Steps run before the caller looks are NOT rolled back: a training loop that cannot afford that runs flags = 0. */
+int coattn_status_accumulate(const void* saved, int B, int N, int T, int d, int L, int dtype, void* acc, void* stream);
 
 /* ---- PhraseConvPool: the question hierarchy's phrase level ----------------
  * Replaces reference model.py:301-334 (`PhraseConvPool.forward`: 1/2/3-gram Conv1d + Tanh with
@@ -217,6 +226,8 @@ int coattn_phrase_backward(const void* X, const coattn_phrase_params* p, const v
  * pieces, like the co-attention's projections): as coattn_status -- synchronises, 0 / -4 -- on the status words behind the
  * argmax bytes of `saved` (saved must have been given to the forward call). */
 int coattn_phrase_status(const void* saved, int B, int T, int E, void* stream, float* amax);
+/* as coattn_status_accumulate, on the status words behind the phrase level's `saved` */
+int coattn_phrase_status_accumulate(const void* saved, int B, int T, int E, void* acc, void* stream);
 
 /* ---- cross entropy of the train step ------------------------------------------------
  * coattn_ce_forward replaces `nn.CrossEntropyLoss()(logits, label)` (main.py:94, :214; mean over the batch)

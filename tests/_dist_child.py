@@ -62,6 +62,13 @@ def main():
     from vqa_amd import dist as vdist, train as T
     dev = torch.device("cuda", 0 if a.same_gpu else a.rank)
     torch.cuda.set_device(dev)
+    if os.environ.get("VQA_TEST_P2P_FAIL_RANK") == str(a.rank):
+        # fault injection lives HERE, not in the product: on this rank exporting a bucket's IPC handle fails
+        import torch.multiprocessing.reductions as _red
+
+        def _fail(_t):
+            raise RuntimeError("export failure injected by the test (VQA_TEST_P2P_FAIL_RANK)")
+        _red.reduce_tensor = _fail
     if a.exchange != "none" and a.backend == "nccl":
         dist.init_process_group("nccl", rank=a.rank, world_size=a.world, device_id=dev)
     elif a.exchange != "none":

@@ -30,6 +30,8 @@ def saved_views(saved, B, N, T, d, L):
 
 
 last_status = None
+MODES = (False, True)       # exact3 of run_hip: the tolerance mode (COATTN_FLAG_FAST16) / flags = 0, fp32-accurate products
+MODE_IDS = ("fast16", "exact")
 LAYOUTS = ("cm", "lm")      # channel-major [B,d,N] (the reference's NCHW encoder) / location-major [B,N,d] (channels_last)
 
 

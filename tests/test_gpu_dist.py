@@ -110,11 +110,11 @@ def test_world2_ranks_sharing_one_gpu_equal_full_batch(tmp_path, exchange):
 
 @pytest.mark.timeout(900)
 def test_p2p_falls_back_to_all_reduce_by_consensus(tmp_path):
-    """exchange="p2p" when ONE rank cannot export its buckets (injected: VQA_P2P_FAIL_RANK=1): every rank reaches the one
+    """exchange="p2p" when ONE rank cannot export its buckets (injected by the test child: VQA_TEST_P2P_FAIL_RANK=1 replaces reduce_tensor there): every rank reaches the one
     collective of the set-up, the decision is all-reduced, BOTH ranks continue on the all-reduce and say why -- the
     gradients are still the full-batch gradients (nobody hangs, nobody trains on unreduced gradients)."""
     full = _run_ranks(tmp_path, "sub", 1, "none", "full")[0]
-    ranks = _run_ranks(tmp_path, "sub", 2, "p2p", "fb", extra=GLOO_ONE_GPU, env={"VQA_P2P_FAIL_RANK": "1"})
+    ranks = _run_ranks(tmp_path, "sub", 2, "p2p", "fb", extra=GLOO_ONE_GPU, env={"VQA_TEST_P2P_FAIL_RANK": "1"})
     for r in ranks:
         assert str(r["exchange_used"][0]) == "allreduce" and "export" in str(r["fallback"][0]), (r["exchange_used"], r["fallback"])
     _check_against_full_batch(full, ranks)

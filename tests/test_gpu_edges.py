@@ -91,17 +91,18 @@ def test_bitwise_deterministic():
     from tests._hip import run_hip
     from tests import _golden as G
     V, Qs, P, gv, gq = G.build_case("g5_cfg2_scaled", torch.float32)
-    for layout in ("cm", "lm"):
-        a = run_hip(V, Qs, P, gv, gq, impl="auto", layout=layout)
-        b = run_hip(V, Qs, P, gv, gq, impl="auto", layout=layout)
+    for layout, exact3 in [(lay, m) for lay in ("cm", "lm") for m in (False, True)]:
+        a = run_hip(V, Qs, P, gv, gq, impl="auto", layout=layout, exact3=exact3)
+        b = run_hip(V, Qs, P, gv, gq, impl="auto", layout=layout, exact3=exact3)
         for k in a:
-            assert torch.equal(a[k], b[k]), (layout, k)
+            assert torch.equal(a[k], b[k]), (layout, exact3, k)
 
 
 @pytest.mark.parametrize("B,N,T,d", [(1, 1, 1, 32), (2, 208, 28, 512), (2, 209, 26, 512), (2, 196, 29, 512),
                                      (3, 64, 7, 256), (2, 65, 26, 512), (1, 16, 16, 128),
                                      (2, 49, 26, 2048), (2, 196, 26, 1024), (2, 49, 20, 768)])
-def test_auto_dispatch_shape_limits(B, N, T, d):
+@pytest.mark.parametrize("exact3", [False, True], ids=["fast16", "exact"])
+def test_auto_dispatch_shape_limits(B, N, T, d, exact3):
     """Shapes on both sides of the fused kernels' limits (N <= 208, T <= 28, d a multiple of 256:
     several 128-channel slices per wave at d = 768, 1024, 2048)."""
     from tests._hip import run_hip
@@ -113,7 +114,7 @@ def test_auto_dispatch_shape_limits(B, N, T, d):
     f = O.coattn_forward(V, Qs, P)
     g = O.coattn_backward(V, Qs, P, gv, gq)
     for layout in ("cm", "lm"):
-        r = run_hip(V, Qs, P, gv, gq, impl="auto", layout=layout)
+        r = run_hip(V, Qs, P, gv, gq, impl="auto", layout=layout, exact3=exact3)
         assert (r["v"].cpu() - f["v"]).abs().max() < 1e-4 and (r["q"].cpu() - f["q"]).abs().max() < 1e-4
         for k in ("dV_phys", "dQ", "dW_v.weight", "dW_q.weight", "dw_v.weight", "dw_q.weight", "dW_v.bias", "dW_q.bias"):
             ref = g[k]
@@ -259,14 +260,16 @@ def test_runs_on_the_callers_stream():
         assert torch.equal(g0[l], Qg[l].grad)
 
 
+@pytest.mark.parametrize("fast", [True, False], ids=["fast16", "exact"])
 @pytest.mark.parametrize("N", [49, 196])
-def test_large_batch_is_sample_independent(N):
+def test_large_batch_is_sample_independent(N, fast):
     """4x the configured batch (B = 640): every sample's outputs and input gradients are the ones it
     gets in a batch of 8 (bitwise for the forward: the per-sample reduction order does not depend on
     the grid), parameter gradients are the sum over samples."""
     torch.manual_seed(1)
     B, T, d = 640, 26, 512
     m = _mod(d)
+    m.fast_products = fast
     V = torch.randn(B, d, N, device="cuda").clamp_min_(0)
     lens = [T] + [1 + (5 * i) % T for i in range(B - 1)]
     mask = (torch.arange(T)[None, :] < torch.tensor(lens)[:, None]).float().unsqueeze(-1).cuda()
@@ -323,7 +326,8 @@ def test_large_batch_backward_workspace():
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(23, 196, 26, 512, "lm"), (9, 49, 26, 512, "cm"), (3, 100, 17, 1024, "lm"),
                                    (640, 196, 26, 512, "cm"), (640, 196, 26, 512, "lm"), (320, 49, 26, 512, "cm")])
-def test_repeated_runs_are_bitwise_identical(shape):
+@pytest.mark.parametrize("fast", [True, False], ids=["fast16", "exact"])
+def test_repeated_runs_are_bitwise_identical(shape, fast):
     """no float atomics, fixed summation orders -- forward outputs and every gradient (image features
     included) of repeated runs on the same inputs are bit-for-bit the same (also a check on the LDS-only barriers and
     counted waits of the fused kernels: a race would show here).  The large batches are there because a race needs a busy
@@ -333,6 +337,7 @@ def test_repeated_runs_are_bitwise_identical(shape):
     B, N, T, d, lay = shape
     torch.manual_seed(7)
     co = vqa_amd.ParallelCoAttention(d).cuda()
+    co.fast_products = fast
     x = (torch.randn(B, d, N, device="cuda") * 0.5).permute(0, 2, 1)
     if lay == "lm":
         x = x.contiguous()
@@ -354,7 +359,8 @@ def test_repeated_runs_are_bitwise_identical(shape):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("layout,N", [("lm", 196), ("cm", 196), ("lm", 49)])
-def test_gradients_do_not_depend_on_whether_dV_is_requested(layout, N):
+@pytest.mark.parametrize("exact3", [False, True], ids=["fast16", "exact"])
+def test_gradients_do_not_depend_on_whether_dV_is_requested(layout, N, exact3):
     """Without dV (the frozen-encoder default) the weight-gradient kernel adds the three levels of dP_v while it
     stages them; with dV a separate pass sums them first.  Same additions in the same order: every other gradient
     must be bit-for-bit the same either way, on both feature layouts."""
@@ -365,8 +371,8 @@ def test_gradients_do_not_depend_on_whether_dV_is_requested(layout, N):
                           scale_q=(2.0 / d) ** 0.5)
     gv = torch.from_numpy(O.hash_normal((3, B, d), 41)).float()
     gq = torch.from_numpy(O.hash_normal((3, B, d), 42)).float()
-    a = run_hip(V, Qs, P, gv, gq, impl="fused", layout=layout, need_dv=True)
-    b = run_hip(V, Qs, P, gv, gq, impl="fused", layout=layout, need_dv=False)
+    a = run_hip(V, Qs, P, gv, gq, impl="fused", layout=layout, need_dv=True, exact3=exact3)
+    b = run_hip(V, Qs, P, gv, gq, impl="fused", layout=layout, need_dv=False, exact3=exact3)
     for k in ("dQ", "dW_v.weight", "dW_q.weight", "dw_v.weight", "dw_q.weight", "dW_v.bias", "dW_q.bias"):
         assert torch.equal(a[k], b[k]), k
 
@@ -519,3 +525,55 @@ def test_fp16_piece_range_report_and_exact_mode_value(layout):
     assert torch.isfinite(ri["q"]).all()                                # (the attention maps stay finite ...)
     re_ = run_hip(Vi, Qs, P, gv, gq, impl="fused", layout=layout, exact3=True)
     assert not torch.isfinite(re_["v"][:, 2]).all()                     # the exact mode surfaces it, as the reference does
+
+
+def test_range_report_is_sticky_across_forwards():
+    """a clamped activation must stay visible until somebody LOOKS, not until the next forward rewrites the status
+    words.  Tolerance mode: one forward with a 2e5 feature between ordinary ones (training forward with `saved`, an inference
+    forward without, a second module in between) -> the first check_range() afterwards raises and names the magnitude, the
+    next one is clean.  The exact mode (the default) reports nothing for the same inputs."""
+    import vqa_amd
+    B, N, T, d = 4, 49, 26, 512
+    m, other = _mod(d), _mod(d, seed=4)
+    V, Qs = O.make_inputs(B, N, T, d, 33, lens=[26, 17, 4, 1], scale_q=(2.0 / d) ** 0.5)
+    Qg = [q.cuda() for q in Qs]
+    good = V.cuda().permute(0, 2, 1).contiguous()
+    bad = good.clone()
+    bad[1, 7, 5] = 2.0e5
+    vqa_amd.check_range()                                     # (whatever earlier tests left behind)
+    for mod in (m, other):
+        mod.fast_products = True
+    m(good.clone().requires_grad_(True), Qg)
+    m(bad.clone().requires_grad_(True), Qg)                   # the step that clamps
+    for _ in range(3):
+        m(good.clone().requires_grad_(True), Qg)              # later steps rewrite the status words of their own `saved`
+    with torch.no_grad():
+        m(good, Qg)                                           # validation pass (status words in the scratch workspace)
+    other(good.clone().requires_grad_(True), Qg)              # another model
+    with pytest.raises(vqa_amd.RangeError, match="2e\\+05|200000"):
+        vqa_amd.check_range()
+    vqa_amd.check_range()                                     # consumed: clean again
+    m.fast_products = False
+    m(bad.clone().requires_grad_(True), Qg)
+    vqa_amd.check_range()
+
+
+def test_trainer_defaults_to_the_references_arithmetic():
+    """train.Trainer / train.py run fp32-accurate products unless asked otherwise (--opt_lvl 0 is the reference's
+    fp32); the tolerance mode is the opt-in, and a range event there switches the trainer to exact."""
+    from vqa_amd import train as T
+    torch.manual_seed(0)
+    model = T.build_model("attention", 60, 10).cuda()
+    tr = T.Trainer(model, 1e-4, torch.device("cuda:0"))
+    assert tr.precision == "exact" and model.co_attention.fast_products is False
+    tr.set_precision("fast")
+    assert model.co_attention.fast_products is True and tr.check_range() is True
+    b = T.synthetic_batch(4, (224, 224), 26, 60, 11, seed=3)      # 7 x 7 grid: a shape the fused kernels take
+    im, qu, la, ln = T.sort_batch(b["image"], b["question"], b["label"], b["ques_len"])
+    with torch.no_grad():
+        model.co_attention.W_q.weight[3, 9] = 300.0           # beyond the scaled FP16 weight image's range
+    tr.step(im.cuda(), qu.cuda(), ln, la.cuda())
+    tr.step(im.cuda(), qu.cuda(), ln, la.cuda())
+    with pytest.warns(UserWarning, match="exact mode"):
+        assert tr.check_range() is False
+    assert tr.precision == "exact" and model.co_attention.fast_products is False

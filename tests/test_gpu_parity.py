@@ -151,9 +151,10 @@ def _full_batch_grads_float64(N, V, Qs, P, gv, gq):
     return _FULL64[N]
 
 
+@pytest.mark.parametrize("exact3", [False, True], ids=["fast16", "exact"])
 @pytest.mark.parametrize("impl,layout,N", [("general", "cm", 196), ("fused", "cm", 196), ("fused", "lm", 196),
                                            ("general", "lm", 49), ("fused", "cm", 49), ("fused", "lm", 49)])
-def test_full_size_cfg2_properties(impl, layout, N):
+def test_full_size_cfg2_properties(impl, layout, N, exact3):
     """BASELINE config 2 (B=160, T=26, d=512) at the reference's own grid (448x448 -> N=196) and at the grid of
     BASELINE's 224x224 images (N=49), both physical layouts of the image features: oracle on a sample subset +
     size-independent properties (attention maps are distributions; v inside the range of V; per-sample
@@ -163,26 +164,33 @@ def test_full_size_cfg2_properties(impl, layout, N):
     B, T, d = 160, 26, 512
     if impl != "general" and not vqa_amd._lib.load().coattn_fused_supported(B, N, T, d, 3, 0):
         pytest.skip("no fused configuration for this shape")
+    if impl == "general" and not exact3:
+        pytest.skip("the general-shape path has one arithmetic (exact): run once")
+    # exact (flags = 0, the reference's arithmetic): held to 2e-5 where the tolerance mode is held to the contract's 1e-4
+    fwd_tol, grad_tol = (2e-5, 2e-5) if exact3 else (FWD_TOL, GRAD_TOL)
     lens = sorted([26] + [3 + (7 * i) % 24 for i in range(B - 1)], reverse=True)
     P = O.make_params(d, 5)
     V, Qs = O.make_inputs(B, N, T, d, 77, lens=lens, scale_q=(2.0 / d) ** 0.5)
     gv = torch.from_numpy(O.hash_normal((3, B, d), 901)).float()
     gq = torch.from_numpy(O.hash_normal((3, B, d), 902)).float()
-    r = run_hip(V, Qs, P, gv, gq, impl=impl, layout=layout)
+    r = run_hip(V, Qs, P, gv, gq, impl=impl, layout=layout, exact3=exact3)
     assert (r["a_v"].sum(-1) - 1).abs().max() < 1e-5 and (r["a_q"].sum(-1) - 1).abs().max() < 1e-5
     Vd = V.cuda()
     assert (r["v"] <= Vd.max(2).values[None] + 1e-5).all() and (r["v"] >= Vd.min(2).values[None] - 1e-5).all()
     # oracle on 3 samples of the batch (forward is per-sample independent)
     idx = [0, 77, 159]
-    f = O.coattn_forward(V[idx], [q[idx] for q in Qs], P)
-    assert (r["v"][:, idx].cpu() - f["v"]).abs().max() < FWD_TOL
-    assert (r["q"][:, idx].cpu() - f["q"]).abs().max() < FWD_TOL
-    g = O.coattn_backward(V[idx], [q[idx] for q in Qs], P, gv[:, idx], gq[:, idx])
+    d64 = lambda t: t.double()                                        # noqa: E731
+    P64 = {k: d64(v) for k, v in P.items()}
+    f = O.coattn_forward(d64(V[idx]), [d64(q[idx]) for q in Qs], P64)
+    ef = max(float((r["v"][:, idx].cpu().double() - f["v"]).abs().max()), float((r["q"][:, idx].cpu().double() - f["q"]).abs().max()))
+    g = O.coattn_backward(d64(V[idx]), [d64(q[idx]) for q in Qs], P64, d64(gv[:, idx]), d64(gq[:, idx]))
     scale = g["dV_phys"].abs().max()
-    assert (r["dV_phys"][idx].cpu() - g["dV_phys"]).abs().max() / scale < GRAD_TOL
-    assert (r["dQ"][:, idx].cpu() - g["dQ"]).abs().max() / g["dQ"].abs().max() < GRAD_TOL
+    eg = max(float((r["dV_phys"][idx].cpu().double() - g["dV_phys"]).abs().max() / scale),
+             float((r["dQ"][:, idx].cpu().double() - g["dQ"]).abs().max() / g["dQ"].abs().max()))
+    print("full batch N=%d %s %s %s: sample subset vs float64 oracle: fwd %.1e, dV/dQ %.1e" % (N, impl, layout, "exact" if exact3 else "fast16", ef, eg))
+    assert ef < fwd_tol and eg < grad_tol, (ef, eg)
     # linearity: backward(2*g) == 2*backward(g)
-    r2 = run_hip(V, Qs, P, 2 * gv, 2 * gq, impl=impl, layout=layout)
+    r2 = run_hip(V, Qs, P, 2 * gv, 2 * gq, impl=impl, layout=layout, exact3=exact3)
     for k in ("dV_phys", "dQ", "dW_v.weight", "dW_q.weight", "dw_v.weight"):
         assert (r2[k] - 2 * r[k]).abs().max() <= 2e-5 * max(1e-3, r[k].abs().max().item()), k
     # full-batch parameter gradients (sums over 160 x N x 3 rows) vs the oracle in FLOAT64 at the contract's 1e-4 -- the
@@ -194,5 +202,6 @@ def test_full_size_cfg2_properties(impl, layout, N):
             continue
         ref = gf[k]
         worst[k] = float((r["d" + k].cpu().double() - ref).abs().max() / ref.abs().max())
-    print("full batch N=%d %s %s: parameter-gradient errors vs float64" % (N, impl, layout), {k: "%.1e" % e for k, e in worst.items()})
-    assert max(worst.values()) < GRAD_TOL, worst
+    print("full batch N=%d %s %s %s: parameter-gradient errors vs float64" % (N, impl, layout, "exact" if exact3 else "fast16"),
+          {k: "%.1e" % e for k, e in worst.items()})
+    assert max(worst.values()) < grad_tol, worst

@@ -8,6 +8,8 @@ bytes of a coalesced streaming read -> doubled; the factor is calibrated on the 
 whose read volume is known exactly (one pass over V + a_v); WRITE_SIZE (KiB) is exact.
 
 usage: tools/pmc_traffic.py <dir with *counter_collection.csv> [...]  B N T d L layout
+env: PRODUCTS (exact | fast16 | bf16; default exact) = the arithmetic the probed launches ran in, COLD (1 | 0; default 1) =
+launches rotated over independent buffer sets (tools/probe_fwd_one.py COLD=1): one entry per (shape, layout, products).
 """
 import csv
 import glob
@@ -32,7 +34,9 @@ has_attend = ("attend_v", "FETCH_SIZE") in mean
 calib = known_attend_read / (mean[("attend_v", "FETCH_SIZE")] * 1024.0) if has_attend else None
 fetch = (mean[("fwd", "FETCH_SIZE")] + mean.get(("attend_v", "FETCH_SIZE"), 0.0)) * 1024.0 * 2.0
 write = (mean[("fwd", "WRITE_SIZE")] + mean.get(("attend_v", "WRITE_SIZE"), 0.0)) * 1024.0
-out = {"shape": {"B": B, "N": N, "T": T, "d": d, "L": L}, "layout": layout,
+products = os.environ.get("PRODUCTS", "exact")
+cold = os.environ.get("COLD", "1") == "1"
+out = {"shape": {"B": B, "N": N, "T": T, "d": d, "L": L}, "layout": layout, "products": products, "cold": cold,
        "hbm_bytes_per_launch": int(fetch + write),
        "fetch_bytes_corrected_x2": int(fetch), "write_bytes": int(write),
        "fetch_calibration_factor_on_attend_v": round(calib, 3) if calib else None,
@@ -47,7 +51,10 @@ try:
     entries = old["entries"] if "entries" in old else [old]
 except (OSError, ValueError):
     entries = []
-entries = [e for e in entries if not (e.get("shape") == out["shape"] and e.get("layout") == layout)] + [out]
+for e in entries:                                   # (entries of rounds 1-5 carry no key: they were tolerance-mode / reduced-precision runs, warm)
+    e.setdefault("products", "bf16" if e["shape"]["d"] == 2048 else "fast16")
+    e.setdefault("cold", False)
+entries = [e for e in entries if not (e.get("shape") == out["shape"] and e.get("layout") == layout and e["products"] == products)] + [out]
 with open(path, "w") as fh:
     json.dump({"entries": entries}, fh, indent=1)
 print(json.dumps(out))

@@ -19,7 +19,7 @@ EXPORTS = ("coattn_version", "coattn_last_error", "coattn_fused_supported", "coa
            "coattn_head_workspace_bytes", "coattn_head_forward", "coattn_head_backward", "coattn_head_status",
            "coattn_ce_status", "coattn_p2p_enable_peer", "coattn_p2p_reduce_scatter", "coattn_p2p_all_gather",
            "coattn_profile_begin", "coattn_profile_end", "coattn_features_native", "coattn_status",
-           "coattn_phrase_status")
+           "coattn_phrase_status", "coattn_status_accumulate", "coattn_phrase_status_accumulate")
 
 F32 = 0
 BF16 = 1                  # storage type of coattn_features_native's input
@@ -140,6 +140,8 @@ def load() -> C.CDLL:
     lib.coattn_ce_status.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.coattn_status.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.POINTER(C.c_float)]
     lib.coattn_phrase_status.argtypes = [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p, C.POINTER(C.c_float)]
+    lib.coattn_status_accumulate.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]
+    lib.coattn_phrase_status_accumulate.argtypes = [C.c_void_p] + [C.c_int] * 3 + [C.c_void_p, C.c_void_p]
     lib.coattn_p2p_enable_peer.argtypes = [C.c_int]
     lib.coattn_p2p_reduce_scatter.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int64, C.c_float, C.c_void_p]
     lib.coattn_p2p_all_gather.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int64, C.c_void_p]
@@ -164,32 +166,77 @@ class RangeError(FloatingPointError):
     clamped, not within tolerance of the reference.  Use the exact mode (the modules' default; Trainer(precision="exact"))."""
 
 
-# (tensor holding the status words, dims) of the last tolerance-mode calls on this thread's modules: check_range() reads them
-_last_status = {"coattn": None, "phrase": None}
+F16_EXACT = 65504.0
+
+# Range report of the tolerance mode, sticky: every tolerance-mode forward notes where its status words are (note_status),
+# and the note is folded -- asynchronously, one tiny launch on the stream the forward ran on -- into a two-float accumulator
+# per device (include/coattn.h coattn_status_accumulate); check_range() reads the accumulators back (synchronising), clears
+# them and raises if ANY forward since the last check left the FP16-piece range.  A later forward, a validate() pass or a
+# second model cannot overwrite an earlier call's report: the accumulator only grows until it is read.
+_pending = []                 # (kind, tensor holding the status words, dims, device, stream pointer)
+_range_acc = {}               # device index -> float32[2] accumulator
+
+
+def note_status(kind: str, buf, dims, dev) -> None:
+    import torch
+    _pending.append((kind, buf, dims, dev, torch.cuda.current_stream(dev).cuda_stream))
+    # folded right away, behind the forward on its own stream: the holder may be a static buffer (graph.py) or the
+    # per-stream scratch (forward without `saved`), which the next call rewrites -- except while the stream is being
+    # captured into a graph (the note then waits for the first fold outside the capture)
+    if not torch.cuda.is_current_stream_capturing():
+        fold_range()
+
+
+def _acc(dev):
+    import torch
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    a = _range_acc.get(key)
+    if a is None:
+        a = _range_acc[key] = torch.zeros(2, device=dev, dtype=torch.float32)
+    return a
+
+
+def fold_range() -> None:
+    """Fold the status words of every tolerance-mode forward noted since the last fold into the per-device accumulators.
+    Asynchronous (one 256-thread launch per call, on the stream the call ran on)."""
+    lib = load()
+    while _pending:
+        kind, buf, dims, dev, st = _pending.pop(0)
+        acc = _acc(dev)
+        with on_device(dev):
+            if kind == "coattn":
+                rc = lib.coattn_status_accumulate(C.c_void_p(buf.data_ptr()), *dims, F32, C.c_void_p(acc.data_ptr()), C.c_void_p(st))
+            else:
+                rc = lib.coattn_phrase_status_accumulate(C.c_void_p(buf.data_ptr()), *dims, C.c_void_p(acc.data_ptr()), C.c_void_p(st))
+        check(rc, "coattn_status_accumulate" if kind == "coattn" else "coattn_phrase_status_accumulate")
+
+
+def range_maxima(reset: bool = True):
+    """(largest out-of-range |activation|, largest |256 W|) over every tolerance-mode forward since the last reset, over
+    all devices of this process.  Synchronises."""
+    fold_range()
+    act = wgt = 0.0
+    for a in _range_acc.values():
+        h = a.cpu()                                      # (synchronises the device)
+        x, w = float(h[0]), float(h[1])
+        act = x if (x > act or x != x) else act
+        wgt = w if (w > wgt or w != w) else wgt
+        if reset:
+            a.zero_()
+    return act, wgt
 
 
 def check_range(stream=None) -> None:
-    """Raise RangeError if the last tolerance-mode co-attention / phrase forward met an operand outside the FP16-piece
-    range (include/coattn.h, coattn_status).  Synchronises the current stream -- call it where the host reads the loss."""
-    import torch
-    lib = load()
-    amax = (C.c_float * 2)()
-    for kind in ("coattn", "phrase"):
-        last = _last_status[kind]
-        if last is None:
-            continue
-        buf, dims, dev = last
-        _last_status[kind] = None                       # (one report per forward call)
-        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream if stream is None else stream)
-        with on_device(dev):
-            if kind == "coattn":
-                rc = lib.coattn_status(C.c_void_p(buf.data_ptr()), *dims, F32, st, amax)
-            else:
-                rc = lib.coattn_phrase_status(C.c_void_p(buf.data_ptr()), *dims, st, amax)
-        if rc == -4:
-            raise RangeError("%s (largest activation beyond the range %.4g, largest 256*|W| %.4g)"
-                             % (lib.coattn_last_error().decode(), amax[0], amax[1]))
-        check(rc, "coattn_status" if kind == "coattn" else "coattn_phrase_status")
+    """Raise RangeError if ANY tolerance-mode co-attention / phrase forward since the last check met an operand outside the
+    FP16-piece range (include/coattn.h, coattn_status_accumulate).  Synchronises -- call it where the host reads the loss."""
+    act, wgt = range_maxima()
+    bad_a, bad_w = not (act <= F16_EXACT), not (wgt <= F16_EXACT)
+    if bad_a or bad_w:
+        raise RangeError("FP16-piece range exceeded in a tolerance-mode forward (COATTN_FLAG_FAST16): %s%s%s -- pieces were "
+                         "clamped; use the exact mode (largest activation beyond the range %.4g, largest 256*|W| %.4g)"
+                         % ("an activation (feature or stored projection) of magnitude > 65504" if bad_a else "",
+                            " and " if bad_a and bad_w else "",
+                            "a projection weight of magnitude > 255.87" if bad_w else "", act, wgt))
 
 
 def check(rc: int, what: str) -> None:

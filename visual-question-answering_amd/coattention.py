@@ -145,7 +145,7 @@ class _CoAttentionFn(torch.autograd.Function):
                                           _ptr(ws), B, N, T, d, L, _lib.F32, impl, C.c_void_p(stream)),
                        "coattn_forward")
         if impl & _lib.FLAG_FAST16:                   # tolerance mode: where _lib.check_range() finds this call's status words
-            _lib._last_status["coattn"] = (saved if saved is not None else ws, (B, N, T, d, L), dev)
+            _lib.note_status("coattn", saved if saved is not None else ws, (B, N, T, d, L), dev)
         if need_grad:
             ctx.save_for_backward(V, saved, *params, *Qs)
             ctx.dims = (B, N, T, d, L, impl)

@@ -16,7 +16,7 @@ void coattn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int coattn_version(void) { return 600; }   // 0.6.0: flags = 0 is the exact mode, COATTN_FLAG_FAST16 the tolerance mode, coattn_status / coattn_phrase_status; 0.5.2: forward-side contractions on two FP16 pieces (COATTN_FLAG_F16PAIR); 0.5.1: coattn_features_native; 0.5.0: widths of the fp32 mode (COATTN_FLAG_EXACT3 / _SPLIT2), coattn_profile_*
+extern "C" int coattn_version(void) { return 601; }   // 0.6.1: coattn_status_accumulate / coattn_phrase_status_accumulate (sticky range report in a caller-owned accumulator); 0.6.0: flags = 0 is the exact mode, COATTN_FLAG_FAST16 the tolerance mode, coattn_status / coattn_phrase_status; 0.5.2: forward-side contractions on two FP16 pieces (COATTN_FLAG_F16PAIR); 0.5.1: coattn_features_native; 0.5.0: widths of the fp32 mode (COATTN_FLAG_EXACT3 / _SPLIT2), coattn_profile_*
 
 // ---------------------------------------------------------------------------------------
 // per-kernel timing (bench.py's backward roofline legs): HIP events recorded between the launches of the calls made
@@ -233,6 +233,36 @@ int read_status_words(const float* status, int n_words, hipStream_t s, float* am
     return -4;
   }
   return 0;
+}
+
+// Folds a call's status words into a caller-owned accumulator (two floats, device): acc[0] = max over calls of the largest
+// out-of-range activation, acc[1] = max over calls of the largest |256 W| -- bit-pattern maxima of non-negative values, so a
+// NaN wins over everything.  One 256-thread workgroup, asynchronous.
+__global__ __launch_bounds__(256) void status_fold_kernel(const float* __restrict__ status, int n_words, float* __restrict__ acc) {
+  if (status[1] != 1.f) return;                       // the call converted nothing to FP16 pieces
+  unsigned m = 0;
+  for (int i = kStatusHdr + (int)threadIdx.x; i < n_words; i += 256) {
+    const unsigned b = __builtin_bit_cast(unsigned, status[i]) & 0x7fffffffu;
+    m = b > m ? b : m;
+  }
+  for (int o = 32; o > 0; o >>= 1) { const unsigned x = (unsigned)__shfl_xor((int)m, o, 64); m = x > m ? x : m; }
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(acc) + 1, m);
+  if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned*>(acc), __builtin_bit_cast(unsigned, status[0]) & 0x7fffffffu);
+}
+
+int fold_status_words(const float* status, int n_words, float* acc, hipStream_t s, const char* what) {
+  CA_CHECK_ARG(acc != nullptr, "%s: null accumulator", what);
+  hipLaunchKernelGGL(status_fold_kernel, dim3(1), dim3(256), 0, s, status, n_words, acc);
+  if (hipGetLastError() != hipSuccess) { coattn_set_error("%s: launch failed", what); return -3; }
+  return 0;
+}
+
+extern "C" int coattn_status_accumulate(const void* saved, int B, int N, int T, int d, int L, int dtype, void* acc, void* stream) {
+  CA_TRY(check_shape(B, N, T, d, L, dtype));
+  CA_CHECK_ARG(saved != nullptr, "status_accumulate: null `saved`");
+  const SavedPlan sp = plan_saved(B, N, T, d, L);
+  return fold_status_words((const float*)saved + sp.status, (int)status_floats(d, d, 2), (float*)acc, (hipStream_t)stream,
+                           "coattn_status_accumulate");
 }
 
 extern "C" int coattn_status(const void* saved, int B, int N, int T, int d, int L, int dtype, void* stream, float* amax) {

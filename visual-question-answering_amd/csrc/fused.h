@@ -227,6 +227,8 @@ constexpr int kStatusHdr = 64;
 constexpr float kF16Exact = 65504.f;
 // synchronises `s`, reads the words back: 0, or -4 with the error message set (api.hip); amax (host, may be NULL): [0] activations, [1] weights
 int read_status_words(const float* status, int n_words, hipStream_t s, float* amax, const char* what);
+// asynchronous: folds the words into acc[0] (activations), acc[1] (weights) by bit-pattern maxima (api.hip)
+int fold_status_words(const float* status, int n_words, float* acc, hipStream_t s, const char* what);
 inline size_t status_floats(int N, int K, int nweights) { return kStatusHdr + (size_t)nweights * ((N + 31) / 32) * ((K + 15) / 16); }
 // Forward-side contractions on two FP16 pieces (x = hi + lo, 22 significand bits; the three products lo*hi, hi*lo, hi*hi on
 // v_mfma_f32_32x32x16_f16): the cost of the two-piece bf16 width with 64 x less error -- for operands of ordinary magnitude

@@ -348,6 +348,12 @@ extern "C" int coattn_phrase_forward(const void* X, const coattn_phrase_params* 
   return 0;
 }
 
+extern "C" int coattn_phrase_status_accumulate(const void* saved, int B, int T, int E, void* acc, void* stream) {
+  CA_CHECK_ARG(saved != nullptr && B >= 1 && T >= 1 && E >= 1, "phrase_status_accumulate: bad argument");
+  const float* status = reinterpret_cast<const float*>(static_cast<const char*>(saved) + al256((size_t)B * T * E));
+  return fold_status_words(status, (int)status_floats(3 * E, 3 * E, 1), (float*)acc, (hipStream_t)stream, "coattn_phrase_status_accumulate");
+}
+
 extern "C" int coattn_phrase_status(const void* saved, int B, int T, int E, void* stream, float* amax) {
   CA_CHECK_ARG(saved != nullptr && B >= 1 && T >= 1 && E >= 1, "phrase_status: bad argument");
   const float* status = reinterpret_cast<const float*>(static_cast<const char*>(saved) + al256((size_t)B * T * E));

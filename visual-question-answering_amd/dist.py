@@ -206,8 +206,6 @@ class GradReducer:
                     raise RuntimeError("exchange='p2p' takes fp32 gradients on a GPU")
             self._dev = self.buckets[0].flat.device
             torch.cuda.synchronize(self._dev)
-            if os.environ.get("VQA_P2P_FAIL_RANK") == str(self.rank):       # test hook: this rank cannot export
-                raise RuntimeError("export failure injected by VQA_P2P_FAIL_RANK")
             mine = [reduce_tensor(b.flat) for b in self.buckets]           # (rebuild function, IPC handle + offset) per bucket
         except Exception as e:                                             # noqa: BLE001
             mine = "%s: %s" % (type(e).__name__, e)

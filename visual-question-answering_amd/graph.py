@@ -58,6 +58,7 @@ class HotPathGraph:
                  capture: bool = True, direct_grads: bool = False, alias_outputs: bool = False):
         self.co, self.mlp = co_attention, mlp_classify
         self.capture, self.direct_grads, self.alias_outputs = capture, direct_grads, alias_outputs
+        self._warned_accumulate = False                          # (one warning when a backward adds into held gradients)
         d = co_attention.hidden_dim
         mlp, K = mlp_classify.W_s.weight.shape[0], mlp_classify.W_h.weight.shape[0]
         self.dims = (B, N, T, d, mlp, K)
@@ -301,7 +302,7 @@ class _HotPathFn(torch.autograd.Function):
         # (as head.answer_head after a forward with labels: Trainer.check_labels() reads this step's status word)
         _head._last = (hp.hsaved, B, d, mlp, K, hp.device)
         if hp.flags & _lib.FLAG_FAST16:                          # tolerance mode: this step's status words (_lib.check_range())
-            _lib._last_status["coattn"] = (hp.saved, (B, N, T, d, 3), hp.device)
+            _lib.note_status("coattn", hp.saved, (B, N, T, d, 3), hp.device)
         ctx.hp, ctx.pair = hp, pair
         ctx.keep = ins                                           # the graphs read these addresses again in backward
         ctx.set_materialize_grads(False)                         # (an unused output arrives as None, not as zeros)
@@ -337,6 +338,14 @@ class _HotPathFn(torch.autograd.Function):
             held = [p.grad is g for p, g in zip(hp.co_params + hp.head_params, hp.co_grads + hp.head_grads)]
             if all(held):
                 acc = 1
+                if not hp._warned_accumulate:
+                    # (inferred from identity: a loop that never drops its gradients -- zero_grad(set_to_none=False), or no
+                    #  zero_grad at all -- lands here too, and an in-place clip / scale of p.grad has changed what is added to)
+                    hp._warned_accumulate = True
+                    import warnings
+                    warnings.warn("HotPathGraph(direct_grads=True): param.grad still holds the static gradient buffers of the "
+                                  "previous backward, so this backward ADDS into them (micro-batch accumulation).  If the "
+                                  "gradients were meant to be overwritten, call zero_grad(set_to_none=True) before every backward.")
             elif any(held):
                 raise RuntimeError("HotPathGraph(direct_grads=True): some parameters still hold the static gradient buffer "
                                    "from the previous backward and others do not -- call zero_grad(set_to_none=True) on all of "

@@ -50,7 +50,7 @@ class _PhraseConvPoolFn(torch.autograd.Function):
             _lib.check(lib.coattn_phrase_forward(_ptr(X), C.byref(p), _ptr(out), _ptr(saved), _ptr(ws), B, T, E,
                                                  _lib.F32, flags, stream), "coattn_phrase_forward")
         if (flags & _lib.FLAG_FAST16) and saved is not None:   # tolerance mode: this call's status words, for _lib.check_range()
-            _lib._last_status["phrase"] = (saved, (B, T, E), x.device)
+            _lib.note_status("phrase", saved, (B, T, E), x.device)
         if need_grad:
             ctx.flags = flags
             ctx.save_for_backward(X, out, saved, *ps)

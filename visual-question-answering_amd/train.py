@@ -238,13 +238,14 @@ class Trainer:
 
     def __init__(self, model: nn.Module, lr: float = 1e-4, device=None, opt_lvl: int = 0,
                  bucket_mb: float = 16.0, encoder_runahead: bool = True, graph: bool = False, static_hot_path: bool = True,
-                 precision: str = "fast"):
+                 precision: str = "exact"):
         self.device = device or next(model.parameters()).device
         self.model = model
-        # Precision of the HIP path's fp32 products (include/coattn.h "Widths of the fp32 mode"): "fast" -- this trainer's
-        # default -- is the tolerance mode (forward products on two FP16 pieces = 22 significand bits, backward on two bf16
-        # pieces = 16; inside the reference contract of 1e-4 for operands below 65,504 in magnitude, and check_range()
-        # reports and falls back when one is not); "exact": fp32-accurate products over fp32's range, the modules' own default.
+        # Precision of the HIP path's fp32 products (include/coattn.h "Widths of the fp32 mode"): "exact" -- the default, the
+        # reference's arithmetic (main.py --opt_lvl 0) -- is fp32-accurate products over fp32's range, the modules' and the
+        # C-ABI's own default; "fast" is the opt-in tolerance mode (forward products on two FP16 pieces = 22 significand
+        # bits, backward on two bf16 pieces = 16; inside the reference contract of 1e-4 for operands below 65,504 in
+        # magnitude; step() checks the range report EVERY step there and falls back to exact when an operand left it).
         if precision not in ("fast", "exact"):
             raise ValueError("precision must be 'fast' or 'exact'")
         self.set_precision(precision)
@@ -356,17 +357,30 @@ class Trainer:
                 m.fast_products = fast
 
     def check_range(self) -> bool:
-        """Tolerance mode only: True if every operand of the last step's forward lay inside the FP16-piece range.  If one
-        did not (its pieces were clamped: that step's values are off), warn, switch this trainer to the exact mode for the
-        following steps and return False.  Synchronises -- call it where the loss is read on the host."""
+        """Tolerance mode only: True if every operand of EVERY forward since the last check lay inside the FP16-piece range
+        (the report is sticky: each tolerance-mode forward folds its status words into a per-device accumulator,
+        _lib.fold_range).  If one did not (its pieces were clamped: that step's values were off, and the Adam updates made
+        since are NOT rolled back), warn, switch this trainer to the exact mode for the following steps and return False.
+        Data-parallel runs decide together: the flag is MAX-reduced over the group, so every rank switches in the same
+        step.  Synchronises -- call it where the loss is read on the host."""
         if self.device.type != "cuda" or self.precision != "fast" or self.opt_lvl > 0:
             return True
         from . import _lib
+        msg = None
         try:
             _lib.check_range()
         except _lib.RangeError as e:
+            msg = str(e)
+        bad = msg is not None
+        if vdist.world_size() > 1:
+            flag = torch.tensor([1.0 if bad else 0.0], device=self.device)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            if float(flag) > 0 and not bad:
+                bad, msg = True, "another rank reported an operand outside the FP16-piece range"
+        if bad:
             import warnings
-            warnings.warn("vqa_amd.Trainer: %s -- continuing in the exact mode" % e)
+            warnings.warn("vqa_amd.Trainer: %s -- continuing in the exact mode (steps since the last check ran on clamped "
+                          "pieces and are not rolled back)" % msg)
             self.set_precision("exact")
             return False
         return True
@@ -460,8 +474,9 @@ def build_parser():
     ap.add_argument("--num_workers", type=int, default=0, help="number of worker processes of the DataLoader")
     # --- this build ---
     ap.add_argument("--num_steps", type=int, default=20, help="synthetic batches per epoch")
-    ap.add_argument("--precision", default="fast", choices=["fast", "exact"],
-                    help="fp32 products of the HIP path: tolerance mode (default) or fp32-accurate (include/coattn.h)")
+    ap.add_argument("--precision", default="exact", choices=["fast", "exact"],
+                    help="fp32 products of the HIP path: fp32-accurate (default: the reference's --opt_lvl 0 arithmetic) or the "
+                         "opt-in tolerance mode (include/coattn.h COATTN_FLAG_FAST16; range-checked at every --log_interval)")
     ap.add_argument("--synthetic", type=str2bool, default="true", help="synthetic data (the only source here)")
     ap.add_argument("--vocab_size", type=int, default=10000)
     ap.add_argument("--max_seq_length", type=int, default=26)

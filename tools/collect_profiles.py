@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "refresh")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 
 
 def one(pattern):
@@ -26,8 +26,15 @@ def one(pattern):
 line = [l for l in open(os.path.join(SRC, "bench.json")) if l.startswith("{")][-1]
 json.loads(line)
 open(os.path.join(DST, "%s_bench.json" % tag), "w").write(line)
+# Everything without "fast16" / "cfg4" in its name ran the reference's arithmetic (fp32-accurate products, flags = 0).
+# exact_* / fast16_*: the forward kernel ALONE, launches rotating over independent buffer sets (cold: bench.py's roofline legs);
+# fwd_bwd_*: coattn_forward + coattn_backward in sequence over three rotating input sets (tools/probe_hot.py)
 for leg, name in (("roofline", "roofline"), ("hot", "hot_path"), ("step", "full_step"), ("bench_stats", "bench"),
-                  ("headline", "headline"), ("headline196", "reference_grid"), ("fb_49", "fwd_bwd_n49"), ("fb_196", "fwd_bwd_n196")):
+                  ("iso_49_512_lm_exact", "exact_headline"), ("iso_196_512_lm_exact", "exact_reference_grid"),
+                  ("iso_196_512_cm_exact", "exact_channel_major"), ("iso_49_512_lm_fast", "fast16_headline"),
+                  ("iso_196_512_lm_fast", "fast16_reference_grid"), ("iso_49_2048_lm_bf16", "cfg4_headline"),
+                  ("fb_49_exact", "fwd_bwd_n49"), ("fb_196_exact", "fwd_bwd_n196"),
+                  ("fb_49_fast", "fast16_fwd_bwd_n49"), ("fb_196_fast", "fast16_fwd_bwd_n196")):
     shutil.copy(one("%s/**/*kernel_stats.csv" % leg), os.path.join(DST, "%s_%s_kernel_stats.csv" % (tag, name)))
 shutil.copy(os.path.join(SRC, "pmc_traffic.json"), os.path.join(DST, "pmc_traffic.json"))
 shutil.copy(os.path.join(SRC, "pmc_traffic_backward.json"), os.path.join(DST, "pmc_traffic_backward.json"))

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Developer tool: the co-attention forward + backward alone at ONE shape (frozen image features: no dV), for a
 per-kernel profile: `rocprofv3 --kernel-trace --stats -- python3 tools/probe_hot.py 196 lm 200`.
-env: D (512), OPT (1 = reduced-precision mode).  Prints the wall time per iteration of the timed half."""
+env: D (512), OPT (1 = reduced-precision mode), VQA_PRECISION (exact, the default | fast), SETS (3: iterations rotate over this
+many independent input sets, so that a kernel finds in the Infinity Cache only what the kernels right before it left there).
+Prints the wall time per iteration of the timed half."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,14 +17,24 @@ dev = torch.device("cuda", 0)
 co = vqa_amd.ParallelCoAttention(d).to(dev)
 co.bf16_projections = os.environ.get("OPT", "0") == "1"
 torch.manual_seed(1)
-if layout == "lm":
-    x = torch.randn(B, N, d, device=dev).clamp_min_(0)
-else:
-    x = torch.randn(B, d, N, device=dev).clamp_min_(0).permute(0, 2, 1)
-Qs = [torch.randn(B, T, d, device=dev).requires_grad_(True) for _ in range(3)]
+SETS = int(os.environ.get("SETS", "3"))
+sets = []
+for _ in range(SETS):
+    if layout == "lm":
+        x = torch.randn(B, N, d, device=dev).clamp_min_(0)
+    else:
+        x = torch.randn(B, d, N, device=dev).clamp_min_(0).permute(0, 2, 1)
+    sets.append((x, [torch.randn(B, T, d, device=dev).requires_grad_(True) for _ in range(3)]))
 g = None
+k = 0
 def it():
-    global g
+    global g, k
+    x, Qs = sets[k % SETS]
+    k += 1
+    for q in Qs:
+        q.grad = None
+    for p in co.parameters():
+        p.grad = None
     vs, qs = co(x, Qs)
     outs = list(vs) + list(qs)
     if g is None:
@@ -35,4 +47,4 @@ t0 = time.perf_counter()
 for _ in range(iters):
     it()
 torch.cuda.synchronize()
-print("N=%d %s d=%d: %.3f ms per forward + backward (wall)" % (N, layout, d, (time.perf_counter() - t0) / iters * 1e3))
+print("N=%d %s d=%d %s: %.3f ms per forward + backward (wall), %d input sets" % (N, layout, d, "fast16" if co.fast_products else ("bf16" if co.bf16_projections else "exact"), (time.perf_counter() - t0) / iters * 1e3, SETS))

@@ -542,7 +542,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     int ks[2], S[2];
     // two-piece width: 128 x 256 tiles on 512-thread workgroups (gemm_tn_wide.hip) -- the same split-K partition, pieces and
     // order of products, so the same bits as the 128 x 128 kernel
-    const bool wide = gemm_tn_wide_supported(tnv) && gemm_tn_wide_supported(tnq) && (!combine || (wdq.N % 256 == 0 && wdq.np == 2));
+    const bool wide = gemm_tn_wide_supported(tnv) && gemm_tn_wide_supported(tnq) && (!combine || (wdq.N % 256 == 0 && !wdq.f16 && (wdq.np == 2) == (tnv.np == 2)));
     const int parts_v = wide ? gemm_tn_wide_plan(tnv, pv, &ks[0], &S[0]) : gemm_tn_plan(tnv, pv, &ks[0], &S[0]);
     tnq.C = part + (size_t)parts_v * d * d;
     const int parts_q = wide ? gemm_tn_wide_plan(tnq, pq, &ks[1], &S[1]) : gemm_tn_plan(tnq, pq, &ks[1], &S[1]);

@@ -298,9 +298,12 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_tn_wide_kernel(const TwJobs jobs
 
 }  // namespace
 
+// pieces per operand of a job (TnGemm.np: 0 / 3 = the exact split)
+static inline int tnw_np(int np) { return np == 2 ? 2 : 3; }
 int gemm_tn_wide_supported(const TnGemm& d) {
-  static const int on = dev_env_int("COATTN_TN_WIDE", 1);   // developer switch
-  return on && gemm_tn_supported(d) && !d.bf16 && d.np == 2 && d.mask_blk == 0 && (d.M % BM) == 0 && (d.N % BN) == 0;
+  static const int on = dev_env_int("COATTN_TN_WIDE", 1);    // developer switches: the kernel at all / at the exact width
+  static const int on3 = dev_env_int("COATTN_TN_WIDE3", 1);
+  return on && (d.np == 2 || on3) && gemm_tn_supported(d) && !d.bf16 && d.mask_blk == 0 && (d.M % BM) == 0 && (d.N % BN) == 0;
 }
 
 // split-K plan for `max_parts` parts (32 parts x 8 tiles of 128 x 256 = one workgroup per CU at d = 512)
@@ -320,8 +323,8 @@ int launch_gemm_tn_wide(const TnGemm* d, const int* ksplit, const int* S, int n,
   TwJobs jobs = {};
   if (wextra) {
     long nbw = 0;
-    CA_CHECK_ARG(wextra->a_sk == 0 && wextra->np == 2 && !wextra->bf16 && wextra->N % 256 == 0 && wextra->kband_n == 0,
-                 "gemm_tn_wide: the extra GEMM must be a row-major two-piece product with N %% 256 == 0");
+    CA_CHECK_ARG(wextra->a_sk == 0 && tnw_np(wextra->np) == tnw_np(d[0].np) && !wextra->f16 && !wextra->bf16 && wextra->N % 256 == 0 && wextra->kband_n == 0,
+                 "gemm_tn_wide: the extra GEMM must be a row-major product of the launch's width with N %% 256 == 0");
     CA_TRY(gemm_w_fill_job(*wextra, jobs.wj, &nbw, 256));
     jobs.nw = (int)nbw;
     static const int first = dev_env_int("COATTN_DQ_FIRST", 0);   // developer switch
@@ -357,25 +360,39 @@ int launch_gemm_tn_wide(const TnGemm* d, const int* ksplit, const int* S, int n,
   jobs.first1 = (int)nb[0];
   const bool sum3 = d[0].a_term != 0, bcm = d[0].b_kdiv != 0;
   const dim3 grid((unsigned)(jobs.nred + nb[0] + nb[1] + (jobs.wfirst ? jobs.wfirst : jobs.nw)));
-  // two buffers of two pieces: 57,344 B; with the [column][k] image of a BCM first job 69,632 B (above the 64 KB default)
-  size_t lds = (size_t)2 * 2 * (IMGA + (bcm ? IMGBC : IMGB)) * sizeof(short);
-  if (wextra && lds < (size_t)2 * 2 * gw::BM * gw::LDR * sizeof(short)) lds = (size_t)2 * 2 * gw::BM * gw::LDR * sizeof(short);
-  if (bcm) {
-    // (set once per device to the LARGEST request any call can make -- the [column][k] form, or the dQ tiles' images if they
-    //  ever outgrow it -- not to the first call's value: ADVICE r4)
-    constexpr size_t kLdsMax = (size_t)2 * 2 * (IMGA + IMGBC) * sizeof(short) > (size_t)2 * 2 * gw::BM * gw::LDR * sizeof(short)
-                                   ? (size_t)2 * 2 * (IMGA + IMGBC) * sizeof(short) : (size_t)2 * 2 * gw::BM * gw::LDR * sizeof(short);
+  // two buffers of NP pieces: 57,344 B at two pieces (69,632 B with the [column][k] image of a BCM first job), 86,016 /
+  // 104,448 B at the exact width -- above the 64 KB default: the attribute is set once per device, for every instantiation, to
+  // the LARGEST request any call can make (not to the first call's value: ADVICE r4)
+  const int npv = tnw_np(d[0].np);
+  CA_CHECK_ARG(n == 1 || tnw_np(d[1].np) == npv, "gemm_tn_wide: the jobs of a launch share the width");
+  size_t lds = (size_t)2 * npv * (IMGA + (bcm ? IMGBC : IMGB)) * sizeof(short);
+  if (wextra && lds < (size_t)2 * npv * gw::BM * gw::LDR * sizeof(short)) lds = (size_t)2 * npv * gw::BM * gw::LDR * sizeof(short);
+  {
+    constexpr size_t kImg = (size_t)2 * 3 * (IMGA + (IMGBC > IMGB ? IMGBC : IMGB)) * sizeof(short);
+    constexpr size_t kW = (size_t)2 * 3 * gw::BM * gw::LDR * sizeof(short);
+    constexpr size_t kLdsMax = kImg > kW ? kImg : kW;
     static DeviceOnce once;
     CA_TRY(once.run([&] {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_wide_kernel<true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
-      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_wide_kernel<false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
+      const void* ks[8] = {reinterpret_cast<const void*>(gemm_tn_wide_kernel<true, 2, true>), reinterpret_cast<const void*>(gemm_tn_wide_kernel<false, 2, true>),
+                           reinterpret_cast<const void*>(gemm_tn_wide_kernel<true, 2>), reinterpret_cast<const void*>(gemm_tn_wide_kernel<false, 2>),
+                           reinterpret_cast<const void*>(gemm_tn_wide_kernel<true, 3, true>), reinterpret_cast<const void*>(gemm_tn_wide_kernel<false, 3, true>),
+                           reinterpret_cast<const void*>(gemm_tn_wide_kernel<true, 3>), reinterpret_cast<const void*>(gemm_tn_wide_kernel<false, 3>)};
+      hipError_t e = hipSuccess;
+      for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
       return e;
     }, "gemm_tn_wide"));
   }
-  if (sum3 && bcm) hipLaunchKernelGGL((gemm_tn_wide_kernel<true, 2, true>), grid, dim3(NTHR), lds, s, jobs);
-  else if (bcm) hipLaunchKernelGGL((gemm_tn_wide_kernel<false, 2, true>), grid, dim3(NTHR), lds, s, jobs);
-  else if (sum3) hipLaunchKernelGGL((gemm_tn_wide_kernel<true, 2>), grid, dim3(NTHR), lds, s, jobs);
-  else hipLaunchKernelGGL((gemm_tn_wide_kernel<false, 2>), grid, dim3(NTHR), lds, s, jobs);
+  if (npv == 2) {
+    if (sum3 && bcm) hipLaunchKernelGGL((gemm_tn_wide_kernel<true, 2, true>), grid, dim3(NTHR), lds, s, jobs);
+    else if (bcm) hipLaunchKernelGGL((gemm_tn_wide_kernel<false, 2, true>), grid, dim3(NTHR), lds, s, jobs);
+    else if (sum3) hipLaunchKernelGGL((gemm_tn_wide_kernel<true, 2>), grid, dim3(NTHR), lds, s, jobs);
+    else hipLaunchKernelGGL((gemm_tn_wide_kernel<false, 2>), grid, dim3(NTHR), lds, s, jobs);
+  } else {
+    if (sum3 && bcm) hipLaunchKernelGGL((gemm_tn_wide_kernel<true, 3, true>), grid, dim3(NTHR), lds, s, jobs);
+    else if (bcm) hipLaunchKernelGGL((gemm_tn_wide_kernel<false, 3, true>), grid, dim3(NTHR), lds, s, jobs);
+    else if (sum3) hipLaunchKernelGGL((gemm_tn_wide_kernel<true, 3>), grid, dim3(NTHR), lds, s, jobs);
+    else hipLaunchKernelGGL((gemm_tn_wide_kernel<false, 3>), grid, dim3(NTHR), lds, s, jobs);
+  }
   CA_CHECK_LAUNCH("gemm_tn_wide");
   return 0;
 }

@@ -172,8 +172,10 @@ int launch_gemm_w(const WGemm* d, int n, hipStream_t s) {
   // single-product mode with wide outputs: 128 x 256 tiles on 512 threads (the A rows are staged once for twice the columns)
   static const int wide2 = dev_env_int("COATTN_GEMMW_WIDE2", 0);   // developer switch
   static const int wide32 = dev_env_int("COATTN_GEMMW_WIDE32", 0);  // developer switch: the forward's (3, 2) launch
+  static const int wide3 = dev_env_int("COATTN_GEMMW_WIDE3", 0);    // developer switch: the exact width on 128 x 256 tiles
   const bool mixed32 = wide32 && !d[0].bf16 && n == 2 && d[0].np != 2 && d[1].np == 2;
-  bool wide = d[0].bf16 != 0 || (wide2 && d[0].np == 2 && (n == 1 || d[1].np == 2)) || mixed32;
+  const bool exact33 = wide3 && !d[0].bf16 && d[0].np != 2 && (n == 1 || d[1].np != 2);
+  bool wide = d[0].bf16 != 0 || (wide2 && d[0].np == 2 && (n == 1 || d[1].np == 2)) || mixed32 || exact33;
   for (int i = 0; i < n; ++i) wide = wide && d[i].N % 256 == 0 && (d[i].kband_n == 0 || d[i].kband_n % 256 == 0);
   for (int i = 0; i < n; ++i) CA_TRY(gemm_w_fill_job(d[i], jobs.job[i], &nb[i], wide ? 256 : BN));
   CA_CHECK_ARG(nb[0] + nb[1] < 2147483647L, "gemm_w: grid too large");
@@ -194,6 +196,9 @@ int launch_gemm_w(const WGemm* d, int n, hipStream_t s) {
   } else if (wide && mixed32) {
     if (d[0].a_sk) hipLaunchKernelGGL((gemm_w_kernel<true, 3, 8, 2>), grid, dim3(512), 0, s, jobs);
     else hipLaunchKernelGGL((gemm_w_kernel<false, 3, 8, 2>), grid, dim3(512), 0, s, jobs);
+  } else if (wide && exact33) {
+    if (d[0].a_sk) hipLaunchKernelGGL((gemm_w_kernel<true, 3, 8>), grid, dim3(512), 0, s, jobs);
+    else hipLaunchKernelGGL((gemm_w_kernel<false, 3, 8>), grid, dim3(512), 0, s, jobs);
   } else if (wide && !d[0].bf16) {
     if (d[0].a_sk) hipLaunchKernelGGL((gemm_w_kernel<true, 2, 8>), grid, dim3(512), 0, s, jobs);
     else hipLaunchKernelGGL((gemm_w_kernel<false, 2, 8>), grid, dim3(512), 0, s, jobs);

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(NW * 64, 2) void bwd_nat32_kernel(const BwdArgs a) 
   const __amdgpu_buffer_rsrc_t rs_dpq = make_rsrc(reinterpret_cast<const char*>(a.dPq) + pair * (size_t)T * d * ES, (unsigned)T * d * ES);
   const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(a.C + pair * (size_t)T * N, (unsigned)T * N * 4u);
   const int nsl = d / (128 * NW);                    // 128-channel slices per wave (1 at d = 512)
-  const __amdgpu_buffer_rsrc_t rs_dpv = make_rsrc(reinterpret_cast<const char*>(a.dPv) + pair * (size_t)N * d * ES, (unsigned)N * d * ES);
+  const __amdgpu_buffer_rsrc_t rs_dpv = make_rsrc(reinterpret_cast<const char*>(a.dPv) + pair * (size_t)N * d * ES,
+                                                  (a.ko_dpv && l > 0) ? 0u : (unsigned)N * d * ES);   // (ko_dpv: developer knock-out, stores dropped)
   // the lane's channel inside a 32-channel unit as the stores see it: bf16 stores leave from the even lanes only (an odd
   // lane's offset lies outside every buffer)
   const int rst = DPB && (lane & 1) ? 0x20000000 : r;

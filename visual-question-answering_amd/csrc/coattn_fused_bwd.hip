@@ -327,6 +327,9 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   ba.B = B; ba.N = N; ba.T = T; ba.d = d; ba.L = L;
   ba.bf16 = bf16_proj;
   ba.np = np;
+  static const int ko_dpv = dev_env_int("COATTN_KO_DPV", 0);      // developer knock-outs (DEV builds; wrong results): what would
+  static const int ko_sum3 = dev_env_int("COATTN_KO_SUM3", 0);    // ONE sum_l dP_v array save in bwd_nat32's stores / the GEMM's reads
+  ba.ko_dpv = ko_dpv;
   ba.dp_bf16 = 0;
   CA_TRY(launch_bwd_dc32(ba, s));                    // dC, dA                       (coattn_bwd32.hip)
   prof_mark(s, "bwd_dc32");
@@ -489,7 +492,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   // (the frozen-encoder default needs no dV: the weight-gradient kernel then adds the three levels while staging them)
   const bool sum_in_gemm = tn_v && L == 3 && !dV;
   if (sum_in_gemm) {
-    tnv.a_term = (long)BNd;
+    tnv.a_term = ko_sum3 ? 0 : (long)BNd;
   } else if (L == 3) {
     CA_TRY(launch_add3_inplace(dPv, dPv + BNd, dPv + 2 * BNd, (int64_t)BNd, s));
   } else {

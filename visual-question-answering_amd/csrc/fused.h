@@ -389,6 +389,7 @@ struct BwdArgs {
   int bf16;               // reduced-precision mode: one MFMA per product (d % 512 == 0)
   int np;                 // (bf16 = 0) width of the contractions: 3 or 2 pieces
   int dp_bf16;            // (with bf16, bwd_nat32_kernel) dPv / dPq are bf16 arrays of the same index order
+  int ko_dpv;             // developer knock-out (DEV builds only, wrong results): bwd_nat32 stores dP_v of level 0 alone
 };
 
 // Image-side softmax backward of one (sample, level) by ONE wave: da_v = the sum of the channel-chunk partials,

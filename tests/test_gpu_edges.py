@@ -577,3 +577,64 @@ def test_trainer_defaults_to_the_references_arithmetic():
     with pytest.warns(UserWarning, match="exact mode"):
         assert tr.check_range() is False
     assert tr.precision == "exact" and model.co_attention.fast_products is False
+
+
+@pytest.mark.parametrize("pattern", ["sorted_pad_tails", "scattered", "none_zero", "one_level_all_zero", "negative_zero_and_nan"])
+@pytest.mark.parametrize("layout", ["lm", "cm"])
+def test_zero_question_rows_take_the_bias_path_bit_for_bit(pattern, layout):
+    """Exact mode: question rows of exact zeros (the pad tokens, model.py:263 / :292-296) are flagged by the weight-split launch,
+    their P_q rows written as (0 + b_q) * scale there, and the projection GEMM runs over the other rows only.  P_q must be
+    BIT-IDENTICAL to the dense product of every row (coattn_linear_forward on the same rows, which has no row bitmap), for
+    pad tails, zero rows scattered anywhere, no zero row at all, a whole level of zeros, rows of -0.0 (zero: skipped) and a
+    row holding a NaN (not zero: computed); outputs and gradients equal the float64 oracle's as ever."""
+    import ctypes as C
+    from tests._hip import run_hip
+    from vqa_amd import _lib
+    B, N, T, d = 24, (49 if layout == "lm" else 52), 26, 512
+    P = O.make_params(d, 17)
+    lens = sorted([T] + [1 + (5 * i) % T for i in range(B - 1)], reverse=True)
+    V, Qs = O.make_inputs(B, N, T, d, 91, lens=[T] * B, scale_q=(2.0 / d) ** 0.5)      # dense rows first
+    Qs = [q.clone() for q in Qs]
+    g = torch.Generator().manual_seed(5)
+    if pattern == "sorted_pad_tails":
+        for b, n in enumerate(lens):
+            for q in Qs:
+                q[b, n:] = 0.0
+    elif pattern == "scattered":
+        for q in Qs:
+            q[torch.rand(B, T, generator=g) < 0.4] = 0.0
+    elif pattern == "one_level_all_zero":
+        Qs[1].zero_()
+    elif pattern == "negative_zero_and_nan":
+        Qs[0][3, 5] = -0.0
+        Qs[2][7, 0:4] = -0.0
+        Qs[1][2, 9, 17] = float("nan")
+    gv = torch.from_numpy(O.hash_normal((3, B, d), 7)).float()
+    gq = torch.from_numpy(O.hash_normal((3, B, d), 8)).float()
+    r = run_hip(V, Qs, P, gv, gq, impl="fused", layout=layout, exact3=True)
+    # the dense product of the same rows through the linear entry point (fused path: P_q is stored times 2 log2(e))
+    lib = _lib.load()
+    kPScale = 2.8853900817779268
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    wimg = torch.empty(lib.coattn_linear_workspace_bytes(d, d) // 4, device="cuda")
+    Wq, bq = P["W_q.weight"].cuda().contiguous(), P["W_q.bias"].cuda().contiguous()
+    for l in range(3):
+        x = Qs[l].cuda().reshape(B * T, d).contiguous()
+        y = torch.full((B * T, d), float("nan"), device="cuda")
+        _lib.check(lib.coattn_linear_forward(x.data_ptr(), d, Wq.data_ptr(), bq.data_ptr(), y.data_ptr(), wimg.data_ptr(),
+                                             B * T, d, d, kPScale, 0, st), "coattn_linear_forward")
+        torch.cuda.synchronize()
+        got = r["P_q"][l].reshape(B * T, d)
+        same = (got == y) | (torch.isnan(got) & torch.isnan(y))
+        assert bool(same.all()), (pattern, l, int((~same).sum()))
+    if pattern == "negative_zero_and_nan":
+        return                                                   # (a NaN feature: nothing to compare with the oracle)
+    d64 = lambda t: t.double()                                   # noqa: E731
+    P64 = {k: d64(v) for k, v in P.items()}
+    f = O.coattn_forward(d64(V), [d64(q) for q in Qs], P64)
+    b = O.coattn_backward(d64(V), [d64(q) for q in Qs], P64, d64(gv), d64(gq))
+    for k in ("v", "q", "a_v", "a_q"):
+        assert (r[k].cpu().double() - f[k]).abs().max().item() < 2e-5, (pattern, k)
+    for k in ("dQ", "dV_phys", "dW_q.weight", "dW_v.weight", "dW_q.bias"):
+        ref = b[k]
+        assert ((r[k].cpu().double().reshape(ref.shape) - ref).abs().max() / ref.abs().max()).item() < 2e-5, (pattern, k)

@@ -256,10 +256,29 @@ struct WGemm {
   int f16;                                                           // (np = 2) the two pieces are FP16 (Wf: a pieces = 16 image)
   int a_bf16;                                                        // (gemm_bf_kernel) A is STORED as bf16; a_sm, a_sz stay in elements
   float* status;                                                     // (f16) status word [0] of the call (see kStatusHdr), or NULL
+  const unsigned* rowbits;                                           // (gemm_w, row-major A, NULL = all rows) bitmap per batch entry z,
+                                                                     // (M + 31) / 32 words each: bit m set = row m of A_z has a non-zero
+                                                                     // element.  The GEMM then runs over the set rows alone (tiles of the
+                                                                     // compacted row list); the rows whose bit is clear must already hold
+                                                                     // (0 + bias) * out_scale -- RowFlagJob writes both
 };
+// Rows of exact zeros (the pad tokens of the question hierarchy: model.py:263 padding_idx, :292-296 pad_packed_sequence) project to
+// the bias alone.  One job of the weight-split launch (its extra workgroups): per batch entry z and 32 rows one word of the bitmap
+// WGemm.rowbits, and (0 + bias) * out_scale into the output rows whose input row is all zeros -- bit for bit what the dense
+// product stores there.
+struct RowFlagJob {
+  const float* a_ptrs[8]; int a_sm;              // A_z[m][k], k contiguous
+  float* C; long c_sz; int c_sm;                 // C_z[m][n]
+  const float* bias_n; float out_scale;
+  int M, N, K, batch;
+  unsigned* rowbits;                             // [batch][(M + 31) / 32]
+};
+constexpr int kRowBitsMaxWords = 512;            // per batch entry (M <= 16,384 rows): the GEMM tiles scan the words serially
+inline size_t rowbits_words(int M, int batch) { return (size_t)batch * ((M + 31) / 32); }
 size_t wsplit_bytes(int N, int K);
 // status_hdr (may be NULL): the launch's first thread writes [0] = 0 and [1] = f16 ? 1 : 0 (the status words' header)
-int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s, float* status_hdr = nullptr, int f16 = 0);
+// rows (may be NULL): a RowFlagJob done by extra workgroups of the same launch
+int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s, float* status_hdr = nullptr, int f16 = 0, const RowFlagJob* rows = nullptr);
 int gemm_w_supported(const WGemm& d);
 int launch_gemm_w(const WGemm* d, int n, hipStream_t s);          // n = 1 or 2 GEMMs in one launch
 // single-product bf16 GEMM for wide shapes (gemm_bf.hip): reads a hi-piece-only weight image (WSplit.pieces = 1)

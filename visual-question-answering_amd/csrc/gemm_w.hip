@@ -31,12 +31,49 @@ using namespace gw;
 struct WJobs { WArgs job[2]; int first1; };   // blocks [0, first1) work on job 0, the rest on job 1
 
 struct SplitJob { const float* W; void* out; int N, K, trans, ld, pieces; float* amax; };
-struct SplitArgs { SplitJob job[3]; int njobs; float* status_hdr; float f16; };
+struct SplitArgs { SplitJob job[3]; int njobs; float* status_hdr; float f16; RowFlagJob rows; int rows_on; };
+
+// The RowFlagJob's workgroups (blockIdx.y == njobs): workgroup x takes 32 rows of one batch entry, a wave 8 of them; a row is
+// read in whole 1 KB segments (a lane per 16 bytes), any non-zero (or NaN) element sets its bit; an all-zero row gets its
+// output written here.
+__device__ __forceinline__ void rowflag_block(const RowFlagJob& j, const int bx) {
+  __shared__ unsigned wbits[4];
+  const int words = (j.M + 31) / 32;
+  if (bx >= j.batch * words) return;
+  const int z = bx / words, wd = bx % words;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float* A = j.a_ptrs[z & 7];
+  float* C = j.C + (long)z * j.c_sz;
+  unsigned bits = 0;
+  for (int i = 0; i < 8; ++i) {
+    const int m = 32 * wd + 8 * wave + i;
+    if (m >= j.M) break;                             // (uniform per wave)
+    const float* row = A + (long)m * j.a_sm;
+    bool nz = false;
+    for (int k = 4 * lane; k < j.K; k += 256) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(row + k);
+      nz = nz || !(x[0] == 0.f && x[1] == 0.f && x[2] == 0.f && x[3] == 0.f);
+    }
+    if (__builtin_amdgcn_ballot_w64(nz) != 0) {
+      bits |= 1u << (8 * wave + i);
+    } else {                                         // the dense product's value for this row: (acc = +0) + bias, scaled
+      float* out = C + (long)m * j.c_sm;
+      for (int n = lane; n < j.N; n += 64) out[n] = (0.f + (j.bias_n ? j.bias_n[n] : 0.f)) * j.out_scale;
+    }
+  }
+  if (lane == 0) wbits[wave] = bits;
+  __syncthreads();
+  if (threadIdx.x == 0) j.rowbits[(long)z * words + wd] = wbits[0] | wbits[1] | wbits[2] | wbits[3];
+}
 
 // One wave per (32-column tile nt, 16-k step ks): lane (li = lane & 31, lh = lane >> 5) holds
 // Bw(k = 16 ks + 8 lh + e, n = 32 nt + li), e = 0..7 -- the B operand layout of v_mfma_f32_32x32x16_bf16.
 // trans = 0: Bw(k, n) = W[n][k] (y = x W^T); trans = 1: Bw(k, n) = W[k][n] (dx = dy W).
 __global__ __launch_bounds__(256) void wsplit_kernel(const SplitArgs a) {
+  if ((int)blockIdx.y == a.njobs) {                  // (only with rows_on: the grid then has njobs + 1 rows of workgroups)
+    rowflag_block(a.rows, (int)blockIdx.x);
+    return;
+  }
   const SplitJob j = a.job[blockIdx.y];
   f16_saturating_conversions();                      // (only the pieces = 16 jobs convert to fp16)
   // header of the call's status words (fused.h kStatusHdr): the projection launch behind this one raises [0]
@@ -92,20 +129,28 @@ __global__ __launch_bounds__(256) void wsplit_kernel(const SplitArgs a) {
 #endif
 template <bool AM0, int NP, int NW = 4, int NP1 = NP, bool H = false>
 __global__ __launch_bounds__(64 * NW, (NP == 2 && NP1 == 2 && NW == 4) ? GEMMW_OCC2 : 2) void gemm_w_kernel(const WJobs jobs) {
-  __shared__ __attribute__((aligned(16))) short smem[2 * (NP > NP1 ? NP : NP1) * BM * LDR];  // three pieces: 61,440 B; two workgroups of 256 threads per CU
+  __shared__ __attribute__((aligned(16))) short smem[2 * (NP > NP1 ? NP : NP1) * BM * LDR + 2 * BM];  // three pieces: 61,440 B (+ 512 B: the row map of a compacted job); two workgroups of 256 threads per CU
   static_assert(BM * LDR == BK * LDT, "both image layouts have the same size");
   if (H) f16_saturating_conversions();
-  if ((int)blockIdx.x < jobs.first1) gemm_w_body<AM0, NP, NW, H>(jobs.job[0], (int)blockIdx.x, smem);
-  else gemm_w_body<false, NP1, NW, H>(jobs.job[1], (int)blockIdx.x - jobs.first1, smem);
+  int* const rowmap = reinterpret_cast<int*>(smem + 2 * (NP > NP1 ? NP : NP1) * BM * LDR);
+  if ((int)blockIdx.x < jobs.first1) gemm_w_body<AM0, NP, NW, H>(jobs.job[0], (int)blockIdx.x, smem, rowmap);
+  else gemm_w_body<false, NP1, NW, H>(jobs.job[1], (int)blockIdx.x - jobs.first1, smem, rowmap);
 }
 
 }  // namespace
 
 size_t wsplit_bytes(int N, int K) { return (size_t)((N + 31) / 32) * ((K + 15) / 16) * kChunkBytes; }
 
-int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s, float* status_hdr, int f16) {
+int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s, float* status_hdr, int f16, const RowFlagJob* rows) {
   CA_CHECK_ARG(njobs >= 1 && njobs <= 3, "wsplit: 1 to 3 jobs per launch");
   SplitArgs a = {};
+  int row_blocks = 0;
+  if (rows) {
+    CA_CHECK_ARG(rows->rowbits && rows->C && rows->M > 0 && rows->batch >= 1 && rows->batch <= 8 && rows->K % 4 == 0 && (rows->a_sm & 3) == 0,
+                 "wsplit: bad row-flag job");
+    a.rows = *rows; a.rows_on = 1;
+    row_blocks = rows->batch * ((rows->M + 31) / 32);
+  }
   a.njobs = njobs;
   a.status_hdr = status_hdr; a.f16 = f16 ? 1.f : 0.f;
   int chunks = 0;
@@ -116,7 +161,8 @@ int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s, float* status_hd
     const int c = ((jobs[i].N + 31) / 32) * ((jobs[i].K + 15) / 16);
     chunks = c > chunks ? c : chunks;
   }
-  hipLaunchKernelGGL(wsplit_kernel, dim3((chunks + 3) / 4, njobs), dim3(256), 0, s, a);
+  const int gx = (chunks + 3) / 4 > row_blocks ? (chunks + 3) / 4 : row_blocks;      // (workgroups past a job's range return at once)
+  hipLaunchKernelGGL(wsplit_kernel, dim3(gx, njobs + (rows ? 1 : 0)), dim3(256), 0, s, a);
   CA_CHECK_LAUNCH("wsplit");
   return 0;
 }
@@ -157,6 +203,9 @@ int gemm_w_fill_job(const WGemm& d, gw::WArgs& g, long* nblk, int bn) {
   g.bias_n = d.bias_n; g.oscale = d.out_scale != 0.f ? d.out_scale : 1.f;
   g.ascale = (d.f16 && d.np == 2 && !d.bf16) ? 1.0f / kF16WScale : 1.0f;
   g.status = g.ascale != 1.0f ? d.status : nullptr;
+  CA_CHECK_ARG(!d.rowbits || (d.a_sk == 0 && bn == BN && (d.M + 31) / 32 <= kRowBitsMaxWords),
+               "gemm_w: a row bitmap needs a row-major A, the four-wave tile and at most %d rows", 32 * kRowBitsMaxWords);
+  g.rowbits = d.rowbits;
   g.M = d.M; g.N = d.N; g.K = d.K;
   const long ntn = (d.N + bn - 1) / bn, ntm = (d.M + BM - 1) / BM;
   g.xcd_group = ntm >= 32 ? 1 : 0;

@@ -29,6 +29,7 @@ struct WArgs {
   float ascale;                                // on the accumulators (1, or 1 / kF16WScale for an FP16 weight image)
   int M, N, K, xcd_group;
   float* status;                               // (H) word [0] of the call's status words (fused.h kStatusHdr), or NULL
+  const unsigned* rowbits;                     // (AM = false, four waves) fused.h WGemm.rowbits: the tiles run over the set rows alone
 };
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -50,7 +51,7 @@ constexpr int LDT = BM + 32;                   // AM: [k][row] image row stride 
 //             column tile is the bound, not the MFMAs.
 // H (NP = 2)  : the two pieces are FP16 (fused.h: split_pair_h, v_mfma_f32_32x32x16_f16) -- the forward's projections.
 template <bool AM, int NP = 3, int NW = 4, bool H = false>
-__device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short* const smem) {
+__device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short* const smem, int* const rowmap = nullptr) {
   static_assert(NP >= 1 && NP <= 3, "pieces per operand");
   static_assert(!H || NP == 2, "FP16 pieces: two per operand");
   constexpr bool P1 = NP == 1;
@@ -77,6 +78,36 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
       if (mt >= ntm) return;
     }
   }
+  // Compacted rows (g.rowbits): tile row r stands for the (m0 + r)-th row of A_z whose bit is set; rowmap[r] = that row, or a
+  // value past every buffer when the list is shorter (loads read 0, stores are dropped by the row test).  Every workgroup
+  // finds its own 128 rows: popcounts of the <= 512 bitmap words into LDS (the image area, not yet in use), then one serial
+  // scan per row (LDS broadcasts) -- about a microsecond of a 35 us tile; a tile past the end of the list returns.
+  const bool cmp = !AM && NW == 4 && rowmap != nullptr && g.rowbits != nullptr;
+  if (cmp) {
+    const int words = (g.M + 31) / 32;
+    const unsigned* bits = g.rowbits + (long)z * words;
+    int* pc = reinterpret_cast<int*>(smem);
+    for (int i = tid; i < words; i += NT) pc[i] = __builtin_popcount(bits[i]);
+    __syncthreads();
+    if (tid < BM) {
+      const int c = m0 + tid;
+      int run = 0, row = 0x3fffffff;
+      for (int wdx = 0; wdx < words; ++wdx) {
+        const int pcw = pc[wdx];
+        if (c < run + pcw) {
+          unsigned b = bits[wdx];
+          for (int k = c - run; k > 0; --k) b &= b - 1;            // drop the lower set bits
+          row = 32 * wdx + __builtin_ctz(b);
+          break;
+        }
+        run += pcw;
+      }
+      rowmap[tid] = row;
+    }
+    __syncthreads();
+    if (rowmap[0] >= g.M) return;                                  // (uniform: the list ends before this tile)
+  }
+  auto tile_row = [&](const int r) { return cmp ? rowmap[r] : m0 + r; };
   const float* Ab = g.a_ptrs[0] ? g.a_ptrs[z & 7] : g.A + (long)z * g.a_sz;
   const long a_bytes = AM ? ((long)((g.M - 1) / g.a_mdiv) * g.a_sdiv + (g.a_mdiv - 1) + (long)(g.K - 1) * g.a_sk + 1) * 4
                           : ((long)(g.M - 1) * g.a_sm + g.K) * 4;
@@ -100,7 +131,8 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
       a_lds[i] = k * LDT + m;
     } else {
       const int m = (tid >> 3) + (NT / 8) * i, k = (tid & 7) * 4;
-      a_voff[i] = (m0 + m) < g.M ? ((m0 + m) * g.a_sm + k) * 4 : 0x40000000;   // rows past M read 0
+      const int arow = tile_row(m);
+      a_voff[i] = arow < g.M ? (arow * g.a_sm + k) * 4 : 0x40000000;           // rows past M read 0
       a_lds[i] = m * LDR + k;
     }
   }
@@ -314,7 +346,7 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int row = tile_row(wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
       if (row >= g.M) continue;
       float* crow = Cb + (long)row * g.c_sm;
 #ifdef GEMMW_NOSTORE

@@ -141,7 +141,13 @@ int coattn_workspace_bytes(int B, int N, int T, int d, int L, int dtype, int fla
 /* Forward of model.py:372-395 for all L levels.
  *   Q      : host array of L device pointers.
  *   saved  : NULL for inference (nothing kept), else a buffer of `saved` bytes.
- *   v_out,q_out : [L,B,d]. */
+ *   v_out,q_out : [L,B,d].
+ * Rows of Q_l that are all zeros -- the pad tokens of the reference's question hierarchy (model.py:263 padding_idx,
+ * :292-296 pad_packed_sequence) -- project to the bias alone, and the exact mode (flags = 0) uses that: the launch that
+ * splits the weights also reads every question row once, flags the rows that hold anything and writes (0 + b_q) into the
+ * other rows of P_q; the projection GEMM then runs over the flagged rows only.  Data-driven (no length argument: the
+ * reference's forward(x_img, x_ques_hierarchy) has none), and bit-identical to the dense product for every input: zero rows
+ * anywhere, none at all, -0.0, NaN (tests/test_gpu_edges.py::test_zero_question_rows_take_the_bias_path_bit_for_bit). */
 int coattn_forward(const void* V, int64_t v_sB, int64_t v_sN, int64_t v_sD, const void* const* Q,
                    const coattn_params* p, void* v_out, void* q_out, void* saved, void* ws,
                    int B, int N, int T, int d, int L, int dtype, int flags, void* stream);

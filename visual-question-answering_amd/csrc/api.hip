@@ -449,7 +449,8 @@ int general_projections(const Ctx& c, const float* V, const float* const* Q, con
     static const int rows_env = dev_env_int("COATTN_SKIP_ZERO_ROWS", 1);   // developer switch
     RowFlagJob rj = {};
     const bool skip_rows = rows_env && q_w && !f16 && !c.bf16_proj && gemm_wx_kernel(wq) == 0 && wq.a_sk == 0 && p->b_q &&
-                           (wq.M + 31) / 32 <= kRowBitsMaxWords;
+                           (wq.M + 31) / 32 <= kRowBitsMaxWords && c.d % 256 == 0 && c.d <= 1024 &&
+                           ((((uintptr_t)p->b_q) | ((uintptr_t)(sv + sp.Pq))) & 15) == 0;      // (16-byte accesses of the flag job)
     if (skip_rows) {
       unsigned* bits = reinterpret_cast<unsigned*>(wimg + 2 * wsplit_bytes(c.d, c.d));
       for (int l = 0; l < c.L; ++l) rj.a_ptrs[l] = Q[l];

@@ -31,11 +31,13 @@ using namespace gw;
 struct WJobs { WArgs job[2]; int first1; };   // blocks [0, first1) work on job 0, the rest on job 1
 
 struct SplitJob { const float* W; void* out; int N, K, trans, ld, pieces; float* amax; };
-struct SplitArgs { SplitJob job[3]; int njobs; float* status_hdr; float f16; RowFlagJob rows; int rows_on; };
+struct SplitArgs { SplitJob job[3]; int njobs; float* status_hdr; float f16; RowFlagJob rows; int row_blocks, cb; };   // grid: [row_blocks][njobs x cb]
 
-// The RowFlagJob's workgroups (blockIdx.y == njobs): workgroup x takes 32 rows of one batch entry, a wave 8 of them; a row is
-// read in whole 1 KB segments (a lane per 16 bytes), any non-zero (or NaN) element sets its bit; an all-zero row gets its
-// output written here.
+// The RowFlagJob's workgroups (the FIRST row_blocks of the launch: they have the most to wait for): workgroup x takes 32 rows of one batch entry, a wave 8 of them, all
+// requested before the first test (one memory latency per wave, not per row); a row is read in whole 1 KB segments (a lane
+// per 16 bytes, KC = K / 256 of them), any non-zero (or NaN) element sets its bit; an all-zero row gets its output written
+// here (16-byte stores; a live row's store is sent outside the buffer instead of branched around).
+template <int KC>
 __device__ __forceinline__ void rowflag_block(const RowFlagJob& j, const int bx) {
   __shared__ unsigned wbits[4];
   const int words = (j.M + 31) / 32;
@@ -43,23 +45,32 @@ __device__ __forceinline__ void rowflag_block(const RowFlagJob& j, const int bx)
   const int z = bx / words, wd = bx % words;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const float* A = j.a_ptrs[z & 7];
-  float* C = j.C + (long)z * j.c_sz;
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(A, (unsigned)(((long)(j.M - 1) * j.a_sm + j.K) * 4));   // rows past M read 0
+  // the output rows of this batch entry as a buffer (rows past M: stores dropped); N == K here (host check): the same lane
+  // pattern writes a row that reads one
+  const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(j.C + (long)z * j.c_sz, (unsigned)(((long)(j.M - 1) * j.c_sm + j.N) * 4));
+  const int r0 = 32 * wd + 8 * wave;
+  f32x4 x[8][KC], fill[KC];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int k = 0; k < KC; ++k) x[i][k] = buf_load4(rs, ((r0 + i) * j.a_sm + 4 * lane + 256 * k) * 4, 0);
+#pragma unroll
+  for (int k = 0; k < KC; ++k) {                     // the dense product's value of an all-zero row: (acc = +0) + bias, scaled
+    const f32x4 b = *reinterpret_cast<const f32x4*>(j.bias_n + 4 * lane + 256 * k);
+    fill[k] = f32x4{(0.f + b[0]) * j.out_scale, (0.f + b[1]) * j.out_scale, (0.f + b[2]) * j.out_scale, (0.f + b[3]) * j.out_scale};
+  }
   unsigned bits = 0;
+#pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const int m = 32 * wd + 8 * wave + i;
-    if (m >= j.M) break;                             // (uniform per wave)
-    const float* row = A + (long)m * j.a_sm;
     bool nz = false;
-    for (int k = 4 * lane; k < j.K; k += 256) {
-      const f32x4 x = *reinterpret_cast<const f32x4*>(row + k);
-      nz = nz || !(x[0] == 0.f && x[1] == 0.f && x[2] == 0.f && x[3] == 0.f);
-    }
-    if (__builtin_amdgcn_ballot_w64(nz) != 0) {
-      bits |= 1u << (8 * wave + i);
-    } else {                                         // the dense product's value for this row: (acc = +0) + bias, scaled
-      float* out = C + (long)m * j.c_sm;
-      for (int n = lane; n < j.N; n += 64) out[n] = (0.f + (j.bias_n ? j.bias_n[n] : 0.f)) * j.out_scale;
-    }
+#pragma unroll
+    for (int k = 0; k < KC; ++k) nz = nz || !(x[i][k][0] == 0.f && x[i][k][1] == 0.f && x[i][k][2] == 0.f && x[i][k][3] == 0.f);
+    const bool live = __builtin_amdgcn_ballot_w64(nz) != 0;
+    if (live) bits |= 1u << (8 * wave + i);
+    // (branch-free: a live row's store goes to an offset outside the buffer)
+#pragma unroll
+    for (int k = 0; k < KC; ++k) buf_store4(fill[k], rs_c, live ? 0x40000000 : ((r0 + i) * j.c_sm + 4 * lane + 256 * k) * 4, 0);
   }
   if (lane == 0) wbits[wave] = bits;
   __syncthreads();
@@ -70,17 +81,25 @@ __device__ __forceinline__ void rowflag_block(const RowFlagJob& j, const int bx)
 // Bw(k = 16 ks + 8 lh + e, n = 32 nt + li), e = 0..7 -- the B operand layout of v_mfma_f32_32x32x16_bf16.
 // trans = 0: Bw(k, n) = W[n][k] (y = x W^T); trans = 1: Bw(k, n) = W[k][n] (dx = dy W).
 __global__ __launch_bounds__(256) void wsplit_kernel(const SplitArgs a) {
-  if ((int)blockIdx.y == a.njobs) {                  // (only with rows_on: the grid then has njobs + 1 rows of workgroups)
-    rowflag_block(a.rows, (int)blockIdx.x);
+  int bid = (int)blockIdx.x;
+  if (bid < a.row_blocks) {
+    switch (a.rows.K >> 8) {                         // K / 256 in 1 .. 4 (host check)
+      case 1: rowflag_block<1>(a.rows, bid); break;
+      case 2: rowflag_block<2>(a.rows, bid); break;
+      case 3: rowflag_block<3>(a.rows, bid); break;
+      default: rowflag_block<4>(a.rows, bid); break;
+    }
     return;
   }
-  const SplitJob j = a.job[blockIdx.y];
+  bid -= a.row_blocks;
+  const int by = bid / a.cb, bx = bid - by * a.cb;
+  const SplitJob j = a.job[by];
   f16_saturating_conversions();                      // (only the pieces = 16 jobs convert to fp16)
   // header of the call's status words (fused.h kStatusHdr): the projection launch behind this one raises [0]
-  if (a.status_hdr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.status_hdr[0] = 0.f; a.status_hdr[1] = a.f16; }
+  if (a.status_hdr && bx == 0 && by == 0 && threadIdx.x == 0) { a.status_hdr[0] = 0.f; a.status_hdr[1] = a.f16; }
   const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
   const int ks16 = (j.K + 15) / 16, nt32 = (j.N + 31) / 32;
-  const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int chunk = bx * 4 + (threadIdx.x >> 6);
   if (chunk >= ks16 * nt32) return;
   const int nt = chunk / ks16, ks = chunk % ks16;
   const int n = 32 * nt + li, k0 = 16 * ks + 8 * lh;
@@ -146,9 +165,12 @@ int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s, float* status_hd
   SplitArgs a = {};
   int row_blocks = 0;
   if (rows) {
-    CA_CHECK_ARG(rows->rowbits && rows->C && rows->M > 0 && rows->batch >= 1 && rows->batch <= 8 && rows->K % 4 == 0 && (rows->a_sm & 3) == 0,
+    CA_CHECK_ARG(rows->rowbits && rows->C && rows->bias_n && rows->M > 0 && rows->batch >= 1 && rows->batch <= 8 && rows->K % 256 == 0 &&
+                 rows->K <= 1024 && rows->N == rows->K && (rows->c_sm & 3) == 0 && ((long)(rows->M - 1) * rows->c_sm + rows->N) * 4 < 0x40000000L &&
+                 ((((uintptr_t)rows->C) | ((uintptr_t)rows->bias_n)) & 15) == 0 && ((rows->c_sz & 3) == 0) && (rows->a_sm & 3) == 0 && ((long)(rows->M - 1) * rows->a_sm + rows->K) * 4 < 0x40000000L,
                  "wsplit: bad row-flag job");
-    a.rows = *rows; a.rows_on = 1;
+    for (int t = 0; t < rows->batch; ++t) CA_CHECK_ARG((((uintptr_t)rows->a_ptrs[t]) & 15) == 0, "wsplit: row-flag job: unaligned rows");
+    a.rows = *rows;
     row_blocks = rows->batch * ((rows->M + 31) / 32);
   }
   a.njobs = njobs;
@@ -161,8 +183,8 @@ int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s, float* status_hd
     const int c = ((jobs[i].N + 31) / 32) * ((jobs[i].K + 15) / 16);
     chunks = c > chunks ? c : chunks;
   }
-  const int gx = (chunks + 3) / 4 > row_blocks ? (chunks + 3) / 4 : row_blocks;      // (workgroups past a job's range return at once)
-  hipLaunchKernelGGL(wsplit_kernel, dim3(gx, njobs + (rows ? 1 : 0)), dim3(256), 0, s, a);
+  a.row_blocks = row_blocks; a.cb = (chunks + 3) / 4;
+  hipLaunchKernelGGL(wsplit_kernel, dim3(row_blocks + njobs * a.cb), dim3(256), 0, s, a);
   CA_CHECK_LAUNCH("wsplit");
   return 0;
 }

@@ -60,7 +60,8 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
   const int wr = wave / WCN, wc = wave % WCN, li = lane & 31, lh = lane >> 5;
   // XCD-aware tile order (as gemm.hip): the column tiles of one row tile share an XCD's L2
   // (with k bands the column tiles are taken from the right: the bands with the long contractions start first)
-  int m0, n0, z;
+  const bool cmp = !AM && NW == 4 && rowmap != nullptr && g.rowbits != nullptr;     // compacted rows (below)
+  int m0, n0, z, grp8 = 0;
   {
     const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
     const int x = id & 7, slot = id >> 3;
@@ -73,34 +74,62 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
       const int per = ntn * ((ntm + 7) / 8);
       z = slot / per;
       const int t = slot % per;
-      const int mt = (t / ntn) * 8 + x;
+      grp8 = (t / ntn) * 8;
+      const int mt = grp8 + x;
       m0 = mt * BM; n0 = (g.kband_n > 0 ? ntn - 1 - t % ntn : t % ntn) * BN;
-      if (mt >= ntm) return;
+      if (mt >= ntm && !cmp) return;                 // (a compacted job picks its row tile below)
     }
   }
   // Compacted rows (g.rowbits): tile row r stands for the (m0 + r)-th row of A_z whose bit is set; rowmap[r] = that row, or a
   // value past every buffer when the list is shorter (loads read 0, stores are dropped by the row test).  Every workgroup
-  // finds its own 128 rows: popcounts of the <= 512 bitmap words into LDS (the image area, not yet in use), then one serial
-  // scan per row (LDS broadcasts) -- about a microsecond of a 35 us tile; a tile past the end of the list returns.
-  const bool cmp = !AM && NW == 4 && rowmap != nullptr && g.rowbits != nullptr;
+  // finds its own 128 rows: exclusive prefix sums of the <= 512 words' popcounts (one wave: 8 words per lane, a DPP-free
+  // shuffle scan over the lanes) into LDS (the image area, not yet in use), then per row a binary search for its word and a
+  // walk over that word's bits -- a few hundred cycles of a 35 us tile; a tile past the end of the list returns.
+  // XCD balance: the set rows fill the row tiles 0 .. nact - 1, so of every 8 consecutive row tiles (one per XCD) only the first
+  // nact % 8 of the last group are live -- on the SAME XCDs for every batch entry z (the levels share their pad structure): the
+  // group's tiles are rotated by z * (nact % 8) XCDs, so the levels' extra tiles tile the ring instead of piling on XCDs 0, 1, ..
+  // (unrotated, N = 49: XCD 0 had 36 live P_q tiles, XCD 7 24 -- three tiles on some CUs, the launch as long as the dense one).
   if (cmp) {
     const int words = (g.M + 31) / 32;
     const unsigned* bits = g.rowbits + (long)z * words;
-    int* pc = reinterpret_cast<int*>(smem);
-    for (int i = tid; i < words; i += NT) pc[i] = __builtin_popcount(bits[i]);
+    int* pre = reinterpret_cast<int*>(smem);                     // [512 + 1] exclusive prefix sums (words past the end: the total)
+    if (wave == 0) {
+      int pcw[8], sum = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int i = 8 * lane + e;
+        pcw[e] = i < words ? __builtin_popcount(bits[i]) : 0;
+        sum += pcw[e];
+      }
+      int incl = sum;                                            // inclusive scan of the lanes' sums
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+      }
+      int run = incl - sum;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { pre[8 * lane + e] = run; run += pcw[e]; }
+      if (lane == 63) pre[512] = run;
+    }
     __syncthreads();
+    if (g.xcd_group) {
+      const int e = ((pre[512] + BM - 1) / BM) & 7;
+      m0 = (grp8 + (((id & 7) - z * e) & 7)) * BM;
+    }
     if (tid < BM) {
       const int c = m0 + tid;
-      int run = 0, row = 0x3fffffff;
-      for (int wdx = 0; wdx < words; ++wdx) {
-        const int pcw = pc[wdx];
-        if (c < run + pcw) {
-          unsigned b = bits[wdx];
-          for (int k = c - run; k > 0; --k) b &= b - 1;            // drop the lower set bits
-          row = 32 * wdx + __builtin_ctz(b);
-          break;
+      int row = 0x3fffffff;
+      if (c < pre[512]) {
+        int lo = 0, hi = 511;                                    // the last word whose prefix is <= c
+#pragma unroll
+        for (int it = 0; it < 9; ++it) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (pre[mid] <= c) lo = mid; else hi = mid - 1;
         }
-        run += pcw;
+        unsigned b = bits[lo];
+        for (int k = c - pre[lo]; k > 0; --k) b &= b - 1;        // drop the lower set bits
+        row = 32 * lo + __builtin_ctz(b);
       }
       rowmap[tid] = row;
     }

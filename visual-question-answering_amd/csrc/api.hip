@@ -139,7 +139,7 @@ extern "C" int coattn_workspace_bytes(int B, int N, int T, int d, int L, int dty
   if (saved) *saved = sp.total * sizeof(float);
   // the forward workspace ends with room for two pre-split weight images (gemm_w.hip)
   // ... and the bitmap of the question rows that are not all zeros (fused.h RowFlagJob)
-  if (ws_fwd) *ws_fwd = fwd_ws_floats(B, N, T, d, L) * sizeof(float) + 2 * wsplit_bytes(d, d) + al64(rowbits_words(B * T, L)) * sizeof(float);
+  if (ws_fwd) *ws_fwd = fwd_ws_floats(B, N, T, d, L) * sizeof(float) + 2 * wsplit_bytes(d, d) + al64(rowbits_words(B * T, L) + 8) * sizeof(float);
   if (ws_bwd) *ws_bwd = bwd_ws_floats(B, N, T, d, L) * sizeof(float);
   return 0;
 }
@@ -431,6 +431,8 @@ int general_projections(const Ctx& c, const float* V, const float* const* Q, con
   projection_jobs(c, V, Q, p, sv, wimg, wv, wq, v_w, q_w, f16);
   float* status = sv + sp.status;
   if (f16) wv.status = wq.status = status;            // both on two FP16 pieces, range-checked
+  RowFlagJob rj = {};
+  bool rows_in_gemm = false;
   if (v_w || q_w) {
     WSplit jobs[3];
     int nj = 0;
@@ -447,7 +449,6 @@ int general_projections(const Ctx& c, const float* V, const float* const* Q, con
     // four-wave GEMM runs over the flagged rows only (same values bit for bit; 44 % fewer rows on BASELINE's synthetic
     // questions, lengths U{3..26} of 26).  Row-major A on gemm_w_kernel only: the other kernels compute every row.
     static const int rows_env = dev_env_int("COATTN_SKIP_ZERO_ROWS", 1);   // developer switch
-    RowFlagJob rj = {};
     const bool skip_rows = rows_env && q_w && !f16 && !c.bf16_proj && gemm_wx_kernel(wq) == 0 && wq.a_sk == 0 && p->b_q &&
                            (wq.M + 31) / 32 <= kRowBitsMaxWords && c.d % 256 == 0 && c.d <= 1024 &&
                            ((((uintptr_t)p->b_q) | ((uintptr_t)(sv + sp.Pq))) & 15) == 0;      // (16-byte accesses of the flag job)
@@ -458,21 +459,29 @@ int general_projections(const Ctx& c, const float* V, const float* const* Q, con
       rj.bias_n = (const float*)p->b_q; rj.out_scale = c.pscale; rj.M = c.B * c.T; rj.N = c.d; rj.K = c.d; rj.batch = c.L;
       rj.rowbits = bits;
       wq.rowbits = bits;
+      // COATTN_FLAGS_IN_GEMM=1 (developer switch, DEV builds): the flag workgroups at the head of the PROJECTION launch instead,
+      // its P_q tiles waiting on a counter the weight-split launch zeroes.  Measured and not adopted: the weight-split launch
+      // gets its 6.6 us back, the projection launch loses 12.5 at N = 49 (392 flag workgroups hold the slots the first tiles
+      // want) and 5 at N = 196 (LAB_NOTES A6.3)
+      static const int in_gemm_env = dev_env_int("COATTN_FLAGS_IN_GEMM", 0);
+      if (in_gemm_env) rj.rowcnt = bits + rowbits_words(c.B * c.T, c.L);
     }
-    CA_TRY(launch_wsplit(jobs, nj, c.s, status, f16 ? 1 : 0, skip_rows ? &rj : nullptr));   // (also writes the header of the call's status words)
+    rows_in_gemm = skip_rows && rj.rowcnt != nullptr;
+    CA_TRY(launch_wsplit(jobs, nj, c.s, status, f16 ? 1 : 0, (skip_rows && !rows_in_gemm) ? &rj : nullptr,
+                         rows_in_gemm ? rj.rowcnt : nullptr));   // (also writes the header of the call's status words)
     prof_mark(c.s, "wsplit");
   } else {                                            // no weight-split launch on this path: header = "no FP16 pieces"
     if (hipMemsetAsync(status, 0, 2 * sizeof(float), c.s) != hipSuccess) { coattn_set_error("forward: hipMemsetAsync failed"); return -3; }
   }
   if (v_w && q_w) {                                   // both projections in one launch
     const WGemm both[2] = {wv, wq};
-    CA_TRY(launch_gemm_wx(both, 2, c.s));
+    CA_TRY(launch_gemm_wx(both, 2, c.s, rows_in_gemm ? &rj : nullptr));
     prof_mark(c.s, "projections");
     return 0;
   }
   if (v_w) CA_TRY(launch_gemm_wx(&wv, 1, c.s));
   else CA_TRY(proj_v(c, V, (const float*)p->W_v, (const float*)p->b_v, sv + sp.Pv));
-  if (q_w) return launch_gemm_wx(&wq, 1, c.s);
+  if (q_w) return launch_gemm_wx(&wq, 1, c.s, rows_in_gemm ? &rj : nullptr);
   // P_q of all levels in one launch: batch z = level, A from the pointer table
   coattn_gemm_desc g = {};
   for (int l = 0; l < c.L; ++l) g.a_ptrs[l] = Q[l];

@@ -272,15 +272,22 @@ struct RowFlagJob {
   const float* bias_n; float out_scale;
   int M, N, K, batch;
   unsigned* rowbits;                             // [batch][(M + 31) / 32]
+  unsigned* rowcnt;                              // (job inside a GEMM launch) [8] words finished per batch entry: zeroed by the launch
+                                                 // before, raised by every workgroup of the job behind its word; NULL otherwise
 };
 constexpr int kRowBitsMaxWords = 512;            // per batch entry (M <= 16,384 rows): the GEMM tiles scan the words serially
 inline size_t rowbits_words(int M, int batch) { return (size_t)batch * ((M + 31) / 32); }
 size_t wsplit_bytes(int N, int K);
 // status_hdr (may be NULL): the launch's first thread writes [0] = 0 and [1] = f16 ? 1 : 0 (the status words' header)
-// rows (may be NULL): a RowFlagJob done by extra workgroups of the same launch
-int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s, float* status_hdr = nullptr, int f16 = 0, const RowFlagJob* rows = nullptr);
+// rows (may be NULL): a RowFlagJob done by extra workgroups of the same launch; zero8 (may be NULL): eight words the launch zeroes
+// (RowFlagJob.rowcnt of a job that rides in the NEXT launch)
+int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s, float* status_hdr = nullptr, int f16 = 0, const RowFlagJob* rows = nullptr,
+                  unsigned* zero8 = nullptr);
 int gemm_w_supported(const WGemm& d);
-int launch_gemm_w(const WGemm* d, int n, hipStream_t s);          // n = 1 or 2 GEMMs in one launch
+// n = 1 or 2 GEMMs in one launch.  rows (may be NULL; exact four-wave launches only): a RowFlagJob whose workgroups come FIRST in
+// the launch; the tiles of a job with WGemm.rowbits then wait (per batch entry) until rows->rowcnt says its words are written --
+// the other job's tiles run meanwhile
+int launch_gemm_w(const WGemm* d, int n, hipStream_t s, const RowFlagJob* rows = nullptr);
 // single-product bf16 GEMM for wide shapes (gemm_bf.hip): reads a hi-piece-only weight image (WSplit.pieces = 1)
 int gemm_bf_supported(const WGemm& d);
 int launch_gemm_bf(const WGemm* d, int n, hipStream_t s);
@@ -290,13 +297,13 @@ int gemm_h2_supported(const WGemm& d);
 int launch_gemm_h2(const WGemm* d, int n, hipStream_t s);
 // the kernel a pre-split-weight GEMM runs on: gemm_bf / gemm_h2 when they take the shape and mode, else gemm_w
 inline int gemm_wx_kernel(const WGemm& d) { return gemm_bf_supported(d) ? 1 : (gemm_h2_supported(d) ? 2 : 0); }
-inline int launch_gemm_wx(const WGemm* d, int n, hipStream_t s) {
+inline int launch_gemm_wx(const WGemm* d, int n, hipStream_t s, const RowFlagJob* rows = nullptr) {
   if (n == 2 && gemm_wx_kernel(d[0]) != gemm_wx_kernel(d[1])) {   // one job on each kernel: two launches
     const int rc = launch_gemm_wx(&d[0], 1, s);
-    return rc ? rc : launch_gemm_wx(&d[1], 1, s);
+    return rc ? rc : launch_gemm_wx(&d[1], 1, s, rows);
   }
   const int k = gemm_wx_kernel(d[0]);
-  return k == 1 ? launch_gemm_bf(d, n, s) : (k == 2 ? launch_gemm_h2(d, n, s) : launch_gemm_w(d, n, s));
+  return k == 1 ? launch_gemm_bf(d, n, s) : (k == 2 ? launch_gemm_h2(d, n, s) : launch_gemm_w(d, n, s, rows));
 }
 
 // ---- weight-gradient GEMM C = A^T B with split-K parts (gemm_tn.hip) ---------------------------------------------

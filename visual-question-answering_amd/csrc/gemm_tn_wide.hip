@@ -34,7 +34,7 @@
 
 // Developer switches (tools/ab_gemmtn.sh with FILE=gemm_tn_wide MACRO=GEMMTNW_KO, never in the shipped library; wrong
 // results): GEMMTNW_KO bit 0 no MFMAs, 1 no global loads after the prologue's, 2 no split arithmetic, 3 no LDS writes,
-// 4 no fragment reads, 5 no barrier.
+// 4 no fragment reads, 5 no barrier, 6 no stores of the split-K partial results.
 #ifndef GEMMTNW_KO
 #define GEMMTNW_KO 0
 #endif
@@ -258,6 +258,7 @@ __device__ __forceinline__ void gemm_tn_wide_body(const TwArgs& g, const int bid
   if (s < steps) step(I0{}, s, img1);
 
   float* Cb = g.C + (long)z * g.M * g.N;
+  if ((GEMMTNW_KO & 64) && acc[0][0][0] != 12345.678f) return;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll

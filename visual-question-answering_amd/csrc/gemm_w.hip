@@ -28,10 +28,10 @@ namespace {
 
 using namespace gw;
 
-struct WJobs { WArgs job[2]; int first1; };   // blocks [0, first1) work on job 0, the rest on job 1
+struct WJobs { WArgs job[2]; int first1; RowFlagJob rows; int nflag; };   // blocks [0, nflag): the row-flag job; then [0, first1) of the rest work on job 0, the others on job 1
 
 struct SplitJob { const float* W; void* out; int N, K, trans, ld, pieces; float* amax; };
-struct SplitArgs { SplitJob job[3]; int njobs; float* status_hdr; float f16; RowFlagJob rows; int row_blocks, cb; };   // grid: [row_blocks][njobs x cb]
+struct SplitArgs { SplitJob job[3]; int njobs; float* status_hdr; float f16; RowFlagJob rows; int row_blocks, cb; unsigned* zero8; };   // grid: [row_blocks][njobs x cb]
 
 // The RowFlagJob's workgroups (the FIRST row_blocks of the launch: they have the most to wait for): workgroup x takes 32 rows of one batch entry, a wave 8 of them, all
 // requested before the first test (one memory latency per wave, not per row); a row is read in whole 1 KB segments (a lane
@@ -74,7 +74,25 @@ __device__ __forceinline__ void rowflag_block(const RowFlagJob& j, const int bx)
   }
   if (lane == 0) wbits[wave] = bits;
   __syncthreads();
-  if (threadIdx.x == 0) j.rowbits[(long)z * words + wd] = wbits[0] | wbits[1] | wbits[2] | wbits[3];
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&j.rowbits[(long)z * words + wd], wbits[0] | wbits[1] | wbits[2] | wbits[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (j.rowcnt) {                                  // (the job rides in a GEMM launch: tell its tiles, behind the word)
+      // The word went out as an agent-scope (write-through) store: once it is acknowledged it is visible device-wide, so the
+      // order is a wait for this thread's stores, NOT a device fence -- __threadfence() writes the XCD's L2 back and the
+      // readers' acquire invalidated theirs: 390 + 396 of those under the running GEMM tiles took the launch from 52 to 100 us
+      __builtin_amdgcn_s_waitcnt(0);
+      atomicAdd(&j.rowcnt[z & 7], 1u);
+    }
+  }
+}
+template <typename = void>
+__device__ __forceinline__ void rowflag_dispatch(const RowFlagJob& j, const int bid) {
+  switch (j.K >> 8) {                                // K / 256 in 1 .. 4 (host check)
+    case 1: rowflag_block<1>(j, bid); break;
+    case 2: rowflag_block<2>(j, bid); break;
+    case 3: rowflag_block<3>(j, bid); break;
+    default: rowflag_block<4>(j, bid); break;
+  }
 }
 
 // One wave per (32-column tile nt, 16-k step ks): lane (li = lane & 31, lh = lane >> 5) holds
@@ -83,15 +101,11 @@ __device__ __forceinline__ void rowflag_block(const RowFlagJob& j, const int bx)
 __global__ __launch_bounds__(256) void wsplit_kernel(const SplitArgs a) {
   int bid = (int)blockIdx.x;
   if (bid < a.row_blocks) {
-    switch (a.rows.K >> 8) {                         // K / 256 in 1 .. 4 (host check)
-      case 1: rowflag_block<1>(a.rows, bid); break;
-      case 2: rowflag_block<2>(a.rows, bid); break;
-      case 3: rowflag_block<3>(a.rows, bid); break;
-      default: rowflag_block<4>(a.rows, bid); break;
-    }
+    rowflag_dispatch(a.rows, bid);
     return;
   }
   bid -= a.row_blocks;
+  if (a.zero8 && bid == 0 && threadIdx.x < 8) a.zero8[threadIdx.x] = 0u;
   const int by = bid / a.cb, bx = bid - by * a.cb;
   const SplitJob j = a.job[by];
   f16_saturating_conversions();                      // (only the pieces = 16 jobs convert to fp16)
@@ -152,24 +166,39 @@ __global__ __launch_bounds__(64 * NW, (NP == 2 && NP1 == 2 && NW == 4) ? GEMMW_O
   static_assert(BM * LDR == BK * LDT, "both image layouts have the same size");
   if (H) f16_saturating_conversions();
   int* const rowmap = reinterpret_cast<int*>(smem + 2 * (NP > NP1 ? NP : NP1) * BM * LDR);
-  if ((int)blockIdx.x < jobs.first1) gemm_w_body<AM0, NP, NW, H>(jobs.job[0], (int)blockIdx.x, smem, rowmap);
-  else gemm_w_body<false, NP1, NW, H>(jobs.job[1], (int)blockIdx.x - jobs.first1, smem, rowmap);
+  int bid = (int)blockIdx.x;
+  if constexpr (NW == 4 && NP == 3 && NP1 == 3 && !H) {  // (the exact four-wave launch: the only one a row-flag job rides in)
+    if (bid < jobs.nflag) {
+      rowflag_dispatch(jobs.rows, bid);
+      return;
+    }
+    bid -= jobs.nflag;
+  }
+  if (bid < jobs.first1) gemm_w_body<AM0, NP, NW, H>(jobs.job[0], bid, smem, rowmap);
+  else gemm_w_body<false, NP1, NW, H>(jobs.job[1], bid - jobs.first1, smem, rowmap);
 }
 
 }  // namespace
 
 size_t wsplit_bytes(int N, int K) { return (size_t)((N + 31) / 32) * ((K + 15) / 16) * kChunkBytes; }
 
-int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s, float* status_hdr, int f16, const RowFlagJob* rows) {
+static int check_rowflag_job(const RowFlagJob* rows) {
+  CA_CHECK_ARG(rows->rowbits && rows->C && rows->bias_n && rows->M > 0 && rows->batch >= 1 && rows->batch <= 8 && rows->K % 256 == 0 &&
+               rows->K <= 1024 && rows->N == rows->K && (rows->c_sm & 3) == 0 && ((long)(rows->M - 1) * rows->c_sm + rows->N) * 4 < 0x40000000L &&
+               ((((uintptr_t)rows->C) | ((uintptr_t)rows->bias_n)) & 15) == 0 && ((rows->c_sz & 3) == 0) &&
+               (rows->a_sm & 3) == 0 && ((long)(rows->M - 1) * rows->a_sm + rows->K) * 4 < 0x40000000L,
+               "row-flag job: bad arguments");
+  for (int t = 0; t < rows->batch; ++t) CA_CHECK_ARG((((uintptr_t)rows->a_ptrs[t]) & 15) == 0, "row-flag job: unaligned rows");
+  return 0;
+}
+
+int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s, float* status_hdr, int f16, const RowFlagJob* rows, unsigned* zero8) {
   CA_CHECK_ARG(njobs >= 1 && njobs <= 3, "wsplit: 1 to 3 jobs per launch");
   SplitArgs a = {};
   int row_blocks = 0;
   if (rows) {
-    CA_CHECK_ARG(rows->rowbits && rows->C && rows->bias_n && rows->M > 0 && rows->batch >= 1 && rows->batch <= 8 && rows->K % 256 == 0 &&
-                 rows->K <= 1024 && rows->N == rows->K && (rows->c_sm & 3) == 0 && ((long)(rows->M - 1) * rows->c_sm + rows->N) * 4 < 0x40000000L &&
-                 ((((uintptr_t)rows->C) | ((uintptr_t)rows->bias_n)) & 15) == 0 && ((rows->c_sz & 3) == 0) && (rows->a_sm & 3) == 0 && ((long)(rows->M - 1) * rows->a_sm + rows->K) * 4 < 0x40000000L,
-                 "wsplit: bad row-flag job");
-    for (int t = 0; t < rows->batch; ++t) CA_CHECK_ARG((((uintptr_t)rows->a_ptrs[t]) & 15) == 0, "wsplit: row-flag job: unaligned rows");
+    CA_TRY(check_rowflag_job(rows));
+    CA_CHECK_ARG(rows->rowcnt == nullptr, "wsplit: a row-flag job of this launch needs no counter");
     a.rows = *rows;
     row_blocks = rows->batch * ((rows->M + 31) / 32);
   }
@@ -183,7 +212,7 @@ int launch_wsplit(const WSplit* jobs, int njobs, hipStream_t s, float* status_hd
     const int c = ((jobs[i].N + 31) / 32) * ((jobs[i].K + 15) / 16);
     chunks = c > chunks ? c : chunks;
   }
-  a.row_blocks = row_blocks; a.cb = (chunks + 3) / 4;
+  a.row_blocks = row_blocks; a.cb = (chunks + 3) / 4; a.zero8 = zero8;
   hipLaunchKernelGGL(wsplit_kernel, dim3(row_blocks + njobs * a.cb), dim3(256), 0, s, a);
   CA_CHECK_LAUNCH("wsplit");
   return 0;
@@ -227,7 +256,7 @@ int gemm_w_fill_job(const WGemm& d, gw::WArgs& g, long* nblk, int bn) {
   g.status = g.ascale != 1.0f ? d.status : nullptr;
   CA_CHECK_ARG(!d.rowbits || (d.a_sk == 0 && bn == BN && (d.M + 31) / 32 <= kRowBitsMaxWords),
                "gemm_w: a row bitmap needs a row-major A, the four-wave tile and at most %d rows", 32 * kRowBitsMaxWords);
-  g.rowbits = d.rowbits;
+  g.rowbits = d.rowbits; g.rowcnt = nullptr; g.rowcnt_words = (d.M + 31) / 32;
   g.M = d.M; g.N = d.N; g.K = d.K;
   const long ntn = (d.N + bn - 1) / bn, ntm = (d.M + BM - 1) / BM;
   g.xcd_group = ntm >= 32 ? 1 : 0;
@@ -236,7 +265,7 @@ int gemm_w_fill_job(const WGemm& d, gw::WArgs& g, long* nblk, int bn) {
 }
 
 // one launch for n = 1 or 2 GEMMs
-int launch_gemm_w(const WGemm* d, int n, hipStream_t s) {
+int launch_gemm_w(const WGemm* d, int n, hipStream_t s, const RowFlagJob* rows) {
   CA_CHECK_ARG(n == 1 || n == 2, "gemm_w: 1 or 2 jobs per launch");
   WJobs jobs = {};
   long nb[2] = {0, 0};
@@ -254,7 +283,16 @@ int launch_gemm_w(const WGemm* d, int n, hipStream_t s) {
   CA_CHECK_ARG(n == 1 || d[1].a_sk == 0, "gemm_w: only the first job may have an m-contiguous A operand");
   CA_CHECK_ARG(n == 1 || d[1].bf16 == d[0].bf16, "gemm_w: the jobs of a launch share the precision mode");
   const bool two0 = d[0].np == 2, two1 = n == 2 ? d[1].np == 2 : two0;      // fp32 mode: the width of each job
-  const dim3 grid((unsigned)(nb[0] + nb[1]));
+  if (rows) {                                         // its workgroups first; the tiles of the job with its bitmap wait for them
+    CA_TRY(check_rowflag_job(rows));
+    CA_CHECK_ARG(rows->rowcnt != nullptr && !wide && !d[0].bf16 && d[0].np != 2 && (n == 1 || d[1].np != 2) && !d[0].f16,
+                 "gemm_w: a row-flag job rides in the exact four-wave launch only");
+    jobs.rows = *rows;
+    jobs.nflag = (rows->batch * ((rows->M + 31) / 32) + 7) / 8 * 8;   // (a multiple of the XCD count: the tiles keep their XCDs)
+    for (int i = 0; i < n; ++i)
+      if (d[i].rowbits == rows->rowbits) { jobs.job[i].rowcnt = rows->rowcnt; jobs.job[i].rowcnt_words = (rows->M + 31) / 32; }
+  }
+  const dim3 grid((unsigned)(jobs.nflag + nb[0] + nb[1]));
   const bool h0 = d[0].f16 && two0 && !d[0].bf16, h1 = n == 2 ? (d[1].f16 && two1 && !d[1].bf16) : h0;
   CA_CHECK_ARG(h0 == h1, "gemm_w: the jobs of a launch share the piece format");
   if (h0 && wide) {                                   // (developer switch COATTN_GEMMW_WIDE2: 128 x 256 tiles, eight waves --

@@ -30,6 +30,8 @@ struct WArgs {
   int M, N, K, xcd_group;
   float* status;                               // (H) word [0] of the call's status words (fused.h kStatusHdr), or NULL
   const unsigned* rowbits;                     // (AM = false, four waves) fused.h WGemm.rowbits: the tiles run over the set rows alone
+  const unsigned* rowcnt; int rowcnt_words;    // != NULL: the bitmap is written by workgroups of THIS launch; rowcnt[z] reaches
+                                               // rowcnt_words when batch entry z's words are complete
 };
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -94,11 +96,19 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
     const unsigned* bits = g.rowbits + (long)z * words;
     int* pre = reinterpret_cast<int*>(smem);                     // [512 + 1] exclusive prefix sums (words past the end: the total)
     if (wave == 0) {
+      if (g.rowcnt) {
+        // The bitmap comes from the first workgroups of this launch (launch_gemm_w): wait until batch entry z's words are all
+        // written.  They are dispatched before every tile and wait for nothing, so the wait ends; the words are stored, counted
+        // and read at agent scope (write-through stores acknowledged before the count, loads that bypass this XCD's L2): no
+        // device fence on either side -- an acquire here would invalidate the L2 the running tiles stream their operands from.
+        while (__hip_atomic_load(&g.rowcnt[z], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)g.rowcnt_words)
+          __builtin_amdgcn_s_sleep(16);
+      }
       int pcw[8], sum = 0;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int i = 8 * lane + e;
-        pcw[e] = i < words ? __builtin_popcount(bits[i]) : 0;
+        pcw[e] = i < words ? __builtin_popcount(__hip_atomic_load(&bits[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0;
         sum += pcw[e];
       }
       int incl = sum;                                            // inclusive scan of the lanes' sums
@@ -127,7 +137,7 @@ __device__ __forceinline__ void gemm_w_body(const WArgs& g, const int id, short*
           const int mid = (lo + hi + 1) >> 1;
           if (pre[mid] <= c) lo = mid; else hi = mid - 1;
         }
-        unsigned b = bits[lo];
+        unsigned b = __hip_atomic_load(&bits[lo], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int k = c - pre[lo]; k > 0; --k) b &= b - 1;        // drop the lower set bits
         row = 32 * lo + __builtin_ctz(b);
       }

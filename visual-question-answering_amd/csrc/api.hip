@@ -138,8 +138,7 @@ extern "C" int coattn_workspace_bytes(int B, int N, int T, int d, int L, int dty
   const SavedPlan sp = plan_saved(B, N, T, d, L);
   if (saved) *saved = sp.total * sizeof(float);
   // the forward workspace ends with room for two pre-split weight images (gemm_w.hip)
-  // ... and the bitmap of the question rows that are not all zeros (fused.h RowFlagJob)
-  if (ws_fwd) *ws_fwd = fwd_ws_floats(B, N, T, d, L) * sizeof(float) + 2 * wsplit_bytes(d, d) + al64(rowbits_words(B * T, L) + 8) * sizeof(float);
+  if (ws_fwd) *ws_fwd = fwd_ws_floats(B, N, T, d, L) * sizeof(float) + 2 * wsplit_bytes(d, d);
   if (ws_bwd) *ws_bwd = bwd_ws_floats(B, N, T, d, L) * sizeof(float);
   return 0;
 }
@@ -418,6 +417,25 @@ bool f16_path(const Ctx& c, const float* V, const float* const* Q, int flags, in
   return v_w && q_w;
 }
 
+// Does the forward write the bitmap of the live question rows (and run P_q over them alone)?  A pure function of the call's
+// shapes, pointers and mode: the backward asks the same question about the same call (rowbits_in_saved).
+static bool rowbits_predicate(const Ctx& c, const WGemm& wq, const coattn_params* p, const float* sv, bool f16) {
+  static const int rows_env = dev_env_int("COATTN_SKIP_ZERO_ROWS", 1);   // developer switch
+  const SavedPlan sp = plan_saved(c.B, c.N, c.T, c.d, c.L);
+  return rows_env && !f16 && !c.bf16_proj && gemm_wx_kernel(wq) == 0 && wq.a_sk == 0 && p->b_q &&
+         (wq.M + 31) / 32 <= kRowBitsMaxWords && c.d % 256 == 0 && c.d <= 1024 &&
+         ((((uintptr_t)p->b_q) | ((uintptr_t)(sv + sp.Pq))) & 15) == 0;      // (16-byte accesses of the flag job)
+}
+bool rowbits_in_saved(const Ctx& c, const float* V, const float* const* Q, const coattn_params* p, const float* sv, int flags, int fused) {
+  WGemm wv, wq;
+  bool v_w, q_w;
+  Ctx cc = c;
+  cc.f16_proj = f16_path(c, V, Q, flags, fused);
+  const bool f16 = cc.f16_proj && !cc.bf16_proj;
+  projection_jobs(cc, V, Q, p, const_cast<float*>(sv), nullptr, wv, wq, v_w, q_w, f16);
+  return q_w && rowbits_predicate(cc, wq, p, sv, f16);
+}
+
 // wimg: room for two pre-split weight images (wsplit_bytes(d, d) each) at the end of the forward workspace
 // keep_wqT: also split W_q the other way round into the saved state (sp.wqT) for the backward's dQ projection
 int general_projections(const Ctx& c, const float* V, const float* const* Q, const coattn_params* p, float* sv, char* wimg,
@@ -448,12 +466,9 @@ int general_projections(const Ctx& c, const float* V, const float* const* Q, con
     // workgroups flag the rows of Q_l that hold anything, write (0 + b_q) * scale into the others' rows of P_q, and the exact
     // four-wave GEMM runs over the flagged rows only (same values bit for bit; 44 % fewer rows on BASELINE's synthetic
     // questions, lengths U{3..26} of 26).  Row-major A on gemm_w_kernel only: the other kernels compute every row.
-    static const int rows_env = dev_env_int("COATTN_SKIP_ZERO_ROWS", 1);   // developer switch
-    const bool skip_rows = rows_env && q_w && !f16 && !c.bf16_proj && gemm_wx_kernel(wq) == 0 && wq.a_sk == 0 && p->b_q &&
-                           (wq.M + 31) / 32 <= kRowBitsMaxWords && c.d % 256 == 0 && c.d <= 1024 &&
-                           ((((uintptr_t)p->b_q) | ((uintptr_t)(sv + sp.Pq))) & 15) == 0;      // (16-byte accesses of the flag job)
+    const bool skip_rows = q_w && rowbits_predicate(c, wq, p, sv, f16);
     if (skip_rows) {
-      unsigned* bits = reinterpret_cast<unsigned*>(wimg + 2 * wsplit_bytes(c.d, c.d));
+      unsigned* bits = reinterpret_cast<unsigned*>(sv + sp.rowbits);        // (kept in `saved`: the backward's dW_q reads it)
       for (int l = 0; l < c.L; ++l) rj.a_ptrs[l] = Q[l];
       rj.a_sm = c.d; rj.C = sv + sp.Pq; rj.c_sz = (long)BTd; rj.c_sm = c.d;
       rj.bias_n = (const float*)p->b_q; rj.out_scale = c.pscale; rj.M = c.B * c.T; rj.N = c.d; rj.K = c.d; rj.batch = c.L;
@@ -464,7 +479,7 @@ int general_projections(const Ctx& c, const float* V, const float* const* Q, con
       // gets its 6.6 us back, the projection launch loses 12.5 at N = 49 (392 flag workgroups hold the slots the first tiles
       // want) and 5 at N = 196 (LAB_NOTES A6.3)
       static const int in_gemm_env = dev_env_int("COATTN_FLAGS_IN_GEMM", 0);
-      if (in_gemm_env) rj.rowcnt = bits + rowbits_words(c.B * c.T, c.L);
+      if (in_gemm_env) rj.rowcnt = reinterpret_cast<unsigned*>(sv + sp.rowcnt);
     }
     rows_in_gemm = skip_rows && rj.rowcnt != nullptr;
     CA_TRY(launch_wsplit(jobs, nj, c.s, status, f16 ? 1 : 0, (skip_rows && !rows_in_gemm) ? &rj : nullptr,
@@ -760,7 +775,8 @@ extern "C" int coattn_backward(const void* V, int64_t v_sB, int64_t v_sN, int64_
     return fused_backward(B, N, T, d, L, (const float*)V, vl, (const float* const*)Q, p, (const float*)saved,
                           (const float*)gv, (const float*)gq, (float*)dV, dvl, (float* const*)dQ, pg, accumulate,
                           (float*)ws, c.s, c.bf16_proj ? 1 : 0,
-                          gemm_w_enabled() ? 1 : 0, np_bwd(flags));
+                          gemm_w_enabled() ? 1 : 0, np_bwd(flags),
+                          rowbits_in_saved(c, (const float*)V, (const float* const*)Q, p, (const float*)saved, flags, fused) ? 1 : 0);
   return backward_general(c, (const float*)V, (const float* const*)Q, p, (const float*)saved, (const float*)gv,
                           (const float*)gq, (float*)dV, dvl, (float* const*)dQ, pg, accumulate, (float*)ws);
 }

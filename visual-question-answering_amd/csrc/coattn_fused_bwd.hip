@@ -105,6 +105,8 @@ struct PreArgs {
   float* dsq;                            // [L*B][32] ds_q, zeros for t >= T
   float* dcs_part;                       // [2][L*B]
   int B, N, T, d, L;
+  TnDyn dyn; TnDynPlan* plan_out;        // plan_out != NULL: ONE more workgroup (the launch's last) evaluates the split-K plan of the
+                                         // weight gradients over the live question rows (fused.h tn_dyn_plan) and leaves it there
 };
 
 // Blocks [0, L*B): one workgroup (256 threads) per (sample, level), question side -- softmax backward of a_q
@@ -116,6 +118,13 @@ struct PreArgs {
 //  22.7 -> 22.3 / 21.6 at N = 49.)
 __global__ __launch_bounds__(256) void bwd_pre_kernel(const PreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (a.plan_out && (int)blockIdx.x == a.L * a.B + a.dav_gx * a.B) {
+    if (threadIdx.x < 64) {                          // one full wave
+      const TnDynPlan pl = tn_dyn_plan(a.dyn);
+      if (threadIdx.x == 0) *a.plan_out = pl;
+    }
+    return;
+  }
   const int d = a.d, T = a.T, B = a.B;
   if ((int)blockIdx.x >= a.L * B) {
     const int id = (int)blockIdx.x - a.L * B;
@@ -274,7 +283,7 @@ hipError_t set_lds(K kern, size_t bytes) {
 
 int launch_pre(const PreArgs& a, hipStream_t s) {
   const size_t lds = 768;                                           // the 3 x 64 g values of a channel-major da_v block; 32 da_q
-  hipLaunchKernelGGL(bwd_pre_kernel, dim3(a.L * a.B + a.dav_gx * a.B), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(bwd_pre_kernel, dim3(a.L * a.B + a.dav_gx * a.B + (a.plan_out ? 1 : 0)), dim3(256), lds, s, a);
   CA_CHECK_LAUNCH("bwd_pre");
   // (the image side's softmax backward -- ds_v from these partials -- happens in the prologues of bwd_dc32_kernel and
   //  bwd_nat32_kernel: fused.h softmax_bwd_v)
@@ -290,7 +299,7 @@ int fused_backward_supported(int B, int N, int T, int d, int L) { return fused_s
 int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLayout& vl, const float* const* Q,
                    const coattn_params* p, const float* saved, const float* gv, const float* gq, float* dV,
                    const VLayout& dvl, float* const* dQ, const coattn_param_grads* pg, int accumulate, float* ws,
-                   hipStream_t s, int bf16_proj, int wgemm, int np) {
+                   hipStream_t s, int bf16_proj, int wgemm, int np, int live_rows) {
   // np: width of the fp32 mode's contractions (fused.h): 2 = hi + mid in the three fused kernels and in the GEMM launch
   // (dW_v, dW_q, dQ = dP_q W_q), 3 = the exact split everywhere; dV (general GEMM) is always exact
   np = (np == 2 && !bf16_proj) ? 2 : 3;
@@ -314,6 +323,18 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
   pa.gq = gq; pa.av = saved + so.av; pa.aq = saved + so.aq;
   pa.dsq = ws + wo.dsq; pa.dcs_part = ws + wo.dcs_part;
   pa.B = B; pa.N = N; pa.T = T; pa.d = d; pa.L = L;
+  // (exact mode: the forward's bitmap of the live question rows is in `saved`; the plan of the weight gradients over those rows
+  //  is a function of it and of shapes known here -- evaluated once, by an extra workgroup of this launch)
+  static const int tn_budget_env = dev_env_int("COATTN_TN_PARTS", 0);   // developer switch
+  const int tn_budget = tn_budget_env > 0 ? tn_budget_env : 32;
+  TnDyn dyn_all = {};
+  pa.dyn = dyn_all; pa.plan_out = nullptr;
+  if (live_rows && L <= kDynLevels && (B * T + 31) / 32 <= kRowBitsMaxWords && tn_budget > L) {
+    dyn_all.bits = reinterpret_cast<const unsigned*>(saved + so.rowbits);
+    dyn_all.words = (B * T + 31) / 32; dyn_all.levels = L; dyn_all.P = tn_budget; dyn_all.K0 = B * N;
+    dyn_all.plan = reinterpret_cast<const TnDynPlan*>(ws + wo.dynplan);
+    pa.dyn = dyn_all; pa.plan_out = reinterpret_cast<TnDynPlan*>(ws + wo.dynplan);
+  }
   CA_TRY(launch_pre(pa, s));
   prof_mark(s, "bwd_pre");
   // 2. the two recompute kernels
@@ -429,7 +450,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     prof_mark(s, "bwd_gemm_dq_projection");
   }
   // (red: the two weight gradients' partial sums, handed to the dQ kernel's launch when it is the bf16-MFMA one)
-  struct RedJob { const float* part[2]; float* out[2]; int np[2]; long n; int acc; bool on; } red = {};
+  struct RedJob { const float* part[2]; float* out[2]; int np[2]; long n; int acc; bool on; TnDyn dyn; } red = {};
   static const int red_in_dq = dev_env_int("COATTN_RED_IN_DQ", 1);   // developer switch
   auto run_dq = [&]() -> int {
     DqArgs da = {};
@@ -437,6 +458,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     if (red.on && dq32) {
       for (int i = 0; i < 2; ++i) { da.red_part[i] = red.part[i]; da.red_out[i] = red.out[i]; da.red_np[i] = red.np[i]; }
       da.red_n = red.n; da.red_acc = red.acc; da.red_jobs = 2; da.red_blocks = (int)((red.n / 4 + 255) / 256);
+      da.red_dyn = red.dyn;
     }
     da.V = V; da.v_sB = vl.sB; da.dA = ws + wo.dA; da.aq = saved + so.aq; da.gq = gq;
     for (int l = 0; l < 8; ++l) da.dQ[l] = l < L ? dQ[l] : nullptr;
@@ -537,8 +559,7 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     // both weight gradients in one launch: 32 split-K parts (x 16 tiles = the 512 workgroup slots) shared in
     // proportion to the contraction lengths, so that all workgroups run about equally long
     const double kv = (double)B * N, kq = (double)L * B * T;
-    static const int budget_env = dev_env_int("COATTN_TN_PARTS", 0);   // developer switch
-    const int budget = budget_env > 0 ? budget_env : 32;
+    const int budget = tn_budget;
     int pv = (int)((double)budget * kv / (kv + kq) + 0.5);
     pv = pv < 1 ? 1 : (pv > budget - 1 ? budget - 1 : pv);
     const int pq = (budget - pv) / L > 0 ? (budget - pv) / L * L : L;
@@ -546,23 +567,32 @@ int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLay
     // two-piece width: 128 x 256 tiles on 512-thread workgroups (gemm_tn_wide.hip) -- the same split-K partition, pieces and
     // order of products, so the same bits as the 128 x 128 kernel
     const bool wide = gemm_tn_wide_supported(tnv) && gemm_tn_wide_supported(tnq) && (!combine || (wdq.N % 256 == 0 && !wdq.f16 && (wdq.np == 2) == (tnv.np == 2)));
+    const bool red_al = (((int64_t)d * d) & 3) == 0 && ((((uintptr_t)part) | ((uintptr_t)pg->dW_v) | ((uintptr_t)pg->dW_q)) & 15) == 0;
+    // The forward left the bitmap of the question rows that are not all zeros in `saved` (exact mode; api.hip rowbits_in_saved):
+    // dW_q = sum dP_q^T Q then contracts over those rows only, and the launch shares its `budget` parts between dW_v and the
+    // levels of dW_q ON THE DEVICE (fused.h TnDyn) -- the partial sums are added by the dQ kernel's extra workgroups, which
+    // evaluate the same plan.  COATTN_DW_LIVE_ROWS=0 (developer switch): the host's static plan over all rows.
+    static const int live_env = dev_env_int("COATTN_DW_LIVE_ROWS", 1);
+    TnDyn dyn = {};
+    const bool use_dyn = live_env && dyn_all.bits && wide && late_dq && dq32 && red_in_dq && red_al && tnq.K <= 8192 && !tnq.a_bf16 &&
+                         (tnq.K + 31) / 32 <= kRowBitsMaxWords && budget > L && budget <= kMaxParts && L <= kDynLevels;
+    if (use_dyn) dyn = dyn_all;
     const int parts_v = wide ? gemm_tn_wide_plan(tnv, pv, &ks[0], &S[0]) : gemm_tn_plan(tnv, pv, &ks[0], &S[0]);
-    tnq.C = part + (size_t)parts_v * d * d;
+    tnq.C = use_dyn ? part : part + (size_t)parts_v * d * d;
     const int parts_q = wide ? gemm_tn_wide_plan(tnq, pq, &ks[1], &S[1]) : gemm_tn_plan(tnq, pq, &ks[1], &S[1]);
     CA_CHECK_ARG(parts_v + parts_q <= kMaxParts, "fused backward: %d split-K parts exceed the workspace", parts_v + parts_q);
     const TnGemm both[2] = {tnv, tnq};
-    if (wide) CA_TRY(launch_gemm_tn_wide(both, ks, S, 2, s, &small, combine ? &wdq : nullptr));
+    if (wide) CA_TRY(launch_gemm_tn_wide(both, ks, S, 2, s, &small, combine ? &wdq : nullptr, use_dyn ? &dyn : nullptr));
     else CA_TRY(launch_gemm_tn(both, ks, S, 2, s, &small, combine ? &wdq : nullptr));
     prof_mark(s, combine ? "bwd_gemm" : "bwd_gemm_dw");
     if (own_dq) {
       CA_TRY(dq_projection(false));
       prof_mark(s, "bwd_gemm_dq_projection");
     }
-    const bool red_al = (((int64_t)d * d) & 3) == 0 && ((((uintptr_t)part) | ((uintptr_t)pg->dW_v) | ((uintptr_t)tnq.C) | ((uintptr_t)pg->dW_q)) & 15) == 0;
     if (late_dq && dq32 && red_in_dq && red_al) {       // the partial sums ride in the dQ kernel's launch
       red.part[0] = part; red.out[0] = (float*)pg->dW_v; red.np[0] = parts_v;
       red.part[1] = tnq.C; red.out[1] = (float*)pg->dW_q; red.np[1] = parts_q;
-      red.n = (long)d * d; red.acc = accumulate; red.on = true;
+      red.n = (long)d * d; red.acc = accumulate; red.on = true; red.dyn = dyn;
       return run_dq();
     }
     if (late_dq) CA_TRY(run_dq());

@@ -22,7 +22,7 @@ int fused_backward_supported(int B, int N, int T, int d, int L);
 int fused_backward(int B, int N, int T, int d, int L, const float* V, const VLayout& vl, const float* const* Q,
                    const coattn_params* p, const float* saved, const float* gv, const float* gq, float* dV,
                    const VLayout& dvl, float* const* dQ, const coattn_param_grads* pg, int accumulate, float* ws,
-                   hipStream_t s, int bf16_proj, int wgemm, int np = 3);   // wgemm: gemm_w / gemm_tn enabled; np: width of the contractions (3 | 2)
+                   hipStream_t s, int bf16_proj, int wgemm, int np = 3, int live_rows = 0);   // wgemm: gemm_w / gemm_tn enabled; np: width of the contractions (3 | 2); live_rows: `saved` holds the forward's bitmap of the non-zero question rows
 
 // Diagnostic build only (tools/probe_stamps.py, -DCOATTN_STAMPS=1): wave 0 of every workgroup writes the
 // 100 MHz constant clock at its phase boundaries into the (otherwise unused) forward workspace tail.
@@ -321,6 +321,46 @@ struct TnGemm {
   int np;                                                            // (bf16 = 0) bf16 pieces per operand: 0 / 3 = the exact split, 2 = hi + mid (three products)
   int a_bf16;                                                        // (gemm_bf_tn_kernel) A is STORED as bf16; a_ld, a_sl, a_term in elements
 };
+// Weight gradients over the LIVE question rows only (the pad rows of Q are exact zeros: their terms of dW_q = sum dP_q^T Q vanish).
+// The launch of the two weight gradients then plans its split-K parts ON THE DEVICE from the forward's row bitmap (fused.h
+// RowFlagJob; `saved` keeps it): P parts in all, S0 of them for job 0 (contraction length K0), S1 per level for job 1 over that
+// level's live rows, chosen so that all parts are about equally long -- the host cannot know the count without a
+// synchronisation.  Every workgroup of the launch and the workgroups that later add the partial results evaluate tn_dyn_plan
+// on the same words: the same integers everywhere.
+constexpr int kDynLevels = 4;                                            // levels a device-planned launch takes (the path has 3)
+struct TnDynPlan { int S0, S1, ks0, live[kDynLevels], ks1[kDynLevels]; };
+struct TnDyn { const unsigned* bits; int words, levels, P, K0;           // bits == NULL: the host's static plan
+               const TnDynPlan* plan; };                                 // the plan, evaluated once (an extra workgroup of bwd_pre_kernel)
+// by ONE full wave (all 64 lanes active); the result is uniform.  (Loops over the levels are unrolled over kDynLevels with the
+// live ones selected by a compare: a run-time index into the arrays would put them in scratch.)
+__device__ __forceinline__ TnDynPlan tn_dyn_plan(const TnDyn& d) {
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  TnDynPlan pl;
+  int tot = 0;
+#pragma unroll
+  for (int l = 0; l < kDynLevels; ++l) {
+    int c = 0;
+    if (l < d.levels) {
+      for (int i = lane; i < d.words; i += 64) c += __builtin_popcount(d.bits[(long)l * d.words + i]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    }
+    pl.live[l] = c;
+    tot += c;
+  }
+  const long den = (long)d.K0 + tot;
+  int S0 = (int)((2L * d.P * d.K0 + den) / (2 * den));
+  S0 = S0 < 1 ? 1 : (S0 > d.P - d.levels ? d.P - d.levels : S0);
+  pl.S0 = S0;
+  pl.S1 = (d.P - S0) / d.levels;
+  pl.ks0 = (((d.K0 + S0 - 1) / S0) + 15) / 16 * 16;
+#pragma unroll
+  for (int l = 0; l < kDynLevels; ++l) {
+    const int n = pl.live[l] > 0 ? pl.live[l] : 1;
+    pl.ks1[l] = (((n + pl.S1 - 1) / pl.S1) + 15) / 16 * 16;
+  }
+  return pl;
+}
 int gemm_tn_supported(const TnGemm& d);
 // the same products in the reduced-precision mode at wide shapes (gemm_bf.hip): 256 x 256 tiles, parts over the concatenated levels
 int gemm_bf_tn_supported(const TnGemm& d);
@@ -341,8 +381,9 @@ int launch_gemm_tn(const TnGemm* d, const int* ksplit, const int* S, int n, hipS
 // the same launch on 128 x 256 tiles / 512-thread workgroups, for the two-piece width (gemm_tn_wide.hip)
 int gemm_tn_wide_supported(const TnGemm& d);
 int gemm_tn_wide_plan(const TnGemm& d, int max_parts, int* ksplit, int* S);
+// dyn (may be NULL; n == 2, both jobs on the same tile grid): TnDyn of the launch -- job 1 contracts over the rows whose bit is set
 int launch_gemm_tn_wide(const TnGemm* d, const int* ksplit, const int* S, int n, hipStream_t s, const TnReduce* red = nullptr,
-                        const WGemm* wextra = nullptr);
+                        const WGemm* wextra = nullptr, const TnDyn* dyn = nullptr);
 
 // XCD-aware block -> (b, l): blocks i and i+8 share an XCD (round-robin dispatch), so give the
 // L levels of one sample consecutive slots on one XCD.  Speed only; any mapping is correct.
@@ -477,12 +518,19 @@ struct DqArgs {
   // (red_blocks of them per job, red_jobs jobs: out[j] (+)= sum_c part[c][j], four floats per thread) -- nothing of it
   // depends on dQ, and a launch of its own cost a launch gap and 7 us during which nothing else ran
   const float* red_part[2]; float* red_out[2]; int red_np[2]; long red_n; int red_acc, red_blocks, red_jobs;
+  TnDyn red_dyn;         // bits != NULL: the parts were planned on the device (tn_dyn_plan): job 0 = parts [0, S0), job 1 = the
+                         // levels * S1 parts behind them, all in red_part[0]
 };
 __device__ __forceinline__ void reduce_partials4_block(const DqArgs& a, int id) {   // (as small_kernels.hip reduce_partials4_kernel)
   const int job = id / a.red_blocks, bx = id - job * a.red_blocks;
   const float* part = a.red_part[job];
   float* out = a.red_out[job];
-  const int nparts = a.red_np[job];
+  int nparts = a.red_np[job];
+  if (a.red_dyn.bits) {                              // (the plan bwd_pre_kernel's extra workgroup left in the workspace)
+    const int S0 = a.red_dyn.plan->S0, S1 = a.red_dyn.plan->S1;
+    nparts = job == 0 ? S0 : a.red_dyn.levels * S1;
+    part = a.red_part[0] + (job == 0 ? 0L : (long)S0 * a.red_n);
+  }
   const long n = a.red_n, j = ((long)bx * 256 + threadIdx.x) * 4;
   if (j >= n) return;
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -509,7 +557,7 @@ int launch_attend_v_lm(const float* V, long v_sB, const float* av, float* v_out,
 inline size_t fal64(size_t n) { return (n + 63) & ~(size_t)63; }
 
 struct SavedOff {
-  size_t Pv, Pq, C, av, aq, Hq, wqT, status, total;
+  size_t Pv, Pq, C, av, aq, Hq, wqT, status, rowcnt, rowbits, total;
 };
 inline SavedOff saved_off(int B, int N, int T, int d, int L) {   // the one layout of `saved`
   SavedOff p;
@@ -524,13 +572,17 @@ inline SavedOff saved_off(int B, int N, int T, int d, int L) {   // the one layo
   // launch, so that the backward has no split launch of its own
   p.wqT = o; o += fal64((size_t)((d + 31) / 32) * ((d + 15) / 16) * 768);
   p.status = o; o += fal64(status_floats(d, d, 2));   // range report of the tolerance mode (W_v, W_q images)
+  // bitmap of the question rows that are not all zeros (RowFlagJob; one word per 32 rows and level) and, in front of it, eight
+  // words of counters: the exact forward writes it, the backward's weight gradients contract over the live rows only
+  p.rowcnt = o; o += 64;
+  p.rowbits = o; o += fal64(rowbits_words(B * T, L));
   p.total = o;
   return p;
 }
 
 // workspace of the fused backward (floats)
 struct FusedBwdOff {
-  size_t dsv, dsq, dPq, dPv, dA, dwv_part, dbv_part, dbq_part, dwq_part, dcs_part, part, total;
+  size_t dsv, dsq, dPq, dPv, dA, dwv_part, dbv_part, dbq_part, dwq_part, dcs_part, dynplan, part, total;
 };
 constexpr int kMaxParts = 40;   // split-K parts of the weight-gradient GEMMs (32 shared by dW_v and dW_q, rounded up per level)
 inline FusedBwdOff fused_bwd_off(int B, int N, int T, int d, int L) {
@@ -546,6 +598,7 @@ inline FusedBwdOff fused_bwd_off(int B, int N, int T, int d, int L) {
   p.dbq_part = o; o += fal64((size_t)L * B * d);
   p.dwq_part = o; o += fal64((size_t)L * B * d);
   p.dcs_part = o; o += fal64((size_t)L * B * 2);
+  p.dynplan = o; o += 64;                          // TnDynPlan of a device-planned weight-gradient launch
   // shared scratch: split-K partials of the weight-gradient GEMMs (<= kMaxParts x d x d) and, before them, the da_v
   // partials of bwd_dav_kernel ([B][d/64][3][N]), which outgrow the former at large B
   const size_t part_gemm = (size_t)kMaxParts * d * d, part_dav = (size_t)B * (d / 64) * 3 * N;

@@ -60,31 +60,74 @@ struct TwJobs {
   TwArgs job[2]; int first1; ReduceJobs red; int nred, red_bx, red_nparts, red_acc; long red_n;
   gw::WArgs wj; int nw;
   int wfirst;                     // > 0: the dQ tiles come FIRST, in this many block slots (nw rounded up to the XCD count), the split-K parts behind them
+  TnDyn dyn;                      // bits != NULL: the parts of both jobs are planned on the device (fused.h)
 };
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // BCM: the B operand is contiguous along k inside groups of b_kdiv rows (channel-major image features [B, d, N]: k =
 // (sample, location), n = channel), as in gemm_tn.hip: float4 = 4 consecutive k of one column, [column][k] images.
-template <bool SUM3, int NP, bool BCM = false>
-__device__ __forceinline__ void gemm_tn_wide_body(const TwArgs& g, const int bid, const int nblk, short* const lds) {
+// GATHER (job 1 of a launch planned on the device, TnDyn): the contraction runs over the rows of level `lvl` whose bit is set in
+// `bits`; [kbeg, kend) then counts positions of that compacted list, and the rows come from a map in LDS (behind the images)
+// that the workgroup builds first: exclusive prefix sums of the words' popcounts (one wave, 8 words per lane), then per position
+// a binary search for its word and a walk over the word's bits (as gemm_w_body.h's compacted tiles).  Positions past the end map
+// to row K: outside the operands' buffers, so the loads return zeros.
+template <bool SUM3, int NP, bool BCM, bool GATHER>
+__device__ __forceinline__ void gemm_tn_wide_core(const TwArgs& g, const int m0, const int n0, const int z, const int lvl, const int p,
+                                                  const int kbeg, const int kend, short* const lds, const unsigned* bits, const int words) {
   static_assert(NP == 2 || NP == 3, "pieces per operand");
+  static_assert(!GATHER || (!SUM3 && !BCM), "the gathered job is the plain row-major one");
   constexpr int OPERA = NP * IMGA, OPERB = NP * (BCM ? IMGBC : IMGB), BUF = OPERA + OPERB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3, li = lane & 31, lh = lane >> 5;
-  // XCD-run order (gemm_tn.hip): the tiles of a part share an XCD's L2
-  const int ntn = g.N / BN, ntiles = (g.M / BM) * ntn;
-  int lin = bid;
-  if ((nblk & 7) == 0) lin = (bid & 7) * (nblk >> 3) + (bid >> 3);
-  const int z = lin / ntiles, t = lin % ntiles;
-  const int m0 = (t / ntn) * BM, n0 = (t % ntn) * BN;
-  const int lvl = z / g.S, p = z % g.S;
   // TNW_INTERLEAVE (developer build, location-major B only): part p takes the 16-row blocks p, p + S, p + 2 S, ... instead of a
   // contiguous range -- all workgroups then read one neighbourhood of rows at a time
-  const bool il = TNW_INTERLEAVE && !BCM;
+  const bool il = TNW_INTERLEAVE && !BCM && !GATHER;
   const int nblk16 = (g.K + BK - 1) / BK;
-  const int kbeg = il ? p * BK : p * g.ksplit, kend = min(g.K, kbeg + g.ksplit);
-  const int steps = il ? (nblk16 > p ? (nblk16 - p + g.S - 1) / g.S : 0) : (kend - kbeg + BK - 1) / BK;
+  const int steps = il ? (nblk16 > p ? (nblk16 - p + g.S - 1) / g.S : 0) : (kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0);
+  int* const rowmap = reinterpret_cast<int*>(lds + 2 * BUF) + 520;       // [(steps + 3) * 16]; the 513 prefix sums in front of it
+  if (GATHER) {
+    int* pre = reinterpret_cast<int*>(lds + 2 * BUF);
+    const unsigned* lb = bits + (long)lvl * words;
+    if (wave == 0) {
+      int pcw[8], sum = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int i = 8 * lane + e;
+        pcw[e] = i < words ? __builtin_popcount(lb[i]) : 0;
+        sum += pcw[e];
+      }
+      int incl = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+      }
+      int run = incl - sum;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { pre[8 * lane + e] = run; run += pcw[e]; }
+      if (lane == 63) pre[512] = run;
+    }
+    __syncthreads();
+    const int total = pre[512], nmap = (steps + 3) * BK;
+    for (int e = tid; e < nmap; e += NTHR) {
+      const int c = kbeg + e;
+      int row = g.K;
+      if (c < kend && c < total) {
+        int lo = 0, hi = 511;
+#pragma unroll
+        for (int it = 0; it < 9; ++it) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (pre[mid] <= c) lo = mid; else hi = mid - 1;
+        }
+        unsigned b = lb[lo];
+        for (int k = c - pre[lo]; k > 0; --k) b &= b - 1;
+        row = 32 * lo + __builtin_ctz(b);
+      }
+      rowmap[e] = row;
+    }
+    __syncthreads();
+  }
   const float* Ab = g.A + (long)lvl * g.a_sl;
   const float* Bb = g.b_ptrs[0] ? g.b_ptrs[lvl & 7] : g.B + (long)lvl * g.b_sl;
   // rows past K read 0 (resource bound); rows past kend belong to the next part: ksplit % 16 == 0, so a step never straddles
@@ -132,6 +175,11 @@ __device__ __forceinline__ void gemm_tn_wide_body(const TwArgs& g, const int bid
   constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
   auto load_raw = [&](int x, int s) {            // (the step goes into the VECTOR offset: the range check does not see the scalar one)
     if ((GEMMTNW_KO & 2) && s >= 2) return;
+    if (GATHER) {                                // rows from the map (x = 0: A row ska; x = 1, 2: B rows skb, skb + 8 of the step)
+      if (x == 0) raw[0] = buf_load4(rs_a, (rowmap[s * BK + ska] * g.a_ld + m0 + sma) * 4, 0);
+      else raw[x] = buf_load4(rs_b, (rowmap[s * BK + skb + 8 * (x - 1)] * g.b_ld + n0 + smb) * 4, 0);
+      return;
+    }
     if (x == 0) {
       raw[0] = buf_load4(rs_a, a_voff + s * a_step, 0);
       if (SUM3) {
@@ -270,12 +318,58 @@ __device__ __forceinline__ void gemm_tn_wide_body(const TwArgs& g, const int bid
     }
 }
 
+// the host's static plan: workgroup bid of a job's nblk -> (part, tile)
+template <bool SUM3, int NP, bool BCM = false>
+__device__ __forceinline__ void gemm_tn_wide_body(const TwArgs& g, const int bid, const int nblk, short* const lds) {
+  // XCD-run order (gemm_tn.hip): the tiles of a part share an XCD's L2
+  const int ntn = g.N / BN, ntiles = (g.M / BM) * ntn;
+  int lin = bid;
+  if ((nblk & 7) == 0) lin = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  const int z = lin / ntiles, t = lin % ntiles;
+  const int m0 = (t / ntn) * BM, n0 = (t % ntn) * BN;
+  const int lvl = z / g.S, p = z % g.S;
+  const bool il = TNW_INTERLEAVE && !BCM;
+  const int kbeg = il ? p * BK : p * g.ksplit, kend = min(g.K, kbeg + g.ksplit);
+  gemm_tn_wide_core<SUM3, NP, BCM, false>(g, m0, n0, z, lvl, p, kbeg, kend, lds, nullptr, 0);
+}
+// the plan made on the device (TnDyn): workgroup bid of the launch's P x tiles -> job 0 part z < S0, or job 1 (level, part)
+template <bool SUM3, int NP, bool BCM>
+__device__ __forceinline__ void gemm_tn_wide_dyn(const TwArgs& g0, const TwArgs& g1, const TnDyn& dyn, const int bid, const int nblk,
+                                                 short* const lds) {
+  const TnDynPlan pl = *dyn.plan;                    // (uniform: scalar loads)
+  const int ntn = g0.N / BN, ntiles = (g0.M / BM) * ntn;
+  int lin = bid;
+  if ((nblk & 7) == 0) lin = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  const int z = lin / ntiles, t = lin % ntiles;
+  const int m0 = (t / ntn) * BM, n0 = (t % ntn) * BN;
+  if (z < pl.S0) {
+    const int kbeg = z * pl.ks0;
+    gemm_tn_wide_core<SUM3, NP, BCM, false>(g0, m0, n0, z, 0, z, kbeg, min(g0.K, kbeg + pl.ks0), lds, nullptr, 0);
+    return;
+  }
+  const int zz = z - pl.S0, lvl = zz / pl.S1, p = zz - lvl * pl.S1;
+  if (lvl >= dyn.levels) return;                                      // (P - S0 is not a multiple of the levels: parts left over)
+  int live = 0, ks1 = BK;
+#pragma unroll
+  for (int l = 0; l < kDynLevels; ++l)
+    if (l == lvl) { live = pl.live[l]; ks1 = pl.ks1[l]; }
+  const int kbeg = p * ks1;
+  gemm_tn_wide_core<false, NP, false, true>(g1, m0, n0, z, lvl, p, kbeg, min(live, kbeg + ks1), lds, dyn.bits, dyn.words);
+}
+
 // [small reductions][job 0 parts][job 1 parts][tiles of the dQ projection on gemm_w_body<.., 8>]
 template <bool SUM3, int NP, bool BCM = false>
 // (__launch_bounds__' second argument is the minimum number of waves per SIMD: 2 = ONE 512-thread workgroup per CU, 256
 //  registers per lane -- the design; 169 used, no scratch: tools/regs.py gemm_tn_wide)
-__global__ __launch_bounds__(NTHR, 2) void gemm_tn_wide_kernel(const TwJobs jobs) {
+__global__ __launch_bounds__(NTHR, 2) void gemm_tn_wide_kernel(const TwJobs jobs_by_value) {
   extern __shared__ __attribute__((aligned(16))) short lds_dyn[];
+  // (read through the kernel-argument segment: a run-time index into the by-value copy -- b_ptrs[level] of the device-planned
+  //  launch -- made hipcc spill the whole 832-byte argument to scratch at kernel entry)
+#if defined(__HIP_DEVICE_COMPILE__)
+  const TwJobs& jobs = *(const TwJobs*)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+  const TwJobs& jobs = jobs_by_value;
+#endif
   int id = (int)blockIdx.x - jobs.nred;
   const int ngemm = (int)gridDim.x - jobs.nred - (jobs.wfirst ? jobs.wfirst : jobs.nw);
   if (jobs.wfirst && id >= 0) {
@@ -293,7 +387,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_tn_wide_kernel(const TwJobs jobs
                       (int)blockIdx.x / jobs.red_bx, reinterpret_cast<float(*)[64]>(lds_dyn), threadIdx.x < 256);
     return;
   }
-  if (id < jobs.first1) gemm_tn_wide_body<SUM3, NP, BCM>(jobs.job[0], id, jobs.first1, lds_dyn);
+  if (jobs.dyn.bits) gemm_tn_wide_dyn<SUM3, NP, BCM>(jobs.job[0], jobs.job[1], jobs.dyn, id, ngemm, lds_dyn);
+  else if (id < jobs.first1) gemm_tn_wide_body<SUM3, NP, BCM>(jobs.job[0], id, jobs.first1, lds_dyn);
   else gemm_tn_wide_body<false, NP>(jobs.job[1], id - jobs.first1, ngemm - jobs.first1, lds_dyn);
 }
 
@@ -318,10 +413,19 @@ int gemm_tn_wide_plan(const TnGemm& d, int max_parts, int* ksplit, int* S) {
   return d.levels * *S;
 }
 
+// rows of the gathered job a device-planned launch takes (its row map lives in LDS behind the images: 4 bytes per row at worst)
+constexpr int kDynMaxRows = 8192;
 int launch_gemm_tn_wide(const TnGemm* d, const int* ksplit, const int* S, int n, hipStream_t s, const TnReduce* red,
-                        const WGemm* wextra) {
+                        const WGemm* wextra, const TnDyn* dyn) {
   CA_CHECK_ARG(n == 1 || n == 2, "gemm_tn_wide: 1 or 2 jobs per launch");
   TwJobs jobs = {};
+  if (dyn) {
+    CA_CHECK_ARG(n == 2 && dyn->bits && dyn->plan && dyn->levels == d[1].levels && dyn->levels <= kDynLevels && d[0].levels == 1 && dyn->K0 == d[0].K && dyn->P > dyn->levels &&
+                 dyn->words == (d[1].K + 31) / 32 && dyn->words <= 512 && d[1].K <= kDynMaxRows && d[0].M == d[1].M && d[0].N == d[1].N &&
+                 d[1].b_kdiv == 0 && d[1].a_term == 0 && d[0].C == d[1].C,
+                 "gemm_tn_wide: bad device-planned launch");
+    jobs.dyn = *dyn;
+  }
   if (wextra) {
     long nbw = 0;
     CA_CHECK_ARG(wextra->a_sk == 0 && tnw_np(wextra->np) == tnw_np(d[0].np) && !wextra->f16 && !wextra->bf16 && wextra->N % 256 == 0 && wextra->kband_n == 0,
@@ -360,6 +464,10 @@ int launch_gemm_tn_wide(const TnGemm* d, const int* ksplit, const int* S, int n,
   CA_CHECK_ARG(nb[0] + nb[1] < 2147483647L, "gemm_tn_wide: grid too large");
   jobs.first1 = (int)nb[0];
   const bool sum3 = d[0].a_term != 0, bcm = d[0].b_kdiv != 0;
+  if (dyn) {                                          // P parts x tiles in all; the kernel shares them between the jobs
+    nb[0] = (long)(d[0].M / BM) * (d[0].N / BN) * dyn->P;
+    nb[1] = 0;
+  }
   const dim3 grid((unsigned)(jobs.nred + nb[0] + nb[1] + (jobs.wfirst ? jobs.wfirst : jobs.nw)));
   // two buffers of NP pieces: 57,344 B at two pieces (69,632 B with the [column][k] image of a BCM first job), 86,016 /
   // 104,448 B at the exact width -- above the 64 KB default: the attribute is set once per device, for every instantiation, to
@@ -367,11 +475,12 @@ int launch_gemm_tn_wide(const TnGemm* d, const int* ksplit, const int* S, int n,
   const int npv = tnw_np(d[0].np);
   CA_CHECK_ARG(n == 1 || tnw_np(d[1].np) == npv, "gemm_tn_wide: the jobs of a launch share the width");
   size_t lds = (size_t)2 * npv * (IMGA + (bcm ? IMGBC : IMGB)) * sizeof(short);
+  if (dyn) lds += (size_t)(520 + (d[1].K + 15) / 16 * 16 + 3 * BK) * sizeof(int);      // prefix sums + the row map of the longest possible part
   if (wextra && lds < (size_t)2 * npv * gw::BM * gw::LDR * sizeof(short)) lds = (size_t)2 * npv * gw::BM * gw::LDR * sizeof(short);
   {
     constexpr size_t kImg = (size_t)2 * 3 * (IMGA + (IMGBC > IMGB ? IMGBC : IMGB)) * sizeof(short);
     constexpr size_t kW = (size_t)2 * 3 * gw::BM * gw::LDR * sizeof(short);
-    constexpr size_t kLdsMax = kImg > kW ? kImg : kW;
+    constexpr size_t kLdsMax = (kImg > kW ? kImg : kW) + (size_t)(520 + kDynMaxRows + 3 * BK) * sizeof(int);
     static DeviceOnce once;
     CA_TRY(once.run([&] {
       const void* ks[8] = {reinterpret_cast<const void*>(gemm_tn_wide_kernel<true, 2, true>), reinterpret_cast<const void*>(gemm_tn_wide_kernel<false, 2, true>),

@@ -2,7 +2,8 @@
 """Developer tool: the co-attention forward + backward alone at ONE shape (frozen image features: no dV), for a
 per-kernel profile: `rocprofv3 --kernel-trace --stats -- python3 tools/probe_hot.py 196 lm 200`.
 env: D (512), OPT (1 = reduced-precision mode), VQA_PRECISION (exact, the default | fast), SETS (3: iterations rotate over this
-many independent input sets, so that a kernel finds in the Infinity Cache only what the kernels right before it left there).
+many independent input sets, so that a kernel finds in the Infinity Cache only what the kernels right before it left there),
+DENSE (1: questions without pad rows; default: BASELINE's synthetic questions, lengths 3..26 of 26, pad rows zero).
 Prints the wall time per iteration of the timed half."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,7 +25,12 @@ for _ in range(SETS):
         x = torch.randn(B, N, d, device=dev).clamp_min_(0)
     else:
         x = torch.randn(B, d, N, device=dev).clamp_min_(0).permute(0, 2, 1)
-    sets.append((x, [torch.randn(B, T, d, device=dev).requires_grad_(True) for _ in range(3)]))
+    # questions as bench.synth_features makes them: descending lengths, rows past a length zeroed (DENSE=1: no pad rows)
+    lens = torch.tensor(sorted([T] + [3 + (7 * i) % (T - 2) for i in range(B - 1)], reverse=True), device=dev)
+    mask = (torch.arange(T, device=dev)[None, :] < lens[:, None]).unsqueeze(-1).float()
+    if os.environ.get("DENSE", "0") == "1":
+        mask = torch.ones_like(mask)
+    sets.append((x, [(torch.randn(B, T, d, device=dev) * mask).requires_grad_(True) for _ in range(3)]))
 g = None
 k = 0
 def it():

@@ -14,7 +14,7 @@ PART=${1:-all}
 mkdir -p gpurun_out/refresh
 R="timeout 400 rocprofv3"
 drop_traces() { find gpurun_out/refresh -name '*_trace.csv' -delete; }
-want() { [ "$PART" = all ] || [ "$PART" = "$1" ]; }
+want() { { [ "$PART" = all ] && [ "$1" != 3b ]; } || [ "$PART" = "$1" ]; }
 if want 1; then
 timeout 500 python3 bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 $R --kernel-trace --stats --output-format csv -d $O/bench_stats -- python3 bench.py --no-cpu-baseline > $O/bench_stats.log 2>&1
@@ -69,6 +69,21 @@ drop_traces
 cp profiles/pmc_traffic.json $O/pmc_traffic.json
 cp profiles/pmc_traffic_backward.json $O/pmc_traffic_backward.json
 tail -5 $O/pmc_traffic.log | cut -c1-400
+fi
+if want 3b; then          # only the forward + backward sequences of part 3 (after a change to tools/probe_hot.py or the backward)
+for N in 49 196; do
+  for P in exact fast; do
+    VQA_PRECISION=$P $R --kernel-trace --stats --output-format csv -d $O/fb_${N}_$P -- python3 tools/probe_hot.py $N lm 200 > $O/fb_${N}_$P.log 2>&1
+    for c in FETCH_SIZE WRITE_SIZE; do
+      VQA_PRECISION=$P $R --pmc $c --output-format csv -d $O/pmcb_${c}_${N}_$P -- python3 tools/probe_hot.py $N lm 30 > $O/pmcb_${c}_${N}_$P.log 2>&1
+    done
+    PP=$P; [ $P = fast ] && PP=fast16
+    PRODUCTS=$PP python3 tools/pmc_traffic_bwd.py $O/pmcb_FETCH_SIZE_${N}_$P $O/pmcb_WRITE_SIZE_${N}_$P 160 $N 26 512 3 lm >> $O/pmc_traffic.log 2>&1
+  done
+  $R --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU --output-format csv -d $O/pmc_fb_$N -- python3 tools/probe_hot.py $N lm 30 > $O/pmc_fb_$N.log 2>&1
+done
+drop_traces
+cp profiles/pmc_traffic_backward.json $O/pmc_traffic_backward.json
 fi
 if want 4; then
 N=49 ITERS=28 $R --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_mfma -- python3 tools/probe_fwd_one.py > $O/pmc_mfma.log 2>&1

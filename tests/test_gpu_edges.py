@@ -638,3 +638,26 @@ def test_zero_question_rows_take_the_bias_path_bit_for_bit(pattern, layout):
     for k in ("dQ", "dV_phys", "dW_q.weight", "dW_v.weight", "dW_q.bias"):
         ref = b[k]
         assert ((r[k].cpu().double().reshape(ref.shape) - ref).abs().max() / ref.abs().max()).item() < 2e-5, (pattern, k)
+
+
+@pytest.mark.parametrize("B", [315, 330, 520])
+def test_live_row_paths_on_both_sides_of_their_limits(B):
+    """The exact mode's live-row machinery has two size limits: the device-planned weight gradients gather through an LDS map of at
+    most 8,192 question rows per level (B T <= 8192: B = 315 is the last batch inside, with the largest map), the row bitmap
+    itself has at most 512 words per level (B T <= 16,384).  B = 330 and 520 run the compacted P_q projection with the host's
+    dense split-K plan behind it.  Fused against the general-shape kernels (which know nothing of pad rows) on the same inputs."""
+    from tests._hip import run_hip
+    N, T, d = 49, 26, 512
+    lens = sorted([T] + [1 + (7 * i) % T for i in range(B - 1)], reverse=True)
+    P = O.make_params(d, 23)
+    V, Qs = O.make_inputs(B, N, T, d, 67, lens=lens, scale_q=(2.0 / d) ** 0.5)
+    gv = torch.from_numpy(O.hash_normal((3, B, d), 25)).float()
+    gq = torch.from_numpy(O.hash_normal((3, B, d), 26)).float()
+    a = run_hip(V, Qs, P, gv, gq, impl="fused", layout="lm", need_dv=False, exact3=True)
+    b = run_hip(V, Qs, P, gv, gq, impl="general", layout="lm", need_dv=False, exact3=True)
+    assert (a["v"] - b["v"]).abs().max().item() < 1e-5 and (a["q"] - b["q"]).abs().max().item() < 1e-5
+    for k in ("dQ", "dW_v.weight", "dW_q.weight", "dw_v.weight", "dw_q.weight", "dW_v.bias", "dW_q.bias"):
+        assert (a[k] - b[k]).abs().max().item() <= 2e-5 * max(1e-3, b[k].abs().max().item()), (B, k)
+    a2 = run_hip(V, Qs, P, gv, gq, impl="fused", layout="lm", need_dv=False, exact3=True)
+    for k in ("v", "q", "dQ", "dW_v.weight", "dW_q.weight"):
+        assert torch.equal(a[k], a2[k]), (B, k)                          # repeatable bit for bit

@@ -133,8 +133,10 @@ int coattn_features_native(const void* x, int x_dtype, int64_t sB, int64_t sN, i
 /* 1 if a fused-kernel configuration exists for this shape (for channel-major or location-major V), else 0 */
 int coattn_fused_supported(int B, int N, int T, int d, int L, int dtype);
 
-/* Buffer sizes in bytes.  saved: forward -> backward state (P_v, P_q, C, a_v, a_q, H_q, and W_q split into bf16
- * pieces for the backward's dQ projection); ws_fwd / ws_bwd: scratch, contents undefined after the call. */
+/* Buffer sizes in bytes.  saved: forward -> backward state (P_v, P_q, C, a_v, a_q, H_q, W_q split into bf16
+ * pieces for the backward's dQ projection, the status words of the tolerance mode, and the bitmap of the question rows that
+ * are not all zeros: one bit per row and level, written by the exact forward, read by the backward's dW_q);
+ * ws_fwd / ws_bwd: scratch, contents undefined after the call. */
 int coattn_workspace_bytes(int B, int N, int T, int d, int L, int dtype, int flags,
                            size_t* saved, size_t* ws_fwd, size_t* ws_bwd);
 
@@ -147,7 +149,11 @@ int coattn_workspace_bytes(int B, int N, int T, int d, int L, int dtype, int fla
  * splits the weights also reads every question row once, flags the rows that hold anything and writes (0 + b_q) into the
  * other rows of P_q; the projection GEMM then runs over the flagged rows only.  Data-driven (no length argument: the
  * reference's forward(x_img, x_ques_hierarchy) has none), and bit-identical to the dense product for every input: zero rows
- * anywhere, none at all, -0.0, NaN (tests/test_gpu_edges.py::test_zero_question_rows_take_the_bias_path_bit_for_bit). */
+ * anywhere, none at all, -0.0, NaN (tests/test_gpu_edges.py::test_zero_question_rows_take_the_bias_path_bit_for_bit).
+ * coattn_backward uses the same bitmap (kept in `saved`): dW_q = sum dP_q^T Q contracts over the flagged rows only, and the
+ * launch of the two weight gradients shares its split-K parts between dW_v and dW_q on the device (the count is not known on
+ * the host).  Deterministic -- a function of the inputs --; the order of the additions differs from the all-rows plan, so dW_v /
+ * dW_q agree with it to fp32 rounding, not bit for bit. */
 int coattn_forward(const void* V, int64_t v_sB, int64_t v_sN, int64_t v_sD, const void* const* Q,
                    const coattn_params* p, void* v_out, void* q_out, void* saved, void* ws,
                    int B, int N, int T, int d, int L, int dtype, int flags, void* stream);

@@ -161,7 +161,11 @@ class CoCase:
         self.co.bf16_projections = bf16
         x = (torch.randn(B, d, N, device=dev) * scale).permute(0, 2, 1)
         self.x = (x.contiguous() if lay == "lm" else x).requires_grad_(not bf16)
-        self.Qs = [(torch.randn(B, T, d, device=dev) * scale).requires_grad_(True) for _ in range(3)]
+        # questions as the reference's hierarchy leaves them: descending lengths, rows past a length exact zeros (round 6: the
+        # exact mode finds those rows and leaves them out of P_q's projection and of dW_q -- bitmap, compacted tiles, LDS row maps)
+        lens = torch.tensor(sorted([T] + [1 + (7 * i) % T for i in range(B - 1)], reverse=True), device=dev)
+        mask = (torch.arange(T, device=dev)[None, :] < lens[:, None]).unsqueeze(-1).float()
+        self.Qs = [(torch.randn(B, T, d, device=dev) * scale * mask).requires_grad_(True) for _ in range(3)]
         self.gv = torch.randn(3, B, d, device=dev); self.gq = torch.randn(3, B, d, device=dev)
         self.first = None
         # float64 reference through autograd of the stock ops

@@ -228,7 +228,10 @@ def range_maxima(reset: bool = True):
 
 def check_range(stream=None) -> None:
     """Raise RangeError if ANY tolerance-mode co-attention / phrase forward since the last check met an operand outside the
-    FP16-piece range (include/coattn.h, coattn_status_accumulate).  Synchronises -- call it where the host reads the loss."""
+    FP16-piece range (include/coattn.h, coattn_status_accumulate).  Synchronises -- call it where the host reads the loss.
+    (`stream` is accepted for compatibility with v0.6.0 callers and ignored: every note is folded on the stream of its own
+    forward.)"""
+    del stream
     act, wgt = range_maxima()
     bad_a, bad_w = not (act <= F16_EXACT), not (wgt <= F16_EXACT)
     if bad_a or bad_w:

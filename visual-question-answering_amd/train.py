@@ -245,7 +245,8 @@ class Trainer:
         # reference's arithmetic (main.py --opt_lvl 0) -- is fp32-accurate products over fp32's range, the modules' and the
         # C-ABI's own default; "fast" is the opt-in tolerance mode (forward products on two FP16 pieces = 22 significand
         # bits, backward on two bf16 pieces = 16; inside the reference contract of 1e-4 for operands below 65,504 in
-        # magnitude; step() checks the range report EVERY step there and falls back to exact when an operand left it).
+        # magnitude; every forward there folds its range report into a sticky accumulator, and check_range() -- called where
+        # the loss is read -- falls back to exact when ANY step since the last check left the range).
         if precision not in ("fast", "exact"):
             raise ValueError("precision must be 'fast' or 'exact'")
         self.set_precision(precision)

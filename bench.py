@@ -39,7 +39,9 @@ hot_path[*].fast16_*, roofline_projection.fast16_f16_pair, roofline_weight_grad.
                 C-ABI calls issued eagerly); host_enqueue_ms = host time to queue one step; modules_*: the same step
                 module by module (ParallelCoAttention -> MLPClassifier.forward_loss); graph_*: replayed from captured
                 HIP graphs (vqa_amd/graph.py); the HIP op's fwd+bwd device time (pipelined calls) and the wall time
-                of single synchronised calls.
+                of single synchronised calls.  The synthetic questions have pad rows (question_pad_row_fraction: exact zeros,
+                as the reference's hierarchy leaves them), which the exact mode leaves out of two contractions;
+                dense_questions_coattn_fwd_bwd_ms is the same measurement on questions without any.
 """
 from __future__ import annotations
 
@@ -95,15 +97,26 @@ def parse():
     return ap.parse_args()
 
 
-def synth_features(B, N, T, d, device, seed=1234, L=3):
+def synth_features(B, N, T, d, device, seed=1234, L=3, dense=False):
     """Device-resident synthetic features of the isolated path: V = relu(N(0,1)) stored
-    channel-major [B,d,N], Q_l ~ N(0,1) [B,T,d] with rows past each (descending) length zeroed."""
+    channel-major [B,d,N], Q_l ~ N(0,1) [B,T,d] with rows past each (descending) length zeroed (dense: every question T
+    tokens long, no pad rows -- the case in which the exact mode's zero-row paths have nothing to skip)."""
     g = torch.Generator().manual_seed(seed)
     V = torch.randn(B, d, N, generator=g).clamp_min_(0)
-    lens = torch.tensor(sorted([T] + [3 + (7 * i) % (T - 2) for i in range(B - 1)], reverse=True))
+    lens = torch.tensor([T] * B if dense else sorted([T] + [3 + (7 * i) % (T - 2) for i in range(B - 1)], reverse=True))
     mask = (torch.arange(T)[None, :] < lens[:, None]).unsqueeze(-1).float()
     Qs = [(torch.randn(B, T, d, generator=g) * mask).to(device) for _ in range(L)]
     return V.to(device), Qs
+
+
+def synth_pad_fraction(B, T):
+    """Share of the question rows of synth_features that are pad rows (exact zeros): lengths [T] + [3 + (7 i) % (T - 2)]."""
+    lens = [T] + [3 + (7 * i) % (T - 2) for i in range(B - 1)]
+    return round(1.0 - sum(lens) / float(B * T), 4)
+
+
+PAD_NOTE = ("pad rows of the questions are exact zeros (as the reference's hierarchy leaves them: model.py:263, :292-296); the exact mode "
+            "finds them from the data and leaves them out of the P_q projection and of dW_q (bit-identical P_q; include/coattn.h)")
 
 
 def device_batch(T, args, rank, device, batch=None, image_size=None):
@@ -263,6 +276,8 @@ def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20, b
     lay_c = layout if (layout == "lm" or N % 4 == 0) else "lm"
     t_dev = coattn_device_time(device, B=B, N=N, T=T, d=d, layout=lay_c, bf16=bf16)
     t_dev_x = None if bf16 else coattn_device_time(device, B=B, N=N, T=T, d=d, layout=lay_c, fast=True)
+    # ... and with questions that have NO pad rows: what the exact mode costs when there is nothing for its zero-row paths to skip
+    t_dev_dense = None if bf16 else coattn_device_time(device, B=B, N=N, T=T, d=d, layout=lay_c, dense=True)
     fwd = bwd = 0.0
     for it in range(iters + 3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -275,7 +290,7 @@ def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20, b
         if it >= 3:
             fwd += t1 - t0; bwd += t3 - t1
     flop = 3.0 * B * (2 * N * d * d + 3 * 2 * T * d * d + 3 * (3 * 2 * T * N * d + 4 * (N + T) * d))
-    return {"N": N, "d": d, "K": K, "layout": layout,
+    return {"N": N, "d": d, "K": K, "layout": layout, "question_pad_row_fraction": synth_pad_fraction(B, T),
             "mode": ("reduced precision (every product ONE bf16 MFMA, fp32 accumulation; dP_v / dP_q stored as bf16)" if bf16 else
                      "fp32-accurate products (flags = 0: 3 x bf16 pieces per operand, 6 partial products); fast16_*: the opt-in tolerance mode "
                      "(forward products 2 x fp16 pieces = 22 bits, backward 2 x bf16 = 16 bits)"),
@@ -283,6 +298,7 @@ def hot_path_leg(device, N, layout="lm", B=160, T=26, d=512, K=1000, iters=20, b
             "pairs_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "host_enqueue_ms": round(host * 1e3, 3),
             "fast16_ms_per_step": round(xdt * 1e3, 3) if xdt is not None else None,
             "fast16_coattn_fwd_bwd_ms": round(t_dev_x * 1e3, 4) if t_dev_x is not None else None,
+            "dense_questions_coattn_fwd_bwd_ms": round(t_dev_dense * 1e3, 4) if t_dev_dense is not None else None,
             "step_path": "train.Trainer's default: one autograd node over static buffers, C-ABI calls issued eagerly",
             "modules_ms_per_step": round(mdt * 1e3, 3), "modules_host_enqueue_ms": round(mhost * 1e3, 3),
             "graph_ms_per_step": round(gdt * 1e3, 3), "graph_host_enqueue_ms": round(ghost * 1e3, 3),
@@ -409,7 +425,7 @@ def roofline_leg(device, B=160, N=196, T=26, d=512, L=3, iters=100, layout="lm",
             "algorithmic_bytes": alg}
 
 
-def coattn_c_calls(device, B, N, T, d, L, layout, bf16, fast=False, seed=78):
+def coattn_c_calls(device, B, N, T, d, L, layout, bf16, fast=False, seed=78, dense=False):
     """coattn_forward / coattn_backward (frozen image encoder: no dV) as closures over pre-built argument blocks on synthetic
     features: (lib, stream, fwd, bwd).  A call costs the host one ctypes crossing, so loops over them are device-paced."""
     import ctypes as C
@@ -418,7 +434,7 @@ def coattn_c_calls(device, B, N, T, d, L, layout, bf16, fast=False, seed=78):
     lib = _lib.load()
     torch.manual_seed(0)
     co = vqa_amd.ParallelCoAttention(d).to(device)
-    V, Qs = synth_features(B, N, T, d, device, seed=seed, L=L)
+    V, Qs = synth_features(B, N, T, d, device, seed=seed, L=L, dense=dense)
     vstr = (d * N, 1, N)
     if layout == "lm":
         V, vstr = V.permute(0, 2, 1).contiguous(), (N * d, d, 1)
@@ -452,10 +468,10 @@ def coattn_c_calls(device, B, N, T, d, L, layout, bf16, fast=False, seed=78):
     return lib, stream, fwd, bwd
 
 
-def coattn_device_time(device, B=160, N=196, T=26, d=512, L=3, layout="lm", bf16=False, iters=50, fast=False):
+def coattn_device_time(device, B=160, N=196, T=26, d=512, L=3, layout="lm", bf16=False, iters=50, fast=False, dense=False):
     """Device time of one coattn_forward + coattn_backward (HIP events around `iters` back-to-back pairs of C-ABI calls, the
     median of three windows after a clock warm-up)."""
-    lib, stream, fwd, bwd = coattn_c_calls(device, B, N, T, d, L, layout, bf16, fast)
+    lib, stream, fwd, bwd = coattn_c_calls(device, B, N, T, d, L, layout, bf16, fast, dense=dense)
     for _ in range(2 * iters):
         fwd(); bwd()
     ts = []
@@ -591,6 +607,7 @@ def backward_legs(device, B=160, N=196, T=26, d=512, L=3, iters=60, layout="lm",
     fwd_us = {nm: round(seq["avg_us"][nm], 2) for nm in seq["order"] if nm in fwd_marks}
     return {"shape": {"B": B, "N": N, "T": T, "d": d, "L": L}, "v_layout": layout, "calls": seq["calls"],
             "products": PRODUCTS[mode], "buffer_sets": seq["buffer_sets"],
+            "question_pad_row_fraction": synth_pad_fraction(B, T), "question_pad_rows": PAD_NOTE,
             "total_us": round(total, 1), "kernels": out, "forward_marks_us": fwd_us,
             "fwd_plus_bwd_us": round(total + sum(fwd_us.values()), 1),
             "traffic_source": "profiles/pmc_traffic_backward.json (rocprofv3 PMC passes of tools/probe_hot.py at this shape and in this "
@@ -1068,6 +1085,8 @@ def main():
                                       (", encoder one step ahead on its own stream" if trainer.runahead else "")
                                       + ("" if args.stock_graph else ", ReLU after MaxPool, conv bias folded into BN running mean")),
                        "precision": "bf16" if args.opt_lvl > 0 else args.precision,
+                       "question_pad_row_fraction": round(1.0 - float(batch[2].sum()) / (args.batch * args.seq_len), 4),
+                       "question_pad_rows": PAD_NOTE,
                        "arithmetic": (ARITHMETIC if (args.opt_lvl == 0 and args.precision == "exact") else
                                       "fp32 storage and accumulation; --precision fast, the opt-in tolerance mode (COATTN_FLAG_FAST16): "
                                       "forward-side products on 2 x fp16 pieces per operand = 22 significand bits, backward products on "

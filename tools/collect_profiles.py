@@ -60,12 +60,28 @@ def newest(pattern):                                # gpurun merges accumulate o
     return [max(hits, key=os.path.getmtime)] if hits else []
 
 
-for f in newest("pmc_mfma/**/*counter_collection.csv"):
-    for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"]
-        kern = ("coattn_fwd32_kernel" if "coattn_fwd32" in k else "attend_v_lm_kernel" if "attend_v" in k else None)
-        if kern:
-            vals.setdefault(kern, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+def counter_rows(src_dir):
+    """(kernel name, counter name, mean value, dispatches) of a --pmc pass: from tools/pmc_reduce.py's JSON when the box left
+    one (the raw CSVs of a whole bench leg exceed what gpurun copies back), else from the newest raw CSV."""
+    js = os.path.join(SRC, src_dir, "counters_by_kernel.json")
+    if os.path.isfile(js):
+        for k, cs in json.load(open(js)).items():
+            for c, (tot, n) in cs.items():
+                yield k, c, tot / max(n, 1), n
+        return
+    acc = {}
+    for f in newest("%s/**/*counter_collection.csv" % src_dir):
+        for r in csv.DictReader(open(f)):
+            e = acc.setdefault((r["Kernel_Name"], r["Counter_Name"]), [0.0, 0])
+            e[0] += float(r["Counter_Value"]); e[1] += 1
+    for (k, c), (tot, n) in acc.items():
+        yield k, c, tot / n, n
+
+
+for k, c, mean, n in counter_rows("pmc_mfma"):
+    kern = ("coattn_fwd32_kernel" if "coattn_fwd32" in k else "attend_v_lm_kernel" if "attend_v" in k else None)
+    if kern:
+        vals.setdefault(kern, {}).setdefault(c, []).append(mean)
 if vals:
     out = {}
     for kern, cs in vals.items():
@@ -80,19 +96,18 @@ if vals:
 # pmc_cfg4_hot: config 4's hot path (the reduced-precision instantiations)
 for src_dir, out_name in (("pmc_hot", "pmc_hot_path_kernels"), ("pmc_cfg4_hot", "pmc_cfg4_hot_path_kernels"),
                           ("pmc_fb_49", "pmc_fwd_bwd_n49_kernels"), ("pmc_fb_196", "pmc_fwd_bwd_n196_kernels")):
-    hot = {}
-    for f in newest("%s/**/*counter_collection.csv" % src_dir):
-        for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"]
-            if "anonymous namespace" not in k or "at::native" in k or "softmax_warp" in k:
-                continue                                   # stock PyTorch / MIOpen / rocBLAS kernels are not ours
-            name = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
-            hot.setdefault(name, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    hot, disp = {}, {}
+    for k, c, mean, n in counter_rows(src_dir):
+        if "anonymous namespace" not in k or "at::native" in k or "softmax_warp" in k:
+            continue                                       # stock PyTorch / MIOpen / rocBLAS kernels are not ours
+        name = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
+        hot.setdefault(name, {})[c] = mean
+        disp[name] = n
     if hot:
         out = {}
         for name, cs in sorted(hot.items()):
-            m = {c: sum(v) / len(v) for c, v in cs.items()}
-            m["dispatches"] = len(next(iter(cs.values())))
+            m = dict(cs)
+            m["dispatches"] = disp[name]
             if m.get("SQ_BUSY_CYCLES") and "SQ_VALU_MFMA_BUSY_CYCLES" in m:
                 m["derived_mfma_busy_frac"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (32.0 * m["SQ_BUSY_CYCLES"]), 4)
             if m.get("SQ_INSTS_MFMA") and "SQ_INSTS_VALU" in m:

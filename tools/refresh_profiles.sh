@@ -52,6 +52,7 @@ for cfg in "49 512 lm exact 0" "196 512 lm exact 0" "196 512 cm exact 0" "49 512
   done
   P=$4; [ $4 = fast ] && P=fast16; [ $5 = 1 ] && P=bf16
   PRODUCTS=$P COLD=1 python3 tools/pmc_traffic.py $O/pmc_FETCH_SIZE_$tag $O/pmc_WRITE_SIZE_$tag 160 $1 26 $2 3 $3 >> $O/pmc_traffic.log 2>&1
+  find $O/pmc_FETCH_SIZE_$tag $O/pmc_WRITE_SIZE_$tag -name '*counter_collection.csv' -delete
 done
 # the co-attention forward + backward alone, one shape and one arithmetic per run (per-kernel averages that do not mix shapes),
 # iterations rotating over three input sets; then the same two counters per kernel
@@ -63,6 +64,7 @@ for N in 49 196; do
     done
     PP=$P; [ $P = fast ] && PP=fast16
     PRODUCTS=$PP python3 tools/pmc_traffic_bwd.py $O/pmcb_FETCH_SIZE_${N}_$P $O/pmcb_WRITE_SIZE_${N}_$P 160 $N 26 512 3 lm >> $O/pmc_traffic.log 2>&1
+    find $O/pmcb_FETCH_SIZE_${N}_$P $O/pmcb_WRITE_SIZE_${N}_$P -name '*counter_collection.csv' -delete
   done
 done
 drop_traces
@@ -79,6 +81,7 @@ for N in 49 196; do
     done
     PP=$P; [ $P = fast ] && PP=fast16
     PRODUCTS=$PP python3 tools/pmc_traffic_bwd.py $O/pmcb_FETCH_SIZE_${N}_$P $O/pmcb_WRITE_SIZE_${N}_$P 160 $N 26 512 3 lm >> $O/pmc_traffic.log 2>&1
+    find $O/pmcb_FETCH_SIZE_${N}_$P $O/pmcb_WRITE_SIZE_${N}_$P -name '*counter_collection.csv' -delete
   done
   $R --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU --output-format csv -d $O/pmc_fb_$N -- python3 tools/probe_hot.py $N lm 30 > $O/pmc_fb_$N.log 2>&1
 done
@@ -86,11 +89,16 @@ drop_traces
 cp profiles/pmc_traffic_backward.json $O/pmc_traffic_backward.json
 fi
 if want 4; then
+# (the raw counter CSVs of a whole bench leg are hundreds of MB: each pass is reduced to per-kernel sums on the box, tools/pmc_reduce.py)
 N=49 ITERS=28 $R --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_mfma -- python3 tools/probe_fwd_one.py > $O/pmc_mfma.log 2>&1
+python3 tools/pmc_reduce.py $O/pmc_mfma
 $R --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU --output-format csv -d $O/pmc_hot -- python3 bench.py --only hot > $O/pmc_hot.log 2>&1
+python3 tools/pmc_reduce.py $O/pmc_hot
 for N in 49 196; do
   $R --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU --output-format csv -d $O/pmc_fb_$N -- python3 tools/probe_hot.py $N lm 30 > $O/pmc_fb_$N.log 2>&1
+  python3 tools/pmc_reduce.py $O/pmc_fb_$N
 done
 $R --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU --output-format csv -d $O/pmc_cfg4_hot -- python3 bench.py --model attention_resnet --opt-lvl 1 --num-cls 3000 --only hot > $O/pmc_cfg4_hot.log 2>&1
+python3 tools/pmc_reduce.py $O/pmc_cfg4_hot
 fi
 echo "refresh part $PART done"

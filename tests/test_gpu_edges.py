@@ -136,9 +136,10 @@ def test_errors_are_loud():
                             m.W_q.bias, m.w_v.weight, m.w_v.bias, m.w_q.weight, m.w_q.bias, impl=_lib.IMPL_FUSED)
 
 
+@pytest.mark.parametrize("exact3", [False, True], ids=["fast16", "exact"])
 @pytest.mark.parametrize("L", [1, 2])
 @pytest.mark.parametrize("impl", ["general", "auto"])
-def test_fewer_than_three_levels(L, impl):
+def test_fewer_than_three_levels(L, impl, exact3):
     """The module loops over whatever hierarchy it is given (model.py:372); L = 1, 2 also work."""
     from tests._hip import run_hip
     B, N, T, d = 3, 49, 26, 256
@@ -146,12 +147,15 @@ def test_fewer_than_three_levels(L, impl):
     V, Qs = O.make_inputs(B, N, T, d, 51, lens=[26, 8, 1], scale_q=(2.0 / d) ** 0.5, L=L)
     gv = torch.from_numpy(O.hash_normal((L, B, d), 7)).float()
     gq = torch.from_numpy(O.hash_normal((L, B, d), 8)).float()
-    r = run_hip(V, Qs, P, gv, gq, impl=impl)
+    if impl == "general" and not exact3:
+        pytest.skip("the general-shape path has one arithmetic (exact): run once")
     f = O.coattn_forward(V, Qs, P)
     g = O.coattn_backward(V, Qs, P, gv, gq)
-    assert (r["v"].cpu() - f["v"]).abs().max() < 1e-4 and (r["q"].cpu() - f["q"]).abs().max() < 1e-4
-    for k in ("dV_phys", "dQ", "dW_v.weight", "dW_q.weight", "dw_v.weight", "dw_q.weight", "dW_v.bias", "dW_q.bias"):
-        assert (r[k].cpu() - g[k]).abs().max() <= 1e-4 * max(1e-3, g[k].abs().max().item()), k
+    for layout in ("cm", "lm"):                                  # (the exact mode's live-row paths with one and two levels too)
+        r = run_hip(V, Qs, P, gv, gq, impl=impl, layout=layout, exact3=exact3)
+        assert (r["v"].cpu() - f["v"]).abs().max() < 1e-4 and (r["q"].cpu() - f["q"]).abs().max() < 1e-4
+        for k in ("dV_phys", "dQ", "dW_v.weight", "dW_q.weight", "dw_v.weight", "dw_q.weight", "dW_v.bias", "dW_q.bias"):
+            assert (r[k].cpu() - g[k]).abs().max() <= 1e-4 * max(1e-3, g[k].abs().max().item()), (layout, k)
 
 
 def test_trainer_validate_forward_only_path():

@@ -34,6 +34,9 @@ def _shapes():
 
 # exact mode (flags = 0: the reference's arithmetic, fp32-accurate products) is held tighter than the contract
 EXACT_TOL = 2e-5
+# dw_v.bias / dw_q.bias are sums of softmax-Jacobian rows -- exactly 0 in real arithmetic -- so what any fp32 implementation returns
+# is its summation noise; they are compared on this absolute scale (tools/fuzz_wide.py raises it for batches of hundreds)
+BIAS_SCALE = 1.0
 
 
 @pytest.mark.parametrize("exact3", [False, True], ids=["fast16", "exact"])
@@ -73,7 +76,7 @@ def test_random_shape_vs_oracle(shape, exact3):
         for k, ref in grads.items():
             got = r[k].double().cpu().reshape(ref.shape)
             assert torch.isfinite(got).all(), (impl, k)
-            scale = max(ref.abs().max().item(), 1.0 if k in ("dw_v.bias", "dw_q.bias") else 1e-30)
+            scale = max(ref.abs().max().item(), BIAS_SCALE if k in ("dw_v.bias", "dw_q.bias") else 1e-30)
             err = (got - ref).abs().max().item() / scale
             assert err < grad_tol, (impl, k, err)
             worst = max(worst, err)

@@ -37,6 +37,9 @@
 #ifndef COATTN_P1_NB          // channel-major stream: tiles per k-step on the bf16 MFMA (the others on the f32 MFMA); -1 = all
 #define COATTN_P1_NB -1
 #endif
+#ifndef COATTN_P1_RING        // location-major stream at N <= 64: slots of 4 KB in a wave's phase-1 ring (4: three units in flight)
+#define COATTN_P1_RING 4
+#endif
 
 namespace {
 
@@ -156,7 +159,12 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
       constexpr int UPK = NT + 1;                    // units per 32-channel step: the Q unit, then the NT tiles
       constexpr int BODY = (UPK % 4 == 0) ? UPK : (UPK % 2 == 0) ? 2 * UPK : 4 * UPK;   // static slot indices
       constexpr int KU = BODY / UPK;
-      char* ringb = smem + w * (4 * 4096);
+      // RS slots per wave: RS - 1 units (of four DMA instructions each) in flight behind the one being read back.  A slot index is
+      // (unit number) % RS: a compile-time value when the body's BODY units are a multiple of RS (RS = 4) or when the wave has
+      // ONE body (d = 512: G == KU); otherwise the body's first slot is carried in a scalar.
+      constexpr int RS = (NT == 2) ? COATTN_P1_RING : 4;
+      static_assert(RS >= 4 && RS <= 6, "phase-1 ring: 4 to 6 slots");
+      char* ringb = smem + w * (RS * 4096);
       const int dvoff = ((lane >> 3) * d) * 4 + (((lane & 7) ^ (lane >> 3)) << 4);
       const int G = 4 * nsl;                         // 32-channel steps of this wave (a multiple of KU)
       auto chan0 = [&](int g) { return ((g >> 2) * NW + w) * 128 + 32 * (g & 3); };
@@ -189,20 +197,25 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
       bf16x8 qa[2][3];
       u32x4 vh[2], vm[2], vl[2];                     // split pieces of the current V unit (two k-steps)
 #pragma unroll
-      for (int p = 0; p < 4; ++p) dma_unit(p / UPK, p % UPK, p);
-      vmcnt_wait(12);                                // unit 0 (the first Q unit) has landed; units 1 .. 3 may fly
+      for (int p = 0; p < RS; ++p) dma_unit(p / UPK, p % UPK, p);
+      vmcnt_wait(4 * (RS - 1));                      // unit 0 (the first Q unit) has landed; units 1 .. RS - 1 may fly
       nxt = read_unit(0);
+      int sbase = 0;                                 // slot of the body's unit 0 (stays 0 when BODY % RS == 0)
 #pragma unroll 1
       for (int g0 = 0; g0 < G; g0 += KU) {
 #pragma unroll
         for (int p = 0; p < BODY; ++p) {             // unit p of the body: step g0 + p / UPK, position p % UPK
           const int j = p % UPK, jn = (p + 1) % UPK;
           const f32x16 cur = nxt;
-          // the read-back of unit p is complete: refill its slot with unit p + 4, then read back unit p + 1
+          int s_cur = p % RS, s_nxt = (p + 1) % RS;
+          if constexpr (BODY % RS != 0) {            // (scalar arithmetic; folds away for the first body)
+            s_cur = (sbase + p % RS) % RS; s_nxt = (sbase + (p + 1) % RS) % RS;
+          }
+          // the read-back of unit p is complete: refill its slot with unit p + RS, then read back unit p + 1
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          dma_unit(g0 + (p + 4) / UPK, (p + 4) % UPK, p % 4);
-          vmcnt_wait(12);                            // units p + 2 .. p + 4 may fly
-          nxt = read_unit((p + 1) % 4);
+          dma_unit(g0 + (p + RS) / UPK, (p + RS) % UPK, s_cur);
+          vmcnt_wait(4 * (RS - 1));                  // units p + 2 .. p + RS may fly
+          nxt = read_unit(s_nxt);
           __builtin_amdgcn_sched_barrier(0);
           if (COATTN_P1_NOMATH) {                    // developer switch: the operand stream alone
             acc[0][p % 16] += nxt[0] + nxt[15];
@@ -240,6 +253,7 @@ __global__ __launch_bounds__(NW * 64, 2) void coattn_fwd32_kernel(const FwdArgs 
             }
           }
         }
+        if constexpr (BODY % RS != 0) sbase = (sbase + BODY) % RS;
       }
     } else {
       // Channel-major operand stream.  Element i of a lane's fragment <-> channel k0 + 4 h + (i & 3) + 8 (i >> 2), the
@@ -863,7 +877,8 @@ template <int NT, int NW, bool LM, int NP, bool FV = false>
 int launch_fwd32(const FwdArgs& a, hipStream_t s) {
   constexpr int NPAD = 32 * NT;
   constexpr int RING_SLOTS = (NT + 1) * ((NT + 1 >= 6) ? 1 : 2);
-  const size_t lds_p2 = (size_t)NPAD * 36 * 4 + (size_t)3 * NPAD * 32 * 2, lds_p1 = LM ? (size_t)NW * 4 * 4096 : (size_t)NW * RING_SLOTS * 2048;
+  const size_t lds_p2 = (size_t)NPAD * 36 * 4 + (size_t)3 * NPAD * 32 * 2,
+               lds_p1 = LM ? (size_t)NW * (NT == 2 ? COATTN_P1_RING : 4) * 4096 : (size_t)NW * RING_SLOTS * 2048;
   const size_t lds = lds_p2 > lds_p1 ? lds_p2 : lds_p1;
   static DeviceOnce once;                            // the attribute is per device
   CA_TRY(once.run([&] {

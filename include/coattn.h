@@ -153,7 +153,9 @@ int coattn_workspace_bytes(int B, int N, int T, int d, int L, int dtype, int fla
  * coattn_backward uses the same bitmap (kept in `saved`): dW_q = sum dP_q^T Q contracts over the flagged rows only, and the
  * launch of the two weight gradients shares its split-K parts between dW_v and dW_q on the device (the count is not known on
  * the host).  Deterministic -- a function of the inputs --; the order of the additions differs from the all-rows plan, so dW_v /
- * dW_q agree with it to fp32 rounding, not bit for bit. */
+ * dW_q agree with it to fp32 rounding, not bit for bit.  (One corner differs in kind: a non-finite dP_q element in a zero row
+ * makes the reference's dW_q NaN through inf * 0; here that row is not contracted.  db_q, which sums every row, is non-finite in
+ * both, so the step still shows.) */
 int coattn_forward(const void* V, int64_t v_sB, int64_t v_sN, int64_t v_sD, const void* const* Q,
                    const coattn_params* p, void* v_out, void* q_out, void* saved, void* ws,
                    int B, int N, int T, int d, int L, int dtype, int flags, void* stream);
